@@ -1,0 +1,199 @@
+"""ORACLE -- test infrastructure, not product code.
+
+CPU restatement (PyTorch eager, fp32 or fp64) of the reference's axial-attention forward
+path, used ONLY as the checker in tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg.  The product path (rna-msm_amd/) never imports this file and fails
+loudly when its HIP library is missing.
+
+Pinned: yes -- against fixtures produced by importing the reference itself
+(/root/reference, authoring container only) with fully randomised seeded weights; see
+tests/golden/make_golden.py and tests/test_oracle_golden.py.  The reference ships no value
+tests of its own for this path.
+
+Every function cites the reference lines it restates (paths relative to /root/reference).
+Layout: one MSA (B=1) is held as x[R, C, D] (reference: [R, C, B=1, D]); token t = r*C + c.
+Padding masks / B>1 are out of scope this round: inputs containing <pad>
+are rejected.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+PAD_IDX = 1
+LN_EPS = 1e-5          # nn.LayerNorm default, modules.py:383
+
+
+def _p(params: Dict[str, torch.Tensor], prefix: str, name: str) -> torch.Tensor:
+    return params[f"{prefix}.{name}" if prefix else name]
+
+
+def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """nn.LayerNorm over the last dim, eps 1e-5, biased variance (modules.py:383,387)."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + LN_EPS) * gamma + beta
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """nn.Linear: x @ w.T + b, w is [out, in]."""
+    return x @ w.t() + b
+
+
+def gelu_erf(x: torch.Tensor) -> torch.Tensor:
+    """nn.GELU() exact-erf form (modules.py:416)."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def positions_from_tokens(tokens: torch.Tensor) -> torch.Tensor:
+    """LearnedPositionalEmbedding.forward index math (modules.py:286-290):
+    pos = cumsum(tok != pad) * (tok != pad) + pad_idx, per row."""
+    mask = (tokens != PAD_IDX).to(torch.int64)
+    return torch.cumsum(mask, dim=-1) * mask + PAD_IDX
+
+
+def embed(tokens: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """K0: model.py:349-362.  tokens int64 [R, C] -> x [R, C, D] after emb_layer_norm_before."""
+    R, C = tokens.shape
+    if R > 1024:
+        raise RuntimeError(
+            "Using model with MSA position embedding trained on maximum MSA "
+            f"depth of 1024, but received {R} alignments.")          # model.py:355-359
+    x = params["embed_tokens.weight"][tokens]
+    x = x + params["embed_positions.weight"][positions_from_tokens(tokens)]
+    x = x + params["msa_position_embedding"][0, :R]                 # [R,1,1] broadcast
+    return layer_norm(x, params["emb_layer_norm_before.weight"], params["emb_layer_norm_before.bias"])
+
+
+def row_attention_logits(x: torch.Tensor, params, prefix: str, num_heads: int,
+                         scaling: float) -> torch.Tensor:
+    """RowSelfAttention.compute_attention_weights (modules.py:752-786), no padding mask.
+    x [r, C, D] (a chunk of rows) -> logits [H, C, C] summed over those rows and head_dim."""
+    r, C, D = x.shape
+    dh = D // num_heads
+    q = linear(x, _p(params, prefix, "q_proj.weight"), _p(params, prefix, "q_proj.bias")) * scaling
+    k = linear(x, _p(params, prefix, "k_proj.weight"), _p(params, prefix, "k_proj.bias"))
+    q = q.view(r, C, num_heads, dh)
+    k = k.view(r, C, num_heads, dh)
+    return torch.einsum("rihd,rjhd->hij", q, k)
+
+
+def row_attention(x: torch.Tensor, params, prefix: str, num_heads: int,
+                  max_tokens: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """RowSelfAttention.forward / _batched_forward (modules.py:802-821, 717-750).
+    Returns (out [R,C,D], probs [H,C,C]).  With max_tokens set and R*C > max_tokens the row-chunked
+    accumulate-then-softmax order of _batched_forward is reproduced (same math, different
+    summation order)."""
+    R, C, D = x.shape
+    dh = D // num_heads
+    scaling = (dh ** -0.5) / math.sqrt(R)                          # align_scaling, modules.py:713-715
+    if max_tokens is not None and R * C > max_tokens:
+        max_rows = max(1, max_tokens // C)                          # modules.py:724
+        logits = 0
+        for s in range(0, R, max_rows):
+            logits = logits + row_attention_logits(x[s:s + max_rows], params, prefix, num_heads, scaling)
+    else:
+        logits = row_attention_logits(x, params, prefix, num_heads, scaling)
+    probs = torch.softmax(logits, dim=-1)                           # modules.py:818 / 739
+    v = linear(x, _p(params, prefix, "v_proj.weight"), _p(params, prefix, "v_proj.bias")).view(R, C, num_heads, dh)
+    ctx = torch.einsum("hij,rjhd->rihd", probs, v).reshape(R, C, D)   # modules.py:797-798
+    out = linear(ctx, _p(params, prefix, "out_proj.weight"), _p(params, prefix, "out_proj.bias"))
+    return out, probs
+
+
+def col_attention(x: torch.Tensor, params, prefix: str, num_heads: int,
+                  return_probs: bool = False, col_chunk: int = 64):
+    """ColumnSelfAttention.compute_attention_update (modules.py:875-924), no padding mask.
+    Column slabs are independent (modules.py:849-873) so they are processed `col_chunk` at a time to
+    keep the [H, c, R, R] probabilities small; probs are returned only on request (the reference
+    computes and discards them)."""
+    R, C, D = x.shape
+    dh = D // num_heads
+    wv, bv = _p(params, prefix, "v_proj.weight"), _p(params, prefix, "v_proj.bias")
+    wo, bo = _p(params, prefix, "out_proj.weight"), _p(params, prefix, "out_proj.bias")
+    if R == 1:                                                      # modules.py:882-894
+        out = linear(linear(x, wv, bv), wo, bo)
+        probs = torch.ones(num_heads, C, 1, 1, dtype=x.dtype) if return_probs else None
+        return (out, probs) if return_probs else out
+    scaling = dh ** -0.5                                            # modules.py:839
+    q = (linear(x, _p(params, prefix, "q_proj.weight"), _p(params, prefix, "q_proj.bias")) * scaling).view(R, C, num_heads, dh)
+    k = linear(x, _p(params, prefix, "k_proj.weight"), _p(params, prefix, "k_proj.bias")).view(R, C, num_heads, dh)
+    v = linear(x, wv, bv).view(R, C, num_heads, dh)
+    ctx = torch.empty(R, C, num_heads, dh, dtype=x.dtype)
+    all_probs: List[torch.Tensor] = []
+    for s in range(0, C, col_chunk):
+        e = min(C, s + col_chunk)
+        w = torch.einsum("ichd,jchd->hcij", q[:, s:e], k[:, s:e])   # modules.py:907
+        p = torch.softmax(w, dim=-1)                                # modules.py:917
+        ctx[:, s:e] = torch.einsum("hcij,jchd->ichd", p, v[:, s:e])  # modules.py:919
+        if return_probs:
+            all_probs.append(p)
+    out = linear(ctx.reshape(R, C, D), wo, bo)
+    if return_probs:
+        return out, torch.cat(all_probs, dim=1)
+    return out
+
+
+def ffn(x: torch.Tensor, params, prefix: str) -> torch.Tensor:
+    """FeedForwardNetwork.forward (modules.py:423-427): fc2(GELU_erf(fc1(x)))."""
+    h = gelu_erf(linear(x, _p(params, prefix, "fc1.weight"), _p(params, prefix, "fc1.bias")))
+    return linear(h, _p(params, prefix, "fc2.weight"), _p(params, prefix, "fc2.bias"))
+
+
+def axial_layer(x: torch.Tensor, params, layer: int, num_heads: int,
+                max_tokens: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """AxialTransformerLayer.forward (modules.py:242-267) with each sub-block wrapped as
+    NormalizedResidualBlock (modules.py:385-401): x + f(LN(x)); dropout is the identity in eval."""
+    base = f"layers.{layer}"
+    pre = f"{base}.row_self_attention"
+    y, row_probs = row_attention(layer_norm(x, params[f"{pre}.layer_norm.weight"], params[f"{pre}.layer_norm.bias"]),
+                                 params, f"{pre}.layer", num_heads, max_tokens)
+    x = x + y
+    pre = f"{base}.column_self_attention"
+    x = x + col_attention(layer_norm(x, params[f"{pre}.layer_norm.weight"], params[f"{pre}.layer_norm.bias"]),
+                          params, f"{pre}.layer", num_heads)
+    pre = f"{base}.feed_forward_layer"
+    x = x + ffn(layer_norm(x, params[f"{pre}.layer_norm.weight"], params[f"{pre}.layer_norm.bias"]),
+                params, f"{pre}.layer")
+    return x, row_probs
+
+
+def forward(tokens: torch.Tensor, params: Dict[str, torch.Tensor], num_layers: int = 10,
+            num_heads: int = 12, max_tokens: Optional[int] = None,
+            layers_to_run: Optional[int] = None) -> Dict[str, torch.Tensor]:
+    """MSATransformer.forward (model.py:338-416) for one MSA, need_head_weights=True,
+    repr_layers=[num_layers]; lm_head / contact head are not on this path.
+    tokens int64 [R, C].  Returns representation [R, C, D] (after emb_layer_norm_after,
+    model.py:396-401) and row_attentions [num_layers, H, C, C] (model.py:392,409, B squeezed)."""
+    assert tokens.ndim == 2
+    if bool((tokens == PAD_IDX).any()):
+        raise NotImplementedError("padding masks are out of scope (SURVEY §8 f2)")
+    x = embed(tokens, params)
+    rows: List[torch.Tensor] = []
+    n = num_layers if layers_to_run is None else layers_to_run
+    for i in range(n):
+        x, pr = axial_layer(x, params, i, num_heads, max_tokens)
+        rows.append(pr)
+    x = layer_norm(x, params["emb_layer_norm_after.weight"], params["emb_layer_norm_after.bias"])
+    return {"representation": x, "row_attentions": torch.stack(rows, 0)}
+
+
+def pack_outputs(result: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """extract_feat's output section (RNA_MSM_Inference.py:151-166): strip <cls>, keep MSA row 0.
+    -> emb [L, D], atp [num_layers*H, L, L] (channel = layer*H + head)."""
+    att = result["row_attentions"][..., 1:, 1:]
+    L = att.shape[-1]
+    emb = result["representation"][0, 1:, :]
+    return emb.contiguous(), att.reshape(-1, L, L).contiguous()
+
+
+def to_torch_params(state: Dict[str, "object"], dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """numpy / torch state_dict -> torch CPU tensors of `dtype`."""
+    out = {}
+    for k, v in state.items():
+        t = v if isinstance(v, torch.Tensor) else torch.from_numpy(v)
+        out[k] = t.detach().to("cpu", dtype)
+    return out

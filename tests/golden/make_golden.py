@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures by running the upstream reference itself.
+
+Runs ONLY in the authoring container (needs /root/reference, read-only).  The fixtures it
+writes next to this file are data: seeded inputs are regenerated from rnamsm.synthetic at test
+time, expected outputs are stored.  Nothing from the reference's source travels.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Fixtures:
+  tokens_*.npz          a2m text -> int64 tokens (bit-exact contract), incl. every character class
+  op_*.npz              per-module outputs of the reference's RowSelfAttention / ColumnSelfAttention /
+                        FeedForwardNetwork / NormalizedResidualBlock / AxialTransformerLayer
+  forward_*.npz         whole 10-layer D=768 forward: emb, atp, per-layer checksums
+  shapes_2DRB_1.json    shape/dtype/layout of the shipped results/2DRB_1_{emb,atp}.npy (values are not
+                        reproducible offline)
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd"))
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+import _refimport
+from rnamsm import synthetic
+
+ref_model, ref_modules, ref_msm, Vocab, MSA = _refimport.reference_modules()
+torch.set_grad_enabled(False)
+torch.manual_seed(0)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}: " + ", ".join(f"{k}{tuple(v.shape)}" for k, v in arrays.items()),
+          f"[{os.path.getsize(path) / 1024:.0f} KiB]")
+
+
+# ----------------------------------------------------------------------------- tokens
+def gen_tokens():
+    alphabet = ref_msm.data.Alphabet.from_architecture("rna language")
+    vocab = Vocab.from_esm_alphabet(alphabet)
+    # (1) first 64 records of the shipped example alignment
+    src = os.path.join(_refimport.REF, "results", "2DRB_1.a2m_msa2")
+    lines = open(src).read().splitlines()
+    recs, cur = [], []
+    for ln in lines:
+        if ln.startswith(">") and cur:
+            recs.append(cur)
+            cur = []
+        cur.append(ln)
+    recs.append(cur)
+    excerpt = "\n".join("\n".join(r) for r in recs[:64]) + "\n"
+    ex_path = os.path.join(HERE, "2DRB_1_first64.a2m_msa2")
+    open(ex_path, "w").write(excerpt)
+    msa = MSA.from_fasta(ex_path)
+    toks = vocab.encode(msa)
+    assert toks.dtype == np.int64
+    save("tokens_2DRB_1_first64.npz", tokens=toks)
+    # (2) synthetic a2m touching every mapping of SURVEY a12: lowercase / '.' / '*' insertions are dropped,
+    #     T->U, each of RYKMSWBDHVN -> X, and the plain alphabet A G C U X -
+    syn = (">q desc with spaces\nACGU-XACGUTT\n"
+           ">ins\nAcgCGU-.*XACGaaUTu.T\n"
+           ">iupac\nRYKMSWBDHVN-\n"
+           ">multi\nACGU-X\nACGUTT\n"
+           ">gaps\n------------\n")
+    syn_path = os.path.join(HERE, "synthetic_chars.a2m_msa2")
+    open(syn_path, "w").write(syn)
+    toks2 = vocab.encode(MSA.from_fasta(syn_path))
+    save("tokens_synthetic_chars.npz", tokens=toks2)
+    # error behaviour, recorded so the tests can assert the same exception types
+    errs = {}
+    bad = os.path.join(HERE, "_tmp_bad.a2m")
+    open(bad, "w").write(">a\nACGU\n>b\nACG\n")
+    try:
+        MSA.from_fasta(bad)
+        errs["ragged"] = "none"
+    except AssertionError as e:
+        errs["ragged"] = f"AssertionError:{e}"
+    open(bad, "w").write(">a\nACGE\n>b\nACGU\n")
+    try:
+        vocab.encode(MSA.from_fasta(bad))
+        errs["invalid_char"] = "none"
+    except ValueError as e:
+        errs["invalid_char"] = f"ValueError:{e}"
+    os.remove(bad)
+    json.dump({"vocab": vocab.to_dict(), "prepend_bos": vocab.prepend_bos, "append_eos": vocab.append_eos,
+               "errors": errs}, open(os.path.join(HERE, "tokens_meta.json"), "w"), indent=1)
+    print("  token errors:", errs)
+    return vocab
+
+
+# ----------------------------------------------------------------------------- per-op
+def load_into(module, state, prefix):
+    sd = {k[len(prefix) + 1:]: t(v) for k, v in state.items() if k.startswith(prefix + ".")}
+    module.load_state_dict(sd, strict=True)
+    return module.eval()
+
+
+def gen_ops():
+    cases = [
+        # name, D, H, R, C, max_tokens (None = direct path)
+        ("d128_r7_c33", 128, 2, 7, 33, None),
+        ("d128_r7_c33_chunk", 128, 2, 7, 33, 66),      # forces row chunks of 2 rows / col slabs of 9
+        ("d128_r1_c5", 128, 2, 1, 5, None),             # R==1 shortcut (modules.py:882-894)
+        ("d128_r34_c66", 128, 2, 34, 66, None),         # crosses 32/64 tile edges in both axes
+        ("d768_r6_c19", 768, 12, 6, 19, None),
+    ]
+    for name, D, H, R, C, max_tokens in cases:
+        state = synthetic.make_state_dict(seed=7, embed_dim=D, num_layers=1, num_heads=H)
+        x = synthetic.normal(f"x:{name}", 7, (R, C, 1, D)).astype(np.float32)
+        xt = t(x)
+        mt = max_tokens if max_tokens is not None else 2 ** 30
+        out = {}
+        row = load_into(ref_modules.RowSelfAttention(D, H, max_tokens_per_msa=mt), state,
+                        "layers.0.row_self_attention.layer")
+        y, p = row(xt)
+        out["row_out"], out["row_probs"] = y.numpy()[:, :, 0], p.numpy()[:, 0]
+        col = load_into(ref_modules.ColumnSelfAttention(D, H, max_tokens_per_msa=mt), state,
+                        "layers.0.column_self_attention.layer")
+        y, p = col(xt)
+        out["col_out"] = y.numpy()[:, :, 0]
+        if R * R * C * H * 4 < 300_000:
+            out["col_probs"] = p.numpy()[:, :, 0]          # [H, C, R, R]
+        ff = load_into(ref_modules.FeedForwardNetwork(D, 4 * D, max_tokens_per_msa=mt), state,
+                       "layers.0.feed_forward_layer.layer")
+        big = R * C * D * 4 > 600_000                       # keep big cases to the attention outputs
+        if not big:
+            out["ffn_out"] = ff(xt).numpy()[:, :, 0]
+        blk = load_into(ref_modules.NormalizedResidualBlock(
+            ref_modules.FeedForwardNetwork(D, 4 * D), D), state, "layers.0.feed_forward_layer")
+        if not big:
+            out["ffn_block_out"] = blk(xt).numpy()[:, :, 0]
+        layer = load_into(ref_modules.AxialTransformerLayer(D, 4 * D, H, max_tokens_per_msa=mt), state, "layers.0")
+        y, cp, rp = layer(xt, need_head_weights=True)
+        out["layer_out"], out["layer_row_probs"] = y.numpy()[:, :, 0], rp.numpy()[:, 0]
+        ln = torch.nn.LayerNorm(D)
+        ln.weight.copy_(t(state["layers.0.row_self_attention.layer_norm.weight"]))
+        ln.bias.copy_(t(state["layers.0.row_self_attention.layer_norm.bias"]))
+        if not big:
+            out["ln_out"] = ln(xt).numpy()[:, :, 0]
+        save(f"op_{name}.npz", meta=np.array([D, H, R, C, -1 if max_tokens is None else max_tokens]), **out)
+
+
+# ----------------------------------------------------------------------------- whole forward
+def gen_forward(vocab):
+    state = synthetic.make_state_dict(seed=0)
+    cases = [("m8_c17", 8, 17, 16384), ("m8_c17_chunk", 8, 17, 64), ("m16_c33", 16, 33, 16384),
+             ("m5_c41", 5, 41, 16384)]
+    for name, M, C, max_tokens in cases:
+        model = ref_model.MSATransformer(vocab, num_layers=10, max_tokens_per_msa=max_tokens, max_seqlen=1024)
+        model.load_state_dict({k: t(v) for k, v in state.items()}, strict=True)
+        model.eval()
+        toks = synthetic.make_tokens(M, C, msa_index={"m8_c17": 0, "m8_c17_chunk": 0, "m16_c33": 1, "m5_c41": 2}[name])
+        reps = list(range(0, 11))
+        res = model(t(toks)[None], repr_layers=reps, need_head_weights=True)
+        att = res["row_attentions"]                                   # [1, 10, 12, C, C]
+        # extract_feat's slicing (RNA_MSM_Inference.py:151-166)
+        atp = att[..., 1:, 1:].reshape(-1, C - 1, C - 1).numpy()
+        emb = res["representations"][10][:, 0, 1:, :].squeeze(0).numpy()
+        absmean = np.array([float(res["representations"][i].abs().mean()) for i in reps], dtype=np.float64)
+        row0 = np.stack([res["representations"][i][0, 0].numpy() for i in (0, 1, 5)], 0)   # [3, C, D] probes
+        save(f"forward_{name}.npz", meta=np.array([M, C, max_tokens]), tokens=toks, emb=emb, atp=atp,
+             layer_absmean=absmean, probe_row0_layers_0_1_5=row0,
+             attn_full_layer0=att[0, 0].numpy())
+        # fp64 run of the same model: the reference's own fp32 noise floor for these inputs
+        m64 = model.double()
+        r64 = m64(t(toks)[None], repr_layers=[10], need_head_weights=True)
+        emb64 = r64["representations"][10][:, 0, 1:, :].squeeze(0).numpy()
+        atp64 = r64["row_attentions"][..., 1:, 1:].reshape(-1, C - 1, C - 1).numpy()
+        rel = np.linalg.norm(emb - emb64) / np.linalg.norm(emb64)
+        print(f"    {name}: reference fp32-vs-fp64 emb rel-L2 {rel:.2e}, atp max-abs {np.abs(atp - atp64).max():.2e}")
+        if name in ("m8_c17", "m16_c33"):
+            save(f"forward_{name}_fp64.npz", emb=emb64.astype(np.float64), atp=atp64.astype(np.float64))
+
+
+def gen_shapes():
+    info = {}
+    for kind in ("emb", "atp"):
+        a = np.load(os.path.join(_refimport.REF, "results", f"2DRB_1_{kind}.npy"))
+        info[kind] = {"shape": list(a.shape), "dtype": str(a.dtype), "fortran_order": bool(np.isfortran(a)),
+                      "row_sum_max": float(a.sum(-1).max()) if kind == "atp" else None}
+    json.dump(info, open(os.path.join(HERE, "shapes_2DRB_1.json"), "w"), indent=1)
+    print("  shapes:", info)
+
+
+if __name__ == "__main__":
+    print("tokens"); vocab = gen_tokens()
+    print("ops"); gen_ops()
+    print("forward"); gen_forward(vocab)
+    print("shapes"); gen_shapes()

@@ -1,0 +1,125 @@
+"""Pins the oracle (oracle/msm_oracle.py, oracle/tokenizer_oracle.py) against fixtures produced by
+the reference itself (tests/golden/make_golden.py).  CPU only.
+
+Tolerances: the oracle is an independent fp32 restatement, so it differs from the reference by
+fp32 summation order only.  The reference's own fp32-vs-fp64 noise floor on these inputs is
+emb rel-L2 ~1e-6, atp max-abs ~6e-6 (printed by make_golden.py); the oracle must sit within
+1e-5 rel-L2 / 2e-5 max-abs of the reference and, run in fp64, within the same distance of the
+reference's fp64 run.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden, rel_l2
+from oracle import msm_oracle as O
+from oracle import tokenizer_oracle as TO
+from rnamsm import synthetic
+
+OP_CASES = ["d128_r7_c33", "d128_r7_c33_chunk", "d128_r1_c5", "d128_r34_c66", "d768_r6_c19"]
+FWD_CASES = ["m8_c17", "m8_c17_chunk", "m16_c33", "m5_c41"]
+
+
+def test_tokens_2drb1_bit_exact():
+    text = open(os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2")).read()
+    want = golden("tokens_2DRB_1_first64.npz")["tokens"]
+    got = TO.encode_msa(text)
+    assert got.dtype == np.int64 and got.shape == want.shape
+    assert np.array_equal(got, want)
+    assert (got[:, 0] == 0).all()
+
+
+def test_tokens_every_character_class_bit_exact():
+    text = open(os.path.join(GOLDEN, "synthetic_chars.a2m_msa2")).read()
+    want = golden("tokens_synthetic_chars.npz")["tokens"]
+    assert np.array_equal(TO.encode_msa(text), want)
+
+
+def test_token_errors_match_reference():
+    meta = json.load(open(os.path.join(GOLDEN, "tokens_meta.json")))
+    assert meta["vocab"] == TO.TOK_TO_IDX
+    assert meta["errors"]["ragged"].startswith("AssertionError")
+    assert meta["errors"]["invalid_char"] == "ValueError:Invalid tokens in input"
+    with pytest.raises(AssertionError):
+        TO.encode_msa(">a\nACGU\n>b\nACG\n")
+    with pytest.raises(ValueError, match="Invalid tokens in input"):
+        TO.encode_msa(">a\nACGE\n>b\nACGU\n")
+
+
+@pytest.mark.parametrize("name", OP_CASES)
+def test_ops_match_reference(name):
+    g = golden(f"op_{name}.npz")
+    D, H, R, C, max_tokens = (int(v) for v in g["meta"])
+    mt = None if max_tokens < 0 else max_tokens
+    state = O.to_torch_params(synthetic.make_state_dict(seed=7, embed_dim=D, num_layers=1, num_heads=H))
+    x = torch.from_numpy(synthetic.normal(f"x:{name}", 7, (R, C, 1, D)).astype(np.float32))[:, :, 0]
+    out, probs = O.row_attention(x, state, "layers.0.row_self_attention.layer", H, mt)
+    assert rel_l2(out, g["row_out"]) < 1e-5
+    assert np.abs(probs.numpy() - g["row_probs"]).max() < 2e-5
+    out, probs = O.col_attention(x, state, "layers.0.column_self_attention.layer", H, return_probs=True)
+    assert rel_l2(out, g["col_out"]) < 1e-5
+    if "col_probs" in g:
+        assert np.abs(probs.numpy() - g["col_probs"]).max() < 2e-5
+    if "ffn_out" in g:
+        assert rel_l2(O.ffn(x, state, "layers.0.feed_forward_layer.layer"), g["ffn_out"]) < 1e-5
+        pre = "layers.0.feed_forward_layer"
+        blk = x + O.ffn(O.layer_norm(x, state[f"{pre}.layer_norm.weight"], state[f"{pre}.layer_norm.bias"]),
+                        state, f"{pre}.layer")
+        assert rel_l2(blk, g["ffn_block_out"]) < 1e-5
+        pre = "layers.0.row_self_attention"
+        ln = O.layer_norm(x, state[f"{pre}.layer_norm.weight"], state[f"{pre}.layer_norm.bias"])
+        assert rel_l2(ln, g["ln_out"]) < 1e-5
+    y, rp = O.axial_layer(x, state, 0, H, mt)
+    assert rel_l2(y, g["layer_out"]) < 1e-5
+    assert np.abs(rp.numpy() - g["layer_row_probs"]).max() < 2e-5
+
+
+@pytest.fixture(scope="module")
+def full_state():
+    return synthetic.make_state_dict(seed=0)
+
+
+@pytest.mark.parametrize("name", FWD_CASES)
+def test_forward_matches_reference(name, full_state):
+    g = golden(f"forward_{name}.npz")
+    M, C, max_tokens = (int(v) for v in g["meta"])
+    toks = synthetic.make_tokens(M, C, {"m8_c17": 0, "m8_c17_chunk": 0, "m16_c33": 1, "m5_c41": 2}[name])
+    assert np.array_equal(toks, g["tokens"])          # the token generator itself is part of the fixture
+    params = O.to_torch_params(full_state)
+    res = O.forward(torch.from_numpy(toks), params, max_tokens=max_tokens)
+    emb, atp = O.pack_outputs(res)
+    assert emb.shape == g["emb"].shape and atp.shape == g["atp"].shape
+    assert rel_l2(emb, g["emb"]) < 1e-5
+    assert np.abs(atp.numpy() - g["atp"]).max() < 2e-5
+    assert np.abs(res["row_attentions"][0].numpy() - g["attn_full_layer0"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("name", ["m8_c17", "m16_c33"])
+def test_forward_fp64_matches_reference_fp64(name, full_state):
+    g = golden(f"forward_{name}.npz")
+    g64 = golden(f"forward_{name}_fp64.npz")
+    params = O.to_torch_params(full_state, torch.float64)
+    res = O.forward(torch.from_numpy(g["tokens"]), params)
+    emb, atp = O.pack_outputs(res)
+    assert rel_l2(emb, g64["emb"]) < 1e-6              # the fixture is a float32-weights fp64 run
+    assert np.abs(atp.numpy() - g64["atp"]).max() < 1e-6
+
+
+def test_shipped_output_contract():
+    info = json.load(open(os.path.join(GOLDEN, "shapes_2DRB_1.json")))
+    assert info["emb"] == {"shape": [35, 768], "dtype": "float32", "fortran_order": False, "row_sum_max": None}
+    assert info["atp"]["shape"] == [120, 35, 35] and info["atp"]["dtype"] == "float32"
+    assert info["atp"]["row_sum_max"] <= 1.0 + 1e-5   # <cls> column stripped => rows sum to < 1
+
+
+def test_rejects_more_than_1024_rows_and_padding(full_state):
+    params = {k: torch.zeros(1) for k in ()}
+    with pytest.raises(RuntimeError, match="maximum MSA"):
+        O.embed(torch.zeros(1025, 4, dtype=torch.int64), {})
+    toks = torch.from_numpy(synthetic.make_tokens(2, 5))
+    toks[1, 3] = 1
+    with pytest.raises(NotImplementedError):
+        O.forward(toks, params)
