@@ -1,0 +1,153 @@
+/*
+ * rnamsm.h -- C ABI of librnamsm_hip.so: the MI355X (gfx950) implementation of RNA-MSM's
+ * axial-attention forward path.
+ *
+ * The reference (yikunpku/RNA-MSM) has no FFI: the path is reached through nn.Module.forward
+ * calls that bottom out in ATen ops.  Each entry point below replaces one
+ * group of those ATen call sites; the citation names the reference lines (relative to the
+ * reference root) whose result it reproduces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer is DEVICE memory owned by the caller;
+ *   - one MSA per call (B = 1, as the reference CLI runs it: RNA_MSM_Inference.py:141-148);
+ *     a token (r, c) of the [R rows, C columns] alignment is row t = r*C + c of a [T, D] matrix;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *     synchronises, nothing allocates (scratch is caller-provided, sized by *_workspace_bytes);
+ *   - return value: RNAMSM_OK or a negative rnamsm_status; rnamsm_last_error() gives the text
+ *     for the calling thread;
+ *   - dtype: RNAMSM_F32 is implemented (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32); RNAMSM_BF16 is
+ *     reserved and returns RNAMSM_ERR_UNSUPPORTED.
+ */
+#ifndef RNAMSM_H_
+#define RNAMSM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RNAMSM_VERSION 100 /* major*10000 + minor*100 + patch */
+
+typedef enum {
+    RNAMSM_OK = 0,
+    RNAMSM_ERR_INVALID = -1,     /* bad shape / null pointer / misaligned argument */
+    RNAMSM_ERR_UNSUPPORTED = -2, /* valid request this build does not implement */
+    RNAMSM_ERR_HIP = -3          /* a HIP runtime call failed (launch, attribute) */
+} rnamsm_status;
+
+typedef enum { RNAMSM_F32 = 0, RNAMSM_BF16 = 1 } rnamsm_dtype;
+typedef enum { RNAMSM_ACT_NONE = 0, RNAMSM_ACT_GELU_ERF = 1 } rnamsm_act;
+
+int rnamsm_version(void);
+const char* rnamsm_last_error(void);
+/* Number of visible HIP devices (0 on a CPU-only box); never initialises a context. */
+int rnamsm_device_count(void);
+
+/* K0 -- MSATransformer.forward embedding section (model.py:349-362) with
+ * LearnedPositionalEmbedding.forward (modules.py:286-300):
+ *   x[r,c,:] = LayerNorm( E_tok[tok[r,c]] + E_pos[pos(r,c)] + row_pos[r] ),
+ *   pos(r,c) = (#non-pad tokens in tok[r,0..c]) * (tok[r,c] != pad) + pad_idx.
+ * tokens int64 [R,C]; embed_tokens [V,D]; embed_positions [P,D]; row_pos [>=R] (the
+ * (1,1024,1,1) msa_position_embedding); out [R*C, D].  Token ids outside [0,V) or positions
+ * outside [0,P) set *err_flag (device int, may be NULL) to 1 and are clamped. */
+int rnamsm_embed_ln(const int64_t* tokens, const float* embed_tokens, const float* embed_positions,
+                    const float* row_pos, const float* gamma, const float* beta, float* out,
+                    int R, int C, int D, int vocab, int num_positions, int pad_idx, float eps,
+                    int* err_flag, void* stream);
+
+/* K1 -- nn.LayerNorm over the last dim (modules.py:383,387; model.py:396): y = (x-mean)/sqrt(var+eps)*gamma+beta,
+ * biased variance.  x, y [T, D] contiguous (y may alias x). */
+int rnamsm_layernorm(const float* x, const float* gamma, const float* beta, float* y,
+                     int64_t T, int D, float eps, void* stream);
+
+/* K2/K3/K8 -- nn.Linear with fused epilogue (modules.py:760-766, 794-799, 896-905, 923, 424-426, 396):
+ *   Cout[m,n] = act( (sum_k A[m,k]*W[n,k] + bias[n]) * (n < scale_cols ? scale : 1) ) + residual[m,n]
+ * A [M,K] row stride lda; W [N,K] contiguous (torch Linear layout); bias [N] or NULL;
+ * residual [M,N] row stride ldr or NULL; Cout [M,N] row stride ldc (may alias residual).
+ * Requires N % 128 == 0, K % 32 == 0, lda/ldr/ldc % 4 == 0 and 16-byte aligned pointers. */
+int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float* W, const float* bias,
+                             const float* residual, int64_t ldr, float* Cout, int64_t ldc,
+                             int64_t M, int N, int K, int act, float scale, int scale_cols,
+                             int dtype, void* stream);
+
+/* K4 -- tied row-attention logits, RowSelfAttention.compute_attention_weights (modules.py:752-786):
+ *   S[h,i,j] = sum_{r,d} q[r,i,h,d] * k[r,j,h,d]      (q already scaled by dh^-0.5/sqrt(R), K3)
+ * q, k: element (r,i,h,d) at ptr[(r*C+i)*ld + h*64 + d]  (head_dim is 64).
+ * The sum over rows is split into `nsplit` contiguous row ranges (rnamsm_row_logits_nsplit);
+ * partial [nsplit, H, C, C] holds one slab per range and K5 adds them in range order, so the
+ * result does not depend on scheduling.  This replaces the reference's chunk-and-sum
+ * _batched_forward (modules.py:717-750): same sum, fixed order. */
+int rnamsm_row_logits_nsplit(int R, int C, int H);
+size_t rnamsm_row_logits_workspace_bytes(int R, int C, int H);
+int rnamsm_row_logits(const float* q, const float* k, int64_t ld, float* partial,
+                      int R, int C, int H, int head_dim, int dtype, void* stream);
+
+/* K5 -- softmax over the last axis of the summed logits (modules.py:818 / 739):
+ *   probs[h,i,:] = softmax_j( sum_s partial[s,h,i,:] ).  probs [H, C, C] is the layer's
+ *   row_attentions slab (model.py:392). */
+int rnamsm_softmax_rows(const float* partial, int nsplit, float* probs, int H, int C, void* stream);
+
+/* K6 -- RowSelfAttention.compute_attention_update's contraction (modules.py:797-798):
+ *   ctx[r,i,h,:] = sum_j probs[h,i,j] * v[r,j,h,:]
+ * v addressed like q/k above; ctx element (r,i,h,d) at ctx[(r*C+i)*ldc + h*64 + d]. */
+int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc,
+                     int R, int C, int H, int head_dim, int dtype, void* stream);
+
+/* K7 -- ColumnSelfAttention.compute_attention_update's attention (modules.py:905-921), fused:
+ *   for every column c and head h: ctx[:,c,h,:] = softmax_j( q[:,c,h,:] k[:,c,h,:]^T ) v[:,c,h,:]
+ * (q already scaled by dh^-0.5).  The [H,C,R,R] probabilities are never written (the reference
+ * computes and discards them).  R == 1 degenerates to ctx = v (modules.py:882-894). */
+int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_t ld,
+                          float* ctx, int64_t ldc, int R, int C, int H, int head_dim,
+                          int dtype, void* stream);
+
+/* K10 -- extract_feat's output section (RNA_MSM_Inference.py:151-166):
+ *   emb[c-1, :]            = x_final[row 0, c, :]                c = 1..C-1      -> [C-1, D]
+ *   atp[l*H+h, i-1, j-1]   = probs_all[l, h, i, j]               i,j = 1..C-1    -> [NL*H, C-1, C-1]
+ * x_final [R*C, D] is the output of emb_layer_norm_after; probs_all [NL, H, C, C]. */
+int rnamsm_pack_outputs(const float* x_final, const float* probs_all, float* emb, float* atp,
+                        int C, int D, int num_layers, int H, void* stream);
+
+/* Whole forward, K0..K10 for one MSA, driven from C++ so that one call enqueues every launch
+ * (MSATransformer.forward, model.py:338-416, with repr_layers=[num_layers], need_head_weights=True,
+ * lm_head / contact head omitted -- their results are unused by the CLI).
+ *
+ * Weights are passed as a table of device pointers in the order documented for
+ * rnamsm_weight_index (fused QKV is packed by the caller: Wqkv [3D, D] = q;k;v rows). */
+typedef struct {
+    int num_layers, embed_dim, num_heads, ffn_dim, vocab, num_positions, pad_idx;
+    float ln_eps;
+} rnamsm_model_dims;
+
+enum {
+    RNAMSM_W_EMBED_TOKENS = 0, RNAMSM_W_EMBED_POSITIONS, RNAMSM_W_ROW_POS,
+    RNAMSM_W_LN_BEFORE_G, RNAMSM_W_LN_BEFORE_B, RNAMSM_W_LN_AFTER_G, RNAMSM_W_LN_AFTER_B,
+    RNAMSM_W_GLOBAL_COUNT
+};
+enum { /* per layer, offset RNAMSM_W_GLOBAL_COUNT + layer * RNAMSM_W_LAYER_COUNT */
+    RNAMSM_WL_ROW_LN_G = 0, RNAMSM_WL_ROW_LN_B, RNAMSM_WL_ROW_WQKV, RNAMSM_WL_ROW_BQKV,
+    RNAMSM_WL_ROW_WO, RNAMSM_WL_ROW_BO,
+    RNAMSM_WL_COL_LN_G, RNAMSM_WL_COL_LN_B, RNAMSM_WL_COL_WQKV, RNAMSM_WL_COL_BQKV,
+    RNAMSM_WL_COL_WO, RNAMSM_WL_COL_BO,
+    RNAMSM_WL_FFN_LN_G, RNAMSM_WL_FFN_LN_B, RNAMSM_WL_FC1_W, RNAMSM_WL_FC1_B,
+    RNAMSM_WL_FC2_W, RNAMSM_WL_FC2_B,
+    RNAMSM_W_LAYER_COUNT
+};
+
+size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int C);
+/* tokens int64 [R,C]; weights: host array of (RNAMSM_W_GLOBAL_COUNT + L*RNAMSM_W_LAYER_COUNT)
+ * device pointers; workspace >= rnamsm_forward_workspace_bytes; row_attn [L,H,C,C] (full, with
+ * <cls>), repr [R*C, D] (after emb_layer_norm_after), emb [C-1, D], atp [L*H, C-1, C-1];
+ * row_attn/repr may be NULL only if the caller provides them inside... no: all four are required. */
+int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
+                   int R, int C, void* workspace, size_t workspace_bytes,
+                   float* row_attn, float* repr, float* emb, float* atp,
+                   int* err_flag, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RNAMSM_H_ */

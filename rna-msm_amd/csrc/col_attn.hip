@@ -1,0 +1,192 @@
+// K7: fused column attention (ColumnSelfAttention.compute_attention_update, modules.py:875-924).
+//
+// For every alignment column c and head h:  ctx[:,c,h,:] = softmax_j(q[:,c,h,:] k[:,c,h,:]^T) v[:,c,h,:]  with the
+// R x R score matrix kept in registers -- the reference materialises [H,C,R,R] probabilities (1.6 GB at R=256,
+// C=512) only to discard them.
+//
+// Structure (exact-fp32 MFMA 32x32x2, online softmax):
+//   block = 8 waves = 256 query rows of one (c, h); wave = 32 query rows, its Q fragment lives in 32 VGPRs.
+//   Keys/values stream through LDS in 64-row chunks (double buffered, register-staged global loads issued before
+//   the MFMAs that hide them).
+//   Scores are computed TRANSPOSED, S^T = K Q^T (A = K rows, B = Q): the accumulator then holds the query row on the
+//   lane and the keys in the 16 registers, so (a) softmax max/sum are per-lane reductions plus one lane-half
+//   exchange, (b) exp(S^T) is, register for register, the B operand of O^T += V^T P^T with no data movement
+//   (the k index of MFMA step t is key (t&3)+8(t>>2)+4*half -- the accumulator's own row map), and (c) O^T also has
+//   the query row on the lane, so the online-softmax rescale is a per-lane scalar multiply.
+// Roofline: MFMA-bound: 4*R*R*64 flops per (c,h) vs 4*R*256 B of q,k,v,ctx (64 flop/B at R=256).
+#include "common.h"
+
+namespace rnamsm {
+
+constexpr int CA_THREADS = 512;
+constexpr int CA_ROWS = 256;          // query rows per block
+constexpr int CA_JC = 64;             // keys per chunk
+constexpr int CA_HD = 64;             // head dim
+constexpr int CA_LDD = CA_HD + 4;     // padded LDS row stride (floats): 16 rows -> 16 distinct 16-B slots
+constexpr int CA_TILE = CA_JC * CA_LDD;
+constexpr int CA_LDS_BYTES = 2 * 2 * CA_TILE * 4;
+
+__global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
+    float* __restrict__ ctx, int64_t ldc, int R, int C, int H) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                    // [2][CA_JC][CA_LDD]
+    float* Vs = smem + 2 * CA_TILE;      // [2][CA_JC][CA_LDD]
+
+    const unsigned iblocks = (R + CA_ROWS - 1) / CA_ROWS;
+    unsigned prob, ib;
+    if (!xcd_panel_map(blockIdx.x, (unsigned)C * H, iblocks, prob, ib)) return;
+    const int c = prob / H, h = prob % H;
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int irow0 = ib * CA_ROWS + wave * 32;              // first query row of this wave
+    const bool active = irow0 < R;                           // wave-uniform
+    const int64_t col_off = (int64_t)c * ld + h * CA_HD;     // + r*C*ld selects the alignment row
+
+    // Q fragment: lane (i, half) holds q[i][8kk + 4*half + s], kk = 0..7, s = 0..3 (B operand of S^T = K Q^T)
+    f32x4 qf[8];
+    {
+        const int qi = min(irow0 + li, R - 1);
+        const float* qp = q + (int64_t)qi * C * ld + col_off + 4 * lh;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const f32x4*>(qp + 8 * kk);
+    }
+
+    // staging map: thread -> (key row tid/16 and +32, 16-B chunk tid%16) of the [64][64] K and V chunks
+    const int d4 = threadIdx.x & 15, jr = threadIdx.x >> 4;
+    f32x4 sk[2], sv[2];
+    auto load_chunk = [&](int ch) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int j = ch * CA_JC + jr + 32 * s;
+            if (j < R) {
+                const int64_t off = (int64_t)j * C * ld + col_off + d4 * 4;
+                sk[s] = *reinterpret_cast<const f32x4*>(k + off);
+                sv[s] = *reinterpret_cast<const f32x4*>(v + off);
+            } else {                                         // keys past R: zero (scores are masked, V must be finite)
+                sk[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                sv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            *reinterpret_cast<f32x4*>(&Ks[buf * CA_TILE + (jr + 32 * s) * CA_LDD + d4 * 4]) = sk[s];
+            *reinterpret_cast<f32x4*>(&Vs[buf * CA_TILE + (jr + 32 * s) * CA_LDD + d4 * 4]) = sv[s];
+        }
+    };
+
+    f32x16 o0, o1;                       // O^T tiles: head dims [0,32) and [32,64) x 32 query rows
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nch = (R + CA_JC - 1) / CA_JC;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    for (int ch = 0; ch < nch; ++ch) {
+        const int cur = ch & 1;
+        const bool more = ch + 1 < nch;
+        if (more) load_chunk(ch + 1);
+        if (active) {
+            const float* Kc = Ks + cur * CA_TILE;
+            const float* Vc = Vs + cur * CA_TILE;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const int jbase = ch * CA_JC + jt * 32;
+                if (jbase < R) {                                                   // block-uniform
+                    // ---- S^T tile = K[32 keys] . Q^T[32 queries], K = 64 head dims
+                    f32x16 s;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) s[t] = 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const f32x4 kf = *reinterpret_cast<const f32x4*>(&Kc[(jt * 32 + li) * CA_LDD + 8 * kk + 4 * lh]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s = mfma32(kf[e], qf[kk][e], s);
+                    }
+                    // ---- mask keys >= R, online softmax (query row = lane, keys = registers x lane half)
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int j = jbase + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                        if (j >= R) s[t] = -INFINITY;
+                        mx = fmaxf(mx, s[t]);
+                    }
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    const float m_new = fmaxf(m_run, mx);                          // finite: key jbase is valid
+                    const float alpha = expf(m_run - m_new);                       // 0 on the first tile
+                    float psum = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        s[t] = expf(s[t] - m_new);
+                        psum += s[t];
+                    }
+                    l_run = l_run * alpha + psum;
+                    m_run = m_new;
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
+                    // ---- O^T += V^T P^T : step t contracts keys (t&3)+8(t>>2)+4*half, i.e. register t of P as it stands
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) {
+                        const int jl = jt * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                        const float v0 = Vc[jl * CA_LDD + li];
+                        const float v1 = Vc[jl * CA_LDD + 32 + li];
+                        o0 = mfma32(v0, s[t], o0);
+                        o1 = mfma32(v1, s[t], o1);
+                    }
+                }
+            }
+        }
+        if (more) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+
+    if (active) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.f / l_tot;
+        const int i = irow0 + li;
+        if (i < R) {
+            float* op = ctx + ((int64_t)i * C + c) * ldc + h * CA_HD + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {      // registers 4g..4g+3 are head dims 8g + 4*half + {0..3}
+                *reinterpret_cast<f32x4*>(op + 8 * g) =
+                    f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(op + 32 + 8 * g) =
+                    f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+            }
+        }
+    }
+}
+
+}  // namespace rnamsm
+
+using namespace rnamsm;
+
+extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_t ld, float* ctx,
+                                     int64_t ldc, int R, int C, int H, int head_dim, int dtype, void* stream) {
+    if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "col_attn: only RNAMSM_F32 is implemented");
+    RNAMSM_CHECK_ARG(q && k && v && ctx, "col_attn: null pointer");
+    RNAMSM_CHECK_ARG(head_dim == CA_HD, "col_attn: head_dim must be 64 (got %d)", head_dim);
+    RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0, "col_attn: bad shape R=%d C=%d H=%d", R, C, H);
+    RNAMSM_CHECK_ARG(ld >= (int64_t)H * CA_HD && ld % 4 == 0 && ldc >= (int64_t)H * CA_HD && ldc % 4 == 0,
+                     "col_attn: ld/ldc must be multiples of 4 and >= H*64");
+    RNAMSM_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(ctx), "col_attn: 16-byte alignment");
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, CA_LDS_BYTES);
+        if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    const unsigned iblocks = (R + CA_ROWS - 1) / CA_ROWS;
+    const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
+    hipLaunchKernelGGL(col_attn_kernel, dim3(grid), dim3(CA_THREADS), CA_LDS_BYTES, static_cast<hipStream_t>(stream),
+                       q, k, v, ld, ctx, ldc, R, C, H);
+    RNAMSM_CHECK_LAUNCH("col_attn");
+    return RNAMSM_OK;
+}

@@ -1,0 +1,69 @@
+// Shared host/device helpers for librnamsm_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/rnamsm.h"
+
+namespace rnamsm {
+
+// ---- error plumbing (thread-local text behind rnamsm_last_error) -------------------------------
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define RNAMSM_CHECK_ARG(cond, ...)                                   \
+    do {                                                              \
+        if (!(cond)) return ::rnamsm::fail(RNAMSM_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define RNAMSM_CHECK_LAUNCH(name)                                                         \
+    do {                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                \
+        if (e_ != hipSuccess)                                                             \
+            return ::rnamsm::fail(RNAMSM_ERR_HIP, "%s launch: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- device helpers ----------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// Exact-fp32 matrix core step: D(32x32) += A(32x2) * B(2x32).
+// Lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31]; accumulator register t of lane l is
+// D[row = (t&3) + 8*(t>>2) + 4*(l>>5)][col = l&31]  (cdna_hip_programming.md §3).
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// XCD-aware block remap for panel-sharing tiled kernels: hardware deals consecutive block ids round-robin over the
+// 8 XCDs (each with a private 4 MiB L2), so blocks b and b+8 share an L2.  Blocks that read the same operand panel
+// are given ids of equal (b % 8): `inner` consecutive logical tiles (one panel) per XCD slot.
+// Returns false for padding blocks.  Speed only -- results never depend on placement.
+__device__ __forceinline__ bool xcd_panel_map(unsigned bid, unsigned num_panels, unsigned inner,
+                                              unsigned& panel, unsigned& in_panel) {
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    panel = (idx / inner) * 8u + xcd;
+    in_panel = idx % inner;
+    return panel < num_panels;
+}
+static inline unsigned xcd_panel_grid(unsigned num_panels, unsigned inner) {
+    return ((num_panels + 7u) / 8u) * 8u * inner;
+}
+
+}  // namespace rnamsm

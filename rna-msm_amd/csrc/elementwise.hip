@@ -1,0 +1,172 @@
+// K0 / K1 / K10: the HBM-bound kernels of the path.  One wave (64 lanes) per token row, 16-B loads and stores,
+// wavefront shuffles for the reductions; nothing is staged through LDS because no value is reused across lanes.
+//   K0 embed_ln      model.py:349-362 + modules.py:286-300    gather 2 table rows + row scalar, LayerNorm
+//   K1 layernorm     modules.py:383,387 ; model.py:396          read 4*D B, write 4*D B per token
+//   K10 pack_outputs RNA_MSM_Inference.py:151-166               strip <cls>, keep MSA row 0
+#include "common.h"
+
+namespace rnamsm {
+
+constexpr int LN_MAX_VEC = 4;     // float4 per lane -> D <= 1024
+
+// LayerNorm of one row held as up to LN_MAX_VEC float4 per lane (biased variance, two-pass like ATen's CPU kernel).
+__device__ __forceinline__ void ln_row(f32x4 (&x)[LN_MAX_VEC], int nvec, int lane, int D, float eps,
+                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* __restrict__ out_row) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < LN_MAX_VEC; ++e)
+        if (lane + 64 * e < nvec) s += (x[e][0] + x[e][1]) + (x[e][2] + x[e][3]);
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < LN_MAX_VEC; ++e)
+        if (lane + 64 * e < nvec) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = x[e][i] - mean;
+                ss += d * d;
+            }
+        }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+#pragma unroll
+    for (int e = 0; e < LN_MAX_VEC; ++e) {
+        const int vi = lane + 64 * e;
+        if (vi < nvec) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * vi);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * vi);
+            f32x4 y;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = (x[e][i] - mean) * rstd * g[i] + b[i];
+            *reinterpret_cast<f32x4*>(out_row + 4 * vi) = y;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* y, int64_t T, int D,
+                                                        float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nvec = D / 4;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += stride) {
+        f32x4 v[LN_MAX_VEC];
+#pragma unroll
+        for (int e = 0; e < LN_MAX_VEC; ++e)
+            if (lane + 64 * e < nvec) v[e] = *reinterpret_cast<const f32x4*>(x + row * D + 4 * (lane + 64 * e));
+        ln_row(v, nvec, lane, D, eps, gamma, beta, y + row * D);
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict__ tokens,
+                                                       const float* __restrict__ embed_tokens,
+                                                       const float* __restrict__ embed_positions,
+                                                       const float* __restrict__ row_pos,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ out, int R, int C, int D, int vocab,
+                                                       int num_positions, int pad_idx, float eps, int* err_flag) {
+    const int lane = threadIdx.x & 63;
+    const int nvec = D / 4;
+    const int64_t T = (int64_t)R * C;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += stride) {
+        const int r = (int)(row / C), c = (int)(row % C);
+        const int64_t* trow = tokens + (int64_t)r * C;
+        // pos = cumsum(tok != pad)[c] * (tok[c] != pad) + pad   (modules.py:288-290)
+        int count = 0;
+        for (int base = 0; base <= c; base += 64) {
+            const int cc = base + lane;
+            const bool nonpad = cc <= c && trow[cc] != pad_idx;
+            count += __popcll(__ballot(nonpad));
+        }
+        int64_t tok = trow[c];
+        int pos = (tok != pad_idx) ? count + pad_idx : pad_idx;
+        if (tok < 0 || tok >= vocab || pos >= num_positions) {
+            if (lane == 0 && err_flag) *err_flag = 1;
+            tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+            pos = pos >= num_positions ? num_positions - 1 : pos;
+        }
+        const float rp = row_pos[r];
+        f32x4 v[LN_MAX_VEC];
+#pragma unroll
+        for (int e = 0; e < LN_MAX_VEC; ++e) {
+            const int vi = lane + 64 * e;
+            if (vi < nvec) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(embed_tokens + tok * D + 4 * vi);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(embed_positions + (int64_t)pos * D + 4 * vi);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[e][i] = (a[i] + b[i]) + rp;     // same association as model.py:349-360
+            }
+        }
+        ln_row(v, nvec, lane, D, eps, gamma, beta, out + row * D);
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_outputs_kernel(const float* __restrict__ x_final,
+                                                           const float* __restrict__ probs_all,
+                                                           float* __restrict__ emb, float* __restrict__ atp, int C,
+                                                           int D, int64_t n_emb, int64_t n_atp) {
+    const int L = C - 1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_emb + n_atp; idx += stride) {
+        if (idx < n_emb) {
+            const int64_t cpos = idx / D, d = idx % D;                        // emb[c-1, d] = x_final[row 0, c, d]
+            emb[idx] = x_final[(cpos + 1) * D + d];
+        } else {
+            const int64_t a = idx - n_emb;
+            const int64_t j = a % L, i = (a / L) % L, ch = a / ((int64_t)L * L);
+            atp[a] = probs_all[(ch * C + (i + 1)) * C + (j + 1)];
+        }
+    }
+}
+
+static unsigned rows_grid(int64_t rows) {
+    const int64_t blocks = (rows + 3) / 4;
+    return (unsigned)(blocks < 4096 ? (blocks > 0 ? blocks : 1) : 4096);     // grid-stride beyond 16 blocks per CU
+}
+
+}  // namespace rnamsm
+
+using namespace rnamsm;
+
+extern "C" int rnamsm_layernorm(const float* x, const float* gamma, const float* beta, float* y, int64_t T, int D,
+                                float eps, void* stream) {
+    RNAMSM_CHECK_ARG(x && gamma && beta && y, "layernorm: null pointer");
+    RNAMSM_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_VEC, "layernorm: need D %% 4 == 0, D <= 1024 (D=%d)", D);
+    RNAMSM_CHECK_ARG(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "layernorm: 16-byte alignment");
+    hipLaunchKernelGGL(layernorm_kernel, dim3(rows_grid(T)), dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma,
+                       beta, y, T, D, eps);
+    RNAMSM_CHECK_LAUNCH("layernorm");
+    return RNAMSM_OK;
+}
+
+extern "C" int rnamsm_embed_ln(const int64_t* tokens, const float* embed_tokens, const float* embed_positions,
+                               const float* row_pos, const float* gamma, const float* beta, float* out, int R, int C,
+                               int D, int vocab, int num_positions, int pad_idx, float eps, int* err_flag,
+                               void* stream) {
+    RNAMSM_CHECK_ARG(tokens && embed_tokens && embed_positions && row_pos && gamma && beta && out, "embed_ln: null pointer");
+    RNAMSM_CHECK_ARG(R > 0 && C > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_VEC, "embed_ln: bad shape R=%d C=%d D=%d", R, C, D);
+    if (R > 1024)   // model.py:355-359
+        return fail(RNAMSM_ERR_INVALID,
+                    "Using model with MSA position embedding trained on maximum MSA depth of 1024, but received %d alignments.", R);
+    RNAMSM_CHECK_ARG(aligned16(embed_tokens) && aligned16(embed_positions) && aligned16(out) && aligned16(gamma) && aligned16(beta),
+                     "embed_ln: 16-byte alignment");
+    hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid((int64_t)R * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       tokens, embed_tokens, embed_positions, row_pos, gamma, beta, out, R, C, D, vocab, num_positions,
+                       pad_idx, eps, err_flag);
+    RNAMSM_CHECK_LAUNCH("embed_ln");
+    return RNAMSM_OK;
+}
+
+extern "C" int rnamsm_pack_outputs(const float* x_final, const float* probs_all, float* emb, float* atp, int C, int D,
+                                   int num_layers, int H, void* stream) {
+    RNAMSM_CHECK_ARG(x_final && probs_all && emb && atp, "pack_outputs: null pointer");
+    RNAMSM_CHECK_ARG(C >= 2 && D > 0 && num_layers > 0 && H > 0, "pack_outputs: bad shape C=%d D=%d", C, D);
+    const int64_t L = C - 1;
+    const int64_t n_emb = L * D, n_atp = (int64_t)num_layers * H * L * L;
+    const int64_t blocks = (n_emb + n_atp + 255) / 256;
+    hipLaunchKernelGGL(pack_outputs_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x_final, probs_all, emb, atp, C, D, n_emb, n_atp);
+    RNAMSM_CHECK_LAUNCH("pack_outputs");
+    return RNAMSM_OK;
+}

@@ -1,0 +1,111 @@
+// Whole-forward driver: one C call enqueues K0..K10 for one MSA on the caller's stream
+// (MSATransformer.forward, model.py:338-416, with AxialTransformerLayer.forward, modules.py:242-267, and
+// NormalizedResidualBlock.forward, modules.py:385-401, unrolled into 13 launches per layer).
+//
+// HBM layout of the workspace (T = R*C tokens, D = embed dim, F = 4D):
+//   x      [T, D]    residual stream, updated in place by the out_proj / fc2 epilogues (K8)
+//   xn     [T, D]    LayerNorm output, the A operand of the next GEMM
+//   wide   [T, 4D]   fused QKV activation [T, 3D] (row stride 3D) followed by the attention context [T, D];
+//                    the FFN hidden activation [T, F] overlays both (they are never live together)
+//   part   [nsplit, H, C, C]  row-logit partial slabs (K4 -> K5)
+// cfg3 (R=256, C=512): 403 MB + 403 MB + 1.61 GB + 75 MB; cfg5 (R=C=1024): 19.3 GB -- one 288 GB HBM3E stack set
+// holds every activation of the largest supported MSA, so nothing is chunked or recomputed.
+#include "common.h"
+
+using namespace rnamsm;
+
+namespace {
+struct Layout {
+    size_t x, xn, wide, part, total;
+};
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+Layout make_layout(const rnamsm_model_dims& d, int R, int C) {
+    const size_t T = (size_t)R * C, D = d.embed_dim;
+    Layout l;
+    size_t off = 0;
+    l.x = off;    off += align256(T * D * 4);
+    l.xn = off;   off += align256(T * D * 4);
+    l.wide = off; off += align256(T * (size_t)(3 * D + D > (size_t)d.ffn_dim ? 4 * D : d.ffn_dim) * 4);
+    l.part = off; off += align256(rnamsm_row_logits_workspace_bytes(R, C, d.num_heads));
+    l.total = off;
+    return l;
+}
+}  // namespace
+
+extern "C" size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int C) {
+    if (!dims || R <= 0 || C <= 0) return 0;
+    return make_layout(*dims, R, C).total;
+}
+
+#define FWD(call)                   \
+    do {                            \
+        int rc_ = (call);           \
+        if (rc_ != RNAMSM_OK) return rc_; \
+    } while (0)
+
+extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
+                              int R, int C, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
+                              float* emb, float* atp, int* err_flag, int dtype, void* stream) {
+    if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "forward: only RNAMSM_F32 is implemented");
+    RNAMSM_CHECK_ARG(dims && weights && tokens && workspace && row_attn && repr && emb && atp, "forward: null pointer");
+    const rnamsm_model_dims& d = *dims;
+    const int D = d.embed_dim, H = d.num_heads, F = d.ffn_dim, NL = d.num_layers;
+    RNAMSM_CHECK_ARG(D > 0 && H > 0 && D == H * 64, "forward: embed_dim must be num_heads * 64 (D=%d H=%d)", D, H);
+    RNAMSM_CHECK_ARG(D % 128 == 0 && F % 128 == 0 && NL > 0, "forward: embed_dim and ffn_dim must be multiples of 128");
+    RNAMSM_CHECK_ARG(C >= 2 && R >= 1, "forward: need R >= 1 and C >= 2 (got R=%d C=%d)", R, C);
+    if (R > 1024)   // model.py:355-359
+        return fail(RNAMSM_ERR_INVALID,
+                    "Using model with MSA position embedding trained on maximum MSA depth of 1024, but received %d alignments.", R);
+    RNAMSM_CHECK_ARG(C <= d.num_positions - d.pad_idx - 1, "forward: C=%d exceeds the positional table", C);
+    const Layout lay = make_layout(d, R, C);
+    RNAMSM_CHECK_ARG(workspace_bytes >= lay.total, "forward: workspace too small (%zu < %zu)", workspace_bytes, lay.total);
+    RNAMSM_CHECK_ARG(aligned16(workspace), "forward: workspace must be 16-byte aligned");
+
+    char* ws = static_cast<char*>(workspace);
+    float* x = reinterpret_cast<float*>(ws + lay.x);
+    float* xn = reinterpret_cast<float*>(ws + lay.xn);
+    float* wide = reinterpret_cast<float*>(ws + lay.wide);
+    float* part = reinterpret_cast<float*>(ws + lay.part);
+    const int64_t T = (int64_t)R * C;
+    const int64_t ldq = 3 * (int64_t)D;
+    float* qkv = wide;                 // [T, 3D]: q | k | v per token
+    float* ctx = wide + T * ldq;       // [T, D]
+    float* hidden = wide;              // [T, F]
+    const float* const* G = weights;
+    const int nsplit = rnamsm_row_logits_nsplit(R, C, H);
+    const float row_scale = (1.0f / sqrtf(64.0f)) / sqrtf((float)R);     // align_scaling, modules.py:713-715
+    const float col_scale = 1.0f / sqrtf(64.0f);                         // modules.py:839
+
+    FWD(rnamsm_embed_ln(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
+                        G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, R, C, D, d.vocab, d.num_positions,
+                        d.pad_idx, d.ln_eps, err_flag, stream));
+    for (int l = 0; l < NL; ++l) {
+        const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
+        float* probs = row_attn + (int64_t)l * H * C * C;
+        // ---- tied row attention block
+        FWD(rnamsm_layernorm(x, W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B], xn, T, D, d.ln_eps, stream));
+        FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, T,
+                                     3 * D, D, RNAMSM_ACT_NONE, row_scale, D, dtype, stream));
+        FWD(rnamsm_row_logits(qkv, qkv + D, ldq, part, R, C, H, 64, dtype, stream));
+        FWD(rnamsm_softmax_rows(part, nsplit, probs, H, C, stream));
+        FWD(rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, dtype, stream));
+        FWD(rnamsm_gemm_bias_act_res(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], x, D, x, D, T, D, D,
+                                     RNAMSM_ACT_NONE, 1.f, 0, dtype, stream));
+        // ---- column attention block
+        FWD(rnamsm_layernorm(x, W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B], xn, T, D, d.ln_eps, stream));
+        FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, T,
+                                     3 * D, D, RNAMSM_ACT_NONE, col_scale, D, dtype, stream));
+        FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, dtype, stream));
+        FWD(rnamsm_gemm_bias_act_res(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], x, D, x, D, T, D, D,
+                                     RNAMSM_ACT_NONE, 1.f, 0, dtype, stream));
+        // ---- feed-forward block
+        FWD(rnamsm_layernorm(x, W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B], xn, T, D, d.ln_eps, stream));
+        FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], nullptr, 0, hidden, F, T, F, D,
+                                     RNAMSM_ACT_GELU_ERF, 1.f, 0, dtype, stream));
+        FWD(rnamsm_gemm_bias_act_res(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], x, D, x, D, T, D, F,
+                                     RNAMSM_ACT_NONE, 1.f, 0, dtype, stream));
+    }
+    FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
+    FWD(rnamsm_pack_outputs(repr, row_attn, emb, atp, C, D, NL, H, stream));
+    return RNAMSM_OK;
+}

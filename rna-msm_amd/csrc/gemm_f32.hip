@@ -1,0 +1,140 @@
+// K2/K3/K8: nn.Linear as an exact-fp32 MFMA GEMM with fused bias / column scale / erf-GELU / residual epilogue.
+//   Cout[m,n] = act((sum_k A[m,k] W[n,k] + bias[n]) * (n < scale_cols ? scale : 1)) + residual[m,n]
+// Reference call sites: modules.py:760-766 (q,k proj + q scaling), :794,:799 (v, out proj), :896-905, :923 (column),
+// :424-426 (fc1 + GELU, fc2), :396 (residual add).
+//
+// Roofline: MFMA-bound.  2*M*N*K flops against v_mfma_f32_32x32x2_f32's 157.3 TFLOP/s; per 128x128x32 K tile a CU
+// issues 256 MFMAs (4096 cycles per SIMD) while 32 KB arrive from L2 (8 B/clk/CU).  Two blocks are resident per CU
+// (73.7 KB LDS, <=128 VGPRs each) so one block's barrier / staging bubbles are covered by the other's MFMAs.
+#include "mma_core.h"
+
+namespace rnamsm {
+
+constexpr int GEMM_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;   // double-buffered A and W tiles
+
+template <int ACT, bool HAS_RES>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
+    const float* residual, int64_t ldr, float* Cout, int64_t ldc,
+    int M, int N, int K, float scale, int scale_cols) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                    // [2][BM][LDK]
+    float* Ws = smem + 2 * TILE_KC;      // [2][BN][LDK]
+
+    const unsigned nb = N / BN, mp = (M + BM - 1) / BM;
+    unsigned mpanel, nblk;
+    if (!xcd_panel_map(blockIdx.x, mp, nb, mpanel, nblk)) return;
+    const int m0 = mpanel * BM, n0 = nblk * BN;
+
+    const WaveCoord w = wave_coord();
+    const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+
+    // per-thread global row pointers (A rows clamped: a clamped row only feeds its own discarded output row)
+    const float* ap[4];
+    const float* wp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + r0 + 32 * i;
+        m = m < M ? m : M - 1;
+        ap[i] = A + (int64_t)m * lda + c4 * 4;
+        wp[i] = W + (int64_t)(n0 + r0 + 32 * i) * K + c4 * 4;
+    }
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+
+    StageKC sa, sw;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sa.v[i] = *reinterpret_cast<const f32x4*>(ap[i]);
+        sw.v[i] = *reinterpret_cast<const f32x4*>(wp[i]);
+    }
+    stage_store_kc(As, sa);
+    stage_store_kc(Ws, sw);
+    __syncthreads();
+
+    const int nk = K / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {   // issue next tile's global loads; they land while the MFMAs below run
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sa.v[i] = *reinterpret_cast<const f32x4*>(ap[i] + (kt + 1) * BK);
+                sw.v[i] = *reinterpret_cast<const f32x4*>(wp[i] + (kt + 1) * BK);
+            }
+        }
+        mma_ktile<true>(As + cur * TILE_KC, Ws + cur * TILE_KC, acc, w);
+        if (more) {   // the other buffer was last read before the previous barrier
+            stage_store_kc(As + (cur ^ 1) * TILE_KC, sa);
+            stage_store_kc(Ws + (cur ^ 1) * TILE_KC, sw);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: each accumulator register covers 32 consecutive columns of one row per lane half (128-B stores)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = n0 + acc_col(w, nt);
+        const float b = bias ? bias[col] : 0.f;
+        const float sc = col < scale_cols ? scale : 1.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int row = m0 + acc_row(w, mt, t);
+                if (row < M) {
+                    float v = (acc[mt][nt][t] + b) * sc;
+                    if (ACT == RNAMSM_ACT_GELU_ERF) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+                    if (HAS_RES) v += residual[(int64_t)row * ldr + col];
+                    Cout[(int64_t)row * ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int ACT, bool HAS_RES>
+static int launch_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
+                       int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
+                       hipStream_t stream) {
+    static bool configured = false;
+    auto kern = gemm_f32_kernel<ACT, HAS_RES>;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    const unsigned grid = xcd_panel_grid((M + BM - 1) / BM, N / BN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, A, lda, W, bias, residual, ldr,
+                       Cout, ldc, M, N, K, scale, scale_cols);
+    RNAMSM_CHECK_LAUNCH("gemm_f32");
+    return RNAMSM_OK;
+}
+
+}  // namespace rnamsm
+
+using namespace rnamsm;
+
+extern "C" int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float* W, const float* bias,
+                                        const float* residual, int64_t ldr, float* Cout, int64_t ldc, int64_t M,
+                                        int N, int K, int act, float scale, int scale_cols, int dtype, void* stream) {
+    if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "gemm: only RNAMSM_F32 is implemented");
+    RNAMSM_CHECK_ARG(A && W && Cout, "gemm: null pointer");
+    RNAMSM_CHECK_ARG(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    RNAMSM_CHECK_ARG(N % BN == 0 && K % BK == 0, "gemm: need N %% 128 == 0 and K %% 32 == 0 (N=%d K=%d)", N, K);
+    RNAMSM_CHECK_ARG(lda >= K && lda % 4 == 0 && ldc >= N, "gemm: bad leading dimension lda=%lld ldc=%lld",
+                     (long long)lda, (long long)ldc);
+    RNAMSM_CHECK_ARG(aligned16(A) && aligned16(W), "gemm: A and W must be 16-byte aligned");
+    RNAMSM_CHECK_ARG(!residual || ldr >= N, "gemm: bad residual stride");
+    RNAMSM_CHECK_ARG(act == RNAMSM_ACT_NONE || act == RNAMSM_ACT_GELU_ERF, "gemm: unknown activation %d", act);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int m = (int)M;
+    if (act == RNAMSM_ACT_GELU_ERF) {
+        return residual ? launch_gemm<RNAMSM_ACT_GELU_ERF, true>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, s)
+                        : launch_gemm<RNAMSM_ACT_GELU_ERF, false>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, s);
+    }
+    return residual ? launch_gemm<RNAMSM_ACT_NONE, true>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, s)
+                    : launch_gemm<RNAMSM_ACT_NONE, false>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, s);
+}

@@ -1,0 +1,350 @@
+// K4 / K5 / K6: tied row attention (RowSelfAttention, modules.py:688-821).
+//
+//  K4 row_logits : S[h,i,j] = sum_{r,d} q[r,i,h,d] k[r,j,h,d]     per head a [C x R*64] x [R*64 x C] GEMM
+//  K5 softmax    : P[h,i,:] = softmax_j(sum_s S_s[h,i,:])         wave-per-row reduction; P is the atp slab
+//  K6 row_apply  : ctx[r,i,h,:] = sum_j P[h,i,j] v[r,j,h,:]       per head a [C x C] x [C x R*64] GEMM
+//
+// Both contractions run on the 128x128x32 fp32 MFMA tile of mma_core.h.  Their operands live in the fused QKV
+// activation [T, 3D] written by K2, addressed in place: element (r,i,h,d) = ptr[(r*C+i)*ld + h*64 + d], so one K tile
+// of K4 is "row r, half of head_dim" (32 contiguous floats per alignment column) and one B tile of K6 is 32 key
+// columns x (2 rows r x 64 d) read as 256-B runs.  Roofline: MFMA-bound (K = R*64 resp. C deep); K4's only HBM
+// output is nsplit*H*C*C partials.
+//
+// Tied attention sums over all R rows before the softmax; the reference does that in max_tokens-sized row chunks
+// (_batched_forward, modules.py:717-750).  Here the rows are cut into nsplit contiguous ranges (to fill 256 CUs: one
+// head has only ceil(C/128)^2 output tiles) and K5 adds the partials in range order -> fixed summation order.
+#include "mma_core.h"
+
+namespace rnamsm {
+
+constexpr int HEAD_DIM = 64;
+constexpr int ROWLOGITS_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;
+constexpr int ROWAPPLY_LDS_BYTES = 2 * (TILE_KC + TILE_NC) * 4;
+
+struct RowSplit {
+    int nsplit, rows_per_split;
+};
+
+// Deterministic function of the shape only.  Picks the split count whose block count best fills
+// 256 CUs x 2 resident blocks, subject to >= 4 rows (8 K tiles) per split.
+static RowSplit choose_row_split(int R, int C, int H) {
+    const long tiles = (long)((C + BM - 1) / BM) * ((C + BN - 1) / BN) * H;
+    const int slots = 512;
+    int best_ns = 1;
+    double best_score = -1.0;
+    const int max_ns = R / 4 > 1 ? (R / 4 < 64 ? R / 4 : 64) : 1;
+    for (int ns = 1; ns <= max_ns; ++ns) {
+        const int rps = (R + ns - 1) / ns;
+        const int real_ns = (R + rps - 1) / rps;
+        const long blocks = tiles * real_ns;
+        const long rounds = (blocks + slots - 1) / slots;
+        double score = (double)blocks / (double)(rounds * slots);   // fill efficiency of the last round
+        score -= 0.002 * real_ns;                                    // prefer fewer partial slabs on ties
+        if (score > best_score + 1e-9) {
+            best_score = score;
+            best_ns = real_ns;
+        }
+    }
+    RowSplit s;
+    s.rows_per_split = (R + best_ns - 1) / best_ns;
+    s.nsplit = (R + s.rows_per_split - 1) / s.rows_per_split;
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------- K4
+// grid.x = xcd-mapped (panel = (head, split), inner = tiles_i * tiles_j): the 16 tiles of one (head, split) share
+// the same q/k row range, so they are placed on one XCD and re-read it from that L2.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, int64_t ld, float* __restrict__ partial,
+    int R, int C, int H, int nsplit, int rows_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;
+    float* Ks = smem + 2 * TILE_KC;
+
+    const unsigned tiles_c = (C + BM - 1) / BM;
+    unsigned panel, tile;
+    if (!xcd_panel_map(blockIdx.x, (unsigned)(H * nsplit), tiles_c * tiles_c, panel, tile)) return;
+    const int h = panel / nsplit, split = panel % nsplit;
+    const int i0 = (tile / tiles_c) * BM, j0 = (tile % tiles_c) * BN;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(R, r_begin + rows_per_split);
+
+    const WaveCoord w = wave_coord();
+    const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+
+    // column (alignment position) handled by each staging slot, clamped; a clamped column only feeds discarded outputs
+    int64_t qoff[4], koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int i = min(i0 + r0 + 32 * s, C - 1), j = min(j0 + r0 + 32 * s, C - 1);
+        qoff[s] = (int64_t)i * ld + h * HEAD_DIM + c4 * 4;
+        koff[s] = (int64_t)j * ld + h * HEAD_DIM + c4 * 4;
+    }
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+
+    const int nk = (r_end - r_begin) * (HEAD_DIM / BK);      // K tile kt = (row r_begin + kt/2, d half kt&1)
+    auto tile_base = [&](int kt) -> int64_t {
+        return (int64_t)(r_begin + (kt >> 1)) * C * ld + (kt & 1) * BK;
+    };
+
+    StageKC sq, sk;
+    {
+        const int64_t b = tile_base(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sq.v[s] = *reinterpret_cast<const f32x4*>(q + b + qoff[s]);
+            sk.v[s] = *reinterpret_cast<const f32x4*>(k + b + koff[s]);
+        }
+    }
+    stage_store_kc(Qs, sq);
+    stage_store_kc(Ks, sk);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const int64_t b = tile_base(kt + 1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sq.v[s] = *reinterpret_cast<const f32x4*>(q + b + qoff[s]);
+                sk.v[s] = *reinterpret_cast<const f32x4*>(k + b + koff[s]);
+            }
+        }
+        mma_ktile<true>(Qs + cur * TILE_KC, Ks + cur * TILE_KC, acc, w);
+        if (more) {
+            stage_store_kc(Qs + (cur ^ 1) * TILE_KC, sq);
+            stage_store_kc(Ks + (cur ^ 1) * TILE_KC, sk);
+        }
+        __syncthreads();
+    }
+
+    float* out = partial + ((int64_t)split * H + h) * C * C;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int j = j0 + acc_col(w, nt);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int i = i0 + acc_row(w, mt, t);
+                if (i < C && j < C) out[(int64_t)i * C + j] = acc[mt][nt][t];
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- K5
+// One wave per (h, i) row: sum the nsplit partial slabs in slab order, then softmax over j in fp32
+// (attn_weights.softmax(-1), modules.py:818/739).  C <= 1024 + 1 fits 17 values per lane.
+constexpr int SOFTMAX_MAX_PER_LANE = 17;
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ partial, int nsplit,
+                                                           float* __restrict__ probs, int64_t rows, int C) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t slab = rows * C;
+    float v[SOFTMAX_MAX_PER_LANE];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+        const int j = lane + 64 * e;
+        float s = -INFINITY;
+        if (j < C) {
+            const float* p = partial + row * C + j;
+            s = p[0];
+            for (int sp = 1; sp < nsplit; ++sp) s += p[(int64_t)sp * slab];
+        }
+        v[e] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+        const int j = lane + 64 * e;
+        v[e] = j < C ? expf(v[e] - mx) : 0.f;
+        sum += v[e];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+        const int j = lane + 64 * e;
+        if (j < C) probs[row * C + j] = v[e] * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- K6
+// out[i, (r,d)] = sum_j P[h][i][j] * V[j, (r,d)].  A = P_h rows (k = j contiguous), B = v read as [j][n] with
+// n = (r_local, d): 2 alignment rows x 64 head dims per 128-wide N tile.
+// grid.x = xcd-mapped (panel = (head, n tile), inner = tiles_i): the i tiles of one V panel share an L2.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
+    const float* __restrict__ probs, const float* __restrict__ v, int64_t ld, float* __restrict__ ctx, int64_t ldc,
+    int R, int C, int H) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ps = smem;                    // [2][BM][LDK]
+    float* Vs = smem + 2 * TILE_KC;      // [2][BK][LDN]
+
+    const unsigned tiles_i = (C + BM - 1) / BM, tiles_n = (R + 1) / 2;
+    unsigned panel, ti;
+    if (!xcd_panel_map(blockIdx.x, (unsigned)H * tiles_n, tiles_i, panel, ti)) return;
+    const int h = panel / tiles_n, rr0 = (panel % tiles_n) * 2;      // alignment rows rr0, rr0+1
+    const int i0 = ti * BM;
+
+    const WaveCoord w = wave_coord();
+    // A staging: thread -> (row = tid/8 + 32*s, chunk tid%8) of the [128][32] P tile
+    const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+    // B staging: thread -> (k = tid/32 + 8*s, n4 = tid%32) of the [32][128] V tile; n4 -> (r_local = n4/16, d4 = n4%16)
+    const int bk0 = threadIdx.x >> 5, n4 = threadIdx.x & 31;
+    const int br = min(rr0 + (n4 >> 4), R - 1);                      // clamped: second row of an odd R is discarded
+    const float* pbase = probs + (int64_t)h * C * C;
+    const float* vbase = v + (int64_t)br * C * ld + h * HEAD_DIM + (n4 & 15) * 4;
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const int nk = (C + BK - 1) / BK;
+
+    f32x4 sp[4], sv[4];
+    auto load_tiles = [&](int kt) {
+        const int j0 = kt * BK;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // P: zero-fill j >= C (K dimension): out-of-range keys must contribute exactly 0
+            const int i = min(i0 + r0 + 32 * s, C - 1);
+            const int j = j0 + c4 * 4;
+            const float* p = pbase + (int64_t)i * C + j;
+            f32x4 t;
+            if (j + 3 < C && ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)) {
+                t = *reinterpret_cast<const f32x4*>(p);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (j + e < C) ? p[e] : 0.f;
+            }
+            sp[s] = t;
+            const int jj = j0 + bk0 + 8 * s;
+            if (jj < C) {
+                sv[s] = *reinterpret_cast<const f32x4*>(vbase + (int64_t)jj * ld);
+            } else {
+                sv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* pt = Ps + buf * TILE_KC;
+        float* vt = Vs + buf * TILE_NC;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            *reinterpret_cast<f32x4*>(&pt[(r0 + 32 * s) * LDK + c4 * 4]) = sp[s];
+            *reinterpret_cast<f32x4*>(&vt[(bk0 + 8 * s) * LDN + n4 * 4]) = sv[s];
+        }
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) load_tiles(kt + 1);
+        mma_ktile<false>(Ps + cur * TILE_KC, Vs + cur * TILE_NC, acc, w);
+        if (more) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // column n of the tile -> (alignment row rr0 + n/64, head dim n%64)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = acc_col(w, nt);
+        const int r = rr0 + (n >> 6), d = n & 63;
+        if (r < R) {
+            float* obase = ctx + (int64_t)r * C * ldc + h * HEAD_DIM + d;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int i = i0 + acc_row(w, mt, t);
+                    if (i < C) obase[(int64_t)i * ldc] = acc[mt][nt][t];
+                }
+        }
+    }
+}
+
+template <typename K>
+static int set_lds(K kern, int bytes, const char* name) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+    return RNAMSM_OK;
+}
+
+}  // namespace rnamsm
+
+using namespace rnamsm;
+
+extern "C" int rnamsm_row_logits_nsplit(int R, int C, int H) {
+    if (R <= 0 || C <= 0 || H <= 0) return 0;
+    return choose_row_split(R, C, H).nsplit;
+}
+
+extern "C" size_t rnamsm_row_logits_workspace_bytes(int R, int C, int H) {
+    if (R <= 0 || C <= 0 || H <= 0) return 0;
+    return (size_t)choose_row_split(R, C, H).nsplit * H * C * C * sizeof(float);
+}
+
+extern "C" int rnamsm_row_logits(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H,
+                                 int head_dim, int dtype, void* stream) {
+    if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "row_logits: only RNAMSM_F32 is implemented");
+    RNAMSM_CHECK_ARG(q && k && partial, "row_logits: null pointer");
+    RNAMSM_CHECK_ARG(head_dim == HEAD_DIM, "row_logits: head_dim must be 64 (got %d)", head_dim);
+    RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0, "row_logits: bad shape R=%d C=%d H=%d", R, C, H);
+    RNAMSM_CHECK_ARG(ld >= (int64_t)H * HEAD_DIM && ld % 4 == 0 && aligned16(q) && aligned16(k),
+                     "row_logits: q/k must be 16-byte aligned with ld %% 4 == 0");
+    static bool configured = false;
+    if (!configured) {
+        int rc = set_lds(row_logits_kernel, ROWLOGITS_LDS_BYTES, "row_logits");
+        if (rc) return rc;
+        configured = true;
+    }
+    const RowSplit sp = choose_row_split(R, C, H);
+    const unsigned tiles_c = (C + BM - 1) / BM;
+    const unsigned grid = xcd_panel_grid((unsigned)(H * sp.nsplit), tiles_c * tiles_c);
+    hipLaunchKernelGGL(row_logits_kernel, dim3(grid), dim3(GEMM_THREADS), ROWLOGITS_LDS_BYTES,
+                       static_cast<hipStream_t>(stream), q, k, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split);
+    RNAMSM_CHECK_LAUNCH("row_logits");
+    return RNAMSM_OK;
+}
+
+extern "C" int rnamsm_softmax_rows(const float* partial, int nsplit, float* probs, int H, int C, void* stream) {
+    RNAMSM_CHECK_ARG(partial && probs, "softmax_rows: null pointer");
+    RNAMSM_CHECK_ARG(nsplit >= 1 && H > 0 && C > 0 && C <= 64 * SOFTMAX_MAX_PER_LANE,
+                     "softmax_rows: bad shape nsplit=%d H=%d C=%d (C <= %d)", nsplit, H, C, 64 * SOFTMAX_MAX_PER_LANE);
+    const int64_t rows = (int64_t)H * C;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), partial, nsplit, probs, rows, C);
+    RNAMSM_CHECK_LAUNCH("softmax_rows");
+    return RNAMSM_OK;
+}
+
+extern "C" int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,
+                                int H, int head_dim, int dtype, void* stream) {
+    if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "row_apply: only RNAMSM_F32 is implemented");
+    RNAMSM_CHECK_ARG(probs && v && ctx, "row_apply: null pointer");
+    RNAMSM_CHECK_ARG(head_dim == HEAD_DIM, "row_apply: head_dim must be 64 (got %d)", head_dim);
+    RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0, "row_apply: bad shape R=%d C=%d H=%d", R, C, H);
+    RNAMSM_CHECK_ARG(ld >= (int64_t)H * HEAD_DIM && ld % 4 == 0 && aligned16(v) && ldc >= (int64_t)H * HEAD_DIM,
+                     "row_apply: v must be 16-byte aligned with ld %% 4 == 0");
+    static bool configured = false;
+    if (!configured) {
+        int rc = set_lds(row_apply_kernel, ROWAPPLY_LDS_BYTES, "row_apply");
+        if (rc) return rc;
+        configured = true;
+    }
+    const unsigned tiles_i = (C + BM - 1) / BM, tiles_n = (R + 1) / 2;
+    const unsigned grid = xcd_panel_grid((unsigned)H * tiles_n, tiles_i);
+    hipLaunchKernelGGL(row_apply_kernel, dim3(grid), dim3(GEMM_THREADS), ROWAPPLY_LDS_BYTES,
+                       static_cast<hipStream_t>(stream), probs, v, ld, ctx, ldc, R, C, H);
+    RNAMSM_CHECK_LAUNCH("row_apply");
+    return RNAMSM_OK;
+}

@@ -1,0 +1,83 @@
+"""ctypes binding of librnamsm_hip.so (include/rnamsm.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  `load()` raises if the
+shared object is missing, and every op wrapper raises if its tensors are not on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librnamsm_hip.so")
+
+RNAMSM_OK = 0
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU_ERF = 0, 1
+
+# index tables of rnamsm_forward's weight-pointer array (include/rnamsm.h)
+W_GLOBAL = ("embed_tokens", "embed_positions", "row_pos", "ln_before_g", "ln_before_b", "ln_after_g", "ln_after_b")
+W_LAYER = ("row_ln_g", "row_ln_b", "row_wqkv", "row_bqkv", "row_wo", "row_bo",
+           "col_ln_g", "col_ln_b", "col_wqkv", "col_bqkv", "col_wo", "col_bo",
+           "ffn_ln_g", "ffn_ln_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+
+
+class ModelDims(ctypes.Structure):
+    _fields_ = [("num_layers", c_int), ("embed_dim", c_int), ("num_heads", c_int), ("ffn_dim", c_int),
+                ("vocab", c_int), ("num_positions", c_int), ("pad_idx", c_int), ("ln_eps", c_float)]
+
+
+_SIGNATURES = {
+    "rnamsm_version": (c_int, []),
+    "rnamsm_last_error": (c_char_p, []),
+    "rnamsm_device_count": (c_int, []),
+    "rnamsm_embed_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "rnamsm_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "rnamsm_gemm_bias_act_res": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                         c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "rnamsm_row_logits_nsplit": (c_int, [c_int, c_int, c_int]),
+    "rnamsm_row_logits_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "rnamsm_row_logits": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rnamsm_softmax_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "rnamsm_row_apply": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,
+                                 c_void_p]),
+    "rnamsm_col_attn_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
+                                      c_int, c_int, c_void_p]),
+    "rnamsm_pack_outputs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "rnamsm_forward_workspace_bytes": (c_size_t, [POINTER(ModelDims), c_int, c_int]),
+    "rnamsm_forward": (c_int, [POINTER(ModelDims), POINTER(c_void_p), c_void_p, c_int, c_int, c_void_p, c_size_t,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class RnamsmError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library; loud failure if it has not been built (python __graft_entry__.py / make -C csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RnamsmError(
+                f"{LIB_PATH} not found: the HIP extension is the only implementation of this path "
+                "(no CPU fallback). Build it with `make -C rna-msm_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if the header and the library disagree
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != RNAMSM_OK:
+        msg = load().rnamsm_last_error().decode(errors="replace")
+        if rc == -2:
+            raise NotImplementedError(msg)
+        raise RnamsmError(f"librnamsm_hip error {rc}: {msg}")

@@ -1,0 +1,222 @@
+"""MSATransformer shell over the HIP path; mirrors the live CLI model (reference model.py:258-434).
+
+Same constructor keywords, `forward(tokens[B,R,C], repr_layers, need_head_weights, return_contacts)`
+result dict, `max_tokens_per_msa_`, and the 275-key state_dict (strict load of a Lightning
+`.ckpt['state_dict']`, RNA_MSM_Inference.py:133-135).  `lm_head.*` and `contact_head.*` parameters are
+held so that strict loading works, but their heads are outside this path:
+"logits" is None and `return_contacts=True` raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Iterable, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .alphabet import RNAAlphabet
+from .modules import AxialTransformerLayer
+
+
+class _LMHeadParams(nn.Module):
+    """Parameter holder for the reference's RobertaLMHead keys (modules.py:303-319); not executed."""
+
+    def __init__(self, embed_dim: int, output_dim: int, weight: nn.Parameter):
+        super().__init__()
+        self.dense = nn.Linear(embed_dim, embed_dim)
+        self.layer_norm = nn.LayerNorm(embed_dim)
+        self.weight = weight                      # tied to embed_tokens.weight (model.py:328-332)
+        self.bias = nn.Parameter(torch.zeros(output_dim))
+
+
+class _ContactHeadParams(nn.Module):
+    """Parameter holder for contact_head.regression.* (modules.py:322-366); not executed."""
+
+    def __init__(self, in_features: int):
+        super().__init__()
+        self.regression = nn.Linear(in_features, 1, True)
+
+
+class MSATransformer(nn.Module):
+    def __init__(self, vocab: Optional[RNAAlphabet] = None, optimizer_config=None, contact_train_data=None,
+                 embed_dim: int = 768, num_attention_heads: int = 12, num_layers: int = 12,
+                 embed_positions_msa: bool = True, dropout: float = 0.1, attention_dropout: float = 0.1,
+                 activation_dropout: float = 0.1, max_tokens_per_msa: int = 2 ** 14, max_seqlen: int = 1024):
+        super().__init__()
+        self.vocab = vocab if vocab is not None else RNAAlphabet()
+        self.embed_dim = embed_dim
+        self.num_attention_heads = num_attention_heads
+        self.num_layers = num_layers
+        self.embed_positions_msa = embed_positions_msa
+        self.dropout = dropout
+        self.attention_dropout = attention_dropout
+        self.activation_dropout = activation_dropout
+        self.max_tokens_per_msa = max_tokens_per_msa
+        self.max_seqlen = max_seqlen
+        if not embed_positions_msa:
+            raise NotImplementedError("embed_positions_msa=False is not part of the CLI path")
+
+        n_vocab, pad = len(self.vocab), self.vocab.pad_idx
+        self.embed_tokens = nn.Embedding(n_vocab, embed_dim, padding_idx=pad)
+        self.msa_position_embedding = nn.Parameter(0.01 * torch.randn(1, 1024, 1, 1), requires_grad=False)
+        self.layers = nn.ModuleList([
+            AxialTransformerLayer(embedding_dim=embed_dim, ffn_embedding_dim=4 * embed_dim,
+                                  num_attention_heads=num_attention_heads, dropout=dropout,
+                                  attention_dropout=attention_dropout, activation_dropout=activation_dropout,
+                                  max_tokens_per_msa=max_tokens_per_msa)
+            for _ in range(num_layers)])
+        self.contact_head = _ContactHeadParams(num_layers * num_attention_heads)
+        # LearnedPositionalEmbedding table: max_seqlen + pad_idx + 1 rows (modules.py:277-283)
+        self.embed_positions = nn.Embedding(max_seqlen + pad + 1, embed_dim, padding_idx=pad)
+        self.emb_layer_norm_before = nn.LayerNorm(embed_dim)
+        self.emb_layer_norm_after = nn.LayerNorm(embed_dim)
+        self.lm_head = _LMHeadParams(embed_dim, n_vocab, self.embed_tokens.weight)
+        self.requires_grad_(False)
+        self._pack_key = None
+        self._pack = None
+        self._workspace = None
+
+    # ------------------------------------------------------------------ reference API
+    def max_tokens_per_msa_(self, value: int) -> None:
+        """Kept for interface parity (model.py:418-428).  The reference uses it to bound memory by chunking;
+        the HIP kernels tile internally, so results are identical for every value."""
+        self.max_tokens_per_msa = value
+        for layer in self.layers:
+            layer.row_self_attention.layer.max_tokens_per_msa = value
+            layer.column_self_attention.layer.max_tokens_per_msa = value
+
+    def get_sequence_attention(self, tokens):
+        return self(tokens.to(device=self.embed_tokens.weight.device), need_head_weights=True)["row_attentions"]
+
+    def predict_contacts(self, tokens):
+        return self(tokens, return_contacts=True)["contacts"]
+
+    # ------------------------------------------------------------------ weight packing for rnamsm_forward
+    def _packed_weights(self):
+        params = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if key == self._pack_key:
+            return self._pack
+        dev = self.embed_tokens.weight.device
+        if dev.type != "cuda":
+            raise _lib.RnamsmError("MSATransformer must be moved to the HIP device (model.to('cuda')): no CPU path exists")
+        keep: List[torch.Tensor] = []
+
+        def f(t: torch.Tensor) -> torch.Tensor:
+            t = t.detach().to(torch.float32).contiguous()
+            keep.append(t)
+            return t
+
+        table: List[torch.Tensor] = [
+            f(self.embed_tokens.weight), f(self.embed_positions.weight), f(self.msa_position_embedding.view(-1)),
+            f(self.emb_layer_norm_before.weight), f(self.emb_layer_norm_before.bias),
+            f(self.emb_layer_norm_after.weight), f(self.emb_layer_norm_after.bias)]
+        for layer in self.layers:
+            for blk in (layer.row_self_attention, layer.column_self_attention):
+                a = blk.layer
+                table += [f(blk.layer_norm.weight), f(blk.layer_norm.bias),
+                          f(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)),
+                          f(torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0)),
+                          f(a.out_proj.weight), f(a.out_proj.bias)]
+            blk = layer.feed_forward_layer
+            table += [f(blk.layer_norm.weight), f(blk.layer_norm.bias), f(blk.layer.fc1.weight), f(blk.layer.fc1.bias),
+                      f(blk.layer.fc2.weight), f(blk.layer.fc2.bias)]
+        assert len(table) == len(_lib.W_GLOBAL) + self.num_layers * len(_lib.W_LAYER)
+        ptrs = (ctypes.c_void_p * len(table))(*[t.data_ptr() for t in table])
+        dims = _lib.ModelDims(self.num_layers, self.embed_dim, self.num_attention_heads, 4 * self.embed_dim,
+                              self.embed_tokens.num_embeddings, self.embed_positions.num_embeddings,
+                              self.vocab.pad_idx, float(self.emb_layer_norm_before.eps))
+        self._pack = (dims, ptrs, keep)
+        self._pack_key = key
+        return self._pack
+
+    def _get_workspace(self, nbytes: int, device) -> torch.Tensor:
+        if self._workspace is None or self._workspace.numel() < nbytes or self._workspace.device != device:
+            self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._workspace
+
+    # ------------------------------------------------------------------ forward
+    def forward_one(self, tokens2d: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """One MSA through the C++ driver (rnamsm_forward): tokens int64 [R, C] on the HIP device ->
+        {"row_attn" [NL,H,C,C], "repr" [R,C,D], "emb" [C-1,D], "atp" [NL*H,C-1,C-1]}."""
+        if self.training:
+            raise NotImplementedError("rnamsm implements the inference path only: call .eval()")
+        if not tokens2d.is_cuda:
+            raise _lib.RnamsmError("tokens must be on the HIP device (no CPU path exists)")
+        R, C = tokens2d.shape
+        if R > 1024:
+            raise RuntimeError(
+                "Using model with MSA position embedding trained on maximum MSA "
+                f"depth of 1024, but received {R} alignments.")                       # model.py:355-359
+        lib = _lib.load()
+        dims, ptrs, _ = self._packed_weights()
+        dev = tokens2d.device
+        NL, H, D = self.num_layers, self.num_attention_heads, self.embed_dim
+        ws_bytes = lib.rnamsm_forward_workspace_bytes(ctypes.byref(dims), R, C)
+        ws = self._get_workspace(ws_bytes, dev)
+        row_attn = torch.empty(NL, H, C, C, device=dev, dtype=torch.float32)
+        rep = torch.empty(R, C, D, device=dev, dtype=torch.float32)
+        emb = torch.empty(C - 1, D, device=dev, dtype=torch.float32)
+        atp = torch.empty(NL * H, C - 1, C - 1, device=dev, dtype=torch.float32)
+        err = torch.zeros(1, device=dev, dtype=torch.int32)
+        toks = tokens2d.to(torch.int64).contiguous()
+        _lib.check(lib.rnamsm_forward(ctypes.byref(dims), ptrs, toks.data_ptr(), R, C, ws.data_ptr(), ws.numel(),
+                                      row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
+                                      err.data_ptr(), _lib.F32, torch.cuda.current_stream().cuda_stream))
+        return {"row_attn": row_attn, "repr": rep, "emb": emb, "atp": atp, "err": err}
+
+    def _forward_layerwise(self, tokens2d: torch.Tensor, repr_layers: Iterable[int]):
+        """Module-by-module path (same HIP kernels, launched from Python) used when intermediate
+        representations are requested."""
+        R, C = tokens2d.shape
+        D = self.embed_dim
+        x = ops.embed_ln(tokens2d.to(torch.int64), self.embed_tokens.weight.detach(), self.embed_positions.weight.detach(),
+                         self.msa_position_embedding.detach().view(-1).contiguous(),
+                         self.emb_layer_norm_before.weight.detach(), self.emb_layer_norm_before.bias.detach(),
+                         self.vocab.pad_idx, self.emb_layer_norm_before.eps).view(R, C, 1, D)
+        reps = {}
+        if 0 in repr_layers:
+            reps[0] = x.permute(2, 0, 1, 3)
+        rows = []
+        for i, layer in enumerate(self.layers):
+            x, _, row_attn = layer(x, need_head_weights=True)
+            rows.append(row_attn.permute(1, 0, 2, 3))                               # [1,H,C,C]
+            if (i + 1) in repr_layers and (i + 1) != self.num_layers:
+                reps[i + 1] = x.permute(2, 0, 1, 3)
+        xf = ops.layernorm(x, self.emb_layer_norm_after.weight.detach(), self.emb_layer_norm_after.bias.detach(),
+                           self.emb_layer_norm_after.eps)
+        if self.num_layers in repr_layers:
+            reps[self.num_layers] = xf.permute(2, 0, 1, 3)
+        return reps, torch.stack(rows, 1)                                           # [1,NL,H,C,C]
+
+    def forward(self, tokens, repr_layers=[], need_head_weights=False, return_contacts=False):
+        if return_contacts:
+            raise NotImplementedError("contact head is outside this path (SURVEY.md §8 f1)")
+        assert tokens.ndim == 3
+        B, R, C = tokens.shape
+        if not tokens.is_cuda:
+            raise _lib.RnamsmError("tokens must be on the HIP device (no CPU path exists)")
+        if bool((tokens == self.vocab.pad_idx).any()):
+            raise NotImplementedError("padding masks are not implemented (SURVEY.md §8 f2)")
+        repr_set = set(repr_layers)
+        reps: Dict[int, List[torch.Tensor]] = {i: [] for i in repr_set}
+        atts: List[torch.Tensor] = []
+        fast = repr_set <= {self.num_layers}
+        for b in range(B):
+            if fast:
+                out = self.forward_one(tokens[b])
+                if int(out["err"].item()) != 0:
+                    raise IndexError("token or position index out of range")
+                if self.num_layers in repr_set:
+                    reps[self.num_layers].append(out["repr"].unsqueeze(0))
+                atts.append(out["row_attn"].unsqueeze(0))
+            else:
+                r, a = self._forward_layerwise(tokens[b], repr_set)
+                for i in repr_set:
+                    reps[i].append(r[i])
+                atts.append(a)
+        result = {"logits": None, "representations": {i: torch.cat(v, 0) for i, v in reps.items()}}
+        if need_head_weights:
+            result["row_attentions"] = torch.cat(atts, 0)                           # [B, NL, H, C, C]
+        return result

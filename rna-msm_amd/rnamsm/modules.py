@@ -1,0 +1,199 @@
+"""Host-side mirror of the reference's axial-attention modules, executing on librnamsm_hip.
+
+Same class names, constructor arguments, forward signatures, return shapes, error behaviour and
+state_dict keys as the reference (modules.py:688-945, 404-427, 369-401, 191-267 == msm/axial_attention.py,
+msm/modules.py), so a checkpoint and a caller written for the reference work unchanged.  The
+nn.Linear / nn.LayerNorm children only HOLD parameters (for state_dict compatibility); no torch
+operator computes anything -- every forward goes through rnamsm.ops to the HIP kernels.
+
+Scope: inference, one MSA per call (B = 1), no padding mask.  Training-mode dropout,
+`self_attn_mask` and padding masks raise instead of silently doing something else.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import ACT_GELU_ERF, ACT_NONE
+
+
+def _check_inference(module: nn.Module, p: float) -> None:
+    if module.training and p > 0.0:
+        raise NotImplementedError("rnamsm implements the inference path only: call .eval() (dropout is not implemented)")
+
+
+def _tokens_2d(x: torch.Tensor):
+    """[R, C, B=1, D] -> ([R*C, D] view, R, C, D)."""
+    if x.dim() != 4:
+        raise ValueError(f"expected x of shape [R, C, B, D], got {tuple(x.shape)}")
+    R, C, B, D = x.shape
+    if B != 1:
+        raise NotImplementedError("rnamsm processes one MSA per call (B = 1); loop over the batch dimension")
+    return x.contiguous().view(R * C, D), R, C, D
+
+
+class _PackedQKV:
+    """Caches the fused [3D, D] q;k;v weight (one GEMM instead of three) until a parameter changes."""
+
+    def __init__(self):
+        self._key = None
+        self._w = self._b = None
+
+    def get(self, q: nn.Linear, k: nn.Linear, v: nn.Linear):
+        key = tuple((p.data_ptr(), p._version) for p in (q.weight, k.weight, v.weight, q.bias, k.bias, v.bias))
+        if key != self._key:
+            self._w = torch.cat([q.weight.detach(), k.weight.detach(), v.weight.detach()], 0).contiguous()
+            self._b = torch.cat([q.bias.detach(), k.bias.detach(), v.bias.detach()], 0).contiguous()
+            self._key = key
+        return self._w, self._b
+
+
+class _AxialAttentionBase(nn.Module):
+    def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0.0, max_tokens_per_msa: int = 2 ** 16):
+        super().__init__()
+        if embed_dim != num_heads * ops.HEAD_DIM:
+            raise ValueError(f"the HIP kernels are built for head_dim 64 (embed_dim={embed_dim}, num_heads={num_heads})")
+        self.num_heads = num_heads
+        self.dropout = dropout
+        self.head_dim = embed_dim // num_heads
+        self.scaling = self.head_dim ** -0.5
+        # Accepted for interface compatibility.  The reference chunks rows/columns above this token budget
+        # (_batched_forward); the kernels tile internally and produce the same sums, so the value changes nothing.
+        self.max_tokens_per_msa = max_tokens_per_msa
+        self.k_proj = nn.Linear(embed_dim, embed_dim)
+        self.v_proj = nn.Linear(embed_dim, embed_dim)
+        self.q_proj = nn.Linear(embed_dim, embed_dim)
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        self._packed = _PackedQKV()
+
+    def _qkv(self, x2: torch.Tensor, q_scale: float) -> torch.Tensor:
+        w, b = self._packed.get(self.q_proj, self.k_proj, self.v_proj)
+        D = x2.shape[1]
+        return ops.linear(x2, w, b, scale=q_scale, scale_cols=D)          # [T, 3D] = q*scale | k | v
+
+    def _project_out(self, ctx: torch.Tensor, residual: Optional[torch.Tensor]) -> torch.Tensor:
+        return ops.linear(ctx, self.out_proj.weight.detach(), self.out_proj.bias.detach(), residual=residual)
+
+    @staticmethod
+    def _reject_masks(self_attn_mask, self_attn_padding_mask):
+        if self_attn_mask is not None:
+            raise NotImplementedError           # same as the reference (modules.py:776-777, 909-910)
+        if self_attn_padding_mask is not None:
+            raise NotImplementedError("padding masks are not implemented (SURVEY.md §8 f2)")
+
+
+class RowSelfAttention(_AxialAttentionBase):
+    """Tied row attention; mirrors modules.py:688-821.  forward(x[R,C,1,D]) -> (out[R,C,1,D], probs[H,1,C,C])."""
+
+    attn_shape = "hnij"
+
+    def align_scaling(self, q: torch.Tensor) -> float:
+        return ops.row_scaling(q.size(0))
+
+    def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, _residual=None):
+        self._reject_masks(self_attn_mask, self_attn_padding_mask)
+        _check_inference(self, self.dropout)
+        x2, R, C, D = _tokens_2d(x)
+        H = self.num_heads
+        qkv = self._qkv(x2, self.align_scaling(x))
+        partial, _ = ops.row_logits(qkv[:, :D], qkv[:, D:2 * D], R, C, H)
+        probs = ops.softmax_rows(partial)
+        ctx = ops.row_apply(probs, qkv[:, 2 * D:], R, C, H)
+        res2 = None if _residual is None else _residual.contiguous().view(R * C, D)
+        out = self._project_out(ctx, res2)
+        return out.view(R, C, 1, D), probs.view(H, 1, C, C)
+
+
+class ColumnSelfAttention(_AxialAttentionBase):
+    """Column attention; mirrors modules.py:824-945.  forward(x[R,C,1,D]) -> (out[R,C,1,D], probs).
+
+    The reference returns the [H,C,1,R,R] probabilities and its only caller discards them
+    (model.py:390); they are 1.6 GB per layer at R=256, C=512 and the fused kernel never forms
+    them, so `probs` is None here."""
+
+    def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, _residual=None):
+        self._reject_masks(self_attn_mask, self_attn_padding_mask)
+        _check_inference(self, self.dropout)
+        x2, R, C, D = _tokens_2d(x)
+        H = self.num_heads
+        qkv = self._qkv(x2, self.scaling)
+        ctx = ops.col_attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], R, C, H)   # R == 1 reduces to ctx = v
+        res2 = None if _residual is None else _residual.contiguous().view(R * C, D)
+        out = self._project_out(ctx, res2)
+        return out.view(R, C, 1, D), None
+
+
+class FeedForwardNetwork(nn.Module):
+    """fc2(GELU_erf(fc1(x))); mirrors modules.py:404-427."""
+
+    def __init__(self, embedding_dim: int, ffn_embedding_dim: int, activation_dropout: float = 0.1,
+                 max_tokens_per_msa: int = 2 ** 14):
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.ffn_embedding_dim = ffn_embedding_dim
+        self.max_tokens_per_msa = max_tokens_per_msa
+        self.activation_dropout = activation_dropout
+        self.fc1 = nn.Linear(embedding_dim, ffn_embedding_dim)
+        self.fc2 = nn.Linear(ffn_embedding_dim, embedding_dim)
+
+    def forward(self, x, _residual=None):
+        _check_inference(self, self.activation_dropout)
+        shape = x.shape
+        x2 = x.contiguous().view(-1, shape[-1])
+        h = ops.linear(x2, self.fc1.weight.detach(), self.fc1.bias.detach(), act=ACT_GELU_ERF)
+        res2 = None if _residual is None else _residual.contiguous().view(-1, shape[-1])
+        return ops.linear(h, self.fc2.weight.detach(), self.fc2.bias.detach(), act=ACT_NONE, residual=res2).view(shape)
+
+
+class NormalizedResidualBlock(nn.Module):
+    """x + layer(LayerNorm(x)); mirrors modules.py:369-401.  The residual add is fused into the wrapped
+    layer's last GEMM epilogue, so `layer` must be one of the modules above."""
+
+    def __init__(self, layer: nn.Module, embedding_dim: int, dropout: float = 0.1):
+        super().__init__()
+        if not isinstance(layer, (RowSelfAttention, ColumnSelfAttention, FeedForwardNetwork)):
+            raise TypeError("NormalizedResidualBlock wraps rnamsm RowSelfAttention / ColumnSelfAttention / FeedForwardNetwork")
+        self.embedding_dim = embedding_dim
+        self.layer = layer
+        self.dropout = dropout
+        self.layer_norm = nn.LayerNorm(self.embedding_dim)
+
+    def forward(self, x, *args, **kwargs):
+        _check_inference(self, self.dropout)
+        xn = ops.layernorm(x, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(), self.layer_norm.eps)
+        outputs = self.layer(xn, *args, _residual=x, **kwargs)
+        return outputs
+
+
+class AxialTransformerLayer(nn.Module):
+    """row attention -> column attention -> FFN, each pre-LN + residual; mirrors modules.py:191-267."""
+
+    def __init__(self, embedding_dim: int = 768, ffn_embedding_dim: int = 3072, num_attention_heads: int = 8,
+                 dropout: float = 0.1, attention_dropout: float = 0.1, activation_dropout: float = 0.1,
+                 max_tokens_per_msa: int = 2 ** 14) -> None:
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.dropout_prob = dropout
+        self.row_self_attention = self.build_residual(
+            RowSelfAttention(embedding_dim, num_attention_heads, dropout=dropout, max_tokens_per_msa=max_tokens_per_msa))
+        self.column_self_attention = self.build_residual(
+            ColumnSelfAttention(embedding_dim, num_attention_heads, dropout=dropout, max_tokens_per_msa=max_tokens_per_msa))
+        self.feed_forward_layer = self.build_residual(
+            FeedForwardNetwork(embedding_dim, ffn_embedding_dim, activation_dropout=activation_dropout,
+                               max_tokens_per_msa=max_tokens_per_msa))
+
+    def build_residual(self, layer: nn.Module):
+        return NormalizedResidualBlock(layer, self.embedding_dim, self.dropout_prob)
+
+    def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, need_head_weights: bool = False):
+        x, row_attn = self.row_self_attention(x, self_attn_mask=self_attn_mask,
+                                              self_attn_padding_mask=self_attn_padding_mask)
+        x, column_attn = self.column_self_attention(x, self_attn_mask=self_attn_mask,
+                                                    self_attn_padding_mask=self_attn_padding_mask)
+        x = self.feed_forward_layer(x)
+        if need_head_weights:
+            return x, column_attn, row_attn
+        return x

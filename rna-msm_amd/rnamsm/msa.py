@@ -1,0 +1,75 @@
+"""a2m / FASTA alignment reader and row sub-sampling for the CLI path.
+
+Replaces MSA.from_fasta (utils/align.py:291-317) + A2MDataset.__getitem__ (dataset.py:80-92) for this
+path.  Row sub-sampling: the reference defaults to the external `hhfilter` binary (utils/align.py:68-102),
+which is not available offline; supported here are `first` (keep the first N rows) and the reference's
+greedy `diversity-max` / `diversity-min` (utils/align.py:128-148), done on the host like the reference
+(SURVEY.md §8 f3 lists the device version as a next step).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import List, Tuple, Union
+
+import numpy as np
+
+from .alphabet import RNAAlphabet
+
+SAMPLE_METHODS = ("hhfilter", "sample-pretrained", "diversity-max", "diversity-min", "first")
+
+
+def read_fasta_records(path_or_text: Union[str, Path], is_text: bool = False) -> List[Tuple[str, str]]:
+    text = path_or_text if is_text else Path(path_or_text).read_text()
+    records: List[Tuple[str, str]] = []
+    header, parts = None, []
+    for raw in text.splitlines():
+        if raw[:1] == ">":
+            if header is not None:
+                records.append((header, "".join(parts)))
+            header, parts = raw[1:].strip(), []
+        elif header is not None:
+            parts.append("".join(raw.split()))
+    if header is not None:
+        records.append((header, "".join(parts)))
+    return records
+
+
+def greedy_select(tokens: np.ndarray, num_seqs: int, mode: str = "max") -> np.ndarray:
+    """Row indices (sorted) chosen by the reference's greedy max/min mean-Hamming rule
+    (utils/align.py:128-148): start from row 0, repeatedly add the row whose mean normalised Hamming
+    distance to the rows chosen so far is largest (smallest), first index on ties."""
+    depth = tokens.shape[0]
+    if depth <= num_seqs:
+        return np.arange(depth)
+    body = tokens[:, 1:] if tokens.shape[1] > 1 else tokens
+    pick = np.argmax if mode == "max" else np.argmin
+    chosen = [0]
+    taken = np.zeros(depth, dtype=bool)
+    taken[0] = True
+    dist_sum = np.zeros(depth, dtype=np.float64)
+    for step in range(1, num_seqs):
+        last = body[chosen[-1]]
+        dist_sum += (body != last[None, :]).mean(1)
+        cand = np.flatnonzero(~taken)
+        best = cand[pick(dist_sum[cand] / step)]
+        chosen.append(int(best))
+        taken[best] = True
+    return np.array(sorted(chosen))
+
+
+def load_msa_tokens(path: Union[str, Path], alphabet: RNAAlphabet, max_seqs_per_msa: int = 512,
+                    sample_method: str = "hhfilter") -> np.ndarray:
+    """.a2m_msa2 file -> int64 tokens [R <= max_seqs, L+1]."""
+    if sample_method not in SAMPLE_METHODS:
+        raise AssertionError(f"unknown sample_method {sample_method!r}")
+    records = read_fasta_records(path)
+    tokens = alphabet.encode_a2m_records([seq for _, seq in records])
+    if max_seqs_per_msa is None or tokens.shape[0] <= max_seqs_per_msa:
+        return tokens
+    if sample_method == "first":
+        return tokens[:max_seqs_per_msa]
+    if sample_method in ("diversity-max", "diversity-min"):
+        return tokens[greedy_select(tokens, max_seqs_per_msa, sample_method.split("-")[1])]
+    raise NotImplementedError(
+        f"sample_method={sample_method!r} needs the external hhfilter binary / random weights of the reference; "
+        "pre-filter the alignment or pass data.sample_method=first | diversity-max | diversity-min")

@@ -1,0 +1,130 @@
+"""Per-kernel Python entry points over the C ABI (torch tensors in, raw device pointers out).
+
+PyTorch is plumbing here: it allocates HBM and owns the HIP stream; every FLOP runs in
+librnamsm_hip.so.  All functions require contiguous float32 tensors on a HIP device and raise
+otherwise -- there is no eager fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU_ERF, ACT_NONE, F32
+
+HEAD_DIM = 64
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.RnamsmError(f"{name}: expected a tensor on the HIP device (no CPU path exists)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _rowmajor(t: torch.Tensor, name: str) -> int:
+    """Leading dimension (in elements) of a 2-D view whose last dim is contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D tensor with contiguous rows, got strides {t.stride()}")
+    return t.stride(0)
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    D = x.shape[-1]
+    x2 = x.contiguous().view(-1, D)
+    y = torch.empty_like(x2) if out is None else out
+    _lib.check(_lib.load().rnamsm_layernorm(_dev(x2, "x"), _dev(gamma, "gamma"), _dev(beta, "beta"), _dev(y, "out"),
+                                            x2.shape[0], D, eps, _stream()))
+    return y.view(x.shape)
+
+
+def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+           residual: Optional[torch.Tensor] = None, scale: float = 1.0, scale_cols: int = 0,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act((a @ w.T + bias) * (col < scale_cols ? scale : 1)) + residual;  a [M,K], w [N,K]."""
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_gemm_bias_act_res(
+        _dev(a, "a"), _rowmajor(a, "a"), _dev(w.contiguous(), "w"), None if bias is None else _dev(bias, "bias"),
+        None if residual is None else _dev(residual, "residual"), 0 if residual is None else _rowmajor(residual, "residual"),
+        _dev(out, "out"), _rowmajor(out, "out"), M, N, K, act, scale, scale_cols, F32, _stream()))
+    return out
+
+
+def row_logits(q: torch.Tensor, k: torch.Tensor, R: int, C: int, H: int) -> Tuple[torch.Tensor, int]:
+    """q, k: [R*C, *] views with row stride ld; returns (partial [nsplit,H,C,C], nsplit)."""
+    lib = _lib.load()
+    nsplit = lib.rnamsm_row_logits_nsplit(R, C, H)
+    partial = torch.empty(nsplit, H, C, C, device=q.device, dtype=torch.float32)
+    ld = _rowmajor(q, "q")
+    assert _rowmajor(k, "k") == ld
+    _lib.check(lib.rnamsm_row_logits(_dev(q, "q"), _dev(k, "k"), ld, _dev(partial, "partial"), R, C, H, HEAD_DIM, F32,
+                                     _stream()))
+    return partial, nsplit
+
+
+def softmax_rows(partial: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    nsplit, H, C, _ = partial.shape
+    probs = torch.empty(H, C, C, device=partial.device, dtype=torch.float32) if out is None else out
+    _lib.check(_lib.load().rnamsm_softmax_rows(_dev(partial, "partial"), nsplit, _dev(probs, "probs"), H, C, _stream()))
+    return probs
+
+
+def row_apply(probs: torch.Tensor, v: torch.Tensor, R: int, C: int, H: int,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    ctx = torch.empty(R * C, H * HEAD_DIM, device=v.device, dtype=torch.float32) if out is None else out
+    _lib.check(_lib.load().rnamsm_row_apply(_dev(probs, "probs"), _dev(v, "v"), _rowmajor(v, "v"), _dev(ctx, "ctx"),
+                                            _rowmajor(ctx, "ctx"), R, C, H, HEAD_DIM, F32, _stream()))
+    return ctx
+
+
+def col_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, R: int, C: int, H: int,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    ctx = torch.empty(R * C, H * HEAD_DIM, device=v.device, dtype=torch.float32) if out is None else out
+    ld = _rowmajor(q, "q")
+    assert _rowmajor(k, "k") == ld and _rowmajor(v, "v") == ld
+    _lib.check(_lib.load().rnamsm_col_attn_fused(_dev(q, "q"), _dev(k, "k"), _dev(v, "v"), ld, _dev(ctx, "ctx"),
+                                                 _rowmajor(ctx, "ctx"), R, C, H, HEAD_DIM, F32, _stream()))
+    return ctx
+
+
+def embed_ln(tokens: torch.Tensor, embed_tokens: torch.Tensor, embed_positions: torch.Tensor, row_pos: torch.Tensor,
+             gamma: torch.Tensor, beta: torch.Tensor, pad_idx: int, eps: float = 1e-5) -> torch.Tensor:
+    """tokens int64 [R,C] -> x [R*C, D]; raises on token / position ids outside the tables."""
+    R, C = tokens.shape
+    D = embed_tokens.shape[1]
+    out = torch.empty(R * C, D, device=tokens.device, dtype=torch.float32)
+    err = torch.zeros(1, device=tokens.device, dtype=torch.int32)
+    _lib.check(_lib.load().rnamsm_embed_ln(
+        _dev(tokens.contiguous(), "tokens", torch.int64), _dev(embed_tokens, "embed_tokens"),
+        _dev(embed_positions, "embed_positions"), _dev(row_pos, "row_pos"), _dev(gamma, "gamma"), _dev(beta, "beta"),
+        _dev(out, "out"), R, C, D, embed_tokens.shape[0], embed_positions.shape[0], pad_idx, eps,
+        _dev(err, "err", torch.int32), _stream()))
+    if int(err.item()) != 0:
+        raise IndexError("embed_ln: token or position index out of range")
+    return out
+
+
+def pack_outputs(x_final: torch.Tensor, probs_all: torch.Tensor, C: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    NL, H = probs_all.shape[0], probs_all.shape[1]
+    D = x_final.shape[-1]
+    emb = torch.empty(C - 1, D, device=x_final.device, dtype=torch.float32)
+    atp = torch.empty(NL * H, C - 1, C - 1, device=x_final.device, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_pack_outputs(_dev(x_final, "x_final"), _dev(probs_all, "probs_all"), _dev(emb, "emb"),
+                                               _dev(atp, "atp"), C, D, NL, H, _stream()))
+    return emb, atp
+
+
+def row_scaling(R: int) -> float:
+    """RowSelfAttention.align_scaling (modules.py:713-715)."""
+    return (HEAD_DIM ** -0.5) / math.sqrt(R)

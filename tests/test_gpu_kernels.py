@@ -1,0 +1,231 @@
+"""GPU parity tests, per kernel, through the C ABI (rnamsm.ops -> librnamsm_hip.so).
+
+Checked against (a) the oracle on the same seeded inputs and (b) the committed golden fixtures produced by the
+reference.  Tolerances: the kernels are exact-fp32 (v_mfma_f32_32x32x2_f32 == an fmaf chain) and differ from the
+CPU only by summation order: rel-L2 <= 2e-5 per op, probabilities max-abs <= 2e-5; north_star's end-to-end bar is
+1e-4 (tests/test_gpu_forward.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, rel_l2
+from oracle import msm_oracle as O
+from rnamsm import synthetic
+
+pytestmark = pytest.mark.gpu
+
+TOL_REL = 2e-5
+TOL_PROB = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from rnamsm import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _rand(name, shape, scale=1.0):
+    return torch.from_numpy((scale * synthetic.normal(name, 11, shape)).astype(np.float32))
+
+
+@pytest.mark.parametrize("T,D", [(1, 128), (7, 768), (1000, 768), (4097, 128), (33, 1024)])
+def test_layernorm(dev, T, D):
+    from rnamsm import ops
+    x, g, b = _rand("ln.x", (T, D), 3.0) + 0.5, 1 + 0.1 * _rand("ln.g", (D,)), 0.1 * _rand("ln.b", (D,))
+    y = ops.layernorm(x.to(dev), g.to(dev), b.to(dev)).cpu()
+    want = O.layer_norm(x.double(), g.double(), b.double())
+    assert rel_l2(y, want) < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 32), (127, 128, 64), (128, 256, 768), (300, 768, 768), (1025, 2304, 768),
+                                   (513, 768, 3072), (4100, 3072, 768)])
+def test_gemm_plain(dev, M, N, K):
+    from rnamsm import ops
+    a, w, b = _rand("g.a", (M, K)), _rand("g.w", (N, K), 0.05), _rand("g.b", (N,), 0.1)
+    y = ops.linear(a.to(dev), w.to(dev), b.to(dev)).cpu()
+    want = a.double() @ w.double().t() + b.double()
+    assert rel_l2(y, want) < 3e-6
+    assert np.abs(y.numpy() - want.numpy()).max() < 1e-4 * float(want.abs().max())
+
+
+def test_gemm_is_exact_on_integers(dev):
+    """Exact-integer data: every product and partial sum is representable, so the MFMA path must be bit-exact, and an
+    asymmetric W catches a transposed or permuted tile (cdna_hip_programming.md §3)."""
+    from rnamsm import ops
+    M, N, K = 200, 256, 96
+    a = torch.from_numpy(((np.arange(M * K).reshape(M, K) * 7 + 3) % 13 - 6).astype(np.float32))
+    w = torch.from_numpy(((np.arange(N * K).reshape(N, K) * 5 + 1) % 11 - 5).astype(np.float32))
+    y = ops.linear(a.to(dev), w.to(dev)).cpu()
+    assert torch.equal(y, a @ w.t())
+
+
+def test_gemm_epilogues(dev):
+    from rnamsm import ops
+    from rnamsm._lib import ACT_GELU_ERF
+    M, N, K = 333, 384, 128
+    a, w, b, r = _rand("e.a", (M, K)), _rand("e.w", (N, K), 0.1), _rand("e.b", (N,), 0.2), _rand("e.r", (M, N))
+    ad, wd, bd, rd = (t.double() for t in (a, w, b, r))
+    base = ad @ wd.t() + bd
+    y = ops.linear(a.to(dev), w.to(dev), b.to(dev), scale=0.125, scale_cols=128).cpu()
+    want = base.clone(); want[:, :128] *= 0.125
+    assert rel_l2(y, want) < 3e-6
+    y = ops.linear(a.to(dev), w.to(dev), b.to(dev), act=ACT_GELU_ERF).cpu()
+    assert rel_l2(y, O.gelu_erf(base)) < 3e-6
+    y = ops.linear(a.to(dev), w.to(dev), b.to(dev), residual=r.to(dev)).cpu()
+    assert rel_l2(y, base + rd) < 3e-6
+    # in-place residual (x = x + f(x)) as the forward driver uses it
+    xr = r.to(dev).clone()
+    ops.linear(a.to(dev), w.to(dev), b.to(dev), residual=xr, out=xr)
+    assert rel_l2(xr.cpu(), base + rd) < 3e-6
+    # strided A / out views (the q|k|v activation is addressed in place)
+    big = torch.zeros(M, 3 * N, device=dev)
+    ops.linear(a.to(dev), w.to(dev), b.to(dev), out=big[:, N:2 * N])
+    assert rel_l2(big[:, N:2 * N].cpu(), base) < 3e-6 and float(big[:, :N].abs().max()) == 0.0
+
+
+def test_gemm_rejects_bad_shapes(dev):
+    from rnamsm import ops, _lib
+    with pytest.raises(_lib.RnamsmError):
+        ops.linear(torch.zeros(4, 32, device=dev), torch.zeros(100, 32, device=dev))
+    with pytest.raises(_lib.RnamsmError):
+        ops.linear(torch.zeros(4, 32), torch.zeros(128, 32))        # CPU tensors: no fallback
+
+
+ATT_SHAPES = [(1, 5, 2), (7, 33, 2), (34, 66, 2), (6, 19, 12), (3, 130, 2), (65, 40, 2), (257, 9, 2), (300, 20, 1)]
+
+
+def _qkv(R, C, H, tag):
+    D = 64 * H
+    t = _rand(f"qkv.{tag}", (R * C, 3 * D))
+    return t, D
+
+
+@pytest.mark.parametrize("R,C,H", ATT_SHAPES)
+def test_row_attention_kernels(dev, R, C, H):
+    from rnamsm import ops
+    qkv, D = _qkv(R, C, H, f"row{R}_{C}")
+    g = qkv.to(dev)
+    scaling = ops.row_scaling(R)
+    q = (qkv[:, :D].double() * scaling).view(R, C, H, 64)
+    k = qkv[:, D:2 * D].double().view(R, C, H, 64)
+    v = qkv[:, 2 * D:].double().view(R, C, H, 64)
+    gq = (g[:, :D] * scaling).contiguous()
+    partial, nsplit = ops.row_logits(gq, g[:, D:2 * D].contiguous(), R, C, H)
+    logits = torch.einsum("rihd,rjhd->hij", q, k)
+    assert rel_l2(partial.sum(0).cpu(), logits) < 5e-6
+    probs = ops.softmax_rows(partial)
+    want_p = torch.softmax(logits, -1)
+    assert np.abs(probs.cpu().numpy() - want_p.numpy()).max() < TOL_PROB
+    assert np.abs(probs.sum(-1).cpu().numpy() - 1).max() < 1e-5
+    # strided q/k/v views into the fused activation
+    partial2, _ = ops.row_logits(g[:, :D], g[:, D:2 * D], R, C, H)
+    assert rel_l2(partial2.sum(0).cpu() * scaling, logits) < 5e-6
+    ctx = ops.row_apply(probs, g[:, 2 * D:], R, C, H).cpu()
+    want = torch.einsum("hij,rjhd->rihd", probs.cpu().double(), v).reshape(R * C, D)
+    assert rel_l2(ctx, want) < 5e-6
+
+
+@pytest.mark.parametrize("R,C,H", ATT_SHAPES)
+def test_col_attention_kernel(dev, R, C, H):
+    from rnamsm import ops
+    qkv, D = _qkv(R, C, H, f"col{R}_{C}")
+    g = qkv.to(dev)
+    q = (qkv[:, :D].double() * 0.125).view(R, C, H, 64)
+    k = qkv[:, D:2 * D].double().view(R, C, H, 64)
+    v = qkv[:, 2 * D:].double().view(R, C, H, 64)
+    gq = g.clone(); gq[:, :D] *= 0.125
+    ctx = ops.col_attn(gq[:, :D], gq[:, D:2 * D], gq[:, 2 * D:], R, C, H).cpu()
+    p = torch.softmax(torch.einsum("ichd,jchd->hcij", q, k), -1)
+    want = torch.einsum("hcij,jchd->ichd", p, v).reshape(R * C, D)
+    assert rel_l2(ctx, want) < 5e-6
+    assert np.abs(ctx.numpy() - want.numpy()).max() < 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_col_attention_online_softmax_rescale_is_exercised(dev):
+    """Forces the running-max rescale branch: one late key dominates every query (spike placed in the last
+    64-key chunk), and a second case puts the dominant key first so later tiles never rescale."""
+    from rnamsm import ops
+    R, C, H = 200, 3, 1
+    for spike_row in (190, 0, 65):
+        qkv = _rand(f"spike{spike_row}", (R * C, 192))
+        qkv[:, :64] = qkv[:, :64].abs() * 0.2
+        k = qkv[:, 64:128].view(R, C, 64)
+        k[spike_row] = 6.0                                   # q.k ~ +60 for that key: exp underflows elsewhere
+        g = qkv.to(dev)
+        ctx = ops.col_attn(g[:, :64], g[:, 64:128], g[:, 128:], R, C, H).cpu()
+        q = qkv[:, :64].double().view(R, C, 1, 64); kk = qkv[:, 64:128].double().view(R, C, 1, 64)
+        v = qkv[:, 128:].double().view(R, C, 1, 64)
+        p = torch.softmax(torch.einsum("ichd,jchd->hcij", q, kk), -1)
+        want = torch.einsum("hcij,jchd->ichd", p, v).reshape(R * C, 64)
+        assert rel_l2(ctx, want) < 5e-6
+
+
+@pytest.mark.parametrize("R,C", [(3, 9), (16, 33), (5, 200)])
+def test_embed_ln_matches_oracle_with_and_without_pad(dev, R, C):
+    from rnamsm import ops
+    state = synthetic.make_state_dict(seed=3, embed_dim=128, num_layers=1, num_heads=2)
+    params = O.to_torch_params(state)
+    toks = torch.from_numpy(synthetic.make_tokens(R, C, 5))
+    args = [params[k].to(dev) for k in ("embed_tokens.weight", "embed_positions.weight")]
+    rowpos = params["msa_position_embedding"].view(-1).to(dev)
+    lnw, lnb = params["emb_layer_norm_before.weight"].to(dev), params["emb_layer_norm_before.bias"].to(dev)
+    x = ops.embed_ln(toks.to(dev), args[0], args[1], rowpos, lnw, lnb, pad_idx=1).cpu()
+    assert rel_l2(x, O.embed(toks, params).reshape(R * C, -1)) < 2e-6
+    # positions must skip <pad> exactly like cumsum(mask)*mask + pad (modules.py:288-290), integer-exact
+    toks[1, 2] = 1; toks[R - 1, C - 1] = 1; toks[2, 0] = 1
+    x = ops.embed_ln(toks.to(dev), args[0], args[1], rowpos, lnw, lnb, pad_idx=1).cpu()
+    assert rel_l2(x, O.embed(toks, params).reshape(R * C, -1)) < 2e-6
+    bad = toks.clone(); bad[0, 1] = 12
+    with pytest.raises(IndexError):
+        ops.embed_ln(bad.to(dev), args[0], args[1], rowpos, lnw, lnb, pad_idx=1)
+
+
+def test_pack_outputs_is_a_pure_copy(dev):
+    from rnamsm import ops
+    C, D, NL, H, R = 21, 128, 3, 2, 4
+    x = _rand("pk.x", (R * C, D)); p = _rand("pk.p", (NL, H, C, C))
+    emb, atp = ops.pack_outputs(x.to(dev), p.to(dev), C)
+    assert torch.equal(emb.cpu(), x.view(R, C, D)[0, 1:])
+    assert torch.equal(atp.cpu(), p[..., 1:, 1:].reshape(NL * H, C - 1, C - 1))
+
+
+OP_CASES = ["d128_r7_c33", "d128_r7_c33_chunk", "d128_r1_c5", "d128_r34_c66", "d768_r6_c19"]
+
+
+@pytest.mark.parametrize("name", OP_CASES)
+def test_modules_match_reference_fixtures(dev, name):
+    """The reference-interface modules (rnamsm.modules) against outputs of the reference's own modules."""
+    from rnamsm import modules as M
+    g = golden(f"op_{name}.npz")
+    D, H, R, C, max_tokens = (int(v) for v in g["meta"])
+    mt = 2 ** 30 if max_tokens < 0 else max_tokens
+    state = synthetic.make_state_dict(seed=7, embed_dim=D, num_layers=1, num_heads=H)
+    x = torch.from_numpy(synthetic.normal(f"x:{name}", 7, (R, C, 1, D)).astype(np.float32)).to(dev)
+
+    def load(mod, prefix):
+        sd = {k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in state.items() if k.startswith(prefix + ".")}
+        mod.load_state_dict(sd, strict=True)
+        return mod.eval().to(dev)
+
+    row = load(M.RowSelfAttention(D, H, max_tokens_per_msa=mt), "layers.0.row_self_attention.layer")
+    y, p = row(x)
+    assert y.shape == (R, C, 1, D) and p.shape == (H, 1, C, C)
+    assert rel_l2(y.cpu()[:, :, 0], g["row_out"]) < TOL_REL
+    assert np.abs(p.cpu().numpy()[:, 0] - g["row_probs"]).max() < TOL_PROB
+    col = load(M.ColumnSelfAttention(D, H, max_tokens_per_msa=mt), "layers.0.column_self_attention.layer")
+    y, _ = col(x)
+    assert rel_l2(y.cpu()[:, :, 0], g["col_out"]) < TOL_REL
+    if "ffn_out" in g:
+        ff = load(M.FeedForwardNetwork(D, 4 * D, max_tokens_per_msa=mt), "layers.0.feed_forward_layer.layer")
+        assert rel_l2(ff(x).cpu()[:, :, 0], g["ffn_out"]) < TOL_REL
+        blk = load(M.NormalizedResidualBlock(M.FeedForwardNetwork(D, 4 * D), D), "layers.0.feed_forward_layer")
+        assert rel_l2(blk(x).cpu()[:, :, 0], g["ffn_block_out"]) < TOL_REL
+    layer = load(M.AxialTransformerLayer(D, 4 * D, H, max_tokens_per_msa=mt), "layers.0")
+    y, cp, rp = layer(x, need_head_weights=True)
+    assert rel_l2(y.cpu()[:, :, 0], g["layer_out"]) < TOL_REL
+    assert np.abs(rp.cpu().numpy()[:, 0] - g["layer_row_probs"]).max() < TOL_PROB
+    with pytest.raises(NotImplementedError):
+        row(x, self_attn_mask=torch.zeros(1))
