@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: MSA-residues/s for the full 10-layer forward (emb + attention maps).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path (K0..K10 through rnamsm_forward) over one synthetic MSA per GPU, inputs and
+weights already resident in HBM, plus (N > 1) the RCCL gather of that step's emb/atp arrays to rank 0, overlapped
+with the next step.  Workload = BASELINE.json configs[2]: M=256 sequences x L=512 columns (column 0 is <cls>),
+D=768, 12 heads, 10 layers, fp32 (exact-fp32 MFMA), random-init weights of that architecture (rnamsm.synthetic).
+Rank 0 prints ONE JSON line; `roofline` is the Linear GEMM kernel (89 % of the flops) measured live with HIP events
+on the launch stream during the timed steps; `cpu_baseline` is the oracle (PyTorch-CPU restatement of the
+reference) timed on this host's cores on a bounded sample (one of the ten layers of the same M x L MSA).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "rna-msm_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+
+
+def flops_per_msa(M, L, D=768, layers=10):
+    """per token per layer 32 D^2 (8 proj + 2 FFN GEMMs) + 4 D (M + L) (row + column QK^T / PV)."""
+    return layers * (32 * D * D + 4 * D * (M + L)) * M * L
+
+
+def cpu_baseline(M, L, state, budget_note):
+    """Oracle (port of the reference) on the host cores: ONE of the ten layers of the same M x L MSA (embedding and
+    final LayerNorm included), extrapolated x10 -- the layers are identical in cost."""
+    from oracle import msm_oracle as O
+    from rnamsm import synthetic
+    torch.set_num_threads(os.cpu_count() or 1)
+    params = O.to_torch_params(state)
+    toks = torch.from_numpy(synthetic.make_tokens(M, L, 0))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.forward(toks, params, layers_to_run=1)
+        dt = time.perf_counter() - t0
+    return {"value": M * L / (10.0 * dt), "unit": "MSA-residues/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/msm_oracle.py forward, 1 of 10 layers of one M={M} L={L} MSA in {dt:.1f} s, x10 "
+                      f"extrapolated; torch {torch.__version__} CPU fp32, {budget_note}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--num-seqs", type=int, default=256, help="M (BASELINE configs[2])")
+    ap.add_argument("--seq-len", type=int, default=512, help="L, columns including <cls>")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL output gather (N > 1)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from rnamsm import _lib, synthetic
+    from rnamsm.model import MSATransformer
+    lib = _lib.load()
+
+    M, L = args.num_seqs, args.seq_len
+    state = synthetic.make_state_dict(seed=0)
+    model = MSATransformer(num_layers=10)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    model = model.eval().to(dev)
+    # one synthetic MSA per step and rank, already resident in HBM (seed 1234 + global index)
+    n_total = args.warmup + args.steps
+    toks = [torch.from_numpy(synthetic.make_tokens(M, L, rank + world * i)).to(dev) for i in range(n_total)]
+
+    gather = world > 1 and not args.no_gather
+    if gather:
+        import torch.distributed as dist
+        recv = None
+        if rank == 0:
+            recv = [[torch.empty(L - 1, 768, device=dev), torch.empty(120, L - 1, L - 1, device=dev)] for _ in range(world)]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    pending = []
+
+    def step(i):
+        out = model.forward_one(toks[i])
+        if gather:
+            # emb/atp of this step go to rank 0 over RCCL while the next step computes
+            for w in pending:
+                w.wait()
+            pending.clear()
+            for j, t in enumerate((out["emb"], out["atp"])):
+                pending.append(dist.gather(t, [r[j] for r in recv] if rank == 0 else None, dst=0, async_op=True))
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    for w in pending:
+        w.wait()
+    pending.clear()
+    sync_all()
+    lib.rnamsm_timing_reset()
+    lib.rnamsm_timing_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_total):
+        step(i)
+    for w in pending:
+        w.wait()
+    pending.clear()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    lib.rnamsm_timing_enable(0)
+    timings = _lib.kernel_timings()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        residues = world * args.steps * M * L
+        g = timings["gemm_f32"]
+        gemm_tflops = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        attn_ms = sum(timings[k]["ms"] for k in ("row_logits", "row_apply", "col_attn"))
+        attn_fl = sum(timings[k]["flops"] for k in ("row_logits", "row_apply", "col_attn"))
+        kern_ms = sum(v["ms"] for v in timings.values())
+        result = {
+            "metric": "MSA-residues/sec forward (emb+attn-map), M=256 L=512",
+            "value": residues / elapsed,
+            "unit": "MSA-residues/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: synthetic MSA M={M} x L={L} (col 0 = <cls>), D=768 H=12 "
+                                   f"10 layers, one MSA per GPU per step, emb+atp outputs"
+                                   + (", RCCL gather to rank 0" if gather else ""),
+                       "num_seqs": M, "seq_len": L, "msas_per_step": world, "sharding": f"independent MSAs x{world}"},
+            "model_tflops": flops_per_msa(M, L) * world * args.steps / elapsed / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (nn.Linear, K2)",
+                         "achieved": gemm_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": gemm_tflops / FP32_MFMA_PEAK_TFLOPS,
+                         "avg_launch_ms": g["ms"] / max(1, g["launches"]), "launches": g["launches"],
+                         "flops_per_launch": g["flops"] / max(1, g["launches"]),
+                         "traffic": None},
+            "attention_mfma": {"kernels": "row_logits+row_apply+col_attn", "achieved": attn_fl / (attn_ms * 1e-3) / 1e12 if attn_ms else 0.0,
+                               "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": (attn_fl / (attn_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if attn_ms else 0.0},
+            "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in timings.items()},
+            "kernel_time_share_of_step": kern_ms / args.steps / (1e3 * elapsed / args.steps),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(M, L, state, f"{os.cpu_count()} logical CPUs on this host")
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

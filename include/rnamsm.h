@@ -140,12 +140,23 @@ enum { /* per layer, offset RNAMSM_W_GLOBAL_COUNT + layer * RNAMSM_W_LAYER_COUNT
 size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int C);
 /* tokens int64 [R,C]; weights: host array of (RNAMSM_W_GLOBAL_COUNT + L*RNAMSM_W_LAYER_COUNT)
  * device pointers; workspace >= rnamsm_forward_workspace_bytes; row_attn [L,H,C,C] (full, with
- * <cls>), repr [R*C, D] (after emb_layer_norm_after), emb [C-1, D], atp [L*H, C-1, C-1];
- * row_attn/repr may be NULL only if the caller provides them inside... no: all four are required. */
+ * <cls>), repr [R*C, D] (after emb_layer_norm_after), emb [C-1, D], atp [L*H, C-1, C-1]; all four are
+ * required outputs. */
 int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
                    int R, int C, void* workspace, size_t workspace_bytes,
                    float* row_attn, float* repr, float* emb, float* atp,
                    int* err_flag, int dtype, void* stream);
+
+/* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's
+ * roofline block; adds two event records per launch while enabled, nothing when disabled).
+ *   rnamsm_timing_enable(1) ... enqueue work ... (caller synchronises the stream) ... rnamsm_timing_collect()
+ * collect folds every completed (start, stop) pair into per-category totals and returns the number of
+ * categories; rnamsm_timing_get reads one: name, launches, total milliseconds, total algorithmic flops and bytes
+ * (the figures DESIGN.md derives per kernel).  rnamsm_timing_reset clears the totals. */
+int rnamsm_timing_enable(int on);
+int rnamsm_timing_collect(void);
+int rnamsm_timing_get(int category, const char** name, long long* launches, double* ms, double* flops, double* bytes);
+void rnamsm_timing_reset(void);
 
 #ifdef __cplusplus
 }

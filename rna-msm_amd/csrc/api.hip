@@ -1,6 +1,8 @@
 // Error plumbing, version and device probes of the C ABI.
 #include "common.h"
 #include <string.h>
+#include <mutex>
+#include <vector>
 
 namespace rnamsm {
 static thread_local char g_err[512] = "";
@@ -18,7 +20,90 @@ int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+
+// ---------------------------------------------------------------------------------- kernel timing
+namespace {
+struct Record {
+    int category;
+    double flops, bytes;
+    hipEvent_t start, stop;
+};
+struct Totals {
+    long long launches = 0;
+    double ms = 0, flops = 0, bytes = 0;
+};
+std::mutex g_tmu;
+bool g_ton = false;
+std::vector<Record> g_pending;
+std::vector<hipEvent_t> g_free;
+Totals g_tot[TC_COUNT];
+const char* const g_tnames[TC_COUNT] = {"gemm_f32", "row_logits", "softmax_rows", "row_apply",
+                                        "col_attn", "layernorm", "embed_ln", "pack_outputs"};
+hipEvent_t take_event() {
+    if (!g_free.empty()) {
+        hipEvent_t e = g_free.back();
+        g_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+bool timing_enabled() { return g_ton; }
+void timing_begin(int category, double flops, double bytes, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    Record r{category, flops, bytes, take_event(), take_event()};
+    (void)hipEventRecord(r.start, stream);
+    g_pending.push_back(r);
+}
+void timing_end(hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_tmu);
+    if (!g_pending.empty()) (void)hipEventRecord(g_pending.back().stop, stream);
+}
 }  // namespace rnamsm
+
+extern "C" int rnamsm_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(rnamsm::g_tmu);
+    rnamsm::g_ton = on != 0;
+    return RNAMSM_OK;
+}
+extern "C" int rnamsm_timing_collect(void) {
+    using namespace rnamsm;
+    std::lock_guard<std::mutex> lk(g_tmu);
+    for (Record& r : g_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.stop) == hipSuccess && hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+            Totals& t = g_tot[r.category];
+            t.launches += 1;
+            t.ms += ms;
+            t.flops += r.flops;
+            t.bytes += r.bytes;
+        }
+        g_free.push_back(r.start);
+        g_free.push_back(r.stop);
+    }
+    g_pending.clear();
+    return TC_COUNT;
+}
+extern "C" int rnamsm_timing_get(int category, const char** name, long long* launches, double* ms, double* flops,
+                                 double* bytes) {
+    using namespace rnamsm;
+    if (category < 0 || category >= TC_COUNT) return fail(RNAMSM_ERR_INVALID, "timing_get: bad category %d", category);
+    std::lock_guard<std::mutex> lk(g_tmu);
+    if (name) *name = g_tnames[category];
+    if (launches) *launches = g_tot[category].launches;
+    if (ms) *ms = g_tot[category].ms;
+    if (flops) *flops = g_tot[category].flops;
+    if (bytes) *bytes = g_tot[category].bytes;
+    return RNAMSM_OK;
+}
+extern "C" void rnamsm_timing_reset(void) {
+    using namespace rnamsm;
+    std::lock_guard<std::mutex> lk(g_tmu);
+    for (Totals& t : g_tot) t = Totals();
+}
 
 extern "C" int rnamsm_version(void) { return RNAMSM_VERSION; }
 extern "C" const char* rnamsm_last_error(void) { return rnamsm::g_err; }

@@ -185,6 +185,8 @@ extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float
     }
     const unsigned iblocks = (R + CA_ROWS - 1) / CA_ROWS;
     const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
+    KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)R * R * CA_HD, 4.0 * 4.0 * R * C * H * CA_HD,
+                      static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(col_attn_kernel, dim3(grid), dim3(CA_THREADS), CA_LDS_BYTES, static_cast<hipStream_t>(stream),
                        q, k, v, ld, ctx, ldc, R, C, H);
     RNAMSM_CHECK_LAUNCH("col_attn");

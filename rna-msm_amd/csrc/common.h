@@ -25,6 +25,24 @@ int fail(int code, const char* fmt, ...);
             return ::rnamsm::fail(RNAMSM_ERR_HIP, "%s launch: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
+// ---- per-kernel timing (api.hip); categories index rnamsm_timing_get -----------------------------
+enum TimingCategory {
+    TC_GEMM = 0, TC_ROW_LOGITS, TC_SOFTMAX, TC_ROW_APPLY, TC_COL_ATTN, TC_LAYERNORM, TC_EMBED, TC_PACK, TC_COUNT
+};
+bool timing_enabled();
+void timing_begin(int category, double flops, double bytes, hipStream_t stream);
+void timing_end(hipStream_t stream);
+struct KernelTimer {   // brackets one launch with two hipEventRecord calls when timing is on
+    hipStream_t s;
+    bool on;
+    KernelTimer(int category, double flops, double bytes, hipStream_t stream) : s(stream), on(timing_enabled()) {
+        if (on) timing_begin(category, flops, bytes, s);
+    }
+    ~KernelTimer() {
+        if (on) timing_end(s);
+    }
+};
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- device helpers ----------------------------------------------------------------------------

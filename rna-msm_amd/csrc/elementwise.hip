@@ -134,6 +134,7 @@ extern "C" int rnamsm_layernorm(const float* x, const float* gamma, const float*
     RNAMSM_CHECK_ARG(x && gamma && beta && y, "layernorm: null pointer");
     RNAMSM_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_VEC, "layernorm: need D %% 4 == 0, D <= 1024 (D=%d)", D);
     RNAMSM_CHECK_ARG(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), "layernorm: 16-byte alignment");
+    KernelTimer timer(TC_LAYERNORM, 0.0, 8.0 * T * D, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(layernorm_kernel, dim3(rows_grid(T)), dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma,
                        beta, y, T, D, eps);
     RNAMSM_CHECK_LAUNCH("layernorm");
@@ -151,6 +152,7 @@ extern "C" int rnamsm_embed_ln(const int64_t* tokens, const float* embed_tokens,
                     "Using model with MSA position embedding trained on maximum MSA depth of 1024, but received %d alignments.", R);
     RNAMSM_CHECK_ARG(aligned16(embed_tokens) && aligned16(embed_positions) && aligned16(out) && aligned16(gamma) && aligned16(beta),
                      "embed_ln: 16-byte alignment");
+    KernelTimer timer(TC_EMBED, 0.0, 12.0 * R * C * D + 8.0 * R * C, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid((int64_t)R * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        tokens, embed_tokens, embed_positions, row_pos, gamma, beta, out, R, C, D, vocab, num_positions,
                        pad_idx, eps, err_flag);
@@ -165,6 +167,7 @@ extern "C" int rnamsm_pack_outputs(const float* x_final, const float* probs_all,
     const int64_t L = C - 1;
     const int64_t n_emb = L * D, n_atp = (int64_t)num_layers * H * L * L;
     const int64_t blocks = (n_emb + n_atp + 255) / 256;
+    KernelTimer timer(TC_PACK, 0.0, 8.0 * (n_emb + n_atp), static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(pack_outputs_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x_final, probs_all, emb, atp, C, D, n_emb, n_atp);
     RNAMSM_CHECK_LAUNCH("pack_outputs");

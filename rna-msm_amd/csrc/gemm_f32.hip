@@ -107,6 +107,8 @@ static int launch_gemm(const float* A, int64_t lda, const float* W, const float*
         configured = true;
     }
     const unsigned grid = xcd_panel_grid((M + BM - 1) / BM, N / BN);
+    // algorithmic work: 2MNK flops; bytes = A + W + C once (+ residual read)
+    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, A, lda, W, bias, residual, ldr,
                        Cout, ldc, M, N, K, scale, scale_cols);
     RNAMSM_CHECK_LAUNCH("gemm_f32");

@@ -310,6 +310,8 @@ extern "C" int rnamsm_row_logits(const float* q, const float* k, int64_t ld, flo
     const RowSplit sp = choose_row_split(R, C, H);
     const unsigned tiles_c = (C + BM - 1) / BM;
     const unsigned grid = xcd_panel_grid((unsigned)(H * sp.nsplit), tiles_c * tiles_c);
+    KernelTimer timer(TC_ROW_LOGITS, 2.0 * H * C * C * R * HEAD_DIM,
+                      4.0 * (2.0 * R * C * H * HEAD_DIM + (double)sp.nsplit * H * C * C), static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(row_logits_kernel, dim3(grid), dim3(GEMM_THREADS), ROWLOGITS_LDS_BYTES,
                        static_cast<hipStream_t>(stream), q, k, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split);
     RNAMSM_CHECK_LAUNCH("row_logits");
@@ -321,6 +323,7 @@ extern "C" int rnamsm_softmax_rows(const float* partial, int nsplit, float* prob
     RNAMSM_CHECK_ARG(nsplit >= 1 && H > 0 && C > 0 && C <= 64 * SOFTMAX_MAX_PER_LANE,
                      "softmax_rows: bad shape nsplit=%d H=%d C=%d (C <= %d)", nsplit, H, C, 64 * SOFTMAX_MAX_PER_LANE);
     const int64_t rows = (int64_t)H * C;
+    KernelTimer timer(TC_SOFTMAX, 0.0, 4.0 * (double)(nsplit + 1) * H * C * C, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), partial, nsplit, probs, rows, C);
     RNAMSM_CHECK_LAUNCH("softmax_rows");
@@ -343,6 +346,8 @@ extern "C" int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, 
     }
     const unsigned tiles_i = (C + BM - 1) / BM, tiles_n = (R + 1) / 2;
     const unsigned grid = xcd_panel_grid((unsigned)H * tiles_n, tiles_i);
+    KernelTimer timer(TC_ROW_APPLY, 2.0 * H * C * C * R * HEAD_DIM,
+                      4.0 * (2.0 * R * C * H * HEAD_DIM + (double)H * C * C), static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(row_apply_kernel, dim3(grid), dim3(GEMM_THREADS), ROWAPPLY_LDS_BYTES,
                        static_cast<hipStream_t>(stream), probs, v, ld, ctx, ldc, R, C, H);
     RNAMSM_CHECK_LAUNCH("row_apply");

@@ -49,6 +49,11 @@ _SIGNATURES = {
     "rnamsm_forward_workspace_bytes": (c_size_t, [POINTER(ModelDims), c_int, c_int]),
     "rnamsm_forward": (c_int, [POINTER(ModelDims), POINTER(c_void_p), c_void_p, c_int, c_int, c_void_p, c_size_t,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rnamsm_timing_enable": (c_int, [c_int]),
+    "rnamsm_timing_collect": (c_int, []),
+    "rnamsm_timing_get": (c_int, [c_int, POINTER(c_char_p), POINTER(ctypes.c_longlong), POINTER(ctypes.c_double),
+                                  POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
+    "rnamsm_timing_reset": (None, []),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -81,3 +86,17 @@ def check(rc: int) -> None:
         if rc == -2:
             raise NotImplementedError(msg)
         raise RnamsmError(f"librnamsm_hip error {rc}: {msg}")
+
+
+def kernel_timings() -> dict:
+    """Fold completed HIP-event pairs and return {kernel: {launches, ms, flops, bytes}} (rnamsm_timing_*)."""
+    lib = load()
+    n = lib.rnamsm_timing_collect()
+    out = {}
+    for c in range(n):
+        name, cnt = c_char_p(), ctypes.c_longlong()
+        ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        check(lib.rnamsm_timing_get(c, ctypes.byref(name), ctypes.byref(cnt), ctypes.byref(ms), ctypes.byref(fl),
+                                    ctypes.byref(by)))
+        out[name.value.decode()] = {"launches": cnt.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+    return out
