@@ -1,0 +1,118 @@
+"""extract_feat: the reference CLI's per-RNA loop (RNA_MSM_Inference.py:90-168) on the HIP path.
+
+For every id in `data.MSA_list` (sorted), reads `<root>/<MSA_path>/<id>.a2m_msa2`, runs the 10-layer forward and
+writes `<id>_emb.npy` float32 (L, 768) and `<id>_atp.npy` float32 (120, L, L) -- the NPY v1 C-order files the
+downstream SS / RSA predictors consume.  With torch.distributed initialised (one process per GPU),
+ids are sharded round-robin over ranks and either written by the rank that computed them (default) or gathered
+to rank 0 over RCCL first (`gather_to_rank0=True`).
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import sharding
+from .alphabet import RNAAlphabet
+from .config import Config
+from .model import MSATransformer
+from .msa import load_msa_tokens
+
+
+def load_checkpoint(model: MSATransformer, path: str, device) -> None:
+    """torch.load(path)['state_dict'] with strict key matching (RNA_MSM_Inference.py:133-135)."""
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    state = blob["state_dict"] if isinstance(blob, dict) and "state_dict" in blob else blob
+    model.load_state_dict(state, strict=True)
+
+
+def find_msa_files(msa_dir: Path, ids: List[str]) -> Dict[str, Path]:
+    """`*.a2m_msa2` files whose stem (up to the first '.') is a requested id (dataset.py:46-64)."""
+    if not msa_dir.exists():
+        raise FileNotFoundError(msa_dir)
+    if not msa_dir.is_dir():
+        raise NotADirectoryError(msa_dir)
+    wanted = set(ids)
+    if not wanted:
+        raise ValueError("Passed an empty split file set")
+    found = {f.stem.split(".")[0]: f for f in sorted(msa_dir.glob("*.a2m_msa2")) if f.stem.split(".")[0] in wanted}
+    if len(found) != len(wanted):
+        raise FileNotFoundError(f"{len(wanted) - len(found)} specified split files not found in directory")
+    return found
+
+
+def crop_tokens(tokens: np.ndarray, max_seqlen: int, rng: np.random.RandomState) -> np.ndarray:
+    """RandomCropDataset.__getitem__ (dataset.py:142-158): when the alignment (incl. <cls>) is wider than
+    max_seqlen keep <cls> plus a random window of max_seqlen - 1 columns."""
+    seqlen = tokens.shape[-1]
+    if seqlen <= max_seqlen:
+        return tokens
+    start = rng.randint(1, seqlen - max_seqlen) if seqlen - max_seqlen > 1 else 1
+    return np.concatenate([tokens[..., :1], tokens[..., start:start + max_seqlen - 1]], -1)
+
+
+def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_rank0: bool = False) -> List[str]:
+    device = torch.device(cfg.data.device)
+    if device.type != "cuda":
+        raise RuntimeError("this build runs on the MI355X HIP path only (data.device=cuda); there is no CPU path")
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if device.index is None and world > 1:
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", rank)))
+    alphabet = RNAAlphabet.from_architecture(cfg.data.architecture)
+    if rank == 0:
+        print(f"Maximum Number of MSA Seqs:{cfg.data.max_seqs_per_msa}")
+        print(f"Inference on: {device}")
+
+    root = Path(cfg.data.root_path)
+    with open(root / cfg.data.MSA_list) as f:
+        ids = sorted(f.read().splitlines())
+    ids = [i for i in ids if i]
+    files = find_msa_files(root / cfg.data.MSA_path, ids)
+
+    if model is None:
+        model = MSATransformer(alphabet, embed_dim=cfg.model.embed_dim, num_attention_heads=cfg.model.num_attention_heads,
+                               num_layers=cfg.model.num_layers, embed_positions_msa=cfg.model.embed_positions_msa,
+                               dropout=cfg.model.dropout, attention_dropout=cfg.model.attention_dropout,
+                               activation_dropout=cfg.model.activation_dropout, max_tokens_per_msa=cfg.data.max_tokens,
+                               max_seqlen=cfg.data.max_seqlen)
+        load_checkpoint(model, cfg.data.model_path, device)
+    model = model.eval().to(device)
+
+    save_dir = root / cfg.data.MSA_path
+    save_dir.mkdir(parents=True, exist_ok=True)
+    rng = np.random.RandomState(42)
+    mine = sharding.shard_indices(len(ids), rank, world)
+    local = {}
+    written: List[str] = []
+
+    def write(rna_id: str, emb: np.ndarray, atp: np.ndarray) -> None:
+        np.save(save_dir / f"{rna_id}_atp.npy", atp)
+        np.save(save_dir / f"{rna_id}_emb.npy", emb)
+        written.append(rna_id)
+
+    with torch.no_grad():
+        for idx in mine:
+            rna_id = ids[idx]
+            tokens = load_msa_tokens(files[rna_id], alphabet, cfg.data.max_seqs_per_msa, cfg.data.sample_method)
+            tokens = crop_tokens(tokens, cfg.data.max_seqlen, rng)
+            out = model.forward_one(torch.from_numpy(tokens).to(device))
+            if int(out["err"].item()) != 0:
+                raise IndexError(f"{rna_id}: token or position index out of range")
+            if gather_to_rank0 and world > 1:
+                local[idx] = (out["emb"], out["atp"])
+            else:
+                write(rna_id, out["emb"].cpu().numpy(), out["atp"].cpu().numpy())
+    if gather_to_rank0 and world > 1:
+        everything = sharding.gather_arrays(local, len(ids), dst=0)
+        if rank == 0:
+            for idx in sorted(everything):
+                emb, atp = everything[idx]
+                write(ids[idx], emb.cpu().numpy(), atp.cpu().numpy())
+    if rank == 0:
+        print(f"Done! Generated files are saved at {save_dir}")
+    return written

@@ -67,7 +67,10 @@ def gen_tokens():
     msa = MSA.from_fasta(ex_path)
     toks = vocab.encode(msa)
     assert toks.dtype == np.int64
-    save("tokens_2DRB_1_first64.npz", tokens=toks)
+    # greedy max/min-Hamming row sub-sampling (utils/align.py:128-148) of the same excerpt, 64 -> 16 rows
+    sel_max = vocab.encode(msa.select_diverse(16, method="diversity-max"))
+    sel_min = vocab.encode(MSA.from_fasta(ex_path).select_diverse(16, method="diversity-min"))
+    save("tokens_2DRB_1_first64.npz", tokens=toks, diversity_max_16=sel_max, diversity_min_16=sel_min)
     # (2) synthetic a2m touching every mapping of SURVEY a12: lowercase / '.' / '*' insertions are dropped,
     #     T->U, each of RYKMSWBDHVN -> X, and the plain alphabet A G C U X -
     syn = (">q desc with spaces\nACGU-XACGUTT\n"

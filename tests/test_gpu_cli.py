@@ -1,0 +1,44 @@
+"""End-to-end drop-in check on the GPU: the CLI (RNA_MSM_Inference.py, same overrides as the reference) turns a shipped
+`.a2m_msa2` alignment + a Lightning-style checkpoint into `<id>_emb.npy` / `<id>_atp.npy` with the reference's
+shape / dtype / layout contract, and the values match the oracle run on the same tokens."""
+import os
+import shutil
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, golden, rel_l2
+from oracle import msm_oracle as O
+from rnamsm import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cli_writes_reference_contract_files(tmp_path):
+    sys.path.insert(0, ROOT)
+    import RNA_MSM_Inference as cli
+    state = synthetic.make_state_dict(seed=0)
+    ckpt = tmp_path / "model.ckpt"
+    torch.save({"state_dict": {k: torch.from_numpy(v) for k, v in state.items()}, "epoch": 0}, ckpt)   # Lightning layout
+    msa_dir = tmp_path / "results"
+    msa_dir.mkdir()
+    shutil.copy(os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2"), msa_dir / "2DRB_1.a2m_msa2")
+    (tmp_path / "rna_id.txt").write_text("2DRB_1\n")
+    cli.main([f"data.root_path={tmp_path}", "data.MSA_path=results", f"data.model_path={ckpt}",
+              "data.MSA_list=rna_id.txt", "data.max_seqs_per_msa=32", "data.sample_method=first"])
+    emb = np.load(msa_dir / "2DRB_1_emb.npy")
+    atp = np.load(msa_dir / "2DRB_1_atp.npy")
+    assert emb.shape == (35, 768) and emb.dtype == np.float32 and emb.flags["C_CONTIGUOUS"]
+    assert atp.shape == (120, 35, 35) and atp.dtype == np.float32 and atp.flags["C_CONTIGUOUS"]
+    assert atp.sum(-1).max() <= 1.0 + 1e-5                      # <cls> column stripped -> rows sum to < 1
+    toks = golden("tokens_2DRB_1_first64.npz")["tokens"][:32]
+    res = O.forward(torch.from_numpy(toks), O.to_torch_params(state))
+    o_emb, o_atp = O.pack_outputs(res)
+    assert rel_l2(emb, o_emb) < 1e-4 and np.abs(atp - o_atp.numpy()).max() < 1e-4
+    # strict checkpoint loading, as the reference (RNA_MSM_Inference.py:133-135)
+    bad = {k: torch.from_numpy(v) for k, v in state.items() if k != "emb_layer_norm_after.bias"}
+    torch.save({"state_dict": bad}, ckpt)
+    with pytest.raises(RuntimeError):
+        cli.main([f"data.root_path={tmp_path}", f"data.model_path={ckpt}", "data.sample_method=first"])

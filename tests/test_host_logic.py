@@ -1,0 +1,202 @@
+"""CPU tests of the host side: tokenizer / a2m reader (bit-exact vs reference fixtures), config overrides, CLI helper
+behaviour, the C-ABI library (loads, exports every symbol of include/rnamsm.h, validates arguments without a GPU),
+and the no-fallback rule (ops refuse CPU tensors)."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, golden
+from rnamsm import msa, synthetic
+from rnamsm.alphabet import RNAAlphabet
+from rnamsm.config import Config, parse_overrides
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from rnamsm import _lib
+    if not os.path.exists(_lib.LIB_PATH):      # fresh checkout: hipcc cross-compiles gfx950 without a GPU
+        subprocess.run(["make", "-C", os.path.join(ROOT, "rna-msm_amd", "csrc"), "-j8"], check=True)
+    return _lib.load()
+
+
+# ------------------------------------------------------------------ tokenizer / reader (integer path: bit-exact)
+def test_alphabet_matches_reference_vocab():
+    meta = json.load(open(os.path.join(GOLDEN, "tokens_meta.json")))
+    a = RNAAlphabet.from_architecture("rna language")
+    assert a.to_dict() == meta["vocab"] and a.prepend_bos == meta["prepend_bos"] and a.append_eos == meta["append_eos"]
+    assert len(a) == 12 and a.pad_idx == 1 and a.cls_idx == 0 and a.mask_idx == 11
+    with pytest.raises(ValueError):
+        RNAAlphabet.from_architecture("ESM-1b")
+
+
+@pytest.mark.parametrize("a2m,fixture", [("2DRB_1_first64.a2m_msa2", "tokens_2DRB_1_first64.npz"),
+                                         ("synthetic_chars.a2m_msa2", "tokens_synthetic_chars.npz")])
+def test_reader_tokens_bit_exact(a2m, fixture):
+    toks = msa.load_msa_tokens(os.path.join(GOLDEN, a2m), RNAAlphabet())
+    want = golden(fixture)["tokens"]
+    assert toks.dtype == np.int64 and np.array_equal(toks, want)
+
+
+def test_reader_agrees_with_oracle_tokenizer_on_random_alignments():
+    from oracle import tokenizer_oracle as TO
+    rng = np.random.RandomState(0)
+    chars = np.array(list("ACGUTXRYKMSWBDHVN-acgu.*"))
+    a = RNAAlphabet()
+    for trial in range(20):
+        R, L = rng.randint(1, 9), rng.randint(1, 40)
+        rows = []
+        for _ in range(R):
+            body = list(rng.choice(list("ACGUTXRYKMSWBDHVN-"), L))
+            for _ in range(rng.randint(0, 5)):                     # insertions are dropped, so they keep rows aligned
+                body.insert(rng.randint(0, len(body) + 1), rng.choice(list("acgun.*")))
+            rows.append("".join(body))
+        text = "".join(f">s{i} x\n{r}\n" for i, r in enumerate(rows))
+        got = a.encode_a2m_records([s for _, s in msa.read_fasta_records(text, is_text=True)])
+        assert np.array_equal(got, TO.encode_msa(text))
+
+
+def test_reader_errors_match_reference():
+    a = RNAAlphabet()
+    with pytest.raises(AssertionError, match="Seqlen Mismatch"):
+        a.encode_a2m_records(["ACGU", "ACG"])
+    with pytest.raises(ValueError, match="Invalid tokens in input"):
+        a.encode_a2m_records(["ACGE", "ACGU"])
+    with pytest.raises(ValueError, match="Invalid tokens in input"):
+        a.encode(["ACGT"])                       # encode() takes already-clean sequences: T is not in the alphabet
+    assert np.array_equal(a.encode("ACGU-XN"), np.array([[0, 4, 6, 5, 7, 10, 8, 9]]))
+
+
+def test_row_subsampling_matches_reference_greedy_select():
+    g = golden("tokens_2DRB_1_first64.npz")
+    path = os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2")
+    a = RNAAlphabet()
+    assert np.array_equal(msa.load_msa_tokens(path, a, 16, "diversity-max"), g["diversity_max_16"])
+    assert np.array_equal(msa.load_msa_tokens(path, a, 16, "diversity-min"), g["diversity_min_16"])
+    assert np.array_equal(msa.load_msa_tokens(path, a, 16, "first"), g["tokens"][:16])
+    assert np.array_equal(msa.load_msa_tokens(path, a, 64, "hhfilter"), g["tokens"])      # no sub-sampling needed
+    with pytest.raises(NotImplementedError):
+        msa.load_msa_tokens(path, a, 16, "hhfilter")
+    with pytest.raises(AssertionError):
+        msa.load_msa_tokens(path, a, 16, "nonsense")
+
+
+def test_synthetic_generators_are_pure_functions():
+    t1, t2 = synthetic.make_tokens(7, 19, 3), synthetic.make_tokens(7, 19, 3)
+    assert np.array_equal(t1, t2) and (t1[:, 0] == 0).all() and set(np.unique(t1[:, 1:])) <= {4, 5, 6, 7, 8, 10}
+    assert not np.array_equal(t1, synthetic.make_tokens(7, 19, 4))
+    sd = synthetic.make_state_dict(seed=1, embed_dim=128, num_layers=2, num_heads=2)
+    b = sd["layers.0.row_self_attention.layer.q_proj.bias"]
+    assert abs(float(b.std()) - 0.05) < 0.02 and sd["lm_head.weight"] is sd["embed_tokens.weight"]
+    w = synthetic.normal("k", 0, (200000,))
+    assert abs(w.mean()) < 0.01 and abs(w.std() - 1) < 0.01
+
+
+def test_state_dict_keys_are_the_reference_275():
+    from rnamsm.model import MSATransformer
+    m = MSATransformer(num_layers=10)
+    keys = set(m.state_dict().keys())
+    spec = {k for k, _, _ in synthetic.state_dict_spec()}
+    assert len(keys) == 275 and keys == spec
+    for k, shape, _ in synthetic.state_dict_spec():
+        assert tuple(m.state_dict()[k].shape) == shape, k
+    sd = {k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(seed=0, embed_dim=128, num_layers=1, num_heads=2).items()}
+    small = MSATransformer(embed_dim=128, num_attention_heads=2, num_layers=1)
+    small.load_state_dict(sd, strict=True)
+    bad = dict(sd); bad.pop("layers.0.feed_forward_layer.layer.fc1.bias")
+    with pytest.raises(RuntimeError):
+        small.load_state_dict(bad, strict=True)
+
+
+# ------------------------------------------------------------------ config / CLI helpers
+def test_config_defaults_and_overrides():
+    c = Config()
+    assert (c.data.device, c.data.MSA_path, c.data.MSA_list, c.data.max_seqlen, c.data.max_tokens,
+            c.data.max_seqs_per_msa, c.data.sample_method, c.data.architecture) == \
+        ("cuda", "results", "rna_id.txt", 1024, 16384, 512, "hhfilter", "rna language")
+    assert (c.model.embed_dim, c.model.num_attention_heads, c.model.num_layers) == (768, 12, 10)
+    c = parse_overrides(["data.root_path=/x", "data.MSA_path=r2", "data.model_path=/m.ckpt", "data.MSA_list=ids.txt",
+                         "model.num_layers=3", "data.max_seqs_per_msa=64", "model.embed_positions_msa=false"])
+    assert c.data.root_path == "/x" and c.data.MSA_path == "r2" and c.model.num_layers == 3
+    assert c.data.max_seqs_per_msa == 64 and c.model.embed_positions_msa is False
+    for bad in (["data.nope=1"], ["nogroup.x=1"], ["data.max_seqlen"], ["data.max_seqlen=abc"]):
+        with pytest.raises((KeyError, ValueError)):
+            parse_overrides(bad)
+
+
+def test_cli_file_discovery_and_crop(tmp_path):
+    from rnamsm.inference import crop_tokens, find_msa_files
+    (tmp_path / "A.a2m_msa2").write_text(">a\nACGU\n")
+    (tmp_path / "B.extra.a2m_msa2").write_text(">b\nACGU\n")
+    found = find_msa_files(tmp_path, ["A", "B"])
+    assert sorted(found) == ["A", "B"]
+    with pytest.raises(FileNotFoundError):
+        find_msa_files(tmp_path, ["A", "C"])
+    with pytest.raises(FileNotFoundError):
+        find_msa_files(tmp_path / "missing", ["A"])
+    with pytest.raises(ValueError):
+        find_msa_files(tmp_path, [])
+    toks = synthetic.make_tokens(3, 1500, 0)
+    out = crop_tokens(toks, 1024, np.random.RandomState(0))
+    assert out.shape == (3, 1024) and (out[:, 0] == 0).all()
+    assert crop_tokens(toks[:, :1024], 1024, np.random.RandomState(0)).shape == (3, 1024)
+    edge = crop_tokens(synthetic.make_tokens(2, 1025, 0), 1024, np.random.RandomState(0))   # reference raises here
+    assert edge.shape == (2, 1024)
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_symbol_declared_in_the_header(lib):
+    from rnamsm import _lib
+    header = open(os.path.join(ROOT, "include", "rnamsm.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(rnamsm_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.rnamsm_version() == 100
+
+
+def test_library_validates_arguments_without_a_gpu(lib):
+    from rnamsm import _lib
+    assert lib.rnamsm_row_logits_nsplit(256, 512, 12) == 8          # deterministic function of the shape
+    assert lib.rnamsm_row_logits_workspace_bytes(256, 512, 12) == 8 * 12 * 512 * 512 * 4
+    dims = _lib.ModelDims(10, 768, 12, 3072, 12, 1026, 1, 1e-5)
+    import ctypes
+    need = lib.rnamsm_forward_workspace_bytes(ctypes.byref(dims), 256, 512)
+    T = 256 * 512
+    assert need >= T * 768 * 4 * 6 + 8 * 12 * 512 * 512 * 4 and need < T * 768 * 4 * 6.5
+    rc = lib.rnamsm_gemm_bias_act_res(None, 0, None, None, None, 0, None, 0, 4, 128, 32, 0, 1.0, 0, 0, None)
+    assert rc == -1 and b"null pointer" in lib.rnamsm_last_error()
+    rc = lib.rnamsm_gemm_bias_act_res(16, 32, 16, None, None, 0, 16, 100, 4, 100, 32, 0, 1.0, 0, 0, None)
+    assert rc == -1 and b"N % 128" in lib.rnamsm_last_error()
+    rc = lib.rnamsm_gemm_bias_act_res(16, 32, 16, None, None, 0, 16, 128, 4, 128, 32, 0, 1.0, 0, 1, None)
+    assert rc == -2                                                  # RNAMSM_BF16 reserved
+    rc = lib.rnamsm_col_attn_fused(16, 16, 16, 64, 16, 64, 4, 4, 1, 32, 0, None)
+    assert rc == -1 and b"head_dim" in lib.rnamsm_last_error()
+    rc = lib.rnamsm_embed_ln(16, 16, 16, 16, 16, 16, 16, 1025, 4, 768, 12, 1026, 1, 1e-5, None, None)
+    assert rc == -1 and b"maximum MSA depth of 1024" in lib.rnamsm_last_error()
+
+
+def test_no_cpu_fallback_exists():
+    from rnamsm import _lib, ops
+    from rnamsm.model import MSATransformer
+    with pytest.raises(_lib.RnamsmError):
+        ops.linear(torch.zeros(4, 32), torch.zeros(128, 32))
+    with pytest.raises(_lib.RnamsmError):
+        ops.layernorm(torch.zeros(4, 128), torch.ones(128), torch.zeros(128))
+    m = MSATransformer(embed_dim=128, num_attention_heads=2, num_layers=1).eval()
+    with pytest.raises(_lib.RnamsmError):
+        m(torch.zeros(1, 2, 5, dtype=torch.int64), need_head_weights=True)
+    # nothing under the product package imports the oracle
+    pkg = os.path.join(ROOT, "rna-msm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("SURVEY", ""), os.path.join(dirpath, f)
+    for f in ("RNA_MSM_Inference.py",):
+        assert "oracle" not in open(os.path.join(ROOT, f)).read()
