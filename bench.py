@@ -35,6 +35,25 @@ def flops_per_msa(M, L, D=768, layers=10):
     return layers * (32 * D * D + 4 * D * (M + L)) * M * L
 
 
+def pmc_traffic_per_launch(kernel_prefix="rnamsm::gemm_f32_kernel"):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r*_pmc_summary.json: FETCH_SIZE x2 per MI355X_MICROARCH.md §HBM, + WRITE_SIZE), launch-weighted over the
+    kernel's template instances.  Counters cannot be collected inside a timed run, so this is the profile's figure for
+    the same workload, or None when no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    summ = json.load(open(files[-1]))
+    tot, n = 0.0, 0
+    for name, v in summ.items():
+        if name.startswith(kernel_prefix) and "hbm_read_bytes_corrected" in v:
+            d = v.get("dispatches_FETCH_SIZE", 1)
+            tot += d * (v["hbm_read_bytes_corrected"] + v.get("hbm_write_bytes", 0.0))
+            n += d
+    return (tot / n if n else None), os.path.basename(files[-1])
+
+
 def cpu_baseline(M, L, state, budget_note):
     """Oracle (port of the reference) on the host cores: ONE of the ten layers of the same M x L MSA (embedding and
     final LayerNorm included), extrapolated x10 -- the layers are identical in cost."""
@@ -163,6 +182,7 @@ def main():
         attn_ms = sum(timings[k]["ms"] for k in ("row_logits", "row_apply", "col_attn"))
         attn_fl = sum(timings[k]["flops"] for k in ("row_logits", "row_apply", "col_attn"))
         kern_ms = sum(v["ms"] for v in timings.values())
+        traffic, traffic_src = pmc_traffic_per_launch()
         result = {
             "metric": "MSA-residues/sec forward (emb+attn-map), M=256 L=512",
             "value": residues / elapsed,
@@ -182,7 +202,9 @@ def main():
                          "frac": gemm_tflops / FP32_MFMA_PEAK_TFLOPS,
                          "avg_launch_ms": g["ms"] / max(1, g["launches"]), "launches": g["launches"],
                          "flops_per_launch": g["flops"] / max(1, g["launches"]),
-                         "traffic": None},
+                         "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side, PMC)",
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"])},
             "attention_mfma": {"kernels": "row_logits+row_apply+col_attn", "achieved": attn_fl / (attn_ms * 1e-3) / 1e12 if attn_ms else 0.0,
                                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": (attn_fl / (attn_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if attn_ms else 0.0},
