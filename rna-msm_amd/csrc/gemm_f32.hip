@@ -44,33 +44,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     zero_acc(acc);
 
     StageKC sa, sw;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        sa.v[i] = *reinterpret_cast<const f32x4*>(ap[i]);
-        sw.v[i] = *reinterpret_cast<const f32x4*>(wp[i]);
-    }
-    stage_store_kc(As, sa);
-    stage_store_kc(Ws, sw);
-    __syncthreads();
-
-    const int nk = K / BK;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) {   // issue next tile's global loads; they land while the MFMAs below run
+    pipelined_kloop<true, 8>(
+        K / BK, As, Ws, TILE_KC, TILE_KC, acc, w,
+        [&](int kt) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                sa.v[i] = *reinterpret_cast<const f32x4*>(ap[i] + (kt + 1) * BK);
-                sw.v[i] = *reinterpret_cast<const f32x4*>(wp[i] + (kt + 1) * BK);
+                sa.v[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
+                sw.v[i] = *reinterpret_cast<const f32x4*>(wp[i] + kt * BK);
             }
-        }
-        mma_ktile<true>(As + cur * TILE_KC, Ws + cur * TILE_KC, acc, w);
-        if (more) {   // the other buffer was last read before the previous barrier
-            stage_store_kc(As + (cur ^ 1) * TILE_KC, sa);
-            stage_store_kc(Ws + (cur ^ 1) * TILE_KC, sw);
-        }
-        __syncthreads();
-    }
+        },
+        [&](int buf) {
+            stage_store_kc(As + buf * TILE_KC, sa);
+            stage_store_kc(Ws + buf * TILE_KC, sw);
+        });
 
     // epilogue: each accumulator register covers 32 consecutive columns of one row per lane half (128-B stores)
 #pragma unroll

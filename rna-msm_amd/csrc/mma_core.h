@@ -60,6 +60,123 @@ __device__ __forceinline__ void mma_ktile(const float* __restrict__ As, const fl
     }
 }
 
+// ---- software-pipelined K loop ----------------------------------------------------------------------------------
+// Fragments of one 8-deep k group: 2 A + 2 B ds_read_b128 (B_KC) per lane.
+struct Frag {
+    f32x4 a[2], b[2];
+};
+template <bool B_KC>
+__device__ __forceinline__ void frag_load(const float* __restrict__ As, const float* __restrict__ Bs, int kk,
+                                          const WaveCoord& w, Frag& f) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+        f.a[mt] = *reinterpret_cast<const f32x4*>(&As[(w.wm * 64 + mt * 32 + w.li) * LDK + kk * 8 + 4 * w.lh]);
+    if (B_KC) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            f.b[nt] = *reinterpret_cast<const f32x4*>(&Bs[(w.wn * 64 + nt * 32 + w.li) * LDK + kk * 8 + 4 * w.lh]);
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) f.b[nt][s] = Bs[(kk * 8 + 4 * w.lh + s) * LDN + w.wn * 64 + nt * 32 + w.li];
+    }
+}
+__device__ __forceinline__ void frag_mma(const Frag& f, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma32(f.a[mt][s], f.b[nt][s], acc[mt][nt]);
+}
+
+// The K loop every tile kernel runs.  `load(kt)` issues the global loads of K tile kt into the caller's staging
+// registers (NV loads per thread), `store(buf)` writes those registers into LDS buffer `buf` (8 ds_write_b128).
+// One iteration = four groups of 16 MFMAs (1024 matrix-pipe cycles each), scheduled so the pipe only ever waits at the
+// barrier itself:
+//   group 0 : fragments of group 1 requested first; then, BETWEEN its MFMAs, the 8 LDS writes of tile t+1 (whose
+//             global loads were issued a whole iteration earlier) and the global loads of tile t+2
+//   group 1 : fragments of group 2 in flight          group 2 : fragments of group 3 in flight
+//   barrier : every wave has its group-3 fragments in registers, tile t+1 is complete in the other buffer
+//   group 3 : covers the LDS latency of tile t+1's group-0 fragments, requested right after the barrier
+// hipcc otherwise sinks each ds_read next to its use and exposes the LDS latency four times per tile, so the order is
+// pinned with sched_group_barrier (interleave inside a group) and sched_barrier (between groups); the steady-state
+// body is branch-free (tail iterations are peeled) because those directives act per basic block.
+// Buffer hazards: tile t+1's buffer was last read before the previous iteration's barrier; nobody reads the current
+// buffer after this iteration's barrier.
+#define RNAMSM_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100, SG_DS_WRITE = 0x200;
+
+template <bool B_KC, int NV, bool DO_STORE, bool DO_LOAD, bool DO_NEXT, class LoadFn, class StoreFn>
+__device__ __forceinline__ void kstep(int kt, float* As, float* Bs, int a_tile, int b_tile, f32x16 (&acc)[2][2],
+                                      const WaveCoord& w, Frag& f0, Frag& f1, LoadFn& load, StoreFn& store) {
+    constexpr int NR = B_KC ? 4 : 10;          // ds_reads per fragment group
+    const int cur = kt & 1, nxt = cur ^ 1;
+    const float* Ac = As + cur * a_tile;
+    const float* Bc = Bs + cur * b_tile;
+    // ---- group 0
+    frag_load<B_KC>(Ac, Bc, 1, w, f1);
+    if (DO_STORE) store(nxt);
+    if (DO_LOAD) load(kt + 2);
+    frag_mma(f0, acc);
+    RNAMSM_SGB(SG_DS_READ, NR);
+    if (DO_STORE) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            RNAMSM_SGB(SG_MFMA, 1);
+            RNAMSM_SGB(SG_DS_WRITE, 1);
+        }
+    }
+    if (DO_LOAD) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            RNAMSM_SGB(SG_MFMA, 1);
+            RNAMSM_SGB(SG_VMEM_READ, NV / 4);
+        }
+    }
+    RNAMSM_SGB(SG_MFMA, 16 - (DO_STORE ? 8 : 0) - (DO_LOAD ? 4 : 0));
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- group 1
+    frag_load<B_KC>(Ac, Bc, 2, w, f0);
+    frag_mma(f1, acc);
+    RNAMSM_SGB(SG_DS_READ, NR);
+    RNAMSM_SGB(SG_MFMA, 16);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- group 2
+    frag_load<B_KC>(Ac, Bc, 3, w, f1);
+    frag_mma(f0, acc);
+    RNAMSM_SGB(SG_DS_READ, NR);
+    RNAMSM_SGB(SG_MFMA, 16);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    // ---- group 3
+    if (DO_NEXT) frag_load<B_KC>(As + nxt * a_tile, Bs + nxt * b_tile, 0, w, f0);
+    frag_mma(f1, acc);
+    if (DO_NEXT) RNAMSM_SGB(SG_DS_READ, NR);
+    RNAMSM_SGB(SG_MFMA, 16);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool B_KC, int NV, class LoadFn, class StoreFn>
+__device__ __forceinline__ void pipelined_kloop(int nk, float* As, float* Bs, int a_tile, int b_tile,
+                                                f32x16 (&acc)[2][2], const WaveCoord& w, LoadFn load, StoreFn store) {
+    load(0);
+    store(0);
+    if (nk > 1) load(1);
+    __syncthreads();
+    Frag f0, f1;
+    frag_load<B_KC>(As, Bs, 0, w, f0);
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt)
+        kstep<B_KC, NV, true, true, true>(kt, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
+    if (kt + 1 < nk) {
+        kstep<B_KC, NV, true, false, true>(kt, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
+        ++kt;
+    }
+    kstep<B_KC, NV, false, false, false>(kt, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
+}
+
 // Register staging of one [128 rows][32 k] tile: thread -> (row = tid/8 + 32*i, 16-B chunk tid%8); 8 lanes cover
 // one row's 128 contiguous bytes.
 struct StageKC {

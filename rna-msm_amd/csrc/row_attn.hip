@@ -90,36 +90,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
     };
 
     StageKC sq, sk;
-    {
-        const int64_t b = tile_base(0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            sq.v[s] = *reinterpret_cast<const f32x4*>(q + b + qoff[s]);
-            sk.v[s] = *reinterpret_cast<const f32x4*>(k + b + koff[s]);
-        }
-    }
-    stage_store_kc(Qs, sq);
-    stage_store_kc(Ks, sk);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            const int64_t b = tile_base(kt + 1);
+    pipelined_kloop<true, 8>(
+        nk, Qs, Ks, TILE_KC, TILE_KC, acc, w,
+        [&](int kt) {
+            const int64_t b = tile_base(kt);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 sq.v[s] = *reinterpret_cast<const f32x4*>(q + b + qoff[s]);
                 sk.v[s] = *reinterpret_cast<const f32x4*>(k + b + koff[s]);
             }
-        }
-        mma_ktile<true>(Qs + cur * TILE_KC, Ks + cur * TILE_KC, acc, w);
-        if (more) {
-            stage_store_kc(Qs + (cur ^ 1) * TILE_KC, sq);
-            stage_store_kc(Ks + (cur ^ 1) * TILE_KC, sk);
-        }
-        __syncthreads();
-    }
+        },
+        [&](int buf) {
+            stage_store_kc(Qs + buf * TILE_KC, sq);
+            stage_store_kc(Ks + buf * TILE_KC, sk);
+        });
 
     float* out = partial + ((int64_t)split * H + h) * C * C;
 #pragma unroll
@@ -180,6 +164,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 // out[i, (r,d)] = sum_j P[h][i][j] * V[j, (r,d)].  A = P_h rows (k = j contiguous), B = v read as [j][n] with
 // n = (r_local, d): 2 alignment rows x 64 head dims per 128-wide N tile.
 // grid.x = xcd-mapped (panel = (head, n tile), inner = tiles_i): the i tiles of one V panel share an L2.
+template <bool ALIGNED>   // ALIGNED: C % 4 == 0 and probs 16-B aligned -> P rows can be read as float4
 __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
     const float* __restrict__ probs, const float* __restrict__ v, int64_t ld, float* __restrict__ ctx, int64_t ldc,
     int R, int C, int H) {
@@ -207,28 +192,31 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
     const int nk = (C + BK - 1) / BK;
 
     f32x4 sp[4], sv[4];
+    // Loads are branch-free (clamped address + select) so the K loop body stays one basic block; keys j >= C are
+    // zero-filled in BOTH operands: they must contribute exactly 0 and clamped data could be NaN.
     auto load_tiles = [&](int kt) {
         const int j0 = kt * BK;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            // P: zero-fill j >= C (K dimension): out-of-range keys must contribute exactly 0
             const int i = min(i0 + r0 + 32 * s, C - 1);
             const int j = j0 + c4 * 4;
-            const float* p = pbase + (int64_t)i * C + j;
+            const float* prow = pbase + (int64_t)i * C;
             f32x4 t;
-            if (j + 3 < C && ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)) {
-                t = *reinterpret_cast<const f32x4*>(p);
+            if (ALIGNED) {
+                t = *reinterpret_cast<const f32x4*>(prow + min(j, C - 4));
+                if (j >= C) t = f32x4{0.f, 0.f, 0.f, 0.f};
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = (j + e < C) ? p[e] : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const float x = prow[min(j + e, C - 1)];
+                    t[e] = (j + e < C) ? x : 0.f;
+                }
             }
             sp[s] = t;
             const int jj = j0 + bk0 + 8 * s;
-            if (jj < C) {
-                sv[s] = *reinterpret_cast<const f32x4*>(vbase + (int64_t)jj * ld);
-            } else {
-                sv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            f32x4 u = *reinterpret_cast<const f32x4*>(vbase + (int64_t)min(jj, C - 1) * ld);
+            if (jj >= C) u = f32x4{0.f, 0.f, 0.f, 0.f};
+            sv[s] = u;
         }
     };
     auto store_tiles = [&](int buf) {
@@ -241,17 +229,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
         }
     };
 
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) load_tiles(kt + 1);
-        mma_ktile<false>(Ps + cur * TILE_KC, Vs + cur * TILE_NC, acc, w);
-        if (more) store_tiles(cur ^ 1);
-        __syncthreads();
-    }
+    pipelined_kloop<false, ALIGNED ? 8 : 20>(nk, Ps, Vs, TILE_KC, TILE_NC, acc, w, load_tiles, store_tiles);
 
     // column n of the tile -> (alignment row rr0 + n/64, head dim n%64)
 #pragma unroll
@@ -340,7 +318,9 @@ extern "C" int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, 
                      "row_apply: v must be 16-byte aligned with ld %% 4 == 0");
     static bool configured = false;
     if (!configured) {
-        int rc = set_lds(row_apply_kernel, ROWAPPLY_LDS_BYTES, "row_apply");
+        int rc = set_lds(row_apply_kernel<true>, ROWAPPLY_LDS_BYTES, "row_apply");
+        if (rc) return rc;
+        rc = set_lds(row_apply_kernel<false>, ROWAPPLY_LDS_BYTES, "row_apply");
         if (rc) return rc;
         configured = true;
     }
@@ -348,8 +328,12 @@ extern "C" int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, 
     const unsigned grid = xcd_panel_grid((unsigned)H * tiles_n, tiles_i);
     KernelTimer timer(TC_ROW_APPLY, 2.0 * H * C * C * R * HEAD_DIM,
                       4.0 * (2.0 * R * C * H * HEAD_DIM + (double)H * C * C), static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(row_apply_kernel, dim3(grid), dim3(GEMM_THREADS), ROWAPPLY_LDS_BYTES,
-                       static_cast<hipStream_t>(stream), probs, v, ld, ctx, ldc, R, C, H);
+    if (C % 4 == 0 && C >= 4 && aligned16(probs))
+        hipLaunchKernelGGL(row_apply_kernel<true>, dim3(grid), dim3(GEMM_THREADS), ROWAPPLY_LDS_BYTES,
+                           static_cast<hipStream_t>(stream), probs, v, ld, ctx, ldc, R, C, H);
+    else
+        hipLaunchKernelGGL(row_apply_kernel<false>, dim3(grid), dim3(GEMM_THREADS), ROWAPPLY_LDS_BYTES,
+                           static_cast<hipStream_t>(stream), probs, v, ld, ctx, ldc, R, C, H);
     RNAMSM_CHECK_LAUNCH("row_apply");
     return RNAMSM_OK;
 }
