@@ -158,6 +158,11 @@ int rnamsm_timing_collect(void);
 int rnamsm_timing_get(int category, const char** name, long long* launches, double* ms, double* flops, double* bytes);
 void rnamsm_timing_reset(void);
 
+/* Tuning knobs for in-process A/B measurements (speed only, never results).  Known names:
+ *   "gemm_stagger"  0 = off, 1 = delay the second resident block of each CU by half a tile (default 1). */
+int rnamsm_set_param(const char* name, int value);
+int rnamsm_get_param(const char* name);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,28 @@ extern "C" void rnamsm_timing_reset(void) {
     for (Totals& t : g_tot) t = Totals();
 }
 
+namespace rnamsm {
+Tuning& tuning() {
+    static Tuning t;
+    return t;
+}
+}  // namespace rnamsm
+extern "C" int rnamsm_set_param(const char* name, int value) {
+    if (name && !strcmp(name, "gemm_stagger")) {
+        rnamsm::tuning().gemm_stagger = value;
+        return RNAMSM_OK;
+    }
+    if (name && !strcmp(name, "gemm_debug")) {
+        rnamsm::tuning().gemm_debug = value;
+        return RNAMSM_OK;
+    }
+    return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: unknown parameter %s", name ? name : "(null)");
+}
+extern "C" int rnamsm_get_param(const char* name) {
+    if (name && !strcmp(name, "gemm_stagger")) return rnamsm::tuning().gemm_stagger;
+    return -1;
+}
+
 extern "C" int rnamsm_version(void) { return RNAMSM_VERSION; }
 extern "C" const char* rnamsm_last_error(void) { return rnamsm::g_err; }
 extern "C" int rnamsm_device_count(void) {

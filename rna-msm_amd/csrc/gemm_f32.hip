@@ -16,7 +16,7 @@ template <int ACT, bool HAS_RES>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc,
-    int M, int N, int K, float scale, int scale_cols) {
+    int M, int N, int K, float scale, int scale_cols, unsigned stagger_cycles, int debug) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                    // [2][BM][LDK]
     float* Ws = smem + 2 * TILE_KC;      // [2][BN][LDK]
@@ -25,6 +25,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     unsigned mpanel, nblk;
     if (!xcd_panel_map(blockIdx.x, mp, nb, mpanel, nblk)) return;
     const int m0 = mpanel * BM, n0 = nblk * BN;
+    stagger_second_resident_block(blockIdx.x, stagger_cycles);
 
     const WaveCoord w = wave_coord();
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
@@ -58,24 +59,47 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
             stage_store_kc(Ws + buf * TILE_KC, sw);
         });
 
-    // epilogue: each accumulator register covers 32 consecutive columns of one row per lane half (128-B stores)
+    // ---- epilogue.  The accumulator layout (one row x 32 columns per register and lane half) would give 64
+    // 4-byte-per-lane stores per wave, and store tails are issue-bound; instead each wave transposes its 64x64 tile
+    // through its own slice of the (now idle) LDS and moves whole 256-B row segments: 16 float4 stores, and 16 float4
+    // residual loads that are issued BEFORE the transpose so their latency hides behind it.
+    constexpr int LDE = 64 + 4;                                   // padded row stride (floats) of the staging tile
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int er = lane >> 4, ec = (lane & 15) * 4;               // lane -> (row er + 4*i, columns ec..ec+3)
+    const int gm0 = m0 + w.wm * 64, gn = n0 + w.wn * 64 + ec;
+    f32x4 res[16];
+    if (HAS_RES) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = min(gm0 + er + 4 * i, M - 1);
+            res[i] = *reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn);
+        }
+    }
+    __syncthreads();                                              // every wave has finished reading operand tiles
+    float* stage = smem + wv * (64 * LDE);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = n0 + acc_col(w, nt);
         const float b = bias ? bias[col] : 0.f;
         const float sc = col < scale_cols ? scale : 1.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const int row = m0 + acc_row(w, mt, t);
-                if (row < M) {
-                    float v = (acc[mt][nt][t] + b) * sc;
-                    if (ACT == RNAMSM_ACT_GELU_ERF) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-                    if (HAS_RES) v += residual[(int64_t)row * ldr + col];
-                    Cout[(int64_t)row * ldc + col] = v;
-                }
+                float v = (acc[mt][nt][t] + b) * sc;
+                if (ACT == RNAMSM_ACT_GELU_ERF) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+                stage[(mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * w.lh) * LDE + nt * 32 + w.li] = v;
             }
+    }
+    // same-wave LDS write -> read: ordered by the hardware queue, the compiler inserts the lgkmcnt wait
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = er + 4 * i;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&stage[r * LDE + ec]);
+        if (HAS_RES) v += res[i];
+        if (gm0 + r < M) {
+            if (debug & 1) asm volatile("" ::"v"(v)); else
+            *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + r) * ldc + gn) = v;
         }
     }
 }
@@ -93,10 +117,12 @@ static int launch_gemm(const float* A, int64_t lda, const float* W, const float*
         configured = true;
     }
     const unsigned grid = xcd_panel_grid((M + BM - 1) / BM, N / BN);
+    // half of a solo tile (K/32 steps x 4096 matrix-pipe cycles): see stagger_second_resident_block
+    const unsigned stagger = (tuning().gemm_stagger && grid > 512) ? (unsigned)(K / BK) * 2048u * tuning().gemm_stagger : 0u;
     // algorithmic work: 2MNK flops; bytes = A + W + C once (+ residual read)
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, A, lda, W, bias, residual, ldr,
-                       Cout, ldc, M, N, K, scale, scale_cols);
+                       Cout, ldc, M, N, K, scale, scale_cols, stagger, tuning().gemm_debug);
     RNAMSM_CHECK_LAUNCH("gemm_f32");
     return RNAMSM_OK;
 }
@@ -115,7 +141,8 @@ extern "C" int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float
     RNAMSM_CHECK_ARG(lda >= K && lda % 4 == 0 && ldc >= N, "gemm: bad leading dimension lda=%lld ldc=%lld",
                      (long long)lda, (long long)ldc);
     RNAMSM_CHECK_ARG(aligned16(A) && aligned16(W), "gemm: A and W must be 16-byte aligned");
-    RNAMSM_CHECK_ARG(!residual || ldr >= N, "gemm: bad residual stride");
+    RNAMSM_CHECK_ARG(!residual || (ldr >= N && ldr % 4 == 0 && aligned16(residual)), "gemm: bad residual stride/alignment");
+    RNAMSM_CHECK_ARG(ldc % 4 == 0 && aligned16(Cout), "gemm: Cout must be 16-byte aligned with ldc %% 4 == 0");
     RNAMSM_CHECK_ARG(act == RNAMSM_ACT_NONE || act == RNAMSM_ACT_GELU_ERF, "gemm: unknown activation %d", act);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int m = (int)M;

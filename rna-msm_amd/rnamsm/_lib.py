@@ -54,6 +54,8 @@ _SIGNATURES = {
     "rnamsm_timing_get": (c_int, [c_int, POINTER(c_char_p), POINTER(ctypes.c_longlong), POINTER(ctypes.c_double),
                                   POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "rnamsm_timing_reset": (None, []),
+    "rnamsm_set_param": (c_int, [c_char_p, c_int]),
+    "rnamsm_get_param": (c_int, [c_char_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
