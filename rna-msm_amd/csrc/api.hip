@@ -116,6 +116,10 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm_stagger = value;
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "gemm_prefetch_depth")) {
+        rnamsm::tuning().gemm_prefetch_depth = value;
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "gemm_debug")) {
         rnamsm::tuning().gemm_debug = value;
         return RNAMSM_OK;

@@ -46,6 +46,7 @@ struct KernelTimer {   // brackets one launch with two hipEventRecord calls when
 // ---- tuning knobs (api.hip) -------------------------------------------------------------------------
 struct Tuning {
     int gemm_stagger = 0;
+    int gemm_prefetch_depth = 1;   // staging register sets of the GEMM K loop (1 or 2)
     int gemm_debug = 0;      // measurement only: bit0 = skip the epilogue stores (results wrong)
 };
 Tuning& tuning();

@@ -12,7 +12,7 @@ namespace rnamsm {
 
 constexpr int GEMM_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;   // double-buffered A and W tiles
 
-template <int ACT, bool HAS_RES>
+template <int ACT, bool HAS_RES, int DEPTH>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc,
@@ -44,19 +44,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     f32x16 acc[2][2];
     zero_acc(acc);
 
-    StageKC sa, sw;
-    pipelined_kloop<true, 8>(
+    StageKC sa[DEPTH], sw[DEPTH];
+    pipelined_kloop<true, 8, DEPTH>(
         K / BK, As, Ws, TILE_KC, TILE_KC, acc, w,
-        [&](int kt) {
+        [&](int kt, auto set) {
+            constexpr int S = decltype(set)::value;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                sa.v[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
-                sw.v[i] = *reinterpret_cast<const f32x4*>(wp[i] + kt * BK);
+                sa[S].v[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
+                sw[S].v[i] = *reinterpret_cast<const f32x4*>(wp[i] + kt * BK);
             }
         },
-        [&](int buf) {
-            stage_store_kc(As + buf * TILE_KC, sa);
-            stage_store_kc(Ws + buf * TILE_KC, sw);
+        [&](int buf, auto set) {
+            constexpr int S = decltype(set)::value;
+            stage_store_kc(As + buf * TILE_KC, sa[S]);
+            stage_store_kc(Ws + buf * TILE_KC, sw[S]);
         });
 
     // ---- epilogue.  The accumulator layout (one row x 32 columns per register and lane half) would give 64
@@ -104,12 +106,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     }
 }
 
-template <int ACT, bool HAS_RES>
+template <int ACT, bool HAS_RES, int DEPTH>
 static int launch_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                        int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
                        hipStream_t stream) {
     static bool configured = false;
-    auto kern = gemm_f32_kernel<ACT, HAS_RES>;
+    auto kern = gemm_f32_kernel<ACT, HAS_RES, DEPTH>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
@@ -146,10 +148,14 @@ extern "C" int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float
     RNAMSM_CHECK_ARG(act == RNAMSM_ACT_NONE || act == RNAMSM_ACT_GELU_ERF, "gemm: unknown activation %d", act);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int m = (int)M;
+#define RNAMSM_GEMM_DISPATCH(ACT_, RES_, DEPTH_) \
+    launch_gemm<ACT_, RES_, DEPTH_>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, s)
+    const bool deep = tuning().gemm_prefetch_depth >= 2;
     if (act == RNAMSM_ACT_GELU_ERF) {
-        return residual ? launch_gemm<RNAMSM_ACT_GELU_ERF, true>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, s)
-                        : launch_gemm<RNAMSM_ACT_GELU_ERF, false>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, s);
+        if (residual) return deep ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, true, 2) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, true, 1);
+        return deep ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, false, 2) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, false, 1);
     }
-    return residual ? launch_gemm<RNAMSM_ACT_NONE, true>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, s)
-                    : launch_gemm<RNAMSM_ACT_NONE, false>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, s);
+    if (residual) return deep ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_NONE, true, 2) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_NONE, true, 1);
+    return deep ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_NONE, false, 2) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_NONE, false, 1);
+#undef RNAMSM_GEMM_DISPATCH
 }

@@ -9,6 +9,8 @@
 // matrix core.  The k order inside a tile is permuted identically for A and B, which is legal for a dot product
 // and fixed, so results are deterministic.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace rnamsm {
@@ -108,34 +110,39 @@ __device__ __forceinline__ void frag_mma(const Frag& f, f32x16 (&acc)[2][2]) {
 #define RNAMSM_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20, SG_DS_READ = 0x100, SG_DS_WRITE = 0x200;
 
-template <bool B_KC, int NV, bool DO_STORE, bool DO_LOAD, bool DO_NEXT, class LoadFn, class StoreFn>
-__device__ __forceinline__ void kstep(int kt, float* As, float* Bs, int a_tile, int b_tile, f32x16 (&acc)[2][2],
-                                      const WaveCoord& w, Frag& f0, Frag& f1, LoadFn& load, StoreFn& store) {
+template <int S>
+using SetTag = std::integral_constant<int, S>;
+
+// One K tile.  S = staging register set holding tile kt+1 (and, once stored, reloaded with tile kt+1+DEPTH).
+// STEADY: all three actions happen and the schedule is pinned; otherwise (the last DEPTH+1 tiles) they are runtime
+// flags and the compiler's own order is accepted.
+template <bool B_KC, int NV, int DEPTH, int S, bool STEADY, class LoadFn, class StoreFn>
+__device__ __forceinline__ void kstep(int kt, bool do_store, bool do_load, bool do_next, float* As, float* Bs,
+                                      int a_tile, int b_tile, f32x16 (&acc)[2][2], const WaveCoord& w, Frag& f0,
+                                      Frag& f1, LoadFn& load, StoreFn& store) {
     constexpr int NR = B_KC ? 4 : 10;          // ds_reads per fragment group
     const int cur = kt & 1, nxt = cur ^ 1;
     const float* Ac = As + cur * a_tile;
     const float* Bc = Bs + cur * b_tile;
     // ---- group 0
     frag_load<B_KC>(Ac, Bc, 1, w, f1);
-    if (DO_STORE) store(nxt);
-    if (DO_LOAD) load(kt + 2);
+    if (STEADY || do_store) store(nxt, SetTag<S>{});
+    if (STEADY || do_load) load(kt + 1 + DEPTH, SetTag<S>{});
     frag_mma(f0, acc);
-    RNAMSM_SGB(SG_DS_READ, NR);
-    if (DO_STORE) {
+    if (STEADY) {
+        RNAMSM_SGB(SG_DS_READ, NR);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             RNAMSM_SGB(SG_MFMA, 1);
             RNAMSM_SGB(SG_DS_WRITE, 1);
         }
-    }
-    if (DO_LOAD) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             RNAMSM_SGB(SG_MFMA, 1);
             RNAMSM_SGB(SG_VMEM_READ, NV / 4);
         }
+        RNAMSM_SGB(SG_MFMA, 4);
     }
-    RNAMSM_SGB(SG_MFMA, 16 - (DO_STORE ? 8 : 0) - (DO_LOAD ? 4 : 0));
     __builtin_amdgcn_sched_barrier(0);
     // ---- group 1
     frag_load<B_KC>(Ac, Bc, 2, w, f0);
@@ -151,30 +158,41 @@ __device__ __forceinline__ void kstep(int kt, float* As, float* Bs, int a_tile, 
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     // ---- group 3
-    if (DO_NEXT) frag_load<B_KC>(As + nxt * a_tile, Bs + nxt * b_tile, 0, w, f0);
+    if (STEADY || do_next) frag_load<B_KC>(As + nxt * a_tile, Bs + nxt * b_tile, 0, w, f0);
     frag_mma(f1, acc);
-    if (DO_NEXT) RNAMSM_SGB(SG_DS_READ, NR);
-    RNAMSM_SGB(SG_MFMA, 16);
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool B_KC, int NV, class LoadFn, class StoreFn>
+// DEPTH = 1: one staging register set, tile t+2 is requested during tile t (distance ~52 MFMAs to its LDS write).
+// DEPTH = 2: two sets (tile t+1 lives in set (t+1)&1), tile t+3 is requested during tile t: a whole extra tile
+//            (64 MFMAs) of latency cover for first-touch HBM reads at +32 VGPRs.
+// `load(kt, SetTag<S>)` / `store(buf, SetTag<S>)` address the caller's staging registers by a compile-time set index
+// (runtime-indexed register arrays would go to scratch), hence the x2 unrolled loops.
+template <bool B_KC, int NV, int DEPTH, class LoadFn, class StoreFn>
 __device__ __forceinline__ void pipelined_kloop(int nk, float* As, float* Bs, int a_tile, int b_tile,
                                                 f32x16 (&acc)[2][2], const WaveCoord& w, LoadFn load, StoreFn store) {
-    load(0);
-    store(0);
-    if (nk > 1) load(1);
+    static_assert(DEPTH == 1 || DEPTH == 2, "prefetch depth");
+    constexpr int S_ODD = DEPTH == 2 ? 1 : 0;       // set of odd tiles
+    load(0, SetTag<0>{});
+    store(0, SetTag<0>{});
+    if (nk > 1) load(1, SetTag<S_ODD>{});
+    if (DEPTH == 2 && nk > 2) load(2, SetTag<0>{});
     __syncthreads();
     Frag f0, f1;
     frag_load<B_KC>(As, Bs, 0, w, f0);
     int kt = 0;
-    for (; kt + 2 < nk; ++kt)
-        kstep<B_KC, NV, true, true, true>(kt, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
-    if (kt + 1 < nk) {
-        kstep<B_KC, NV, true, false, true>(kt, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
-        ++kt;
+    for (; kt + 2 + DEPTH < nk; kt += 2) {           // both steps are full: (kt + 1) + 1 + DEPTH < nk
+        kstep<B_KC, NV, DEPTH, S_ODD, true>(kt, true, true, true, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
+        kstep<B_KC, NV, DEPTH, 0, true>(kt + 1, true, true, true, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
     }
-    kstep<B_KC, NV, false, false, false>(kt, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
+#pragma unroll 1
+    for (; kt < nk; kt += 2) {                       // kt even: tile kt+1 is odd -> set S_ODD
+        kstep<B_KC, NV, DEPTH, S_ODD, false>(kt, kt + 1 < nk, kt + 1 + DEPTH < nk, kt + 1 < nk, As, Bs, a_tile, b_tile,
+                                             acc, w, f0, f1, load, store);
+        if (kt + 1 < nk)
+            kstep<B_KC, NV, DEPTH, 0, false>(kt + 1, kt + 2 < nk, kt + 2 + DEPTH < nk, kt + 2 < nk, As, Bs, a_tile,
+                                             b_tile, acc, w, f0, f1, load, store);
+    }
 }
 
 // Register staging of one [128 rows][32 k] tile: thread -> (row = tid/8 + 32*i, 16-B chunk tid%8); 8 lanes cover

@@ -90,9 +90,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
     };
 
     StageKC sq, sk;
-    pipelined_kloop<true, 8>(
+    pipelined_kloop<true, 8, 1>(
         nk, Qs, Ks, TILE_KC, TILE_KC, acc, w,
-        [&](int kt) {
+        [&](int kt, auto) {
             const int64_t b = tile_base(kt);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
                 sk.v[s] = *reinterpret_cast<const f32x4*>(k + b + koff[s]);
             }
         },
-        [&](int buf) {
+        [&](int buf, auto) {
             stage_store_kc(Qs + buf * TILE_KC, sq);
             stage_store_kc(Ks + buf * TILE_KC, sk);
         });
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
     f32x4 sp[4], sv[4];
     // Loads are branch-free (clamped address + select) so the K loop body stays one basic block; keys j >= C are
     // zero-filled in BOTH operands: they must contribute exactly 0 and clamped data could be NaN.
-    auto load_tiles = [&](int kt) {
+    auto load_tiles = [&](int kt, auto) {
         const int j0 = kt * BK;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
             sv[s] = u;
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, auto) {
         float* pt = Ps + buf * TILE_KC;
         float* vt = Vs + buf * TILE_NC;
 #pragma unroll
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
         }
     };
 
-    pipelined_kloop<false, ALIGNED ? 8 : 20>(nk, Ps, Vs, TILE_KC, TILE_NC, acc, w, load_tiles, store_tiles);
+    pipelined_kloop<false, ALIGNED ? 8 : 20, 1>(nk, Ps, Vs, TILE_KC, TILE_NC, acc, w, load_tiles, store_tiles);
 
     // column n of the tile -> (alignment row rr0 + n/64, head dim n%64)
 #pragma unroll
