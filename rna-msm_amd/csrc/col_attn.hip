@@ -5,7 +5,10 @@
 // C=512) only to discard them.
 //
 // Structure (exact-fp32 MFMA 32x32x2, online softmax):
-//   block = 8 waves = 256 query rows of one (c, h); wave = 32 query rows, its Q fragment lives in 32 VGPRs.
+//   block = 4 waves = 128 query rows of one (c, h); wave = 32 query rows, its Q fragment lives in 32 VGPRs.  Two blocks
+//   are resident per CU (the kernel needs ~256 VGPRs): one block's prologue/epilogue (strided q/k/v rows, ~10 us)
+//   hides behind the other's MFMAs, and the two waves of a SIMD belong to different blocks, so their softmax (VALU)
+//   and MFMA phases interleave instead of coinciding.  The i-blocks of one (c, h) share an XCD and re-read K/V from L2.
 //   Keys/values stream through LDS in 64-row chunks (double buffered, register-staged global loads issued before
 //   the MFMAs that hide them).
 //   Scores are computed TRANSPOSED, S^T = K Q^T (A = K rows, B = Q): the accumulator then holds the query row on the
@@ -18,8 +21,8 @@
 
 namespace rnamsm {
 
-constexpr int CA_THREADS = 512;
-constexpr int CA_ROWS = 256;          // query rows per block
+constexpr int CA_THREADS = 256;
+constexpr int CA_ROWS = 128;          // query rows per block
 constexpr int CA_JC = 64;             // keys per chunk
 constexpr int CA_HD = 64;             // head dim
 constexpr int CA_LDD = CA_HD + 4;     // padded LDS row stride (floats): 16 rows -> 16 distinct 16-B slots
@@ -53,13 +56,14 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
         for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const f32x4*>(qp + 8 * kk);
     }
 
-    // staging map: thread -> (key row tid/16 and +32, 16-B chunk tid%16) of the [64][64] K and V chunks
+    // staging map: thread -> (key rows tid/16 + 16*s, 16-B chunk tid%16) of the [64][64] K and V chunks
+    constexpr int NST = CA_JC * 16 / CA_THREADS, JSTEP = CA_THREADS / 16;
     const int d4 = threadIdx.x & 15, jr = threadIdx.x >> 4;
-    f32x4 sk[2], sv[2];
+    f32x4 sk[NST], sv[NST];
     auto load_chunk = [&](int ch) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int j = ch * CA_JC + jr + 32 * s;
+        for (int s = 0; s < NST; ++s) {
+            const int j = ch * CA_JC + jr + JSTEP * s;
             if (j < R) {
                 const int64_t off = (int64_t)j * C * ld + col_off + d4 * 4;
                 sk[s] = *reinterpret_cast<const f32x4*>(k + off);
@@ -72,9 +76,9 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            *reinterpret_cast<f32x4*>(&Ks[buf * CA_TILE + (jr + 32 * s) * CA_LDD + d4 * 4]) = sk[s];
-            *reinterpret_cast<f32x4*>(&Vs[buf * CA_TILE + (jr + 32 * s) * CA_LDD + d4 * 4]) = sv[s];
+        for (int s = 0; s < NST; ++s) {
+            *reinterpret_cast<f32x4*>(&Ks[buf * CA_TILE + (jr + JSTEP * s) * CA_LDD + d4 * 4]) = sk[s];
+            *reinterpret_cast<f32x4*>(&Vs[buf * CA_TILE + (jr + JSTEP * s) * CA_LDD + d4 * 4]) = sv[s];
         }
     };
 
@@ -83,10 +87,84 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
     for (int t = 0; t < 16; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
+    // K fragments of one 32-key tile: lane (key j, half) holds K[j][8kk + 4*half + s] (A operand of S^T = K Q^T)
+    f32x4 kf[8];
+    auto read_kfrags = [&](const float* Kc, int jt) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            kf[kk] = *reinterpret_cast<const f32x4*>(&Kc[(jt * 32 + li) * CA_LDD + 8 * kk + 4 * lh]);
+    };
+
+    // One 32-key tile, one basic block, order pinned (hipcc otherwise reuses one register quad for every K fragment
+    // and waits lgkmcnt(0) after each ds_read: the LDS latency was exposed every 4 MFMAs):
+    //   S^T = K Q^T   32 MFMAs on fragments already in registers, the 32 V values of this tile requested between them
+    //   softmax       VALU on the accumulator (query row = lane, keys = registers x lane half), hardware exp2
+    //   O^T += V^T P^T 32 MFMAs on the V registers, the NEXT tile's 8 K-fragment reads requested between them
+    auto tile = [&](const float* Kc, const float* Vc, int jt, int jbase, bool next_in_chunk) {
+        f32x16 s;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s[t] = 0.f;
+        float vv[32];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {       // MFMA step t of P.V contracts key (t&3)+8(t>>2)+4*half
+            const int jl = jt * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
+            vv[2 * t] = Vc[jl * CA_LDD + li];
+            vv[2 * t + 1] = Vc[jl * CA_LDD + 32 + li];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = mfma32(kf[kk][e], qf[kk][e], s);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);     // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- online softmax; keys >= R (last tile only) are masked branch-free.  __expf = v_exp_f32(x*log2e):
+        // relative error <= ~2e-6 for the |x| <= 20 that matter, 100x inside the parity bar.
+        const int limit = R - jbase;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            s[t] = ((t & 3) + 8 * (t >> 2) + 4 * lh < limit) ? s[t] : -INFINITY;
+        float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);                    // finite: key jbase is valid
+        const float alpha = __expf(m_run - m_new);               // 0 on the first tile
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            s[t] = __expf(s[t] - m_new);
+            psum += s[t];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- O^T += V^T P^T: register t of P, as it stands, is the B operand of step t
+        if (next_in_chunk) read_kfrags(Kc, jt + 1);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            o0 = mfma32(vv[2 * t], s[t], o0);
+            o1 = mfma32(vv[2 * t + 1], s[t], o1);
+        }
+        if (next_in_chunk) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     const int nch = (R + CA_JC - 1) / CA_JC;
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
+    if (active) read_kfrags(Ks, 0);
 
     for (int ch = 0; ch < nch; ++ch) {
         const int cur = ch & 1;
@@ -95,55 +173,17 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
         if (active) {
             const float* Kc = Ks + cur * CA_TILE;
             const float* Vc = Vs + cur * CA_TILE;
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt) {
-                const int jbase = ch * CA_JC + jt * 32;
-                if (jbase < R) {                                                   // block-uniform
-                    // ---- S^T tile = K[32 keys] . Q^T[32 queries], K = 64 head dims
-                    f32x16 s;
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) s[t] = 0.f;
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        const f32x4 kf = *reinterpret_cast<const f32x4*>(&Kc[(jt * 32 + li) * CA_LDD + 8 * kk + 4 * lh]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) s = mfma32(kf[e], qf[kk][e], s);
-                    }
-                    // ---- mask keys >= R, online softmax (query row = lane, keys = registers x lane half)
-                    float mx = -INFINITY;
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const int j = jbase + (t & 3) + 8 * (t >> 2) + 4 * lh;
-                        if (j >= R) s[t] = -INFINITY;
-                        mx = fmaxf(mx, s[t]);
-                    }
-                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                    const float m_new = fmaxf(m_run, mx);                          // finite: key jbase is valid
-                    const float alpha = expf(m_run - m_new);                       // 0 on the first tile
-                    float psum = 0.f;
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        s[t] = expf(s[t] - m_new);
-                        psum += s[t];
-                    }
-                    l_run = l_run * alpha + psum;
-                    m_run = m_new;
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
-                    // ---- O^T += V^T P^T : step t contracts keys (t&3)+8(t>>2)+4*half, i.e. register t of P as it stands
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) {
-                        const int jl = jt * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
-                        const float v0 = Vc[jl * CA_LDD + li];
-                        const float v1 = Vc[jl * CA_LDD + 32 + li];
-                        o0 = mfma32(v0, s[t], o0);
-                        o1 = mfma32(v1, s[t], o1);
-                    }
-                }
+            const int jbase = ch * CA_JC;
+            if (jbase + 32 < R) {                                // block-uniform: both tiles of the chunk hold keys
+                tile(Kc, Vc, 0, jbase, true);
+                tile(Kc, Vc, 1, jbase + 32, false);
+            } else {
+                tile(Kc, Vc, 0, jbase, false);
             }
         }
         if (more) store_chunk(cur ^ 1);
         __syncthreads();
+        if (more && active) read_kfrags(Ks + (cur ^ 1) * CA_TILE, 0);
     }
 
     if (active) {
