@@ -111,6 +111,13 @@ int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_
 int rnamsm_pack_outputs(const float* x_final, const float* probs_all, float* emb, float* atp,
                         int C, int D, int num_layers, int H, void* stream);
 
+/* f1 -- contact head on the stacked row attentions (ContactPredictionHead.forward, modules.py:344-366 with
+ * symmetrize/apc, utils/tensor.py:98-113; model.py:412-414): row_attn [nch = L*H, C, C] (with <cls>) ->
+ * contacts [C-1, C-1] = sigmoid(regression(apc(symmetrize(row_attn[:, 1:, 1:])))).  weight [nch], bias [1]. */
+size_t rnamsm_contact_head_workspace_bytes(int C, int nch);
+int rnamsm_contact_head(const float* row_attn, const float* weight, const float* bias, float* contacts,
+                        void* workspace, size_t workspace_bytes, int C, int nch, void* stream);
+
 /* Whole forward, K0..K10 for one MSA, driven from C++ so that one call enqueues every launch
  * (MSATransformer.forward, model.py:338-416, with repr_layers=[num_layers], need_head_weights=True,
  * lm_head / contact head omitted -- their results are unused by the CLI).

@@ -190,6 +190,30 @@ def pack_outputs(result: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.T
     return emb.contiguous(), att.reshape(-1, L, L).contiguous()
 
 
+def lm_head(features: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """RobertaLMHead.forward (modules.py:312-319): dense -> gelu (erf form, modules.py:11-20) -> layer_norm ->
+    tied projection + bias.  features [..., D] -> logits [..., vocab]."""
+    x = linear(features, params["lm_head.dense.weight"], params["lm_head.dense.bias"])
+    x = gelu_erf(x)
+    x = layer_norm(x, params["lm_head.layer_norm.weight"], params["lm_head.layer_norm.bias"])
+    return x @ params["lm_head.weight"].t() + params["lm_head.bias"]
+
+
+def contact_head(row_attentions: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """ContactPredictionHead.forward (modules.py:344-366) for the RNA alphabet (prepend_bos, no eos) with
+    symmetrize / apc (utils/tensor.py:98-113).  row_attentions [NL, H, C, C] -> contacts [C-1, C-1]."""
+    a = row_attentions[..., 1:, 1:]
+    T = a.shape[-1]
+    a = a.reshape(-1, T, T)
+    a = a + a.transpose(-1, -2)
+    a1 = a.sum(-1, keepdim=True)
+    a2 = a.sum(-2, keepdim=True)
+    a12 = a.sum((-1, -2), keepdim=True)
+    a = a - (a1 * a2) / a12
+    z = torch.einsum("cij,c->ij", a, weight.reshape(-1)) + bias.reshape(())
+    return torch.sigmoid(z)
+
+
 def to_torch_params(state: Dict[str, "object"], dtype=torch.float32) -> Dict[str, torch.Tensor]:
     """numpy / torch state_dict -> torch CPU tensors of `dtype`."""
     out = {}

@@ -3,8 +3,9 @@
 Same constructor keywords, `forward(tokens[B,R,C], repr_layers, need_head_weights, return_contacts)`
 result dict, `max_tokens_per_msa_`, and the 275-key state_dict (strict load of a Lightning
 `.ckpt['state_dict']`, RNA_MSM_Inference.py:133-135).  `lm_head.*` and `contact_head.*` parameters are
-held so that strict loading works, but their heads are outside this path:
-"logits" is None and `return_contacts=True` raises.
+held so that strict loading works.  `return_contacts=True` runs the contact head kernel (§8 f1).  The LM head
+(§8 f4) is computed on request (`need_logits=True` or `model.compute_logits = True`): the reference always
+computes it and its CLI always discards it, so by default "logits" is None.
 """
 from __future__ import annotations
 
@@ -20,7 +21,7 @@ from .modules import AxialTransformerLayer
 
 
 class _LMHeadParams(nn.Module):
-    """Parameter holder for the reference's RobertaLMHead keys (modules.py:303-319); not executed."""
+    """Parameters of the reference's RobertaLMHead (modules.py:303-319); run by MSATransformer.lm_logits."""
 
     def __init__(self, embed_dim: int, output_dim: int, weight: nn.Parameter):
         super().__init__()
@@ -31,7 +32,7 @@ class _LMHeadParams(nn.Module):
 
 
 class _ContactHeadParams(nn.Module):
-    """Parameter holder for contact_head.regression.* (modules.py:322-366); not executed."""
+    """Parameter holder for contact_head.regression.* (modules.py:322-366); executed by ops.contact_head."""
 
     def __init__(self, in_features: int):
         super().__init__()
@@ -76,6 +77,8 @@ class MSATransformer(nn.Module):
         self._pack_key = None
         self._pack = None
         self._workspace = None
+        self._lm_pad = None
+        self.compute_logits = False
 
     # ------------------------------------------------------------------ reference API
     def max_tokens_per_msa_(self, value: int) -> None:
@@ -136,6 +139,27 @@ class MSATransformer(nn.Module):
             self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self._workspace
 
+    # ------------------------------------------------------------------ LM head (§8 f4)
+    def lm_logits(self, features: torch.Tensor) -> torch.Tensor:
+        """RobertaLMHead.forward (modules.py:312-319): layer_norm(gelu_erf(dense(x))) @ weight.T + bias.
+        features [..., D] (output of emb_layer_norm_after) -> logits [..., vocab].  The projection weight
+        (tied to embed_tokens, 12 rows) is zero-padded to one 128-row GEMM tile."""
+        lm = self.lm_head
+        D, V = self.embed_dim, lm.bias.numel()
+        x2 = features.contiguous().view(-1, D)
+        key = (lm.weight.data_ptr(), lm.weight._version, lm.bias.data_ptr(), lm.bias._version)
+        if self._lm_pad is None or self._lm_pad[0] != key:
+            wpad = torch.zeros(128, D, device=x2.device, dtype=torch.float32)
+            bpad = torch.zeros(128, device=x2.device, dtype=torch.float32)
+            wpad[:V] = lm.weight.detach()
+            bpad[:V] = lm.bias.detach()
+            self._lm_pad = (key, wpad, bpad)
+        _, wpad, bpad = self._lm_pad
+        h = ops.linear(x2, lm.dense.weight.detach(), lm.dense.bias.detach(), act=_lib.ACT_GELU_ERF)
+        h = ops.layernorm(h, lm.layer_norm.weight.detach(), lm.layer_norm.bias.detach(), lm.layer_norm.eps)
+        out = ops.linear(h, wpad, bpad)
+        return out[:, :V].contiguous().view(*features.shape[:-1], V)
+
     # ------------------------------------------------------------------ forward
     def forward_one(self, tokens2d: torch.Tensor) -> Dict[str, torch.Tensor]:
         """One MSA through the C++ driver (rnamsm_forward): tokens int64 [R, C] on the HIP device ->
@@ -190,16 +214,20 @@ class MSATransformer(nn.Module):
             reps[self.num_layers] = xf.permute(2, 0, 1, 3)
         return reps, torch.stack(rows, 1)                                           # [1,NL,H,C,C]
 
-    def forward(self, tokens, repr_layers=[], need_head_weights=False, return_contacts=False):
+    def forward(self, tokens, repr_layers=[], need_head_weights=False, return_contacts=False, need_logits=None):
         if return_contacts:
-            raise NotImplementedError("contact head is outside this path (SURVEY.md §8 f1)")
+            need_head_weights = True
         assert tokens.ndim == 3
         B, R, C = tokens.shape
         if not tokens.is_cuda:
             raise _lib.RnamsmError("tokens must be on the HIP device (no CPU path exists)")
         if bool((tokens == self.vocab.pad_idx).any()):
             raise NotImplementedError("padding masks are not implemented (SURVEY.md §8 f2)")
+        need_logits = self.compute_logits if need_logits is None else need_logits
         repr_set = set(repr_layers)
+        want = set(repr_set)
+        if need_logits:
+            repr_set = repr_set | {self.num_layers}
         reps: Dict[int, List[torch.Tensor]] = {i: [] for i in repr_set}
         atts: List[torch.Tensor] = []
         fast = repr_set <= {self.num_layers}
@@ -216,7 +244,13 @@ class MSATransformer(nn.Module):
                 for i in repr_set:
                     reps[i].append(r[i])
                 atts.append(a)
-        result = {"logits": None, "representations": {i: torch.cat(v, 0) for i, v in reps.items()}}
+        full = {i: torch.cat(v, 0) for i, v in reps.items()}
+        logits = self.lm_logits(full[self.num_layers]) if need_logits else None     # model.py:402
+        result = {"logits": logits, "representations": {i: v for i, v in full.items() if i in want}}
         if need_head_weights:
             result["row_attentions"] = torch.cat(atts, 0)                           # [B, NL, H, C, C]
+        if return_contacts:                                                         # model.py:412-414
+            reg = self.contact_head.regression
+            result["contacts"] = torch.stack(
+                [ops.contact_head(a[0], reg.weight.detach(), reg.bias.detach()) for a in atts], 0)
         return result

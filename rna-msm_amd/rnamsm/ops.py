@@ -125,6 +125,19 @@ def pack_outputs(x_final: torch.Tensor, probs_all: torch.Tensor, C: int) -> Tupl
     return emb, atp
 
 
+def contact_head(row_attn: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """row_attn [NL, H, C, C] (or [NL*H, C, C]) -> contacts [C-1, C-1] (modules.py:344-366)."""
+    C = row_attn.shape[-1]
+    nch = row_attn.numel() // (C * C)
+    lib = _lib.load()
+    ws = torch.empty(lib.rnamsm_contact_head_workspace_bytes(C, nch), dtype=torch.uint8, device=row_attn.device)
+    out = torch.empty(C - 1, C - 1, device=row_attn.device, dtype=torch.float32)
+    _lib.check(lib.rnamsm_contact_head(_dev(row_attn.contiguous(), "row_attn"), _dev(weight.contiguous().view(-1), "weight"),
+                                       _dev(bias.contiguous().view(-1), "bias"), _dev(out, "contacts"), ws.data_ptr(),
+                                       ws.numel(), C, nch, _stream()))
+    return out
+
+
 def row_scaling(R: int) -> float:
     """RowSelfAttention.align_scaling (modules.py:713-715)."""
     return (HEAD_DIM ** -0.5) / math.sqrt(R)

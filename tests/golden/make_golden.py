@@ -167,7 +167,7 @@ def gen_forward(vocab):
         model.eval()
         toks = synthetic.make_tokens(M, C, msa_index={"m8_c17": 0, "m8_c17_chunk": 0, "m16_c33": 1, "m5_c41": 2}[name])
         reps = list(range(0, 11))
-        res = model(t(toks)[None], repr_layers=reps, need_head_weights=True)
+        res = model(t(toks)[None], repr_layers=reps, need_head_weights=True, return_contacts=True)
         att = res["row_attentions"]                                   # [1, 10, 12, C, C]
         # extract_feat's slicing (RNA_MSM_Inference.py:151-166)
         atp = att[..., 1:, 1:].reshape(-1, C - 1, C - 1).numpy()
@@ -176,7 +176,8 @@ def gen_forward(vocab):
         row0 = np.stack([res["representations"][i][0, 0].numpy() for i in (0, 1, 5)], 0)   # [3, C, D] probes
         save(f"forward_{name}.npz", meta=np.array([M, C, max_tokens]), tokens=toks, emb=emb, atp=atp,
              layer_absmean=absmean, probe_row0_layers_0_1_5=row0,
-             attn_full_layer0=att[0, 0].numpy())
+             attn_full_layer0=att[0, 0].numpy(), contacts=res["contacts"][0].numpy(),
+             logits=res["logits"][0].numpy())
         # fp64 run of the same model: the reference's own fp32 noise floor for these inputs
         m64 = model.double()
         r64 = m64(t(toks)[None], repr_layers=[10], need_head_weights=True)

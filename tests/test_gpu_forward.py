@@ -46,6 +46,34 @@ def test_forward_matches_reference_fixture(model, name):
     assert torch.equal(out2["emb"], out["emb"]) and torch.equal(out2["atp"], out["atp"])
 
 
+@pytest.mark.parametrize("name", ["m8_c17", "m16_c33", "m5_c41"])
+def test_contact_head_and_lm_head_match_reference_fixture(model, name):
+    """§8 f1 / f4: MSATransformer.forward(return_contacts=True) and the LM-head logits vs the reference's outputs."""
+    m, _ = model
+    g = golden(f"forward_{name}.npz")
+    toks = torch.from_numpy(g["tokens"]).to("cuda:0")
+    res = m(toks[None], repr_layers=[10], return_contacts=True, need_logits=True)
+    assert res["contacts"].shape == (1,) + g["contacts"].shape
+    assert np.abs(res["contacts"][0].cpu().numpy() - g["contacts"]).max() < 1e-5
+    assert res["logits"].shape == (1,) + g["logits"].shape
+    assert rel_l2(res["logits"][0].cpu().numpy(), g["logits"]) < 1e-4
+    assert m(toks[None], need_head_weights=True)["logits"] is None          # default: the CLI never reads them
+    assert torch.equal(m.predict_contacts(toks[None]), res["contacts"])
+
+
+def test_contact_head_kernel_on_random_maps_with_large_weights(model):
+    """The synthetic regression weights are small (contacts stay near 0.5); drive the kernel with O(1) weights and
+    ragged sizes against the oracle's symmetrize/apc/logistic."""
+    from rnamsm import ops
+    for C, nch in ((2, 3), (9, 5), (34, 120), (130, 24)):
+        a = torch.softmax(torch.from_numpy(synthetic.normal(f"ch{C}", 5, (nch, C, C))).float() * 3, -1)
+        w = torch.from_numpy(synthetic.normal(f"chw{C}", 5, (1, nch))).float() * 20
+        b = torch.tensor([0.3])
+        got = ops.contact_head(a.cuda(), w.cuda(), b.cuda()).cpu().numpy()
+        want = O.contact_head(a.double(), w.double(), b.double()).numpy()
+        assert got.shape == (C - 1, C - 1) and np.abs(got - want).max() < 2e-5, C
+
+
 def test_forward_error_vs_fp64_truth_is_at_the_reference_noise_floor(model):
     m, _ = model
     for name in ("m8_c17", "m16_c33"):

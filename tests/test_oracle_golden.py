@@ -95,6 +95,11 @@ def test_forward_matches_reference(name, full_state):
     assert rel_l2(emb, g["emb"]) < 1e-5
     assert np.abs(atp.numpy() - g["atp"]).max() < 2e-5
     assert np.abs(res["row_attentions"][0].numpy() - g["attn_full_layer0"]).max() < 2e-5
+    # f1 contact head and f4 LM head of the same forward (model.py:402, 412-414)
+    c = O.contact_head(res["row_attentions"], params["contact_head.regression.weight"], params["contact_head.regression.bias"])
+    assert c.shape == g["contacts"].shape and np.abs(c.numpy() - g["contacts"]).max() < 2e-6
+    logits = O.lm_head(res["representation"], params)
+    assert logits.shape == g["logits"].shape and rel_l2(logits, g["logits"]) < 1e-5
 
 
 @pytest.mark.parametrize("name", ["m8_c17", "m16_c33"])
