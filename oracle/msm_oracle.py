@@ -190,6 +190,19 @@ def pack_outputs(result: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.T
     return emb.contiguous(), att.reshape(-1, L, L).contiguous()
 
 
+def multihead_self_attention(x: torch.Tensor, params, prefix: str, num_heads: int) -> torch.Tensor:
+    """Self-attention path of msm/multihead_attention.py:154-397 (no masks, no bias_kv, eval): q = q_proj(x)*dh^-0.5
+    (:256), bmm (:349), softmax (:371), bmm (:379), out_proj (:387).  x [T, B, E] -> [T, B, E]."""
+    T, B, E = x.shape
+    dh = E // num_heads
+    q = (linear(x, _p(params, prefix, "q_proj.weight"), _p(params, prefix, "q_proj.bias")) * dh ** -0.5).view(T, B, num_heads, dh)
+    k = linear(x, _p(params, prefix, "k_proj.weight"), _p(params, prefix, "k_proj.bias")).view(T, B, num_heads, dh)
+    v = linear(x, _p(params, prefix, "v_proj.weight"), _p(params, prefix, "v_proj.bias")).view(T, B, num_heads, dh)
+    p = torch.softmax(torch.einsum("ibhd,jbhd->bhij", q, k), -1)
+    ctx = torch.einsum("bhij,jbhd->ibhd", p, v).reshape(T, B, E)
+    return linear(ctx, _p(params, prefix, "out_proj.weight"), _p(params, prefix, "out_proj.bias"))
+
+
 def lm_head(features: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor:
     """RobertaLMHead.forward (modules.py:312-319): dense -> gelu (erf form, modules.py:11-20) -> layer_norm ->
     tied projection + bias.  features [..., D] -> logits [..., vocab]."""

@@ -98,7 +98,7 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
     with torch.no_grad():
         for idx in mine:
             rna_id = ids[idx]
-            tokens = load_msa_tokens(files[rna_id], alphabet, cfg.data.max_seqs_per_msa, cfg.data.sample_method)
+            tokens = load_msa_tokens(files[rna_id], alphabet, cfg.data.max_seqs_per_msa, cfg.data.sample_method, device=device)
             tokens = crop_tokens(tokens, cfg.data.max_seqlen, rng)
             out = model.forward_one(torch.from_numpy(tokens).to(device))
             if int(out["err"].item()) != 0:

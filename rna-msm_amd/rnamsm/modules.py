@@ -197,3 +197,42 @@ class AxialTransformerLayer(nn.Module):
         if need_head_weights:
             return x, column_attn, row_attn
         return x
+
+
+class MultiheadAttention(_AxialAttentionBase):
+    """Generic 1-D self-attention entry point; mirrors the self-attention path of the reference's
+    fairseq-style MultiheadAttention (msm/multihead_attention.py:66-397: q*scaling -> bmm -> softmax -> bmm ->
+    out_proj) and loads its q_proj / k_proj / v_proj / out_proj state_dict.
+
+    forward(query[T,B,E], key, value) with key/value the same tensor as query -> (attn[T,B,E], None).  In this
+    layout it IS the fused column-attention kernel with R := T and C := B (every batch element attends along T),
+    so T <= 1024 and head_dim 64.  Everything outside plain eval-mode self-attention raises: masks, incremental
+    state, bias_kv / zero_attn, cross-attention, and the averaged attention weights (the fused kernel never forms
+    the [B*H,T,T] probabilities)."""
+
+    def __init__(self, embed_dim, num_heads, kdim=None, vdim=None, dropout=0.0, bias=True, add_bias_kv=False,
+                 add_zero_attn=False, self_attention=False, encoder_decoder_attention=False):
+        if not bias or add_bias_kv or add_zero_attn or encoder_decoder_attention:
+            raise NotImplementedError("only biased self-attention without bias_kv / zero_attn is implemented")
+        if (kdim not in (None, embed_dim)) or (vdim not in (None, embed_dim)):
+            raise NotImplementedError("kdim / vdim must equal embed_dim (self-attention)")
+        super().__init__(embed_dim, num_heads, dropout=dropout)
+        self.embed_dim = embed_dim
+        self.self_attention = True
+
+    def forward(self, query, key=None, value=None, key_padding_mask=None, incremental_state=None, need_weights=False,
+                static_kv=False, attn_mask=None, before_softmax=False, need_head_weights=False):
+        if key_padding_mask is not None or attn_mask is not None or incremental_state is not None or static_kv:
+            raise NotImplementedError("masks / incremental decoding are not implemented")
+        if need_weights or need_head_weights or before_softmax:
+            raise NotImplementedError("attention weights are never materialised by the fused kernel")
+        if (key is not None and key is not query) or (value is not None and value is not query):
+            raise NotImplementedError("only self-attention (key = value = query) is implemented")
+        _check_inference(self, self.dropout)
+        if query.dim() != 3:
+            raise ValueError(f"expected query of shape [T, B, E], got {tuple(query.shape)}")
+        T, B, E = query.shape
+        x2 = query.contiguous().view(T * B, E)
+        qkv = self._qkv(x2, self.scaling)
+        ctx = ops.col_attn(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], T, B, self.num_heads)
+        return self._project_out(ctx, None).view(T, B, E), None

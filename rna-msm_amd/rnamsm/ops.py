@@ -138,6 +138,20 @@ def contact_head(row_attn: torch.Tensor, weight: torch.Tensor, bias: torch.Tenso
     return out
 
 
+def greedy_select(msa_u8: torch.Tensor, num_seqs: int, mode: str = "max") -> torch.Tensor:
+    """msa uint8 [N, L] on the device -> int32 [num_seqs] ascending row indices (utils/align.py:128-148)."""
+    if mode not in ("max", "min"):
+        raise AssertionError(mode)
+    N, L = msa_u8.shape
+    lib = _lib.load()
+    ws = torch.empty(lib.rnamsm_greedy_select_workspace_bytes(N, num_seqs), dtype=torch.uint8, device=msa_u8.device)
+    out = torch.empty(num_seqs, dtype=torch.int32, device=msa_u8.device)
+    _lib.check(lib.rnamsm_greedy_select(_dev(msa_u8.contiguous(), "msa", torch.uint8), N, L, num_seqs,
+                                        1 if mode == "min" else 0, _dev(out, "out", torch.int32), ws.data_ptr(),
+                                        ws.numel(), _stream()))
+    return out
+
+
 def row_scaling(R: int) -> float:
     """RowSelfAttention.align_scaling (modules.py:713-715)."""
     return (HEAD_DIM ** -0.5) / math.sqrt(R)

@@ -189,6 +189,18 @@ def gen_forward(vocab):
             save(f"forward_{name}_fp64.npz", emb=emb64.astype(np.float64), atp=atp64.astype(np.float64))
 
 
+def gen_mha():
+    """Generic 1-D MHA (msm/multihead_attention.py) self-attention, [T,B,E] in -> [T,B,E] out."""
+    from msm.multihead_attention import MultiheadAttention
+    for name, T, B, E, H in (("t37_b3_e128", 37, 3, 128, 2), ("t70_b2_e768", 70, 2, 768, 12)):
+        state = synthetic.make_state_dict(seed=11, embed_dim=E, num_layers=1, num_heads=H)
+        mha = MultiheadAttention(E, H, self_attention=True)
+        load_into(mha, state, "layers.0.row_self_attention.layer")       # same four Linear key names
+        x = t(synthetic.normal(f"mha:{name}", 11, (T, B, E)).astype(np.float32))
+        y, w = mha(x, x, x, need_weights=True)
+        save(f"mha_{name}.npz", meta=np.array([T, B, E, H]), out=y.numpy(), avg_weights=w.numpy())
+
+
 def gen_shapes():
     info = {}
     for kind in ("emb", "atp"):
@@ -203,4 +215,5 @@ if __name__ == "__main__":
     print("tokens"); vocab = gen_tokens()
     print("ops"); gen_ops()
     print("forward"); gen_forward(vocab)
+    print("mha"); gen_mha()
     print("shapes"); gen_shapes()

@@ -229,3 +229,47 @@ def test_modules_match_reference_fixtures(dev, name):
     assert np.abs(rp.cpu().numpy()[:, 0] - g["layer_row_probs"]).max() < TOL_PROB
     with pytest.raises(NotImplementedError):
         row(x, self_attn_mask=torch.zeros(1))
+
+
+@pytest.mark.parametrize("name", ["t37_b3_e128", "t70_b2_e768"])
+def test_generic_mha_matches_reference_fixture(dev, name):
+    """the 1-D MHA entry point ([T,B,E] self-attention) against msm/multihead_attention.py's output."""
+    from rnamsm import modules as M
+    g = golden(f"mha_{name}.npz")
+    T, B, E, H = (int(v) for v in g["meta"])
+    state = synthetic.make_state_dict(seed=11, embed_dim=E, num_layers=1, num_heads=H)
+    prefix = "layers.0.row_self_attention.layer"
+    mha = M.MultiheadAttention(E, H, self_attention=True)
+    mha.load_state_dict({k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in state.items() if k.startswith(prefix + ".")},
+                        strict=True)
+    mha = mha.eval().to(dev)
+    x = torch.from_numpy(synthetic.normal(f"mha:{name}", 11, (T, B, E)).astype(np.float32)).to(dev)
+    y, w = mha(x, x, x)
+    assert w is None and y.shape == (T, B, E)
+    assert rel_l2(y.cpu(), g["out"]) < TOL_REL
+    with pytest.raises(NotImplementedError):
+        mha(x, x, x, need_weights=True)
+    with pytest.raises(NotImplementedError):
+        mha(x, x, x, key_padding_mask=torch.zeros(B, T, dtype=torch.bool, device=dev))
+
+
+def test_greedy_select_on_device_equals_host_and_reference(dev):
+    """device greedy max/min-Hamming sub-sampling picks exactly the reference's rows (fixture from
+    MSA.greedy_select) and exactly the host implementation's rows on larger random alignments with many ties."""
+    import os
+    from conftest import GOLDEN
+    from rnamsm import msa
+    from rnamsm.alphabet import RNAAlphabet
+    g = golden("tokens_2DRB_1_first64.npz")
+    path = os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2")
+    a = RNAAlphabet()
+    assert np.array_equal(msa.load_msa_tokens(path, a, 16, "diversity-max", device=dev), g["diversity_max_16"])
+    assert np.array_equal(msa.load_msa_tokens(path, a, 16, "diversity-min", device=dev), g["diversity_min_16"])
+    rng = np.random.RandomState(3)
+    for N, L, K in ((50, 7, 50), (300, 33, 40), (5000, 120, 64), (1500, 513, 17)):
+        toks = np.concatenate([np.zeros((N, 1), np.int64), rng.choice([4, 5, 6, 7, 10], size=(N, L), p=[.3, .3, .2, .1, .1])], 1)
+        toks[rng.randint(0, N, N // 3)] = toks[0]            # duplicated rows: exact ties, first index must win
+        for mode in ("max", "min"):
+            want = msa.greedy_select(toks, K, mode)
+            got = msa.greedy_select_device(toks, K, mode, dev)
+            assert np.array_equal(got, want), (N, L, K, mode)

@@ -128,3 +128,13 @@ def test_rejects_more_than_1024_rows_and_padding(full_state):
     toks[1, 3] = 1
     with pytest.raises(NotImplementedError):
         O.forward(toks, params)
+
+
+@pytest.mark.parametrize("name", ["t37_b3_e128", "t70_b2_e768"])
+def test_generic_mha_matches_reference(name):
+    g = golden(f"mha_{name}.npz")
+    T, B, E, H = (int(v) for v in g["meta"])
+    st = O.to_torch_params(synthetic.make_state_dict(seed=11, embed_dim=E, num_layers=1, num_heads=H))
+    x = torch.from_numpy(synthetic.normal(f"mha:{name}", 11, (T, B, E)).astype(np.float32))
+    y = O.multihead_self_attention(x, st, "layers.0.row_self_attention.layer", H)
+    assert rel_l2(y, g["out"]) < 1e-5
