@@ -67,11 +67,13 @@ int rnamsm_layernorm(const float* x, const float* gamma, const float* beta, floa
  *   Cout[m,n] = act( (sum_k A[m,k]*W[n,k] + bias[n]) * (n < scale_cols ? scale : 1) ) + residual[m,n]
  * A [M,K] row stride lda; W [N,K] contiguous (torch Linear layout); bias [N] or NULL;
  * residual [M,N] row stride ldr or NULL; Cout [M,N] row stride ldc (may alias residual).
- * Requires N % 128 == 0, K % 32 == 0, lda/ldr/ldc % 4 == 0 and 16-byte aligned pointers. */
+ * Requires N % 128 == 0, K % 32 == 0, lda/ldr/ldc % 4 == 0 and 16-byte aligned pointers.
+ * zero_rows (uint8 [M], may be NULL): rows flagged 1 get 0 in the scaled columns -- the reference's
+ * `q *= 1 - padding_mask` (modules.py:767-772). */
 int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float* W, const float* bias,
                              const float* residual, int64_t ldr, float* Cout, int64_t ldc,
                              int64_t M, int N, int K, int act, float scale, int scale_cols,
-                             int dtype, void* stream);
+                             const uint8_t* zero_rows, int dtype, void* stream);
 
 /* K4 -- tied row-attention logits, RowSelfAttention.compute_attention_weights (modules.py:752-786):
  *   S[h,i,j] = sum_{r,d} q[r,i,h,d] * k[r,j,h,d]      (q already scaled by dh^-0.5/sqrt(R), K3)
@@ -87,8 +89,10 @@ int rnamsm_row_logits(const float* q, const float* k, int64_t ld, float* partial
 
 /* K5 -- softmax over the last axis of the summed logits (modules.py:818 / 739):
  *   probs[h,i,:] = softmax_j( sum_s partial[s,h,i,:] ).  probs [H, C, C] is the layer's
- *   row_attentions slab (model.py:392). */
-int rnamsm_softmax_rows(const float* partial, int nsplit, float* probs, int H, int C, void* stream);
+ *   row_attentions slab (model.py:392).  key_mask (uint8 [C], may be NULL): keys flagged 1 have their summed
+ *   logit replaced by -10000 first (masked_fill with padding_mask[:, 0], modules.py:781-785). */
+int rnamsm_softmax_rows(const float* partial, int nsplit, float* probs, int H, int C,
+                        const uint8_t* key_mask, void* stream);
 
 /* K6 -- RowSelfAttention.compute_attention_update's contraction (modules.py:797-798):
  *   ctx[r,i,h,:] = sum_j probs[h,i,j] * v[r,j,h,:]
@@ -99,10 +103,14 @@ int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, float* ctx,
 /* K7 -- ColumnSelfAttention.compute_attention_update's attention (modules.py:905-921), fused:
  *   for every column c and head h: ctx[:,c,h,:] = softmax_j( q[:,c,h,:] k[:,c,h,:]^T ) v[:,c,h,:]
  * (q already scaled by dh^-0.5).  The [H,C,R,R] probabilities are never written (the reference
- * computes and discards them).  R == 1 degenerates to ctx = v (modules.py:882-894). */
+ * computes and discards them).  R == 1 degenerates to ctx = v (modules.py:882-894).
+ * pad_mask (uint8 [R, C], may be NULL): scores of keys flagged 1 are replaced by -10000 (modules.py:911-915). */
 int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_t ld,
                           float* ctx, int64_t ldc, int R, int C, int H, int head_dim,
-                          int dtype, void* stream);
+                          const uint8_t* pad_mask, int dtype, void* stream);
+
+/* f2 -- padding_mask = tokens.eq(pad_idx) (model.py:346): mask uint8 [n]. */
+int rnamsm_pad_mask(const int64_t* tokens, uint8_t* mask, int64_t n, int pad_idx, void* stream);
 
 /* K10 -- extract_feat's output section (RNA_MSM_Inference.py:151-166):
  *   emb[c-1, :]            = x_final[row 0, c, :]                c = 1..C-1      -> [C-1, D]
@@ -156,11 +164,13 @@ size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int 
 /* tokens int64 [R,C]; weights: host array of (RNAMSM_W_GLOBAL_COUNT + L*RNAMSM_W_LAYER_COUNT)
  * device pointers; workspace >= rnamsm_forward_workspace_bytes; row_attn [L,H,C,C] (full, with
  * <cls>), repr [R*C, D] (after emb_layer_norm_after), emb [C-1, D], atp [L*H, C-1, C-1]; all four are
- * required outputs. */
+ * required outputs.  has_padding != 0: the MSA contains <pad> tokens; the driver builds the padding mask and applies
+ * the reference's direct-path mask semantics (§8 f2): zeroed embeddings and q at padded tokens, -10000 on keys whose
+ * first-row token is <pad> (row attention) and on padded keys (column attention). */
 int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
                    int R, int C, void* workspace, size_t workspace_bytes,
                    float* row_attn, float* repr, float* emb, float* atp,
-                   int* err_flag, int dtype, void* stream);
+                   int* err_flag, int has_padding, int dtype, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's
  * roofline block; adds two event records per launch while enabled, nothing when disabled).

@@ -12,8 +12,10 @@ tests of its own for this path.
 
 Every function cites the reference lines it restates (paths relative to /root/reference).
 Layout: one MSA (B=1) is held as x[R, C, D] (reference: [R, C, B=1, D]); token t = r*C + c.
-Padding masks / B>1 are out of scope this round: inputs containing <pad>
-are rejected.
+Padding masks follow the reference's DIRECT path (max_tokens_per_msa large): with padding the
+reference's chunked path fills -10000 per chunk using each chunk's first row (modules.py:727-737), a quirk that
+changes nothing unless every key of a query is masked; the kernels tile internally, so the direct semantics are
+the contract.  A batch is processed one MSA at a time (B is a loop).
 """
 from __future__ import annotations
 
@@ -65,24 +67,34 @@ def embed(tokens: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor
     x = params["embed_tokens.weight"][tokens]
     x = x + params["embed_positions.weight"][positions_from_tokens(tokens)]
     x = x + params["msa_position_embedding"][0, :R]                 # [R,1,1] broadcast
-    return layer_norm(x, params["emb_layer_norm_before.weight"], params["emb_layer_norm_before.bias"])
+    x = layer_norm(x, params["emb_layer_norm_before.weight"], params["emb_layer_norm_before.bias"])
+    pad = tokens == PAD_IDX
+    if bool(pad.any()):                                             # model.py:366-367
+        x = x * (1 - pad.unsqueeze(-1).to(x.dtype))
+    return x
 
 
 def row_attention_logits(x: torch.Tensor, params, prefix: str, num_heads: int,
-                         scaling: float) -> torch.Tensor:
-    """RowSelfAttention.compute_attention_weights (modules.py:752-786), no padding mask.
-    x [r, C, D] (a chunk of rows) -> logits [H, C, C] summed over those rows and head_dim."""
+                         scaling: float, pad: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """RowSelfAttention.compute_attention_weights (modules.py:752-786).
+    x [r, C, D] (a chunk of rows) -> logits [H, C, C] summed over those rows and head_dim.  pad [r, C] bool:
+    q is zeroed at padded tokens (:767-772) and keys whose first-row token is padded are filled with -10000 (:781-785)."""
     r, C, D = x.shape
     dh = D // num_heads
     q = linear(x, _p(params, prefix, "q_proj.weight"), _p(params, prefix, "q_proj.bias")) * scaling
     k = linear(x, _p(params, prefix, "k_proj.weight"), _p(params, prefix, "k_proj.bias"))
+    if pad is not None:
+        q = q * (1 - pad.unsqueeze(-1).to(q.dtype))
     q = q.view(r, C, num_heads, dh)
     k = k.view(r, C, num_heads, dh)
-    return torch.einsum("rihd,rjhd->hij", q, k)
+    w = torch.einsum("rihd,rjhd->hij", q, k)
+    if pad is not None:
+        w = w.masked_fill(pad[0][None, None, :], -10000)
+    return w
 
 
 def row_attention(x: torch.Tensor, params, prefix: str, num_heads: int,
-                  max_tokens: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                  max_tokens: Optional[int] = None, pad: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """RowSelfAttention.forward / _batched_forward (modules.py:802-821, 717-750).
     Returns (out [R,C,D], probs [H,C,C]).  With max_tokens set and R*C > max_tokens the row-chunked
     accumulate-then-softmax order of _batched_forward is reproduced (same math, different
@@ -90,7 +102,9 @@ def row_attention(x: torch.Tensor, params, prefix: str, num_heads: int,
     R, C, D = x.shape
     dh = D // num_heads
     scaling = (dh ** -0.5) / math.sqrt(R)                          # align_scaling, modules.py:713-715
-    if max_tokens is not None and R * C > max_tokens:
+    if pad is not None:                                             # direct-path semantics (see module docstring)
+        logits = row_attention_logits(x, params, prefix, num_heads, scaling, pad)
+    elif max_tokens is not None and R * C > max_tokens:
         max_rows = max(1, max_tokens // C)                          # modules.py:724
         logits = 0
         for s in range(0, R, max_rows):
@@ -105,7 +119,7 @@ def row_attention(x: torch.Tensor, params, prefix: str, num_heads: int,
 
 
 def col_attention(x: torch.Tensor, params, prefix: str, num_heads: int,
-                  return_probs: bool = False, col_chunk: int = 64):
+                  return_probs: bool = False, col_chunk: int = 64, pad: Optional[torch.Tensor] = None):
     """ColumnSelfAttention.compute_attention_update (modules.py:875-924), no padding mask.
     Column slabs are independent (modules.py:849-873) so they are processed `col_chunk` at a time to
     keep the [H, c, R, R] probabilities small; probs are returned only on request (the reference
@@ -127,6 +141,8 @@ def col_attention(x: torch.Tensor, params, prefix: str, num_heads: int,
     for s in range(0, C, col_chunk):
         e = min(C, s + col_chunk)
         w = torch.einsum("ichd,jchd->hcij", q[:, s:e], k[:, s:e])   # modules.py:907
+        if pad is not None:                                         # modules.py:911-915: padded keys (rows j) of column c
+            w = w.masked_fill(pad[:, s:e].t()[None, :, None, :], -10000)
         p = torch.softmax(w, dim=-1)                                # modules.py:917
         ctx[:, s:e] = torch.einsum("hcij,jchd->ichd", p, v[:, s:e])  # modules.py:919
         if return_probs:
@@ -144,17 +160,17 @@ def ffn(x: torch.Tensor, params, prefix: str) -> torch.Tensor:
 
 
 def axial_layer(x: torch.Tensor, params, layer: int, num_heads: int,
-                max_tokens: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                max_tokens: Optional[int] = None, pad: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """AxialTransformerLayer.forward (modules.py:242-267) with each sub-block wrapped as
     NormalizedResidualBlock (modules.py:385-401): x + f(LN(x)); dropout is the identity in eval."""
     base = f"layers.{layer}"
     pre = f"{base}.row_self_attention"
     y, row_probs = row_attention(layer_norm(x, params[f"{pre}.layer_norm.weight"], params[f"{pre}.layer_norm.bias"]),
-                                 params, f"{pre}.layer", num_heads, max_tokens)
+                                 params, f"{pre}.layer", num_heads, max_tokens, pad)
     x = x + y
     pre = f"{base}.column_self_attention"
     x = x + col_attention(layer_norm(x, params[f"{pre}.layer_norm.weight"], params[f"{pre}.layer_norm.bias"]),
-                          params, f"{pre}.layer", num_heads)
+                          params, f"{pre}.layer", num_heads, pad=pad)
     pre = f"{base}.feed_forward_layer"
     x = x + ffn(layer_norm(x, params[f"{pre}.layer_norm.weight"], params[f"{pre}.layer_norm.bias"]),
                 params, f"{pre}.layer")
@@ -163,19 +179,19 @@ def axial_layer(x: torch.Tensor, params, layer: int, num_heads: int,
 
 def forward(tokens: torch.Tensor, params: Dict[str, torch.Tensor], num_layers: int = 10,
             num_heads: int = 12, max_tokens: Optional[int] = None,
-            layers_to_run: Optional[int] = None) -> Dict[str, torch.Tensor]:
+            layers_to_run: Optional[int] = None, force_mask: bool = False) -> Dict[str, torch.Tensor]:
     """MSATransformer.forward (model.py:338-416) for one MSA, need_head_weights=True,
     repr_layers=[num_layers]; lm_head / contact head are not on this path.
     tokens int64 [R, C].  Returns representation [R, C, D] (after emb_layer_norm_after,
     model.py:396-401) and row_attentions [num_layers, H, C, C] (model.py:392,409, B squeezed)."""
     assert tokens.ndim == 2
-    if bool((tokens == PAD_IDX).any()):
-        raise NotImplementedError("padding masks are out of scope (SURVEY §8 f2)")
+    pad = tokens == PAD_IDX
+    pad = pad if (bool(pad.any()) or force_mask) else None          # model.py:346-348
     x = embed(tokens, params)
     rows: List[torch.Tensor] = []
     n = num_layers if layers_to_run is None else layers_to_run
     for i in range(n):
-        x, pr = axial_layer(x, params, i, num_heads, max_tokens)
+        x, pr = axial_layer(x, params, i, num_heads, max_tokens, pad)
         rows.append(pr)
     x = layer_norm(x, params["emb_layer_norm_after.weight"], params["emb_layer_norm_after.bias"])
     return {"representation": x, "row_attentions": torch.stack(rows, 0)}

@@ -29,9 +29,10 @@ constexpr int CA_LDD = CA_HD + 4;     // padded LDS row stride (floats): 16 rows
 constexpr int CA_TILE = CA_JC * CA_LDD;
 constexpr int CA_LDS_BYTES = 2 * 2 * CA_TILE * 4;
 
+template <bool MASKED>   // MASKED: a padding mask is applied (f2); the un-masked instance carries no mask code at all
 __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
-    float* __restrict__ ctx, int64_t ldc, int R, int C, int H) {
+    float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                    // [2][CA_JC][CA_LDD]
     float* Vs = smem + 2 * CA_TILE;      // [2][CA_JC][CA_LDD]
@@ -127,6 +128,13 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
 #pragma unroll
         for (int t = 0; t < 16; ++t)
             s[t] = ((t & 3) + 8 * (t >> 2) + 4 * lh < limit) ? s[t] : -INFINITY;
+        if (MASKED) {       // f2: masked_fill(padding_mask, -10000) on padded keys of this column (modules.py:911-915)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = jbase + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                if (j < R && pad_mask[(int64_t)j * C + c]) s[t] = -10000.f;
+            }
+        }
         float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
         mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -208,7 +216,8 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
 using namespace rnamsm;
 
 extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_t ld, float* ctx,
-                                     int64_t ldc, int R, int C, int H, int head_dim, int dtype, void* stream) {
+                                     int64_t ldc, int R, int C, int H, int head_dim, const uint8_t* pad_mask,
+                                     int dtype, void* stream) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "col_attn: only RNAMSM_F32 is implemented");
     RNAMSM_CHECK_ARG(q && k && v && ctx, "col_attn: null pointer");
     RNAMSM_CHECK_ARG(head_dim == CA_HD, "col_attn: head_dim must be 64 (got %d)", head_dim);
@@ -218,17 +227,23 @@ extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float
     RNAMSM_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(ctx), "col_attn: 16-byte alignment");
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, CA_LDS_BYTES);
-        if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        for (const void* kern : {reinterpret_cast<const void*>(col_attn_kernel<false>),
+                                 reinterpret_cast<const void*>(col_attn_kernel<true>)}) {
+            hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, CA_LDS_BYTES);
+            if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
         configured = true;
     }
     const unsigned iblocks = (R + CA_ROWS - 1) / CA_ROWS;
     const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
     KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)R * R * CA_HD, 4.0 * 4.0 * R * C * H * CA_HD,
                       static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(col_attn_kernel, dim3(grid), dim3(CA_THREADS), CA_LDS_BYTES, static_cast<hipStream_t>(stream),
-                       q, k, v, ld, ctx, ldc, R, C, H);
+    if (pad_mask)
+        hipLaunchKernelGGL(col_attn_kernel<true>, dim3(grid), dim3(CA_THREADS), CA_LDS_BYTES,
+                           static_cast<hipStream_t>(stream), q, k, v, ld, ctx, ldc, R, C, H, pad_mask);
+    else
+        hipLaunchKernelGGL(col_attn_kernel<false>, dim3(grid), dim3(CA_THREADS), CA_LDS_BYTES,
+                           static_cast<hipStream_t>(stream), q, k, v, ld, ctx, ldc, R, C, H, pad_mask);
     RNAMSM_CHECK_LAUNCH("col_attn");
     return RNAMSM_OK;
 }

@@ -98,8 +98,22 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
                 for (int i = 0; i < 4; ++i) v[e][i] = (a[i] + b[i]) + rp;     // same association as model.py:349-360
             }
         }
-        ln_row(v, nvec, lane, D, eps, gamma, beta, out + row * D);
+        if (trow[c] == pad_idx) {      // x * (1 - padding_mask) after emb_layer_norm_before (model.py:366-367)
+#pragma unroll
+            for (int e = 0; e < LN_MAX_VEC; ++e)
+                if (lane + 64 * e < nvec)
+                    *reinterpret_cast<f32x4*>(out + row * D + 4 * (lane + 64 * e)) = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            ln_row(v, nvec, lane, D, eps, gamma, beta, out + row * D);
+        }
     }
+}
+
+// f2: padding_mask = tokens.eq(pad) (model.py:346), one byte per token
+__global__ __launch_bounds__(256) void pad_mask_kernel(const int64_t* __restrict__ tokens, uint8_t* __restrict__ mask,
+                                                       int64_t n, int pad_idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) mask[i] = tokens[i] == pad_idx;
 }
 
 __global__ __launch_bounds__(256) void pack_outputs_kernel(const float* __restrict__ x_final,
@@ -157,6 +171,14 @@ extern "C" int rnamsm_embed_ln(const int64_t* tokens, const float* embed_tokens,
                        tokens, embed_tokens, embed_positions, row_pos, gamma, beta, out, R, C, D, vocab, num_positions,
                        pad_idx, eps, err_flag);
     RNAMSM_CHECK_LAUNCH("embed_ln");
+    return RNAMSM_OK;
+}
+
+extern "C" int rnamsm_pad_mask(const int64_t* tokens, uint8_t* mask, int64_t n, int pad_idx, void* stream) {
+    RNAMSM_CHECK_ARG(tokens && mask && n > 0, "pad_mask: bad arguments");
+    hipLaunchKernelGGL(pad_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       tokens, mask, n, pad_idx);
+    RNAMSM_CHECK_LAUNCH("pad_mask");
     return RNAMSM_OK;
 }
 

@@ -16,7 +16,7 @@ using namespace rnamsm;
 
 namespace {
 struct Layout {
-    size_t x, xn, wide, part, total;
+    size_t x, xn, wide, part, mask, total;
 };
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 Layout make_layout(const rnamsm_model_dims& d, int R, int C) {
@@ -27,6 +27,7 @@ Layout make_layout(const rnamsm_model_dims& d, int R, int C) {
     l.xn = off;   off += align256(T * D * 4);
     l.wide = off; off += align256(T * (size_t)(3 * D + D > (size_t)d.ffn_dim ? 4 * D : d.ffn_dim) * 4);
     l.part = off; off += align256(rnamsm_row_logits_workspace_bytes(R, C, d.num_heads));
+    l.mask = off; off += align256(T);
     l.total = off;
     return l;
 }
@@ -45,7 +46,7 @@ extern "C" size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, 
 
 extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
                               int R, int C, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
-                              float* emb, float* atp, int* err_flag, int dtype, void* stream) {
+                              float* emb, float* atp, int* err_flag, int has_padding, int dtype, void* stream) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "forward: only RNAMSM_F32 is implemented");
     RNAMSM_CHECK_ARG(dims && weights && tokens && workspace && row_attn && repr && emb && atp, "forward: null pointer");
     const rnamsm_model_dims& d = *dims;
@@ -76,6 +77,11 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     const float row_scale = (1.0f / sqrtf(64.0f)) / sqrtf((float)R);     // align_scaling, modules.py:713-715
     const float col_scale = 1.0f / sqrtf(64.0f);                         // modules.py:839
 
+    uint8_t* mask = nullptr;           // [R, C]; row 0 of it is the tied-attention key mask
+    if (has_padding) {
+        mask = reinterpret_cast<uint8_t*>(ws + lay.mask);
+        FWD(rnamsm_pad_mask(tokens, mask, T, d.pad_idx, stream));
+    }
     FWD(rnamsm_embed_ln(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
                         G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, R, C, D, d.vocab, d.num_positions,
                         d.pad_idx, d.ln_eps, err_flag, stream));
@@ -85,25 +91,25 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         // ---- tied row attention block
         FWD(rnamsm_layernorm(x, W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B], xn, T, D, d.ln_eps, stream));
         FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, T,
-                                     3 * D, D, RNAMSM_ACT_NONE, row_scale, D, dtype, stream));
+                                     3 * D, D, RNAMSM_ACT_NONE, row_scale, D, mask, dtype, stream));
         FWD(rnamsm_row_logits(qkv, qkv + D, ldq, part, R, C, H, 64, dtype, stream));
-        FWD(rnamsm_softmax_rows(part, nsplit, probs, H, C, stream));
+        FWD(rnamsm_softmax_rows(part, nsplit, probs, H, C, mask, stream));
         FWD(rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, dtype, stream));
         FWD(rnamsm_gemm_bias_act_res(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], x, D, x, D, T, D, D,
-                                     RNAMSM_ACT_NONE, 1.f, 0, dtype, stream));
+                                     RNAMSM_ACT_NONE, 1.f, 0, nullptr, dtype, stream));
         // ---- column attention block
         FWD(rnamsm_layernorm(x, W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B], xn, T, D, d.ln_eps, stream));
         FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, T,
-                                     3 * D, D, RNAMSM_ACT_NONE, col_scale, D, dtype, stream));
-        FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, dtype, stream));
+                                     3 * D, D, RNAMSM_ACT_NONE, col_scale, D, nullptr, dtype, stream));
+        FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, mask, dtype, stream));
         FWD(rnamsm_gemm_bias_act_res(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], x, D, x, D, T, D, D,
-                                     RNAMSM_ACT_NONE, 1.f, 0, dtype, stream));
+                                     RNAMSM_ACT_NONE, 1.f, 0, nullptr, dtype, stream));
         // ---- feed-forward block
         FWD(rnamsm_layernorm(x, W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B], xn, T, D, d.ln_eps, stream));
         FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], nullptr, 0, hidden, F, T, F, D,
-                                     RNAMSM_ACT_GELU_ERF, 1.f, 0, dtype, stream));
+                                     RNAMSM_ACT_GELU_ERF, 1.f, 0, nullptr, dtype, stream));
         FWD(rnamsm_gemm_bias_act_res(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], x, D, x, D, T, D, F,
-                                     RNAMSM_ACT_NONE, 1.f, 0, dtype, stream));
+                                     RNAMSM_ACT_NONE, 1.f, 0, nullptr, dtype, stream));
     }
     FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
     FWD(rnamsm_pack_outputs(repr, row_attn, emb, atp, C, D, NL, H, stream));

@@ -12,11 +12,12 @@ namespace rnamsm {
 
 constexpr int GEMM_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;   // double-buffered A and W tiles
 
-template <int ACT, bool HAS_RES, int DEPTH>
+template <int ACT, bool HAS_RES, int DEPTH, bool ZROWS>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc,
-    int M, int N, int K, float scale, int scale_cols, unsigned stagger_cycles, int debug) {
+    int M, int N, int K, float scale, int scale_cols, const uint8_t* __restrict__ zero_rows, unsigned stagger_cycles,
+    int debug) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                    // [2][BM][LDK]
     float* Ws = smem + 2 * TILE_KC;      // [2][BN][LDK]
@@ -99,6 +100,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
         const int r = er + 4 * i;
         f32x4 v = *reinterpret_cast<const f32x4*>(&stage[r * LDE + ec]);
         if (HAS_RES) v += res[i];
+        // f2: q *= 1 - padding_mask (modules.py:767-772): padded tokens get q = 0 (the scaled columns are q)
+        if (ZROWS && gn < scale_cols && zero_rows[min(gm0 + r, M - 1)]) v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (gm0 + r < M) {
             if (debug & 1) asm volatile("" ::"v"(v)); else
             *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + r) * ldc + gn) = v;
@@ -106,12 +109,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     }
 }
 
-template <int ACT, bool HAS_RES, int DEPTH>
+template <int ACT, bool HAS_RES, int DEPTH, bool ZROWS = false>
 static int launch_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                        int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
-                       hipStream_t stream) {
+                       const uint8_t* zero_rows, hipStream_t stream) {
     static bool configured = false;
-    auto kern = gemm_f32_kernel<ACT, HAS_RES, DEPTH>;
+    auto kern = gemm_f32_kernel<ACT, HAS_RES, DEPTH, ZROWS>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
@@ -124,7 +127,7 @@ static int launch_gemm(const float* A, int64_t lda, const float* W, const float*
     // algorithmic work: 2MNK flops; bytes = A + W + C once (+ residual read)
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, A, lda, W, bias, residual, ldr,
-                       Cout, ldc, M, N, K, scale, scale_cols, stagger, tuning().gemm_debug);
+                       Cout, ldc, M, N, K, scale, scale_cols, zero_rows, stagger, tuning().gemm_debug);
     RNAMSM_CHECK_LAUNCH("gemm_f32");
     return RNAMSM_OK;
 }
@@ -135,7 +138,8 @@ using namespace rnamsm;
 
 extern "C" int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float* W, const float* bias,
                                         const float* residual, int64_t ldr, float* Cout, int64_t ldc, int64_t M,
-                                        int N, int K, int act, float scale, int scale_cols, int dtype, void* stream) {
+                                        int N, int K, int act, float scale, int scale_cols, const uint8_t* zero_rows,
+                                        int dtype, void* stream) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "gemm: only RNAMSM_F32 is implemented");
     RNAMSM_CHECK_ARG(A && W && Cout, "gemm: null pointer");
     RNAMSM_CHECK_ARG(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "gemm: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
@@ -149,8 +153,13 @@ extern "C" int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int m = (int)M;
 #define RNAMSM_GEMM_DISPATCH(ACT_, RES_, DEPTH_) \
-    launch_gemm<ACT_, RES_, DEPTH_>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, s)
+    launch_gemm<ACT_, RES_, DEPTH_>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, zero_rows, s)
     const bool deep = tuning().gemm_prefetch_depth >= 2;
+    if (zero_rows) {   // f2: only the QKV projection of row attention uses it (no activation, no residual)
+        RNAMSM_CHECK_ARG(act == RNAMSM_ACT_NONE && !residual, "gemm: zero_rows is supported without activation / residual");
+        return launch_gemm<RNAMSM_ACT_NONE, false, 1, true>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale,
+                                                            scale_cols, zero_rows, s);
+    }
     if (act == RNAMSM_ACT_GELU_ERF) {
         if (residual) return deep ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, true, 2) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, true, 1);
         return deep ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, false, 2) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, false, 1);

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
 // (attn_weights.softmax(-1), modules.py:818/739).  C <= 1024 + 1 fits 17 values per lane.
 constexpr int SOFTMAX_MAX_PER_LANE = 17;
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ partial, int nsplit,
-                                                           float* __restrict__ probs, int64_t rows, int C) {
+                                                           float* __restrict__ probs, int64_t rows, int C,
+                                                           const uint8_t* __restrict__ key_mask) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -139,6 +140,8 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
             const float* p = partial + row * C + j;
             s = p[0];
             for (int sp = 1; sp < nsplit; ++sp) s += p[(int64_t)sp * slab];
+            // f2: masked_fill(padding_mask[:, 0], -10000) on the key axis (modules.py:781-785)
+            if (key_mask && key_mask[j]) s = -10000.f;
         }
         v[e] = s;
         mx = fmaxf(mx, s);
@@ -296,14 +299,15 @@ extern "C" int rnamsm_row_logits(const float* q, const float* k, int64_t ld, flo
     return RNAMSM_OK;
 }
 
-extern "C" int rnamsm_softmax_rows(const float* partial, int nsplit, float* probs, int H, int C, void* stream) {
+extern "C" int rnamsm_softmax_rows(const float* partial, int nsplit, float* probs, int H, int C,
+                                   const uint8_t* key_mask, void* stream) {
     RNAMSM_CHECK_ARG(partial && probs, "softmax_rows: null pointer");
     RNAMSM_CHECK_ARG(nsplit >= 1 && H > 0 && C > 0 && C <= 64 * SOFTMAX_MAX_PER_LANE,
                      "softmax_rows: bad shape nsplit=%d H=%d C=%d (C <= %d)", nsplit, H, C, 64 * SOFTMAX_MAX_PER_LANE);
     const int64_t rows = (int64_t)H * C;
     KernelTimer timer(TC_SOFTMAX, 0.0, 4.0 * (double)(nsplit + 1) * H * C * C, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), partial, nsplit, probs, rows, C);
+                       static_cast<hipStream_t>(stream), partial, nsplit, probs, rows, C, key_mask);
     RNAMSM_CHECK_LAUNCH("softmax_rows");
     return RNAMSM_OK;
 }

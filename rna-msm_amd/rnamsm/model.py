@@ -161,7 +161,7 @@ class MSATransformer(nn.Module):
         return out[:, :V].contiguous().view(*features.shape[:-1], V)
 
     # ------------------------------------------------------------------ forward
-    def forward_one(self, tokens2d: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def forward_one(self, tokens2d: torch.Tensor, has_padding: Optional[bool] = None) -> Dict[str, torch.Tensor]:
         """One MSA through the C++ driver (rnamsm_forward): tokens int64 [R, C] on the HIP device ->
         {"row_attn" [NL,H,C,C], "repr" [R,C,D], "emb" [C-1,D], "atp" [NL*H,C-1,C-1]}."""
         if self.training:
@@ -185,16 +185,20 @@ class MSATransformer(nn.Module):
         atp = torch.empty(NL * H, C - 1, C - 1, device=dev, dtype=torch.float32)
         err = torch.zeros(1, device=dev, dtype=torch.int32)
         toks = tokens2d.to(torch.int64).contiguous()
+        if has_padding is None:       # padding_mask = tokens.eq(pad); None when nothing is padded (model.py:346-348)
+            has_padding = bool((toks == self.vocab.pad_idx).any())
         _lib.check(lib.rnamsm_forward(ctypes.byref(dims), ptrs, toks.data_ptr(), R, C, ws.data_ptr(), ws.numel(),
                                       row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
-                                      err.data_ptr(), _lib.F32, torch.cuda.current_stream().cuda_stream))
+                                      err.data_ptr(), int(has_padding), _lib.F32,
+                                      torch.cuda.current_stream().cuda_stream))
         return {"row_attn": row_attn, "repr": rep, "emb": emb, "atp": atp, "err": err}
 
-    def _forward_layerwise(self, tokens2d: torch.Tensor, repr_layers: Iterable[int]):
+    def _forward_layerwise(self, tokens2d: torch.Tensor, repr_layers: Iterable[int], has_padding: bool = False):
         """Module-by-module path (same HIP kernels, launched from Python) used when intermediate
         representations are requested."""
         R, C = tokens2d.shape
         D = self.embed_dim
+        pmask = (tokens2d == self.vocab.pad_idx)[None] if has_padding else None      # [1, R, C]
         x = ops.embed_ln(tokens2d.to(torch.int64), self.embed_tokens.weight.detach(), self.embed_positions.weight.detach(),
                          self.msa_position_embedding.detach().view(-1).contiguous(),
                          self.emb_layer_norm_before.weight.detach(), self.emb_layer_norm_before.bias.detach(),
@@ -204,7 +208,7 @@ class MSATransformer(nn.Module):
             reps[0] = x.permute(2, 0, 1, 3)
         rows = []
         for i, layer in enumerate(self.layers):
-            x, _, row_attn = layer(x, need_head_weights=True)
+            x, _, row_attn = layer(x, self_attn_padding_mask=pmask, need_head_weights=True)
             rows.append(row_attn.permute(1, 0, 2, 3))                               # [1,H,C,C]
             if (i + 1) in repr_layers and (i + 1) != self.num_layers:
                 reps[i + 1] = x.permute(2, 0, 1, 3)
@@ -221,8 +225,8 @@ class MSATransformer(nn.Module):
         B, R, C = tokens.shape
         if not tokens.is_cuda:
             raise _lib.RnamsmError("tokens must be on the HIP device (no CPU path exists)")
-        if bool((tokens == self.vocab.pad_idx).any()):
-            raise NotImplementedError("padding masks are not implemented (SURVEY.md §8 f2)")
+        # padding_mask is batch-global in the reference (model.py:346-348); masks of un-padded elements are all-false
+        has_padding = bool((tokens == self.vocab.pad_idx).any())
         need_logits = self.compute_logits if need_logits is None else need_logits
         repr_set = set(repr_layers)
         want = set(repr_set)
@@ -233,14 +237,14 @@ class MSATransformer(nn.Module):
         fast = repr_set <= {self.num_layers}
         for b in range(B):
             if fast:
-                out = self.forward_one(tokens[b])
+                out = self.forward_one(tokens[b], has_padding)
                 if int(out["err"].item()) != 0:
                     raise IndexError("token or position index out of range")
                 if self.num_layers in repr_set:
                     reps[self.num_layers].append(out["repr"].unsqueeze(0))
                 atts.append(out["row_attn"].unsqueeze(0))
             else:
-                r, a = self._forward_layerwise(tokens[b], repr_set)
+                r, a = self._forward_layerwise(tokens[b], repr_set, has_padding)
                 for i in repr_set:
                     reps[i].append(r[i])
                 atts.append(a)

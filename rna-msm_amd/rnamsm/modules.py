@@ -6,8 +6,9 @@ msm/modules.py), so a checkpoint and a caller written for the reference work unc
 nn.Linear / nn.LayerNorm children only HOLD parameters (for state_dict compatibility); no torch
 operator computes anything -- every forward goes through rnamsm.ops to the HIP kernels.
 
-Scope: inference, one MSA per call (B = 1), no padding mask.  Training-mode dropout,
-`self_attn_mask` and padding masks raise instead of silently doing something else.
+Scope: inference, one MSA per call (B = 1; the model loops over a batch).  Padding masks follow the
+reference's direct (un-chunked) path (§8 f2).  Training-mode dropout and `self_attn_mask` raise instead of silently
+doing something else.
 """
 from __future__ import annotations
 
@@ -69,20 +70,25 @@ class _AxialAttentionBase(nn.Module):
         self.out_proj = nn.Linear(embed_dim, embed_dim)
         self._packed = _PackedQKV()
 
-    def _qkv(self, x2: torch.Tensor, q_scale: float) -> torch.Tensor:
+    def _qkv(self, x2: torch.Tensor, q_scale: float, zero_rows=None) -> torch.Tensor:
         w, b = self._packed.get(self.q_proj, self.k_proj, self.v_proj)
         D = x2.shape[1]
-        return ops.linear(x2, w, b, scale=q_scale, scale_cols=D)          # [T, 3D] = q*scale | k | v
+        return ops.linear(x2, w, b, scale=q_scale, scale_cols=D, zero_rows=zero_rows)   # [T, 3D] = q*scale | k | v
 
     def _project_out(self, ctx: torch.Tensor, residual: Optional[torch.Tensor]) -> torch.Tensor:
         return ops.linear(ctx, self.out_proj.weight.detach(), self.out_proj.bias.detach(), residual=residual)
 
     @staticmethod
-    def _reject_masks(self_attn_mask, self_attn_padding_mask):
+    def _mask_bytes(self_attn_mask, self_attn_padding_mask, R: int, C: int):
+        """self_attn_padding_mask [B=1, R, C] bool -> uint8 [R*C] on the device (None if absent)."""
         if self_attn_mask is not None:
             raise NotImplementedError           # same as the reference (modules.py:776-777, 909-910)
-        if self_attn_padding_mask is not None:
-            raise NotImplementedError("padding masks are not implemented (SURVEY.md §8 f2)")
+        if self_attn_padding_mask is None:
+            return None
+        m = self_attn_padding_mask
+        if m.dim() != 3 or m.shape[0] != 1 or tuple(m.shape[1:]) != (R, C):
+            raise ValueError(f"expected padding mask of shape [1, {R}, {C}], got {tuple(m.shape)}")
+        return m[0].to(torch.uint8).contiguous().view(-1)
 
 
 class RowSelfAttention(_AxialAttentionBase):
@@ -94,13 +100,14 @@ class RowSelfAttention(_AxialAttentionBase):
         return ops.row_scaling(q.size(0))
 
     def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, _residual=None):
-        self._reject_masks(self_attn_mask, self_attn_padding_mask)
         _check_inference(self, self.dropout)
         x2, R, C, D = _tokens_2d(x)
+        mask = self._mask_bytes(self_attn_mask, self_attn_padding_mask, R, C)
         H = self.num_heads
-        qkv = self._qkv(x2, self.align_scaling(x))
+        # padded tokens: q = 0 (modules.py:767-772); keys whose FIRST-row token is <pad>: logit -10000 (:781-785)
+        qkv = self._qkv(x2, self.align_scaling(x), zero_rows=mask)
         partial, _ = ops.row_logits(qkv[:, :D], qkv[:, D:2 * D], R, C, H)
-        probs = ops.softmax_rows(partial)
+        probs = ops.softmax_rows(partial, key_mask=None if mask is None else mask[:C])
         ctx = ops.row_apply(probs, qkv[:, 2 * D:], R, C, H)
         res2 = None if _residual is None else _residual.contiguous().view(R * C, D)
         out = self._project_out(ctx, res2)
@@ -115,12 +122,13 @@ class ColumnSelfAttention(_AxialAttentionBase):
     them, so `probs` is None here."""
 
     def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, _residual=None):
-        self._reject_masks(self_attn_mask, self_attn_padding_mask)
         _check_inference(self, self.dropout)
         x2, R, C, D = _tokens_2d(x)
+        mask = self._mask_bytes(self_attn_mask, self_attn_padding_mask, R, C)
         H = self.num_heads
         qkv = self._qkv(x2, self.scaling)
-        ctx = ops.col_attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], R, C, H)   # R == 1 reduces to ctx = v
+        # R == 1 reduces to ctx = v; padded keys get score -10000 (modules.py:911-915)
+        ctx = ops.col_attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], R, C, H, pad_mask=mask if R > 1 else None)
         res2 = None if _residual is None else _residual.contiguous().view(R * C, D)
         out = self._project_out(ctx, res2)
         return out.view(R, C, 1, D), None

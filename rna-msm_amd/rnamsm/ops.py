@@ -48,8 +48,9 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
            residual: Optional[torch.Tensor] = None, scale: float = 1.0, scale_cols: int = 0,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = act((a @ w.T + bias) * (col < scale_cols ? scale : 1)) + residual;  a [M,K], w [N,K]."""
+           out: Optional[torch.Tensor] = None, zero_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act((a @ w.T + bias) * (col < scale_cols ? scale : 1)) + residual;  a [M,K], w [N,K].
+    zero_rows (uint8 [M]): flagged rows get 0 in the scaled columns (q *= 1 - padding_mask)."""
     M, K = a.shape
     N = w.shape[0]
     if out is None:
@@ -57,7 +58,8 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     _lib.check(_lib.load().rnamsm_gemm_bias_act_res(
         _dev(a, "a"), _rowmajor(a, "a"), _dev(w.contiguous(), "w"), None if bias is None else _dev(bias, "bias"),
         None if residual is None else _dev(residual, "residual"), 0 if residual is None else _rowmajor(residual, "residual"),
-        _dev(out, "out"), _rowmajor(out, "out"), M, N, K, act, scale, scale_cols, F32, _stream()))
+        _dev(out, "out"), _rowmajor(out, "out"), M, N, K, act, scale, scale_cols,
+        None if zero_rows is None else _dev(zero_rows, "zero_rows", torch.uint8), F32, _stream()))
     return out
 
 
@@ -73,10 +75,13 @@ def row_logits(q: torch.Tensor, k: torch.Tensor, R: int, C: int, H: int) -> Tupl
     return partial, nsplit
 
 
-def softmax_rows(partial: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def softmax_rows(partial: torch.Tensor, out: Optional[torch.Tensor] = None,
+                 key_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     nsplit, H, C, _ = partial.shape
     probs = torch.empty(H, C, C, device=partial.device, dtype=torch.float32) if out is None else out
-    _lib.check(_lib.load().rnamsm_softmax_rows(_dev(partial, "partial"), nsplit, _dev(probs, "probs"), H, C, _stream()))
+    _lib.check(_lib.load().rnamsm_softmax_rows(_dev(partial, "partial"), nsplit, _dev(probs, "probs"), H, C,
+                                               None if key_mask is None else _dev(key_mask, "key_mask", torch.uint8),
+                                               _stream()))
     return probs
 
 
@@ -89,12 +94,14 @@ def row_apply(probs: torch.Tensor, v: torch.Tensor, R: int, C: int, H: int,
 
 
 def col_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, R: int, C: int, H: int,
-             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, pad_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     ctx = torch.empty(R * C, H * HEAD_DIM, device=v.device, dtype=torch.float32) if out is None else out
     ld = _rowmajor(q, "q")
     assert _rowmajor(k, "k") == ld and _rowmajor(v, "v") == ld
     _lib.check(_lib.load().rnamsm_col_attn_fused(_dev(q, "q"), _dev(k, "k"), _dev(v, "v"), ld, _dev(ctx, "ctx"),
-                                                 _rowmajor(ctx, "ctx"), R, C, H, HEAD_DIM, F32, _stream()))
+                                                 _rowmajor(ctx, "ctx"), R, C, H, HEAD_DIM,
+                                                 None if pad_mask is None else _dev(pad_mask, "pad_mask", torch.uint8),
+                                                 F32, _stream()))
     return ctx
 
 

@@ -189,6 +189,23 @@ def gen_forward(vocab):
             save(f"forward_{name}_fp64.npz", emb=emb64.astype(np.float64), atp=atp64.astype(np.float64))
 
 
+def gen_padded(vocab):
+    """a ragged batch (B=2) through the reference with <pad>: element 0 has 6 rows x 21 columns, element
+    1 has 4 rows x 15 columns and is padded on both axes; plus isolated pads inside element 0.  Direct path
+    (max_tokens large), 10 layers, D=768."""
+    state = synthetic.make_state_dict(seed=0)
+    model = ref_model.MSATransformer(vocab, num_layers=10, max_tokens_per_msa=2 ** 30, max_seqlen=1024)
+    model.load_state_dict({k: t(v) for k, v in state.items()}, strict=True)
+    model.eval()
+    toks = np.full((2, 6, 21), 1, dtype=np.int64)
+    toks[0] = synthetic.make_tokens(6, 21, 7)
+    toks[1, :4, :15] = synthetic.make_tokens(4, 15, 8)
+    toks[0, 2, 5] = 1; toks[0, 5, 20] = 1; toks[0, 0, 9] = 1          # a pad in row 0 masks key column 9 for every row
+    res = model(t(toks), repr_layers=[0, 10], need_head_weights=True, return_contacts=False)
+    save("forward_padded_b2.npz", tokens=toks, rep0=res["representations"][0].numpy(),
+         rep10=res["representations"][10].numpy(), row_attentions=res["row_attentions"].numpy())
+
+
 def gen_mha():
     """Generic 1-D MHA (msm/multihead_attention.py) self-attention, [T,B,E] in -> [T,B,E] out."""
     from msm.multihead_attention import MultiheadAttention
@@ -215,5 +232,6 @@ if __name__ == "__main__":
     print("tokens"); vocab = gen_tokens()
     print("ops"); gen_ops()
     print("forward"); gen_forward(vocab)
+    print("padded"); gen_padded(vocab)
     print("mha"); gen_mha()
     print("shapes"); gen_shapes()

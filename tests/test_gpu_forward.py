@@ -140,7 +140,28 @@ def test_rejections(model):
         m.forward_one(torch.zeros(1025, 4, dtype=torch.int64, device="cuda:0"))
     with pytest.raises(_lib.RnamsmError):
         m.forward_one(torch.zeros(4, 4, dtype=torch.int64))            # CPU tensor: loud failure, no fallback
-    bad = torch.from_numpy(synthetic.make_tokens(2, 6, 0)).to("cuda:0")[None].clone()
-    bad[0, 1, 3] = 1
     with pytest.raises(NotImplementedError):
-        m(bad, need_head_weights=True)
+        m.train()(torch.from_numpy(synthetic.make_tokens(2, 6, 0)).to("cuda:0")[None])
+    m.eval()
+
+
+def test_padded_ragged_batch_matches_reference_fixture(model):
+    """B=2 batch with <pad> on both axes and isolated pads, against the reference's own output
+    (direct path).  Both execution paths: the C++ driver (fast) and the module-by-module path."""
+    m, _ = model
+    g = golden("forward_padded_b2.npz")
+    toks = torch.from_numpy(g["tokens"]).to("cuda:0")
+    res = m(toks, repr_layers=[10], need_head_weights=True)
+    assert res["row_attentions"].shape == g["row_attentions"].shape
+    for b in range(2):
+        assert rel_l2(res["representations"][10][b].cpu().numpy(), g["rep10"][b]) < 1e-4
+        assert np.abs(res["row_attentions"][b].cpu().numpy() - g["row_attentions"][b]).max() < 1e-4
+    # keys whose first-row token is <pad> get (numerically) zero tied-attention probability
+    assert float(res["row_attentions"][0, :, :, :, 9].max()) == 0.0
+    assert float(res["row_attentions"][1, :, :, :, 15:].max()) == 0.0
+    res2 = m(toks, repr_layers=[0, 10], need_head_weights=True)               # layer-wise path
+    for b in range(2):
+        assert rel_l2(res2["representations"][0][b].cpu().numpy(), g["rep0"][b]) < 1e-5
+        assert float(res2["representations"][0][b][toks[b] == 1].abs().max()) == 0.0     # x * (1 - padding_mask)
+        assert rel_l2(res2["representations"][10][b].cpu().numpy(), g["rep10"][b]) < 1e-4
+        assert np.abs(res2["row_attentions"][b].cpu().numpy() - g["row_attentions"][b]).max() < 1e-4

@@ -273,3 +273,31 @@ def test_greedy_select_on_device_equals_host_and_reference(dev):
             want = msa.greedy_select(toks, K, mode)
             got = msa.greedy_select_device(toks, K, mode, dev)
             assert np.array_equal(got, want), (N, L, K, mode)
+
+
+def test_padding_mask_kernel_semantics(dev):
+    """SURVEY §8 f2 at kernel level: zero_rows on the q columns of the QKV GEMM, -10000 key fill in the row softmax,
+    -10000 fill of padded keys in fused column attention (including a fully padded column -> uniform weights)."""
+    from rnamsm import ops
+    R, C, H = 9, 13, 2
+    D = 64 * H
+    rng = np.random.RandomState(0)
+    pad = torch.from_numpy(rng.rand(R, C) < 0.2)
+    pad[:, 4] = True                                            # one column padded in every row
+    pad[0, 7] = True
+    mask = pad.to(torch.uint8).contiguous().view(-1).to(dev)
+    x, w, b = _rand("pm.x", (R * C, D)), _rand("pm.w", (3 * D, D), 0.1), _rand("pm.b", (3 * D,), 0.1)
+    qkv = ops.linear(x.to(dev), w.to(dev), b.to(dev), scale=0.25, scale_cols=D, zero_rows=mask)
+    want = x.double() @ w.double().t() + b.double()
+    want[:, :D] *= 0.25
+    want[pad.view(-1), :D] = 0
+    assert rel_l2(qkv.cpu(), want) < 3e-6 and float(qkv[mask.bool(), :D].abs().max()) == 0.0
+    q, k, v = (want[:, i * D:(i + 1) * D].view(R, C, H, 64) for i in range(3))
+    partial, _ = ops.row_logits(qkv[:, :D], qkv[:, D:2 * D], R, C, H)
+    probs = ops.softmax_rows(partial, key_mask=mask[:C]).cpu()
+    logits = torch.einsum("rihd,rjhd->hij", q, k).masked_fill(pad[0][None, None, :], -10000)
+    assert np.abs(probs.numpy() - torch.softmax(logits, -1).numpy()).max() < TOL_PROB
+    ctx = ops.col_attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], R, C, H, pad_mask=mask).cpu()
+    wc = torch.einsum("ichd,jchd->hcij", q, k).masked_fill(pad.t()[None, :, None, :], -10000)
+    want_ctx = torch.einsum("hcij,jchd->ichd", torch.softmax(wc, -1), v).reshape(R * C, D)
+    assert rel_l2(ctx, want_ctx) < 5e-6

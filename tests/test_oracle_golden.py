@@ -124,10 +124,18 @@ def test_rejects_more_than_1024_rows_and_padding(full_state):
     params = {k: torch.zeros(1) for k in ()}
     with pytest.raises(RuntimeError, match="maximum MSA"):
         O.embed(torch.zeros(1025, 4, dtype=torch.int64), {})
-    toks = torch.from_numpy(synthetic.make_tokens(2, 5))
-    toks[1, 3] = 1
-    with pytest.raises(NotImplementedError):
-        O.forward(toks, params)
+
+
+def test_padded_ragged_batch_matches_reference(full_state):
+    """padding-mask semantics (zeroed embeddings and q, -10000 key fills) on a B=2 ragged batch."""
+    g = golden("forward_padded_b2.npz")
+    params = O.to_torch_params(full_state)
+    for b in range(2):
+        res = O.forward(torch.from_numpy(g["tokens"][b]), params, force_mask=True)
+        assert rel_l2(res["representation"], g["rep10"][b]) < 1e-5
+        assert np.abs(res["row_attentions"].numpy() - g["row_attentions"][b]).max() < 2e-5
+        x0 = O.embed(torch.from_numpy(g["tokens"][b]), params)
+        assert rel_l2(x0, g["rep0"][b]) < 1e-5
 
 
 @pytest.mark.parametrize("name", ["t37_b3_e128", "t70_b2_e768"])
