@@ -16,8 +16,8 @@
  *     synchronises, nothing allocates (scratch is caller-provided, sized by *_workspace_bytes);
  *   - return value: RNAMSM_OK or a negative rnamsm_status; rnamsm_last_error() gives the text
  *     for the calling thread;
- *   - dtype: RNAMSM_F32 is implemented (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32); RNAMSM_BF16 is
- *     reserved and returns RNAMSM_ERR_UNSUPPORTED.
+ *   - dtype: the per-kernel entry points implement RNAMSM_F32 (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32) and return
+ *     RNAMSM_ERR_UNSUPPORTED otherwise; rnamsm_gemm_bf16 and rnamsm_forward's dtype select the bf16 matrix-core modes.
  */
 #ifndef RNAMSM_H_
 #define RNAMSM_H_
@@ -38,7 +38,14 @@ typedef enum {
     RNAMSM_ERR_HIP = -3          /* a HIP runtime call failed (launch, attribute) */
 } rnamsm_status;
 
-typedef enum { RNAMSM_F32 = 0, RNAMSM_BF16 = 1 } rnamsm_dtype;
+/* Arithmetic of the Linear GEMMs inside rnamsm_forward (everything else -- attention contractions, softmax,
+ * LayerNorm, residual stream, outputs -- is fp32 in every mode):
+ *   RNAMSM_F32     exact-fp32 MFMA (default; the parity path)
+ *   RNAMSM_BF16    bf16 MFMA on bf16-rounded operands, fp32 accumulate (mixed precision; BASELINE config 4)
+ *   RNAMSM_BF16X3  bf16 MFMA on hi/lo-split operands, 3 products, fp32 accumulate (~2^-17 operand error)
+ *   RNAMSM_F16X3   fp16 MFMA on hi/lo-split operands, 3 products, fp32 accumulate (~2^-22 operand error: fp32-grade
+ *                  for the fp16-range operands this model feeds its Linear layers) */
+typedef enum { RNAMSM_F32 = 0, RNAMSM_BF16 = 1, RNAMSM_BF16X3 = 2, RNAMSM_F16X3 = 3 } rnamsm_dtype;
 typedef enum { RNAMSM_ACT_NONE = 0, RNAMSM_ACT_GELU_ERF = 1 } rnamsm_act;
 
 int rnamsm_version(void);
@@ -74,6 +81,19 @@ int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float* W, const 
                              const float* residual, int64_t ldr, float* Cout, int64_t ldc,
                              int64_t M, int N, int K, int act, float scale, int scale_cols,
                              const uint8_t* zero_rows, int dtype, void* stream);
+
+/* Linear on the bf16 matrix cores (fp32 accumulate, fp32 activations in HBM), same epilogue as above.
+ *   split = 1: operands rounded to bf16 (mixed-precision mode, BASELINE config 4);
+ *   split = 3: "bf16x3" -- both operands as hi + lo bf16 pairs, product = hi*hi + hi*lo + lo*hi (~2^-17 relative
+ *              operand error, fp32 accumulation); opt-in fast mode, the exact-fp32 kernel stays the default.
+ *   fmt   = 0: bf16 halves;  fmt = 1 (split 3 only): fp16 halves, "f16x3": a hi/lo fp16 pair carries ~22 mantissa
+ *              bits (fp32: 24) for operands inside fp16 range (|x| < 65504).
+ * W_hi / W_lo [N, K] are bf16 planes produced once by rnamsm_split_bf16 (lo = bf16(w - hi); may be NULL there
+ * and here when split = 1); A is split while it is staged.  Requires N % 128 == 0, K % 64 == 0. */
+int rnamsm_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, int fmt, void* stream);
+int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
+                     const float* residual, int64_t ldr, float* Cout, int64_t ldc, int64_t M, int N, int K,
+                     int act, float scale, int scale_cols, int split, int fmt, void* stream);
 
 /* K4 -- tied row-attention logits, RowSelfAttention.compute_attention_weights (modules.py:752-786):
  *   S[h,i,j] = sum_{r,d} q[r,i,h,d] * k[r,j,h,d]      (q already scaled by dh^-0.5/sqrt(R), K3)
@@ -167,10 +187,14 @@ size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int 
  * required outputs.  has_padding != 0: the MSA contains <pad> tokens; the driver builds the padding mask and applies
  * the reference's direct-path mask semantics (§8 f2): zeroed embeddings and q at padded tokens, -10000 on keys whose
  * first-row token is <pad> (row attention) and on padded keys (column attention). */
+/* weight_planes (host array, may be NULL when dtype == RNAMSM_F32): for every layer 12 device pointers to bf16 planes
+ * from rnamsm_split_bf16, in the order {row_wqkv, row_wo, col_wqkv, col_wo, fc1_w, fc2_w} x {hi, lo} (lo may be
+ * NULL for RNAMSM_BF16). */
+#define RNAMSM_PLANES_PER_LAYER 12
 int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
                    int R, int C, void* workspace, size_t workspace_bytes,
                    float* row_attn, float* repr, float* emb, float* atp,
-                   int* err_flag, int has_padding, int dtype, void* stream);
+                   int* err_flag, int has_padding, int dtype, const uint16_t* const* weight_planes, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's
  * roofline block; adds two event records per launch while enabled, nothing when disabled).

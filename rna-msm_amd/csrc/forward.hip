@@ -46,8 +46,10 @@ extern "C" size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, 
 
 extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
                               int R, int C, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
-                              float* emb, float* atp, int* err_flag, int has_padding, int dtype, void* stream) {
-    if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "forward: only RNAMSM_F32 is implemented");
+                              float* emb, float* atp, int* err_flag, int has_padding, int dtype,
+                              const uint16_t* const* weight_planes, void* stream) {
+    RNAMSM_CHECK_ARG(dtype >= RNAMSM_F32 && dtype <= RNAMSM_F16X3, "forward: unknown dtype %d", dtype);
+    RNAMSM_CHECK_ARG(dtype == RNAMSM_F32 || weight_planes, "forward: bf16 modes need weight_planes");
     RNAMSM_CHECK_ARG(dims && weights && tokens && workspace && row_attn && repr && emb && atp, "forward: null pointer");
     const rnamsm_model_dims& d = *dims;
     const int D = d.embed_dim, H = d.num_heads, F = d.ffn_dim, NL = d.num_layers;
@@ -74,6 +76,19 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     float* hidden = wide;              // [T, F]
     const float* const* G = weights;
     const int nsplit = rnamsm_row_logits_nsplit(R, C, H);
+    // Linear dispatch: exact-fp32 MFMA, or the bf16 matrix cores on pre-split weight planes (slot = index into the
+    // layer's plane table).  The masked QKV projection (f2) always takes the fp32 kernel.
+    const int f32 = RNAMSM_F32;
+    auto linear = [&](int layer, int slot, const float* A, int64_t lda, const float* Wf, const float* bias,
+                      const float* res, int64_t ldr, float* out, int64_t ldc, int N, int K, int act, float scale,
+                      int scale_cols, const uint8_t* zero_rows) -> int {
+        if (dtype == RNAMSM_F32 || zero_rows)
+            return rnamsm_gemm_bias_act_res(A, lda, Wf, bias, res, ldr, out, ldc, T, N, K, act, scale, scale_cols,
+                                            zero_rows, f32, stream);
+        const uint16_t* const* P = weight_planes + (size_t)layer * RNAMSM_PLANES_PER_LAYER + 2 * slot;
+        return rnamsm_gemm_bf16(A, lda, P[0], P[1], bias, res, ldr, out, ldc, T, N, K, act, scale, scale_cols,
+                                dtype == RNAMSM_BF16 ? 1 : 3, dtype == RNAMSM_F16X3 ? 1 : 0, stream);
+    };
     const float row_scale = (1.0f / sqrtf(64.0f)) / sqrtf((float)R);     // align_scaling, modules.py:713-715
     const float col_scale = 1.0f / sqrtf(64.0f);                         // modules.py:839
 
@@ -90,26 +105,23 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         float* probs = row_attn + (int64_t)l * H * C * C;
         // ---- tied row attention block
         FWD(rnamsm_layernorm(x, W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B], xn, T, D, d.ln_eps, stream));
-        FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, T,
-                                     3 * D, D, RNAMSM_ACT_NONE, row_scale, D, mask, dtype, stream));
-        FWD(rnamsm_row_logits(qkv, qkv + D, ldq, part, R, C, H, 64, dtype, stream));
+        FWD(linear(l, 0, xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
+                   RNAMSM_ACT_NONE, row_scale, D, mask));
+        FWD(rnamsm_row_logits(qkv, qkv + D, ldq, part, R, C, H, 64, f32, stream));
         FWD(rnamsm_softmax_rows(part, nsplit, probs, H, C, mask, stream));
-        FWD(rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, dtype, stream));
-        FWD(rnamsm_gemm_bias_act_res(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], x, D, x, D, T, D, D,
-                                     RNAMSM_ACT_NONE, 1.f, 0, nullptr, dtype, stream));
+        FWD(rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, f32, stream));
+        FWD(linear(l, 1, ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
         // ---- column attention block
         FWD(rnamsm_layernorm(x, W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B], xn, T, D, d.ln_eps, stream));
-        FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, T,
-                                     3 * D, D, RNAMSM_ACT_NONE, col_scale, D, nullptr, dtype, stream));
-        FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, mask, dtype, stream));
-        FWD(rnamsm_gemm_bias_act_res(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], x, D, x, D, T, D, D,
-                                     RNAMSM_ACT_NONE, 1.f, 0, nullptr, dtype, stream));
+        FWD(linear(l, 2, xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
+                   RNAMSM_ACT_NONE, col_scale, D, nullptr));
+        FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, mask, f32, stream));
+        FWD(linear(l, 3, ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
         // ---- feed-forward block
         FWD(rnamsm_layernorm(x, W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B], xn, T, D, d.ln_eps, stream));
-        FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], nullptr, 0, hidden, F, T, F, D,
-                                     RNAMSM_ACT_GELU_ERF, 1.f, 0, nullptr, dtype, stream));
-        FWD(rnamsm_gemm_bias_act_res(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], x, D, x, D, T, D, F,
-                                     RNAMSM_ACT_NONE, 1.f, 0, nullptr, dtype, stream));
+        FWD(linear(l, 4, xn, D, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], nullptr, 0, hidden, F, F, D, RNAMSM_ACT_GELU_ERF,
+                   1.f, 0, nullptr));
+        FWD(linear(l, 5, hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], x, D, x, D, D, F, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
     }
     FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
     FWD(rnamsm_pack_outputs(repr, row_attn, emb, atp, C, D, NL, H, stream));

@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librnamsm_hip.so")
 
 RNAMSM_OK = 0
-F32, BF16 = 0, 1
+F32, BF16, BF16X3, F16X3 = 0, 1, 2, 3
+DTYPES = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3, "f16x3": F16X3}
 ACT_NONE, ACT_GELU_ERF = 0, 1
 
 # index tables of rnamsm_forward's weight-pointer array (include/rnamsm.h)
@@ -37,6 +38,9 @@ _SIGNATURES = {
     "rnamsm_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "rnamsm_gemm_bias_act_res": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                          c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),
+    "rnamsm_split_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "rnamsm_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                 c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p]),
     "rnamsm_row_logits_nsplit": (c_int, [c_int, c_int, c_int]),
     "rnamsm_row_logits_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rnamsm_row_logits": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -53,7 +57,7 @@ _SIGNATURES = {
     "rnamsm_greedy_select": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rnamsm_forward_workspace_bytes": (c_size_t, [POINTER(ModelDims), c_int, c_int]),
     "rnamsm_forward": (c_int, [POINTER(ModelDims), POINTER(c_void_p), c_void_p, c_int, c_int, c_void_p, c_size_t,
-                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p), c_void_p]),
     "rnamsm_timing_enable": (c_int, [c_int]),
     "rnamsm_timing_collect": (c_int, []),
     "rnamsm_timing_get": (c_int, [c_int, POINTER(c_char_p), POINTER(ctypes.c_longlong), POINTER(ctypes.c_double),

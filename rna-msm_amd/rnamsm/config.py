@@ -36,6 +36,8 @@ class MSATransformerModelConfig:        # RNA_MSM_Inference.py:35-43
     dropout: float = 0.1
     attention_dropout: float = 0.1
     activation_dropout: float = 0.1
+    # extra (not in the reference): arithmetic of the Linear GEMMs -- f32 (exact, default) | f16x3 | bf16x3 | bf16
+    gemm_dtype: str = "f32"
 
 
 @dataclass

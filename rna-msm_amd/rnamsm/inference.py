@@ -82,6 +82,7 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                                max_seqlen=cfg.data.max_seqlen)
         load_checkpoint(model, cfg.data.model_path, device)
     model = model.eval().to(device)
+    model.gemm_dtype = cfg.model.gemm_dtype
 
     save_dir = root / cfg.data.MSA_path
     save_dir.mkdir(parents=True, exist_ok=True)

@@ -79,6 +79,9 @@ class MSATransformer(nn.Module):
         self._workspace = None
         self._lm_pad = None
         self.compute_logits = False
+        # Arithmetic of the Linear GEMMs in the C++ driver: "f32" (exact, default), "bf16" or "bf16x3" (include/rnamsm.h).
+        self.gemm_dtype = "f32"
+        self._planes = None
 
     # ------------------------------------------------------------------ reference API
     def max_tokens_per_msa_(self, value: int) -> None:
@@ -134,6 +137,24 @@ class MSATransformer(nn.Module):
         self._pack_key = key
         return self._pack
 
+    def _weight_planes(self):
+        """bf16 hi/lo planes of the six GEMM weights per layer (rnamsm_split_bf16), built once per weight version."""
+        dims, ptrs, keep = self._packed_weights()
+        fmt = 1 if self.gemm_dtype == "f16x3" else 0
+        if self._planes is not None and self._planes[0] is self._pack_key and self._planes[3] == fmt:
+            return self._planes[1]
+        ng, nl = len(_lib.W_GLOBAL), len(_lib.W_LAYER)
+        slots = [_lib.W_LAYER.index(n) for n in ("row_wqkv", "row_wo", "col_wqkv", "col_wo", "fc1_w", "fc2_w")]
+        tensors, addrs = [], []
+        for layer in range(self.num_layers):
+            for s in slots:
+                hi, lo = ops.split_bf16(keep[ng + layer * nl + s], fmt=fmt)
+                tensors += [hi, lo]
+                addrs += [hi.data_ptr(), lo.data_ptr()]
+        arr = (ctypes.c_void_p * len(addrs))(*addrs)
+        self._planes = (self._pack_key, arr, tensors, fmt)
+        return arr
+
     def _get_workspace(self, nbytes: int, device) -> torch.Tensor:
         if self._workspace is None or self._workspace.numel() < nbytes or self._workspace.device != device:
             self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -184,12 +205,14 @@ class MSATransformer(nn.Module):
         emb = torch.empty(C - 1, D, device=dev, dtype=torch.float32)
         atp = torch.empty(NL * H, C - 1, C - 1, device=dev, dtype=torch.float32)
         err = torch.zeros(1, device=dev, dtype=torch.int32)
+        dtype = _lib.DTYPES[self.gemm_dtype]
+        planes = self._weight_planes() if dtype != _lib.F32 else None
         toks = tokens2d.to(torch.int64).contiguous()
         if has_padding is None:       # padding_mask = tokens.eq(pad); None when nothing is padded (model.py:346-348)
             has_padding = bool((toks == self.vocab.pad_idx).any())
         _lib.check(lib.rnamsm_forward(ctypes.byref(dims), ptrs, toks.data_ptr(), R, C, ws.data_ptr(), ws.numel(),
                                       row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
-                                      err.data_ptr(), int(has_padding), _lib.F32,
+                                      err.data_ptr(), int(has_padding), dtype, planes,
                                       torch.cuda.current_stream().cuda_stream))
         return {"row_attn": row_attn, "repr": rep, "emb": emb, "atp": atp, "err": err}
 

@@ -63,6 +63,33 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+def split_bf16(w: torch.Tensor, want_lo: bool = True, fmt: int = 0):
+    """fp32 tensor -> (hi, lo) 16-bit planes (fmt 0 = bf16, 1 = fp16) as int16 tensors of the same shape
+    (lo = half(w - hi), None if not wanted)."""
+    w = w.contiguous()
+    hi = torch.empty(w.shape, dtype=torch.int16, device=w.device)
+    lo = torch.empty(w.shape, dtype=torch.int16, device=w.device) if want_lo else None
+    _lib.check(_lib.load().rnamsm_split_bf16(_dev(w, "w"), hi.data_ptr(), None if lo is None else lo.data_ptr(),
+                                             w.numel(), fmt, _stream()))
+    return hi, lo
+
+
+def linear_bf16(a: torch.Tensor, w_hi: torch.Tensor, w_lo: Optional[torch.Tensor], bias: Optional[torch.Tensor] = None,
+                act: int = ACT_NONE, residual: Optional[torch.Tensor] = None, scale: float = 1.0, scale_cols: int = 0,
+                out: Optional[torch.Tensor] = None, split: int = 3, fmt: int = 0) -> torch.Tensor:
+    """`linear` on the 16-bit matrix cores: split = 1 (bf16 operands) or 3 (hi/lo split; fmt 0 = bf16x3, 1 = f16x3)."""
+    M, K = a.shape
+    N = w_hi.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_gemm_bf16(
+        _dev(a, "a"), _rowmajor(a, "a"), _dev(w_hi, "w_hi", torch.int16), None if w_lo is None else _dev(w_lo, "w_lo", torch.int16),
+        None if bias is None else _dev(bias, "bias"), None if residual is None else _dev(residual, "residual"),
+        0 if residual is None else _rowmajor(residual, "residual"), _dev(out, "out"), _rowmajor(out, "out"), M, N, K, act,
+        scale, scale_cols, split, fmt, _stream()))
+    return out
+
+
 def row_logits(q: torch.Tensor, k: torch.Tensor, R: int, C: int, H: int) -> Tuple[torch.Tensor, int]:
     """q, k: [R*C, *] views with row stride ld; returns (partial [nsplit,H,C,C], nsplit)."""
     lib = _lib.load()

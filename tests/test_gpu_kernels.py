@@ -301,3 +301,28 @@ def test_padding_mask_kernel_semantics(dev):
     wc = torch.einsum("ichd,jchd->hcij", q, k).masked_fill(pad.t()[None, :, None, :], -10000)
     want_ctx = torch.einsum("hcij,jchd->ichd", torch.softmax(wc, -1), v).reshape(R * C, D)
     assert rel_l2(ctx, want_ctx) < 5e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 64), (300, 384, 128), (1025, 768, 768), (513, 768, 3072)])
+def test_gemm_16bit_matrix_core_modes(dev, M, N, K):
+    """rnamsm_gemm_bf16 (include/rnamsm.h): stated error of each operand mode vs fp64 -- bf16 (2^-9 operands),
+    bf16x3 (hi/lo bf16, ~2^-17), f16x3 (hi/lo fp16, ~2^-22: the same as the exact-fp32 kernel) -- with every epilogue."""
+    from rnamsm import ops
+    from rnamsm._lib import ACT_GELU_ERF
+    a, w, b, r = _rand("h.a", (M, K)), _rand("h.w", (N, K), 0.05), _rand("h.b", (N,), 0.1), _rand("h.r", (M, N))
+    base = a.double() @ w.double().t() + b.double()
+    planes = {0: ops.split_bf16(w.to(dev), fmt=0), 1: ops.split_bf16(w.to(dev), fmt=1)}
+    for split, fmt, tol in ((1, 0, 6e-3), (3, 0, 3e-5), (3, 1, 3e-6)):
+        hi, lo = planes[fmt]
+        y = ops.linear_bf16(a.to(dev), hi, lo if split == 3 else None, b.to(dev), split=split, fmt=fmt).cpu()
+        assert rel_l2(y, base) < tol, (split, fmt)
+        y = ops.linear_bf16(a.to(dev), hi, lo if split == 3 else None, b.to(dev), act=ACT_GELU_ERF, residual=r.to(dev),
+                            scale=0.5, scale_cols=128, split=split, fmt=fmt).cpu()
+        want = base.clone(); want[:, :128] *= 0.5
+        assert rel_l2(y, O.gelu_erf(want) + r.double()) < tol, (split, fmt)
+    # exact-integer operands are exactly representable in both 16-bit formats: bit-exact and transposition-proof
+    ai = torch.from_numpy(((np.arange(M * K).reshape(M, K) * 7 + 3) % 13 - 6).astype(np.float32))
+    wi = torch.from_numpy(((np.arange(N * K).reshape(N, K) * 5 + 1) % 11 - 5).astype(np.float32))
+    for fmt in (0, 1):
+        hi, lo = ops.split_bf16(wi.to(dev), fmt=fmt)
+        assert torch.equal(ops.linear_bf16(ai.to(dev), hi, lo, split=3, fmt=fmt).cpu(), ai @ wi.t())

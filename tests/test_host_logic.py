@@ -118,7 +118,7 @@ def test_config_defaults_and_overrides():
     assert (c.data.device, c.data.MSA_path, c.data.MSA_list, c.data.max_seqlen, c.data.max_tokens,
             c.data.max_seqs_per_msa, c.data.sample_method, c.data.architecture) == \
         ("cuda", "results", "rna_id.txt", 1024, 16384, 512, "hhfilter", "rna language")
-    assert (c.model.embed_dim, c.model.num_attention_heads, c.model.num_layers) == (768, 12, 10)
+    assert (c.model.embed_dim, c.model.num_attention_heads, c.model.num_layers, c.model.gemm_dtype) == (768, 12, 10, "f32")
     c = parse_overrides(["data.root_path=/x", "data.MSA_path=r2", "data.model_path=/m.ckpt", "data.MSA_list=ids.txt",
                          "model.num_layers=3", "data.max_seqs_per_msa=64", "model.embed_positions_msa=false"])
     assert c.data.root_path == "/x" and c.data.MSA_path == "r2" and c.model.num_layers == 3
