@@ -220,12 +220,19 @@ __global__ __launch_bounds__(HB_THREADS, SPLIT == 3 ? 1 : 2) void gemm_bf16_kern
                 stage[(mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh) * LDE + nt * 32 + li] = v;
             }
     }
+    f32x4 ov[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int r = er + 4 * i;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&stage[r * LDE + ec]);
-        if (HAS_RES) v += res[i];
-        if (gm0 + r < M) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + r) * ldc + gn) = v;
+        ov[i] = *reinterpret_cast<const f32x4*>(&stage[(er + 4 * i) * LDE + ec]);
+        if (HAS_RES) ov[i] += res[i];
+    }
+    if (m0 + HB_BM <= M) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (gm0 + er + 4 * i < M) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
     }
 }
 

@@ -95,17 +95,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
             }
     }
     // same-wave LDS write -> read: ordered by the hardware queue, the compiler inserts the lgkmcnt wait
+    // all 16 LDS reads first, then the stores; full tiles (the common case) carry no per-row bounds branch -- hipcc
+    // otherwise sinks each read into its row's branch and serialises read -> wait -> store sixteen times
+    f32x4 ov[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int r = er + 4 * i;
-        f32x4 v = *reinterpret_cast<const f32x4*>(&stage[r * LDE + ec]);
-        if (HAS_RES) v += res[i];
+        ov[i] = *reinterpret_cast<const f32x4*>(&stage[r * LDE + ec]);
+        if (HAS_RES) ov[i] += res[i];
         // f2: q *= 1 - padding_mask (modules.py:767-772): padded tokens get q = 0 (the scaled columns are q)
-        if (ZROWS && gn < scale_cols && zero_rows[min(gm0 + r, M - 1)]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (gm0 + r < M) {
-            if (debug & 1) asm volatile("" ::"v"(v)); else
-            *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + r) * ldc + gn) = v;
-        }
+        if (ZROWS && gn < scale_cols && zero_rows[min(gm0 + r, M - 1)]) ov[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (debug & 1) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(ov[i]));
+    } else if (m0 + BM <= M) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (gm0 + er + 4 * i < M) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
     }
 }
 
