@@ -42,7 +42,9 @@ def pmc_traffic_per_launch(kernel_prefix="rnamsm::gemm_f32_kernel"):
     kernel's template instances.  Counters cannot be collected inside a timed run, so this is the profile's figure for
     the same workload, or None when no summary is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))
+                   if re.fullmatch(r"r\d+_pmc_summary\.json", os.path.basename(f)))
     if not files:
         return None, None
     summ = json.load(open(files[-1]))

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Fold rocprofv3 --pmc counter_collection CSVs (gpurun_out/pmc*/) into profiles/<tag>_pmc_*.csv and <tag>_pmc_summary.json.
+HBM-side bytes: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced streaming read
+(MI355X_MICROARCH.md §HBM) and is doubled."""
+import collections, csv, glob, json, sys
+tag = sys.argv[1]
+out = {}
+for d, name in (("pmc1", "fetch_size"), ("pmc2", "write_size"), ("pmc3", "sq")):
+    files = glob.glob(f"gpurun_out/{d}/*/*counter_collection.csv")
+    if not files:
+        continue
+    rows = list(csv.DictReader(open(files[0])))
+    agg = collections.OrderedDict()
+    for r in rows:
+        key = (r["Kernel_Name"], r["Counter_Name"], r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"])
+        a = agg.setdefault(key, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
+    with open(f"profiles/{tag}_pmc_{name}.csv", "w", newline="") as fo:
+        w = csv.writer(fo)
+        w.writerow(["Kernel_Name", "Counter_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Dispatches", "Mean_Counter_Value"])
+        for k, (n, s) in agg.items():
+            w.writerow(list(k) + [n, s / n])
+    per = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for r in rows:
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if k.startswith("rnamsm"):
+            a = per[k][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+    for k, v in per.items():
+        for c, (n, s) in v.items():
+            out.setdefault(k, {})[c + "_per_dispatch"] = s / n
+            out[k]["dispatches_" + ("FETCH_SIZE" if d == "pmc1" else "WRITE_SIZE" if d == "pmc2" else "SQ")] = n
+for k, v in out.items():
+    if "FETCH_SIZE_per_dispatch" in v:
+        v["hbm_read_bytes_corrected"] = 2 * 1024 * v["FETCH_SIZE_per_dispatch"]
+        v["hbm_write_bytes"] = 1024 * v.get("WRITE_SIZE_per_dispatch", 0.0)
+json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1, sort_keys=True)
+for k, v in out.items():
+    print(k, {a: round(b / 1e6, 1) for a, b in v.items() if "bytes" in a},
+          {a: f"{b:.3e}" for a, b in v.items() if a.startswith("SQ_")})
