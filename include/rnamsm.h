@@ -93,7 +93,14 @@ int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float* W, const 
 int rnamsm_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, int fmt, void* stream);
 int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                      const float* residual, int64_t ldr, float* Cout, int64_t ldc, int64_t M, int N, int K,
-                     int act, float scale, int scale_cols, int split, int fmt, void* stream);
+                     int act, float scale, int scale_cols, int split, int fmt,
+                     const uint16_t* A_hi, const uint16_t* A_lo, uint16_t* O_hi, uint16_t* O_lo, void* stream);
+/* LayerNorm (K1) whose output is written as 16-bit hi/lo planes [T, D] (lo may be NULL), the pre-split A operand of
+ * rnamsm_gemm_bf16: with A_hi/A_lo given (row stride lda halves) A is ignored and no conversion runs in the GEMM;
+ * with O_hi/O_lo given (fc1: GELU, no residual) the result is written as planes with row stride ldc for the next
+ * GEMM instead of fp32 Cout. */
+int rnamsm_layernorm_split(const float* x, const float* gamma, const float* beta, uint16_t* hi, uint16_t* lo,
+                           int64_t T, int D, float eps, int fmt, void* stream);
 
 /* K4 -- tied row-attention logits, RowSelfAttention.compute_attention_weights (modules.py:752-786):
  *   S[h,i,j] = sum_{r,d} q[r,i,h,d] * k[r,j,h,d]      (q already scaled by dh^-0.5/sqrt(R), K3)

@@ -120,6 +120,10 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm_prefetch_depth = value;
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "gemm16_dma")) {
+        rnamsm::tuning().gemm16_dma = value;
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "gemm_debug")) {
         rnamsm::tuning().gemm_debug = value;
         return RNAMSM_OK;

@@ -87,7 +87,28 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
                                             zero_rows, f32, stream);
         const uint16_t* const* P = weight_planes + (size_t)layer * RNAMSM_PLANES_PER_LAYER + 2 * slot;
         return rnamsm_gemm_bf16(A, lda, P[0], P[1], bias, res, ldr, out, ldc, T, N, K, act, scale, scale_cols,
-                                dtype == RNAMSM_BF16 ? 1 : 3, dtype == RNAMSM_F16X3 ? 1 : 0, stream);
+                                dtype == RNAMSM_BF16 ? 1 : 3, dtype == RNAMSM_F16X3 ? 1 : 0, nullptr, nullptr, nullptr,
+                                nullptr, stream);
+    };
+    // 16-bit modes without padding: LayerNorm and the fc1 epilogue write their outputs directly as hi/lo planes (the
+    // A operands of the QKV / fc1 / fc2 GEMMs), so those GEMMs stage plain 16-B copies.  The planes overlay the fp32
+    // buffers they replace (2 x 2 B per element).
+    const bool planes = dtype != RNAMSM_F32 && !has_padding;
+    const int split = dtype == RNAMSM_BF16 ? 1 : 3, fmt = dtype == RNAMSM_F16X3 ? 1 : 0;
+    uint16_t* xn_hi = reinterpret_cast<uint16_t*>(xn);
+    uint16_t* xn_lo = split == 3 ? xn_hi + T * D : nullptr;
+    uint16_t* hid_hi = reinterpret_cast<uint16_t*>(hidden);
+    uint16_t* hid_lo = split == 3 ? hid_hi + T * (int64_t)F : nullptr;
+    auto ln_for_gemm = [&](const float* g, const float* b) -> int {
+        if (planes) return rnamsm_layernorm_split(x, g, b, xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream);
+        return rnamsm_layernorm(x, g, b, xn, T, D, d.ln_eps, stream);
+    };
+    auto linear_pl = [&](int layer, int slot, const uint16_t* ahi, const uint16_t* alo, int64_t lda, const float* bias,
+                         const float* res, int64_t ldr, float* out, uint16_t* ohi, uint16_t* olo, int64_t ldc, int N,
+                         int K, int act, float scale, int scale_cols) -> int {
+        const uint16_t* const* P = weight_planes + (size_t)layer * RNAMSM_PLANES_PER_LAYER + 2 * slot;
+        return rnamsm_gemm_bf16(nullptr, lda, P[0], P[1], bias, res, ldr, out, ldc, T, N, K, act, scale, scale_cols, split,
+                                fmt, ahi, alo, ohi, olo, stream);
     };
     const float row_scale = (1.0f / sqrtf(64.0f)) / sqrtf((float)R);     // align_scaling, modules.py:713-715
     const float col_scale = 1.0f / sqrtf(64.0f);                         // modules.py:839
@@ -104,24 +125,40 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
         float* probs = row_attn + (int64_t)l * H * C * C;
         // ---- tied row attention block
-        FWD(rnamsm_layernorm(x, W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B], xn, T, D, d.ln_eps, stream));
-        FWD(linear(l, 0, xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
-                   RNAMSM_ACT_NONE, row_scale, D, mask));
+        FWD(ln_for_gemm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
+        if (planes)
+            FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
+                          RNAMSM_ACT_NONE, row_scale, D));
+        else
+            FWD(linear(l, 0, xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
+                       RNAMSM_ACT_NONE, row_scale, D, mask));
         FWD(rnamsm_row_logits(qkv, qkv + D, ldq, part, R, C, H, 64, f32, stream));
         FWD(rnamsm_softmax_rows(part, nsplit, probs, H, C, mask, stream));
         FWD(rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, f32, stream));
         FWD(linear(l, 1, ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
         // ---- column attention block
-        FWD(rnamsm_layernorm(x, W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B], xn, T, D, d.ln_eps, stream));
-        FWD(linear(l, 2, xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
-                   RNAMSM_ACT_NONE, col_scale, D, nullptr));
+        FWD(ln_for_gemm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
+        if (planes)
+            FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
+                          RNAMSM_ACT_NONE, col_scale, D));
+        else
+            FWD(linear(l, 2, xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
+                       RNAMSM_ACT_NONE, col_scale, D, nullptr));
         FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, mask, f32, stream));
         FWD(linear(l, 3, ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
         // ---- feed-forward block
-        FWD(rnamsm_layernorm(x, W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B], xn, T, D, d.ln_eps, stream));
-        FWD(linear(l, 4, xn, D, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], nullptr, 0, hidden, F, F, D, RNAMSM_ACT_GELU_ERF,
-                   1.f, 0, nullptr));
-        FWD(linear(l, 5, hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], x, D, x, D, D, F, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
+        FWD(ln_for_gemm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
+        if (planes) {
+            FWD(linear_pl(l, 4, xn_hi, xn_lo, D, W[RNAMSM_WL_FC1_B], nullptr, 0, nullptr, hid_hi, hid_lo, F, F, D,
+                          RNAMSM_ACT_GELU_ERF, 1.f, 0));
+            FWD(linear_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, D, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE,
+                          1.f, 0));
+        } else {
+            FWD(linear(l, 4, xn, D, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], nullptr, 0, hidden, F, F, D,
+                       RNAMSM_ACT_GELU_ERF, 1.f, 0, nullptr));
+            FWD(linear(l, 5, hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], x, D, x, D, D, F, RNAMSM_ACT_NONE, 1.f, 0,
+                       nullptr));
+        }
     }
     FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
     FWD(rnamsm_pack_outputs(repr, row_attn, emb, atp, C, D, NL, H, stream));

@@ -100,11 +100,83 @@ __device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, typename 
     }
 }
 
-template <int ACT, bool HAS_RES, int SPLIT, int FMT>
+// Epilogue shared by the 16-bit GEMM kernels: identical to gemm_f32.hip (the 32x32 accumulator map does not depend on
+// the operand dtype); O_PL writes 16-bit planes for the next GEMM instead of fp32.
+template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
+__device__ __forceinline__ void hb_epilogue(f32x16 (&acc)[2][2], char* smem_b, int m0, int n0, int wm, int wn, int wv,
+                                            int lane, int li, int lh, const float* __restrict__ bias,
+                                            const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M,
+                                            float scale, int scale_cols, uint16_t* __restrict__ Ohi,
+                                            uint16_t* __restrict__ Olo) {
+    constexpr int LDE = 64 + 4;
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+    const int gm0 = m0 + wm * 64, gn = n0 + wn * 64 + ec;
+    f32x4 res[16];
+    if (HAS_RES) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = min(gm0 + er + 4 * i, M - 1);
+            res[i] = *reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn);
+        }
+    }
+    __syncthreads();
+    float* stage = reinterpret_cast<float*>(smem_b) + wv * (64 * LDE);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = n0 + wn * 64 + nt * 32 + li;
+        const float b = bias ? bias[col] : 0.f;
+        const float sc = col < scale_cols ? scale : 1.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                float v = (acc[mt][nt][t] + b) * sc;
+                if (ACT == RNAMSM_ACT_GELU_ERF) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+                stage[(mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh) * LDE + nt * 32 + li] = v;
+            }
+    }
+    f32x4 ov[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        ov[i] = *reinterpret_cast<const f32x4*>(&stage[(er + 4 * i) * LDE + ec]);
+        if (HAS_RES) ov[i] += res[i];
+    }
+    if (O_PL) {      // 4 values -> 4 halves hi (+ 4 halves lo): 8-byte stores into the planes
+        typedef typename Half16<FMT>::T H;
+        typedef H H4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (gm0 + er + 4 * i < M) {
+                H4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hi[e] = (H)ov[i][e];
+                    lo[e] = (H)(ov[i][e] - (float)hi[e]);
+                }
+                const int64_t o = (int64_t)(gm0 + er + 4 * i) * ldc + gn;
+                *reinterpret_cast<H4*>(Ohi + o) = hi;
+                if (SPLIT == 3) *reinterpret_cast<H4*>(Olo + o) = lo;
+            }
+        }
+    } else if (m0 + HB_BM <= M) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (gm0 + er + 4 * i < M) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
+    }
+}
+
+// A_PL: the A operand arrives pre-split as 16-bit planes (Ahi/Alo, row stride lda halves) written by its producer
+//       (rnamsm_layernorm_split, or this kernel's O_PL epilogue) -- staging is then a plain 16-B copy, no conversion.
+// O_PL: the epilogue writes the result as 16-bit planes (Ohi/Olo, row stride ldc halves) for the next GEMM.
+template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool A_PL, bool O_PL>
 __global__ __launch_bounds__(HB_THREADS, SPLIT == 3 ? 1 : 2) void gemm_bf16_kernel(
     const float* __restrict__ A, int64_t lda, const uint16_t* __restrict__ Whi, const uint16_t* __restrict__ Wlo,
     const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K,
-    float scale, int scale_cols) {
+    float scale, int scale_cols, const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo,
+    uint16_t* __restrict__ Ohi, uint16_t* __restrict__ Olo) {
     using Cfg = HbCfg<SPLIT>;
     typedef typename Half16<FMT>::V8 bf16x8;
     constexpr int NPL = Cfg::NPL;
@@ -120,12 +192,13 @@ __global__ __launch_bounds__(HB_THREADS, SPLIT == 3 ? 1 : 2) void gemm_bf16_kern
     const int c8 = threadIdx.x & 7, r0 = threadIdx.x >> 3;        // staging: rows r0 + 32 i, 8-element chunk c8
 
     const float* ap[4];
-    int64_t woff[4];
+    int64_t woff[4], aoff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int m = m0 + r0 + 32 * i;
         m = m < M ? m : M - 1;
         ap[i] = A + (int64_t)m * lda + c8 * 8;
+        aoff[i] = (int64_t)m * lda + c8 * 8;
         woff[i] = (int64_t)(n0 + r0 + 32 * i) * K + c8 * 8;
     }
 
@@ -137,13 +210,19 @@ __global__ __launch_bounds__(HB_THREADS, SPLIT == 3 ? 1 : 2) void gemm_bf16_kern
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
 
-    f32x4 sa[4][2];
+    f32x4 sa[A_PL ? 1 : 4][2];
+    u32x4 sah[NPL][A_PL ? 4 : 1];
     u32x4 sw[NPL][4];
     auto load = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            sa[i][0] = *reinterpret_cast<const f32x4*>(ap[i] + kt * HB_BK);
-            sa[i][1] = *reinterpret_cast<const f32x4*>(ap[i] + kt * HB_BK + 4);
+            if (A_PL) {
+                sah[0][i] = *reinterpret_cast<const u32x4*>(Ahi + aoff[i] + kt * HB_BK);
+                if (SPLIT == 3) sah[NPL - 1][i] = *reinterpret_cast<const u32x4*>(Alo + aoff[i] + kt * HB_BK);
+            } else {
+                sa[i][0] = *reinterpret_cast<const f32x4*>(ap[i] + kt * HB_BK);
+                sa[i][1] = *reinterpret_cast<const f32x4*>(ap[i] + kt * HB_BK + 4);
+            }
             sw[0][i] = *reinterpret_cast<const u32x4*>(Whi + woff[i] + kt * HB_BK);
             if (SPLIT == 3) sw[NPL - 1][i] = *reinterpret_cast<const u32x4*>(Wlo + woff[i] + kt * HB_BK);
         }
@@ -153,10 +232,15 @@ __global__ __launch_bounds__(HB_THREADS, SPLIT == 3 ? 1 : 2) void gemm_bf16_kern
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int off = (r0 + 32 * i) * HB_LDB + c8 * 16;
-            bf16x8 hi, lo;
-            split8<FMT>(sa[i][0], sa[i][1], hi, lo, SPLIT == 3);
-            *reinterpret_cast<bf16x8*>(base + off) = hi;
-            if (SPLIT == 3) *reinterpret_cast<bf16x8*>(base + HB_PLANE + off) = lo;
+            if (A_PL) {
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(base + p * HB_PLANE + off) = sah[p][i];
+            } else {
+                bf16x8 hi, lo;
+                split8<FMT>(sa[i][0], sa[i][1], hi, lo, SPLIT == 3);
+                *reinterpret_cast<bf16x8*>(base + off) = hi;
+                if (SPLIT == 3) *reinterpret_cast<bf16x8*>(base + HB_PLANE + off) = lo;
+            }
 #pragma unroll
             for (int p = 0; p < NPL; ++p) *reinterpret_cast<u32x4*>(base + (NPL + p) * HB_PLANE + off) = sw[p][i];
         }
@@ -192,47 +276,184 @@ __global__ __launch_bounds__(HB_THREADS, SPLIT == 3 ? 1 : 2) void gemm_bf16_kern
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // ---- epilogue: identical to gemm_f32.hip (the 32x32 accumulator map does not depend on the operand dtype)
-    constexpr int LDE = 64 + 4;
-    const int er = lane >> 4, ec = (lane & 15) * 4;
-    const int gm0 = m0 + wm * 64, gn = n0 + wn * 64 + ec;
-    f32x4 res[16];
-    if (HAS_RES) {
+    hb_epilogue<ACT, HAS_RES, SPLIT, FMT, O_PL>(acc, smem_b, m0, n0, wm, wn, wv, lane, li, lh, bias, residual, ldr, Cout, ldc,
+                                                M, scale, scale_cols, Ohi, Olo);
+}
+
+// ---- plane-input GEMM with LDS-DMA staging -------------------------------------------------------------------------
+// Both operands are 16-bit planes in HBM (A from rnamsm_layernorm_split / an O_PL epilogue, W from rnamsm_split_bf16), so
+// they go global -> LDS by global_load_lds_dwordx4 with no VGPR and no ds_write: the register-staged kernel above is
+// bound by the LDS write path (64 KB per K tile per CU at ~79 B/clk) plus its fragment reads.  A DMA writes 64 lanes x 16 B
+// linearly, so tiles are unpadded [128 rows][128 B] and the bank-conflict fix is an XOR swizzle applied on the SOURCE
+// address and on the READ (cdna_hip_programming.md rule 21): physical 16-B chunk = logical chunk ^ ((row >> 1) & 7).  For
+// any ds_read_b128 lane group (16 rows, one logical chunk) that yields 16 distinct slots of the 256-B bank row.
+constexpr int HD_PLANE = 128 * 128;                 // bytes, unpadded
+template <int SPLIT>
+struct HdCfg {
+    static constexpr int NPL = SPLIT == 3 ? 2 : 1;
+    static constexpr int BUF = 2 * NPL * HD_PLANE;
+    static constexpr int LDS = (2 * BUF) > 4 * 64 * 68 * 4 ? (2 * BUF) : 4 * 64 * 68 * 4;    // >= epilogue staging
+};
+
+template <int SPLIT, int FMT>
+__device__ __forceinline__ void hd_frag_load(const char* buf, int kk, int wm, int wn, int li, int lh, HbFrag<SPLIT, FMT>& f) {
+    typedef typename Half16<FMT>::V8 V8;
+    constexpr int NPL = HdCfg<SPLIT>::NPL;
+    const int chunk = ((2 * kk + lh) ^ ((li >> 1) & 7)) * 16;       // tile rows are multiples of 32 + li: (row>>1)&7 = (li>>1)&7
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = min(gm0 + er + 4 * i, M - 1);
-            res[i] = *reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn);
+    for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f.a[p][t] = *reinterpret_cast<const V8*>(buf + p * HD_PLANE + (wm * 64 + t * 32 + li) * 128 + chunk);
+            f.b[p][t] = *reinterpret_cast<const V8*>(buf + (NPL + p) * HD_PLANE + (wn * 64 + t * 32 + li) * 128 + chunk);
         }
     }
-    __syncthreads();
-    float* stage = reinterpret_cast<float*>(smem_b) + wv * (64 * LDE);
+}
+
+template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
+__global__ __launch_bounds__(HB_THREADS, SPLIT == 3 ? 1 : 2) void gemm16_dma_kernel(
+    const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo, int64_t lda, const uint16_t* __restrict__ Whi,
+    const uint16_t* __restrict__ Wlo, const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout,
+    int64_t ldc, int M, int N, int K, float scale, int scale_cols, uint16_t* __restrict__ Ohi, uint16_t* __restrict__ Olo) {
+    using Cfg = HdCfg<SPLIT>;
+    constexpr int NPL = Cfg::NPL;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+
+    const unsigned nb = N / HB_BN, mp = (M + HB_BM - 1) / HB_BM;
+    unsigned mpanel, nblk;
+    if (!xcd_panel_map(blockIdx.x, mp, nb, mpanel, nblk)) return;
+    const int m0 = mpanel * HB_BM, n0 = nblk * HB_BN;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv >> 1, wn = wv & 1, li = lane & 31, lh = lane >> 5;
+
+    // DMA map: one wave instruction = 8 rows x 128 B; wave w moves row groups w, w+4, w+8, w+12 of every plane.
+    // lane -> (row R0 + lane/8, physical chunk lane%8) which must hold logical chunk (lane%8) ^ ((row>>1)&7).
+    const int drow = lane >> 3;
+    const int dchunk = (lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7);       // (row>>1)&7 does not depend on j
+    int64_t aoff[4], woff[4];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = n0 + wn * 64 + nt * 32 + li;
-        const float b = bias ? bias[col] : 0.f;
-        const float sc = col < scale_cols ? scale : 1.f;
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * (wv + 4 * j) + drow;
+        int m = m0 + row;
+        m = m < M ? m : M - 1;
+        aoff[j] = (int64_t)m * lda + dchunk * 8;
+        woff[j] = (int64_t)(n0 + row) * K + dchunk * 8;
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto issue = [&](int kt, int buf) {
+        char* base = smem_b + buf * Cfg::BUF;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int j = 0; j < 4; ++j) {
+            const int loff = (8 * (wv + 4 * j)) * 128;                          // wave-uniform LDS row-group offset
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ahi + aoff[j] + kt * HB_BK), (lptr_t)(base + loff), 16, 0, 0);
+            if (SPLIT == 3)
+                __builtin_amdgcn_global_load_lds((gptr_t)(Alo + aoff[j] + kt * HB_BK), (lptr_t)(base + HD_PLANE + loff), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Whi + woff[j] + kt * HB_BK), (lptr_t)(base + NPL * HD_PLANE + loff), 16, 0, 0);
+            if (SPLIT == 3)
+                __builtin_amdgcn_global_load_lds((gptr_t)(Wlo + woff[j] + kt * HB_BK), (lptr_t)(base + (NPL + 1) * HD_PLANE + loff), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                float v = (acc[mt][nt][t] + b) * sc;
-                if (ACT == RNAMSM_ACT_GELU_ERF) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-                stage[(mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh) * LDE + nt * 32 + li] = v;
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
+
+    const int nk = K / HB_BK;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                 // vmcnt(0) + barrier: tile kt has landed, the other buffer is free again
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* cur = smem_b + (kt & 1) * Cfg::BUF;
+        HbFrag<SPLIT, FMT> f0, f1;
+        hd_frag_load<SPLIT, FMT>(cur, 0, wm, wn, li, lh, f0);
+        hd_frag_load<SPLIT, FMT>(cur, 1, wm, wn, li, lh, f1);
+        hb_frag_mma<SPLIT, FMT>(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        hd_frag_load<SPLIT, FMT>(cur, 2, wm, wn, li, lh, f0);
+        hb_frag_mma<SPLIT, FMT>(f1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        hd_frag_load<SPLIT, FMT>(cur, 3, wm, wn, li, lh, f1);
+        hb_frag_mma<SPLIT, FMT>(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        hb_frag_mma<SPLIT, FMT>(f1, acc);
+    }
+    hb_epilogue<ACT, HAS_RES, SPLIT, FMT, O_PL>(acc, smem_b, m0, n0, wm, wn, wv, lane, li, lh, bias, residual, ldr, Cout, ldc,
+                                                M, scale, scale_cols, Ohi, Olo);
+}
+
+template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
+static int launch_hd(const uint16_t* Whi, const uint16_t* Wlo, const float* bias, const float* residual, int64_t ldr,
+                     float* Cout, int64_t ldc, int64_t lda, int M, int N, int K, float scale, int scale_cols,
+                     const uint16_t* a_hi, const uint16_t* a_lo, uint16_t* o_hi, uint16_t* o_lo, hipStream_t stream) {
+    static bool configured = false;
+    auto kern = gemm16_dma_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL>;
+    constexpr int lds = HdCfg<SPLIT>::LDS;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_dma: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    const unsigned grid = xcd_panel_grid((M + HB_BM - 1) / HB_BM, N / HB_BN);
+    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 2.0 * HdCfg<SPLIT>::NPL * ((double)M * K + (double)N * K) + 4.0 * (double)M * N * (HAS_RES ? 2 : 1), stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(HB_THREADS), lds, stream, a_hi, a_lo, lda, Whi, Wlo, bias, residual, ldr, Cout,
+                       ldc, M, N, K, scale, scale_cols, o_hi, o_lo);
+    RNAMSM_CHECK_LAUNCH("gemm16_dma");
+    return RNAMSM_OK;
+}
+
+// LayerNorm whose output goes straight into 16-bit hi/lo planes (the A operand of the following matrix-core GEMM):
+// same arithmetic as layernorm_kernel (elementwise.hip), only the store differs.
+template <int FMT>
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, uint16_t* __restrict__ hi,
+                                                              uint16_t* __restrict__ lo, int64_t T, int D, float eps) {
+    typedef typename Half16<FMT>::T H;
+    typedef H H4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, nvec = D / 4;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += stride) {
+        f32x4 v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (lane + 64 * e < nvec) {
+                v[e] = *reinterpret_cast<const f32x4*>(x + row * D + 4 * (lane + 64 * e));
+                s += (v[e][0] + v[e][1]) + (v[e][2] + v[e][3]);
             }
-    }
-    f32x4 ov[16];
+        const float mean = wave_sum(s) / (float)D;
+        float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        ov[i] = *reinterpret_cast<const f32x4*>(&stage[(er + 4 * i) * LDE + ec]);
-        if (HAS_RES) ov[i] += res[i];
-    }
-    if (m0 + HB_BM <= M) {
+        for (int e = 0; e < 4; ++e)
+            if (lane + 64 * e < nvec) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
-    } else {
+                for (int i = 0; i < 4; ++i) {
+                    const float d = v[e][i] - mean;
+                    ss += d * d;
+                }
+            }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (gm0 + er + 4 * i < M) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
+        for (int e = 0; e < 4; ++e) {
+            const int vi = lane + 64 * e;
+            if (vi < nvec) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * vi);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * vi);
+                H4 h, l;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float y = (v[e][i] - mean) * rstd * g[i] + b[i];
+                    h[i] = (H)y;
+                    l[i] = (H)(y - (float)h[i]);
+                }
+                *reinterpret_cast<H4*>(hi + row * D + 4 * vi) = h;
+                if (lo) *reinterpret_cast<H4*>(lo + row * D + 4 * vi) = l;
+            }
+        }
     }
 }
 
@@ -249,12 +470,17 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     }
 }
 
-template <int ACT, bool HAS_RES, int SPLIT, int FMT>
+struct HbPlanes {
+    const uint16_t *a_hi, *a_lo;
+    uint16_t *o_hi, *o_lo;
+};
+
+template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool A_PL = false, bool O_PL = false>
 static int launch_hb(const float* A, int64_t lda, const uint16_t* Whi, const uint16_t* Wlo, const float* bias,
                      const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale,
-                     int scale_cols, hipStream_t stream) {
+                     int scale_cols, HbPlanes pl, hipStream_t stream) {
     static bool configured = false;
-    auto kern = gemm_bf16_kernel<ACT, HAS_RES, SPLIT, FMT>;
+    auto kern = gemm_bf16_kernel<ACT, HAS_RES, SPLIT, FMT, A_PL, O_PL>;
     constexpr int lds = HbCfg<SPLIT>::LDS;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -264,7 +490,7 @@ static int launch_hb(const float* A, int64_t lda, const uint16_t* Whi, const uin
     const unsigned grid = xcd_panel_grid((M + HB_BM - 1) / HB_BM, N / HB_BN);
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + 0.5 * HbCfg<SPLIT>::NPL * (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HB_THREADS), lds, stream, A, lda, Whi, Wlo, bias, residual, ldr, Cout, ldc, M,
-                       N, K, scale, scale_cols);
+                       N, K, scale, scale_cols, pl.a_hi, pl.a_lo, pl.o_hi, pl.o_lo);
     RNAMSM_CHECK_LAUNCH("gemm_bf16");
     return RNAMSM_OK;
 }
@@ -287,29 +513,66 @@ extern "C" int rnamsm_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, i
 
 extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_hi, const uint16_t* W_lo, const float* bias,
                                 const float* residual, int64_t ldr, float* Cout, int64_t ldc, int64_t M, int N, int K,
-                                int act, float scale, int scale_cols, int split, int fmt, void* stream) {
-    RNAMSM_CHECK_ARG(A && W_hi && Cout, "gemm_bf16: null pointer");
+                                int act, float scale, int scale_cols, int split, int fmt, const uint16_t* A_hi,
+                                const uint16_t* A_lo, uint16_t* O_hi, uint16_t* O_lo, void* stream) {
+    RNAMSM_CHECK_ARG((A || A_hi) && W_hi && (Cout || O_hi), "gemm_bf16: null pointer");
+    RNAMSM_CHECK_ARG(!A_hi || (split == 1 || A_lo), "gemm_bf16: split 3 needs the A lo plane");
+    RNAMSM_CHECK_ARG(!O_hi || (act == RNAMSM_ACT_GELU_ERF && !residual && A_hi && (split == 1 || O_lo)),
+                     "gemm_bf16: plane output is built for the fc1 shape (GELU, no residual, plane input)");
+    RNAMSM_CHECK_ARG(!A_hi || O_hi || act == RNAMSM_ACT_NONE, "gemm_bf16: plane input supports act none (f32 out) or GELU (plane out)");
     RNAMSM_CHECK_ARG(split == 1 || (split == 3 && W_lo), "gemm_bf16: split must be 1, or 3 with a lo plane");
     RNAMSM_CHECK_ARG((fmt == 0) || (fmt == 1 && split == 3), "gemm_bf16: fmt 0 (bf16) or 1 (fp16, split 3 only)");
     RNAMSM_CHECK_ARG(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "gemm_bf16: bad shape");
     RNAMSM_CHECK_ARG(N % HB_BN == 0 && K % HB_BK == 0, "gemm_bf16: need N %% 128 == 0 and K %% 64 == 0 (N=%d K=%d)", N, K);
-    RNAMSM_CHECK_ARG(lda >= K && lda % 4 == 0 && ldc >= N && ldc % 4 == 0, "gemm_bf16: bad leading dimension");
-    RNAMSM_CHECK_ARG(aligned16(A) && aligned16(W_hi) && aligned16(Cout) && (!W_lo || aligned16(W_lo)), "gemm_bf16: 16-byte alignment");
+    RNAMSM_CHECK_ARG(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 4 == 0, "gemm_bf16: bad leading dimension");
+    RNAMSM_CHECK_ARG((A_hi ? aligned16(A_hi) && (!A_lo || aligned16(A_lo)) : aligned16(A)) && aligned16(W_hi) &&
+                     (O_hi ? (reinterpret_cast<uintptr_t>(O_hi) & 7u) == 0 : aligned16(Cout)) && (!W_lo || aligned16(W_lo)),
+                     "gemm_bf16: alignment");
     RNAMSM_CHECK_ARG(!residual || (ldr >= N && ldr % 4 == 0 && aligned16(residual)), "gemm_bf16: bad residual");
     RNAMSM_CHECK_ARG(act == RNAMSM_ACT_NONE || act == RNAMSM_ACT_GELU_ERF, "gemm_bf16: unknown activation %d", act);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int m = (int)M;
-#define HB_GO(ACT_, RES_, SP_, FMT_) \
-    launch_hb<ACT_, RES_, SP_, FMT_>(A, lda, W_hi, W_lo, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, s)
-#define HB_ACT_RES(SP_, FMT_)                                                                                     \
-    do {                                                                                                          \
-        if (act == RNAMSM_ACT_GELU_ERF)                                                                           \
-            return residual ? HB_GO(RNAMSM_ACT_GELU_ERF, true, SP_, FMT_) : HB_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_); \
-        return residual ? HB_GO(RNAMSM_ACT_NONE, true, SP_, FMT_) : HB_GO(RNAMSM_ACT_NONE, false, SP_, FMT_);       \
+    const HbPlanes pl{A_hi, A_lo, O_hi, O_lo};
+#define HB_GO(ACT_, RES_, SP_, FMT_, APL_, OPL_) \
+    launch_hb<ACT_, RES_, SP_, FMT_, APL_, OPL_>(A, lda, W_hi, W_lo, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, pl, s)
+#define HD_GO(ACT_, RES_, SP_, FMT_, OPL_) \
+    launch_hd<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
+#define HB_ACT_RES(SP_, FMT_)                                                                                       \
+    do {                                                                                                            \
+        if (A_hi && tuning().gemm16_dma) {                                                                          \
+            if (O_hi) return HD_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true);                                    \
+            return residual ? HD_GO(RNAMSM_ACT_NONE, true, SP_, FMT_, false) : HD_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, false); \
+        }                                                                                                           \
+        if (O_hi) return HB_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true, true);                                  \
+        if (A_hi) return residual ? HB_GO(RNAMSM_ACT_NONE, true, SP_, FMT_, true, false)                            \
+                                  : HB_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, true, false);                          \
+        if (act == RNAMSM_ACT_GELU_ERF)                                                                             \
+            return residual ? HB_GO(RNAMSM_ACT_GELU_ERF, true, SP_, FMT_, false, false)                             \
+                            : HB_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, false, false);                           \
+        return residual ? HB_GO(RNAMSM_ACT_NONE, true, SP_, FMT_, false, false)                                     \
+                        : HB_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, false, false);                                   \
     } while (0)
     if (fmt == 1) HB_ACT_RES(3, 1);
     if (split == 3) HB_ACT_RES(3, 0);
     HB_ACT_RES(1, 0);
 #undef HB_ACT_RES
+#undef HD_GO
 #undef HB_GO
+}
+
+extern "C" int rnamsm_layernorm_split(const float* x, const float* gamma, const float* beta, uint16_t* hi, uint16_t* lo,
+                                      int64_t T, int D, float eps, int fmt, void* stream) {
+    RNAMSM_CHECK_ARG(x && gamma && beta && hi, "layernorm_split: null pointer");
+    RNAMSM_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024 && (fmt == 0 || fmt == 1), "layernorm_split: bad shape / fmt");
+    RNAMSM_CHECK_ARG(aligned16(x) && aligned16(gamma) && aligned16(beta) && (reinterpret_cast<uintptr_t>(hi) & 7u) == 0 &&
+                     (!lo || (reinterpret_cast<uintptr_t>(lo) & 7u) == 0), "layernorm_split: alignment");
+    const int64_t blocks = (T + 3) / 4;
+    const dim3 grid((unsigned)(blocks < 4096 ? blocks : 4096));
+    KernelTimer timer(TC_LAYERNORM, 0.0, (4.0 + (lo ? 4.0 : 2.0)) * T * D, static_cast<hipStream_t>(stream));
+    if (fmt == 1)
+        hipLaunchKernelGGL(layernorm_split_kernel<1>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma, beta, hi, lo, T, D, eps);
+    else
+        hipLaunchKernelGGL(layernorm_split_kernel<0>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma, beta, hi, lo, T, D, eps);
+    RNAMSM_CHECK_LAUNCH("layernorm_split");
+    return RNAMSM_OK;
 }

@@ -40,7 +40,10 @@ _SIGNATURES = {
                                          c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),
     "rnamsm_split_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rnamsm_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
-                                 c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p]),
+                                 c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "rnamsm_layernorm_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int,
+                                       c_void_p]),
     "rnamsm_row_logits_nsplit": (c_int, [c_int, c_int, c_int]),
     "rnamsm_row_logits_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rnamsm_row_logits": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -86,7 +86,7 @@ def linear_bf16(a: torch.Tensor, w_hi: torch.Tensor, w_lo: Optional[torch.Tensor
         _dev(a, "a"), _rowmajor(a, "a"), _dev(w_hi, "w_hi", torch.int16), None if w_lo is None else _dev(w_lo, "w_lo", torch.int16),
         None if bias is None else _dev(bias, "bias"), None if residual is None else _dev(residual, "residual"),
         0 if residual is None else _rowmajor(residual, "residual"), _dev(out, "out"), _rowmajor(out, "out"), M, N, K, act,
-        scale, scale_cols, split, fmt, _stream()))
+        scale, scale_cols, split, fmt, None, None, None, None, _stream()))
     return out
 
 
