@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes
 import os
+
+import torch  # noqa: F401  (load order: see rnamsm/__init__.py)
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
