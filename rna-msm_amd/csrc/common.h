@@ -47,7 +47,7 @@ struct KernelTimer {   // brackets one launch with two hipEventRecord calls when
 struct Tuning {
     int gemm_stagger = 0;
     int gemm_prefetch_depth = 1;   // staging register sets of the GEMM K loop (1 or 2)
-    int gemm16_dma = 1;            // plane-input 16-bit GEMMs: LDS-DMA staging (1) or register staging (0)
+    int gemm16_dma = 2;            // plane-input 16-bit GEMMs: 0 register staging, 1 LDS-DMA 128x128, 2 LDS-DMA 256x256 when it fits
     int gemm_debug = 0;      // measurement only: bit0 = skip the epilogue stores (results wrong)
 };
 Tuning& tuning();

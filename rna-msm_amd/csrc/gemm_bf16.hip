@@ -103,14 +103,14 @@ __device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, typename 
 // Epilogue shared by the 16-bit GEMM kernels: identical to gemm_f32.hip (the 32x32 accumulator map does not depend on
 // the operand dtype); O_PL writes 16-bit planes for the next GEMM instead of fp32.
 template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
-__device__ __forceinline__ void hb_epilogue(f32x16 (&acc)[2][2], char* smem_b, int m0, int n0, int wm, int wn, int wv,
+__device__ __forceinline__ void hb_epilogue(f32x16 (&acc)[2][2], char* smem_b, int gm0, int gnb, int wv,
                                             int lane, int li, int lh, const float* __restrict__ bias,
                                             const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M,
                                             float scale, int scale_cols, uint16_t* __restrict__ Ohi,
                                             uint16_t* __restrict__ Olo) {
     constexpr int LDE = 64 + 4;
     const int er = lane >> 4, ec = (lane & 15) * 4;
-    const int gm0 = m0 + wm * 64, gn = n0 + wn * 64 + ec;
+    const int gn = gnb + ec;                                  // gm0 / gnb: global origin of this wave's 64x64 slab
     f32x4 res[16];
     if (HAS_RES) {
 #pragma unroll
@@ -123,7 +123,7 @@ __device__ __forceinline__ void hb_epilogue(f32x16 (&acc)[2][2], char* smem_b, i
     float* stage = reinterpret_cast<float*>(smem_b) + wv * (64 * LDE);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int col = n0 + wn * 64 + nt * 32 + li;
+        const int col = gnb + nt * 32 + li;
         const float b = bias ? bias[col] : 0.f;
         const float sc = col < scale_cols ? scale : 1.f;
 #pragma unroll
@@ -158,7 +158,7 @@ __device__ __forceinline__ void hb_epilogue(f32x16 (&acc)[2][2], char* smem_b, i
                 if (SPLIT == 3) *reinterpret_cast<H4*>(Olo + o) = lo;
             }
         }
-    } else if (m0 + HB_BM <= M) {
+    } else if (gm0 + 64 <= M) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
     } else {
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(HB_THREADS, SPLIT == 3 ? 1 : 2) void gemm_bf16_kern
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    hb_epilogue<ACT, HAS_RES, SPLIT, FMT, O_PL>(acc, smem_b, m0, n0, wm, wn, wv, lane, li, lh, bias, residual, ldr, Cout, ldc,
-                                                M, scale, scale_cols, Ohi, Olo);
+    hb_epilogue<ACT, HAS_RES, SPLIT, FMT, O_PL>(acc, smem_b, m0 + wm * 64, n0 + wn * 64, wv, lane, li, lh, bias, residual, ldr,
+                                                Cout, ldc, M, scale, scale_cols, Ohi, Olo);
 }
 
 // ---- plane-input GEMM with LDS-DMA staging -------------------------------------------------------------------------
@@ -382,8 +382,8 @@ __global__ __launch_bounds__(HB_THREADS, SPLIT == 3 ? 1 : 2) void gemm16_dma_ker
         __builtin_amdgcn_sched_barrier(0);
         hb_frag_mma<SPLIT, FMT>(f1, acc);
     }
-    hb_epilogue<ACT, HAS_RES, SPLIT, FMT, O_PL>(acc, smem_b, m0, n0, wm, wn, wv, lane, li, lh, bias, residual, ldr, Cout, ldc,
-                                                M, scale, scale_cols, Ohi, Olo);
+    hb_epilogue<ACT, HAS_RES, SPLIT, FMT, O_PL>(acc, smem_b, m0 + wm * 64, n0 + wn * 64, wv, lane, li, lh, bias, residual, ldr,
+                                                Cout, ldc, M, scale, scale_cols, Ohi, Olo);
 }
 
 template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
@@ -403,6 +403,149 @@ static int launch_hd(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HB_THREADS), lds, stream, a_hi, a_lo, lda, Whi, Wlo, bias, residual, ldr, Cout,
                        ldc, M, N, K, scale, scale_cols, o_hi, o_lo);
     RNAMSM_CHECK_LAUNCH("gemm16_dma");
+    return RNAMSM_OK;
+}
+
+// ---- 256x256 tile, 8 waves: the same LDS-DMA scheme sized for the DMA latency --------------------------------------
+// Little's law: a CU consumes operand bytes at (bytes per K tile) / (MFMA cycles per K tile) and a DMA takes ~3000 cycles
+// to land, so bytes-in-flight must cover rate x latency.  The 128x128 tile eats 42 B/clk (126 KB needed, 64 KB in
+// flight); a 256x256 tile with BK = 32 eats 21 B/clk (64 KB needed = exactly the one 64 KB buffer in flight).
+// 8 waves as 2(M) x 4(N), wave tile 128x64 = 4x2 MFMA tiles (128 accumulator VGPRs), two waves per SIMD.
+// Rows are 64 B (32 halves): physical 16-B chunk = logical chunk ^ ((row >> 2) & 3), again 16 distinct slots per
+// ds_read_b128 lane group.
+constexpr int HX_BM = 256, HX_BN = 256, HX_BK = 32, HX_THREADS = 512;
+constexpr int HX_ROWB = HX_BK * 2;                     // 64 bytes per row
+constexpr int HX_PLANE = 256 * HX_ROWB;                // 16 KB
+template <int SPLIT>
+struct HxCfg {
+    static constexpr int NPL = SPLIT == 3 ? 2 : 1;
+    static constexpr int BUF = 2 * NPL * HX_PLANE;
+    static constexpr int EPI = 8 * 64 * 68 * 4;        // epilogue staging: 8 waves x [64][68] f32
+    static constexpr int LDS = (2 * BUF) > EPI ? (2 * BUF) : EPI;
+};
+template <int SPLIT, int FMT>
+struct HxFrag {
+    typename Half16<FMT>::V8 a[HxCfg<SPLIT>::NPL][4], b[HxCfg<SPLIT>::NPL][2];
+};
+template <int SPLIT, int FMT>
+__device__ __forceinline__ void hx_frag_load(const char* buf, int kk, int wm, int wn, int li, int lh, HxFrag<SPLIT, FMT>& f) {
+    typedef typename Half16<FMT>::V8 V8;
+    constexpr int NPL = HxCfg<SPLIT>::NPL;
+    const int chunk = ((2 * kk + lh) ^ ((li >> 2) & 3)) * 16;      // rows are multiples of 32 + li
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            f.a[p][t] = *reinterpret_cast<const V8*>(buf + p * HX_PLANE + (wm * 128 + t * 32 + li) * HX_ROWB + chunk);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            f.b[p][t] = *reinterpret_cast<const V8*>(buf + (NPL + p) * HX_PLANE + (wn * 64 + t * 32 + li) * HX_ROWB + chunk);
+    }
+}
+template <int SPLIT, int FMT>
+__device__ __forceinline__ void hx_frag_mma(const HxFrag<SPLIT, FMT>& f, f32x16 (&acc)[4][2]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            if (SPLIT == 3) {
+                acc[mt][nt] = Half16<FMT>::mfma(f.a[1][mt], f.b[0][nt], acc[mt][nt]);
+                acc[mt][nt] = Half16<FMT>::mfma(f.a[0][mt], f.b[1][nt], acc[mt][nt]);
+            }
+            acc[mt][nt] = Half16<FMT>::mfma(f.a[0][mt], f.b[0][nt], acc[mt][nt]);
+        }
+}
+
+template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
+__global__ __launch_bounds__(HX_THREADS, 2) void gemm16_dma256_kernel(
+    const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo, int64_t lda, const uint16_t* __restrict__ Whi,
+    const uint16_t* __restrict__ Wlo, const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout,
+    int64_t ldc, int M, int N, int K, float scale, int scale_cols, uint16_t* __restrict__ Ohi, uint16_t* __restrict__ Olo) {
+    using Cfg = HxCfg<SPLIT>;
+    constexpr int NPL = Cfg::NPL;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+
+    const unsigned nb = N / HX_BN, mp = (M + HX_BM - 1) / HX_BM;
+    unsigned mpanel, nblk;
+    if (!xcd_panel_map(blockIdx.x, mp, nb, mpanel, nblk)) return;
+    const int m0 = mpanel * HX_BM, n0 = nblk * HX_BN;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv >> 2, wn = wv & 3, li = lane & 31, lh = lane >> 5;
+
+    // DMA map: one wave instruction = 16 rows x 64 B; wave w moves row groups w and w + 8 of every plane.
+    // lane -> (row R0 + lane/4, physical chunk lane%4) holding logical chunk (lane%4) ^ ((row>>2)&3), (row>>2)&3 = (lane>>4)&3.
+    const int drow = lane >> 2;
+    const int dchunk = (lane & 3) ^ ((lane >> 4) & 3);
+    int64_t aoff[2], woff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 16 * (wv + 8 * j) + drow;
+        int m = m0 + row;
+        m = m < M ? m : M - 1;
+        aoff[j] = (int64_t)m * lda + dchunk * 8;
+        woff[j] = (int64_t)(n0 + row) * K + dchunk * 8;
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto issue = [&](int kt, int buf) {
+        char* base = smem_b + buf * Cfg::BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int loff = (16 * (wv + 8 * j)) * HX_ROWB;
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ahi + aoff[j] + kt * HX_BK), (lptr_t)(base + loff), 16, 0, 0);
+            if (SPLIT == 3)
+                __builtin_amdgcn_global_load_lds((gptr_t)(Alo + aoff[j] + kt * HX_BK), (lptr_t)(base + HX_PLANE + loff), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Whi + woff[j] + kt * HX_BK), (lptr_t)(base + NPL * HX_PLANE + loff), 16, 0, 0);
+            if (SPLIT == 3)
+                __builtin_amdgcn_global_load_lds((gptr_t)(Wlo + woff[j] + kt * HX_BK), (lptr_t)(base + (NPL + 1) * HX_PLANE + loff), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
+
+    const int nk = K / HX_BK;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                 // vmcnt(0) + barrier: tile kt has landed, the other buffer is free again
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* cur = smem_b + (kt & 1) * Cfg::BUF;
+        HxFrag<SPLIT, FMT> f;
+        hx_frag_load<SPLIT, FMT>(cur, 0, wm, wn, li, lh, f);
+        hx_frag_mma<SPLIT, FMT>(f, acc);
+        hx_frag_load<SPLIT, FMT>(cur, 1, wm, wn, li, lh, f);
+        hx_frag_mma<SPLIT, FMT>(f, acc);
+    }
+    // epilogue in two 64-row passes of the 128-row wave tile (each pass = the shared 64x64-slab epilogue)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        hb_epilogue<ACT, HAS_RES, SPLIT, FMT, O_PL>(reinterpret_cast<f32x16(&)[2][2]>(acc[2 * p]), smem_b,
+                                                    m0 + wm * 128 + p * 64, n0 + wn * 64, wv, lane, li, lh, bias, residual,
+                                                    ldr, Cout, ldc, M, scale, scale_cols, Ohi, Olo);
+}
+
+template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
+static int launch_hx(const uint16_t* Whi, const uint16_t* Wlo, const float* bias, const float* residual, int64_t ldr,
+                     float* Cout, int64_t ldc, int64_t lda, int M, int N, int K, float scale, int scale_cols,
+                     const uint16_t* a_hi, const uint16_t* a_lo, uint16_t* o_hi, uint16_t* o_lo, hipStream_t stream) {
+    static bool configured = false;
+    auto kern = gemm16_dma256_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL>;
+    constexpr int lds = HxCfg<SPLIT>::LDS;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_dma256: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    const unsigned grid = xcd_panel_grid((M + HX_BM - 1) / HX_BM, N / HX_BN);
+    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 2.0 * HxCfg<SPLIT>::NPL * ((double)M * K + (double)N * K) + 4.0 * (double)M * N * (HAS_RES ? 2 : 1), stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, a_lo, lda, Whi, Wlo, bias, residual, ldr, Cout,
+                       ldc, M, N, K, scale, scale_cols, o_hi, o_lo);
+    RNAMSM_CHECK_LAUNCH("gemm16_dma256");
     return RNAMSM_OK;
 }
 
@@ -535,10 +678,16 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
     const HbPlanes pl{A_hi, A_lo, O_hi, O_lo};
 #define HB_GO(ACT_, RES_, SP_, FMT_, APL_, OPL_) \
     launch_hb<ACT_, RES_, SP_, FMT_, APL_, OPL_>(A, lda, W_hi, W_lo, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, pl, s)
+#define HX_GO(ACT_, RES_, SP_, FMT_, OPL_) \
+    launch_hx<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
 #define HD_GO(ACT_, RES_, SP_, FMT_, OPL_) \
     launch_hd<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
 #define HB_ACT_RES(SP_, FMT_)                                                                                       \
     do {                                                                                                            \
+        if (A_hi && tuning().gemm16_dma >= 2 && N % HX_BN == 0 && m >= 2048) {   /* 256x256 tile for large problems */ \
+            if (O_hi) return HX_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true);                                    \
+            return residual ? HX_GO(RNAMSM_ACT_NONE, true, SP_, FMT_, false) : HX_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, false); \
+        }                                                                                                           \
         if (A_hi && tuning().gemm16_dma) {                                                                          \
             if (O_hi) return HD_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true);                                    \
             return residual ? HD_GO(RNAMSM_ACT_NONE, true, SP_, FMT_, false) : HD_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, false); \
@@ -557,6 +706,7 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
     HB_ACT_RES(1, 0);
 #undef HB_ACT_RES
 #undef HD_GO
+#undef HX_GO
 #undef HB_GO
 }
 
