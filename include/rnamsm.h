@@ -123,18 +123,23 @@ int rnamsm_softmax_rows(const float* partial, int nsplit, float* probs, int H, i
 
 /* K6 -- RowSelfAttention.compute_attention_update's contraction (modules.py:797-798):
  *   ctx[r,i,h,:] = sum_j probs[h,i,j] * v[r,j,h,:]
- * v addressed like q/k above; ctx element (r,i,h,d) at ctx[(r*C+i)*ldc + h*64 + d]. */
+ * v addressed like q/k above; ctx element (r,i,h,d) at ctx[(r*C+i)*ldc + h*64 + d].
+ * With ctx_hi given the context is written instead as 16-bit hi (+ lo if non-NULL) planes with the same indexing
+ * (plane_fmt 0 = bf16, 1 = fp16): the pre-split A operand of rnamsm_gemm_bf16 for the following out_proj. */
 int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc,
-                     int R, int C, int H, int head_dim, int dtype, void* stream);
+                     int R, int C, int H, int head_dim, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt,
+                     int dtype, void* stream);
 
 /* K7 -- ColumnSelfAttention.compute_attention_update's attention (modules.py:905-921), fused:
  *   for every column c and head h: ctx[:,c,h,:] = softmax_j( q[:,c,h,:] k[:,c,h,:]^T ) v[:,c,h,:]
  * (q already scaled by dh^-0.5).  The [H,C,R,R] probabilities are never written (the reference
  * computes and discards them).  R == 1 degenerates to ctx = v (modules.py:882-894).
- * pad_mask (uint8 [R, C], may be NULL): scores of keys flagged 1 are replaced by -10000 (modules.py:911-915). */
+ * pad_mask (uint8 [R, C], may be NULL): scores of keys flagged 1 are replaced by -10000 (modules.py:911-915).
+ * ctx_hi / ctx_lo / plane_fmt: optional 16-bit plane output as for rnamsm_row_apply (not with pad_mask). */
 int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_t ld,
                           float* ctx, int64_t ldc, int R, int C, int H, int head_dim,
-                          const uint8_t* pad_mask, int dtype, void* stream);
+                          const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt,
+                          int dtype, void* stream);
 
 /* f2 -- padding_mask = tokens.eq(pad_idx) (model.py:346): mask uint8 [n]. */
 int rnamsm_pad_mask(const int64_t* tokens, uint8_t* mask, int64_t n, int pad_idx, void* stream);

@@ -17,7 +17,7 @@
 //   (the k index of MFMA step t is key (t&3)+8(t>>2)+4*half -- the accumulator's own row map), and (c) O^T also has
 //   the query row on the lane, so the online-softmax rescale is a per-lane scalar multiply.
 // Roofline: MFMA-bound: 4*R*R*64 flops per (c,h) vs 4*R*256 B of q,k,v,ctx (64 flop/B at R=256).
-#include "common.h"
+#include "half16.h"
 
 namespace rnamsm {
 
@@ -29,10 +29,13 @@ constexpr int CA_LDD = CA_HD + 4;     // padded LDS row stride (floats): 16 rows
 constexpr int CA_TILE = CA_JC * CA_LDD;
 constexpr int CA_LDS_BYTES = 2 * 2 * CA_TILE * 4;
 
-template <bool MASKED>   // MASKED: a padding mask is applied (f2); the un-masked instance carries no mask code at all
+// MASKED: a padding mask is applied (f2); the un-masked instance carries no mask code at all.
+// OUT: 0 = fp32 context; 1 / 2 = bf16 / fp16 hi(+lo) planes, the pre-split A operand of the following out_proj GEMM.
+template <bool MASKED, int OUT>
 __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
-    float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask) {
+    float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask,
+    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                    // [2][CA_JC][CA_LDD]
     float* Vs = smem + 2 * CA_TILE;      // [2][CA_JC][CA_LDD]
@@ -199,13 +202,30 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
         const float inv = 1.f / l_tot;
         const int i = irow0 + li;
         if (i < R) {
-            float* op = ctx + ((int64_t)i * C + c) * ldc + h * CA_HD + 4 * lh;
+            const int64_t ooff = ((int64_t)i * C + c) * ldc + h * CA_HD + 4 * lh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {      // registers 4g..4g+3 are head dims 8g + 4*half + {0..3}
-                *reinterpret_cast<f32x4*>(op + 8 * g) =
-                    f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
-                *reinterpret_cast<f32x4*>(op + 32 + 8 * g) =
-                    f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+                const f32x4 a = f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+                const f32x4 b = f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+                if (OUT == 0) {
+                    *reinterpret_cast<f32x4*>(ctx + ooff + 8 * g) = a;
+                    *reinterpret_cast<f32x4*>(ctx + ooff + 32 + 8 * g) = b;
+                } else {
+                    typedef typename Half16<(OUT > 0 ? OUT - 1 : 0)>::T Hh;
+                    typedef Hh H4 __attribute__((ext_vector_type(4)));
+                    H4 ah, al, bh, bl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ah[e] = (Hh)a[e]; al[e] = (Hh)(a[e] - (float)ah[e]);
+                        bh[e] = (Hh)b[e]; bl[e] = (Hh)(b[e] - (float)bh[e]);
+                    }
+                    *reinterpret_cast<H4*>(ctx_hi + ooff + 8 * g) = ah;
+                    *reinterpret_cast<H4*>(ctx_hi + ooff + 32 + 8 * g) = bh;
+                    if (ctx_lo) {
+                        *reinterpret_cast<H4*>(ctx_lo + ooff + 8 * g) = al;
+                        *reinterpret_cast<H4*>(ctx_lo + ooff + 32 + 8 * g) = bl;
+                    }
+                }
             }
         }
     }
@@ -217,33 +237,37 @@ using namespace rnamsm;
 
 extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_t ld, float* ctx,
                                      int64_t ldc, int R, int C, int H, int head_dim, const uint8_t* pad_mask,
-                                     int dtype, void* stream) {
+                                     uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt, int dtype, void* stream) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "col_attn: only RNAMSM_F32 is implemented");
-    RNAMSM_CHECK_ARG(q && k && v && ctx, "col_attn: null pointer");
+    RNAMSM_CHECK_ARG(q && k && v && (ctx || ctx_hi), "col_attn: null pointer");
     RNAMSM_CHECK_ARG(head_dim == CA_HD, "col_attn: head_dim must be 64 (got %d)", head_dim);
     RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0, "col_attn: bad shape R=%d C=%d H=%d", R, C, H);
     RNAMSM_CHECK_ARG(ld >= (int64_t)H * CA_HD && ld % 4 == 0 && ldc >= (int64_t)H * CA_HD && ldc % 4 == 0,
                      "col_attn: ld/ldc must be multiples of 4 and >= H*64");
-    RNAMSM_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(ctx), "col_attn: 16-byte alignment");
-    static bool configured = false;
-    if (!configured) {
-        for (const void* kern : {reinterpret_cast<const void*>(col_attn_kernel<false>),
-                                 reinterpret_cast<const void*>(col_attn_kernel<true>)}) {
-            hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, CA_LDS_BYTES);
-            if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        }
-        configured = true;
-    }
+    RNAMSM_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v), "col_attn: 16-byte alignment");
+    RNAMSM_CHECK_ARG(ctx_hi ? (!pad_mask && (reinterpret_cast<uintptr_t>(ctx_hi) & 7u) == 0 && (plane_fmt == 0 || plane_fmt == 1))
+                            : aligned16(ctx), "col_attn: output alignment / plane format (plane output has no masked variant)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned iblocks = (R + CA_ROWS - 1) / CA_ROWS;
     const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
-    KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)R * R * CA_HD, 4.0 * 4.0 * R * C * H * CA_HD,
-                      static_cast<hipStream_t>(stream));
-    if (pad_mask)
-        hipLaunchKernelGGL(col_attn_kernel<true>, dim3(grid), dim3(CA_THREADS), CA_LDS_BYTES,
-                           static_cast<hipStream_t>(stream), q, k, v, ld, ctx, ldc, R, C, H, pad_mask);
-    else
-        hipLaunchKernelGGL(col_attn_kernel<false>, dim3(grid), dim3(CA_THREADS), CA_LDS_BYTES,
-                           static_cast<hipStream_t>(stream), q, k, v, ld, ctx, ldc, R, C, H, pad_mask);
+    KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)R * R * CA_HD, 4.0 * 4.0 * R * C * H * CA_HD, s);
+#define CA_GO(M_, OUT_)                                                                                             \
+    do {                                                                                                            \
+        static bool cfg_ = false;                                                                                   \
+        if (!cfg_) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn_kernel<M_, OUT_>),            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, CA_LDS_BYTES);           \
+            if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
+            cfg_ = true;                                                                                            \
+        }                                                                                                           \
+        hipLaunchKernelGGL((col_attn_kernel<M_, OUT_>), dim3(grid), dim3(CA_THREADS), CA_LDS_BYTES, s, q, k, v, ld, ctx, \
+                           ldc, R, C, H, pad_mask, ctx_hi, ctx_lo);                                                 \
+    } while (0)
+    if (pad_mask) CA_GO(true, 0);
+    else if (!ctx_hi) CA_GO(false, 0);
+    else if (plane_fmt == 0) CA_GO(false, 1);
+    else CA_GO(false, 2);
+#undef CA_GO
     RNAMSM_CHECK_LAUNCH("col_attn");
     return RNAMSM_OK;
 }

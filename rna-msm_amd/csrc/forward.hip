@@ -97,6 +97,8 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     const int split = dtype == RNAMSM_BF16 ? 1 : 3, fmt = dtype == RNAMSM_F16X3 ? 1 : 0;
     uint16_t* xn_hi = reinterpret_cast<uint16_t*>(xn);
     uint16_t* xn_lo = split == 3 ? xn_hi + T * D : nullptr;
+    uint16_t* ctx_hi = planes ? reinterpret_cast<uint16_t*>(ctx) : nullptr;     // context planes overlay the fp32 ctx
+    uint16_t* ctx_lo = planes && split == 3 ? ctx_hi + T * D : nullptr;
     uint16_t* hid_hi = reinterpret_cast<uint16_t*>(hidden);
     uint16_t* hid_lo = split == 3 ? hid_hi + T * (int64_t)F : nullptr;
     auto ln_for_gemm = [&](const float* g, const float* b) -> int {
@@ -134,8 +136,11 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
                        RNAMSM_ACT_NONE, row_scale, D, mask));
         FWD(rnamsm_row_logits(qkv, qkv + D, ldq, part, R, C, H, 64, f32, stream));
         FWD(rnamsm_softmax_rows(part, nsplit, probs, H, C, mask, stream));
-        FWD(rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, f32, stream));
-        FWD(linear(l, 1, ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
+        FWD(rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, ctx_hi, ctx_lo, fmt, f32, stream));
+        if (planes)
+            FWD(linear_pl(l, 1, ctx_hi, ctx_lo, D, W[RNAMSM_WL_ROW_BO], x, D, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE, 1.f, 0));
+        else
+            FWD(linear(l, 1, ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
         // ---- column attention block
         FWD(ln_for_gemm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
         if (planes)
@@ -144,8 +149,11 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         else
             FWD(linear(l, 2, xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
                        RNAMSM_ACT_NONE, col_scale, D, nullptr));
-        FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, mask, f32, stream));
-        FWD(linear(l, 3, ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
+        FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, mask, ctx_hi, ctx_lo, fmt, f32, stream));
+        if (planes)
+            FWD(linear_pl(l, 3, ctx_hi, ctx_lo, D, W[RNAMSM_WL_COL_BO], x, D, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE, 1.f, 0));
+        else
+            FWD(linear(l, 3, ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
         // ---- feed-forward block
         FWD(ln_for_gemm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
         if (planes) {

@@ -12,28 +12,11 @@
 // with the row stride padded to 144 B -- byte-for-byte the layout of the fp32 kernel's [128][32 f32] tile, so the
 // conflict-free ds_read_b128 pattern carries over: 16 B at row*144 + 32*kk + 16*half = k 16kk + 8*half + j, exactly
 // the operand map of the 32x32x16 MFMA (lane (r, half) holds k = 8*half + j).
-#include "common.h"
+#include "half16.h"
 
 namespace rnamsm {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// 16-bit operand format: FMT 0 = bf16 (8-bit mantissa, fp32 range), FMT 1 = fp16 (11-bit mantissa, |x| < 65504).
-// An fp16 hi/lo pair carries ~22 mantissa bits (fp32: 24): "f16x3" is fp32-grade arithmetic at the bf16 MFMA rate for
-// operands inside fp16 range -- true for this model's GEMM inputs (LayerNorm outputs, attention contexts, GELU
-// activations, 0.04-scale weights); values below 2^-24 * 2^11 of an element's magnitude fall into fp16 subnormals of
-// the lo plane, an ABSOLUTE error <= 3e-8 per element.
-template <int FMT> struct Half16;
-template <> struct Half16<0> {
-    typedef __bf16 T;
-    typedef __bf16 V8 __attribute__((ext_vector_type(8)));
-    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-};
-template <> struct Half16<1> {
-    typedef _Float16 T;
-    typedef _Float16 V8 __attribute__((ext_vector_type(8)));
-    static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-};
 
 constexpr int HB_BM = 128, HB_BN = 128, HB_BK = 64;
 constexpr int HB_LDB = HB_BK * 2 + 16;             // bytes per LDS row (64 bf16 + 16 B pad)

@@ -13,6 +13,7 @@
 // Tied attention sums over all R rows before the softmax; the reference does that in max_tokens-sized row chunks
 // (_batched_forward, modules.py:717-750).  Here the rows are cut into nsplit contiguous ranges (to fill 256 CUs: one
 // head has only ceil(C/128)^2 output tiles) and K5 adds the partials in range order -> fixed summation order.
+#include "half16.h"
 #include "mma_core.h"
 
 namespace rnamsm {
@@ -167,10 +168,12 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 // out[i, (r,d)] = sum_j P[h][i][j] * V[j, (r,d)].  A = P_h rows (k = j contiguous), B = v read as [j][n] with
 // n = (r_local, d): 2 alignment rows x 64 head dims per 128-wide N tile.
 // grid.x = xcd-mapped (panel = (head, n tile), inner = tiles_i): the i tiles of one V panel share an L2.
-template <bool ALIGNED>   // ALIGNED: C % 4 == 0 and probs 16-B aligned -> P rows can be read as float4
+// ALIGNED: C % 4 == 0 and probs 16-B aligned -> P rows can be read as float4.
+// OUT: 0 = fp32 context; 1 / 2 = bf16 / fp16 hi(+lo) planes, the pre-split A operand of the following out_proj GEMM.
+template <bool ALIGNED, int OUT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
     const float* __restrict__ probs, const float* __restrict__ v, int64_t ld, float* __restrict__ ctx, int64_t ldc,
-    int R, int C, int H) {
+    int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ps = smem;                    // [2][BM][LDK]
     float* Vs = smem + 2 * TILE_KC;      // [2][BK][LDN]
@@ -234,22 +237,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
 
     pipelined_kloop<false, ALIGNED ? 8 : 20, 1>(nk, Ps, Vs, TILE_KC, TILE_NC, acc, w, load_tiles, store_tiles);
 
-    // column n of the tile -> (alignment row rr0 + n/64, head dim n%64)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = acc_col(w, nt);
-        const int r = rr0 + (n >> 6), d = n & 63;
-        if (r < R) {
-            float* obase = ctx + (int64_t)r * C * ldc + h * HEAD_DIM + d;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int i = i0 + acc_row(w, mt, t);
-                    if (i < C) obase[(int64_t)i * ldc] = acc[mt][nt][t];
-                }
-        }
-    }
+    // The wave's 64 columns are exactly one alignment row (r = rr0 + wn) x 64 head dims, its 64 rows are alignment
+    // columns i: the slab leaves as 256-B context segments ctx[(r*C + i), h*64 .. h*64+63] through LDS.
+    __syncthreads();                                              // every wave has finished reading operand tiles
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = rr0 + w.wn;
+    const int ibase = i0 + w.wm * 64;
+    auto rowoff = [&](int row) -> int64_t {
+        const int i = ibase + row;
+        return (r < R && i < C) ? ((int64_t)r * C + i) * ldc + h * HEAD_DIM : (int64_t)-1;
+    };
+    slab_store_64x64<OUT>(acc, smem + wv * (64 * 68), w.li, w.lh, lane, rowoff, ctx, ctx_hi, ctx_lo);
 }
 
 template <typename K>
@@ -313,31 +311,39 @@ extern "C" int rnamsm_softmax_rows(const float* partial, int nsplit, float* prob
 }
 
 extern "C" int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,
-                                int H, int head_dim, int dtype, void* stream) {
+                                int H, int head_dim, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt, int dtype,
+                                void* stream) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "row_apply: only RNAMSM_F32 is implemented");
-    RNAMSM_CHECK_ARG(probs && v && ctx, "row_apply: null pointer");
+    RNAMSM_CHECK_ARG(probs && v && (ctx || ctx_hi), "row_apply: null pointer");
     RNAMSM_CHECK_ARG(head_dim == HEAD_DIM, "row_apply: head_dim must be 64 (got %d)", head_dim);
     RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0, "row_apply: bad shape R=%d C=%d H=%d", R, C, H);
-    RNAMSM_CHECK_ARG(ld >= (int64_t)H * HEAD_DIM && ld % 4 == 0 && aligned16(v) && ldc >= (int64_t)H * HEAD_DIM,
-                     "row_apply: v must be 16-byte aligned with ld %% 4 == 0");
-    static bool configured = false;
-    if (!configured) {
-        int rc = set_lds(row_apply_kernel<true>, ROWAPPLY_LDS_BYTES, "row_apply");
-        if (rc) return rc;
-        rc = set_lds(row_apply_kernel<false>, ROWAPPLY_LDS_BYTES, "row_apply");
-        if (rc) return rc;
-        configured = true;
-    }
+    RNAMSM_CHECK_ARG(ld >= (int64_t)H * HEAD_DIM && ld % 4 == 0 && aligned16(v) && ldc >= (int64_t)H * HEAD_DIM && ldc % 4 == 0,
+                     "row_apply: v must be 16-byte aligned with ld, ldc %% 4 == 0");
+    RNAMSM_CHECK_ARG(ctx_hi ? ((reinterpret_cast<uintptr_t>(ctx_hi) & 7u) == 0 && (plane_fmt == 0 || plane_fmt == 1)) : aligned16(ctx),
+                     "row_apply: output alignment / plane format");
+    hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned tiles_i = (C + BM - 1) / BM, tiles_n = (R + 1) / 2;
     const unsigned grid = xcd_panel_grid((unsigned)H * tiles_n, tiles_i);
-    KernelTimer timer(TC_ROW_APPLY, 2.0 * H * C * C * R * HEAD_DIM,
-                      4.0 * (2.0 * R * C * H * HEAD_DIM + (double)H * C * C), static_cast<hipStream_t>(stream));
-    if (C % 4 == 0 && C >= 4 && aligned16(probs))
-        hipLaunchKernelGGL(row_apply_kernel<true>, dim3(grid), dim3(GEMM_THREADS), ROWAPPLY_LDS_BYTES,
-                           static_cast<hipStream_t>(stream), probs, v, ld, ctx, ldc, R, C, H);
-    else
-        hipLaunchKernelGGL(row_apply_kernel<false>, dim3(grid), dim3(GEMM_THREADS), ROWAPPLY_LDS_BYTES,
-                           static_cast<hipStream_t>(stream), probs, v, ld, ctx, ldc, R, C, H);
+    const bool al = C % 4 == 0 && C >= 4 && aligned16(probs);
+    const int out = ctx_hi ? 1 + plane_fmt : 0;
+    KernelTimer timer(TC_ROW_APPLY, 2.0 * H * C * C * R * HEAD_DIM, 4.0 * (2.0 * R * C * H * HEAD_DIM + (double)H * C * C), s);
+#define RA_GO(AL_, OUT_)                                                                                          \
+    do {                                                                                                          \
+        static bool cfg_ = false;                                                                                 \
+        if (!cfg_) {                                                                                              \
+            int rc = set_lds(row_apply_kernel<AL_, OUT_>, ROWAPPLY_LDS_BYTES, "row_apply");                      \
+            if (rc) return rc;                                                                                    \
+            cfg_ = true;                                                                                          \
+        }                                                                                                         \
+        hipLaunchKernelGGL((row_apply_kernel<AL_, OUT_>), dim3(grid), dim3(GEMM_THREADS), ROWAPPLY_LDS_BYTES, s, probs, \
+                           v, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo);                                             \
+    } while (0)
+    if (al) {
+        if (out == 0) RA_GO(true, 0); else if (out == 1) RA_GO(true, 1); else RA_GO(true, 2);
+    } else {
+        if (out == 0) RA_GO(false, 0); else if (out == 1) RA_GO(false, 1); else RA_GO(false, 2);
+    }
+#undef RA_GO
     RNAMSM_CHECK_LAUNCH("row_apply");
     return RNAMSM_OK;
 }

@@ -50,10 +50,10 @@ _SIGNATURES = {
     "rnamsm_row_logits_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rnamsm_row_logits": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rnamsm_softmax_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "rnamsm_row_apply": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,
-                                 c_void_p]),
+    "rnamsm_row_apply": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rnamsm_col_attn_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
-                                      c_int, c_void_p, c_int, c_void_p]),
+                                      c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rnamsm_pad_mask": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rnamsm_pack_outputs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rnamsm_contact_head_workspace_bytes": (c_size_t, [c_int, c_int]),

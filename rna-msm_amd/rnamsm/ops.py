@@ -116,7 +116,7 @@ def row_apply(probs: torch.Tensor, v: torch.Tensor, R: int, C: int, H: int,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     ctx = torch.empty(R * C, H * HEAD_DIM, device=v.device, dtype=torch.float32) if out is None else out
     _lib.check(_lib.load().rnamsm_row_apply(_dev(probs, "probs"), _dev(v, "v"), _rowmajor(v, "v"), _dev(ctx, "ctx"),
-                                            _rowmajor(ctx, "ctx"), R, C, H, HEAD_DIM, F32, _stream()))
+                                            _rowmajor(ctx, "ctx"), R, C, H, HEAD_DIM, None, None, 0, F32, _stream()))
     return ctx
 
 
@@ -128,7 +128,7 @@ def col_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, R: int, C: int, 
     _lib.check(_lib.load().rnamsm_col_attn_fused(_dev(q, "q"), _dev(k, "k"), _dev(v, "v"), ld, _dev(ctx, "ctx"),
                                                  _rowmajor(ctx, "ctx"), R, C, H, HEAD_DIM,
                                                  None if pad_mask is None else _dev(pad_mask, "pad_mask", torch.uint8),
-                                                 F32, _stream()))
+                                                 None, None, 0, F32, _stream()))
     return ctx
 
 
