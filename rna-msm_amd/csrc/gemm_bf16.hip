@@ -114,7 +114,7 @@ __device__ __forceinline__ void hb_epilogue(f32x16 (&acc)[2][2], char* smem_b, i
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 float v = (acc[mt][nt][t] + b) * sc;
-                if (ACT == RNAMSM_ACT_GELU_ERF) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+                if (ACT == RNAMSM_ACT_GELU_ERF) v = gelu_erf(v);
                 stage[(mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh) * LDE + nt * 32 + li] = v;
             }
     }

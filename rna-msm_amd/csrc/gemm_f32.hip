@@ -90,7 +90,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 float v = (acc[mt][nt][t] + b) * sc;
-                if (ACT == RNAMSM_ACT_GELU_ERF) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+                if (ACT == RNAMSM_ACT_GELU_ERF) v = gelu_erf(v);
                 stage[(mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * w.lh) * LDE + nt * 32 + w.li] = v;
             }
     }
