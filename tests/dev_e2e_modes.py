@@ -2,7 +2,7 @@
 """End-to-end error and speed of the GEMM arithmetic modes (f32 / bf16x3 / bf16) of rnamsm_forward:
 error vs the reference fixtures (fp32 and fp64 runs of the reference) and vs the CPU oracle at M=64, L=128."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from rnamsm import synthetic
