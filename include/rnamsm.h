@@ -220,7 +220,8 @@ int rnamsm_timing_get(int category, const char** name, long long* launches, doub
 void rnamsm_timing_reset(void);
 
 /* Tuning knobs for in-process A/B measurements (speed only, never results).  Known names:
- *   "gemm_stagger"  0 = off, 1 = delay the second resident block of each CU by half a tile (default 1). */
+ *   "gemm16_dma"  staging of the plane-input 16-bit GEMMs: 0 register-staged, 1 LDS-DMA 128x128 tile,
+ *                 2 LDS-DMA 256x256 tile when the problem allows (default). */
 int rnamsm_set_param(const char* name, int value);
 int rnamsm_get_param(const char* name);
 

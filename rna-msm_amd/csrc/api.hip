@@ -112,26 +112,14 @@ Tuning& tuning() {
 }
 }  // namespace rnamsm
 extern "C" int rnamsm_set_param(const char* name, int value) {
-    if (name && !strcmp(name, "gemm_stagger")) {
-        rnamsm::tuning().gemm_stagger = value;
-        return RNAMSM_OK;
-    }
-    if (name && !strcmp(name, "gemm_prefetch_depth")) {
-        rnamsm::tuning().gemm_prefetch_depth = value;
-        return RNAMSM_OK;
-    }
     if (name && !strcmp(name, "gemm16_dma")) {
         rnamsm::tuning().gemm16_dma = value;
-        return RNAMSM_OK;
-    }
-    if (name && !strcmp(name, "gemm_debug")) {
-        rnamsm::tuning().gemm_debug = value;
         return RNAMSM_OK;
     }
     return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: unknown parameter %s", name ? name : "(null)");
 }
 extern "C" int rnamsm_get_param(const char* name) {
-    if (name && !strcmp(name, "gemm_stagger")) return rnamsm::tuning().gemm_stagger;
+    if (name && !strcmp(name, "gemm16_dma")) return rnamsm::tuning().gemm16_dma;
     return -1;
 }
 

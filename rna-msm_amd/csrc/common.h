@@ -45,10 +45,7 @@ struct KernelTimer {   // brackets one launch with two hipEventRecord calls when
 
 // ---- tuning knobs (api.hip) -------------------------------------------------------------------------
 struct Tuning {
-    int gemm_stagger = 0;
-    int gemm_prefetch_depth = 1;   // staging register sets of the GEMM K loop (1 or 2)
     int gemm16_dma = 2;            // plane-input 16-bit GEMMs: 0 register staging, 1 LDS-DMA 128x128, 2 LDS-DMA 256x256 when it fits
-    int gemm_debug = 0;      // measurement only: bit0 = skip the epilogue stores (results wrong)
 };
 Tuning& tuning();
 
@@ -109,19 +106,6 @@ __device__ __forceinline__ bool xcd_panel_map(unsigned bid, unsigned num_panels,
     in_panel = idx % inner;
     return panel < num_panels;
 }
-// Phase stagger (speed only).  All blocks of a launch start together and, having equal work, would finish together:
-// every round's epilogue (an HBM burst: 64 KB stored, +64 KB residual read per block) and the next round's prologue
-// would then leave the matrix pipes idle chip-wide.  Two blocks are resident per CU; delaying the second one
-// (ids [256,512) under the dispatcher's one-block-per-CU-first placement) by `cycles` puts its epilogue/prologue in
-// the middle of its partner's main loop, and later rounds inherit the phase because a new block starts when an old
-// one exits.  While one block waits its partner owns the whole pipe, so the delay itself costs nothing.
-__device__ __forceinline__ void stagger_second_resident_block(unsigned bid, unsigned cycles) {
-    if (cycles != 0 && bid >= 256u && bid < 512u) {
-        const unsigned long long t0 = __builtin_readcyclecounter();
-        while (__builtin_readcyclecounter() - t0 < cycles) __builtin_amdgcn_s_sleep(16);
-    }
-}
-
 static inline unsigned xcd_panel_grid(unsigned num_panels, unsigned inner) {
     return ((num_panels + 7u) / 8u) * 8u * inner;
 }

@@ -12,12 +12,11 @@ namespace rnamsm {
 
 constexpr int GEMM_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;   // double-buffered A and W tiles
 
-template <int ACT, bool HAS_RES, int DEPTH, bool ZROWS>
+template <int ACT, bool HAS_RES, bool ZROWS>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc,
-    int M, int N, int K, float scale, int scale_cols, const uint8_t* __restrict__ zero_rows, unsigned stagger_cycles,
-    int debug) {
+    int M, int N, int K, float scale, int scale_cols, const uint8_t* __restrict__ zero_rows) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                    // [2][BM][LDK]
     float* Ws = smem + 2 * TILE_KC;      // [2][BN][LDK]
@@ -26,7 +25,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     unsigned mpanel, nblk;
     if (!xcd_panel_map(blockIdx.x, mp, nb, mpanel, nblk)) return;
     const int m0 = mpanel * BM, n0 = nblk * BN;
-    stagger_second_resident_block(blockIdx.x, stagger_cycles);
 
     const WaveCoord w = wave_coord();
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
@@ -45,8 +43,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     f32x16 acc[2][2];
     zero_acc(acc);
 
-    StageKC sa[DEPTH], sw[DEPTH];
-    pipelined_kloop<true, 8, DEPTH>(
+    StageKC sa[1], sw[1];
+    pipelined_kloop<true, 8, 1>(
         K / BK, As, Ws, TILE_KC, TILE_KC, acc, w,
         [&](int kt, auto set) {
             constexpr int S = decltype(set)::value;
@@ -106,10 +104,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
         // f2: q *= 1 - padding_mask (modules.py:767-772): padded tokens get q = 0 (the scaled columns are q)
         if (ZROWS && gn < scale_cols && zero_rows[min(gm0 + r, M - 1)]) ov[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (debug & 1) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(ov[i]));
-    } else if (m0 + BM <= M) {
+    if (m0 + BM <= M) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
     } else {
@@ -119,12 +114,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     }
 }
 
-template <int ACT, bool HAS_RES, int DEPTH, bool ZROWS = false>
+template <int ACT, bool HAS_RES, bool ZROWS = false>
 static int launch_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                        int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
                        const uint8_t* zero_rows, hipStream_t stream) {
     static bool configured = false;
-    auto kern = gemm_f32_kernel<ACT, HAS_RES, DEPTH, ZROWS>;
+    auto kern = gemm_f32_kernel<ACT, HAS_RES, ZROWS>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
@@ -132,12 +127,10 @@ static int launch_gemm(const float* A, int64_t lda, const float* W, const float*
         configured = true;
     }
     const unsigned grid = xcd_panel_grid((M + BM - 1) / BM, N / BN);
-    // half of a solo tile (K/32 steps x 4096 matrix-pipe cycles): see stagger_second_resident_block
-    const unsigned stagger = (tuning().gemm_stagger && grid > 512) ? (unsigned)(K / BK) * 2048u * tuning().gemm_stagger : 0u;
     // algorithmic work: 2MNK flops; bytes = A + W + C once (+ residual read)
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, A, lda, W, bias, residual, ldr,
-                       Cout, ldc, M, N, K, scale, scale_cols, zero_rows, stagger, tuning().gemm_debug);
+                       Cout, ldc, M, N, K, scale, scale_cols, zero_rows);
     RNAMSM_CHECK_LAUNCH("gemm_f32");
     return RNAMSM_OK;
 }
@@ -162,19 +155,14 @@ extern "C" int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float
     RNAMSM_CHECK_ARG(act == RNAMSM_ACT_NONE || act == RNAMSM_ACT_GELU_ERF, "gemm: unknown activation %d", act);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int m = (int)M;
-#define RNAMSM_GEMM_DISPATCH(ACT_, RES_, DEPTH_) \
-    launch_gemm<ACT_, RES_, DEPTH_>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, zero_rows, s)
-    const bool deep = tuning().gemm_prefetch_depth >= 2;
+#define RNAMSM_GEMM_DISPATCH(ACT_, RES_) \
+    launch_gemm<ACT_, RES_>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, zero_rows, s)
     if (zero_rows) {   // f2: only the QKV projection of row attention uses it (no activation, no residual)
         RNAMSM_CHECK_ARG(act == RNAMSM_ACT_NONE && !residual, "gemm: zero_rows is supported without activation / residual");
-        return launch_gemm<RNAMSM_ACT_NONE, false, 1, true>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale,
-                                                            scale_cols, zero_rows, s);
+        return launch_gemm<RNAMSM_ACT_NONE, false, true>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale,
+                                                         scale_cols, zero_rows, s);
     }
-    if (act == RNAMSM_ACT_GELU_ERF) {
-        if (residual) return deep ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, true, 2) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, true, 1);
-        return deep ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, false, 2) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, false, 1);
-    }
-    if (residual) return deep ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_NONE, true, 2) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_NONE, true, 1);
-    return deep ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_NONE, false, 2) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_NONE, false, 1);
+    if (act == RNAMSM_ACT_GELU_ERF) return residual ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, true) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, false);
+    return residual ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_NONE, true) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_NONE, false);
 #undef RNAMSM_GEMM_DISPATCH
 }

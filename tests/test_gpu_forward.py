@@ -133,6 +133,17 @@ def test_cfg2_shape_against_oracle(model):
     assert rel_l2(out["repr"].cpu().numpy(), res["representation"]) < 1e-4
 
 
+def test_mid_size_odd_shape_against_oracle(model):
+    """Odd R and C (33 x 131: crosses the 32/64/128 tile edges, unaligned probability rows, a partial key tile in
+    column attention) through the whole 10-layer forward vs the oracle."""
+    m, state = model
+    toks = synthetic.make_tokens(33, 131, 9)
+    out = m.forward_one(torch.from_numpy(toks).to("cuda:0"))
+    emb, atp = O.pack_outputs(O.forward(torch.from_numpy(toks), O.to_torch_params(state)))
+    assert rel_l2(out["emb"].cpu().numpy(), emb) < 1e-4
+    assert np.abs(out["atp"].cpu().numpy() - atp.numpy()).max() < 1e-4
+
+
 def test_full_size_invariants_cfg3(model):
     """BASELINE config 2 (M=256, L=512): too large for the CPU oracle in seconds, so check size-independent
     properties: probabilities are a distribution, outputs finite, bit-identical reruns, and row-permutation
