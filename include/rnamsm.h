@@ -97,7 +97,7 @@ int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_hi, const ui
                      const uint16_t* A_hi, const uint16_t* A_lo, uint16_t* O_hi, uint16_t* O_lo, void* stream);
 /* LayerNorm (K1) whose output is written as 16-bit hi/lo planes [T, D] (lo may be NULL), the pre-split A operand of
  * rnamsm_gemm_bf16: with A_hi/A_lo given (row stride lda halves) A is ignored and no conversion runs in the GEMM;
- * with O_hi/O_lo given (fc1: GELU, no residual) the result is written as planes with row stride ldc for the next
+ * with O_hi/O_lo given (fc1: GELU; QKV: no activation; never with a residual) the result is written as planes with row stride ldc for the next
  * GEMM instead of fp32 Cout. */
 int rnamsm_layernorm_split(const float* x, const float* gamma, const float* beta, uint16_t* hi, uint16_t* lo,
                            int64_t T, int D, float eps, int fmt, void* stream);
@@ -140,6 +140,31 @@ int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_
                           float* ctx, int64_t ldc, int R, int C, int H, int head_dim,
                           const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt,
                           int dtype, void* stream);
+
+/* K4' / K5' / K6' / K7' -- the attention contractions of the 16-bit modes (same reference lines as K4..K7).  Operands
+ * are 16-bit planes in HBM, addressed like their fp32 counterparts (element (r,c,h,d) = plane[(r*C+c)*ld + h*64 + d],
+ * ld in halves): q/k/v as written by rnamsm_gemm_bf16's plane epilogue (O_hi/O_lo over the fused [T,3D] QKV output),
+ * P as written by rnamsm_softmax_rows_planes.  All *_lo NULL = bf16 operands, one MFMA per product (fmt must be 0);
+ * all *_lo given = hi/lo pairs, three MFMAs per product (fmt 0 = bf16x3, 1 = f16x3; f16x3 is fp32-grade).
+ * Accumulation, softmax and the partial-slab sum stay fp32.  No padding-mask variant: masked batches take K4..K7. */
+/* Scaling is applied to fp32 accumulators, never to 16-bit operands (a q scaled by ~1e-2 or a probability ~1e-3 would
+ * push its fp16 lo plane into subnormals): q arrives UNSCALED and `scale` multiplies the logits; P planes hold
+ * P * plane_scale (a power of two, 4096 in rnamsm_forward) and out_scale = 1 / plane_scale undoes it. */
+int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
+                        int64_t ld, float* partial, int R, int C, int H, int head_dim, float scale, int fmt,
+                        void* stream);
+/* rnamsm_softmax_rows that also writes P * plane_scale as planes [H*C, ldp] (ldp = C rounded up to 64, tail zeroed). */
+int rnamsm_softmax_rows_planes(const float* partial, int nsplit, float* probs, uint16_t* p_hi, uint16_t* p_lo,
+                               int64_t ldp, float plane_scale, int H, int C, const uint8_t* key_mask, int fmt,
+                               void* stream);
+/* ctx = out_scale * P v as fp32 (ctx_hi NULL) or as ctx_hi(+ctx_lo) planes in the operands' format. */
+int rnamsm_row_apply16(const uint16_t* p_hi, const uint16_t* p_lo, int64_t ldp, const uint16_t* v_hi,
+                       const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H, int head_dim,
+                       float out_scale, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, void* stream);
+/* ctx = softmax_j(scale * q k^T) v per (column, head). */
+int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
+                      const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C,
+                      int H, int head_dim, float scale, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, void* stream);
 
 /* f2 -- padding_mask = tokens.eq(pad_idx) (model.py:346): mask uint8 [n]. */
 int rnamsm_pad_mask(const int64_t* tokens, uint8_t* mask, int64_t n, int pad_idx, void* stream);
@@ -219,9 +244,12 @@ int rnamsm_timing_collect(void);
 int rnamsm_timing_get(int category, const char** name, long long* launches, double* ms, double* flops, double* bytes);
 void rnamsm_timing_reset(void);
 
-/* Tuning knobs for in-process A/B measurements (speed only, never results).  Known names:
+/* Knobs for in-process A/B measurements.  Known names:
  *   "gemm16_dma"  staging of the plane-input 16-bit GEMMs: 0 register-staged, 1 LDS-DMA 128x128 tile,
- *                 2 LDS-DMA 256x256 tile when the problem allows (default). */
+ *                 2 LDS-DMA 256x256 tile when the problem allows (default).  Speed only.
+ *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit
+ *                 matrix cores in the mode's operand format (K4'..K7'), 0 = they stay on the exact-fp32 kernels.
+ *                 The RNAMSM_F32 path is not affected by either. */
 int rnamsm_set_param(const char* name, int value);
 int rnamsm_get_param(const char* name);
 

@@ -116,10 +116,15 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm16_dma = value;
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "attn16")) {
+        rnamsm::tuning().attn16 = value;
+        return RNAMSM_OK;
+    }
     return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: unknown parameter %s", name ? name : "(null)");
 }
 extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "gemm16_dma")) return rnamsm::tuning().gemm16_dma;
+    if (name && !strcmp(name, "attn16")) return rnamsm::tuning().attn16;
     return -1;
 }
 

@@ -8,6 +8,9 @@
 //   wide   [T, 4D]   fused QKV activation [T, 3D] (row stride 3D) followed by the attention context [T, D];
 //                    the FFN hidden activation [T, F] overlays both (they are never live together)
 //   part   [nsplit, H, C, C]  row-logit partial slabs (K4 -> K5)
+//   pplanes [2][H*C, ldp]     row-attention probabilities as 16-bit hi / lo planes (16-bit modes, K5' -> K6')
+// In the 16-bit modes the same regions hold 16-bit planes instead: xn = LayerNorm hi|lo, the QKV slot of wide = q|k|v
+// hi plane [T,3D] then lo plane [T,3D] (2 x 2 B = the fp32 footprint), ctx = context hi|lo, hidden = GELU hi|lo.
 // cfg3 (R=256, C=512): 403 MB + 403 MB + 1.61 GB + 75 MB; cfg5 (R=C=1024): 19.3 GB -- one 288 GB HBM3E stack set
 // holds every activation of the largest supported MSA, so nothing is chunked or recomputed.
 #include "common.h"
@@ -16,7 +19,7 @@ using namespace rnamsm;
 
 namespace {
 struct Layout {
-    size_t x, xn, wide, part, mask, total;
+    size_t x, xn, wide, part, mask, pplanes, total;
 };
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 Layout make_layout(const rnamsm_model_dims& d, int R, int C) {
@@ -28,6 +31,7 @@ Layout make_layout(const rnamsm_model_dims& d, int R, int C) {
     l.wide = off; off += align256(T * (size_t)(3 * D + D > (size_t)d.ffn_dim ? 4 * D : d.ffn_dim) * 4);
     l.part = off; off += align256(rnamsm_row_logits_workspace_bytes(R, C, d.num_heads));
     l.mask = off; off += align256(T);
+    l.pplanes = off; off += align256((size_t)d.num_heads * C * (size_t)((C + 63) / 64 * 64) * 4);   // P hi + lo planes (K5' -> K6')
     l.total = off;
     return l;
 }
@@ -99,6 +103,14 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     uint16_t* xn_lo = split == 3 ? xn_hi + T * D : nullptr;
     uint16_t* ctx_hi = planes ? reinterpret_cast<uint16_t*>(ctx) : nullptr;     // context planes overlay the fp32 ctx
     uint16_t* ctx_lo = planes && split == 3 ? ctx_hi + T * D : nullptr;
+    // 16-bit attention (K4'..K7'): the QKV epilogue writes q|k|v planes over the fp32 qkv slot
+    const bool attn16 = planes && tuning().attn16 != 0;
+    uint16_t* qkv_hi = reinterpret_cast<uint16_t*>(qkv);
+    uint16_t* qkv_lo = split == 3 ? qkv_hi + T * ldq : nullptr;
+    auto lo_at = [&](int64_t off) -> uint16_t* { return qkv_lo ? qkv_lo + off : nullptr; };
+    const int64_t ldp = (C + 63) / 64 * 64;
+    uint16_t* p_hi = reinterpret_cast<uint16_t*>(ws + lay.pplanes);
+    uint16_t* p_lo = split == 3 ? p_hi + (int64_t)H * C * ldp : nullptr;
     uint16_t* hid_hi = reinterpret_cast<uint16_t*>(hidden);
     uint16_t* hid_lo = split == 3 ? hid_hi + T * (int64_t)F : nullptr;
     auto ln_for_gemm = [&](const float* g, const float* b) -> int {
@@ -128,28 +140,45 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         float* probs = row_attn + (int64_t)l * H * C * C;
         // ---- tied row attention block
         FWD(ln_for_gemm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
-        if (planes)
-            FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
-                          RNAMSM_ACT_NONE, row_scale, D));
-        else
-            FWD(linear(l, 0, xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
-                       RNAMSM_ACT_NONE, row_scale, D, mask));
-        FWD(rnamsm_row_logits(qkv, qkv + D, ldq, part, R, C, H, 64, f32, stream));
-        FWD(rnamsm_softmax_rows(part, nsplit, probs, H, C, mask, stream));
-        FWD(rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, ctx_hi, ctx_lo, fmt, f32, stream));
+        if (attn16) {
+            // q stays unscaled in the planes; the scaling multiplies the fp32 logits (see include/rnamsm.h)
+            FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
+                          RNAMSM_ACT_NONE, 1.f, 0));
+            FWD(rnamsm_row_logits16(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), ldq, part, R, C, H, 64, row_scale, fmt, stream));
+            FWD(rnamsm_softmax_rows_planes(part, nsplit, probs, p_hi, p_lo, ldp, 4096.f, H, C, nullptr, fmt, stream));
+            FWD(rnamsm_row_apply16(p_hi, p_lo, ldp, qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C, H, 64, 1.f / 4096.f,
+                                   ctx_hi, ctx_lo, fmt, stream));
+        } else {
+            if (planes)
+                FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
+                              RNAMSM_ACT_NONE, row_scale, D));
+            else
+                FWD(linear(l, 0, xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
+                           RNAMSM_ACT_NONE, row_scale, D, mask));
+            FWD(rnamsm_row_logits(qkv, qkv + D, ldq, part, R, C, H, 64, f32, stream));
+            FWD(rnamsm_softmax_rows(part, nsplit, probs, H, C, mask, stream));
+            FWD(rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, ctx_hi, ctx_lo, fmt, f32, stream));
+        }
         if (planes)
             FWD(linear_pl(l, 1, ctx_hi, ctx_lo, D, W[RNAMSM_WL_ROW_BO], x, D, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE, 1.f, 0));
         else
             FWD(linear(l, 1, ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
         // ---- column attention block
         FWD(ln_for_gemm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
-        if (planes)
-            FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
-                          RNAMSM_ACT_NONE, col_scale, D));
-        else
-            FWD(linear(l, 2, xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
-                       RNAMSM_ACT_NONE, col_scale, D, nullptr));
-        FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, mask, ctx_hi, ctx_lo, fmt, f32, stream));
+        if (attn16) {
+            FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
+                          RNAMSM_ACT_NONE, 1.f, 0));
+            FWD(rnamsm_col_attn16(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C,
+                                  H, 64, col_scale, ctx_hi, ctx_lo, fmt, stream));
+        } else {
+            if (planes)
+                FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
+                              RNAMSM_ACT_NONE, col_scale, D));
+            else
+                FWD(linear(l, 2, xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
+                           RNAMSM_ACT_NONE, col_scale, D, nullptr));
+            FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, mask, ctx_hi, ctx_lo, fmt, f32, stream));
+        }
         if (planes)
             FWD(linear_pl(l, 3, ctx_hi, ctx_lo, D, W[RNAMSM_WL_COL_BO], x, D, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE, 1.f, 0));
         else

@@ -643,9 +643,9 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
                                 const uint16_t* A_lo, uint16_t* O_hi, uint16_t* O_lo, void* stream) {
     RNAMSM_CHECK_ARG((A || A_hi) && W_hi && (Cout || O_hi), "gemm_bf16: null pointer");
     RNAMSM_CHECK_ARG(!A_hi || (split == 1 || A_lo), "gemm_bf16: split 3 needs the A lo plane");
-    RNAMSM_CHECK_ARG(!O_hi || (act == RNAMSM_ACT_GELU_ERF && !residual && A_hi && (split == 1 || O_lo)),
-                     "gemm_bf16: plane output is built for the fc1 shape (GELU, no residual, plane input)");
-    RNAMSM_CHECK_ARG(!A_hi || O_hi || act == RNAMSM_ACT_NONE, "gemm_bf16: plane input supports act none (f32 out) or GELU (plane out)");
+    RNAMSM_CHECK_ARG(!O_hi || (!residual && A_hi && (split == 1 || O_lo)),
+                     "gemm_bf16: plane output is built for the fc1 / QKV shapes (no residual, plane input)");
+    RNAMSM_CHECK_ARG(!A_hi || O_hi || act == RNAMSM_ACT_NONE, "gemm_bf16: plane input with fp32 output supports act none only");
     RNAMSM_CHECK_ARG(split == 1 || (split == 3 && W_lo), "gemm_bf16: split must be 1, or 3 with a lo plane");
     RNAMSM_CHECK_ARG((fmt == 0) || (fmt == 1 && split == 3), "gemm_bf16: fmt 0 (bf16) or 1 (fp16, split 3 only)");
     RNAMSM_CHECK_ARG(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "gemm_bf16: bad shape");
@@ -668,14 +668,17 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
 #define HB_ACT_RES(SP_, FMT_)                                                                                       \
     do {                                                                                                            \
         if (A_hi && tuning().gemm16_dma >= 2 && N % HX_BN == 0 && m >= 2048) {   /* 256x256 tile for large problems */ \
-            if (O_hi) return HX_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true);                                    \
+            if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HX_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true)        \
+                                                        : HX_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, true);           \
             return residual ? HX_GO(RNAMSM_ACT_NONE, true, SP_, FMT_, false) : HX_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, false); \
         }                                                                                                           \
         if (A_hi && tuning().gemm16_dma) {                                                                          \
-            if (O_hi) return HD_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true);                                    \
+            if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HD_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true)        \
+                                                        : HD_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, true);           \
             return residual ? HD_GO(RNAMSM_ACT_NONE, true, SP_, FMT_, false) : HD_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, false); \
         }                                                                                                           \
-        if (O_hi) return HB_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true, true);                                  \
+        if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HB_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true, true)      \
+                                                    : HB_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, true, true);         \
         if (A_hi) return residual ? HB_GO(RNAMSM_ACT_NONE, true, SP_, FMT_, true, false)                            \
                                   : HB_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, true, false);                          \
         if (act == RNAMSM_ACT_GELU_ERF)                                                                             \

@@ -15,42 +15,13 @@
 // head has only ceil(C/128)^2 output tiles) and K5 adds the partials in range order -> fixed summation order.
 #include "half16.h"
 #include "mma_core.h"
+#include "row_split.h"
 
 namespace rnamsm {
 
 constexpr int HEAD_DIM = 64;
 constexpr int ROWLOGITS_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;
 constexpr int ROWAPPLY_LDS_BYTES = 2 * (TILE_KC + TILE_NC) * 4;
-
-struct RowSplit {
-    int nsplit, rows_per_split;
-};
-
-// Deterministic function of the shape only.  Picks the split count whose block count best fills
-// 256 CUs x 2 resident blocks, subject to >= 4 rows (8 K tiles) per split.
-static RowSplit choose_row_split(int R, int C, int H) {
-    const long tiles = (long)((C + BM - 1) / BM) * ((C + BN - 1) / BN) * H;
-    const int slots = 512;
-    int best_ns = 1;
-    double best_score = -1.0;
-    const int max_ns = R / 4 > 1 ? (R / 4 < 64 ? R / 4 : 64) : 1;
-    for (int ns = 1; ns <= max_ns; ++ns) {
-        const int rps = (R + ns - 1) / ns;
-        const int real_ns = (R + rps - 1) / rps;
-        const long blocks = tiles * real_ns;
-        const long rounds = (blocks + slots - 1) / slots;
-        double score = (double)blocks / (double)(rounds * slots);   // fill efficiency of the last round
-        score -= 0.002 * real_ns;                                    // prefer fewer partial slabs on ties
-        if (score > best_score + 1e-9) {
-            best_score = score;
-            best_ns = real_ns;
-        }
-    }
-    RowSplit s;
-    s.rows_per_split = (R + best_ns - 1) / best_ns;
-    s.nsplit = (R + s.rows_per_split - 1) / s.rows_per_split;
-    return s;
-}
 
 // ---------------------------------------------------------------------------------------------- K4
 // grid.x = xcd-mapped (panel = (head, split), inner = tiles_i * tiles_j): the 16 tiles of one (head, split) share
@@ -123,10 +94,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
 // ---------------------------------------------------------------------------------------------- K5
 // One wave per (h, i) row: sum the nsplit partial slabs in slab order, then softmax over j in fp32
 // (attn_weights.softmax(-1), modules.py:818/739).  C <= 1024 + 1 fits 17 values per lane.
+// PL: 0 = fp32 probabilities only; 1 / 2 = additionally bf16 / fp16 hi(+lo) planes [rows][ldp] (ldp = C rounded up
+// to 64, the tail zero-filled) holding P * plane_scale: the k-contiguous A operand of the 16-bit row_apply.
 constexpr int SOFTMAX_MAX_PER_LANE = 17;
+template <int PL>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ partial, int nsplit,
                                                            float* __restrict__ probs, int64_t rows, int C,
-                                                           const uint8_t* __restrict__ key_mask) {
+                                                           const uint8_t* __restrict__ key_mask,
+                                                           uint16_t* __restrict__ p_hi, uint16_t* __restrict__ p_lo,
+                                                           int64_t ldp, float plane_scale) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -161,6 +137,13 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
         const int j = lane + 64 * e;
         if (j < C) probs[row * C + j] = v[e] * inv;
+        if (PL != 0 && j < ldp) {
+            typedef typename Half16<(PL > 0 ? PL - 1 : 0)>::T Hh;
+            const float p = j < C ? v[e] * inv * plane_scale : 0.f;
+            const Hh hi = (Hh)p;
+            reinterpret_cast<Hh*>(p_hi)[row * ldp + j] = hi;
+            if (p_lo) reinterpret_cast<Hh*>(p_lo)[row * ldp + j] = (Hh)(p - (float)hi);
+        }
     }
 }
 
@@ -297,17 +280,38 @@ extern "C" int rnamsm_row_logits(const float* q, const float* k, int64_t ld, flo
     return RNAMSM_OK;
 }
 
-extern "C" int rnamsm_softmax_rows(const float* partial, int nsplit, float* probs, int H, int C,
-                                   const uint8_t* key_mask, void* stream) {
+static int softmax_rows_launch(const float* partial, int nsplit, float* probs, int H, int C, const uint8_t* key_mask,
+                               uint16_t* p_hi, uint16_t* p_lo, int64_t ldp, float plane_scale, int fmt, void* stream) {
     RNAMSM_CHECK_ARG(partial && probs, "softmax_rows: null pointer");
     RNAMSM_CHECK_ARG(nsplit >= 1 && H > 0 && C > 0 && C <= 64 * SOFTMAX_MAX_PER_LANE,
                      "softmax_rows: bad shape nsplit=%d H=%d C=%d (C <= %d)", nsplit, H, C, 64 * SOFTMAX_MAX_PER_LANE);
+    RNAMSM_CHECK_ARG(!p_hi || (ldp >= C && ldp % 64 == 0 && ldp <= 64 * SOFTMAX_MAX_PER_LANE && (fmt == 0 || fmt == 1)),
+                     "softmax_rows: plane stride must be C rounded up to a multiple of 64, fmt 0 (bf16) or 1 (fp16)");
     const int64_t rows = (int64_t)H * C;
-    KernelTimer timer(TC_SOFTMAX, 0.0, 4.0 * (double)(nsplit + 1) * H * C * C, static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), partial, nsplit, probs, rows, C, key_mask);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    KernelTimer timer(TC_SOFTMAX, 0.0, 4.0 * (double)(nsplit + 1) * H * C * C + (p_hi ? (p_lo ? 4.0 : 2.0) * rows * ldp : 0.0), s);
+    if (!p_hi)
+        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale);
+    else if (fmt == 0)
+        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale);
     RNAMSM_CHECK_LAUNCH("softmax_rows");
     return RNAMSM_OK;
+}
+
+extern "C" int rnamsm_softmax_rows(const float* partial, int nsplit, float* probs, int H, int C,
+                                   const uint8_t* key_mask, void* stream) {
+    return softmax_rows_launch(partial, nsplit, probs, H, C, key_mask, nullptr, nullptr, 0, 1.f, 0, stream);
+}
+
+extern "C" int rnamsm_softmax_rows_planes(const float* partial, int nsplit, float* probs, uint16_t* p_hi, uint16_t* p_lo,
+                                          int64_t ldp, float plane_scale, int H, int C, const uint8_t* key_mask, int fmt,
+                                          void* stream) {
+    RNAMSM_CHECK_ARG(p_hi, "softmax_rows_planes: null plane pointer");
+    RNAMSM_CHECK_ARG(plane_scale > 0.f && plane_scale <= 32768.f, "softmax_rows_planes: plane_scale must be in (0, 32768]");
+    return softmax_rows_launch(partial, nsplit, probs, H, C, key_mask, p_hi, p_lo, ldp, plane_scale, fmt, stream);
 }
 
 extern "C" int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,

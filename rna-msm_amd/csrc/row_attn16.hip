@@ -1,0 +1,334 @@
+// K4' / K6': tied row attention on the 16-bit matrix cores (the 16-bit modes of RowSelfAttention, modules.py:688-821).
+//
+// Same contractions as row_attn.hip, on operands that already live in HBM as 16-bit planes: the QKV GEMM epilogue
+// writes q (unscaled) | k | v as hi (+lo) planes [T, 3D], the softmax kernel writes P as hi (+lo) planes [H*C, ldp].
+// SPLIT 1 = one bf16 MFMA per product; SPLIT 3 = hi*hi + hi*lo + lo*hi on hi/lo pairs (bf16x3 / f16x3, see half16.h).
+//
+//  K4' row_logits16 : S[h,i,j] = scale * sum_{r,d} q[r,i,h,d] k[r,j,h,d].  128x128 output tile, K tile = one alignment row r
+//                     (64 head dims = one 128-B run per alignment column): both operands are "k" tiles of tile16.h,
+//                     DMA-staged, read with ds_read_b128 -- the loop of gemm16_dma_kernel with a different address map.
+//  K6' row_apply16  : ctx[r,i,h,:] = out_scale * sum_j P[h,i,j] v[r,j,h,:].  A = P rows ("k" tile, k = j); B = v for two alignment
+//                     rows, staged as it lies in memory ([key j][64 d], a "t" tile) and read TRANSPOSED by
+//                     ds_read_b64_tr_b16, so no transposed copy of V is ever made.
+// Scaling happens on the fp32 accumulators, not on the operands: q scaled by dh^-0.5 / sqrt(R) (~1e-2) would push its
+// fp16 lo plane into subnormals (absolute step 6e-8, only ~2^-18 of q), and probabilities are stored as P * 2^12 for the
+// same reason (exact power of two, undone by out_scale).
+// Roofline: MFMA-bound like the fp32 kernels (same flops, 16-bit rate x 1 or / 3).
+#include "row_split.h"
+#include "tile16.h"
+
+namespace rnamsm {
+
+constexpr int R16_THREADS = 256;
+constexpr int R16_PLANE = 128 * T16_ROWB;          // one [128][64 halves] operand plane tile = 16 KB
+constexpr int R16_STAGE = 4 * 64 * 68 * 4;         // slab_store_64x64 staging (row_apply16 epilogue)
+template <int SPLIT>
+struct R16Cfg {
+    static constexpr int NPL = SPLIT == 3 ? 2 : 1;
+    static constexpr int BUF = 2 * NPL * R16_PLANE;                       // A planes then B planes
+    static constexpr int LDS = 2 * BUF > R16_STAGE ? 2 * BUF : R16_STAGE;
+};
+
+template <int SPLIT, int FMT>
+struct R16Frag {
+    typename Half16<FMT>::V8 a[2][SPLIT == 3 ? 2 : 1], b[2][SPLIT == 3 ? 2 : 1];
+};
+
+template <int SPLIT, int FMT>
+__device__ __forceinline__ void r16_mma(const R16Frag<SPLIT, FMT>& f, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mma16<SPLIT, FMT>(f.a[mt], f.b[nt], acc[mt][nt]);
+}
+
+// ---------------------------------------------------------------------------------------------- K4'
+template <int SPLIT, int FMT>
+__global__ __launch_bounds__(R16_THREADS, SPLIT == 3 ? 1 : 2) void row_logits16_kernel(
+    const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
+    const uint16_t* __restrict__ klo, int64_t ld, float* __restrict__ partial, int R, int C, int H, int nsplit,
+    int rows_per_split, float scale) {
+    using Cfg = R16Cfg<SPLIT>;
+    constexpr int NPL = Cfg::NPL;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+
+    const unsigned tiles_c = (C + 127) / 128;
+    unsigned panel, tile;
+    if (!xcd_panel_map(blockIdx.x, (unsigned)(H * nsplit), tiles_c * tiles_c, panel, tile)) return;
+    const int h = panel / nsplit, split = panel % nsplit;
+    const int i0 = (tile / tiles_c) * 128, j0 = (tile % tiles_c) * 128;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(R, r_begin + rows_per_split);
+
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv >> 1, wn = wv & 1, li = lane & 31, lh = lane >> 5;
+
+    // DMA map: wave wv moves row groups wv, wv+4, wv+8, wv+12 (8 rows each) of every plane tile; a clamped alignment
+    // column only feeds discarded outputs.
+    const int drow = lane >> 3;
+    const int dchunk = dma_chunk_k(lane, wv);                  // 4*(wv+4j) = 4*wv (mod 8)
+    int64_t qoff[4], koff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * (wv + 4 * j) + drow;
+        qoff[j] = (int64_t)min(i0 + row, C - 1) * ld + h * 64 + dchunk * 8;
+        koff[j] = (int64_t)min(j0 + row, C - 1) * ld + h * 64 + dchunk * 8;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* base = smem_b + buf * Cfg::BUF;
+        const int64_t rb = (int64_t)(r_begin + kt) * C * ld;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int loff = (8 * (wv + 4 * j)) * T16_ROWB;
+            dma16(qhi + rb + qoff[j], base + loff);
+            if (SPLIT == 3) dma16(qlo + rb + qoff[j], base + R16_PLANE + loff);
+            dma16(khi + rb + koff[j], base + NPL * R16_PLANE + loff);
+            if (SPLIT == 3) dma16(klo + rb + koff[j], base + (NPL + 1) * R16_PLANE + loff);
+        }
+    };
+    auto frags = [&](const char* cur, int kk, R16Frag<SPLIT, FMT>& f) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f.a[t][p] = frag_k<FMT>(cur + p * R16_PLANE, wm * 64 + t * 32 + li, kk, lh);
+                f.b[t][p] = frag_k<FMT>(cur + (NPL + p) * R16_PLANE, wn * 64 + t * 32 + li, kk, lh);
+            }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
+
+    const int nk = r_end - r_begin;          // K tile kt = alignment row r_begin + kt
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();                     // vmcnt(0) + barrier: tile kt has landed, the other buffer is free again
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* cur = smem_b + (kt & 1) * Cfg::BUF;
+        R16Frag<SPLIT, FMT> f0, f1;
+        frags(cur, 0, f0);
+        frags(cur, 1, f1);
+        r16_mma<SPLIT, FMT>(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        frags(cur, 2, f0);
+        r16_mma<SPLIT, FMT>(f1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        frags(cur, 3, f1);
+        r16_mma<SPLIT, FMT>(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        r16_mma<SPLIT, FMT>(f1, acc);
+    }
+
+    float* out = partial + ((int64_t)split * H + h) * C * C;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int j = j0 + wn * 64 + nt * 32 + li;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int i = i0 + wm * 64 + mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                if (i < C && j < C) out[(int64_t)i * C + j] = acc[mt][nt][t] * scale;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- K6'
+// grid.x = xcd-mapped (panel = (head, pair of alignment rows), inner = tiles_i) as in row_apply_kernel.
+// The B region of a buffer is [2 rows r][64 keys][128 B] per plane: wave column wn reads alignment row rr0 + wn.
+template <int SPLIT, int FMT, int OUT>
+__global__ __launch_bounds__(R16_THREADS, SPLIT == 3 ? 1 : 2) void row_apply16_kernel(
+    const uint16_t* __restrict__ phi, const uint16_t* __restrict__ plo, int64_t ldp, const uint16_t* __restrict__ vhi,
+    const uint16_t* __restrict__ vlo, int64_t ld, float* __restrict__ ctx, int64_t ldc, int R, int C, int H,
+    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, float out_scale) {
+    using Cfg = R16Cfg<SPLIT>;
+    constexpr int NPL = Cfg::NPL;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+
+    const unsigned tiles_i = (C + 127) / 128, tiles_n = (R + 1) / 2;
+    unsigned panel, ti;
+    if (!xcd_panel_map(blockIdx.x, (unsigned)H * tiles_n, tiles_i, panel, ti)) return;
+    const int h = panel / tiles_n, rr0 = (panel % tiles_n) * 2;
+    const int i0 = ti * 128;
+
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv >> 1, wn = wv & 1, li = lane & 31, lh = lane >> 5;
+
+    const int drow = lane >> 3;
+    const int ck = dma_chunk_k(lane, wv), ct = dma_chunk_t(lane);
+    int64_t poff[4], voff[4];
+    int vkey[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * (wv + 4 * j) + drow;                       // P: tile row i; V: (r_local = row / 64, key = row % 64)
+        poff[j] = ((int64_t)h * C + min(i0 + row, C - 1)) * ldp + ck * 8;
+        const int r = min(rr0 + (row >> 6), R - 1);                    // second row of an odd R is discarded
+        voff[j] = (int64_t)r * C * ld + h * 64 + ct * 8;
+        vkey[j] = row & 63;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* base = smem_b + buf * Cfg::BUF;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int loff = (8 * (wv + 4 * j)) * T16_ROWB;
+            // keys past C: P is zero-padded there, V is clamped (finite) -> contributes exactly 0
+            const int64_t vo = voff[j] + (int64_t)min(kt * 64 + vkey[j], C - 1) * ld;
+            dma16(phi + poff[j] + kt * 64, base + loff);
+            if (SPLIT == 3) dma16(plo + poff[j] + kt * 64, base + R16_PLANE + loff);
+            dma16(vhi + vo, base + NPL * R16_PLANE + loff);
+            if (SPLIT == 3) dma16(vlo + vo, base + (NPL + 1) * R16_PLANE + loff);
+        }
+    };
+    // transposed-read geometry of this lane (tile16.h): addresses row q of the 4-row block, columns 4p..4p+3
+    const int tq = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    auto frags = [&](const char* cur, int kk, R16Frag<SPLIT, FMT>& f) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f.a[t][p] = frag_k<FMT>(cur + p * R16_PLANE, wm * 64 + t * 32 + li, kk, lh);
+                // B[k = key][n = d]: lane (d = t*32 + li, lh) needs keys 16kk + 8lh + 0..7
+                const int ka = 16 * kk + 8 * lh + tq;
+                f.b[t][p] = frag_t<FMT>(cur + (NPL + p) * R16_PLANE + wn * 64 * T16_ROWB, ka, ka + 4, t * 32 + tcol);
+            }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
+
+    const int nk = (C + 63) / 64;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* cur = smem_b + (kt & 1) * Cfg::BUF;
+        R16Frag<SPLIT, FMT> f0, f1;
+        frags(cur, 0, f0);
+        frags(cur, 1, f1);
+        r16_mma<SPLIT, FMT>(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        frags(cur, 2, f0);
+        r16_mma<SPLIT, FMT>(f1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        frags(cur, 3, f1);
+        r16_mma<SPLIT, FMT>(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        r16_mma<SPLIT, FMT>(f1, acc);
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[mt][nt][t] *= out_scale;
+    // wave slab = alignment row rr0 + wn, alignment columns i0 + wm*64 .. +63, 64 head dims -> 256-B / 128-B segments
+    __syncthreads();
+    const int r = rr0 + wn;
+    const int ibase = i0 + wm * 64;
+    auto rowoff = [&](int row) -> int64_t {
+        const int i = ibase + row;
+        return (r < R && i < C) ? ((int64_t)r * C + i) * ldc + h * 64 : (int64_t)-1;
+    };
+    slab_store_64x64<OUT>(acc, reinterpret_cast<float*>(smem_b) + wv * (64 * 68), li, lh, lane, rowoff, ctx, ctx_hi, ctx_lo);
+}
+
+template <typename K>
+static int set_lds16(K kern, int bytes, const char* name) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+    return RNAMSM_OK;
+}
+
+}  // namespace rnamsm
+
+using namespace rnamsm;
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
+                                   int64_t ld, float* partial, int R, int C, int H, int head_dim, float scale, int fmt,
+                                   void* stream) {
+    RNAMSM_CHECK_ARG(q_hi && k_hi && partial, "row_logits16: null pointer");
+    RNAMSM_CHECK_ARG((q_lo == nullptr) == (k_lo == nullptr), "row_logits16: q_lo and k_lo must both be given (x3) or both be null");
+    RNAMSM_CHECK_ARG(head_dim == 64, "row_logits16: head_dim must be 64 (got %d)", head_dim);
+    RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0, "row_logits16: bad shape R=%d C=%d H=%d", R, C, H);
+    RNAMSM_CHECK_ARG(fmt == 0 || (fmt == 1 && q_lo), "row_logits16: fmt must be 0 (bf16) or 1 (fp16, hi/lo only)");
+    RNAMSM_CHECK_ARG(ld >= (int64_t)H * 64 && ld % 8 == 0 && al16(q_hi) && al16(k_hi) && al16(q_lo) && al16(k_lo),
+                     "row_logits16: planes must be 16-byte aligned with ld %% 8 == 0");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const RowSplit sp = choose_row_split(R, C, H);
+    const unsigned tiles_c = (C + 127) / 128;
+    const unsigned grid = xcd_panel_grid((unsigned)(H * sp.nsplit), tiles_c * tiles_c);
+    KernelTimer timer(TC_ROW_LOGITS, 2.0 * H * C * C * R * 64,
+                      (q_lo ? 4.0 : 2.0) * 2.0 * R * C * H * 64 + 4.0 * (double)sp.nsplit * H * C * C, s);
+#define RL_GO(SP_, FMT_)                                                                                            \
+    do {                                                                                                            \
+        static bool cfg_ = false;                                                                                   \
+        if (!cfg_) {                                                                                                \
+            int rc = set_lds16(row_logits16_kernel<SP_, FMT_>, R16Cfg<SP_>::LDS, "row_logits16");                  \
+            if (rc) return rc;                                                                                      \
+            cfg_ = true;                                                                                            \
+        }                                                                                                           \
+        hipLaunchKernelGGL((row_logits16_kernel<SP_, FMT_>), dim3(grid), dim3(R16_THREADS), R16Cfg<SP_>::LDS, s, q_hi, \
+                           q_lo, k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale);            \
+    } while (0)
+    if (!q_lo) RL_GO(1, 0);
+    else if (fmt == 0) RL_GO(3, 0);
+    else RL_GO(3, 1);
+#undef RL_GO
+    RNAMSM_CHECK_LAUNCH("row_logits16");
+    return RNAMSM_OK;
+}
+
+extern "C" int rnamsm_row_apply16(const uint16_t* p_hi, const uint16_t* p_lo, int64_t ldp, const uint16_t* v_hi,
+                                  const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
+                                  int head_dim, float out_scale, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, void* stream) {
+    RNAMSM_CHECK_ARG(p_hi && v_hi && (ctx || ctx_hi), "row_apply16: null pointer");
+    RNAMSM_CHECK_ARG((p_lo == nullptr) == (v_lo == nullptr), "row_apply16: p_lo and v_lo must both be given (x3) or both be null");
+    RNAMSM_CHECK_ARG(!ctx_hi || (ctx_lo == nullptr) == (p_lo == nullptr), "row_apply16: ctx_lo must match the operand split");
+    RNAMSM_CHECK_ARG(head_dim == 64, "row_apply16: head_dim must be 64 (got %d)", head_dim);
+    RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0, "row_apply16: bad shape R=%d C=%d H=%d", R, C, H);
+    RNAMSM_CHECK_ARG(fmt == 0 || (fmt == 1 && p_lo), "row_apply16: fmt must be 0 (bf16) or 1 (fp16, hi/lo only)");
+    RNAMSM_CHECK_ARG(ldp >= C && ldp % 64 == 0, "row_apply16: P plane stride must be C rounded up to a multiple of 64");
+    RNAMSM_CHECK_ARG(ld >= (int64_t)H * 64 && ld % 8 == 0 && al16(p_hi) && al16(p_lo) && al16(v_hi) && al16(v_lo),
+                     "row_apply16: planes must be 16-byte aligned with ld %% 8 == 0");
+    RNAMSM_CHECK_ARG(ldc >= (int64_t)H * 64 && ldc % 4 == 0 && (ctx_hi ? (reinterpret_cast<uintptr_t>(ctx_hi) & 7u) == 0 : al16(ctx)),
+                     "row_apply16: output alignment");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned tiles_i = (C + 127) / 128, tiles_n = (R + 1) / 2;
+    const unsigned grid = xcd_panel_grid((unsigned)H * tiles_n, tiles_i);
+    KernelTimer timer(TC_ROW_APPLY, 2.0 * H * C * C * R * 64,
+                      (p_lo ? 4.0 : 2.0) * ((double)R * C * H * 64 + (double)H * C * ldp) + 4.0 * R * C * H * 64, s);
+#define RA_GO(SP_, FMT_, OUT_)                                                                                      \
+    do {                                                                                                            \
+        static bool cfg_ = false;                                                                                   \
+        if (!cfg_) {                                                                                                \
+            int rc = set_lds16(row_apply16_kernel<SP_, FMT_, OUT_>, R16Cfg<SP_>::LDS, "row_apply16");              \
+            if (rc) return rc;                                                                                      \
+            cfg_ = true;                                                                                            \
+        }                                                                                                           \
+        hipLaunchKernelGGL((row_apply16_kernel<SP_, FMT_, OUT_>), dim3(grid), dim3(R16_THREADS), R16Cfg<SP_>::LDS, s, p_hi, \
+                           p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale);                \
+    } while (0)
+    if (!p_lo) {
+        if (ctx_hi) RA_GO(1, 0, 1); else RA_GO(1, 0, 0);
+    } else if (fmt == 0) {
+        if (ctx_hi) RA_GO(3, 0, 1); else RA_GO(3, 0, 0);
+    } else {
+        if (ctx_hi) RA_GO(3, 1, 2); else RA_GO(3, 1, 0);
+    }
+#undef RA_GO
+    RNAMSM_CHECK_LAUNCH("row_apply16");
+    return RNAMSM_OK;
+}

@@ -132,6 +132,60 @@ def col_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, R: int, C: int, 
     return ctx
 
 
+# ---- 16-bit attention contractions: operands are (hi, lo) int16 plane pairs, lo = None for plain bf16 ---------------
+def _pl(t: Optional[torch.Tensor], name: str):
+    return None if t is None else _dev(t, name, torch.int16)
+
+
+def row_logits16(q, k, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0) -> Tuple[torch.Tensor, int]:
+    """q, k: (hi, lo) plane views [R*C, *] with row stride ld (halves); returns (partial [nsplit,H,C,C] fp32, nsplit);
+    scale multiplies the fp32 logits (q is expected UNSCALED)."""
+    lib = _lib.load()
+    nsplit = lib.rnamsm_row_logits_nsplit(R, C, H)
+    partial = torch.empty(nsplit, H, C, C, device=q[0].device, dtype=torch.float32)
+    ld = _rowmajor(q[0], "q_hi")
+    _lib.check(lib.rnamsm_row_logits16(_pl(q[0], "q_hi"), _pl(q[1], "q_lo"), _pl(k[0], "k_hi"), _pl(k[1], "k_lo"), ld,
+                                       _dev(partial, "partial"), R, C, H, HEAD_DIM, scale, fmt, _stream()))
+    return partial, nsplit
+
+
+def softmax_rows_planes(partial: torch.Tensor, split: int = 3, fmt: int = 0, key_mask: Optional[torch.Tensor] = None,
+                        plane_scale: float = 1.0):
+    """softmax_rows that also returns P * plane_scale as planes (hi, lo | None) [H*C, ldp], ldp = C rounded up to 64,
+    tail zeroed."""
+    nsplit, H, C, _ = partial.shape
+    ldp = (C + 63) // 64 * 64
+    probs = torch.empty(H, C, C, device=partial.device, dtype=torch.float32)
+    p_hi = torch.empty(H * C, ldp, device=partial.device, dtype=torch.int16)
+    p_lo = torch.empty(H * C, ldp, device=partial.device, dtype=torch.int16) if split == 3 else None
+    _lib.check(_lib.load().rnamsm_softmax_rows_planes(
+        _dev(partial, "partial"), nsplit, _dev(probs, "probs"), p_hi.data_ptr(), None if p_lo is None else p_lo.data_ptr(),
+        ldp, plane_scale, H, C, None if key_mask is None else _dev(key_mask, "key_mask", torch.uint8), fmt, _stream()))
+    return probs, (p_hi, p_lo)
+
+
+def row_apply16(p, v, R: int, C: int, H: int, fmt: int = 0, out_scale: float = 1.0) -> torch.Tensor:
+    """p: (hi, lo) planes [H*C, ldp]; v: (hi, lo) plane views [R*C, *]; returns out_scale * P v, fp32 [R*C, H*64]."""
+    ctx = torch.empty(R * C, H * HEAD_DIM, device=v[0].device, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_row_apply16(_pl(p[0], "p_hi"), _pl(p[1], "p_lo"), _rowmajor(p[0], "p_hi"),
+                                              _pl(v[0], "v_hi"), _pl(v[1], "v_lo"), _rowmajor(v[0], "v_hi"),
+                                              _dev(ctx, "ctx"), _rowmajor(ctx, "ctx"), R, C, H, HEAD_DIM, out_scale, None, None,
+                                              fmt, _stream()))
+    return ctx
+
+
+def col_attn16(q, k, v, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0) -> torch.Tensor:
+    """q, k, v: (hi, lo) plane views [R*C, *] with a common row stride; returns softmax(scale * q k^T) v, fp32
+    [R*C, H*64] (q UNSCALED)."""
+    ctx = torch.empty(R * C, H * HEAD_DIM, device=v[0].device, dtype=torch.float32)
+    ld = _rowmajor(q[0], "q_hi")
+    assert _rowmajor(k[0], "k_hi") == ld and _rowmajor(v[0], "v_hi") == ld
+    _lib.check(_lib.load().rnamsm_col_attn16(_pl(q[0], "q_hi"), _pl(q[1], "q_lo"), _pl(k[0], "k_hi"), _pl(k[1], "k_lo"),
+                                             _pl(v[0], "v_hi"), _pl(v[1], "v_lo"), ld, _dev(ctx, "ctx"), _rowmajor(ctx, "ctx"),
+                                             R, C, H, HEAD_DIM, scale, None, None, fmt, _stream()))
+    return ctx
+
+
 def embed_ln(tokens: torch.Tensor, embed_tokens: torch.Tensor, embed_positions: torch.Tensor, row_pos: torch.Tensor,
              gamma: torch.Tensor, beta: torch.Tensor, pad_idx: int, eps: float = 1e-5) -> torch.Tensor:
     """tokens int64 [R,C] -> x [R*C, D]; raises on token / position ids outside the tables."""

@@ -15,9 +15,11 @@ G = os.path.join(ROOT, "tests", "golden")
 toks64 = synthetic.make_tokens(64, 128, 0)
 res = O.forward(torch.from_numpy(toks64), O.to_torch_params(state, torch.float64))
 o_emb, o_atp = (t.numpy() for t in O.pack_outputs(res))
-for mode in ("f32", "f16x3", "bf16x3", "bf16"):
+from rnamsm import _lib
+for mode, attn16 in (("f32", 1), ("f16x3", 0), ("f16x3", 1), ("bf16x3", 0), ("bf16x3", 1), ("bf16", 0), ("bf16", 1)):
     m.gemm_dtype = mode
-    line = [mode]
+    _lib.check(_lib.load().rnamsm_set_param(b"attn16", attn16))
+    line = [f"{mode} attn16={attn16}"]
     for name in ("m8_c17", "m16_c33"):
         g, g64 = np.load(f"{G}/forward_{name}.npz"), np.load(f"{G}/forward_{name}_fp64.npz")
         out = m.forward_one(torch.from_numpy(g["tokens"]).cuda())

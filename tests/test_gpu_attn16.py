@@ -1,0 +1,216 @@
+"""GPU parity tests of the 16-bit attention kernels (K4', K5', K6', K7' of include/rnamsm.h) through the C ABI.
+
+Two references per case, both fp64 on the host:
+  * "eff": the contraction evaluated on the values the planes actually hold (hi, or hi + lo).  What the kernel adds to
+    that is fp32 accumulation and, for the x3 modes, the dropped lo*lo term (2^-16 relative for bf16 pairs, 2^-22 for
+    fp16 pairs): a TIGHT bound that catches any wrong lane / swizzle / transposed-read mapping in every mode;
+  * the contraction on the original fp32 operands, at the mode's stated accuracy (bf16 2^-9 operands, bf16x3 ~2^-17,
+    f16x3 ~2^-22 = fp32-grade).
+Integer operands are exactly representable in both 16-bit formats, so row_logits16 / row_apply16 must be bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from rnamsm import synthetic
+
+pytestmark = pytest.mark.gpu
+
+ATT_SHAPES = [(1, 5, 2), (7, 33, 2), (34, 66, 2), (6, 19, 12), (3, 130, 2), (65, 40, 2), (257, 9, 2), (300, 20, 1), (16, 200, 3)]
+# (split, fmt, tolerance vs eff operands, tolerance vs fp32 operands)
+MODES = [(1, 0, 2e-6, 8e-3), (3, 0, 4e-5, 4e-5), (3, 1, 3e-6, 3e-6)]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from rnamsm import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _rand(name, shape, scale=1.0):
+    return torch.from_numpy((scale * synthetic.normal(name, 23, shape)).astype(np.float32))
+
+
+def _planes(x_dev, split, fmt):
+    """fp32 device tensor -> ((hi, lo|None) int16 planes, fp64 host tensor of the values they hold)."""
+    from rnamsm import ops
+    hi, lo = ops.split_bf16(x_dev, want_lo=(split == 3), fmt=fmt)
+    ht = torch.float16 if fmt == 1 else torch.bfloat16
+    eff = hi.view(ht).double()
+    if lo is not None:
+        eff = eff + lo.view(ht).double()
+    return (hi, lo), eff.cpu()
+
+
+def _views(pl, a, b):
+    return (pl[0][:, a:b], None if pl[1] is None else pl[1][:, a:b])
+
+
+@pytest.mark.parametrize("split,fmt,tol_eff,tol_f32", MODES)
+@pytest.mark.parametrize("R,C,H", ATT_SHAPES)
+def test_row_attention_16bit(dev, R, C, H, split, fmt, tol_eff, tol_f32):
+    from rnamsm import ops
+    D = 64 * H
+    qkv = _rand(f"row16.{R}.{C}", (R * C, 3 * D))
+    scale = ops.row_scaling(R)                  # applied by the kernel to the fp32 logits; q stays unscaled in the planes
+    pl, eff = _planes(qkv.to(dev), split, fmt)
+
+    def parts(t):
+        t = t.double()
+        return t[:, :D].view(R, C, H, 64), t[:, D:2 * D].view(R, C, H, 64), t[:, 2 * D:].view(R, C, H, 64)
+
+    partial, nsplit = ops.row_logits16(_views(pl, 0, D), _views(pl, D, 2 * D), R, C, H, fmt=fmt, scale=scale)
+    got = partial.sum(0).cpu()
+    qe, ke, ve = parts(eff)
+    q, k, v = parts(qkv)
+    assert rel_l2(got, scale * torch.einsum("rihd,rjhd->hij", qe, ke)) < tol_eff
+    assert rel_l2(got, scale * torch.einsum("rihd,rjhd->hij", q, k)) < tol_f32
+
+    PS = 4096.0                                 # plane scale used by rnamsm_forward (keeps fp16 lo planes normal)
+    probs, pp = ops.softmax_rows_planes(partial, split=split, fmt=fmt, plane_scale=PS)
+    want_p = torch.softmax(partial.sum(0).double().cpu(), -1)
+    assert np.abs(probs.cpu().numpy() - want_p.numpy()).max() < 2e-6
+    ht = torch.float16 if fmt == 1 else torch.bfloat16
+    ldp = (C + 63) // 64 * 64
+    assert pp[0].shape == (H * C, ldp)
+    assert torch.equal(pp[0][:, :C].reshape(H, C, C), (probs * PS).to(ht).view(torch.int16))    # hi = round(P * 2^12)
+    assert int(pp[0][:, C:].abs().max() if ldp > C else 0) == 0                                  # zero tail
+    p_eff = pp[0].view(ht).double()
+    if split == 3:
+        assert int(pp[1][:, C:].abs().max() if ldp > C else 0) == 0
+        p_eff = p_eff + pp[1].view(ht).double()
+        assert np.abs(p_eff[:, :C].cpu().numpy().reshape(H, C, C) / PS - probs.double().cpu().numpy()).max() < (2e-5 if fmt == 0 else 3e-7)
+    p_eff = p_eff[:, :C].reshape(H, C, C).cpu() / PS
+
+    ctx = ops.row_apply16(pp, _views(pl, 2 * D, 3 * D), R, C, H, fmt=fmt, out_scale=1.0 / PS).cpu()
+    assert rel_l2(ctx, torch.einsum("hij,rjhd->rihd", p_eff, ve).reshape(R * C, D)) < tol_eff
+    assert rel_l2(ctx, torch.einsum("hij,rjhd->rihd", want_p, v).reshape(R * C, D)) < tol_f32
+
+
+@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 0), (3, 1)])
+def test_row_kernels_16bit_are_exact_on_integers(dev, split, fmt):
+    """Small integers are exact in bf16 and fp16 (lo planes = 0) and every partial sum is exact in fp32: the result must
+    equal the integer contraction bit for bit.  The data are asymmetric in every index, so a transposed tile, a swapped
+    k order inside a fragment or a wrong swizzle cannot cancel."""
+    from rnamsm import ops
+    R, C, H = 5, 150, 2
+    D = 64 * H
+    n = R * C * 3 * D
+    qkv = torch.from_numpy((((np.arange(n, dtype=np.int64) * 7 + (np.arange(n, dtype=np.int64) // 191) * 3) % 13) - 6)
+                           .astype(np.float32)).view(R * C, 3 * D)
+    pl, eff = _planes(qkv.to(dev), split, fmt)
+    assert torch.equal(eff.float(), qkv)
+    partial, _ = ops.row_logits16(_views(pl, 0, D), _views(pl, D, 2 * D), R, C, H, fmt=fmt)
+    q = qkv[:, :D].double().view(R, C, H, 64); k = qkv[:, D:2 * D].double().view(R, C, H, 64)
+    v = qkv[:, 2 * D:].double().view(R, C, H, 64)
+    assert torch.equal(partial.sum(0).cpu().double(), torch.einsum("rihd,rjhd->hij", q, k))
+    # integer "probabilities" handed to row_apply16 as planes [H*C, ldp]
+    ldp = (C + 63) // 64 * 64
+    m = H * C * ldp
+    pint = torch.from_numpy((((np.arange(m, dtype=np.int64) * 5 + (np.arange(m, dtype=np.int64) // 67)) % 7) - 3)
+                            .astype(np.float32)).view(H * C, ldp)
+    pint[:, C:] = 0
+    pp, _ = _planes(pint.to(dev), split, fmt)
+    ctx = ops.row_apply16(pp, _views(pl, 2 * D, 3 * D), R, C, H, fmt=fmt).cpu()
+    want = torch.einsum("hij,rjhd->rihd", pint[:, :C].double().view(H, C, C), v).reshape(R * C, D)
+    assert torch.equal(ctx.double(), want)
+
+
+def _col_ref(q, k, v):
+    p = torch.softmax(torch.einsum("ichd,jchd->hcij", q, k), -1)
+    return torch.einsum("hcij,jchd->ichd", p, v), p
+
+
+@pytest.mark.parametrize("split,fmt,tol_eff,tol_f32", MODES)
+@pytest.mark.parametrize("R,C,H", ATT_SHAPES)
+def test_col_attention_16bit(dev, R, C, H, split, fmt, tol_eff, tol_f32):
+    """P is rounded to the operand format inside the kernel (bf16: 2^-9 per element, pairs: 2^-17 / 2^-22), so the
+    plain-bf16 bound vs the eff reference is the P rounding, not the q/k/v rounding."""
+    from rnamsm import ops
+    D = 64 * H
+    qkv = _rand(f"col16.{R}.{C}", (R * C, 3 * D))
+    pl, eff = _planes(qkv.to(dev), split, fmt)
+    ctx = ops.col_attn16(_views(pl, 0, D), _views(pl, D, 2 * D), _views(pl, 2 * D, 3 * D), R, C, H, fmt=fmt, scale=0.125).cpu()
+
+    def ref(t):
+        t = t.double()
+        return _col_ref(0.125 * t[:, :D].view(R, C, H, 64), t[:, D:2 * D].view(R, C, H, 64), t[:, 2 * D:].view(R, C, H, 64))[0]
+
+    assert rel_l2(ctx, ref(eff).reshape(R * C, D)) < (3e-3 if split == 1 else tol_eff)
+    assert rel_l2(ctx, ref(qkv).reshape(R * C, D)) < tol_f32
+
+
+@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 1)])
+def test_col_attention_16bit_selects_the_right_value_rows(dev, split, fmt):
+    """One-hot attention: query i = +-e_(i % 64) and key perm[i] carries +-40 on that axis, so ctx[i] must be v[perm[i]]
+    to rounding; with integer v[j][d] = (3j + 5d) % 251 (exact in both formats) a wrong key order in the transposed V
+    read or in the P fragment shows up as a wrong integer."""
+    from rnamsm import ops
+    R, C, H = 96, 2, 1
+    q = torch.zeros(R, C, 64); k = torch.zeros(R, C, 64); v = torch.zeros(R, C, 64)
+    perm = (np.arange(R) * 37 + 11) % R                        # query i attends key perm[i]
+    for i in range(R):
+        q[i, :, i % 64] = 1.0 if i < 64 else -1.0              # 96 distinct directions: +-e_(i%64), sign by i // 64 ...
+    for i in range(R):
+        j = int(perm[i])
+        k[j, :, i % 64] += 40.0 if i < 64 else -40.0
+    # a key can be the target of one query only (perm is a bijection); cross terms: query i (dir e_m, sign s) sees key
+    # perm[i'] with i' % 64 == m, i' != i: score -40 -> never the maximum.
+    v[:] = ((3 * torch.arange(R)[:, None, None] + 5 * torch.arange(64)[None, None, :]) % 251).float()
+    qkv = torch.cat([q, k, v], -1).view(R * C, 192)
+    pl, _ = _planes(qkv.to(dev), split, fmt)
+    ctx = ops.col_attn16(_views(pl, 0, 64), _views(pl, 64, 128), _views(pl, 128, 192), R, C, H, fmt=fmt).cpu().view(R, C, 64)
+    want = v[torch.from_numpy(perm.astype(np.int64))]
+    assert np.abs(ctx.numpy() - want.numpy()).max() < 1e-3
+
+
+@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 1)])
+def test_col_attention_16bit_online_softmax_rescale(dev, split, fmt):
+    from rnamsm import ops
+    R, C, H = 200, 3, 1
+    for spike_row in (190, 0, 65):
+        qkv = _rand(f"spike16.{spike_row}", (R * C, 192))
+        qkv[:, :64] = qkv[:, :64].abs() * 0.2
+        qkv[:, 64:128].view(R, C, 64)[spike_row] = 6.0
+        pl, eff = _planes(qkv.to(dev), split, fmt)
+        ctx = ops.col_attn16(_views(pl, 0, 64), _views(pl, 64, 128), _views(pl, 128, 192), R, C, H, fmt=fmt).cpu()
+        e = eff.double()
+        want = _col_ref(e[:, :64].view(R, C, 1, 64), e[:, 64:128].view(R, C, 1, 64), e[:, 128:].view(R, C, 1, 64))[0]
+        assert rel_l2(ctx, want.reshape(R * C, 64)) < (3e-3 if split == 1 else 3e-6)
+
+
+def test_16bit_attention_rejects_inconsistent_planes(dev):
+    from rnamsm import ops, _lib
+    R, C, H = 4, 8, 1
+    x = _rand("rej", (R * C, 192)).to(dev)
+    hi, lo = ops.split_bf16(x, fmt=0)
+    with pytest.raises(_lib.RnamsmError):          # lo given for q but not for k
+        ops.row_logits16((hi[:, :64], lo[:, :64]), (hi[:, 64:128], None), R, C, H)
+    with pytest.raises(_lib.RnamsmError):          # fp16 needs hi/lo pairs
+        ops.col_attn16((hi[:, :64], None), (hi[:, 64:128], None), (hi[:, 128:], None), R, C, H, fmt=1)
+
+
+def test_forward_attn16_switch(dev):
+    """rnamsm_set_param("attn16"): the f16x3 forward with 16-bit attention must stay within the fp32-grade distance of
+    the same forward with exact-fp32 attention (both inside the 1e-4 bar of tests/test_gpu_forward.py)."""
+    from rnamsm import _lib
+    from rnamsm.model import MSATransformer
+    lib = _lib.load()
+    state = synthetic.make_state_dict(seed=0)
+    m = MSATransformer(num_layers=10).cuda().eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    toks = torch.from_numpy(synthetic.make_tokens(24, 70, 3)).cuda()
+    m.gemm_dtype = "f16x3"
+    try:
+        assert lib.rnamsm_get_param(b"attn16") == 1
+        a = m.forward_one(toks)
+        _lib.check(lib.rnamsm_set_param(b"attn16", 0))
+        b = m.forward_one(toks)
+    finally:
+        _lib.check(lib.rnamsm_set_param(b"attn16", 1))
+    assert not torch.equal(a["emb"], b["emb"])                 # the switch really changes the kernels
+    assert rel_l2(a["emb"].cpu().numpy(), b["emb"].cpu().numpy()) < 2e-5
+    assert np.abs(a["atp"].cpu().numpy() - b["atp"].cpu().numpy()).max() < 2e-5
