@@ -45,7 +45,8 @@ struct KernelTimer {   // brackets one launch with two hipEventRecord calls when
 
 // ---- tuning knobs (api.hip) -------------------------------------------------------------------------
 struct Tuning {
-    int gemm16_dma = 2;            // plane-input 16-bit GEMMs: 0 register staging, 1 LDS-DMA 128x128, 2 LDS-DMA 256x256 when it fits
+    int gemm16_dma = 3;            // plane-input 16-bit GEMMs: 0 register staging, 1 LDS-DMA 128x128, 2 LDS-DMA 256x256,
+                                   // 3 = LDS-DMA 256x256 with software-pipelined fragments (default)
     int attn16 = 1;                // 16-bit modes of rnamsm_forward: 1 = attention contractions on the 16-bit matrix cores too, 0 = fp32 attention
 };
 Tuning& tuning();

@@ -532,6 +532,149 @@ static int launch_hx(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
     return RNAMSM_OK;
 }
 
+template <int N>
+__device__ __forceinline__ void wait_dma_then_barrier() {
+    // all of this wave's LDS reads are done (lgkmcnt 0) and its DMA older than the N youngest have landed
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// ---- 256x256 tile, two buffers, software-pipelined fragments -------------------------------------------------------
+// gemm16_dma256_kernel reads a k-step's fragments and waits for them right before the MFMAs that use them; its two
+// waves per SIMD are barrier-synchronised, so they tend to sit in those waits together and the matrix pipe idles
+// (PMC, split 3 QKV: 56% MFMA busy at the actual clock, waves 32% of their time in s_waitcnt).  Here a k-step's
+// fragments are requested while the PREVIOUS step's MFMAs issue (two fragment sets, interleave pinned with
+// sched_group_barrier), also across the tile boundary: the barrier sits in the middle of a tile, right after the tile's
+// last fragment read -- at that point every wave is done READING the buffer, so the DMA of tile kt+2 can start
+// overwriting it while the MFMAs of tile kt are still issuing, and the first fragments of tile kt+1 load under them.
+// Measured against the kernel above in one process (cfg3 shapes): +3..5% for split 3 (QKV 337 -> 356 TF algorithmic,
+// matrix pipe 56% -> 60% busy at the ~1.7 GHz the chip sustains here) and +4..10% for split 1.  What remains is not
+// fragment latency: a 4-stage DMA pipeline with counted vmcnt (three tiles in flight, BK = 16 for split 3) was also
+// built and measured -- split 1 +5..10%, split 3 -7..12% (twice the barriers for the same bytes) -- and dropped.  The
+// waves still spend ~28% (split 3) / ~50% (split 1) of their time in s_waitcnt: LDS bandwidth (fragment reads + DMA
+// writes ~ 67% / ~100% of the 128 B/clk) is the co-limiter; the next step would be 128x128 wave tiles (-33% reads).
+template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
+__global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
+    const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo, int64_t lda, const uint16_t* __restrict__ Whi,
+    const uint16_t* __restrict__ Wlo, const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout,
+    int64_t ldc, int M, int N, int K, float scale, int scale_cols, uint16_t* __restrict__ Ohi, uint16_t* __restrict__ Olo) {
+    using Cfg = HxCfg<SPLIT>;
+    constexpr int NPL = Cfg::NPL;
+    constexpr int NMF = 8 * (SPLIT == 3 ? 3 : 1);          // MFMAs per k step per wave
+    constexpr int NDS = 6 * NPL;                           // fragment reads per k step per wave
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+
+    const unsigned nb = N / HX_BN, mp = (M + HX_BM - 1) / HX_BM;
+    unsigned mpanel, nblk;
+    if (!xcd_panel_map(blockIdx.x, mp, nb, mpanel, nblk)) return;
+    const int m0 = mpanel * HX_BM, n0 = nblk * HX_BN;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv >> 2, wn = wv & 3, li = lane & 31, lh = lane >> 5;
+
+    const int drow = lane >> 2;
+    const int dchunk = (lane & 3) ^ ((lane >> 4) & 3);
+    int64_t aoff[2], woff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 16 * (wv + 8 * j) + drow;
+        int m = m0 + row;
+        m = m < M ? m : M - 1;
+        aoff[j] = (int64_t)m * lda + dchunk * 8;
+        woff[j] = (int64_t)(n0 + row) * K + dchunk * 8;
+    }
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto issue = [&](int kt, int buf) {
+        char* base = smem_b + buf * Cfg::BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int loff = (16 * (wv + 8 * j)) * HX_ROWB;
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ahi + aoff[j] + kt * HX_BK), (lptr_t)(base + loff), 16, 0, 0);
+            if (SPLIT == 3)
+                __builtin_amdgcn_global_load_lds((gptr_t)(Alo + aoff[j] + kt * HX_BK), (lptr_t)(base + HX_PLANE + loff), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Whi + woff[j] + kt * HX_BK), (lptr_t)(base + NPL * HX_PLANE + loff), 16, 0, 0);
+            if (SPLIT == 3)
+                __builtin_amdgcn_global_load_lds((gptr_t)(Wlo + woff[j] + kt * HX_BK), (lptr_t)(base + (NPL + 1) * HX_PLANE + loff), 16, 0, 0);
+        }
+    };
+    // pin "NMF MFMAs with NDS fragment reads spread between them"
+    auto interleave = [&]() {
+        // one read per MFMA from the start: the last read has the rest of the run to land before the next phase waits
+        constexpr int PER = 1;
+#pragma unroll
+        for (int i = 0; i < NDS; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - PER * NDS, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
+
+    const int nk = K / HX_BK;
+    issue(0, 0);
+    wait_dma_then_barrier<0>();                               // tile 0 landed
+    issue(nk > 1 ? 1 : 0, 1);                                 // (a redundant reload when nk == 1: never read)
+    HxFrag<SPLIT, FMT> f0, f1;
+    hx_frag_load<SPLIT, FMT>(smem_b, 0, wm, wn, li, lh, f0);
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const char* cur = smem_b + (kt & 1) * Cfg::BUF;
+        const char* nxt = smem_b + ((kt & 1) ^ 1) * Cfg::BUF;
+        // step 0 of tile kt on f0, step 1's fragments arriving
+        hx_frag_load<SPLIT, FMT>(cur, 1, wm, wn, li, lh, f1);
+        hx_frag_mma<SPLIT, FMT>(f0, acc);
+        interleave();
+        // every wave is done reading `cur` once its f1 has arrived; tile kt+1 (issued one tile ago) must have landed
+        wait_dma_then_barrier<0>();
+        const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;         // clamped: the last reload is never read
+        issue(k2, kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // step 1 of tile kt on f1, step 0 of tile kt+1 arriving
+        hx_frag_load<SPLIT, FMT>(nxt, 0, wm, wn, li, lh, f0);
+        hx_frag_mma<SPLIT, FMT>(f1, acc);
+        interleave();
+    }
+    {   // last tile
+        const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
+        hx_frag_load<SPLIT, FMT>(cur, 1, wm, wn, li, lh, f1);
+        hx_frag_mma<SPLIT, FMT>(f0, acc);
+        interleave();
+        hx_frag_mma<SPLIT, FMT>(f1, acc);
+    }
+    wait_dma_then_barrier<0>();                               // the clamped reload has landed: LDS is free for the epilogue
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        hb_epilogue<ACT, HAS_RES, SPLIT, FMT, O_PL>(reinterpret_cast<f32x16(&)[2][2]>(acc[2 * p]), smem_b,
+                                                    m0 + wm * 128 + p * 64, n0 + wn * 64, wv, lane, li, lh, bias, residual,
+                                                    ldr, Cout, ldc, M, scale, scale_cols, Ohi, Olo);
+}
+
+template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
+static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias, const float* residual, int64_t ldr,
+                     float* Cout, int64_t ldc, int64_t lda, int M, int N, int K, float scale, int scale_cols,
+                     const uint16_t* a_hi, const uint16_t* a_lo, uint16_t* o_hi, uint16_t* o_lo, hipStream_t stream) {
+    static bool configured = false;
+    auto kern = gemm16_swp_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL>;
+    constexpr int lds = HxCfg<SPLIT>::LDS;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_swp: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured = true;
+    }
+    const unsigned grid = xcd_panel_grid((M + HX_BM - 1) / HX_BM, N / HX_BN);
+    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 2.0 * HxCfg<SPLIT>::NPL * ((double)M * K + (double)N * K) + 4.0 * (double)M * N * (HAS_RES ? 2 : 1), stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, a_lo, lda, Whi, Wlo, bias, residual, ldr, Cout,
+                       ldc, M, N, K, scale, scale_cols, o_hi, o_lo);
+    RNAMSM_CHECK_LAUNCH("gemm16_swp");
+    return RNAMSM_OK;
+}
+
 // LayerNorm whose output goes straight into 16-bit hi/lo planes (the A operand of the following matrix-core GEMM):
 // same arithmetic as layernorm_kernel (elementwise.hip), only the store differs.
 template <int FMT>
@@ -663,10 +806,17 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
     launch_hb<ACT_, RES_, SP_, FMT_, APL_, OPL_>(A, lda, W_hi, W_lo, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, pl, s)
 #define HX_GO(ACT_, RES_, SP_, FMT_, OPL_) \
     launch_hx<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
+#define HS_GO(ACT_, RES_, SP_, FMT_, OPL_) \
+    launch_hs<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
 #define HD_GO(ACT_, RES_, SP_, FMT_, OPL_) \
     launch_hd<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
 #define HB_ACT_RES(SP_, FMT_)                                                                                       \
     do {                                                                                                            \
+        if (A_hi && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= 2048) {   /* software-pipelined fragments */    \
+            if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HS_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true)        \
+                                                        : HS_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, true);           \
+            return residual ? HS_GO(RNAMSM_ACT_NONE, true, SP_, FMT_, false) : HS_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, false); \
+        }                                                                                                           \
         if (A_hi && tuning().gemm16_dma >= 2 && N % HX_BN == 0 && m >= 2048) {   /* 256x256 tile for large problems */ \
             if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HX_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true)        \
                                                         : HX_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, true);           \
@@ -692,6 +842,7 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
     HB_ACT_RES(1, 0);
 #undef HB_ACT_RES
 #undef HD_GO
+#undef HS_GO
 #undef HX_GO
 #undef HB_GO
 }

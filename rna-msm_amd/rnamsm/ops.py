@@ -137,6 +137,31 @@ def _pl(t: Optional[torch.Tensor], name: str):
     return None if t is None else _dev(t, name, torch.int16)
 
 
+def linear_planes(a, w, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
+                  scale: float = 1.0, scale_cols: int = 0, out: Optional[torch.Tensor] = None, out_planes: bool = False,
+                  fmt: int = 0):
+    """16-bit GEMM whose A operand is already (hi, lo | None) planes [M, K] (the LDS-DMA kernels): returns fp32 [M, N],
+    or (hi, lo | None) planes when out_planes (no residual then)."""
+    a_hi, a_lo = a
+    w_hi, w_lo = w
+    M, K = a_hi.shape
+    N = w_hi.shape[0]
+    split = 3 if w_lo is not None else 1
+    o_hi = o_lo = None
+    if out_planes:
+        o_hi = torch.empty(M, N, dtype=torch.int16, device=a_hi.device)
+        o_lo = torch.empty(M, N, dtype=torch.int16, device=a_hi.device) if split == 3 else None
+    elif out is None:
+        out = torch.empty(M, N, device=a_hi.device, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_gemm_bf16(
+        None, _rowmajor(a_hi, "a_hi"), _pl(w_hi, "w_hi"), _pl(w_lo, "w_lo"), None if bias is None else _dev(bias, "bias"),
+        None if residual is None else _dev(residual, "residual"), 0 if residual is None else _rowmajor(residual, "residual"),
+        None if out_planes else _dev(out, "out"), N if out_planes else _rowmajor(out, "out"), M, N, K, act, scale, scale_cols,
+        split, fmt, _pl(a_hi, "a_hi"), _pl(a_lo, "a_lo"), None if o_hi is None else o_hi.data_ptr(),
+        None if o_lo is None else o_lo.data_ptr(), _stream()))
+    return (o_hi, o_lo) if out_planes else out
+
+
 def row_logits16(q, k, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0) -> Tuple[torch.Tensor, int]:
     """q, k: (hi, lo) plane views [R*C, *] with row stride ld (halves); returns (partial [nsplit,H,C,C] fp32, nsplit);
     scale multiplies the fp32 logits (q is expected UNSCALED)."""

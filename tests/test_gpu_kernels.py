@@ -326,3 +326,40 @@ def test_gemm_16bit_matrix_core_modes(dev, M, N, K):
     for fmt in (0, 1):
         hi, lo = ops.split_bf16(wi.to(dev), fmt=fmt)
         assert torch.equal(ops.linear_bf16(ai.to(dev), hi, lo, split=3, fmt=fmt).cpu(), ai @ wi.t())
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 256, 64), (2300, 768, 768), (4100, 512, 3072)])
+def test_plane_input_gemm_kernels_agree(dev, M, N, K):
+    """The plane-input 16-bit GEMM has four staging variants (rnamsm_set_param "gemm16_dma": 0 register-staged, 1 LDS-DMA
+    128x128, 2 LDS-DMA 256x256, 3 LDS-DMA 256x256 with software-pipelined fragments = default).  Same
+    operands, same MFMA order per output element within a k16 step -> every variant must match the fp64 result of the
+    plane values at fp32-accumulation accuracy, for fp32 and plane outputs, and be exact on integers."""
+    from rnamsm import ops, _lib
+    from rnamsm._lib import ACT_GELU_ERF
+    lib = _lib.load()
+    a, w, b, r = _rand("p.a", (M, K)), _rand("p.w", (N, K), 0.05), _rand("p.b", (N,), 0.1), _rand("p.r", (M, N))
+    ai = torch.from_numpy(((np.arange(M * K).reshape(M, K) * 7 + 3) % 13 - 6).astype(np.float32))
+    wi = torch.from_numpy(((np.arange(N * K).reshape(N, K) * 5 + 1) % 11 - 5).astype(np.float32))
+    default = lib.rnamsm_get_param(b"gemm16_dma")
+    try:
+        for variant in (0, 1, 2, 3):
+            _lib.check(lib.rnamsm_set_param(b"gemm16_dma", variant))
+            for split, fmt, tol in ((1, 0, 2e-6), (3, 0, 4e-5), (3, 1, 3e-6)):
+                ht = torch.float16 if fmt == 1 else torch.bfloat16
+                ap = ops.split_bf16(a.to(dev), want_lo=split == 3, fmt=fmt)
+                wp = ops.split_bf16(w.to(dev), want_lo=split == 3, fmt=fmt)
+                eff = lambda pl: sum(p.view(ht).double().cpu() for p in pl if p is not None)
+                base = eff(ap) @ eff(wp).t() + b.double()
+                y = ops.linear_planes(ap, wp, b.to(dev), residual=r.to(dev), fmt=fmt).cpu()
+                assert rel_l2(y, base + r.double()) < tol, (variant, split, fmt)
+                oh, ol = ops.linear_planes(ap, wp, b.to(dev), act=ACT_GELU_ERF, out_planes=True, fmt=fmt)
+                got = eff((oh, ol))
+                assert rel_l2(got, O.gelu_erf(base)) < (6e-3 if split == 1 else 4e-5 if fmt == 0 else 3e-6), (variant, split, fmt)
+                oh, ol = ops.linear_planes(ap, wp, b.to(dev), scale=0.25, scale_cols=128, out_planes=True, fmt=fmt)   # QKV form
+                want = base.clone(); want[:, :128] *= 0.25
+                assert rel_l2(eff((oh, ol)), want) < (6e-3 if split == 1 else 4e-5 if fmt == 0 else 3e-6), (variant, split, fmt)
+                aip = ops.split_bf16(ai.to(dev), want_lo=split == 3, fmt=fmt)
+                wip = ops.split_bf16(wi.to(dev), want_lo=split == 3, fmt=fmt)
+                assert torch.equal(ops.linear_planes(aip, wip, fmt=fmt).cpu(), ai @ wi.t()), (variant, split, fmt)
+    finally:
+        _lib.check(lib.rnamsm_set_param(b"gemm16_dma", default))
