@@ -549,9 +549,10 @@ __device__ __forceinline__ void wait_dma_then_barrier() {
 // Measured against the kernel above in one process (cfg3 shapes): +3..5% for split 3 (QKV 337 -> 356 TF algorithmic,
 // matrix pipe 56% -> 60% busy at the ~1.7 GHz the chip sustains here) and +4..10% for split 1.  What remains is not
 // fragment latency: a 4-stage DMA pipeline with counted vmcnt (three tiles in flight, BK = 16 for split 3) was also
-// built and measured -- split 1 +5..10%, split 3 -7..12% (twice the barriers for the same bytes) -- and dropped.  The
-// waves still spend ~28% (split 3) / ~50% (split 1) of their time in s_waitcnt: LDS bandwidth (fragment reads + DMA
-// writes ~ 67% / ~100% of the 128 B/clk) is the co-limiter; the next step would be 128x128 wave tiles (-33% reads).
+// built and measured -- split 1 +5..10%, split 3 -7..12% (twice the barriers for the same bytes) -- and dropped.
+// What-if builds: skipping the B fragment reads gains <= 2% (LDS read bandwidth is not the limiter);
+// skipping the DMA gains 23-45%; a DMA-only loop takes 60-75% of the kernel time.  Data movement and MFMA each need
+// most of the time and overlap imperfectly -- contention of the LDS-DMA path or the power budget, still open.
 template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
 __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo, int64_t lda, const uint16_t* __restrict__ Whi,
