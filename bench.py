@@ -224,21 +224,29 @@ def main():
                 "deviation_from_f32_path": {"emb_rel_l2": dev_emb, "atp_max_abs": dev_atp},
                 "f32_path_reordering_noise": {"emb_rel_l2": noise_emb, "atp_max_abs": noise_atp,
                                               "what": "exact path vs itself with alignment rows 1.. permuted"},
-                "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<split 3, fp16>", "achieved": raw,
+                "roofline": {"bound": "mfma", "kernel": "gemm16_swp_kernel<split 3, fp16>", "achieved": raw,
                              "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (executed MFMA flops = 3 x algorithmic)",
                              "frac": raw / F16_MFMA_PEAK_TFLOPS, "algorithmic_tflops": raw / 3.0},
+                "attention": "16-bit kernels (row_logits16 / row_apply16 / col_attn16, same operand format)",
                 "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in tim2.items()}}
 
     if rank == 0:
         residues = world * args.steps * M * L
         g = timings["gemm_f32"]
-        gemm_tflops = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        # executed MFMA flops per algorithmic flop and the matrix-core peak of the mode actually timed
+        mult = {"f32": 1.0, "bf16": 1.0, "bf16x3": 3.0, "f16x3": 3.0}[args.gemm_dtype]
+        peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_dtype == "f32" else F16_MFMA_PEAK_TFLOPS
+        gemm_kernel = {"f32": "gemm_f32_kernel (nn.Linear, K2)", "bf16": "gemm16_swp_kernel<split 1, bf16> (nn.Linear, K2)",
+                       "bf16x3": "gemm16_swp_kernel<split 3, bf16> (nn.Linear, K2)",
+                       "f16x3": "gemm16_swp_kernel<split 3, fp16> (nn.Linear, K2)"}[args.gemm_dtype]
+        flop_unit = "TFLOP/s" if mult == 1.0 else "TFLOP/s (executed MFMA flops = 3 x algorithmic)"
+        gemm_tflops = mult * g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
         attn_ms = sum(timings[k]["ms"] for k in ("row_logits", "row_apply", "col_attn"))
-        attn_fl = sum(timings[k]["flops"] for k in ("row_logits", "row_apply", "col_attn"))
+        attn_fl = mult * sum(timings[k]["flops"] for k in ("row_logits", "row_apply", "col_attn"))
         kern_ms = sum(v["ms"] for v in timings.values())
-        traffic, traffic_src = pmc_traffic_per_launch()
+        traffic, traffic_src = pmc_traffic_per_launch() if (args.gemm_dtype == "f32" and (M, L) == (256, 512)) else (None, None)
         result = {
-            "metric": "MSA-residues/sec forward (emb+attn-map), M=256 L=512",
+            "metric": f"MSA-residues/sec forward (emb+attn-map), M={M} L={L}",
             "value": residues / elapsed,
             "unit": "MSA-residues/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -252,17 +260,17 @@ def main():
                        "gather": gather_note,
                        "num_seqs": M, "seq_len": L, "msas_per_step": world, "sharding": f"independent MSAs x{world}"},
             "model_tflops": flops_per_msa(M, L) * world * args.steps / elapsed / 1e12,
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel (nn.Linear, K2)",
-                         "achieved": gemm_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gemm_tflops / FP32_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": gemm_kernel,
+                         "achieved": gemm_tflops, "peak": peak, "unit": flop_unit,
+                         "frac": gemm_tflops / peak,
                          "avg_launch_ms": g["ms"] / max(1, g["launches"]), "launches": g["launches"],
                          "flops_per_launch": g["flops"] / max(1, g["launches"]),
                          "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side, PMC)",
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"])},
             "attention_mfma": {"kernels": "row_logits+row_apply+col_attn", "achieved": attn_fl / (attn_ms * 1e-3) / 1e12 if attn_ms else 0.0,
-                               "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": (attn_fl / (attn_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if attn_ms else 0.0},
+                               "peak": peak, "unit": flop_unit,
+                               "frac": (attn_fl / (attn_ms * 1e-3) / 1e12 / peak) if attn_ms else 0.0},
             "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in timings.items()},
             "kernel_time_share_of_step": kern_ms / args.steps / (1e3 * elapsed / args.steps),
         }
