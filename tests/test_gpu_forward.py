@@ -200,3 +200,33 @@ def test_padded_ragged_batch_matches_reference_fixture(model):
         assert float(res2["representations"][0][b][toks[b] == 1].abs().max()) == 0.0     # x * (1 - padding_mask)
         assert rel_l2(res2["representations"][10][b].cpu().numpy(), g["rep10"][b]) < 1e-4
         assert np.abs(res2["row_attentions"][b].cpu().numpy() - g["row_attentions"][b]).max() < 1e-4
+
+
+def test_masked_pseudo_likelihood_matches_oracle(model):
+    """§8 f4, utils/likelihood.py:39-120: one masked copy of the MSA per query position, forward + LM head, logits at the
+    masked position; checked against the oracle running the same masked copies on the host (chunked and un-chunked
+    batching must agree bit for bit: each copy is an independent forward)."""
+    from rnamsm import likelihood
+    m, state = model
+    params = O.to_torch_params(state)
+    toks = torch.from_numpy(synthetic.make_tokens(5, 12, 7))
+    idx = [1, 4, 11]
+    got = likelihood.sequence_logits(m, toks.cuda(), indices=idx, max_tokens=5 * 12 * 2)       # batches of 2 copies
+    got_all = likelihood.sequence_logits(m, toks.cuda(), indices=idx, max_tokens=1)            # one copy at a time
+    assert torch.equal(got, got_all) and got.shape == (3, len(m.vocab))
+    want = []
+    for i in idx:
+        t = toks.clone(); t[0, i] = m.vocab.mask_idx
+        res = O.forward(t, params)
+        want.append(O.lm_head(res["representation"][0, i], params))
+    want = torch.stack(want)
+    assert np.abs(got.cpu().numpy() - want.numpy()).max() < 1e-4 * max(1.0, float(want.abs().max()))
+    # unmasked variant and the score table
+    plain = likelihood.sequence_logits(m, toks.cuda(), mask_positions=False, indices=idx).cpu()
+    res = O.forward(toks, params)
+    assert np.abs(plain.numpy() - O.lm_head(res["representation"][0, idx], params).numpy()).max() < 1e-4 * max(1.0, float(want.abs().max()))
+    sc = likelihood.masked_marginal_scores(m, toks.cuda(), indices=idx).cpu()
+    lp = want.log_softmax(-1)
+    ref_sc = lp - lp[torch.arange(3), toks[0, idx]].unsqueeze(1)
+    assert np.abs(sc.numpy() - ref_sc.numpy()).max() < 2e-4
+    assert float(sc[torch.arange(3), toks[0, idx]].abs().max()) == 0.0

@@ -200,3 +200,16 @@ def test_no_cpu_fallback_exists():
                 assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("SURVEY", ""), os.path.join(dirpath, f)
     for f in ("RNA_MSM_Inference.py",):
         assert "oracle" not in open(os.path.join(ROOT, f)).read()
+
+
+def test_mask_and_repeat_matches_reference_semantics():
+    """utils/likelihood.py:18-27: copy i of the alignment has <mask> at (row 0, indices[i]) and nothing else changes."""
+    import torch
+    from rnamsm.likelihood import mask_and_repeat
+    toks = torch.arange(3 * 7).view(3, 7)
+    out = mask_and_repeat(toks, [2, 5, 6, 2], mask_idx=99)
+    assert out.shape == (4, 3, 7)
+    for i, c in enumerate([2, 5, 6, 2]):
+        want = toks.clone(); want[0, c] = 99
+        assert torch.equal(out[i], want)
+    assert torch.equal(toks, torch.arange(3 * 7).view(3, 7))          # the input is not modified
