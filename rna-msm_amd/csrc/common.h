@@ -47,6 +47,7 @@ struct KernelTimer {   // brackets one launch with two hipEventRecord calls when
 struct Tuning {
     int gemm16_dma = 3;            // plane-input 16-bit GEMMs: 0 register staging, 1 LDS-DMA 128x128, 2 LDS-DMA 256x256,
                                    // 3 = LDS-DMA 256x256 with software-pipelined fragments (default)
+    int gemm_group = 0;            // fp32 GEMM: row panels per XCD group of the block order (xcd_panel_map_grouped); 0 = by shape
     int attn16 = 1;                // 16-bit modes of rnamsm_forward: 1 = attention contractions on the 16-bit matrix cores too, 0 = fp32 attention
 };
 Tuning& tuning();
@@ -110,6 +111,24 @@ __device__ __forceinline__ bool xcd_panel_map(unsigned bid, unsigned num_panels,
 }
 static inline unsigned xcd_panel_grid(unsigned num_panels, unsigned inner) {
     return ((num_panels + 7u) / 8u) * 8u * inner;
+}
+
+// Same, with the XCD's panels taken in groups of G and the tiles of a group ordered in_panel-major: the blocks
+// resident on an XCD at one time then cover G panels x (resident / G) consecutive in_panel values instead of
+// (resident / inner) whole panels, so the operand indexed by in_panel (the weight column block of a GEMM) is
+// re-streamed from the fabric once per G panels.  G == 1 is xcd_panel_map.
+__device__ __forceinline__ bool xcd_panel_map_grouped(unsigned bid, unsigned num_panels, unsigned inner, unsigned G,
+                                                      unsigned& panel, unsigned& in_panel) {
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    const unsigned per_group = G * inner;
+    const unsigned group = idx / per_group, rem = idx % per_group;
+    in_panel = rem / G;
+    panel = (group * G + rem % G) * 8u + xcd;
+    return panel < num_panels;
+}
+static inline unsigned xcd_panel_grid_grouped(unsigned num_panels, unsigned inner, unsigned G) {
+    const unsigned local = (num_panels + 7u) / 8u;                 // panels per XCD
+    return ((local + G - 1u) / G) * G * 8u * inner;
 }
 
 }  // namespace rnamsm

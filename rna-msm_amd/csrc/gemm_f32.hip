@@ -16,14 +16,14 @@ template <int ACT, bool HAS_RES, bool ZROWS>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc,
-    int M, int N, int K, float scale, int scale_cols, const uint8_t* __restrict__ zero_rows) {
+    int M, int N, int K, float scale, int scale_cols, const uint8_t* __restrict__ zero_rows, int group) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                    // [2][BM][LDK]
     float* Ws = smem + 2 * TILE_KC;      // [2][BN][LDK]
 
     const unsigned nb = N / BN, mp = (M + BM - 1) / BM;
     unsigned mpanel, nblk;
-    if (!xcd_panel_map(blockIdx.x, mp, nb, mpanel, nblk)) return;
+    if (!xcd_panel_map_grouped(blockIdx.x, mp, nb, (unsigned)group, mpanel, nblk)) return;
     const int m0 = mpanel * BM, n0 = nblk * BN;
 
     const WaveCoord w = wave_coord();
@@ -126,11 +126,16 @@ static int launch_gemm(const float* A, int64_t lda, const float* W, const float*
         if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured = true;
     }
-    const unsigned grid = xcd_panel_grid((M + BM - 1) / BM, N / BN);
+    // Block order (speed/traffic only): 64 blocks are resident per XCD.  With more than 8 column blocks per row panel a
+    // whole-panel order keeps only 64/nb panels in flight and re-streams W (7-9 MB > the 4 MB L2) for each of them;
+    // groups of 8 panels x 8 column blocks halve the fabric reads (PMC, cfg3: QKV 4.9 -> 2.9 GB, fc1 8.0 -> 3.6 GB per
+    // launch; same speed, the kernel is MFMA-bound).  N = 768 (6 column blocks) is already balanced and stays ungrouped.
+    const int group = tuning().gemm_group > 0 ? tuning().gemm_group : (N / BN > 8 ? 8 : 1);
+    const unsigned grid = xcd_panel_grid_grouped((M + BM - 1) / BM, N / BN, (unsigned)group);
     // algorithmic work: 2MNK flops; bytes = A + W + C once (+ residual read)
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, A, lda, W, bias, residual, ldr,
-                       Cout, ldc, M, N, K, scale, scale_cols, zero_rows);
+                       Cout, ldc, M, N, K, scale, scale_cols, zero_rows, group);
     RNAMSM_CHECK_LAUNCH("gemm_f32");
     return RNAMSM_OK;
 }

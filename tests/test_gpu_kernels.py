@@ -363,3 +363,29 @@ def test_plane_input_gemm_kernels_agree(dev, M, N, K):
                 assert torch.equal(ops.linear_planes(aip, wip, fmt=fmt).cpu(), ai @ wi.t()), (variant, split, fmt)
     finally:
         _lib.check(lib.rnamsm_set_param(b"gemm16_dma", default))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 2304, 96), (4100, 1280, 64), (1025, 768, 768), (129, 3072, 32)])
+def test_gemm_block_order_never_changes_results(dev, M, N, K):
+    """rnamsm_set_param("gemm_group"): the XCD-aware block order (whole panels, groups of G panels, by-shape default)
+    only permutes which block computes which tile -- every setting must give bit-identical output, including ragged M
+    (padding blocks of the grouped grid must exit without touching memory)."""
+    from rnamsm import ops, _lib
+    lib = _lib.load()
+    a, w, b = _rand("go.a", (M, K)), _rand("go.w", (N, K), 0.05), _rand("go.b", (N,), 0.1)
+    ga, gw, gb = a.to(dev), w.to(dev), b.to(dev)
+    try:
+        outs = []
+        for g in (0, 1, 3, 8, 64):
+            _lib.check(lib.rnamsm_set_param(b"gemm_group", g))
+            guard = torch.full((M + 1, N), 7.0, device=dev)                  # one sentinel row behind the output
+            ops.linear(ga, gw, gb, out=guard[:M])
+            assert bool((guard[M] == 7.0).all()), g
+            outs.append(guard[:M].clone())
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+        assert rel_l2(outs[0].cpu(), a.double() @ w.double().t() + b.double()) < 3e-6
+        with pytest.raises(_lib.RnamsmError):
+            _lib.check(lib.rnamsm_set_param(b"gemm_group", 65))
+    finally:
+        _lib.check(lib.rnamsm_set_param(b"gemm_group", 0))
