@@ -248,8 +248,8 @@ void rnamsm_timing_reset(void);
  *   "gemm16_dma"  staging of the plane-input 16-bit GEMMs: 0 register-staged, 1 LDS-DMA 128x128 tile,
  *                 2 LDS-DMA 256x256 tile when the problem allows, 3 (default) = 2 with software-pipelined fragment
  *                 reads and a mid-tile barrier.  Speed only.
- *   "gemm_group"  fp32 GEMM block order: row panels per XCD group (0 = chosen from the shape, default; 1 = whole
- *                 panels).  Changes HBM-side traffic, not results or (measurably) speed.
+ *   "gemm_group"  GEMM block order (fp32 kernel and the 256x256 16-bit kernel): row panels per XCD group (0 = chosen
+ *                 from the shape, default; 1 = whole panels).  Changes HBM-side traffic and speed, never results.
  *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit
  *                 matrix cores in the mode's operand format (K4'..K7'), 0 = they stay on the exact-fp32 kernels.
  *                 The RNAMSM_F32 path is not affected by either. */

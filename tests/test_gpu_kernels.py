@@ -342,8 +342,9 @@ def test_plane_input_gemm_kernels_agree(dev, M, N, K):
     wi = torch.from_numpy(((np.arange(N * K).reshape(N, K) * 5 + 1) % 11 - 5).astype(np.float32))
     default = lib.rnamsm_get_param(b"gemm16_dma")
     try:
-        for variant in (0, 1, 2, 3):
+        for variant, group in ((0, 0), (1, 0), (2, 0), (3, 0), (3, 1), (3, 5)):
             _lib.check(lib.rnamsm_set_param(b"gemm16_dma", variant))
+            _lib.check(lib.rnamsm_set_param(b"gemm_group", group))
             for split, fmt, tol in ((1, 0, 2e-6), (3, 0, 4e-5), (3, 1, 3e-6)):
                 ht = torch.float16 if fmt == 1 else torch.bfloat16
                 ap = ops.split_bf16(a.to(dev), want_lo=split == 3, fmt=fmt)
@@ -363,6 +364,7 @@ def test_plane_input_gemm_kernels_agree(dev, M, N, K):
                 assert torch.equal(ops.linear_planes(aip, wip, fmt=fmt).cpu(), ai @ wi.t()), (variant, split, fmt)
     finally:
         _lib.check(lib.rnamsm_set_param(b"gemm16_dma", default))
+        _lib.check(lib.rnamsm_set_param(b"gemm_group", 0))
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 2304, 96), (4100, 1280, 64), (1025, 768, 768), (129, 3072, 32)])

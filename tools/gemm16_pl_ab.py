@@ -11,6 +11,7 @@ T = int(os.environ.get("T", 131072))
 ONLY = os.environ.get("ONLY")
 REPS = int(os.environ.get("REPS", 6))
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "2,3").split(",")]
+KNOB = os.environ.get("KNOB", "gemm16_dma").encode()      # which rnamsm_set_param knob VARIANTS sweeps
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 def timeit(fn, n=REPS):
@@ -34,7 +35,7 @@ for tag, N, K, act, res, opl in [("qkv", 2304, 768, ACT_NONE, False, True), ("ou
         from rnamsm import _lib
         ts = []
         for variant in VARIANTS:
-            _lib.check(_lib.load().rnamsm_set_param(b"gemm16_dma", variant))
+            _lib.check(_lib.load().rnamsm_set_param(KNOB, variant))
             fn(); torch.cuda.synchronize()
             ts.append(timeit(fn))
         line.append(f"{name}: " + " / ".join(f"v{v} {t:.3f} ms {fl / t / 1e9:.0f} TF" for v, t in zip(VARIANTS, ts)))
