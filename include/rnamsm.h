@@ -247,7 +247,8 @@ void rnamsm_timing_reset(void);
 /* Knobs for in-process A/B measurements.  Known names:
  *   "gemm16_dma"  staging of the plane-input 16-bit GEMMs: 0 register-staged, 1 LDS-DMA 128x128 tile,
  *                 2 LDS-DMA 256x256 tile when the problem allows, 3 (default) = 2 with software-pipelined fragment
- *                 reads and a mid-tile barrier.  Speed only.
+ *                 reads and a mid-tile barrier (K tile 64 deep for plain bf16, 32 for the hi/lo modes), 4 = 3 with
+ *                 32-deep K tiles for every mode.  Speed only.
  *   "gemm_group"  GEMM block order (fp32 kernel and the 256x256 16-bit kernel): row panels per XCD group (0 = chosen
  *                 from the shape, default; 1 = whole panels).  Changes HBM-side traffic and speed, never results.
  *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit

@@ -46,7 +46,8 @@ struct KernelTimer {   // brackets one launch with two hipEventRecord calls when
 // ---- tuning knobs (api.hip) -------------------------------------------------------------------------
 struct Tuning {
     int gemm16_dma = 3;            // plane-input 16-bit GEMMs: 0 register staging, 1 LDS-DMA 128x128, 2 LDS-DMA 256x256,
-                                   // 3 = LDS-DMA 256x256 with software-pipelined fragments (default)
+                                   // 3 = LDS-DMA 256x256 with software-pipelined fragments, BK = 64 for split 1 (default),
+                                   // 4 = the same with BK = 32 for every split
     int gemm_group = 0;            // fp32 GEMM: row panels per XCD group of the block order (xcd_panel_map_grouped); 0 = by shape
     int attn16 = 1;                // 16-bit modes of rnamsm_forward: 1 = attention contractions on the 16-bit matrix cores too, 0 = fp32 attention
 };

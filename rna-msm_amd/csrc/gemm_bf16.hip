@@ -553,16 +553,34 @@ __device__ __forceinline__ void wait_dma_then_barrier() {
 // What-if builds: skipping the B fragment reads gains <= 2% (LDS read bandwidth is not the limiter);
 // skipping the DMA gains 23-45%; a DMA-only loop takes 60-75% of the kernel time.  Data movement and MFMA each need
 // most of the time and overlap imperfectly -- contention of the LDS-DMA path or the power budget, still open.
-template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
+// BK = 32 (64-B tile rows) or 64 (128-B rows = whole cache lines per DMA row, twice the bytes in flight, half the
+// barriers; only split 1 fits: 2 buffers x 64 KB).  Split 1 with BK = 64 against BK = 32, one process, cfg3 shapes:
+// QKV 775 -> 882 TF, out_proj 515 -> 553, fc1 714 -> 759, fc2 830 -> 996 TF ("gemm16_dma" = 4 forces BK = 32).
+template <int SPLIT, int BK>
+struct HsCfg {
+    static constexpr int NPL = SPLIT == 3 ? 2 : 1;
+    static constexpr int ROWB = BK * 2;
+    static constexpr int PLANE = 256 * ROWB;
+    static constexpr int BUF = 2 * NPL * PLANE;
+    static constexpr int EPI = 8 * 64 * 68 * 4;
+    static constexpr int LDS = (2 * BUF) > EPI ? (2 * BUF) : EPI;
+    static constexpr int RPI = 1024 / ROWB;                 // tile rows per wave DMA instruction
+    static constexpr int IPW = 256 / RPI / 8;               // DMA instructions per wave per plane tile
+    static constexpr int KS = BK / 16;                      // MFMA k steps per tile
+};
+
+template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL, int BK>
 __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo, int64_t lda, const uint16_t* __restrict__ Whi,
     const uint16_t* __restrict__ Wlo, const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout,
     int64_t ldc, int M, int N, int K, float scale, int scale_cols, uint16_t* __restrict__ Ohi, uint16_t* __restrict__ Olo,
     int group) {
-    using Cfg = HxCfg<SPLIT>;
-    constexpr int NPL = Cfg::NPL;
+    using Cfg = HsCfg<SPLIT, BK>;
+    constexpr int NPL = Cfg::NPL, ROWB = Cfg::ROWB, PLANE = Cfg::PLANE, KS = Cfg::KS;
     constexpr int NMF = 8 * (SPLIT == 3 ? 3 : 1);          // MFMAs per k step per wave
     constexpr int NDS = 6 * NPL;                           // fragment reads per k step per wave
+    typedef typename Half16<FMT>::V8 V8;
+    static_assert(BK == 32 || BK == 64, "tile depth");
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
 
     const unsigned nb = N / HX_BN, mp = (M + HX_BM - 1) / HX_BM;
@@ -572,12 +590,16 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wv >> 2, wn = wv & 3, li = lane & 31, lh = lane >> 5;
 
-    const int drow = lane >> 2;
-    const int dchunk = (lane & 3) ^ ((lane >> 4) & 3);
-    int64_t aoff[2], woff[2];
+    // DMA map: a wave instruction covers RPI rows; lane -> (row RPI*g + lane / chunks-per-row, physical chunk lane %
+    // chunks-per-row), fetching the logical chunk the read-side swizzle expects there.  g = wv + 8j.
+    constexpr int CPR = ROWB / 16;
+    const int drow = lane / CPR;
+    const int dchunk = BK == 32 ? ((lane & 3) ^ ((lane >> 4) & 3))                      // (row >> 2) & 3
+                                : ((lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7));    // (row >> 1) & 7, row = 8g + lane/8
+    int64_t aoff[Cfg::IPW], woff[Cfg::IPW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 16 * (wv + 8 * j) + drow;
+    for (int j = 0; j < Cfg::IPW; ++j) {
+        const int row = Cfg::RPI * (wv + 8 * j) + drow;
         int m = m0 + row;
         m = m < M ? m : M - 1;
         aoff[j] = (int64_t)m * lda + dchunk * 8;
@@ -588,26 +610,37 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     auto issue = [&](int kt, int buf) {
         char* base = smem_b + buf * Cfg::BUF;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int loff = (16 * (wv + 8 * j)) * HX_ROWB;
-            __builtin_amdgcn_global_load_lds((gptr_t)(Ahi + aoff[j] + kt * HX_BK), (lptr_t)(base + loff), 16, 0, 0);
+        for (int j = 0; j < Cfg::IPW; ++j) {
+            const int loff = (Cfg::RPI * (wv + 8 * j)) * ROWB;
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ahi + aoff[j] + kt * BK), (lptr_t)(base + loff), 16, 0, 0);
             if (SPLIT == 3)
-                __builtin_amdgcn_global_load_lds((gptr_t)(Alo + aoff[j] + kt * HX_BK), (lptr_t)(base + HX_PLANE + loff), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(Whi + woff[j] + kt * HX_BK), (lptr_t)(base + NPL * HX_PLANE + loff), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(Alo + aoff[j] + kt * BK), (lptr_t)(base + PLANE + loff), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Whi + woff[j] + kt * BK), (lptr_t)(base + NPL * PLANE + loff), 16, 0, 0);
             if (SPLIT == 3)
-                __builtin_amdgcn_global_load_lds((gptr_t)(Wlo + woff[j] + kt * HX_BK), (lptr_t)(base + (NPL + 1) * HX_PLANE + loff), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(Wlo + woff[j] + kt * BK), (lptr_t)(base + (NPL + 1) * PLANE + loff), 16, 0, 0);
         }
     };
-    // pin "NMF MFMAs with NDS fragment reads spread between them"
+    auto frag_load = [&](const char* buf, int kk, HxFrag<SPLIT, FMT>& f) {
+        const int chunk = (BK == 32 ? ((2 * kk + lh) ^ ((li >> 2) & 3)) : ((2 * kk + lh) ^ ((li >> 1) & 7))) * 16;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                f.a[p][t] = *reinterpret_cast<const V8*>(buf + p * PLANE + (wm * 128 + t * 32 + li) * ROWB + chunk);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                f.b[p][t] = *reinterpret_cast<const V8*>(buf + (NPL + p) * PLANE + (wn * 64 + t * 32 + li) * ROWB + chunk);
+        }
+    };
+    // pin "NMF MFMAs with NDS fragment reads between them": one read per MFMA from the start, so the last read has the
+    // rest of the run to land before the next phase waits for it
     auto interleave = [&]() {
-        // one read per MFMA from the start: the last read has the rest of the run to land before the next phase waits
-        constexpr int PER = 1;
 #pragma unroll
         for (int i = 0; i < NDS; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF - PER * NDS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - NDS, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -619,35 +652,41 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
 
-    const int nk = K / HX_BK;
+    const int nk = K / BK;
     issue(0, 0);
     wait_dma_then_barrier<0>();                               // tile 0 landed
     issue(nk > 1 ? 1 : 0, 1);                                 // (a redundant reload when nk == 1: never read)
-    HxFrag<SPLIT, FMT> f0, f1;
-    hx_frag_load<SPLIT, FMT>(smem_b, 0, wm, wn, li, lh, f0);
+    HxFrag<SPLIT, FMT> f[2];                                  // step kk lives in f[kk & 1]; KS is even
+    frag_load(smem_b, 0, f[0]);
     for (int kt = 0; kt + 1 < nk; ++kt) {
         const char* cur = smem_b + (kt & 1) * Cfg::BUF;
         const char* nxt = smem_b + ((kt & 1) ^ 1) * Cfg::BUF;
-        // step 0 of tile kt on f0, step 1's fragments arriving
-        hx_frag_load<SPLIT, FMT>(cur, 1, wm, wn, li, lh, f1);
-        hx_frag_mma<SPLIT, FMT>(f0, acc);
-        interleave();
-        // every wave is done reading `cur` once its f1 has arrived; tile kt+1 (issued one tile ago) must have landed
+#pragma unroll
+        for (int kk = 0; kk + 1 < KS; ++kk) {                 // step kk on f[kk&1], step kk+1's fragments arriving
+            frag_load(cur, kk + 1, f[(kk + 1) & 1]);
+            hx_frag_mma<SPLIT, FMT>(f[kk & 1], acc);
+            interleave();
+        }
+        // every wave is done reading `cur` once its last fragments have arrived; tile kt+1 (issued one tile ago) must
+        // have landed
         wait_dma_then_barrier<0>();
         const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;         // clamped: the last reload is never read
         issue(k2, kt & 1);
         __builtin_amdgcn_sched_barrier(0);
-        // step 1 of tile kt on f1, step 0 of tile kt+1 arriving
-        hx_frag_load<SPLIT, FMT>(nxt, 0, wm, wn, li, lh, f0);
-        hx_frag_mma<SPLIT, FMT>(f1, acc);
+        // last step of tile kt, step 0 of tile kt+1 arriving
+        frag_load(nxt, 0, f[0]);
+        hx_frag_mma<SPLIT, FMT>(f[(KS - 1) & 1], acc);
         interleave();
     }
     {   // last tile
         const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
-        hx_frag_load<SPLIT, FMT>(cur, 1, wm, wn, li, lh, f1);
-        hx_frag_mma<SPLIT, FMT>(f0, acc);
-        interleave();
-        hx_frag_mma<SPLIT, FMT>(f1, acc);
+#pragma unroll
+        for (int kk = 0; kk + 1 < KS; ++kk) {
+            frag_load(cur, kk + 1, f[(kk + 1) & 1]);
+            hx_frag_mma<SPLIT, FMT>(f[kk & 1], acc);
+            interleave();
+        }
+        hx_frag_mma<SPLIT, FMT>(f[(KS - 1) & 1], acc);
     }
     wait_dma_then_barrier<0>();                               // the clamped reload has landed: LDS is free for the epilogue
 #pragma unroll
@@ -657,13 +696,13 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
                                                     ldr, Cout, ldc, M, scale, scale_cols, Ohi, Olo);
 }
 
-template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
+template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL, int BK>
 static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias, const float* residual, int64_t ldr,
                      float* Cout, int64_t ldc, int64_t lda, int M, int N, int K, float scale, int scale_cols,
                      const uint16_t* a_hi, const uint16_t* a_lo, uint16_t* o_hi, uint16_t* o_lo, hipStream_t stream) {
     static bool configured = false;
-    auto kern = gemm16_swp_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL>;
-    constexpr int lds = HxCfg<SPLIT>::LDS;
+    auto kern = gemm16_swp_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL, BK>;
+    constexpr int lds = HsCfg<SPLIT, BK>::LDS;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_swp: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -813,7 +852,9 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
 #define HX_GO(ACT_, RES_, SP_, FMT_, OPL_) \
     launch_hx<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
 #define HS_GO(ACT_, RES_, SP_, FMT_, OPL_) \
-    launch_hs<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
+    ((SP_ == 1 && tuning().gemm16_dma != 4 && K % 64 == 0)                                                             \
+         ? launch_hs<ACT_, RES_, SP_, FMT_, OPL_, (SP_ == 1 ? 64 : 32)>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s) \
+         : launch_hs<ACT_, RES_, SP_, FMT_, OPL_, 32>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s))
 #define HD_GO(ACT_, RES_, SP_, FMT_, OPL_) \
     launch_hd<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
 #define HB_ACT_RES(SP_, FMT_)                                                                                       \

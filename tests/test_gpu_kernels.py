@@ -331,7 +331,8 @@ def test_gemm_16bit_matrix_core_modes(dev, M, N, K):
 @pytest.mark.parametrize("M,N,K", [(2048, 256, 64), (2300, 768, 768), (4100, 512, 3072)])
 def test_plane_input_gemm_kernels_agree(dev, M, N, K):
     """The plane-input 16-bit GEMM has four staging variants (rnamsm_set_param "gemm16_dma": 0 register-staged, 1 LDS-DMA
-    128x128, 2 LDS-DMA 256x256, 3 LDS-DMA 256x256 with software-pipelined fragments = default).  Same
+    128x128, 2 LDS-DMA 256x256, 3 LDS-DMA 256x256 with software-pipelined fragments = default, 4 = 3 with 32-deep K tiles
+    for plain bf16 too) and a block-order knob ("gemm_group").  Same
     operands, same MFMA order per output element within a k16 step -> every variant must match the fp64 result of the
     plane values at fp32-accumulation accuracy, for fp32 and plane outputs, and be exact on integers."""
     from rnamsm import ops, _lib
@@ -342,7 +343,7 @@ def test_plane_input_gemm_kernels_agree(dev, M, N, K):
     wi = torch.from_numpy(((np.arange(N * K).reshape(N, K) * 5 + 1) % 11 - 5).astype(np.float32))
     default = lib.rnamsm_get_param(b"gemm16_dma")
     try:
-        for variant, group in ((0, 0), (1, 0), (2, 0), (3, 0), (3, 1), (3, 5)):
+        for variant, group in ((0, 0), (1, 0), (2, 0), (3, 0), (3, 1), (3, 5), (4, 0)):
             _lib.check(lib.rnamsm_set_param(b"gemm16_dma", variant))
             _lib.check(lib.rnamsm_set_param(b"gemm_group", group))
             for split, fmt, tol in ((1, 0, 2e-6), (3, 0, 4e-5), (3, 1, 3e-6)):
