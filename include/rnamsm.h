@@ -251,6 +251,9 @@ void rnamsm_timing_reset(void);
  *                 32-deep K tiles for every mode.  Speed only.
  *   "gemm_group"  GEMM block order (fp32 kernel and the 256x256 16-bit kernel): row panels per XCD group (0 = chosen
  *                 from the shape, default; 1 = whole panels).  Changes HBM-side traffic and speed, never results.
+ *   "gemm_tile"   fp32 GEMM block tile: 0 (default) = 128x128, or 128x64 where that evens out the last round of blocks
+ *                 on a small problem; 1 = always 128x128; 2 = always 128x64.  Results are bit-identical under either
+ *                 tile: each output element sums its K products in the same order.
  *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit
  *                 matrix cores in the mode's operand format (K4'..K7'), 0 = they stay on the exact-fp32 kernels.
  *                 The RNAMSM_F32 path is not affected by either. */

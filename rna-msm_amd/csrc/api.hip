@@ -121,6 +121,11 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm_group = value;
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "gemm_tile")) {
+        if (value < 0 || value > 2) return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: gemm_tile must be 0, 1 or 2");
+        rnamsm::tuning().gemm_tile = value;
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "attn16")) {
         rnamsm::tuning().attn16 = value;
         return RNAMSM_OK;
@@ -130,6 +135,7 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
 extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "gemm16_dma")) return rnamsm::tuning().gemm16_dma;
     if (name && !strcmp(name, "attn16")) return rnamsm::tuning().attn16;
+    if (name && !strcmp(name, "gemm_tile")) return rnamsm::tuning().gemm_tile;
     if (name && !strcmp(name, "gemm_group")) return rnamsm::tuning().gemm_group;
     return -1;
 }

@@ -49,6 +49,7 @@ struct Tuning {
                                    // 3 = LDS-DMA 256x256 with software-pipelined fragments, BK = 64 for split 1 (default),
                                    // 4 = the same with BK = 32 for every split
     int gemm_group = 0;            // fp32 GEMM: row panels per XCD group of the block order (xcd_panel_map_grouped); 0 = by shape
+    int gemm_tile = 0;             // fp32 GEMM block tile: 0 = by shape, 1 = always 128x128, 2 = always 128x64
     int attn16 = 1;                // 16-bit modes of rnamsm_forward: 1 = attention contractions on the 16-bit matrix cores too, 0 = fp32 attention
 };
 Tuning& tuning();

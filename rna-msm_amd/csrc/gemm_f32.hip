@@ -10,77 +10,96 @@
 
 namespace rnamsm {
 
-constexpr int GEMM_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;   // double-buffered A and W tiles
+// NT = MFMA tiles per wave along N: 2 -> block tile 128x128 (default), 1 -> 128x64.  All tiles of a GEMM take the same
+// time and two blocks share a CU, so a launch costs ceil(blocks / 512) rounds; on small problems the last round is
+// mostly empty (T = 8192, N = 768: 384 blocks = 75 % of one round).  Half-width tiles are ~3.5 % less efficient per flop
+// (a wave's A fragments feed one B tile instead of two, half-size epilogue stores) but twice as many, which evens the
+// rounds out; launch_gemm picks whichever its time model says finishes first.
+template <int NT>
+struct GemmCfg {
+    static constexpr int BN_ = 64 * NT;
+    static constexpr int TILE_W = BN_ * LDK;                         // floats in one W tile
+    static constexpr int LDS_BYTES = 2 * (TILE_KC + TILE_W) * 4;     // double-buffered A and W tiles
+    static constexpr int LDE = 32 * NT + 4;                          // padded row stride of the epilogue staging tile
+    static_assert(4 * 64 * LDE * 4 <= LDS_BYTES, "epilogue staging must fit the operand buffers");
+};
 
-template <int ACT, bool HAS_RES, bool ZROWS>
+template <int ACT, bool HAS_RES, bool ZROWS, int NT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc,
     int M, int N, int K, float scale, int scale_cols, const uint8_t* __restrict__ zero_rows, int group) {
+    using Cfg = GemmCfg<NT>;
+    constexpr int BN_ = Cfg::BN_, TILE_W = Cfg::TILE_W;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                    // [2][BM][LDK]
-    float* Ws = smem + 2 * TILE_KC;      // [2][BN][LDK]
+    float* Ws = smem + 2 * TILE_KC;      // [2][BN_][LDK]
 
-    const unsigned nb = N / BN, mp = (M + BM - 1) / BM;
+    const unsigned nb = N / BN_, mp = (M + BM - 1) / BM;
     unsigned mpanel, nblk;
     if (!xcd_panel_map_grouped(blockIdx.x, mp, nb, (unsigned)group, mpanel, nblk)) return;
-    const int m0 = mpanel * BM, n0 = nblk * BN;
+    const int m0 = mpanel * BM, n0 = nblk * BN_;
 
     const WaveCoord w = wave_coord();
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
 
     // per-thread global row pointers (A rows clamped: a clamped row only feeds its own discarded output row)
     const float* ap[4];
-    const float* wp[4];
+    const float* wp[2 * NT];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int m = m0 + r0 + 32 * i;
         m = m < M ? m : M - 1;
         ap[i] = A + (int64_t)m * lda + c4 * 4;
-        wp[i] = W + (int64_t)(n0 + r0 + 32 * i) * K + c4 * 4;
     }
-
-    f32x16 acc[2][2];
-    zero_acc(acc);
-
-    StageKC sa[1], sw[1];
-    pipelined_kloop<true, 8, 1>(
-        K / BK, As, Ws, TILE_KC, TILE_KC, acc, w,
-        [&](int kt, auto set) {
-            constexpr int S = decltype(set)::value;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sa[S].v[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
-                sw[S].v[i] = *reinterpret_cast<const f32x4*>(wp[i] + kt * BK);
-            }
+    for (int i = 0; i < 2 * NT; ++i) wp[i] = W + (int64_t)(n0 + r0 + 32 * i) * K + c4 * 4;
+
+    f32x16 acc[2][NT];
+    zero_acc<NT>(acc);
+
+    f32x4 sa[4], sw[2 * NT];             // staging registers of one K tile: thread -> (row tid/8 + 32 i, 16-B chunk tid%8)
+    pipelined_kloop<true, 4 + 2 * NT, 1, NT>(
+        K / BK, As, Ws, TILE_KC, TILE_W, acc, w,
+        [&](int kt, auto) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sa[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
+#pragma unroll
+            for (int i = 0; i < 2 * NT; ++i) sw[i] = *reinterpret_cast<const f32x4*>(wp[i] + kt * BK);
         },
-        [&](int buf, auto set) {
-            constexpr int S = decltype(set)::value;
-            stage_store_kc(As + buf * TILE_KC, sa[S]);
-            stage_store_kc(Ws + buf * TILE_KC, sw[S]);
+        [&](int buf, auto) {
+            float* at = As + buf * TILE_KC;
+            float* wt = Ws + buf * TILE_W;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&at[(r0 + 32 * i) * LDK + c4 * 4]) = sa[i];
+#pragma unroll
+            for (int i = 0; i < 2 * NT; ++i) *reinterpret_cast<f32x4*>(&wt[(r0 + 32 * i) * LDK + c4 * 4]) = sw[i];
         });
 
-    // ---- epilogue.  The accumulator layout (one row x 32 columns per register and lane half) would give 64
-    // 4-byte-per-lane stores per wave, and store tails are issue-bound; instead each wave transposes its 64x64 tile
-    // through its own slice of the (now idle) LDS and moves whole 256-B row segments: 16 float4 stores, and 16 float4
-    // residual loads that are issued BEFORE the transpose so their latency hides behind it.
-    constexpr int LDE = 64 + 4;                                   // padded row stride (floats) of the staging tile
+    // ---- epilogue.  The accumulator layout (one row x 32 columns per register and lane half) would give 32 NT
+    // 4-byte-per-lane stores per wave, and store tails are issue-bound; instead each wave transposes its 64 x 32NT tile
+    // through its own slice of the (now idle) LDS and moves whole row segments (256 B / 128 B): 8 NT float4 stores, and
+    // as many float4 residual loads that are issued BEFORE the transpose so their latency hides behind it.
+    constexpr int LDE = Cfg::LDE;
+    constexpr int LPR = 8 * NT;                                   // lanes per staged row (float4 each)
+    constexpr int RPP = 64 / LPR;                                 // rows per pass
+    constexpr int NP = 64 / RPP;                                  // passes
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int er = lane >> 4, ec = (lane & 15) * 4;               // lane -> (row er + 4*i, columns ec..ec+3)
-    const int gm0 = m0 + w.wm * 64, gn = n0 + w.wn * 64 + ec;
-    f32x4 res[16];
+    const int er = lane / LPR, ec = (lane % LPR) * 4;             // lane -> (row er + RPP*i, columns ec..ec+3)
+    const int gm0 = m0 + w.wm * 64, gn = n0 + w.wn * 32 * NT + ec;
+    f32x4 res[NP];
     if (HAS_RES) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = min(gm0 + er + 4 * i, M - 1);
+        for (int i = 0; i < NP; ++i) {
+            const int row = min(gm0 + er + RPP * i, M - 1);
             res[i] = *reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn);
         }
     }
     __syncthreads();                                              // every wave has finished reading operand tiles
     float* stage = smem + wv * (64 * LDE);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int col = n0 + acc_col(w, nt);
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + w.wn * 32 * NT + nt * 32 + w.li;
         const float b = bias ? bias[col] : 0.f;
         const float sc = col < scale_cols ? scale : 1.f;
 #pragma unroll
@@ -93,12 +112,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
             }
     }
     // same-wave LDS write -> read: ordered by the hardware queue, the compiler inserts the lgkmcnt wait
-    // all 16 LDS reads first, then the stores; full tiles (the common case) carry no per-row bounds branch -- hipcc
-    // otherwise sinks each read into its row's branch and serialises read -> wait -> store sixteen times
-    f32x4 ov[16];
+    // all LDS reads first, then the stores; full tiles (the common case) carry no per-row bounds branch -- hipcc
+    // otherwise sinks each read into its row's branch and serialises read -> wait -> store every time
+    f32x4 ov[NP];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int r = er + 4 * i;
+    for (int i = 0; i < NP; ++i) {
+        const int r = er + RPP * i;
         ov[i] = *reinterpret_cast<const f32x4*>(&stage[r * LDE + ec]);
         if (HAS_RES) ov[i] += res[i];
         // f2: q *= 1 - padding_mask (modules.py:767-772): padded tokens get q = 0 (the scaled columns are q)
@@ -106,23 +125,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     }
     if (m0 + BM <= M) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
+        for (int i = 0; i < NP; ++i) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + RPP * i) * ldc + gn) = ov[i];
     } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (gm0 + er + 4 * i < M) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
+        for (int i = 0; i < NP; ++i)
+            if (gm0 + er + RPP * i < M) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + RPP * i) * ldc + gn) = ov[i];
     }
 }
 
-template <int ACT, bool HAS_RES, bool ZROWS = false>
-static int launch_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
-                       int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
-                       const uint8_t* zero_rows, hipStream_t stream) {
+template <int ACT, bool HAS_RES, bool ZROWS, int NT>
+static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
+                          int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
+                          const uint8_t* zero_rows, hipStream_t stream) {
+    using Cfg = GemmCfg<NT>;
     static bool configured = false;
-    auto kern = gemm_f32_kernel<ACT, HAS_RES, ZROWS>;
+    auto kern = gemm_f32_kernel<ACT, HAS_RES, ZROWS, NT>;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured = true;
     }
@@ -130,14 +150,44 @@ static int launch_gemm(const float* A, int64_t lda, const float* W, const float*
     // whole-panel order keeps only 64/nb panels in flight and re-streams W (7-9 MB > the 4 MB L2) for each of them;
     // groups of 8 panels x 8 column blocks halve the fabric reads (PMC, cfg3: QKV 4.9 -> 2.9 GB, fc1 8.0 -> 3.6 GB per
     // launch; same speed, the kernel is MFMA-bound).  N = 768 (6 column blocks) is already balanced and stays ungrouped.
-    const int group = tuning().gemm_group > 0 ? tuning().gemm_group : (N / BN > 8 ? 8 : 1);
-    const unsigned grid = xcd_panel_grid_grouped((M + BM - 1) / BM, N / BN, (unsigned)group);
+    const int nb = N / Cfg::BN_;
+    const int group = tuning().gemm_group > 0 ? tuning().gemm_group : (nb > 8 * (3 - NT) ? 8 : 1);
+    const unsigned grid = xcd_panel_grid_grouped((M + BM - 1) / BM, nb, (unsigned)group);
     // algorithmic work: 2MNK flops; bytes = A + W + C once (+ residual read)
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, A, lda, W, bias, residual, ldr,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), Cfg::LDS_BYTES, stream, A, lda, W, bias, residual, ldr,
                        Cout, ldc, M, N, K, scale, scale_cols, zero_rows, group);
     RNAMSM_CHECK_LAUNCH("gemm_f32");
     return RNAMSM_OK;
+}
+
+// Tile width from a per-CU time model calibrated on the box (tools/gemm_ab.py gemm_tile=1,2 at T = 8192 .. 131072):
+// blocks are dealt evenly, a CU holding b of them runs them two at a time; a co-resident pair costs 2 units of matrix
+// pipe time, a block running alone 1.1 (it nearly saturates the pipe by itself), a half-width block 0.5175 of a full
+// one (3.5 % per-flop penalty).  Half-width tiles are taken when the model gains more than 3 %: e.g. T = 8192, N = 768:
+// 384 full blocks -> 2 per busiest CU = 2.0 units, 768 half blocks -> 3 per CU = 1.6 units (measured 0.101 -> 0.082 ms);
+// cfg3 (exact multiples of 512 blocks) stays on full tiles.
+static inline bool half_width_tiles_win(int M, int N) {
+    const int t = tuning().gemm_tile;
+    if (t == 1) return false;
+    if (t == 2) return true;
+    const long mp = (M + BM - 1) / BM;
+    auto cu_time = [](long blocks) {
+        const long b = (blocks + 255) / 256;
+        return 2.0 * (double)(b / 2) + 1.1 * (double)(b % 2);
+    };
+    return 0.5175 * cu_time(mp * (N / 64)) < 0.97 * cu_time(mp * (N / 128));
+}
+
+template <int ACT, bool HAS_RES, bool ZROWS = false>
+static int launch_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
+                       int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
+                       const uint8_t* zero_rows, hipStream_t stream) {
+    if (!ZROWS && half_width_tiles_win(M, N))
+        return launch_gemm_nt<ACT, HAS_RES, false, 1>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, scale, scale_cols,
+                                                      zero_rows, stream);
+    return launch_gemm_nt<ACT, HAS_RES, ZROWS, 2>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, scale, scale_cols,
+                                                  zero_rows, stream);
 }
 
 }  // namespace rnamsm

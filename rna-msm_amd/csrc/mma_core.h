@@ -63,34 +63,39 @@ __device__ __forceinline__ void mma_ktile(const float* __restrict__ As, const fl
 }
 
 // ---- software-pipelined K loop ----------------------------------------------------------------------------------
-// Fragments of one 8-deep k group: 2 A + 2 B ds_read_b128 (B_KC) per lane.
-struct Frag {
-    f32x4 a[2], b[2];
+// Fragments of one 8-deep k group: 2 A + NT B ds_read_b128 (B_KC) per lane.  NT = MFMA tiles per wave along N:
+// 2 (wave tile 64x64, block tile 128x128) or 1 (wave tile 64x32, block tile 128x64 -- the half-width GEMM tile that
+// evens out the last round of blocks on small problems).
+template <int NT>
+struct FragT {
+    f32x4 a[2], b[NT];
 };
-template <bool B_KC>
+using Frag = FragT<2>;
+template <bool B_KC, int NT>
 __device__ __forceinline__ void frag_load(const float* __restrict__ As, const float* __restrict__ Bs, int kk,
-                                          const WaveCoord& w, Frag& f) {
+                                          const WaveCoord& w, FragT<NT>& f) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
         f.a[mt] = *reinterpret_cast<const f32x4*>(&As[(w.wm * 64 + mt * 32 + w.li) * LDK + kk * 8 + 4 * w.lh]);
     if (B_KC) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-            f.b[nt] = *reinterpret_cast<const f32x4*>(&Bs[(w.wn * 64 + nt * 32 + w.li) * LDK + kk * 8 + 4 * w.lh]);
+        for (int nt = 0; nt < NT; ++nt)
+            f.b[nt] = *reinterpret_cast<const f32x4*>(&Bs[(w.wn * 32 * NT + nt * 32 + w.li) * LDK + kk * 8 + 4 * w.lh]);
     } else {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) f.b[nt][s] = Bs[(kk * 8 + 4 * w.lh + s) * LDN + w.wn * 64 + nt * 32 + w.li];
+            for (int s = 0; s < 4; ++s) f.b[nt][s] = Bs[(kk * 8 + 4 * w.lh + s) * LDN + w.wn * 32 * NT + nt * 32 + w.li];
     }
 }
-__device__ __forceinline__ void frag_mma(const Frag& f, f32x16 (&acc)[2][2]) {
+template <int NT>
+__device__ __forceinline__ void frag_mma(const FragT<NT>& f, f32x16 (&acc)[2][NT]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma32(f.a[mt][s], f.b[nt][s], acc[mt][nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma32(f.a[mt][s], f.b[nt][s], acc[mt][nt]);
 }
 
 // The K loop every tile kernel runs.  `load(kt)` issues the global loads of K tile kt into the caller's staging
@@ -116,50 +121,53 @@ using SetTag = std::integral_constant<int, S>;
 // One K tile.  S = staging register set holding tile kt+1 (and, once stored, reloaded with tile kt+1+DEPTH).
 // STEADY: all three actions happen and the schedule is pinned; otherwise (the last DEPTH+1 tiles) they are runtime
 // flags and the compiler's own order is accepted.
-template <bool B_KC, int NV, int DEPTH, int S, bool STEADY, class LoadFn, class StoreFn>
+template <bool B_KC, int NV, int DEPTH, int S, bool STEADY, int NT, class LoadFn, class StoreFn>
 __device__ __forceinline__ void kstep(int kt, bool do_store, bool do_load, bool do_next, float* As, float* Bs,
-                                      int a_tile, int b_tile, f32x16 (&acc)[2][2], const WaveCoord& w, Frag& f0,
-                                      Frag& f1, LoadFn& load, StoreFn& store) {
-    constexpr int NR = B_KC ? 4 : 10;          // ds_reads per fragment group
+                                      int a_tile, int b_tile, f32x16 (&acc)[2][NT], const WaveCoord& w, FragT<NT>& f0,
+                                      FragT<NT>& f1, LoadFn& load, StoreFn& store) {
+    constexpr int NR = B_KC ? 2 + NT : 2 + 4 * NT;     // ds_reads per fragment group
+    constexpr int NM = 8 * NT;                          // MFMAs per group
+    constexpr int NWR = 4 + 2 * NT;                     // ds_write_b128 per staged tile (A 128 rows + B 64*NT rows)
+    constexpr int LG = (NM - NWR) < 4 ? (NM - NWR) : 4; // MFMA slots of group 0 that carry the global loads
     const int cur = kt & 1, nxt = cur ^ 1;
     const float* Ac = As + cur * a_tile;
     const float* Bc = Bs + cur * b_tile;
     // ---- group 0
-    frag_load<B_KC>(Ac, Bc, 1, w, f1);
+    frag_load<B_KC, NT>(Ac, Bc, 1, w, f1);
     if (STEADY || do_store) store(nxt, SetTag<S>{});
     if (STEADY || do_load) load(kt + 1 + DEPTH, SetTag<S>{});
-    frag_mma(f0, acc);
+    frag_mma<NT>(f0, acc);
     if (STEADY) {
         RNAMSM_SGB(SG_DS_READ, NR);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NWR; ++i) {
             RNAMSM_SGB(SG_MFMA, 1);
             RNAMSM_SGB(SG_DS_WRITE, 1);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < LG; ++i) {
             RNAMSM_SGB(SG_MFMA, 1);
-            RNAMSM_SGB(SG_VMEM_READ, NV / 4);
+            RNAMSM_SGB(SG_VMEM_READ, (NV + LG - 1) / LG);
         }
-        RNAMSM_SGB(SG_MFMA, 4);
+        RNAMSM_SGB(SG_MFMA, NM - NWR - LG);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- group 1
-    frag_load<B_KC>(Ac, Bc, 2, w, f0);
-    frag_mma(f1, acc);
+    frag_load<B_KC, NT>(Ac, Bc, 2, w, f0);
+    frag_mma<NT>(f1, acc);
     RNAMSM_SGB(SG_DS_READ, NR);
-    RNAMSM_SGB(SG_MFMA, 16);
+    RNAMSM_SGB(SG_MFMA, NM);
     __builtin_amdgcn_sched_barrier(0);
     // ---- group 2
-    frag_load<B_KC>(Ac, Bc, 3, w, f1);
-    frag_mma(f0, acc);
+    frag_load<B_KC, NT>(Ac, Bc, 3, w, f1);
+    frag_mma<NT>(f0, acc);
     RNAMSM_SGB(SG_DS_READ, NR);
-    RNAMSM_SGB(SG_MFMA, 16);
+    RNAMSM_SGB(SG_MFMA, NM);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     // ---- group 3
-    if (STEADY || do_next) frag_load<B_KC>(As + nxt * a_tile, Bs + nxt * b_tile, 0, w, f0);
-    frag_mma(f1, acc);
+    if (STEADY || do_next) frag_load<B_KC, NT>(As + nxt * a_tile, Bs + nxt * b_tile, 0, w, f0);
+    frag_mma<NT>(f1, acc);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -168,9 +176,9 @@ __device__ __forceinline__ void kstep(int kt, bool do_store, bool do_load, bool 
 //            (64 MFMAs) of latency cover for first-touch HBM reads at +32 VGPRs.
 // `load(kt, SetTag<S>)` / `store(buf, SetTag<S>)` address the caller's staging registers by a compile-time set index
 // (runtime-indexed register arrays would go to scratch), hence the x2 unrolled loops.
-template <bool B_KC, int NV, int DEPTH, class LoadFn, class StoreFn>
+template <bool B_KC, int NV, int DEPTH, int NT = 2, class LoadFn, class StoreFn>
 __device__ __forceinline__ void pipelined_kloop(int nk, float* As, float* Bs, int a_tile, int b_tile,
-                                                f32x16 (&acc)[2][2], const WaveCoord& w, LoadFn load, StoreFn store) {
+                                                f32x16 (&acc)[2][NT], const WaveCoord& w, LoadFn load, StoreFn store) {
     static_assert(DEPTH == 1 || DEPTH == 2, "prefetch depth");
     constexpr int S_ODD = DEPTH == 2 ? 1 : 0;       // set of odd tiles
     load(0, SetTag<0>{});
@@ -178,20 +186,20 @@ __device__ __forceinline__ void pipelined_kloop(int nk, float* As, float* Bs, in
     if (nk > 1) load(1, SetTag<S_ODD>{});
     if (DEPTH == 2 && nk > 2) load(2, SetTag<0>{});
     __syncthreads();
-    Frag f0, f1;
-    frag_load<B_KC>(As, Bs, 0, w, f0);
+    FragT<NT> f0, f1;
+    frag_load<B_KC, NT>(As, Bs, 0, w, f0);
     int kt = 0;
     for (; kt + 2 + DEPTH < nk; kt += 2) {           // both steps are full: (kt + 1) + 1 + DEPTH < nk
-        kstep<B_KC, NV, DEPTH, S_ODD, true>(kt, true, true, true, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
-        kstep<B_KC, NV, DEPTH, 0, true>(kt + 1, true, true, true, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
+        kstep<B_KC, NV, DEPTH, S_ODD, true, NT>(kt, true, true, true, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
+        kstep<B_KC, NV, DEPTH, 0, true, NT>(kt + 1, true, true, true, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
     }
 #pragma unroll 1
     for (; kt < nk; kt += 2) {                       // kt even: tile kt+1 is odd -> set S_ODD
-        kstep<B_KC, NV, DEPTH, S_ODD, false>(kt, kt + 1 < nk, kt + 1 + DEPTH < nk, kt + 1 < nk, As, Bs, a_tile, b_tile,
-                                             acc, w, f0, f1, load, store);
+        kstep<B_KC, NV, DEPTH, S_ODD, false, NT>(kt, kt + 1 < nk, kt + 1 + DEPTH < nk, kt + 1 < nk, As, Bs, a_tile, b_tile,
+                                                 acc, w, f0, f1, load, store);
         if (kt + 1 < nk)
-            kstep<B_KC, NV, DEPTH, 0, false>(kt + 1, kt + 2 < nk, kt + 2 + DEPTH < nk, kt + 2 < nk, As, Bs, a_tile,
-                                             b_tile, acc, w, f0, f1, load, store);
+            kstep<B_KC, NV, DEPTH, 0, false, NT>(kt + 1, kt + 2 < nk, kt + 2 + DEPTH < nk, kt + 2 < nk, As, Bs, a_tile,
+                                                 b_tile, acc, w, f0, f1, load, store);
     }
 }
 
@@ -206,11 +214,12 @@ __device__ __forceinline__ void stage_store_kc(float* tile, const StageKC& s) {
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&tile[(r0 + 32 * i) * LDK + c4 * 4]) = s.v[i];
 }
 
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NT]) {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
 }

@@ -379,11 +379,12 @@ def test_gemm_block_order_never_changes_results(dev, M, N, K):
     ga, gw, gb = a.to(dev), w.to(dev), b.to(dev)
     try:
         outs = []
-        for g in (0, 1, 3, 8, 64):
+        for g, tile in ((0, 0), (1, 1), (3, 1), (8, 1), (64, 1), (1, 2), (5, 2), (0, 2)):     # tile 1 = 128x128, 2 = 128x64
             _lib.check(lib.rnamsm_set_param(b"gemm_group", g))
+            _lib.check(lib.rnamsm_set_param(b"gemm_tile", tile))
             guard = torch.full((M + 1, N), 7.0, device=dev)                  # one sentinel row behind the output
             ops.linear(ga, gw, gb, out=guard[:M])
-            assert bool((guard[M] == 7.0).all()), g
+            assert bool((guard[M] == 7.0).all()), (g, tile)
             outs.append(guard[:M].clone())
         for o in outs[1:]:
             assert torch.equal(o, outs[0])
@@ -392,3 +393,25 @@ def test_gemm_block_order_never_changes_results(dev, M, N, K):
             _lib.check(lib.rnamsm_set_param(b"gemm_group", 65))
     finally:
         _lib.check(lib.rnamsm_set_param(b"gemm_group", 0))
+        _lib.check(lib.rnamsm_set_param(b"gemm_tile", 0))
+
+
+def test_gemm_half_width_tile_epilogues(dev):
+    """The 128x64 block tile (rnamsm_set_param("gemm_tile", 2); chosen by shape on small problems) with every epilogue:
+    bias, column scale, erf-GELU, residual, ragged M -- bit-identical to the 128x128 tile."""
+    from rnamsm import ops, _lib
+    from rnamsm._lib import ACT_GELU_ERF
+    lib = _lib.load()
+    M, N, K = 333, 384, 160
+    a, w, b, r = _rand("hw.a", (M, K)), _rand("hw.w", (N, K), 0.05), _rand("hw.b", (N,), 0.1), _rand("hw.r", (M, N))
+    try:
+        got = {}
+        for tile in (1, 2):
+            _lib.check(lib.rnamsm_set_param(b"gemm_tile", tile))
+            got[tile] = (ops.linear(a.to(dev), w.to(dev), b.to(dev), act=ACT_GELU_ERF, residual=r.to(dev), scale=0.5, scale_cols=96).cpu(),
+                         ops.linear(a.to(dev), w.to(dev), None, scale=0.25, scale_cols=N).cpu())
+        assert torch.equal(got[1][0], got[2][0]) and torch.equal(got[1][1], got[2][1])
+        want = a.double() @ w.double().t() + b.double(); want[:, :96] *= 0.5
+        assert rel_l2(got[2][0], O.gelu_erf(want) + r.double()) < 3e-6
+    finally:
+        _lib.check(lib.rnamsm_set_param(b"gemm_tile", 0))

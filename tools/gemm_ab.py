@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """In-process interleaved A/B timing of the Linear GEMM shapes of the forward (cfg3: T = 131072) under tuning knobs.
-usage: python tools/gemm_ab.py name=v1,v2,...   e.g.  gemm16_dma=0,1,2 (only knob left; plain timing: gemm16_dma=2,2)"""
+usage: python tools/gemm_ab.py name=v1,v2,...   e.g.  gemm_group=1,8  or  T=8192 python tools/gemm_ab.py gemm_tile=1,2,0"""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd"))
