@@ -99,11 +99,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU path"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Test hooks for exercising the N > 1 control flow on a one-GPU box (never set by the driver): every rank on
+    # device 0 and a gloo process group instead of RCCL (which refuses two ranks on one device).
+    one_device = os.environ.get("RNAMSM_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("RNAMSM_BENCH_BACKEND", "nccl")
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from rnamsm import _lib, synthetic
     from rnamsm.model import MSATransformer
