@@ -232,6 +232,17 @@ def test_padded_ragged_batch_matches_reference_fixture(model):
         assert float(res2["representations"][0][b][toks[b] == 1].abs().max()) == 0.0     # x * (1 - padding_mask)
         assert rel_l2(res2["representations"][10][b].cpu().numpy(), g["rep10"][b]) < 1e-4
         assert np.abs(res2["row_attentions"][b].cpu().numpy() - g["row_attentions"][b]).max() < 1e-4
+    # a padded batch in the f16x3 mode: masked batches keep the exact-fp32 attention kernels and the masked QKV GEMM,
+    # the other Linear layers run split-fp16 on fp32 activations (register-staged kernel) -- same bar
+    try:
+        m.gemm_dtype = "f16x3"
+        res3 = m(toks, repr_layers=[10], need_head_weights=True)
+        for b in range(2):
+            assert rel_l2(res3["representations"][10][b].cpu().numpy(), g["rep10"][b]) < 1e-4
+            assert np.abs(res3["row_attentions"][b].cpu().numpy() - g["row_attentions"][b]).max() < 1e-4
+        assert float(res3["row_attentions"][0, :, :, :, 9].max()) == 0.0
+    finally:
+        m.gemm_dtype = "f32"
 
 
 def test_masked_pseudo_likelihood_matches_oracle(model):
