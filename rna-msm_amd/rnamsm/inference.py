@@ -9,6 +9,9 @@ to rank 0 over RCCL first (`gather_to_rank0=True`).
 from __future__ import annotations
 
 import os
+import queue
+import threading
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import Dict, List, Optional
 
@@ -54,7 +57,60 @@ def crop_tokens(tokens: np.ndarray, max_seqlen: int, rng: np.random.RandomState)
     return np.concatenate([tokens[..., :1], tokens[..., start:start + max_seqlen - 1]], -1)
 
 
-def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_rank0: bool = False) -> List[str]:
+class _AsyncNpyWriter:
+    """Device tensors -> `.npy` files off the critical path: the D2H copy runs on a side stream into pinned buffers and a
+    worker thread waits for it and calls np.save, so the GPU starts the next MSA while this one's 126 MB (L = 512) of maps
+    are still on their way to disk.  At most `depth` MSAs are in flight (bounds the pinned memory).  Files are written
+    in submission order; `close()` drains the queue and re-raises a worker exception."""
+
+    def __init__(self, device: torch.device, depth: int = 2):
+        self._stream = torch.cuda.Stream(device)
+        self._q: "queue.Queue" = queue.Queue(maxsize=depth)
+        self._err: Optional[BaseException] = None
+        self._thread = threading.Thread(target=self._run, name="rnamsm-npy-writer", daemon=True)
+        self._thread.start()
+
+    def _run(self) -> None:
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            event, jobs, done = item
+            try:
+                if self._err is None:
+                    event.synchronize()
+                    for path, host in jobs:
+                        np.save(path, host.numpy())
+                    done()
+            except BaseException as e:                  # noqa: BLE001  (reported by close())
+                self._err = e
+
+    def submit(self, jobs, done) -> None:
+        """jobs: [(path, device tensor)], written in this order; done(): called by the worker after the last file."""
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        staged = []
+        with torch.cuda.stream(self._stream):
+            for path, t in jobs:
+                host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                host.copy_(t, non_blocking=True)
+                t.record_stream(self._stream)           # the allocator must not recycle t before the copy has run
+                staged.append((path, host))
+            event = torch.cuda.Event()
+            event.record(self._stream)
+        self._q.put((event, staged, done))              # blocks when `depth` MSAs are already in flight
+
+    def close(self) -> None:
+        self._q.put(None)
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
+
+
+def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_rank0: bool = False,
+                 async_io: bool = True) -> List[str]:
+    """async_io: read/tokenise the next alignment on a helper thread while the GPU runs the current one, and move the
+    outputs to disk through `_AsyncNpyWriter`; False = the reference's strictly sequential loop (same files)."""
     device = torch.device(cfg.data.device)
     if device.type != "cuda":
         raise RuntimeError("this build runs on the MI355X HIP path only (data.device=cuda); there is no CPU path")
@@ -96,18 +152,35 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
         np.save(save_dir / f"{rna_id}_emb.npy", emb)
         written.append(rna_id)
 
-    with torch.no_grad():
-        for idx in mine:
-            rna_id = ids[idx]
-            tokens = load_msa_tokens(files[rna_id], alphabet, cfg.data.max_seqs_per_msa, cfg.data.sample_method, device=device)
-            tokens = crop_tokens(tokens, cfg.data.max_seqlen, rng)
-            out = model.forward_one(torch.from_numpy(tokens).to(device))
-            if int(out["err"].item()) != 0:
-                raise IndexError(f"{rna_id}: token or position index out of range")
-            if gather_to_rank0 and world > 1:
-                local[idx] = (out["emb"], out["atp"])
-            else:
-                write(rna_id, out["emb"].cpu().numpy(), out["atp"].cpu().numpy())
+    def read(idx: int) -> np.ndarray:
+        return load_msa_tokens(files[ids[idx]], alphabet, cfg.data.max_seqs_per_msa, cfg.data.sample_method, device=device)
+
+    writer = _AsyncNpyWriter(device) if async_io and not (gather_to_rank0 and world > 1) else None
+    reader = ThreadPoolExecutor(1, thread_name_prefix="rnamsm-msa-reader") if async_io else None
+    try:
+        with torch.no_grad():
+            pending = reader.submit(read, mine[0]) if reader and len(mine) else None
+            for n, idx in enumerate(mine):
+                rna_id = ids[idx]
+                tokens = pending.result() if reader else read(idx)
+                if reader and n + 1 < len(mine):
+                    pending = reader.submit(read, mine[n + 1])       # parsed while the GPU runs this MSA
+                tokens = crop_tokens(tokens, cfg.data.max_seqlen, rng)
+                out = model.forward_one(torch.from_numpy(tokens).to(device))
+                if int(out["err"].item()) != 0:
+                    raise IndexError(f"{rna_id}: token or position index out of range")
+                if gather_to_rank0 and world > 1:
+                    local[idx] = (out["emb"], out["atp"])
+                elif writer is not None:
+                    writer.submit([(save_dir / f"{rna_id}_atp.npy", out["atp"]), (save_dir / f"{rna_id}_emb.npy", out["emb"])],
+                                  lambda r=rna_id: written.append(r))
+                else:
+                    write(rna_id, out["emb"].cpu().numpy(), out["atp"].cpu().numpy())
+    finally:
+        if reader is not None:
+            reader.shutdown(wait=True)
+        if writer is not None:
+            writer.close()
     if gather_to_rank0 and world > 1:
         everything = sharding.gather_arrays(local, len(ids), dst=0)
         if rank == 0:

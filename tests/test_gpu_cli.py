@@ -42,3 +42,34 @@ def test_cli_writes_reference_contract_files(tmp_path):
     torch.save({"state_dict": bad}, ckpt)
     with pytest.raises(RuntimeError):
         cli.main([f"data.root_path={tmp_path}", f"data.model_path={ckpt}", "data.sample_method=first"])
+
+
+def test_async_io_pipeline_writes_the_same_files(tmp_path):
+    """extract_feat(async_io=True): alignments are parsed one ahead on a helper thread and the outputs leave through a
+    side-stream D2H copy + writer thread; the files must be byte-identical to the sequential loop's, in the same order."""
+    from rnamsm.config import Config
+    from rnamsm.inference import extract_feat
+    from rnamsm.model import MSATransformer
+    state = synthetic.make_state_dict(seed=0)
+    model = MSATransformer(num_layers=10)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    ids = ["rnaC", "rnaA", "rnaD", "rnaB", "rnaE"]
+    outs = {}
+    for mode in (False, True):
+        root = tmp_path / ("async" if mode else "sync")
+        (root / "results").mkdir(parents=True)
+        for n, i in enumerate(ids):           # different depths so consecutive MSAs differ in shape and content
+            lines = open(os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2")).read().splitlines()
+            (root / "results" / f"{i}.a2m_msa2").write_text("\n".join(lines[: 2 * (8 + 5 * n)]) + "\n")
+        (root / "rna_id.txt").write_text("\n".join(ids) + "\n")
+        cfg = Config()
+        cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = str(root), "results", "rna_id.txt"
+        cfg.data.sample_method, cfg.data.max_seqs_per_msa = "first", 64
+        written = extract_feat(cfg, model=model, async_io=mode)
+        assert written == sorted(ids)
+        outs[mode] = {f.name: f.read_bytes() for f in sorted((root / "results").glob("*.npy"))}
+    assert len(outs[True]) == 2 * len(ids) and outs[True].keys() == outs[False].keys()
+    for name in outs[True]:
+        assert outs[True][name] == outs[False][name], name
+    emb = np.load(tmp_path / "async" / "results" / "rnaA_emb.npy")
+    assert emb.shape == (35, 768) and emb.dtype == np.float32

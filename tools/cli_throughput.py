@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Wall-clock throughput of the CLI loop (rnamsm.inference.extract_feat) on synthetic alignments, sequential vs
+pipelined I/O: N alignments of M sequences x L columns written to a scratch directory, forward in exact fp32."""
+import os, sys, tempfile, time, shutil
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd"))
+import numpy as np, torch
+from rnamsm import synthetic
+from rnamsm.config import Config
+from rnamsm.inference import extract_feat
+from rnamsm.model import MSATransformer
+N, M, L = int(os.environ.get("N", 12)), int(os.environ.get("M", 256)), int(os.environ.get("L", 300))
+state = synthetic.make_state_dict(seed=0)
+model = MSATransformer(num_layers=10)
+model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+rng = np.random.RandomState(0)
+letters = np.array(list("ACGU-"))
+for mode in (False, True, False, True):
+    root = tempfile.mkdtemp(prefix="rnamsm_cli_", dir=os.environ.get("SCRATCH", "/tmp"))
+    os.makedirs(os.path.join(root, "results"))
+    ids = [f"rna{i:03d}" for i in range(N)]
+    for i in ids:
+        rows = letters[rng.randint(0, 5, size=(M, L))]
+        with open(os.path.join(root, "results", f"{i}.a2m_msa2"), "w") as f:
+            for r in range(M):
+                f.write(f">s{r}\n{''.join(rows[r])}\n")
+    open(os.path.join(root, "rna_id.txt"), "w").write("\n".join(ids) + "\n")
+    cfg = Config()
+    cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = root, "results", "rna_id.txt"
+    cfg.data.sample_method, cfg.data.max_seqs_per_msa = "first", M
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    extract_feat(cfg, model=model, async_io=mode)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    nbytes = sum(os.path.getsize(os.path.join(root, "results", f)) for f in os.listdir(os.path.join(root, "results")) if f.endswith(".npy"))
+    print(f"async_io={mode}: {N} MSAs ({M} x {L}) in {dt:.2f} s = {N / dt:.2f} MSA/s, {N * M * L / dt:.0f} residues/s, {nbytes / 1e6:.0f} MB written", flush=True)
+    shutil.rmtree(root)
