@@ -126,6 +126,10 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm_tile = value;
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "row_vt")) {
+        rnamsm::tuning().row_vt = value != 0;
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "attn16")) {
         rnamsm::tuning().attn16 = value;
         return RNAMSM_OK;
@@ -135,6 +139,7 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
 extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "gemm16_dma")) return rnamsm::tuning().gemm16_dma;
     if (name && !strcmp(name, "attn16")) return rnamsm::tuning().attn16;
+    if (name && !strcmp(name, "row_vt")) return rnamsm::tuning().row_vt;
     if (name && !strcmp(name, "gemm_tile")) return rnamsm::tuning().gemm_tile;
     if (name && !strcmp(name, "gemm_group")) return rnamsm::tuning().gemm_group;
     return -1;

@@ -121,14 +121,16 @@ using SetTag = std::integral_constant<int, S>;
 // One K tile.  S = staging register set holding tile kt+1 (and, once stored, reloaded with tile kt+1+DEPTH).
 // STEADY: all three actions happen and the schedule is pinned; otherwise (the last DEPTH+1 tiles) they are runtime
 // flags and the compiler's own order is accepted.
-template <bool B_KC, int NV, int DEPTH, int S, bool STEADY, int NT, class LoadFn, class StoreFn>
+template <bool B_KC, int NV, int DEPTH, int S, bool STEADY, int NT, int NWR_, class LoadFn, class StoreFn>
 __device__ __forceinline__ void kstep(int kt, bool do_store, bool do_load, bool do_next, float* As, float* Bs,
                                       int a_tile, int b_tile, f32x16 (&acc)[2][NT], const WaveCoord& w, FragT<NT>& f0,
                                       FragT<NT>& f1, LoadFn& load, StoreFn& store) {
     constexpr int NR = B_KC ? 2 + NT : 2 + 4 * NT;     // ds_reads per fragment group
     constexpr int NM = 8 * NT;                          // MFMAs per group
-    constexpr int NWR = 4 + 2 * NT;                     // ds_write_b128 per staged tile (A 128 rows + B 64*NT rows)
-    constexpr int LG = (NM - NWR) < 4 ? (NM - NWR) : 4; // MFMA slots of group 0 that carry the global loads
+    constexpr int NWR = NWR_ > 0 ? NWR_ : 4 + 2 * NT;   // LDS writes per staged tile (default: A 128 rows + B 64*NT rows, b128)
+    constexpr int WPS = NWR > NM - 2 ? 2 : 1;           // writes per MFMA slot of group 0
+    constexpr int WSL = (NWR + WPS - 1) / WPS;          // MFMA slots that carry writes
+    constexpr int LG = (NM - WSL) < 4 ? (NM - WSL) : 4; // MFMA slots that carry the global loads
     const int cur = kt & 1, nxt = cur ^ 1;
     const float* Ac = As + cur * a_tile;
     const float* Bc = Bs + cur * b_tile;
@@ -140,16 +142,16 @@ __device__ __forceinline__ void kstep(int kt, bool do_store, bool do_load, bool 
     if (STEADY) {
         RNAMSM_SGB(SG_DS_READ, NR);
 #pragma unroll
-        for (int i = 0; i < NWR; ++i) {
+        for (int i = 0; i < WSL; ++i) {
             RNAMSM_SGB(SG_MFMA, 1);
-            RNAMSM_SGB(SG_DS_WRITE, 1);
+            RNAMSM_SGB(SG_DS_WRITE, WPS);
         }
 #pragma unroll
         for (int i = 0; i < LG; ++i) {
             RNAMSM_SGB(SG_MFMA, 1);
             RNAMSM_SGB(SG_VMEM_READ, (NV + LG - 1) / LG);
         }
-        RNAMSM_SGB(SG_MFMA, NM - NWR - LG);
+        RNAMSM_SGB(SG_MFMA, NM - WSL - LG);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- group 1
@@ -176,7 +178,7 @@ __device__ __forceinline__ void kstep(int kt, bool do_store, bool do_load, bool 
 //            (64 MFMAs) of latency cover for first-touch HBM reads at +32 VGPRs.
 // `load(kt, SetTag<S>)` / `store(buf, SetTag<S>)` address the caller's staging registers by a compile-time set index
 // (runtime-indexed register arrays would go to scratch), hence the x2 unrolled loops.
-template <bool B_KC, int NV, int DEPTH, int NT = 2, class LoadFn, class StoreFn>
+template <bool B_KC, int NV, int DEPTH, int NT = 2, int NWR = 0, class LoadFn, class StoreFn>
 __device__ __forceinline__ void pipelined_kloop(int nk, float* As, float* Bs, int a_tile, int b_tile,
                                                 f32x16 (&acc)[2][NT], const WaveCoord& w, LoadFn load, StoreFn store) {
     static_assert(DEPTH == 1 || DEPTH == 2, "prefetch depth");
@@ -190,15 +192,15 @@ __device__ __forceinline__ void pipelined_kloop(int nk, float* As, float* Bs, in
     frag_load<B_KC, NT>(As, Bs, 0, w, f0);
     int kt = 0;
     for (; kt + 2 + DEPTH < nk; kt += 2) {           // both steps are full: (kt + 1) + 1 + DEPTH < nk
-        kstep<B_KC, NV, DEPTH, S_ODD, true, NT>(kt, true, true, true, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
-        kstep<B_KC, NV, DEPTH, 0, true, NT>(kt + 1, true, true, true, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
+        kstep<B_KC, NV, DEPTH, S_ODD, true, NT, NWR>(kt, true, true, true, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
+        kstep<B_KC, NV, DEPTH, 0, true, NT, NWR>(kt + 1, true, true, true, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
     }
 #pragma unroll 1
     for (; kt < nk; kt += 2) {                       // kt even: tile kt+1 is odd -> set S_ODD
-        kstep<B_KC, NV, DEPTH, S_ODD, false, NT>(kt, kt + 1 < nk, kt + 1 + DEPTH < nk, kt + 1 < nk, As, Bs, a_tile, b_tile,
+        kstep<B_KC, NV, DEPTH, S_ODD, false, NT, NWR>(kt, kt + 1 < nk, kt + 1 + DEPTH < nk, kt + 1 < nk, As, Bs, a_tile, b_tile,
                                                  acc, w, f0, f1, load, store);
         if (kt + 1 < nk)
-            kstep<B_KC, NV, DEPTH, 0, false, NT>(kt + 1, kt + 2 < nk, kt + 2 + DEPTH < nk, kt + 2 < nk, As, Bs, a_tile,
+            kstep<B_KC, NV, DEPTH, 0, false, NT, NWR>(kt + 1, kt + 2 < nk, kt + 2 + DEPTH < nk, kt + 2 < nk, As, Bs, a_tile,
                                                  b_tile, acc, w, f0, f1, load, store);
     }
 }

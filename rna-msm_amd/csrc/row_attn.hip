@@ -22,6 +22,7 @@ namespace rnamsm {
 constexpr int HEAD_DIM = 64;
 constexpr int ROWLOGITS_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;
 constexpr int ROWAPPLY_LDS_BYTES = 2 * (TILE_KC + TILE_NC) * 4;
+constexpr int ROWAPPLY_VT_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;
 
 // ---------------------------------------------------------------------------------------------- K4
 // grid.x = xcd-mapped (panel = (head, split), inner = tiles_i * tiles_j): the 16 tiles of one (head, split) share
@@ -153,13 +154,20 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 // grid.x = xcd-mapped (panel = (head, n tile), inner = tiles_i): the i tiles of one V panel share an L2.
 // ALIGNED: C % 4 == 0 and probs 16-B aligned -> P rows can be read as float4.
 // OUT: 0 = fp32 context; 1 / 2 = bf16 / fp16 hi(+lo) planes, the pre-split A operand of the following out_proj GEMM.
-template <bool ALIGNED, int OUT>
+// VT: the V tile is transposed WHILE it is staged ([n][k], k contiguous, the layout of the GEMM's W tile), so its
+// fragments are ds_read_b128 and the loop is the B_KC one that row_logits and the GEMM run at 90 % matrix-pipe busy;
+// without it the tile stays [k][n] and every fragment costs four ds_read_b32 (70 % busy).  The transpose is free of
+// bank conflicts because the lanes of a wave are mapped key-fastest: lane -> (key = lane/2, 16-B half = lane%2), two
+// lanes fetch one 32-B sector of a V row and write 4 + 4 scalars to LDS rows n..n+3 at column key (each half-wave
+// touches 32 distinct banks).
+template <bool ALIGNED, int OUT, bool VT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
     const float* __restrict__ probs, const float* __restrict__ v, int64_t ld, float* __restrict__ ctx, int64_t ldc,
     int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ps = smem;                    // [2][BM][LDK]
-    float* Vs = smem + 2 * TILE_KC;      // [2][BK][LDN]
+    float* Vs = smem + 2 * TILE_KC;      // [2][BK][LDN], or [2][BN][LDK] when VT
+    constexpr int TILE_V = VT ? TILE_KC : TILE_NC;
 
     const unsigned tiles_i = (C + BM - 1) / BM, tiles_n = (R + 1) / 2;
     unsigned panel, ti;
@@ -171,54 +179,72 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
     // A staging: thread -> (row = tid/8 + 32*s, chunk tid%8) of the [128][32] P tile
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
     // B staging: thread -> (k = tid/32 + 8*s, n4 = tid%32) of the [32][128] V tile; n4 -> (r_local = n4/16, d4 = n4%16)
-    const int bk0 = threadIdx.x >> 5, n4 = threadIdx.x & 31;
+    // VT staging: thread -> key k = lane/2, n chunk q = 2*(4*wave + s) + lane%2 (n = 4q..4q+3; waves 0,1 hold
+    // alignment row rr0, waves 2,3 row rr0+1)
+    const int lane_ = threadIdx.x & 63, wave_ = threadIdx.x >> 6;
+    const int bk0 = VT ? (lane_ >> 1) : (threadIdx.x >> 5), n4 = VT ? (8 * wave_ + (lane_ & 1)) : (threadIdx.x & 31);
     const int br = min(rr0 + (n4 >> 4), R - 1);                      // clamped: second row of an odd R is discarded
     const float* pbase = probs + (int64_t)h * C * C;
-    const float* vbase = v + (int64_t)br * C * ld + h * HEAD_DIM + (n4 & 15) * 4;
+    const float* vbase = v + (int64_t)br * C * ld + h * HEAD_DIM + (n4 & 15) * 4;      // VT: + 8*s floats per slot s
 
     f32x16 acc[2][2];
     zero_acc(acc);
     const int nk = (C + BK - 1) / BK;
 
     f32x4 sp[4], sv[4];
-    // Loads are branch-free (clamped address + select) so the K loop body stays one basic block; keys j >= C are
-    // zero-filled in BOTH operands: they must contribute exactly 0 and clamped data could be NaN.
+    int staged_j0 = 0;                   // first key of the tile sitting in sp / sv
+    // Loads are branch-free (clamped addresses) and NOTHING consumes the loaded values here: the zero-fill of keys
+    // j >= C (they must contribute exactly 0 in BOTH operands, clamped data could be NaN) happens a tile later, when the
+    // registers are written to LDS -- a select at load time would make the wave wait for its own loads immediately
+    // (that was 23 % of the kernel's wave time in s_waitcnt).
     auto load_tiles = [&](int kt, auto) {
         const int j0 = kt * BK;
+        staged_j0 = j0;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int i = min(i0 + r0 + 32 * s, C - 1);
             const int j = j0 + c4 * 4;
             const float* prow = pbase + (int64_t)i * C;
-            f32x4 t;
             if (ALIGNED) {
-                t = *reinterpret_cast<const f32x4*>(prow + min(j, C - 4));
-                if (j >= C) t = f32x4{0.f, 0.f, 0.f, 0.f};
+                sp[s] = *reinterpret_cast<const f32x4*>(prow + min(j, C - 4));
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x = prow[min(j + e, C - 1)];
-                    t[e] = (j + e < C) ? x : 0.f;
-                }
+                for (int e = 0; e < 4; ++e) sp[s][e] = prow[min(j + e, C - 1)];
             }
-            sp[s] = t;
-            const int jj = j0 + bk0 + 8 * s;
-            f32x4 u = *reinterpret_cast<const f32x4*>(vbase + (int64_t)min(jj, C - 1) * ld);
-            if (jj >= C) u = f32x4{0.f, 0.f, 0.f, 0.f};
-            sv[s] = u;
+            const int jj = VT ? j0 + bk0 : j0 + bk0 + 8 * s;
+            sv[s] = *reinterpret_cast<const f32x4*>(vbase + (int64_t)min(jj, C - 1) * ld + (VT ? 8 * s : 0));
         }
     };
     auto store_tiles = [&](int buf, auto) {
         float* pt = Ps + buf * TILE_KC;
-        float* vt = Vs + buf * TILE_NC;
+        float* vt = Vs + buf * TILE_V;
+        const int j = staged_j0 + c4 * 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            *reinterpret_cast<f32x4*>(&pt[(r0 + 32 * s) * LDK + c4 * 4]) = sp[s];
-            *reinterpret_cast<f32x4*>(&vt[(bk0 + 8 * s) * LDN + n4 * 4]) = sv[s];
+            f32x4 t = sp[s];
+            if (ALIGNED) {
+                if (j >= C) t = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = (j + e < C) ? t[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(&pt[(r0 + 32 * s) * LDK + c4 * 4]) = t;
+            const int jj = VT ? staged_j0 + bk0 : staged_j0 + bk0 + 8 * s;
+            f32x4 u = sv[s];
+            if (jj >= C) u = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (VT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vt[((n4 + 2 * s) * 4 + e) * LDK + bk0] = u[e];
+            } else {
+                *reinterpret_cast<f32x4*>(&vt[(bk0 + 8 * s) * LDN + n4 * 4]) = u;
+            }
         }
     };
 
-    pipelined_kloop<false, ALIGNED ? 8 : 20, 1>(nk, Ps, Vs, TILE_KC, TILE_NC, acc, w, load_tiles, store_tiles);
+    if (VT)
+        pipelined_kloop<true, ALIGNED ? 8 : 20, 1, 2, 20>(nk, Ps, Vs, TILE_KC, TILE_V, acc, w, load_tiles, store_tiles);
+    else
+        pipelined_kloop<false, ALIGNED ? 8 : 20, 1>(nk, Ps, Vs, TILE_KC, TILE_V, acc, w, load_tiles, store_tiles);
 
     // The wave's 64 columns are exactly one alignment row (r = rr0 + wn) x 64 head dims, its 64 rows are alignment
     // columns i: the slab leaves as 256-B context segments ctx[(r*C + i), h*64 .. h*64+63] through LDS.
@@ -331,22 +357,28 @@ extern "C" int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, 
     const bool al = C % 4 == 0 && C >= 4 && aligned16(probs);
     const int out = ctx_hi ? 1 + plane_fmt : 0;
     KernelTimer timer(TC_ROW_APPLY, 2.0 * H * C * C * R * HEAD_DIM, 4.0 * (2.0 * R * C * H * HEAD_DIM + (double)H * C * C), s);
-#define RA_GO(AL_, OUT_)                                                                                          \
+#define RA_GO2(AL_, OUT_, VT_)                                                                                    \
     do {                                                                                                          \
         static bool cfg_ = false;                                                                                 \
+        constexpr int lds_ = VT_ ? ROWAPPLY_VT_LDS_BYTES : ROWAPPLY_LDS_BYTES;                                     \
         if (!cfg_) {                                                                                              \
-            int rc = set_lds(row_apply_kernel<AL_, OUT_>, ROWAPPLY_LDS_BYTES, "row_apply");                      \
+            int rc = set_lds(row_apply_kernel<AL_, OUT_, VT_>, lds_, "row_apply");                               \
             if (rc) return rc;                                                                                    \
             cfg_ = true;                                                                                          \
         }                                                                                                         \
-        hipLaunchKernelGGL((row_apply_kernel<AL_, OUT_>), dim3(grid), dim3(GEMM_THREADS), ROWAPPLY_LDS_BYTES, s, probs, \
+        hipLaunchKernelGGL((row_apply_kernel<AL_, OUT_, VT_>), dim3(grid), dim3(GEMM_THREADS), lds_, s, probs,    \
                            v, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo);                                             \
+    } while (0)
+#define RA_GO(AL_, OUT_)                                                                                          \
+    do {                                                                                                          \
+        if (tuning().row_vt) RA_GO2(AL_, OUT_, true); else RA_GO2(AL_, OUT_, false);                              \
     } while (0)
     if (al) {
         if (out == 0) RA_GO(true, 0); else if (out == 1) RA_GO(true, 1); else RA_GO(true, 2);
     } else {
         if (out == 0) RA_GO(false, 0); else if (out == 1) RA_GO(false, 1); else RA_GO(false, 2);
     }
+#undef RA_GO2
 #undef RA_GO
     RNAMSM_CHECK_LAUNCH("row_apply");
     return RNAMSM_OK;
