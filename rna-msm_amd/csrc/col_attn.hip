@@ -67,15 +67,12 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
     auto load_chunk = [&](int ch) {
 #pragma unroll
         for (int s = 0; s < NST; ++s) {
-            const int j = ch * CA_JC + jr + JSTEP * s;
-            if (j < R) {
-                const int64_t off = (int64_t)j * C * ld + col_off + d4 * 4;
-                sk[s] = *reinterpret_cast<const f32x4*>(k + off);
-                sv[s] = *reinterpret_cast<const f32x4*>(v + off);
-            } else {                                         // keys past R: zero (scores are masked, V must be finite)
-                sk[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-                sv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            // keys past R are clamped to the last key (branch-free): their scores are masked to -inf and their
+            // (finite) values only ever meet P = 0
+            const int j = min(ch * CA_JC + jr + JSTEP * s, R - 1);
+            const int64_t off = (int64_t)j * C * ld + col_off + d4 * 4;
+            sk[s] = *reinterpret_cast<const f32x4*>(k + off);
+            sv[s] = *reinterpret_cast<const f32x4*>(v + off);
         }
     };
     auto store_chunk = [&](int buf) {
