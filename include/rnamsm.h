@@ -150,6 +150,11 @@ int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_
 /* Scaling is applied to fp32 accumulators, never to 16-bit operands (a q scaled by ~1e-2 or a probability ~1e-3 would
  * push its fp16 lo plane into subnormals): q arrives UNSCALED and `scale` multiplies the logits; P planes hold
  * P * plane_scale (a power of two, 4096 in rnamsm_forward) and out_scale = 1 / plane_scale undoes it. */
+/* Row split of rnamsm_row_logits16 for split = 1 (hi planes only) or 3 (hi/lo pairs); it may differ from
+ * rnamsm_row_logits_nsplit (large C in the hi/lo modes uses a 256x256 tile with its own split), and the size of a
+ * partial buffer that fits either tiling. */
+int rnamsm_row_logits16_nsplit(int R, int C, int H, int split);
+size_t rnamsm_row_logits16_workspace_bytes(int R, int C, int H);
 int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
                         int64_t ld, float* partial, int R, int C, int H, int head_dim, float scale, int fmt,
                         void* stream);

@@ -29,7 +29,10 @@ Layout make_layout(const rnamsm_model_dims& d, int R, int C) {
     l.x = off;    off += align256(T * D * 4);
     l.xn = off;   off += align256(T * D * 4);
     l.wide = off; off += align256(T * (size_t)(3 * D + D > (size_t)d.ffn_dim ? 4 * D : d.ffn_dim) * 4);
-    l.part = off; off += align256(rnamsm_row_logits_workspace_bytes(R, C, d.num_heads));
+    {
+        const size_t a = rnamsm_row_logits_workspace_bytes(R, C, d.num_heads), b = rnamsm_row_logits16_workspace_bytes(R, C, d.num_heads);
+        l.part = off; off += align256(a > b ? a : b);
+    }
     l.mask = off; off += align256(T);
     l.pplanes = off; off += align256((size_t)d.num_heads * C * (size_t)((C + 63) / 64 * 64) * 4);   // P hi + lo planes (K5' -> K6')
     l.total = off;
@@ -145,7 +148,8 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
                           RNAMSM_ACT_NONE, 1.f, 0));
             FWD(rnamsm_row_logits16(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), ldq, part, R, C, H, 64, row_scale, fmt, stream));
-            FWD(rnamsm_softmax_rows_planes(part, nsplit, probs, p_hi, p_lo, ldp, 4096.f, H, C, nullptr, fmt, stream));
+            FWD(rnamsm_softmax_rows_planes(part, rnamsm_row_logits16_nsplit(R, C, H, split), probs, p_hi, p_lo, ldp, 4096.f, H, C,
+                                           nullptr, fmt, stream));
             FWD(rnamsm_row_apply16(p_hi, p_lo, ldp, qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C, H, 64, 1.f / 4096.f,
                                    ctx_hi, ctx_lo, fmt, stream));
         } else {

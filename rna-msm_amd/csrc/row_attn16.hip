@@ -243,6 +243,311 @@ __global__ __launch_bounds__(R16_THREADS, SPLIT == 3 ? 1 : 2) void row_apply16_k
     slab_store_64x64<OUT>(acc, reinterpret_cast<float*>(smem_b) + wv * (64 * 68), li, lh, lane, rowoff, ctx, ctx_hi, ctx_lo);
 }
 
+// ---------------------------------------------------------------------------------------------- K4' (large C)
+// 256x256 tile version of row_logits16 for C >= 256 (half the operand bytes per flop, see K6' (large C) below): both
+// operands are "k" tiles with 64-B rows, K tile = half of one alignment row's head dims (32 of 64), i.e. exactly the
+// loop of gemm16_swp_kernel with q / k planes for A / W.  One block per CU, so the row split is chosen for 256 slots.
+constexpr int R16L_PLANE = 256 * 64;               // [256 rows][32 halves] = 16 KB
+template <int SPLIT>
+struct R16LCfg {
+    static constexpr int NPL = SPLIT == 3 ? 2 : 1;
+    static constexpr int BUF = 2 * NPL * R16L_PLANE;
+    static constexpr int LDS = 2 * BUF;
+};
+template <int SPLIT, int FMT>
+struct R16LFrag {
+    typename Half16<FMT>::V8 a[SPLIT == 3 ? 2 : 1][4], b[SPLIT == 3 ? 2 : 1][2];
+};
+
+template <int SPLIT, int FMT>
+__global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
+    const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
+    const uint16_t* __restrict__ klo, int64_t ld, float* __restrict__ partial, int R, int C, int H, int nsplit,
+    int rows_per_split, float scale) {
+    using Cfg = R16LCfg<SPLIT>;
+    constexpr int NPL = Cfg::NPL;
+    constexpr int NMF = 8 * (SPLIT == 3 ? 3 : 1);
+    constexpr int NDS = 6 * NPL;
+    typedef typename Half16<FMT>::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+
+    const unsigned tiles_c = (C + 255) / 256;
+    unsigned panel, tile;
+    if (!xcd_panel_map(blockIdx.x, (unsigned)(H * nsplit), tiles_c * tiles_c, panel, tile)) return;
+    const int h = panel / nsplit, split = panel % nsplit;
+    const int i0 = (tile / tiles_c) * 256, j0 = (tile % tiles_c) * 256;
+    const int r_begin = split * rows_per_split;
+    const int r_end = min(R, r_begin + rows_per_split);
+
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv >> 2, wn = wv & 3, li = lane & 31, lh = lane >> 5;
+
+    const int dchunk = (lane & 3) ^ ((lane >> 4) & 3);
+    int64_t qoff[2], koff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 16 * (wv + 8 * j) + (lane >> 2);
+        qoff[j] = (int64_t)min(i0 + row, C - 1) * ld + h * 64 + dchunk * 8;     // clamped columns feed discarded outputs
+        koff[j] = (int64_t)min(j0 + row, C - 1) * ld + h * 64 + dchunk * 8;
+    }
+    auto issue = [&](int kt, int buf) {                      // K tile kt = (alignment row r_begin + kt/2, d half kt&1)
+        char* base = smem_b + buf * Cfg::BUF;
+        const int64_t rb = (int64_t)(r_begin + (kt >> 1)) * C * ld + (kt & 1) * 32;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int loff = (16 * (wv + 8 * j)) * 64;
+            dma16(qhi + rb + qoff[j], base + loff);
+            if (SPLIT == 3) dma16(qlo + rb + qoff[j], base + R16L_PLANE + loff);
+            dma16(khi + rb + koff[j], base + NPL * R16L_PLANE + loff);
+            if (SPLIT == 3) dma16(klo + rb + koff[j], base + (NPL + 1) * R16L_PLANE + loff);
+        }
+    };
+    auto frag_load = [&](const char* buf, int kk, R16LFrag<SPLIT, FMT>& f) {
+        const int chunk = ((2 * kk + lh) ^ ((li >> 2) & 3)) * 16;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                f.a[p][t] = *reinterpret_cast<const V8*>(buf + p * R16L_PLANE + (wm * 128 + t * 32 + li) * 64 + chunk);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                f.b[p][t] = *reinterpret_cast<const V8*>(buf + (NPL + p) * R16L_PLANE + (wn * 64 + t * 32 + li) * 64 + chunk);
+        }
+    };
+    auto frag_mma = [&](const R16LFrag<SPLIT, FMT>& f, f32x16 (&acc)[4][2]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (SPLIT == 3) {
+                    acc[mt][nt] = Half16<FMT>::mfma(f.a[1][mt], f.b[0][nt], acc[mt][nt]);
+                    acc[mt][nt] = Half16<FMT>::mfma(f.a[0][mt], f.b[1][nt], acc[mt][nt]);
+                }
+                acc[mt][nt] = Half16<FMT>::mfma(f.a[0][mt], f.b[0][nt], acc[mt][nt]);
+            }
+    };
+    auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < NDS; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - NDS, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
+
+    const int nk = 2 * (r_end - r_begin);
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    issue(1, 1);                                             // nk >= 2 always
+    R16LFrag<SPLIT, FMT> f0, f1;
+    frag_load(smem_b, 0, f0);
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const char* cur = smem_b + (kt & 1) * Cfg::BUF;
+        const char* nxt = smem_b + ((kt & 1) ^ 1) * Cfg::BUF;
+        frag_load(cur, 1, f1);
+        frag_mma(f0, acc);
+        interleave();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue(kt + 2 < nk ? kt + 2 : nk - 1, kt & 1);        // clamped: the last reload is never read
+        __builtin_amdgcn_sched_barrier(0);
+        frag_load(nxt, 0, f0);
+        frag_mma(f1, acc);
+        interleave();
+    }
+    {
+        const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
+        frag_load(cur, 1, f1);
+        frag_mma(f0, acc);
+        interleave();
+        frag_mma(f1, acc);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the clamped reload has landed before the block exits
+
+    float* out = partial + ((int64_t)split * H + h) * C * C;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int j = j0 + wn * 64 + nt * 32 + li;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int i = i0 + wm * 128 + mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                if (i < C && j < C) out[(int64_t)i * C + j] = acc[mt][nt][t] * scale;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- K6' (large C)
+// 256x256 tile version of row_apply16 for C >= 256: M = 256 alignment columns i, N = 4 alignment rows x 64 head dims,
+// K tile = 32 keys.  Per flop it moves half the operand bytes of the 128x128 kernel above -- the 16-bit kernels lose
+// matrix-pipe time in proportion to the bytes they pull into the CU, so the tile size is the lever.
+// 8 waves as 2 (M) x 4 (N): wave tile 128 x 64 = one alignment row; the loop is gemm16_swp_kernel's (two fragment sets,
+// one LDS read per MFMA, barrier in the middle of a tile), with the B fragments coming from "t" tiles by transposed read.
+constexpr int R16X_THREADS = 512;
+constexpr int R16X_PA = 256 * 64;                  // A plane tile: [256 rows i][32 keys] = 16 KB
+constexpr int R16X_PB = 4 * 32 * T16_ROWB;         // B plane tile: [4 rows r][32 keys][64 d] = 16 KB
+template <int SPLIT>
+struct R16XCfg {
+    static constexpr int NPL = SPLIT == 3 ? 2 : 1;
+    static constexpr int BUF = NPL * (R16X_PA + R16X_PB);
+    static constexpr int EPI = 8 * 64 * 68 * 4;
+    static constexpr int LDS = 2 * BUF > EPI ? 2 * BUF : EPI;
+};
+template <int SPLIT, int FMT>
+struct R16XFrag {
+    typename Half16<FMT>::V8 a[SPLIT == 3 ? 2 : 1][4], b[SPLIT == 3 ? 2 : 1][2];
+};
+
+template <int SPLIT, int FMT, int OUT>
+__global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
+    const uint16_t* __restrict__ phi, const uint16_t* __restrict__ plo, int64_t ldp, const uint16_t* __restrict__ vhi,
+    const uint16_t* __restrict__ vlo, int64_t ld, float* __restrict__ ctx, int64_t ldc, int R, int C, int H,
+    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, float out_scale) {
+    using Cfg = R16XCfg<SPLIT>;
+    constexpr int NPL = Cfg::NPL;
+    constexpr int NMF = 8 * (SPLIT == 3 ? 3 : 1);          // MFMAs per k step per wave
+    constexpr int NDS = 8 * NPL;                           // LDS reads per k step per wave (4 b128 + 4 tr per plane)
+    typedef typename Half16<FMT>::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+
+    const unsigned tiles_i = (C + 255) / 256, tiles_n = (R + 3) / 4;
+    unsigned panel, ti;
+    if (!xcd_panel_map(blockIdx.x, (unsigned)H * tiles_n, tiles_i, panel, ti)) return;
+    const int h = panel / tiles_n, rr0 = (panel % tiles_n) * 4;
+    const int i0 = ti * 256;
+
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv >> 2, wn = wv & 3, li = lane & 31, lh = lane >> 5;
+
+    // DMA maps.  A (64-B rows): wave w moves row groups w and w+8 (16 rows each), lane -> (row 16g + lane/4, physical
+    // chunk lane%4) fetching logical chunk (lane%4) ^ ((row>>2)&3).  B (128-B rows, rows = r_local*32 + key): row groups
+    // w and w+8 (8 rows each), lane -> (row 8g + lane/8, physical chunk lane%8) fetching (lane%8) ^ swz_t(row).
+    const int ca = (lane & 3) ^ ((lane >> 4) & 3), ct = dma_chunk_t(lane);
+    int64_t poff[2], voff[2];
+    int vkey[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rowa = 16 * (wv + 8 * j) + (lane >> 2);
+        poff[j] = ((int64_t)h * C + min(i0 + rowa, C - 1)) * ldp + ca * 8;
+        const int rowb = 8 * (wv + 8 * j) + (lane >> 3);
+        const int r = min(rr0 + (rowb >> 5), R - 1);                   // rows past R are discarded at the store
+        voff[j] = (int64_t)r * C * ld + h * 64 + ct * 8;
+        vkey[j] = rowb & 31;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* base = smem_b + buf * Cfg::BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int la = (16 * (wv + 8 * j)) * 64, lb = (8 * (wv + 8 * j)) * T16_ROWB;
+            // keys past C: P is zero-padded there, V is clamped (finite) -> contributes exactly 0
+            const int64_t vo = voff[j] + (int64_t)min(kt * 32 + vkey[j], C - 1) * ld;
+            dma16(phi + poff[j] + kt * 32, base + la);
+            if (SPLIT == 3) dma16(plo + poff[j] + kt * 32, base + R16X_PA + la);
+            dma16(vhi + vo, base + NPL * R16X_PA + lb);
+            if (SPLIT == 3) dma16(vlo + vo, base + NPL * R16X_PA + R16X_PB + lb);
+        }
+    };
+    const int tq = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);    // transposed-read geometry
+    auto frag_load = [&](const char* buf, int kk, R16XFrag<SPLIT, FMT>& f) {
+        const int chunk = ((2 * kk + lh) ^ ((li >> 2) & 3)) * 16;
+        const int ka = 16 * kk + 8 * lh + tq;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                f.a[p][t] = *reinterpret_cast<const V8*>(buf + p * R16X_PA + (wm * 128 + t * 32 + li) * 64 + chunk);
+            const char* bt = buf + NPL * R16X_PA + p * R16X_PB + wn * 32 * T16_ROWB;    // this wave's alignment row
+#pragma unroll
+            for (int t = 0; t < 2; ++t) f.b[p][t] = frag_t<FMT>(bt, ka, ka + 4, t * 32 + tcol);
+        }
+    };
+    auto frag_mma = [&](const R16XFrag<SPLIT, FMT>& f, f32x16 (&acc)[4][2]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                if (SPLIT == 3) {
+                    acc[mt][nt] = Half16<FMT>::mfma(f.a[1][mt], f.b[0][nt], acc[mt][nt]);
+                    acc[mt][nt] = Half16<FMT>::mfma(f.a[0][mt], f.b[1][nt], acc[mt][nt]);
+                }
+                acc[mt][nt] = Half16<FMT>::mfma(f.a[0][mt], f.b[0][nt], acc[mt][nt]);
+            }
+    };
+    auto interleave = [&]() {
+#pragma unroll
+        for (int i = 0; i < (NDS < NMF ? NDS : NMF); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NDS > NMF ? 2 : 1, 0);
+        }
+        if (NMF > NDS) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NDS, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
+
+    const int nk = (C + 31) / 32;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    issue(nk > 1 ? 1 : 0, 1);
+    R16XFrag<SPLIT, FMT> f0, f1;
+    frag_load(smem_b, 0, f0);
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const char* cur = smem_b + (kt & 1) * Cfg::BUF;
+        const char* nxt = smem_b + ((kt & 1) ^ 1) * Cfg::BUF;
+        frag_load(cur, 1, f1);
+        frag_mma(f0, acc);
+        interleave();
+        // every wave is done reading `cur` once its f1 has arrived; tile kt+1 (issued one tile ago) must have landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        issue(kt + 2 < nk ? kt + 2 : nk - 1, kt & 1);              // clamped: the last reload is never read
+        __builtin_amdgcn_sched_barrier(0);
+        frag_load(nxt, 0, f0);
+        frag_mma(f1, acc);
+        interleave();
+    }
+    {
+        const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
+        frag_load(cur, 1, f1);
+        frag_mma(f0, acc);
+        interleave();
+        frag_mma(f1, acc);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is free for the epilogue staging
+
+    const int r = rr0 + wn;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        f32x16 (&a2)[2][2] = reinterpret_cast<f32x16(&)[2][2]>(acc[2 * p]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) a2[mt][nt][t] *= out_scale;
+        const int ibase = i0 + wm * 128 + p * 64;
+        auto rowoff = [&](int row) -> int64_t {
+            const int i = ibase + row;
+            return (r < R && i < C) ? ((int64_t)r * C + i) * ldc + h * 64 : (int64_t)-1;
+        };
+        slab_store_64x64<OUT>(a2, reinterpret_cast<float*>(smem_b) + wv * (64 * 68), li, lh, lane, rowoff, ctx, ctx_hi, ctx_lo);
+    }
+}
+
 template <typename K>
 static int set_lds16(K kern, int bytes, const char* name) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -256,6 +561,23 @@ using namespace rnamsm;
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// The 256x256 kernel (and the 256-slot row split that goes with it) is used for C >= 256 in the hi/lo modes: measured at
+// cfg3 in one process, split 3 0.40 -> 0.34 ms, but plain bf16 0.166 -> 0.185 ms (its 128x128 kernel already runs
+// 64-deep tiles of whole cache lines with two blocks per CU), so split 1 stays on 128x128.  "attn16" = 2 forces 128x128.
+static inline bool row_logits16_big(int C, bool split3) { return split3 && C >= 256 && tuning().attn16 != 2; }
+
+extern "C" int rnamsm_row_logits16_nsplit(int R, int C, int H, int split) {
+    if (R <= 0 || C <= 0 || H <= 0) return 0;
+    return (row_logits16_big(C, split == 3) ? choose_row_split(R, C, H, 256, 256) : choose_row_split(R, C, H)).nsplit;
+}
+
+extern "C" size_t rnamsm_row_logits16_workspace_bytes(int R, int C, int H) {
+    if (R <= 0 || C <= 0 || H <= 0) return 0;
+    // the larger of the two tilings, so a workspace stays valid when the "attn16" knob flips
+    const int a = choose_row_split(R, C, H, 256, 256).nsplit, b = choose_row_split(R, C, H).nsplit;
+    return (size_t)(a > b ? a : b) * H * C * C * sizeof(float);
+}
+
 extern "C" int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
                                    int64_t ld, float* partial, int R, int C, int H, int head_dim, float scale, int fmt,
                                    void* stream) {
@@ -267,13 +589,25 @@ extern "C" int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, c
     RNAMSM_CHECK_ARG(ld >= (int64_t)H * 64 && ld % 8 == 0 && al16(q_hi) && al16(k_hi) && al16(q_lo) && al16(k_lo),
                      "row_logits16: planes must be 16-byte aligned with ld %% 8 == 0");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const RowSplit sp = choose_row_split(R, C, H);
-    const unsigned tiles_c = (C + 127) / 128;
+    const bool big = row_logits16_big(C, q_lo != nullptr);
+    const RowSplit sp = big ? choose_row_split(R, C, H, 256, 256) : choose_row_split(R, C, H);
+    const unsigned tiles_c = big ? (C + 255) / 256 : (C + 127) / 128;
     const unsigned grid = xcd_panel_grid((unsigned)(H * sp.nsplit), tiles_c * tiles_c);
     KernelTimer timer(TC_ROW_LOGITS, 2.0 * H * C * C * R * 64,
                       (q_lo ? 4.0 : 2.0) * 2.0 * R * C * H * 64 + 4.0 * (double)sp.nsplit * H * C * C, s);
 #define RL_GO(SP_, FMT_)                                                                                            \
     do {                                                                                                            \
+        if (big) {                                                                                                  \
+            static bool cfgx_ = false;                                                                              \
+            if (!cfgx_) {                                                                                           \
+                int rc = set_lds16(row_logits16x_kernel<SP_, FMT_>, R16LCfg<SP_>::LDS, "row_logits16x");           \
+                if (rc) return rc;                                                                                  \
+                cfgx_ = true;                                                                                       \
+            }                                                                                                       \
+            hipLaunchKernelGGL((row_logits16x_kernel<SP_, FMT_>), dim3(grid), dim3(512), R16LCfg<SP_>::LDS, s, q_hi, q_lo,  \
+                               k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale);              \
+            break;                                                                                                  \
+        }                                                                                                           \
         static bool cfg_ = false;                                                                                   \
         if (!cfg_) {                                                                                                \
             int rc = set_lds16(row_logits16_kernel<SP_, FMT_>, R16Cfg<SP_>::LDS, "row_logits16");                  \
@@ -306,12 +640,24 @@ extern "C" int rnamsm_row_apply16(const uint16_t* p_hi, const uint16_t* p_lo, in
     RNAMSM_CHECK_ARG(ldc >= (int64_t)H * 64 && ldc % 4 == 0 && (ctx_hi ? (reinterpret_cast<uintptr_t>(ctx_hi) & 7u) == 0 : al16(ctx)),
                      "row_apply16: output alignment");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const unsigned tiles_i = (C + 127) / 128, tiles_n = (R + 1) / 2;
+    const bool big = C >= 256 && R >= 4 && tuning().attn16 != 2;      // 256x256 tiles ("attn16" = 2 forces 128x128: A/B)
+    const unsigned tiles_i = big ? (C + 255) / 256 : (C + 127) / 128, tiles_n = big ? (R + 3) / 4 : (R + 1) / 2;
     const unsigned grid = xcd_panel_grid((unsigned)H * tiles_n, tiles_i);
     KernelTimer timer(TC_ROW_APPLY, 2.0 * H * C * C * R * 64,
                       (p_lo ? 4.0 : 2.0) * ((double)R * C * H * 64 + (double)H * C * ldp) + 4.0 * R * C * H * 64, s);
 #define RA_GO(SP_, FMT_, OUT_)                                                                                      \
     do {                                                                                                            \
+        if (big) {                                                                                                  \
+            static bool cfgx_ = false;                                                                              \
+            if (!cfgx_) {                                                                                           \
+                int rc = set_lds16(row_apply16x_kernel<SP_, FMT_, OUT_>, R16XCfg<SP_>::LDS, "row_apply16x");       \
+                if (rc) return rc;                                                                                  \
+                cfgx_ = true;                                                                                       \
+            }                                                                                                       \
+            hipLaunchKernelGGL((row_apply16x_kernel<SP_, FMT_, OUT_>), dim3(grid), dim3(R16X_THREADS), R16XCfg<SP_>::LDS, \
+                               s, p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale);   \
+            break;                                                                                                  \
+        }                                                                                                           \
         static bool cfg_ = false;                                                                                   \
         if (!cfg_) {                                                                                                \
             int rc = set_lds16(row_apply16_kernel<SP_, FMT_, OUT_>, R16Cfg<SP_>::LDS, "row_apply16");              \

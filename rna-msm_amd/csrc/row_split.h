@@ -10,9 +10,10 @@ struct RowSplit {
 
 // Deterministic function of the shape only.  Picks the split count whose block count best fills
 // 256 CUs x 2 resident blocks, subject to >= 4 rows (8 K tiles) per split.
-inline RowSplit choose_row_split(int R, int C, int H) {
-    const long tiles = (long)((C + 127) / 128) * ((C + 127) / 128) * H;
-    const int slots = 512;
+// tile / slots: output tile edge and resident block slots of the kernel that consumes the split (128 / 512 for the
+// 128x128 kernels with two blocks per CU, 256 / 256 for the 256x256 16-bit kernel with one).
+inline RowSplit choose_row_split(int R, int C, int H, int tile = 128, int slots = 512) {
+    const long tiles = (long)((C + tile - 1) / tile) * ((C + tile - 1) / tile) * H;
     int best_ns = 1;
     double best_score = -1.0;
     const int max_ns = R / 4 > 1 ? (R / 4 < 64 ? R / 4 : 64) : 1;

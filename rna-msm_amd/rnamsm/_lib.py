@@ -54,6 +54,8 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rnamsm_col_attn_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                       c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "rnamsm_row_logits16_nsplit": (c_int, [c_int, c_int, c_int, c_int]),
+    "rnamsm_row_logits16_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rnamsm_row_logits16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int,
                                     c_float, c_int, c_void_p]),
     "rnamsm_softmax_rows_planes": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_int, c_int,

@@ -166,7 +166,7 @@ def row_logits16(q, k, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0)
     """q, k: (hi, lo) plane views [R*C, *] with row stride ld (halves); returns (partial [nsplit,H,C,C] fp32, nsplit);
     scale multiplies the fp32 logits (q is expected UNSCALED)."""
     lib = _lib.load()
-    nsplit = lib.rnamsm_row_logits_nsplit(R, C, H)
+    nsplit = lib.rnamsm_row_logits16_nsplit(R, C, H, 1 if q[1] is None else 3)
     partial = torch.empty(nsplit, H, C, C, device=q[0].device, dtype=torch.float32)
     ld = _rowmajor(q[0], "q_hi")
     _lib.check(lib.rnamsm_row_logits16(_pl(q[0], "q_hi"), _pl(q[1], "q_lo"), _pl(k[0], "k_hi"), _pl(k[1], "k_lo"), ld,

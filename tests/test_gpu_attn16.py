@@ -17,7 +17,9 @@ from rnamsm import synthetic
 
 pytestmark = pytest.mark.gpu
 
-ATT_SHAPES = [(1, 5, 2), (7, 33, 2), (34, 66, 2), (6, 19, 12), (3, 130, 2), (65, 40, 2), (257, 9, 2), (300, 20, 1), (16, 200, 3)]
+# C >= 256 (with R >= 4) takes the 256x256-tile row kernels: ragged both ways, R not a multiple of 4, C = 256 exactly
+ATT_SHAPES = [(1, 5, 2), (7, 33, 2), (34, 66, 2), (6, 19, 12), (3, 130, 2), (65, 40, 2), (257, 9, 2), (300, 20, 1), (16, 200, 3),
+              (8, 300, 2), (5, 520, 1), (9, 257, 2), (4, 256, 1), (3, 300, 1)]
 # (split, fmt, tolerance vs eff operands, tolerance vs fp32 operands)
 MODES = [(1, 0, 2e-6, 8e-3), (3, 0, 4e-5, 4e-5), (3, 1, 3e-6, 3e-6)]
 
@@ -90,13 +92,14 @@ def test_row_attention_16bit(dev, R, C, H, split, fmt, tol_eff, tol_f32):
     assert rel_l2(ctx, torch.einsum("hij,rjhd->rihd", want_p, v).reshape(R * C, D)) < tol_f32
 
 
+@pytest.mark.parametrize("R,C", [(5, 150), (6, 300)])
 @pytest.mark.parametrize("split,fmt", [(1, 0), (3, 0), (3, 1)])
-def test_row_kernels_16bit_are_exact_on_integers(dev, split, fmt):
+def test_row_kernels_16bit_are_exact_on_integers(dev, split, fmt, R, C):
     """Small integers are exact in bf16 and fp16 (lo planes = 0) and every partial sum is exact in fp32: the result must
     equal the integer contraction bit for bit.  The data are asymmetric in every index, so a transposed tile, a swapped
     k order inside a fragment or a wrong swizzle cannot cancel."""
     from rnamsm import ops
-    R, C, H = 5, 150, 2
+    H = 2
     D = 64 * H
     n = R * C * 3 * D
     qkv = torch.from_numpy((((np.arange(n, dtype=np.int64) * 7 + (np.arange(n, dtype=np.int64) // 191) * 3) % 13) - 6)

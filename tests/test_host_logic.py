@@ -169,7 +169,11 @@ def test_library_validates_arguments_without_a_gpu(lib):
     import ctypes
     need = lib.rnamsm_forward_workspace_bytes(ctypes.byref(dims), 256, 512)
     T = 256 * 512
-    assert need >= T * 768 * 4 * 6 + 8 * 12 * 512 * 512 * 4 + T and need < T * 768 * 4 * 6.5
+    assert lib.rnamsm_row_logits16_nsplit(256, 512, 12, 3) == 16    # 256x256 tiles, one block per CU: 12 * 16 * 4 = 3 rounds
+    assert lib.rnamsm_row_logits16_nsplit(256, 512, 12, 1) == 8     # plain bf16 stays on the 128x128 kernel
+    assert lib.rnamsm_row_logits16_nsplit(256, 100, 12, 3) == lib.rnamsm_row_logits_nsplit(256, 100, 12)   # small C: 128x128 tiles
+    assert lib.rnamsm_row_logits16_workspace_bytes(256, 512, 12) == 16 * 12 * 512 * 512 * 4
+    assert need >= T * 768 * 4 * 6 + 16 * 12 * 512 * 512 * 4 + T and need < T * 768 * 4 * 6.6
     rc = lib.rnamsm_gemm_bias_act_res(None, 0, None, None, None, 0, None, 0, 4, 128, 32, 0, 1.0, 0, None, 0, None)
     assert rc == -1 and b"null pointer" in lib.rnamsm_last_error()
     rc = lib.rnamsm_gemm_bias_act_res(16, 32, 16, None, None, 0, 16, 100, 4, 100, 32, 0, 1.0, 0, None, 0, None)
