@@ -273,3 +273,24 @@ def test_masked_pseudo_likelihood_matches_oracle(model):
     ref_sc = lp - lp[torch.arange(3), toks[0, idx]].unsqueeze(1)
     assert np.abs(sc.numpy() - ref_sc.numpy()).max() < 2e-4
     assert float(sc[torch.arange(3), toks[0, idx]].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("R,C", [(3, 2), (5, 260), (70, 7), (9, 300), (2, 129), (37, 64), (17, 257)])
+def test_forward_shape_sweep_against_oracle_all_fp32_grade_modes(model, R, C):
+    """Shapes chosen to cross every kernel-selection threshold with ragged edges: C = 2 (the minimum), C >= 256 (256x256
+    row kernels of the 16-bit modes), tiny and odd R (a lone alignment row in a 2- or 4-row block), T = R*C small enough
+    for the half-width GEMM tile and the 128x128 16-bit GEMM.  Exact fp32 and f16x3 must both hold the 1e-4 bar against
+    the oracle; bf16x3 its own (1e-3 on the maps)."""
+    m, state = model
+    toks = synthetic.make_tokens(R, C, 100 + R)
+    emb, atp = O.pack_outputs(O.forward(torch.from_numpy(toks), O.to_torch_params(state)))
+    t = torch.from_numpy(toks).to("cuda:0")
+    try:
+        for mode, emb_tol, atp_tol in (("f32", 1e-4, 1e-4), ("f16x3", 1e-4, 1e-4), ("bf16x3", 2e-4, 1e-3)):
+            m.gemm_dtype = mode
+            out = m.forward_one(t)
+            assert out["emb"].shape == (C - 1, 768) and out["atp"].shape == (120, C - 1, C - 1)
+            assert rel_l2(out["emb"].cpu().numpy(), emb) < emb_tol, mode
+            assert np.abs(out["atp"].cpu().numpy() - atp.numpy()).max() < atp_tol, mode
+    finally:
+        m.gemm_dtype = "f32"
