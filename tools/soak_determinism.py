@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Soak test: the same forward N times per arithmetic mode, every output compared bit for bit with the first run.
+The 16-bit kernels synchronise with hand-written s_waitcnt / s_barrier sequences around LDS-DMA; a latent race would show
+up here as a rare mismatch.  ITER (default 150), shapes cfg3 and an odd mid-size one."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd"))
+import torch
+from rnamsm import synthetic
+from rnamsm.model import MSATransformer
+ITER = int(os.environ.get("ITER", 150))
+state = synthetic.make_state_dict(seed=0)
+m = MSATransformer(num_layers=10)
+m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+m = m.eval().cuda()
+bad = 0
+for (R, C), iters in (((256, 512), ITER), ((37, 300), 2 * ITER), ((64, 128), 2 * ITER)):
+    toks = torch.from_numpy(synthetic.make_tokens(R, C, 5)).cuda()
+    for mode in ("f32", "f16x3", "bf16"):
+        m.gemm_dtype = mode
+        ref = m.forward_one(toks)
+        ref_emb, ref_atp = ref["emb"].clone(), ref["atp"].clone()
+        mism = 0
+        for i in range(iters):
+            out = m.forward_one(toks)
+            if not (torch.equal(out["emb"], ref_emb) and torch.equal(out["atp"], ref_atp)):
+                mism += 1
+        bad += mism
+        print(f"{R}x{C} {mode}: {iters} reruns, {mism} mismatches", flush=True)
+print("SOAK", "FAILED" if bad else "OK")
+sys.exit(1 if bad else 0)
