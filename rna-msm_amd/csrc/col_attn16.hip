@@ -19,16 +19,20 @@ namespace rnamsm {
 
 constexpr int C16_THREADS = 256;
 constexpr int C16_ROWS = 128;                  // query rows per block (4 waves x 32)
-constexpr int C16_JC = 64;                     // keys per chunk
-constexpr int C16_TILE = C16_JC * T16_ROWB;    // 8 KB per plane tile
+// keys per chunk JC: 64 (two 32-key tiles per barrier) for plain bf16, 32 for the hi/lo modes -- their four planes per
+// chunk would otherwise cost 64 KB of LDS per block and cap the CU at two blocks; at 32 KB three fit (the registers'
+// limit), and this kernel lives on occupancy: one problem's loop is shorter than the fixed cost around it (strided q
+// rows, first chunk, output stores), which only other resident blocks can hide.
 
-template <int SPLIT, int FMT, int OUT>
-__global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
+template <int SPLIT, int FMT, int OUT, int JC>
+__global__ __launch_bounds__(C16_THREADS, JC == 32 ? 3 : 2) void col_attn16_kernel(
     const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
     const uint16_t* __restrict__ klo, const uint16_t* __restrict__ vhi, const uint16_t* __restrict__ vlo, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo,
     float scale) {
     constexpr int NPL = SPLIT == 3 ? 2 : 1;
+    constexpr int C16_JC = JC;
+    constexpr int C16_TILE = JC * T16_ROWB;            // bytes per plane tile
     constexpr int BUF = 2 * NPL * C16_TILE;            // K planes then V planes
     typedef typename Half16<FMT>::T Hh;
     typedef typename Half16<FMT>::V8 V8;
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
     auto issue = [&](int ch, int buf) {
         char* base = smem_b + buf * BUF;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < JC / 32; ++j) {
             const int row = 8 * (wave + 4 * j) + drow;
             const int64_t ko = (int64_t)min(ch * C16_JC + row, R - 1) * C * ld + col_off;
             const int loff = (8 * (wave + 4 * j)) * T16_ROWB;
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
             const char* Vc = Kc + NPL * C16_TILE;
             const int jbase = ch * C16_JC;
             tile(Kc, Vc, 0, jbase);
-            if (jbase + 32 < R) tile(Kc, Vc, 1, jbase + 32);     // block-uniform
+            if (JC == 64 && jbase + 32 < R) tile(Kc, Vc, 1, jbase + 32);     // block-uniform
         }
     }
 
@@ -223,18 +227,19 @@ extern "C" int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, con
     const unsigned iblocks = (R + C16_ROWS - 1) / C16_ROWS;
     const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
     const int npl = q_lo ? 2 : 1;
-    const int lds = 2 * 2 * npl * C16_TILE;
+    const int jc = q_lo ? 32 : 64;
+    const int lds = 2 * 2 * npl * jc * T16_ROWB;
     KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)R * R * 64, (2.0 * npl * 3.0 + 4.0) * R * C * H * 64, s);
 #define CA_GO(SP_, FMT_, OUT_)                                                                                      \
     do {                                                                                                            \
         static bool cfg_ = false;                                                                                   \
         if (!cfg_) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn16_kernel<SP_, FMT_, OUT_>),   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn16_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64)>),   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);                    \
             if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn16: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
             cfg_ = true;                                                                                            \
         }                                                                                                           \
-        hipLaunchKernelGGL((col_attn16_kernel<SP_, FMT_, OUT_>), dim3(grid), dim3(C16_THREADS), lds, s, q_hi, q_lo, k_hi, \
+        hipLaunchKernelGGL((col_attn16_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64)>), dim3(grid), dim3(C16_THREADS), lds, s, q_hi, q_lo, k_hi, \
                            k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, scale);                         \
     } while (0)
     if (!q_lo) {
