@@ -259,8 +259,11 @@ void rnamsm_timing_reset(void);
  *   "gemm_tile"   fp32 GEMM block tile: 0 (default) = 128x128, or 128x64 where that evens out the last round of blocks
  *                 on a small problem; 1 = always 128x128; 2 = always 128x64.  Results are bit-identical under either
  *                 tile: each output element sums its K products in the same order.
+ *   "row_vt"      fp32 rnamsm_row_apply: 1 (default) = the V tile is transposed while it is staged (ds_read_b128
+ *                 fragments), 0 = staged as it lies in memory.  Speed only, results bit-identical.
  *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit
- *                 matrix cores in the mode's operand format (K4'..K7'), 0 = they stay on the exact-fp32 kernels.
+ *                 matrix cores in the mode's operand format (K4'..K7'), 0 = they stay on the exact-fp32 kernels,
+ *                 2 = as 1 but the row kernels keep 128x128 tiles for every C (A/B of the 256x256-tile kernels).
  *                 The RNAMSM_F32 path is not affected by either. */
 int rnamsm_set_param(const char* name, int value);
 int rnamsm_get_param(const char* name);
