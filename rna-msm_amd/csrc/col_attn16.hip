@@ -158,7 +158,7 @@ __global__ __launch_bounds__(C16_THREADS, JC == 32 ? 3 : 2) void col_attn16_kern
     const int nch = (R + C16_JC - 1) / C16_JC;
     issue(0, 0);
     for (int ch = 0; ch < nch; ++ch) {
-        __syncthreads();                 // vmcnt(0) + barrier: chunk ch has landed, the other buffer is free again
+        wait_dma_then_barrier<0>();      // chunk ch has landed (every wave's share), the other buffer is free again
         if (ch + 1 < nch) issue(ch + 1, (ch + 1) & 1);
         if (active) {
             const char* Kc = smem_b + (ch & 1) * BUF;

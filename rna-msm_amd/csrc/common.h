@@ -101,6 +101,17 @@ __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v * (1.f + er);
 }
 
+// Barrier of the LDS-DMA staged loops: "my LDS reads are done (lgkmcnt 0), my global_load_lds older than the N
+// youngest have landed (vmcnt N), then s_barrier" -- after it EVERY wave's share of the awaited tile is in LDS.
+// __syncthreads() must not be used for this: its workgroup-scope fence does not wait for vmcnt, and whether hipcc adds a
+// vmcnt wait for an LDS-DMA depends on its alias guess about later ds_reads (col_attn16 got none before its K-fragment
+// reads: a wave could read rows another wave's DMA had not delivered yet -- a race that 2250 bit-identical soak reruns
+// never hit with 64-key chunks and that showed up at once with 32-key chunks and three blocks per CU).
+template <int N>
+__device__ __forceinline__ void wait_dma_then_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 // XCD-aware block remap for panel-sharing tiled kernels: hardware deals consecutive block ids round-robin over the
 // 8 XCDs (each with a private 4 MiB L2), so blocks b and b+8 share an L2.  Blocks that read the same operand panel
 // are given ids of equal (b % 8): `inner` consecutive logical tiles (one panel) per XCD slot.

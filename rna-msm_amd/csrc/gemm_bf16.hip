@@ -349,7 +349,7 @@ __global__ __launch_bounds__(HB_THREADS, SPLIT == 3 ? 1 : 2) void gemm16_dma_ker
     const int nk = K / HB_BK;
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                 // vmcnt(0) + barrier: tile kt has landed, the other buffer is free again
+        wait_dma_then_barrier<0>();      // tile kt has landed (every wave's share), the other buffer is free again
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const char* cur = smem_b + (kt & 1) * Cfg::BUF;
         HbFrag<SPLIT, FMT> f0, f1;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(HX_THREADS, 2) void gemm16_dma256_kernel(
     const int nk = K / HX_BK;
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                 // vmcnt(0) + barrier: tile kt has landed, the other buffer is free again
+        wait_dma_then_barrier<0>();      // tile kt has landed (every wave's share), the other buffer is free again
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const char* cur = smem_b + (kt & 1) * Cfg::BUF;
         HxFrag<SPLIT, FMT> f;
@@ -530,12 +530,6 @@ static int launch_hx(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
                        ldc, M, N, K, scale, scale_cols, o_hi, o_lo);
     RNAMSM_CHECK_LAUNCH("gemm16_dma256");
     return RNAMSM_OK;
-}
-
-template <int N>
-__device__ __forceinline__ void wait_dma_then_barrier() {
-    // all of this wave's LDS reads are done (lgkmcnt 0) and its DMA older than the N youngest have landed
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
 // ---- 256x256 tile, two buffers, software-pipelined fragments -------------------------------------------------------

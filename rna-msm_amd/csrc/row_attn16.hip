@@ -107,7 +107,7 @@ __global__ __launch_bounds__(R16_THREADS, SPLIT == 3 ? 1 : 2) void row_logits16_
     const int nk = r_end - r_begin;          // K tile kt = alignment row r_begin + kt
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                     // vmcnt(0) + barrier: tile kt has landed, the other buffer is free again
+        wait_dma_then_barrier<0>();          // tile kt has landed (every wave's share), the other buffer is free again
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const char* cur = smem_b + (kt & 1) * Cfg::BUF;
         R16Frag<SPLIT, FMT> f0, f1;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(R16_THREADS, SPLIT == 3 ? 1 : 2) void row_apply16_k
     const int nk = (C + 63) / 64;
     issue(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();
+        wait_dma_then_barrier<0>();
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const char* cur = smem_b + (kt & 1) * Cfg::BUF;
         R16Frag<SPLIT, FMT> f0, f1;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(R16_THREADS, SPLIT == 3 ? 1 : 2) void row_apply16_k
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[mt][nt][t] *= out_scale;
     // wave slab = alignment row rr0 + wn, alignment columns i0 + wm*64 .. +63, 64 head dims -> 256-B / 128-B segments
-    __syncthreads();
+    wait_dma_then_barrier<0>();
     const int r = rr0 + wn;
     const int ibase = i0 + wm * 64;
     auto rowoff = [&](int row) -> int64_t {
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
 
     const int nk = 2 * (r_end - r_begin);
     issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    wait_dma_then_barrier<0>();
     issue(1, 1);                                             // nk >= 2 always
     R16LFrag<SPLIT, FMT> f0, f1;
     frag_load(smem_b, 0, f0);
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
         frag_load(cur, 1, f1);
         frag_mma(f0, acc);
         interleave();
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        wait_dma_then_barrier<0>();
         issue(kt + 2 < nk ? kt + 2 : nk - 1, kt & 1);        // clamped: the last reload is never read
         __builtin_amdgcn_sched_barrier(0);
         frag_load(nxt, 0, f0);
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
 
     const int nk = (C + 31) / 32;
     issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    wait_dma_then_barrier<0>();
     issue(nk > 1 ? 1 : 0, 1);
     R16XFrag<SPLIT, FMT> f0, f1;
     frag_load(smem_b, 0, f0);
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
         frag_mma(f0, acc);
         interleave();
         // every wave is done reading `cur` once its f1 has arrived; tile kt+1 (issued one tile ago) must have landed
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        wait_dma_then_barrier<0>();
         issue(kt + 2 < nk ? kt + 2 : nk - 1, kt & 1);              // clamped: the last reload is never read
         __builtin_amdgcn_sched_barrier(0);
         frag_load(nxt, 0, f0);
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
         interleave();
         frag_mma(f1, acc);
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is free for the epilogue staging
+    wait_dma_then_barrier<0>();   // LDS is free for the epilogue staging
 
     const int r = rr0 + wn;
 #pragma unroll

@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 # C >= 256 (with R >= 4) takes the 256x256-tile row kernels: ragged both ways, R not a multiple of 4, C = 256 exactly
 ATT_SHAPES = [(1, 5, 2), (7, 33, 2), (34, 66, 2), (6, 19, 12), (3, 130, 2), (65, 40, 2), (257, 9, 2), (300, 20, 1), (16, 200, 3),
-              (8, 300, 2), (5, 520, 1), (9, 257, 2), (4, 256, 1), (3, 300, 1)]
+              (8, 300, 2), (5, 520, 1), (9, 257, 2), (4, 256, 1), (3, 300, 1),
+              (64, 128, 12), (96, 70, 12)]       # thousands of blocks, several resident per CU: staging races show up here
 # (split, fmt, tolerance vs eff operands, tolerance vs fp32 operands)
 MODES = [(1, 0, 2e-6, 8e-3), (3, 0, 4e-5, 4e-5), (3, 1, 3e-6, 3e-6)]
 
