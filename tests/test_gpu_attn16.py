@@ -218,3 +218,42 @@ def test_forward_attn16_switch(dev):
     assert not torch.equal(a["emb"], b["emb"])                 # the switch really changes the kernels
     assert rel_l2(a["emb"].cpu().numpy(), b["emb"].cpu().numpy()) < 2e-5
     assert np.abs(a["atp"].cpu().numpy() - b["atp"].cpu().numpy()).max() < 2e-5
+
+
+def _int_tensor(shape, mul, mod, off, dev):
+    n = int(np.prod(shape))
+    i = torch.arange(n, device=dev, dtype=torch.int64)
+    return (((i * mul + (i // 191) * 3) % mod) - off).to(torch.float32).view(*shape)
+
+
+@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 1)])
+def test_full_grid_16bit_kernels_equal_the_exact_kernels_on_integers(dev, split, fmt):
+    """BASELINE configs[2] grid sizes (tens of thousands of blocks, every CU holding its maximum of resident blocks): on
+    small-integer operands the 16-bit kernels and the exact-fp32 kernels are both exact, so their outputs must be EQUAL
+    -- GEMM (256x256 software-pipelined tiles, QKV- and fc2-shaped), row logits (256x256 tiles in the hi/lo modes) and
+    row apply (256x256 tiles).  A staging race or a wrong tile edge anywhere in the grid breaks the equality."""
+    from rnamsm import ops
+    R, C, H = 256, 512, 12
+    D = 64 * H
+    T = R * C
+    a = _int_tensor((T, D), 7, 13, 6, dev)
+    for N, K in ((3 * D, D), (D, 4 * D)):
+        w = _int_tensor((N, K), 5, 11, 5, dev)
+        x = a if K == D else _int_tensor((T, K), 3, 7, 3, dev)
+        want = ops.linear(x, w)
+        got = ops.linear_planes(ops.split_bf16(x, want_lo=split == 3, fmt=fmt), ops.split_bf16(w, want_lo=split == 3, fmt=fmt), fmt=fmt)
+        assert torch.equal(got, want), (N, K)
+        del want, got, w
+    qkv = _int_tensor((T, 3 * D), 7, 5, 2, dev)                       # |q.k| sums stay far below 2^24
+    pl = ops.split_bf16(qkv, want_lo=split == 3, fmt=fmt)
+    v = lambda lo_, hi_: (pl[0][:, lo_:hi_], None if pl[1] is None else pl[1][:, lo_:hi_])
+    p16, _ = ops.row_logits16(v(0, D), v(D, 2 * D), R, C, H, fmt=fmt)
+    p32, _ = ops.row_logits(qkv[:, :D], qkv[:, D:2 * D], R, C, H)
+    assert torch.equal(p16.sum(0), p32.sum(0))
+    ldp = (C + 63) // 64 * 64
+    pint = _int_tensor((H * C, ldp), 5, 7, 3, dev)
+    pint[:, C:] = 0
+    pp = ops.split_bf16(pint, want_lo=split == 3, fmt=fmt)
+    c16 = ops.row_apply16(pp, v(2 * D, 3 * D), R, C, H, fmt=fmt)
+    c32 = ops.row_apply(pint[:, :C].reshape(H, C, C).contiguous(), qkv[:, 2 * D:], R, C, H)
+    assert torch.equal(c16, c32)
