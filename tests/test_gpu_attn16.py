@@ -257,3 +257,20 @@ def test_full_grid_16bit_kernels_equal_the_exact_kernels_on_integers(dev, split,
     c16 = ops.row_apply16(pp, v(2 * D, 3 * D), R, C, H, fmt=fmt)
     c32 = ops.row_apply(pint[:, :C].reshape(H, C, C).contiguous(), qkv[:, 2 * D:], R, C, H)
     assert torch.equal(c16, c32)
+
+
+def test_full_grid_col_attention_16bit_against_the_exact_kernel(dev):
+    """Same idea for column attention (its softmax rules out bit equality): at the BASELINE configs[2] grid the f16x3
+    kernel must sit at fp32-grade distance from the exact-fp32 kernel on operands both represent exactly -- any block
+    that read a K/V chunk before it had landed would be off by orders of magnitude more."""
+    from rnamsm import ops
+    R, C, H = 256, 512, 12
+    D = 64 * H
+    qkv = (_int_tensor((R * C, 3 * D), 7, 9, 4, dev) / 4.0).contiguous()         # multiples of 1/4 in [-1, 1]: exact in fp16
+    pl = ops.split_bf16(qkv, fmt=1)
+    v = lambda lo_, hi_: (pl[0][:, lo_:hi_], pl[1][:, lo_:hi_])
+    c16 = ops.col_attn16(v(0, D), v(D, 2 * D), v(2 * D, 3 * D), R, C, H, fmt=1, scale=0.125)
+    q32 = qkv.clone(); q32[:, :D] *= 0.125
+    c32 = ops.col_attn(q32[:, :D], q32[:, D:2 * D], q32[:, 2 * D:], R, C, H)
+    diff = (c16 - c32).abs()
+    assert float(diff.max()) < 2e-5 and float(diff.double().norm() / c32.double().norm()) < 2e-6
