@@ -415,3 +415,31 @@ def test_gemm_half_width_tile_epilogues(dev):
         assert rel_l2(got[2][0], O.gelu_erf(want) + r.double()) < 3e-6
     finally:
         _lib.check(lib.rnamsm_set_param(b"gemm_tile", 0))
+
+
+def test_full_grid_exact_kernels_on_integers(dev):
+    """BASELINE configs[2] sizes (T = 131072 tokens: 18432-block GEMM grids, every CU at its resident-block limit): on
+    small-integer operands the exact-fp32 kernels must reproduce the integer contraction bit for bit over the WHOLE
+    output -- reference = torch's own GPU fp32 matmul / einsum, also exact on such data (plumbing as a checker)."""
+    from rnamsm import ops
+    R, C, H = 256, 512, 12
+    D = 64 * H
+    T = R * C
+
+    def ints(shape, mul, mod, off):
+        i = torch.arange(int(np.prod(shape)), device=dev, dtype=torch.int64)
+        return (((i * mul + (i // 191) * 3) % mod) - off).to(torch.float32).view(*shape)
+
+    a = ints((T, D), 7, 13, 6)
+    for N, K in ((3 * D, D), (D, 4 * D)):
+        w = ints((N, K), 5, 11, 5)
+        x = a if K == D else ints((T, K), 3, 7, 3)
+        assert torch.equal(ops.linear(x, w), x @ w.t()), (N, K)
+        del w
+    qkv = ints((T, 3 * D), 7, 5, 2)
+    q, k, v = (qkv[:, i * D:(i + 1) * D].view(R, C, H, 64) for i in range(3))
+    part, _ = ops.row_logits(qkv[:, :D], qkv[:, D:2 * D], R, C, H)
+    assert torch.equal(part.sum(0), torch.einsum("rihd,rjhd->hij", q, k))
+    p = ints((H, C, C), 5, 7, 3)
+    ctx = ops.row_apply(p, qkv[:, 2 * D:], R, C, H)
+    assert torch.equal(ctx.view(R, C, H, 64), torch.einsum("hij,rjhd->rihd", p, v))
