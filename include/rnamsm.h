@@ -146,7 +146,8 @@ int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_
  * ld in halves): q/k/v as written by rnamsm_gemm_bf16's plane epilogue (O_hi/O_lo over the fused [T,3D] QKV output),
  * P as written by rnamsm_softmax_rows_planes.  All *_lo NULL = bf16 operands, one MFMA per product (fmt must be 0);
  * all *_lo given = hi/lo pairs, three MFMAs per product (fmt 0 = bf16x3, 1 = f16x3; f16x3 is fp32-grade).
- * Accumulation, softmax and the partial-slab sum stay fp32.  No padding-mask variant: masked batches take K4..K7. */
+ * Accumulation, softmax and the partial-slab sum stay fp32.  Padding masks (f2): rnamsm_zero_plane_rows on the q
+ * planes, key_mask in rnamsm_softmax_rows_planes, pad_mask in rnamsm_col_attn16. */
 /* Scaling is applied to fp32 accumulators, never to 16-bit operands (a q scaled by ~1e-2 or a probability ~1e-3 would
  * push its fp16 lo plane into subnormals): q arrives UNSCALED and `scale` multiplies the logits; P planes hold
  * P * plane_scale (a power of two, 4096 in rnamsm_forward) and out_scale = 1 / plane_scale undoes it. */
@@ -166,10 +167,15 @@ int rnamsm_softmax_rows_planes(const float* partial, int nsplit, float* probs, u
 int rnamsm_row_apply16(const uint16_t* p_hi, const uint16_t* p_lo, int64_t ldp, const uint16_t* v_hi,
                        const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H, int head_dim,
                        float out_scale, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, void* stream);
-/* ctx = softmax_j(scale * q k^T) v per (column, head). */
+/* ctx = softmax_j(scale * q k^T) v per (column, head); pad_mask (uint8 [R, C], may be NULL): scaled scores of keys
+ * flagged 1 are replaced by -10000 (modules.py:911-915). */
 int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
                       const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C,
-                      int H, int head_dim, float scale, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, void* stream);
+                      int H, int head_dim, float scale, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo,
+                      int fmt, void* stream);
+/* f2 in the 16-bit modes: zero the first ncols halves of the plane rows flagged in mask (uint8 [T]) -- q *= 1 -
+ * padding_mask (modules.py:767-772) applied to the q planes after the QKV GEMM. */
+int rnamsm_zero_plane_rows(uint16_t* hi, uint16_t* lo, const uint8_t* mask, int64_t T, int ncols, int64_t ld, void* stream);
 
 /* f2 -- padding_mask = tokens.eq(pad_idx) (model.py:346): mask uint8 [n]. */
 int rnamsm_pad_mask(const int64_t* tokens, uint8_t* mask, int64_t n, int pad_idx, void* stream);

@@ -24,12 +24,14 @@ constexpr int C16_ROWS = 128;                  // query rows per block (4 waves 
 // limit), and this kernel lives on occupancy: one problem's loop is shorter than the fixed cost around it (strided q
 // rows, first chunk, output stores), which only other resident blocks can hide.
 
-template <int SPLIT, int FMT, int OUT, int JC>
+// MASKED: f2 padding mask (scores of padded keys of this column become -10000 after scaling, modules.py:911-915); the
+// un-masked instances carry no mask code.
+template <int SPLIT, int FMT, int OUT, int JC, bool MASKED>
 __global__ __launch_bounds__(C16_THREADS, JC == 32 ? 3 : 2) void col_attn16_kernel(
     const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
     const uint16_t* __restrict__ klo, const uint16_t* __restrict__ vhi, const uint16_t* __restrict__ vlo, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo,
-    float scale) {
+    float scale, const uint8_t* __restrict__ pad_mask) {
     constexpr int NPL = SPLIT == 3 ? 2 : 1;
     constexpr int C16_JC = JC;
     constexpr int C16_TILE = JC * T16_ROWB;            // bytes per plane tile
@@ -118,6 +120,13 @@ __global__ __launch_bounds__(C16_THREADS, JC == 32 ? 3 : 2) void col_attn16_kern
 #pragma unroll
         for (int t = 0; t < 16; ++t)
             s[t] = ((t & 3) + 8 * (t >> 2) + 4 * lh < limit) ? s[t] * scale : -INFINITY;
+        if (MASKED) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = jbase + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                if (j < R && pad_mask[(int64_t)j * C + c]) s[t] = -10000.f;
+            }
+        }
         float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
         mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -211,7 +220,8 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 
 extern "C" int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
                                  const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R,
-                                 int C, int H, int head_dim, float scale, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, void* stream) {
+                                 int C, int H, int head_dim, float scale, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt,
+                                 void* stream) {
     RNAMSM_CHECK_ARG(q_hi && k_hi && v_hi && (ctx || ctx_hi), "col_attn16: null pointer");
     RNAMSM_CHECK_ARG((q_lo == nullptr) == (k_lo == nullptr) && (q_lo == nullptr) == (v_lo == nullptr),
                      "col_attn16: the lo planes must all be given (x3) or all be null");
@@ -232,15 +242,19 @@ extern "C" int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, con
     KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)R * R * 64, (2.0 * npl * 3.0 + 4.0) * R * C * H * 64, s);
 #define CA_GO(SP_, FMT_, OUT_)                                                                                      \
     do {                                                                                                            \
+        if (pad_mask) CA_GO2(SP_, FMT_, OUT_, true); else CA_GO2(SP_, FMT_, OUT_, false);                           \
+    } while (0)
+#define CA_GO2(SP_, FMT_, OUT_, MASK_)                                                                              \
+    do {                                                                                                            \
         static bool cfg_ = false;                                                                                   \
         if (!cfg_) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn16_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64)>),   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn16_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64), MASK_>),   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);                    \
             if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn16: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
             cfg_ = true;                                                                                            \
         }                                                                                                           \
-        hipLaunchKernelGGL((col_attn16_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64)>), dim3(grid), dim3(C16_THREADS), lds, s, q_hi, q_lo, k_hi, \
-                           k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, scale);                         \
+        hipLaunchKernelGGL((col_attn16_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64), MASK_>), dim3(grid), dim3(C16_THREADS), lds, s, q_hi, q_lo, k_hi, \
+                           k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, scale, pad_mask);               \
     } while (0)
     if (!q_lo) {
         if (ctx_hi) CA_GO(1, 0, 1); else CA_GO(1, 0, 0);
@@ -250,6 +264,7 @@ extern "C" int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, con
         if (ctx_hi) CA_GO(3, 1, 2); else CA_GO(3, 1, 0);
     }
 #undef CA_GO
+#undef CA_GO2
     RNAMSM_CHECK_LAUNCH("col_attn16");
     return RNAMSM_OK;
 }

@@ -116,6 +116,20 @@ __global__ __launch_bounds__(256) void pad_mask_kernel(const int64_t* __restrict
     if (i < n) mask[i] = tokens[i] == pad_idx;
 }
 
+// f2 in the 16-bit modes: q *= 1 - padding_mask (modules.py:767-772) on q planes the QKV GEMM has already written: one
+// wave per flagged token row zeroes its first `ncols` halves in the hi (and lo) plane; unflagged rows are not touched.
+__global__ __launch_bounds__(256) void zero_plane_rows_kernel(uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
+                                                              const uint8_t* __restrict__ mask, int64_t T, int ncols,
+                                                              int64_t ld) {
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T || !mask[t]) return;
+    const int lane = threadIdx.x & 63;
+    for (int c = lane * 4; c < ncols; c += 256) {            // 8-byte stores (ncols % 4 == 0)
+        *reinterpret_cast<uint2*>(hi + t * ld + c) = uint2{0u, 0u};
+        if (lo) *reinterpret_cast<uint2*>(lo + t * ld + c) = uint2{0u, 0u};
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_outputs_kernel(const float* __restrict__ x_final,
                                                            const float* __restrict__ probs_all,
                                                            float* __restrict__ emb, float* __restrict__ atp, int C,
@@ -179,6 +193,18 @@ extern "C" int rnamsm_pad_mask(const int64_t* tokens, uint8_t* mask, int64_t n, 
     hipLaunchKernelGGL(pad_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        tokens, mask, n, pad_idx);
     RNAMSM_CHECK_LAUNCH("pad_mask");
+    return RNAMSM_OK;
+}
+
+extern "C" int rnamsm_zero_plane_rows(uint16_t* hi, uint16_t* lo, const uint8_t* mask, int64_t T, int ncols, int64_t ld,
+                                      void* stream) {
+    RNAMSM_CHECK_ARG(hi && mask, "zero_plane_rows: null pointer");
+    RNAMSM_CHECK_ARG(T > 0 && ncols > 0 && ncols % 4 == 0 && ld >= ncols && ld % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(hi) & 7u) == 0 && (reinterpret_cast<uintptr_t>(lo) & 7u) == 0,
+                     "zero_plane_rows: ncols and ld must be multiples of 4, planes 8-byte aligned");
+    hipLaunchKernelGGL(zero_plane_rows_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       hi, lo, mask, T, ncols, ld);
+    RNAMSM_CHECK_LAUNCH("zero_plane_rows");
     return RNAMSM_OK;
 }
 

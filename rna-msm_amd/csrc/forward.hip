@@ -100,7 +100,8 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     // 16-bit modes without padding: LayerNorm and the fc1 epilogue write their outputs directly as hi/lo planes (the
     // A operands of the QKV / fc1 / fc2 GEMMs), so those GEMMs stage plain 16-B copies.  The planes overlay the fp32
     // buffers they replace (2 x 2 B per element).
-    const bool planes = dtype != RNAMSM_F32 && !has_padding;
+    // (a padded batch with the "attn16" knob off keeps the fp32 attention kernels and the masked fp32 QKV GEMM)
+    const bool planes = dtype != RNAMSM_F32 && (!has_padding || tuning().attn16 != 0);
     const int split = dtype == RNAMSM_BF16 ? 1 : 3, fmt = dtype == RNAMSM_F16X3 ? 1 : 0;
     uint16_t* xn_hi = reinterpret_cast<uint16_t*>(xn);
     uint16_t* xn_lo = split == 3 ? xn_hi + T * D : nullptr;
@@ -147,9 +148,10 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             // q stays unscaled in the planes; the scaling multiplies the fp32 logits (see include/rnamsm.h)
             FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
                           RNAMSM_ACT_NONE, 1.f, 0));
+            if (mask) FWD(rnamsm_zero_plane_rows(qkv_hi, qkv_lo, mask, T, D, ldq, stream));      // q *= 1 - padding_mask
             FWD(rnamsm_row_logits16(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), ldq, part, R, C, H, 64, row_scale, fmt, stream));
             FWD(rnamsm_softmax_rows_planes(part, rnamsm_row_logits16_nsplit(R, C, H, split), probs, p_hi, p_lo, ldp, 4096.f, H, C,
-                                           nullptr, fmt, stream));
+                                           mask, fmt, stream));
             FWD(rnamsm_row_apply16(p_hi, p_lo, ldp, qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C, H, 64, 1.f / 4096.f,
                                    ctx_hi, ctx_lo, fmt, stream));
         } else {
@@ -173,7 +175,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
                           RNAMSM_ACT_NONE, 1.f, 0));
             FWD(rnamsm_col_attn16(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C,
-                                  H, 64, col_scale, ctx_hi, ctx_lo, fmt, stream));
+                                  H, 64, col_scale, mask, ctx_hi, ctx_lo, fmt, stream));
         } else {
             if (planes)
                 FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,

@@ -63,7 +63,8 @@ _SIGNATURES = {
     "rnamsm_row_apply16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                    c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     "rnamsm_col_attn16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
-                                  c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
+                                  c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rnamsm_zero_plane_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
     "rnamsm_pad_mask": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rnamsm_pack_outputs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rnamsm_contact_head_workspace_bytes": (c_size_t, [c_int, c_int]),

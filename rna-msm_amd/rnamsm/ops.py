@@ -199,7 +199,14 @@ def row_apply16(p, v, R: int, C: int, H: int, fmt: int = 0, out_scale: float = 1
     return ctx
 
 
-def col_attn16(q, k, v, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0) -> torch.Tensor:
+def zero_plane_rows(pl, mask: torch.Tensor, ncols: int) -> None:
+    """In place: zero the first ncols halves of the plane rows flagged in mask (uint8 [T]) -- q *= 1 - padding_mask."""
+    _lib.check(_lib.load().rnamsm_zero_plane_rows(_pl(pl[0], "hi"), _pl(pl[1], "lo"), _dev(mask, "mask", torch.uint8),
+                                                  pl[0].shape[0], ncols, _rowmajor(pl[0], "hi"), _stream()))
+
+
+def col_attn16(q, k, v, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0,
+               pad_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q, k, v: (hi, lo) plane views [R*C, *] with a common row stride; returns softmax(scale * q k^T) v, fp32
     [R*C, H*64] (q UNSCALED)."""
     ctx = torch.empty(R * C, H * HEAD_DIM, device=v[0].device, dtype=torch.float32)
@@ -207,7 +214,9 @@ def col_attn16(q, k, v, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0
     assert _rowmajor(k[0], "k_hi") == ld and _rowmajor(v[0], "v_hi") == ld
     _lib.check(_lib.load().rnamsm_col_attn16(_pl(q[0], "q_hi"), _pl(q[1], "q_lo"), _pl(k[0], "k_hi"), _pl(k[1], "k_lo"),
                                              _pl(v[0], "v_hi"), _pl(v[1], "v_lo"), ld, _dev(ctx, "ctx"), _rowmajor(ctx, "ctx"),
-                                             R, C, H, HEAD_DIM, scale, None, None, fmt, _stream()))
+                                             R, C, H, HEAD_DIM, scale,
+                                             None if pad_mask is None else _dev(pad_mask, "pad_mask", torch.uint8),
+                                             None, None, fmt, _stream()))
     return ctx
 
 

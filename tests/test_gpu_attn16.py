@@ -274,3 +274,44 @@ def test_full_grid_col_attention_16bit_against_the_exact_kernel(dev):
     c32 = ops.col_attn(q32[:, :D], q32[:, D:2 * D], q32[:, 2 * D:], R, C, H)
     diff = (c16 - c32).abs()
     assert float(diff.max()) < 2e-5 and float(diff.double().norm() / c32.double().norm()) < 2e-6
+
+
+@pytest.mark.parametrize("split,fmt,tol", [(1, 0, 3e-3), (3, 1, 3e-6)])
+def test_padding_masks_in_the_16bit_attention_kernels(dev, split, fmt, tol):
+    """§8 f2 on the 16-bit kernels: q planes zeroed at padded tokens (rnamsm_zero_plane_rows), -10000 on keys whose
+    first-row token is padded (row softmax), -10000 on padded keys of a column (col_attn16) -- against the reference's
+    direct-path arithmetic (modules.py:767-785, 911-915) evaluated in fp64 on the values the planes hold."""
+    from rnamsm import ops
+    R, C, H = 37, 45, 2
+    D = 64 * H
+    qkv = _rand("pad16", (R * C, 3 * D))
+    pad = torch.zeros(R, C, dtype=torch.bool)
+    pad[:, 40:] = True            # padded columns (in every row, so also in row 0)
+    pad[30:, :] = True            # padded alignment rows
+    pad[3, 7] = True              # an isolated pad
+    mask = pad.to(torch.uint8).to(dev).contiguous()
+    pl, eff = _planes(qkv.to(dev), split, fmt)
+    ht = torch.float16 if fmt == 1 else torch.bfloat16
+    # q *= 1 - padding_mask
+    ops.zero_plane_rows(_views(pl, 0, D), mask.view(-1), D)
+    got_q = pl[0][:, :D].view(ht).double().cpu() + (pl[1][:, :D].view(ht).double().cpu() if pl[1] is not None else 0)
+    want_q = eff[:, :D] * (~pad).view(-1, 1)
+    assert torch.equal(got_q, want_q)
+    assert torch.equal(pl[0][:, D:].cpu(), _planes(qkv.to(dev), split, fmt)[0][0][:, D:].cpu())      # k, v untouched
+    q = want_q.view(R, C, H, 64); k = eff[:, D:2 * D].view(R, C, H, 64); v = eff[:, 2 * D:].view(R, C, H, 64)
+    # tied row attention with the first-row key mask
+    scale = ops.row_scaling(R)
+    partial, _ = ops.row_logits16(_views(pl, 0, D), _views(pl, D, 2 * D), R, C, H, fmt=fmt, scale=scale)
+    probs, pp = ops.softmax_rows_planes(partial, split=split, fmt=fmt, key_mask=mask[0].contiguous(), plane_scale=4096.0)
+    logits = scale * torch.einsum("rihd,rjhd->hij", q, k)
+    want_p = torch.softmax(logits.masked_fill(pad[0][None, None, :], -10000.0), -1)
+    assert np.abs(probs.cpu().numpy() - want_p.numpy()).max() < (2e-3 if split == 1 else 2e-6)
+    assert float(probs[:, :, 40:].max()) == 0.0
+    # column attention with the per-column key mask (q NOT zeroed there: use the un-zeroed q planes)
+    pl2, eff2 = _planes(qkv.to(dev), split, fmt)
+    ctx = ops.col_attn16(_views(pl2, 0, D), _views(pl2, D, 2 * D), _views(pl2, 2 * D, 3 * D), R, C, H, fmt=fmt, scale=0.125,
+                         pad_mask=mask).cpu()
+    q2 = 0.125 * eff2[:, :D].view(R, C, H, 64)
+    wc = torch.einsum("ichd,jchd->hcij", q2, k).masked_fill(pad.t()[None, :, None, :], -10000.0)
+    want_ctx = torch.einsum("hcij,jchd->ichd", torch.softmax(wc, -1), v).reshape(R * C, D)
+    assert rel_l2(ctx, want_ctx) < tol

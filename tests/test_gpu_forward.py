@@ -232,17 +232,23 @@ def test_padded_ragged_batch_matches_reference_fixture(model):
         assert float(res2["representations"][0][b][toks[b] == 1].abs().max()) == 0.0     # x * (1 - padding_mask)
         assert rel_l2(res2["representations"][10][b].cpu().numpy(), g["rep10"][b]) < 1e-4
         assert np.abs(res2["row_attentions"][b].cpu().numpy() - g["row_attentions"][b]).max() < 1e-4
-    # a padded batch in the f16x3 mode: masked batches keep the exact-fp32 attention kernels and the masked QKV GEMM,
-    # the other Linear layers run split-fp16 on fp32 activations (register-staged kernel) -- same bar
+    # a padded batch in the f16x3 mode: the masks run in the 16-bit kernels (q planes zeroed after the QKV GEMM, key masks
+    # in the row softmax and in col_attn16); with the "attn16" knob off the batch falls back to the exact-fp32 attention
+    # kernels and the masked fp32 QKV GEMM -- same bar either way
+    from rnamsm import _lib
+    lib = _lib.load()
     try:
         m.gemm_dtype = "f16x3"
-        res3 = m(toks, repr_layers=[10], need_head_weights=True)
-        for b in range(2):
-            assert rel_l2(res3["representations"][10][b].cpu().numpy(), g["rep10"][b]) < 1e-4
-            assert np.abs(res3["row_attentions"][b].cpu().numpy() - g["row_attentions"][b]).max() < 1e-4
-        assert float(res3["row_attentions"][0, :, :, :, 9].max()) == 0.0
+        for knob in (1, 0):
+            _lib.check(lib.rnamsm_set_param(b"attn16", knob))
+            res3 = m(toks, repr_layers=[10], need_head_weights=True)
+            for b in range(2):
+                assert rel_l2(res3["representations"][10][b].cpu().numpy(), g["rep10"][b]) < 1e-4, knob
+                assert np.abs(res3["row_attentions"][b].cpu().numpy() - g["row_attentions"][b]).max() < 1e-4, knob
+            assert float(res3["row_attentions"][0, :, :, :, 9].max()) == 0.0
     finally:
         m.gemm_dtype = "f32"
+        _lib.check(lib.rnamsm_set_param(b"attn16", 1))
 
 
 def test_masked_pseudo_likelihood_matches_oracle(model):
