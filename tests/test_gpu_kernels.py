@@ -443,3 +443,25 @@ def test_full_grid_exact_kernels_on_integers(dev):
     p = ints((H, C, C), 5, 7, 3)
     ctx = ops.row_apply(p, qkv[:, 2 * D:], R, C, H)
     assert torch.equal(ctx.view(R, C, H, 64), torch.einsum("hij,rjhd->rihd", p, v))
+
+
+def test_integration_md_ctypes_stub_runs_and_matches_the_mirror_module(dev):
+    """INTEGRATION.md (Level 2) shows the ctypes stub a maintainer of the reference would paste into
+    RowSelfAttention.forward.  Execute exactly that text against the library: it must agree with the mirror module bit
+    for bit (same kernels, same order), so the document cannot drift from the C ABI."""
+    import os
+    import re
+    from conftest import ROOT
+    from rnamsm import modules
+    src = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\nimport ctypes, math, torch\n(.*?)```", src, re.S).group(0)[len("```python\n"):-3]
+    code = code.replace('ctypes.CDLL("rna-msm_amd/rnamsm/librnamsm_hip.so")',
+                        f'ctypes.CDLL("{os.path.join(ROOT, "rna-msm_amd", "rnamsm", "librnamsm_hip.so")}")')
+    ns = {}
+    exec(code, ns)                                            # the repo's own documentation, not external input
+    torch.manual_seed(0)
+    m = modules.RowSelfAttention(768, 12).to(dev).eval()
+    x = torch.randn(6, 19, 1, 768, device=dev)
+    want, want_p = m(x)
+    got, got_p = ns["row_self_attention_forward"](m, x)
+    assert torch.equal(got, want) and torch.equal(got_p, want_p)
