@@ -105,10 +105,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                float v = (acc[mt][nt][t] + b) * sc;
-                if (ACT == RNAMSM_ACT_GELU_ERF) v = gelu_erf(v);
-                stage[(mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * w.lh) * LDE + nt * 32 + w.li] = v;
+            for (int t = 0; t < 16; t += 2) {                    // pairs: the GELU runs on the packed-fp32 VALU
+                f32x2 v = f32x2{(acc[mt][nt][t] + b) * sc, (acc[mt][nt][t + 1] + b) * sc};
+                if (ACT == RNAMSM_ACT_GELU_ERF) v = gelu_erf2(v);
+                stage[(mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * w.lh) * LDE + nt * 32 + w.li] = v[0];
+                stage[(mt * 32 + ((t + 1) & 3) + 8 * ((t + 1) >> 2) + 4 * w.lh) * LDE + nt * 32 + w.li] = v[1];
             }
     }
     // same-wave LDS write -> read: ordered by the hardware queue, the compiler inserts the lgkmcnt wait
