@@ -161,6 +161,35 @@ def test_library_exports_every_symbol_declared_in_the_header(lib):
     assert lib.rnamsm_version() == 100
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype of include/rnamsm.h against the ctypes table of rnamsm/_lib.py: same number of parameters, and per
+    parameter the same class (pointer / 64-bit integer / int / float / size_t) -- a drifted binding would otherwise pass
+    garbage through the C ABI silently (ctypes does not check)."""
+    import ctypes
+    from rnamsm import _lib
+    header = open(os.path.join(ROOT, "include", "rnamsm.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = dict(re.findall(r"\b(rnamsm_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S))
+    assert set(protos) == set(_lib._SIGNATURES)
+
+    def klass(decl: str) -> str:
+        decl = " ".join(decl.split())
+        if "*" in decl or decl.endswith("]"):
+            return "ptr"
+        base = decl.rsplit(" ", 1)[0] if " " in decl else decl
+        return {"int64_t": "i64", "long long": "i64", "size_t": "size", "int": "int", "float": "float"}[base.replace("const ", "")]
+
+    ctype_class = {ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr", ctypes.c_int64: "i64", ctypes.c_longlong: "i64",
+                   ctypes.c_size_t: "size", ctypes.c_int: "int", ctypes.c_float: "float"}
+    for name, params in protos.items():
+        params = params.strip()
+        want = [] if params in ("", "void") else [klass(x) for x in params.split(",")]
+        got = []
+        for t in _lib._SIGNATURES[name][1]:
+            got.append("ptr" if hasattr(t, "_type_") and not isinstance(t._type_, str) else ctype_class[t])
+        assert got == want, (name, got, want)
+
+
 def test_library_validates_arguments_without_a_gpu(lib):
     from rnamsm import _lib
     assert lib.rnamsm_row_logits_nsplit(256, 512, 12) == 8          # deterministic function of the shape
