@@ -197,8 +197,9 @@ int rnamsm_contact_head(const float* row_attn, const float* weight, const float*
 /* f3 -- greedy max/min mean-Hamming row sub-sampling (MSA.greedy_select, utils/align.py:128-148, via
  * select_diverse "diversity-max" / "diversity-min", :165-181): msa uint8 [N, L] (any per-character code, e.g. the raw
  * bytes or token ids), keeps row 0, returns the num_seqs selected row indices in ascending order.  Performs the
- * reference's float64 operations in the reference's order, so the indices are identical to numpy's. */
-size_t rnamsm_greedy_select_workspace_bytes(int N, int num_seqs);
+ * reference's float64 operations in the reference's order (numpy's pairwise summation of every candidate's distance
+ * history), so the indices are identical to numpy's.  L < 65536, num_seqs <= 2048. */
+size_t rnamsm_greedy_select_workspace_bytes(int N, int L, int num_seqs);
 int rnamsm_greedy_select(const uint8_t* msa, int N, int L, int num_seqs, int minimise, int* out_indices,
                          void* workspace, size_t workspace_bytes, void* stream);
 

@@ -12,10 +12,10 @@ tests of its own for this path.
 
 Every function cites the reference lines it restates (paths relative to /root/reference).
 Layout: one MSA (B=1) is held as x[R, C, D] (reference: [R, C, B=1, D]); token t = r*C + c.
-Padding masks follow the reference's DIRECT path (max_tokens_per_msa large): with padding the
-reference's chunked path fills -10000 per chunk using each chunk's first row (modules.py:727-737), a quirk that
-changes nothing unless every key of a query is masked; the kernels tile internally, so the direct semantics are
-the contract.  A batch is processed one MSA at a time (B is a loop).
+Padding masks: the direct path (R*C <= max_tokens) masks keys by the MSA's first row; the chunked
+path fills -10000 per row chunk using each chunk's own first row (modules.py:727-737) and sums the filled slabs -- both are
+restated (row_attention) and pinned (forward_padded_b2.npz, forward_padded_b2_chunked.npz).  A batch is processed one
+MSA at a time (B is a loop).
 """
 from __future__ import annotations
 
@@ -34,7 +34,11 @@ def _p(params: Dict[str, torch.Tensor], prefix: str, name: str) -> torch.Tensor:
 
 
 def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
-    """nn.LayerNorm over the last dim, eps 1e-5, biased variance (modules.py:383,387)."""
+    """nn.LayerNorm over the last dim, eps 1e-5, biased variance (modules.py:383,387).  In 16-bit dtypes the
+    reference's nn.LayerNorm keeps its statistics in fp32 and rounds only the result, so the same ATen call is made
+    here (the spelled-out form below would round every intermediate and overstate the reference's bf16 drift)."""
+    if x.dtype in (torch.bfloat16, torch.float16):
+        return F.layer_norm(x, (x.shape[-1],), gamma, beta, LN_EPS)
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
     return (x - mu) * torch.rsqrt(var + LN_EPS) * gamma + beta
@@ -46,7 +50,10 @@ def linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def gelu_erf(x: torch.Tensor) -> torch.Tensor:
-    """nn.GELU() exact-erf form (modules.py:416)."""
+    """nn.GELU() exact-erf form (modules.py:416); 16-bit dtypes go through the same ATen kernel as the reference
+    (fp32 inside, one rounding)."""
+    if x.dtype in (torch.bfloat16, torch.float16):
+        return F.gelu(x)
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
@@ -102,15 +109,18 @@ def row_attention(x: torch.Tensor, params, prefix: str, num_heads: int,
     R, C, D = x.shape
     dh = D // num_heads
     scaling = (dh ** -0.5) / math.sqrt(R)                          # align_scaling, modules.py:713-715
-    if pad is not None:                                             # direct-path semantics (see module docstring)
-        logits = row_attention_logits(x, params, prefix, num_heads, scaling, pad)
-    elif max_tokens is not None and R * C > max_tokens:
+    if max_tokens is not None and R * C > max_tokens:
+        # _batched_forward (modules.py:717-750): every row chunk gets the padding mask of ITS rows, so a chunk's -10000
+        # fill comes from the chunk's own first row (:727-737) and the filled slabs are then summed -- with padding this
+        # differs from the direct path (a pad on a chunk-starting row masks that key; an all-padded chunk start shifts
+        # every logit by -10000 and costs ~1e-3 of fp32 resolution)
         max_rows = max(1, max_tokens // C)                          # modules.py:724
         logits = 0
         for s in range(0, R, max_rows):
-            logits = logits + row_attention_logits(x[s:s + max_rows], params, prefix, num_heads, scaling)
+            logits = logits + row_attention_logits(x[s:s + max_rows], params, prefix, num_heads, scaling,
+                                                    None if pad is None else pad[s:s + max_rows])
     else:
-        logits = row_attention_logits(x, params, prefix, num_heads, scaling)
+        logits = row_attention_logits(x, params, prefix, num_heads, scaling, pad)
     probs = torch.softmax(logits, dim=-1)                           # modules.py:818 / 739
     v = linear(x, _p(params, prefix, "v_proj.weight"), _p(params, prefix, "v_proj.bias")).view(R, C, num_heads, dh)
     ctx = torch.einsum("hij,rjhd->rihd", probs, v).reshape(R, C, D)   # modules.py:797-798
@@ -130,13 +140,13 @@ def col_attention(x: torch.Tensor, params, prefix: str, num_heads: int,
     wo, bo = _p(params, prefix, "out_proj.weight"), _p(params, prefix, "out_proj.bias")
     if R == 1:                                                      # modules.py:882-894
         out = linear(linear(x, wv, bv), wo, bo)
-        probs = torch.ones(num_heads, C, 1, 1, dtype=x.dtype) if return_probs else None
+        probs = torch.ones(num_heads, C, 1, 1, dtype=x.dtype, device=x.device) if return_probs else None
         return (out, probs) if return_probs else out
     scaling = dh ** -0.5                                            # modules.py:839
     q = (linear(x, _p(params, prefix, "q_proj.weight"), _p(params, prefix, "q_proj.bias")) * scaling).view(R, C, num_heads, dh)
     k = linear(x, _p(params, prefix, "k_proj.weight"), _p(params, prefix, "k_proj.bias")).view(R, C, num_heads, dh)
     v = linear(x, wv, bv).view(R, C, num_heads, dh)
-    ctx = torch.empty(R, C, num_heads, dh, dtype=x.dtype)
+    ctx = torch.empty(R, C, num_heads, dh, dtype=x.dtype, device=x.device)
     all_probs: List[torch.Tensor] = []
     for s in range(0, C, col_chunk):
         e = min(C, s + col_chunk)
@@ -153,14 +163,22 @@ def col_attention(x: torch.Tensor, params, prefix: str, num_heads: int,
     return out
 
 
-def ffn(x: torch.Tensor, params, prefix: str) -> torch.Tensor:
-    """FeedForwardNetwork.forward (modules.py:423-427): fc2(GELU_erf(fc1(x)))."""
-    h = gelu_erf(linear(x, _p(params, prefix, "fc1.weight"), _p(params, prefix, "fc1.bias")))
-    return linear(h, _p(params, prefix, "fc2.weight"), _p(params, prefix, "fc2.bias"))
+def ffn(x: torch.Tensor, params, prefix: str, token_chunk: Optional[int] = None) -> torch.Tensor:
+    """FeedForwardNetwork.forward (modules.py:423-427): fc2(GELU_erf(fc1(x))).  Tokens are independent, so with
+    `token_chunk` the [.., 4D] hidden activation is formed that many tokens at a time (memory only: an fp64 truth at
+    M = L = 1024 would otherwise hold 26 GB of it plus temporaries)."""
+    def run(xc):
+        h = gelu_erf(linear(xc, _p(params, prefix, "fc1.weight"), _p(params, prefix, "fc1.bias")))
+        return linear(h, _p(params, prefix, "fc2.weight"), _p(params, prefix, "fc2.bias"))
+    if token_chunk is None or x.numel() // x.shape[-1] <= token_chunk:
+        return run(x)
+    flat = x.reshape(-1, x.shape[-1])
+    return torch.cat([run(flat[s:s + token_chunk]) for s in range(0, flat.shape[0], token_chunk)], 0).view(x.shape)
 
 
 def axial_layer(x: torch.Tensor, params, layer: int, num_heads: int,
-                max_tokens: Optional[int] = None, pad: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                max_tokens: Optional[int] = None, pad: Optional[torch.Tensor] = None,
+                ffn_token_chunk: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """AxialTransformerLayer.forward (modules.py:242-267) with each sub-block wrapped as
     NormalizedResidualBlock (modules.py:385-401): x + f(LN(x)); dropout is the identity in eval."""
     base = f"layers.{layer}"
@@ -173,13 +191,14 @@ def axial_layer(x: torch.Tensor, params, layer: int, num_heads: int,
                           params, f"{pre}.layer", num_heads, pad=pad)
     pre = f"{base}.feed_forward_layer"
     x = x + ffn(layer_norm(x, params[f"{pre}.layer_norm.weight"], params[f"{pre}.layer_norm.bias"]),
-                params, f"{pre}.layer")
+                params, f"{pre}.layer", ffn_token_chunk)
     return x, row_probs
 
 
 def forward(tokens: torch.Tensor, params: Dict[str, torch.Tensor], num_layers: int = 10,
             num_heads: int = 12, max_tokens: Optional[int] = None,
-            layers_to_run: Optional[int] = None, force_mask: bool = False) -> Dict[str, torch.Tensor]:
+            layers_to_run: Optional[int] = None, force_mask: bool = False,
+            ffn_token_chunk: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """MSATransformer.forward (model.py:338-416) for one MSA, need_head_weights=True,
     repr_layers=[num_layers]; lm_head / contact head are not on this path.
     tokens int64 [R, C].  Returns representation [R, C, D] (after emb_layer_norm_after,
@@ -191,7 +210,7 @@ def forward(tokens: torch.Tensor, params: Dict[str, torch.Tensor], num_layers: i
     rows: List[torch.Tensor] = []
     n = num_layers if layers_to_run is None else layers_to_run
     for i in range(n):
-        x, pr = axial_layer(x, params, i, num_heads, max_tokens, pad)
+        x, pr = axial_layer(x, params, i, num_heads, max_tokens, pad, ffn_token_chunk)
         rows.append(pr)
     x = layer_norm(x, params["emb_layer_norm_after.weight"], params["emb_layer_norm_after.bias"])
     return {"representation": x, "row_attentions": torch.stack(rows, 0)}
@@ -206,17 +225,24 @@ def pack_outputs(result: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.T
     return emb.contiguous(), att.reshape(-1, L, L).contiguous()
 
 
-def multihead_self_attention(x: torch.Tensor, params, prefix: str, num_heads: int) -> torch.Tensor:
-    """Self-attention path of msm/multihead_attention.py:154-397 (no masks, no bias_kv, eval): q = q_proj(x)*dh^-0.5
-    (:256), bmm (:349), softmax (:371), bmm (:379), out_proj (:387).  x [T, B, E] -> [T, B, E]."""
+def multihead_self_attention(x: torch.Tensor, params, prefix: str, num_heads: int,
+                             key_padding_mask: Optional[torch.Tensor] = None, return_weights: bool = False):
+    """Self-attention path of msm/multihead_attention.py:154-397 (no attn_mask, no bias_kv, eval): q = q_proj(x)*dh^-0.5
+    (:256), bmm (:349), key_padding_mask [B, T] -> -inf on masked keys (:360-369), softmax (:371), bmm (:379), out_proj
+    (:387).  x [T, B, E] -> out [T, B, E]; with return_weights also the per-head probabilities [H, B, T, T] (:389-393;
+    the reference's default returns their mean over heads, :394-397)."""
     T, B, E = x.shape
     dh = E // num_heads
     q = (linear(x, _p(params, prefix, "q_proj.weight"), _p(params, prefix, "q_proj.bias")) * dh ** -0.5).view(T, B, num_heads, dh)
     k = linear(x, _p(params, prefix, "k_proj.weight"), _p(params, prefix, "k_proj.bias")).view(T, B, num_heads, dh)
     v = linear(x, _p(params, prefix, "v_proj.weight"), _p(params, prefix, "v_proj.bias")).view(T, B, num_heads, dh)
-    p = torch.softmax(torch.einsum("ibhd,jbhd->bhij", q, k), -1)
+    w = torch.einsum("ibhd,jbhd->bhij", q, k)
+    if key_padding_mask is not None:
+        w = w.masked_fill(key_padding_mask.to(torch.bool)[:, None, None, :], float("-inf"))
+    p = torch.softmax(w, -1)
     ctx = torch.einsum("bhij,jbhd->ibhd", p, v).reshape(T, B, E)
-    return linear(ctx, _p(params, prefix, "out_proj.weight"), _p(params, prefix, "out_proj.bias"))
+    out = linear(ctx, _p(params, prefix, "out_proj.weight"), _p(params, prefix, "out_proj.bias"))
+    return (out, p.transpose(0, 1)) if return_weights else out
 
 
 def lm_head(features: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor:
@@ -243,10 +269,11 @@ def contact_head(row_attentions: torch.Tensor, weight: torch.Tensor, bias: torch
     return torch.sigmoid(z)
 
 
-def to_torch_params(state: Dict[str, "object"], dtype=torch.float32) -> Dict[str, torch.Tensor]:
-    """numpy / torch state_dict -> torch CPU tensors of `dtype`."""
+def to_torch_params(state: Dict[str, "object"], dtype=torch.float32, device="cpu") -> Dict[str, torch.Tensor]:
+    """numpy / torch state_dict -> torch tensors of `dtype` on `device` (CPU by default; the tests also run this same
+    code in fp64 on the GPU box's device as the full-size truth, tests/truth.py -- still only as the checker)."""
     out = {}
     for k, v in state.items():
         t = v if isinstance(v, torch.Tensor) else torch.from_numpy(v)
-        out[k] = t.detach().to("cpu", dtype)
+        out[k] = t.detach().to(device, dtype)
     return out

@@ -69,7 +69,7 @@ _SIGNATURES = {
     "rnamsm_pack_outputs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rnamsm_contact_head_workspace_bytes": (c_size_t, [c_int, c_int]),
     "rnamsm_contact_head": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
-    "rnamsm_greedy_select_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "rnamsm_greedy_select_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rnamsm_greedy_select": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rnamsm_forward_workspace_bytes": (c_size_t, [POINTER(ModelDims), c_int, c_int]),
     "rnamsm_forward": (c_int, [POINTER(ModelDims), POINTER(c_void_p), c_void_p, c_int, c_int, c_void_p, c_size_t,

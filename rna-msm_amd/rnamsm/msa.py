@@ -3,8 +3,8 @@
 Replaces MSA.from_fasta (utils/align.py:291-317) + A2MDataset.__getitem__ (dataset.py:80-92) for this
 path.  Row sub-sampling: the reference defaults to the external `hhfilter` binary (utils/align.py:68-102),
 which is not available offline; supported here are `first` (keep the first N rows) and the reference's
-greedy `diversity-max` / `diversity-min` (utils/align.py:128-148), done on the host like the reference
-(SURVEY.md §8 f3 lists the device version as a next step).
+greedy `diversity-max` / `diversity-min` (utils/align.py:128-148), on the HIP device when one is given
+(rnamsm_greedy_select) or on the host -- index-identical to the reference either way.
 """
 from __future__ import annotations
 
@@ -37,7 +37,15 @@ def read_fasta_records(path_or_text: Union[str, Path], is_text: bool = False) ->
 def greedy_select(tokens: np.ndarray, num_seqs: int, mode: str = "max") -> np.ndarray:
     """Row indices (sorted) chosen by the reference's greedy max/min mean-Hamming rule
     (utils/align.py:128-148): start from row 0, repeatedly add the row whose mean normalised Hamming
-    distance to the rows chosen so far is largest (smallest), first index on ties."""
+    distance to the rows chosen so far is largest (smallest), first index on ties.
+
+    Candidates with equal mismatch totals are everywhere in real alignments (at step n the totals are integers below
+    n*L), and since m/L is inexact in float64 the winner among them is decided by the ORDER of the n additions.  The
+    reference takes `.mean(0)` of a [n, candidates] matrix whose reduction axis is the contiguous one (np.delete along
+    axis 1 hands back such a layout), i.e. numpy's pairwise summation: 8 interleaved accumulators up to 128 terms, halves
+    rounded to multiples of 8 above.  Keeping one float64 per (candidate, step) and reducing along the contiguous step
+    axis reproduces exactly that order, so the indices are the reference's (pinned on the shipped 1176-row 2DRB_1
+    alignment, where a running sum goes a different way at step 46)."""
     depth = tokens.shape[0]
     if depth <= num_seqs:
         return np.arange(depth)
@@ -46,12 +54,12 @@ def greedy_select(tokens: np.ndarray, num_seqs: int, mode: str = "max") -> np.nd
     chosen = [0]
     taken = np.zeros(depth, dtype=bool)
     taken[0] = True
-    dist_sum = np.zeros(depth, dtype=np.float64)
+    hist = np.empty((depth, num_seqs - 1), dtype=np.float64)        # [candidate, step]: step axis contiguous
     for step in range(1, num_seqs):
         last = body[chosen[-1]]
-        dist_sum += (body != last[None, :]).mean(1)
+        hist[:, step - 1] = (body != last[None, :]).mean(1)         # cdist(..., "hamming") = mismatches / L
         cand = np.flatnonzero(~taken)
-        best = cand[pick(dist_sum[cand] / step)]
+        best = cand[pick(hist[cand, :step].sum(1) / step)]
         chosen.append(int(best))
         taken[best] = True
     return np.array(sorted(chosen))

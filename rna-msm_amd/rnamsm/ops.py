@@ -266,7 +266,7 @@ def greedy_select(msa_u8: torch.Tensor, num_seqs: int, mode: str = "max") -> tor
         raise AssertionError(mode)
     N, L = msa_u8.shape
     lib = _lib.load()
-    ws = torch.empty(lib.rnamsm_greedy_select_workspace_bytes(N, num_seqs), dtype=torch.uint8, device=msa_u8.device)
+    ws = torch.empty(lib.rnamsm_greedy_select_workspace_bytes(N, L, num_seqs), dtype=torch.uint8, device=msa_u8.device)
     out = torch.empty(num_seqs, dtype=torch.int32, device=msa_u8.device)
     _lib.check(lib.rnamsm_greedy_select(_dev(msa_u8.contiguous(), "msa", torch.uint8), N, L, num_seqs,
                                         1 if mode == "min" else 0, _dev(out, "out", torch.int32), ws.data_ptr(),

@@ -146,3 +146,81 @@ def test_generic_mha_matches_reference(name):
     x = torch.from_numpy(synthetic.normal(f"mha:{name}", 11, (T, B, E)).astype(np.float32))
     y = O.multihead_self_attention(x, st, "layers.0.row_self_attention.layer", H)
     assert rel_l2(y, g["out"]) < 1e-5
+
+
+# ---------------------------------------------------------------------------- round-2 fixtures (make_golden_r2.py)
+def test_padded_batch_on_the_chunked_path_matches_reference(full_state):
+    """SURVEY §8 f2 "chunk quirk" (modules.py:717-750): with R*C > max_tokens_per_msa every row chunk is filled with
+    -10000 from ITS first row and the filled slabs are summed.  The fixture holds the reference's chunked AND direct
+    outputs of the same padded B=2 batch; they differ by 0.95 (a pad on a chunk-starting row masks that key) and by
+    3.6e-4 (an all-padded chunk start shifts every logit by -10000), so this pins both semantics of the oracle."""
+    g = golden("forward_padded_b2_chunked.npz")
+    params = O.to_torch_params(full_state)
+    mt = int(g["max_tokens"])
+    for b in range(2):
+        toks = torch.from_numpy(g["tokens"][b])
+        res = O.forward(toks, params, max_tokens=mt, force_mask=True)
+        assert rel_l2(res["representation"], g["rep10_chunked"][b]) < 3e-5
+        d = np.abs(res["row_attentions"].numpy() - g["row_attentions_chunked"][b])
+        if b == 0:
+            assert d.max() < 2e-5
+        else:
+            # element 1 has an all-padded chunk start: its logits carry -10000 and are quantised to fp32's 9.8e-4 step
+            # there, so any fp32 re-ordering upstream can flip a rounding: bounded by one step, and ~13x closer on
+            # average than the direct semantics are (8.6e-6)
+            assert d.max() < 1e-3 and d.mean() < 2e-6
+            assert d[0].max() == 0.0 or d[0].max() < 2e-6          # layer 0: same inputs, same quantisation
+        res = O.forward(toks, params, force_mask=True)
+        assert rel_l2(res["representation"], g["rep10_direct"][b]) < 1e-5
+        assert np.abs(res["row_attentions"].numpy() - g["row_attentions_direct"][b]).max() < 2e-5
+    d = np.abs(g["row_attentions_chunked"] - g["row_attentions_direct"])
+    assert d[0].max() > 0.5 and 1e-5 < d[1].max() < 1e-2          # where the two paths diverge, and by how much
+
+
+def test_oracle_bf16_mode_reproduces_the_reference_bf16_drift(full_state):
+    """BASELINE configs[4]'s yardstick: the reference model in .bfloat16() (fixture) against the fp64 run.  The oracle in
+    bf16 issues the same ATen calls (bf16 matmuls with fp32 accumulation, fp32-inside LayerNorm / softmax / GELU), so its
+    drift must be the reference's drift -- not bit-identical (einsum contraction order), but the same size."""
+    g, g64 = golden("forward_m16_c33_bf16.npz"), golden("forward_m16_c33_fp64.npz")
+    ref_emb, ref_atp = rel_l2(g["emb"], g64["emb"]), float(np.abs(g["atp"] - g64["atp"]).max())
+    assert 5e-3 < ref_emb < 5e-2 and 1e-2 < ref_atp < 3e-1        # SURVEY §6 measured 2.2e-2 / 9e-2
+    params = O.to_torch_params(full_state, torch.bfloat16)
+    emb, atp = O.pack_outputs(O.forward(torch.from_numpy(g["tokens"]), params))
+    assert emb.dtype == torch.bfloat16
+    o_emb = rel_l2(emb.float().numpy(), g64["emb"])
+    o_atp = float(np.abs(atp.float().numpy() - g64["atp"]).max())
+    assert 0.5 * ref_emb < o_emb < 2.0 * ref_emb, (o_emb, ref_emb)
+    assert 0.4 * ref_atp < o_atp < 2.5 * ref_atp, (o_atp, ref_atp)
+    assert rel_l2(emb.float().numpy(), g["emb"]) < 3.0 * ref_emb
+
+
+@pytest.mark.parametrize("name", ["t37_b3_e128", "t70_b2_e768"])
+def test_generic_mha_weights_and_key_padding_mask_match_reference(name):
+    """msm/multihead_attention.py:154-397 as msm/modules.py:123-131 calls it: need_weights=True (the default) returns the
+    head-averaged probabilities [B,T,T]; need_head_weights the per-head ones [H,B,T,T]; key_padding_mask [B,T]."""
+    g = golden(f"mha_masks_{name}.npz")
+    T, B, E, H = (int(v) for v in g["meta"])
+    st = O.to_torch_params(synthetic.make_state_dict(seed=11, embed_dim=E, num_layers=1, num_heads=H))
+    x = torch.from_numpy(synthetic.normal(f"mha:{name}", 11, (T, B, E)).astype(np.float32))
+    pre = "layers.0.row_self_attention.layer"
+    y, w = O.multihead_self_attention(x, st, pre, H, return_weights=True)
+    assert rel_l2(y, g["out_default"]) < 1e-5 and np.abs(w.mean(0).numpy() - g["avg_weights_default"]).max() < 2e-6
+    kpm = torch.from_numpy(g["key_padding_mask"])
+    y, w = O.multihead_self_attention(x, st, pre, H, key_padding_mask=kpm, return_weights=True)
+    assert rel_l2(y, g["out_masked"]) < 1e-5
+    assert w.shape == g["head_weights_masked"].shape and np.abs(w.numpy() - g["head_weights_masked"]).max() < 2e-6
+    assert np.abs(w.mean(0).numpy() - g["avg_weights_masked"]).max() < 2e-6
+    assert float(w[:, 0, :, T - 5:].max()) == 0.0 and float(w[:, B - 1, :, 3].max()) == 0.0
+
+
+def test_full_2drb1_alignment_tokens_and_default_subsampling_bit_exact():
+    """BASELINE configs[0] at full depth: the shipped 1176-row alignment through the reader, then `diversity-max` to the
+    CLI default of 512 rows (utils/align.py:128-148) -- tokens bit-exact with the reference's."""
+    g = golden("tokens_2DRB_1_full.npz")
+    text = open(os.path.join(GOLDEN, "2DRB_1.a2m_msa2")).read()
+    toks = TO.encode_msa(text)
+    assert toks.shape == tuple(g["depth_seqlen"]) == (1176, 36)
+    assert np.array_equal(toks[:512], g["first_512"])
+    from rnamsm.msa import greedy_select
+    sel = greedy_select(toks, 512, "max")
+    assert np.array_equal(toks[sel], g["diversity_max_512"])
