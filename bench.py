@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: MSA-residues/s for the full 10-layer forward (emb + attention maps).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload configs2|configs3]
 
-A step = one pass of the hot path (K0..K10 through rnamsm_forward) over one synthetic MSA per GPU, inputs and
-weights already resident in HBM, plus (N > 1) the RCCL gather of that step's emb/atp arrays to rank 0, overlapped
-with the next step.  Workload = BASELINE.json configs[2]: M=256 sequences x L=512 columns (column 0 is <cls>),
-D=768, 12 heads, 10 layers, fp32 (exact-fp32 MFMA), random-init weights of that architecture (rnamsm.synthetic).
-Rank 0 prints ONE JSON line; `roofline` is the Linear GEMM kernel (89 % of the flops) measured live with HIP events
-on the launch stream during the timed steps; `cpu_baseline` is the oracle (PyTorch-CPU restatement of the
-reference) timed on this host's cores on a bounded sample (one of the ten layers of the same M x L MSA).
-`fast_mode` / `bf16_mode` are extra measurements of the same workload with every contraction on the 16-bit matrix
-cores (f16x3: fp16 hi/lo-split operands, fp32-grade; bf16: BASELINE config 4's precision), each with its deviation
-from the exact path; they never replace `value`.
+With N > 1 and no launcher environment this process (which makes no GPU call) starts the N ranks itself, one per
+GPU, and exits with their status; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
+it runs as one rank.  Ranks talk over RCCL (backend "nccl"); rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json `configs`):
+  configs2 (default, the metric's config): one synthetic MSA of M=256 x L=512 per GPU per step -- weak scaling.
+  configs3: a batch of 512 synthetic MSAs of M=128 x L=256 dealt round-robin over the ranks
+            (rnamsm.sharding.shard_indices), a step = one pass over the whole batch -- strong scaling.
+A step = the hot path (K0..K10 through rnamsm_forward) over the step's MSAs, inputs and weights already resident in
+HBM, plus (N > 1) the gather of every emb/atp pair to rank 0 with rnamsm.sharding.RoundGatherer (point-to-point RCCL,
+round k's transfers overlapping round k+1's forward) -- the same gather the CLI uses.
+
+Three separate loops: W warm-up steps; the HEADLINE loop of exactly K steps with the per-kernel timing hooks off
+(`value`, `ms_per_step`); then a ROOFLINE pass over the same work with HIP-event pairs around every launch on the
+launch stream (`roofline`, `kernel_ms_per_step`) -- the headline never pays for the instrumentation.
+`cpu_baseline` (N = 1) is the oracle (PyTorch-CPU restatement of the reference) on this host's cores at the best
+thread count of a sweep.  `fast_mode` / `bf16_mode` are extra measurements of the same workload with every
+contraction on the 16-bit matrix cores; they never replace `value`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,13 +35,76 @@ for p in (os.path.join(ROOT, "rna-msm_amd"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np
-import torch
-
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16/f16 MFMA (no sparsity)
+WORKLOADS = {"configs2": "configs2", "configs[2]": "configs2", "single": "configs2",
+             "configs3": "configs3", "configs[3]": "configs3", "cfg3": "configs3", "batch512": "configs3"}
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 8; configs3: 1 pass over the batch)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 2; configs3: 1 short pass)")
+    ap.add_argument("--workload", default="configs2", choices=sorted(WORKLOADS))
+    ap.add_argument("--num-seqs", type=int, default=None, help="M (default 256; configs3: 128)")
+    ap.add_argument("--seq-len", type=int, default=None, help="L, columns including <cls> (default 512; configs3: 256)")
+    ap.add_argument("--num-msas", type=int, default=512, help="configs3: MSAs in the batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the output gather to rank 0 (N > 1)")
+    ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "f16x3", "bf16x3", "bf16"],
+                    help="arithmetic of the contractions for the headline value (default: exact fp32)")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16x3 / bf16 measurements")
+    ap.add_argument("--digest", action="store_true",
+                    help="report an order-independent bit digest of every gathered output (N=1 and N=2 must agree)")
+    ap.add_argument("--backend", default=os.environ.get("RNAMSM_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="test hook: gloo stages the gather through host memory (RCCL refuses two ranks on one device)")
+    ap.add_argument("--one-device", action="store_true", default=os.environ.get("RNAMSM_BENCH_ONE_DEVICE") == "1",
+                    help="test hook: every rank on device 0 (exercises the N > 1 flow on a one-GPU box)")
+    args = ap.parse_args(argv)
+    args.workload = WORKLOADS[args.workload]
+    batch = args.workload == "configs3"
+    args.num_seqs = args.num_seqs or (128 if batch else 256)
+    args.seq_len = args.seq_len or (256 if batch else 512)
+    args.steps = args.steps if args.steps is not None else (1 if batch else 8)
+    args.warmup = args.warmup if args.warmup is not None else (1 if batch else 2)
+    return args
+
+
+# --------------------------------------------------------------------------------------------- launcher (no GPU call)
+def launch_ranks(args) -> int:
+    """Start one rank per GPU as child processes and wait for them.  This parent has not touched the GPU (importing
+    torch or counting devices does not initialise HIP), so starting children is safe; nothing is ever re-exec'ed."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in live:                  # a rank died: its peers would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc if rc >= 0 else 1
+
+
+# --------------------------------------------------------------------------------------------- helpers
 def flops_per_msa(M, L, D=768, layers=10):
     """per token per layer 32 D^2 (8 proj + 2 FFN GEMMs) + 4 D (M + L) (row + column QK^T / PV)."""
     return layers * (32 * D * D + 4 * D * (M + L)) * M * L
@@ -60,95 +131,154 @@ def pmc_traffic_per_launch(kernel_prefix="rnamsm::gemm_f32_kernel"):
     return (tot / n if n else None), os.path.basename(files[-1])
 
 
-def cpu_baseline(M, L, state, budget_note):
-    """Oracle (port of the reference) on the host cores: ONE of the ten layers of the same M x L MSA (embedding and
-    final LayerNorm included), extrapolated x10 -- the layers are identical in cost."""
+def host_cpu_info():
+    """(model name, physical cores, logical CPUs) from /proc/cpuinfo."""
+    model, cores = "unknown", set()
+    phys = core = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, (len(cores) or logical), logical
+
+
+def cpu_baseline(M, L, state):
+    """The oracle (port of the reference) on the host's cores.  torch's intra-op pool is swept over
+    {physical cores, 1/2, 1/4, 64, 32, 16, 8} on one layer of the M=64 x L=128 MSA (BASELINE configs[1]); at the best
+    setting: the complete 10-layer configs[1] forward, then ONE full layer of this bench's M x L MSA (embedding and
+    final LayerNorm included), x10 -- the ten layers are identical in cost -- which is `value`."""
+    import torch
     from oracle import msm_oracle as O
     from rnamsm import synthetic
-    torch.set_num_threads(os.cpu_count() or 1)
+    model, physical, logical = host_cpu_info()
     params = O.to_torch_params(state)
-    toks = torch.from_numpy(synthetic.make_tokens(M, L, 0))
+    small = torch.from_numpy(synthetic.make_tokens(64, 128, 0))
+    sweep = {}
     with torch.no_grad():
+        torch.set_num_threads(min(physical, logical))
+        O.forward(small, params, layers_to_run=1)                      # page the weights in, spin the pool up
+        for n in sorted({physical, physical // 2, physical // 4, 64, 32, 16, 8}, reverse=True):
+            if n < 1 or n > logical:
+                continue
+            torch.set_num_threads(n)
+            O.forward(small, params, layers_to_run=1)
+            t0 = time.perf_counter()
+            O.forward(small, params, layers_to_run=1)
+            sweep[n] = time.perf_counter() - t0
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(best)
+        t0 = time.perf_counter()
+        O.forward(small, params)
+        t_cfg1 = time.perf_counter() - t0
+        toks = torch.from_numpy(synthetic.make_tokens(M, L, 0))
         t0 = time.perf_counter()
         O.forward(toks, params, layers_to_run=1)
         dt = time.perf_counter() - t0
-    return {"value": M * L / (10.0 * dt), "unit": "MSA-residues/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/msm_oracle.py forward, 1 of 10 layers of one M={M} L={L} MSA in {dt:.1f} s, x10 "
-                      f"extrapolated; torch {torch.__version__} CPU fp32, {budget_note}"}
+    return {"value": M * L / (10.0 * dt), "unit": "MSA-residues/s", "cores": best, "kind": "port",
+            "cpu_model": model, "physical_cores": physical, "logical_cpus": logical,
+            "thread_sweep_s_per_layer_M64_L128": {str(k): round(v, 4) for k, v in sweep.items()},
+            "configs1_full_forward": {"M": 64, "L": 128, "seconds": round(t_cfg1, 3), "residues_per_s": 64 * 128 / t_cfg1},
+            "sample": f"oracle/msm_oracle.py on {model} ({physical} cores / {logical} threads), torch {torch.__version__} "
+                      f"CPU fp32 with {best} intra-op threads (fastest of the sweep): 1 of 10 layers of one M={M} L={L} "
+                      f"MSA in {dt:.2f} s, x10 extrapolated; the complete 10-layer M=64 L=128 forward took {t_cfg1:.2f} s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--num-seqs", type=int, default=256, help="M (BASELINE configs[2])")
-    ap.add_argument("--seq-len", type=int, default=512, help="L, columns including <cls>")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL output gather (N > 1)")
-    ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "f16x3", "bf16x3", "bf16"],
-                    help="arithmetic of the Linear GEMMs for the headline value (default: exact fp32)")
-    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16x3 measurement")
-    args = ap.parse_args()
-
+# --------------------------------------------------------------------------------------------- one rank
+def run_rank(args) -> int:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (must precede HIP init)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    import numpy as np  # noqa: F401
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device: there is no CPU path"
-    # Test hooks for exercising the N > 1 control flow on a one-GPU box (never set by the driver): every rank on
-    # device 0 and a gloo process group instead of RCCL (which refuses two ranks on one device).
-    one_device = os.environ.get("RNAMSM_BENCH_ONE_DEVICE") == "1"
-    backend = os.environ.get("RNAMSM_BENCH_BACKEND", "nccl")
-    dev_index = 0 if one_device else local_rank
+    dev_index = 0 if args.one_device else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    dist = None
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
+        if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from rnamsm import _lib, synthetic
+    if os.environ.get("RNAMSM_BENCH_FAIL_RANK") == str(rank):       # test hook: a rank that dies must fail the whole run
+        raise SystemExit(f"rank {rank}: RNAMSM_BENCH_FAIL_RANK")
+    from rnamsm import _lib, sharding, synthetic
     from rnamsm.model import MSATransformer
     lib = _lib.load()
 
     M, L = args.num_seqs, args.seq_len
+    batch = args.workload == "configs3"
     state = synthetic.make_state_dict(seed=0)
     model = MSATransformer(num_layers=10)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
     model = model.eval().to(dev)
     model.gemm_dtype = args.gemm_dtype
-    # one synthetic MSA per step and rank, already resident in HBM (seed 1234 + global index)
-    n_total = args.warmup + args.steps
-    toks = [torch.from_numpy(synthetic.make_tokens(M, L, rank + world * i)).to(dev) for i in range(n_total)]
+    model.check_finite = False                    # a host sync per MSA; the bench checks finiteness once, below
+
+    # ---- the step's work list: global MSA indices of this rank, tokens already resident in HBM (seed 1234 + index)
+    if batch:
+        per_step = args.num_msas                                  # strong scaling: the batch is fixed, ranks share it
+        warm_items = min(per_step, 2 * world)                     # a warm-up "step" is a short pass (2 MSAs per rank)
+        distinct = per_step
+    else:
+        per_step = world                                          # weak scaling: one MSA per GPU per step
+        warm_items = world
+        distinct = world * (args.warmup + args.steps)
+    mine_all = sharding.shard_indices(distinct, rank, world)
+    toks = {i: torch.from_numpy(synthetic.make_tokens(M, L, i)).to(dev) for i in mine_all}
+
+    def step_items(step_no):
+        """Global item indices of one step, and the index of the MSA (token set) behind each."""
+        if batch:
+            return [(i, i) for i in range(per_step)]
+        return [(r, step_no * world + r) for r in range(world)]
 
     gather = world > 1 and not args.no_gather
-    gather_note = "none (single GPU)" if world == 1 else "disabled by flag"
-    recv = None
-    if gather:
-        # Probe the RCCL gather once, outside the timed region; if the fabric refuses it the bench still measures
-        # the sharded compute and says so, instead of dying inside the timed loop.
-        try:
-            if rank == 0:
-                recv = [[torch.empty(L - 1, 768, device=dev), torch.empty(120, L - 1, L - 1, device=dev)]
-                        for _ in range(world)]
-            probe = [torch.zeros(L - 1, 768, device=dev), torch.zeros(120, L - 1, L - 1, device=dev)]
-            for j, t in enumerate(probe):
-                dist.gather(t, [r[j] for r in recv] if rank == 0 else None, dst=0)
-            torch.cuda.synchronize()
-            ok = torch.ones(1, device=dev)
-        except Exception as e:                                        # noqa: BLE001
-            ok = torch.zeros(1, device=dev)
-            gather_note = f"failed in probe: {type(e).__name__}: {e}"
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        gather = bool(ok.item() > 0)
-        if gather:
-            gather_note = "RCCL gather of emb+atp to rank 0 every step, overlapped with the next step"
+    digest = torch.zeros((), dtype=torch.int64, device=dev)
+    delivered = [0]
+
+    def on_item(base, index, tensors):
+        nonlocal digest
+        delivered[0] += 1
+        if args.digest:
+            for t in tensors:
+                digest = digest + (base + index + 1) * t.contiguous().view(torch.int32).to(torch.int64).sum()
+
+    def run_step(step_no, items=None, use_gather=True):
+        """One step: forward of this rank's MSAs (+ gather to rank 0)."""
+        items = step_items(step_no) if items is None else items
+        base = step_no * 1000003
+        g = None
+        if (gather and use_gather) or (args.digest and world == 1):
+            g = sharding.RoundGatherer(len(items), on_item=lambda i, ts: on_item(base, i, ts), tensors_per_item=2,
+                                       dst=0, device=dev)
+        for pos, msa in items:
+            if sharding.owner_of(pos, world) != rank:
+                continue
+            out = model.forward_one(toks[msa], has_padding=False)
+            if g is not None:
+                g.submit(pos, (out["emb"], out["atp"]))
+        if g is not None:
+            g.finish()
+        return len(items)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -156,86 +286,91 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pending = []
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        if args.backend != "nccl":
+            t = t.cpu()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    def step(i):
-        out = model.forward_one(toks[i])
-        if gather:
-            # emb/atp of this step go to rank 0 over RCCL while the next step computes
-            for w in pending:
-                w.wait()
-            pending.clear()
-            for j, t in enumerate((out["emb"], out["atp"])):
-                pending.append(dist.gather(t, [r[j] for r in recv] if rank == 0 else None, dst=0, async_op=True))
-        return out
+    # ---- warm-up (untimed), then the headline loop: exactly K steps, timing hooks off
+    for w in range(args.warmup):
+        run_step(w, items=step_items(w)[:warm_items] if batch else None)
+    sync_all()
+    digest.zero_()
+    delivered[0] = 0
+    msas_timed = 0
+    lib.rnamsm_timing_enable(0)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        msas_timed += run_step(args.warmup + k if not batch else k)
+    sync_all()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    headline_digest = int(digest.item()) if args.digest else None
+    headline_delivered = delivered[0]
 
-    for i in range(args.warmup):
-        step(i)
-    for w in pending:
-        w.wait()
-    pending.clear()
+    # ---- roofline pass: the same work with HIP-event pairs around every launch (no gather: kernels only)
+    roof_items = None
+    roof_steps = args.steps
+    if batch:
+        roof_items = step_items(0)[:max(world, min(per_step, 8 * world))]
+        roof_steps = 1
     sync_all()
     lib.rnamsm_timing_reset()
     lib.rnamsm_timing_enable(1)
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_total):
-        step(i)
-    for w in pending:
-        w.wait()
-    pending.clear()
+    t1 = time.perf_counter()
+    roof_msas = 0
+    for k in range(roof_steps):
+        roof_msas += run_step(args.warmup + k if not batch else 0, items=roof_items, use_gather=False)
     sync_all()
-    elapsed = time.perf_counter() - t0
+    roof_elapsed = time.perf_counter() - t1
     lib.rnamsm_timing_enable(0)
     timings = _lib.kernel_timings()
+    roof_local = max(1, len([1 for k in range(roof_steps) for pos, _ in (roof_items or step_items(0))
+                             if sharding.owner_of(pos, world) == rank]))
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # Extra measurement (never the headline): the same workload with the Linear GEMMs on the fp16 matrix cores in
-    # hi/lo-split form ("f16x3", ~22-bit operands, fp32 accumulate), plus its deviation from the exact path on the
-    # same MSA, measured here and now.
-    fast = None
-    bf16_mode = None
-    if args.gemm_dtype == "f32" and not args.no_fast_mode:
-        ref = model.forward_one(toks[0])
+    # ---- extra modes (N = 1, default workload): every contraction on the 16-bit matrix cores
+    fast = bf16_mode = None
+    first = toks[mine_all[0]]
+    if args.gemm_dtype == "f32" and not args.no_fast_mode and world == 1 and not batch:
+        ref = model.forward_one(first)
         ref_emb, ref_atp = ref["emb"].clone(), ref["atp"].clone()
         # yardstick: the exact path against ITSELF when alignment rows 1.. are permuted (mathematically a no-op for row
-        # 0's embedding and the tied maps; only fp32 summation order changes).  At M=256 the synthetic weights make the
-        # problem ill-conditioned enough that this pure re-ordering noise is the floor any arithmetic can be held to.
-        perm = torch.cat([torch.zeros(1, dtype=torch.long), 1 + torch.randperm(M - 1, generator=torch.Generator().manual_seed(0))]).to(dev)
-        per = model.forward_one(toks[0][perm])
+        # 0's embedding and the tied maps; only fp32 summation order changes)
+        perm = torch.cat([torch.zeros(1, dtype=torch.long),
+                          1 + torch.randperm(M - 1, generator=torch.Generator().manual_seed(0))]).to(dev)
+        per = model.forward_one(first[perm])
         noise_emb = float(((per["emb"] - ref_emb).double().norm() / ref_emb.double().norm()).item())
         noise_atp = float((per["atp"] - ref_atp).abs().max().item())
 
         def measure_mode(mode, mult):
             model.gemm_dtype = mode
-            out = model.forward_one(toks[0])
+            out = model.forward_one(first)
             dev_emb = float(((out["emb"] - ref_emb).double().norm() / ref_emb.double().norm()).item())
             dev_atp = float((out["atp"] - ref_atp).abs().max().item())
             dev_atp_mean = float((out["atp"] - ref_atp).abs().mean().item())
-            for i in range(args.warmup):
+            for i in mine_all[:args.warmup]:
                 model.forward_one(toks[i])
             sync_all()
+            t2 = time.perf_counter()
+            for i in mine_all[args.warmup:]:
+                model.forward_one(toks[i])
+            sync_all()
+            el2 = time.perf_counter() - t2
             lib.rnamsm_timing_reset()
             lib.rnamsm_timing_enable(1)
-            t1 = time.perf_counter()
-            for i in range(args.warmup, n_total):
+            for i in mine_all[args.warmup:]:
                 model.forward_one(toks[i])
             sync_all()
-            el2 = time.perf_counter() - t1
             lib.rnamsm_timing_enable(0)
             tim2 = _lib.kernel_timings()
             model.gemm_dtype = "f32"
-            if world > 1:
-                t = torch.tensor([el2], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el2 = float(t.item())
             g2 = tim2["gemm_f32"]
             raw = mult * g2["flops"] / (g2["ms"] * 1e-3) / 1e12 if g2["ms"] > 0 else 0.0
-            return {"gemm_dtype": mode, "value": world * args.steps * M * L / el2, "unit": "MSA-residues/s",
-                    "ms_per_step": 1e3 * el2 / args.steps, "gather": "not included",
+            return {"gemm_dtype": mode, "value": args.steps * M * L / el2, "unit": "MSA-residues/s",
+                    "ms_per_step": 1e3 * el2 / args.steps,
                     "deviation_from_f32_path": {"emb_rel_l2": dev_emb, "atp_max_abs": dev_atp, "atp_mean_abs": dev_atp_mean},
                     "roofline": {"bound": "mfma", "kernel": f"gemm16_swp_kernel<split {int(mult)}, {'fp16' if mode == 'f16x3' else 'bf16'}>",
                                  "achieved": raw, "peak": F16_MFMA_PEAK_TFLOPS,
@@ -244,22 +379,18 @@ def main():
                     "attention": "16-bit kernels (row_logits16 / row_apply16 / col_attn16, same operand format)",
                     "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in tim2.items()}}
 
-        # Extra measurements (never the headline): the same workload with every contraction on the 16-bit matrix cores.
-        # f16x3 = fp16 hi/lo-split operands (~22 bits, fp32 accumulate): fp32-grade; bf16 = plain bf16 operands, the
-        # precision BASELINE config 4 is quoted at.  Each with its deviation from the exact path on the same MSA.
         fast = measure_mode("f16x3", 3.0)
         fast["f32_path_reordering_noise"] = {"emb_rel_l2": noise_emb, "atp_max_abs": noise_atp,
                                              "what": "exact path vs itself with alignment rows 1.. permuted"}
         bf16_mode = measure_mode("bf16", 1.0)
-        bf16_mode["note"] = ("plain bf16 operands (2^-9): at this depth the synthetic weights make the softmaxes sharp, so "
-                             "single map entries can flip (max-abs ~1) while the mean deviation stays small; against the "
-                             "reference fixtures and the M=64 oracle case bf16 is at the reference's own bf16 drift "
-                             "(DESIGN.md 3.1b)")
+        bf16_mode["accuracy"] = ("tests/test_gpu_fullsize.py holds this mode to 1.5x the drift of the reference's own "
+                                 ".bfloat16() arithmetic against an fp64 truth at every BASELINE size "
+                                 "(profiles/r02_fullsize_parity.json)")
 
+    finite = bool(torch.isfinite(model.forward_one(first)["emb"]).all())
     if rank == 0:
-        residues = world * args.steps * M * L
+        residues = msas_timed * M * L
         g = timings["gemm_f32"]
-        # executed MFMA flops per algorithmic flop and the matrix-core peak of the mode actually timed
         mult = {"f32": 1.0, "bf16": 1.0, "bf16x3": 3.0, "f16x3": 3.0}[args.gemm_dtype]
         peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_dtype == "f32" else F16_MFMA_PEAK_TFLOPS
         gemm_kernel = {"f32": "gemm_f32_kernel (nn.Linear, K2)", "bf16": "gemm16_swp_kernel<split 1, bf16> (nn.Linear, K2)",
@@ -271,21 +402,37 @@ def main():
         attn_fl = mult * sum(timings[k]["flops"] for k in ("row_logits", "row_apply", "col_attn"))
         kern_ms = sum(v["ms"] for v in timings.values())
         traffic, traffic_src = pmc_traffic_per_launch() if (args.gemm_dtype == "f32" and (M, L) == (256, 512)) else (None, None)
+        if world == 1:
+            gather_note = "none (single GPU)"
+        elif not gather:
+            gather_note = "disabled by flag"
+        else:
+            gather_note = (f"rnamsm.sharding.RoundGatherer: emb+atp of every MSA to rank 0 over "
+                           f"{'RCCL point-to-point' if args.backend == 'nccl' else args.backend + ' (host-staged)'}, "
+                           f"round k overlapping the forward of round k+1; {headline_delivered} MSAs delivered in the timed region")
+        base_cfg = "configs[3]" if batch else "configs[2]"
         result = {
             "metric": f"MSA-residues/sec forward (emb+attn-map), M={M} L={L}",
             "value": residues / elapsed,
             "unit": "MSA-residues/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if batch else "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "f16x3": "f16x3 (fp16 hi/lo split, f32 accumulate)", "bf16x3": "bf16x3", "bf16": "bf16"}[args.gemm_dtype],
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: synthetic MSA M={M} x L={L} (col 0 = <cls>), D=768 H=12 "
-                                   f"10 layers, one MSA per GPU per step, emb+atp outputs"
-                                   + (", RCCL gather to rank 0" if gather else ""),
+            "config": {"workload": (f"BASELINE {base_cfg}: " + (f"batch of {per_step} synthetic MSAs" if batch else "synthetic MSA")
+                                    + f" M={M} x L={L} (col 0 = <cls>), D=768 H=12 10 layers, "
+                                    + ("dealt round-robin over the ranks, a step = one pass over the batch" if batch
+                                       else "one MSA per GPU per step") + ", emb+atp outputs"
+                                    + (", gathered to rank 0" if gather else "")),
                        "gather": gather_note,
-                       "num_seqs": M, "seq_len": L, "msas_per_step": world, "sharding": f"independent MSAs x{world}"},
-            "model_tflops": flops_per_msa(M, L) * world * args.steps / elapsed / 1e12,
+                       "num_seqs": M, "seq_len": L, "msas_per_step": per_step, "sharding": f"independent MSAs over {world} rank(s)",
+                       "world_size_initialised": dist.get_world_size() if world > 1 else 1,
+                       "backend": ("nccl (RCCL)" if args.backend == "nccl" else args.backend) if world > 1 else "none",
+                       "devices": "all ranks on device 0 (test hook)" if args.one_device and world > 1 else "one per rank",
+                       "warmup_note": (f"a warm-up step is a pass over the first {warm_items} MSAs of the batch" if batch else "full steps")},
+            "outputs_finite": finite,
+            "model_tflops": flops_per_msa(M, L) * msas_timed / elapsed / 1e12,
             "roofline": {"bound": "mfma", "kernel": gemm_kernel,
                          "achieved": gemm_tflops, "peak": peak, "unit": flop_unit,
                          "frac": gemm_tflops / peak,
@@ -293,22 +440,36 @@ def main():
                          "flops_per_launch": g["flops"] / max(1, g["launches"]),
                          "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side, PMC)",
                          "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"])},
+                         "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"]),
+                         "measured_in": f"separate pass after the headline loop, HIP-event pairs on the launch stream, "
+                                        f"{roof_local} MSA(s) on rank 0 in {roof_elapsed:.3f} s"},
             "attention_mfma": {"kernels": "row_logits+row_apply+col_attn", "achieved": attn_fl / (attn_ms * 1e-3) / 1e12 if attn_ms else 0.0,
                                "peak": peak, "unit": flop_unit,
                                "frac": (attn_fl / (attn_ms * 1e-3) / 1e12 / peak) if attn_ms else 0.0},
-            "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in timings.items()},
-            "kernel_time_share_of_step": kern_ms / args.steps / (1e3 * elapsed / args.steps),
+            "kernel_ms_per_msa": {k: v["ms"] / roof_local for k, v in timings.items()},
+            "kernel_time_share_of_roofline_pass": kern_ms / (1e3 * roof_elapsed),
         }
+        if args.digest:
+            result["output_digest"] = {"value": headline_digest, "items": headline_delivered,
+                                       "what": "sum over gathered outputs of (step*1000003 + item + 1) * sum(int32 bit patterns), mod 2^64"}
         if fast is not None:
             result["fast_mode"] = fast
             result["bf16_mode"] = bf16_mode
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline(M, L, state, f"{os.cpu_count()} logical CPUs on this host")
-        print(json.dumps(result))
+            result["cpu_baseline"] = cpu_baseline(M, L, state)
+        print(json.dumps(result), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def main() -> int:
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

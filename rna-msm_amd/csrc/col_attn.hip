@@ -250,12 +250,12 @@ extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float
     KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)R * R * CA_HD, 4.0 * 4.0 * R * C * H * CA_HD, s);
 #define CA_GO(M_, OUT_)                                                                                             \
     do {                                                                                                            \
-        static bool cfg_ = false;                                                                                   \
-        if (!cfg_) {                                                                                                \
+        static DeviceOnce cfg_;                                                                                   \
+        if (cfg_.pending()) {                                                                                                \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn_kernel<M_, OUT_>),            \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, CA_LDS_BYTES);           \
             if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
-            cfg_ = true;                                                                                            \
+            cfg_.mark();                                                                                            \
         }                                                                                                           \
         hipLaunchKernelGGL((col_attn_kernel<M_, OUT_>), dim3(grid), dim3(CA_THREADS), CA_LDS_BYTES, s, q, k, v, ld, ctx, \
                            ldc, R, C, H, pad_mask, ctx_hi, ctx_lo);                                                 \

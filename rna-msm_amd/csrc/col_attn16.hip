@@ -246,12 +246,12 @@ extern "C" int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, con
     } while (0)
 #define CA_GO2(SP_, FMT_, OUT_, MASK_)                                                                              \
     do {                                                                                                            \
-        static bool cfg_ = false;                                                                                   \
-        if (!cfg_) {                                                                                                \
+        static DeviceOnce cfg_;                                                                                   \
+        if (cfg_.pending()) {                                                                                                \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn16_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64), MASK_>),   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);                    \
             if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn16: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
-            cfg_ = true;                                                                                            \
+            cfg_.mark();                                                                                            \
         }                                                                                                           \
         hipLaunchKernelGGL((col_attn16_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64), MASK_>), dim3(grid), dim3(C16_THREADS), lds, s, q_hi, q_lo, k_hi, \
                            k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, scale, pad_mask);               \

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/rnamsm.h"
 
@@ -54,6 +55,25 @@ struct Tuning {
     int attn16 = 1;                // 16-bit modes of rnamsm_forward: 1 = attention contractions on the 16-bit matrix cores too, 0 = fp32 attention
 };
 Tuning& tuning();
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the (function, DEVICE) pair, so "already configured" is
+// remembered per device of the calling thread, not per process (a process may drive several GPUs: data.device=cuda:1,
+// or a helper thread whose current device differs).  Racing threads may both configure -- the call is idempotent.
+struct DeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    static int current() {
+        int d = -1;
+        return hipGetDevice(&d) == hipSuccess ? d : -1;
+    }
+    bool pending() const {
+        const int d = current();
+        return d < 0 || d >= 64 || !((mask.load(std::memory_order_acquire) >> d) & 1ull);
+    }
+    void mark() {
+        const int d = current();
+        if (d >= 0 && d < 64) mask.fetch_or(1ull << d, std::memory_order_release);
+    }
+};
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -374,13 +374,13 @@ template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
 static int launch_hd(const uint16_t* Whi, const uint16_t* Wlo, const float* bias, const float* residual, int64_t ldr,
                      float* Cout, int64_t ldc, int64_t lda, int M, int N, int K, float scale, int scale_cols,
                      const uint16_t* a_hi, const uint16_t* a_lo, uint16_t* o_hi, uint16_t* o_lo, hipStream_t stream) {
-    static bool configured = false;
+    static DeviceOnce configured;
     auto kern = gemm16_dma_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL>;
     constexpr int lds = HdCfg<SPLIT>::LDS;
-    if (!configured) {
+    if (configured.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_dma: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
+        configured.mark();
     }
     const unsigned grid = xcd_panel_grid((M + HB_BM - 1) / HB_BM, N / HB_BN);
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 2.0 * HdCfg<SPLIT>::NPL * ((double)M * K + (double)N * K) + 4.0 * (double)M * N * (HAS_RES ? 2 : 1), stream);
@@ -517,13 +517,13 @@ template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
 static int launch_hx(const uint16_t* Whi, const uint16_t* Wlo, const float* bias, const float* residual, int64_t ldr,
                      float* Cout, int64_t ldc, int64_t lda, int M, int N, int K, float scale, int scale_cols,
                      const uint16_t* a_hi, const uint16_t* a_lo, uint16_t* o_hi, uint16_t* o_lo, hipStream_t stream) {
-    static bool configured = false;
+    static DeviceOnce configured;
     auto kern = gemm16_dma256_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL>;
     constexpr int lds = HxCfg<SPLIT>::LDS;
-    if (!configured) {
+    if (configured.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_dma256: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
+        configured.mark();
     }
     const unsigned grid = xcd_panel_grid((M + HX_BM - 1) / HX_BM, N / HX_BN);
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 2.0 * HxCfg<SPLIT>::NPL * ((double)M * K + (double)N * K) + 4.0 * (double)M * N * (HAS_RES ? 2 : 1), stream);
@@ -695,13 +695,13 @@ template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL, int BK>
 static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias, const float* residual, int64_t ldr,
                      float* Cout, int64_t ldc, int64_t lda, int M, int N, int K, float scale, int scale_cols,
                      const uint16_t* a_hi, const uint16_t* a_lo, uint16_t* o_hi, uint16_t* o_lo, hipStream_t stream) {
-    static bool configured = false;
+    static DeviceOnce configured;
     auto kern = gemm16_swp_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL, BK>;
     constexpr int lds = HsCfg<SPLIT, BK>::LDS;
-    if (!configured) {
+    if (configured.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_swp: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
+        configured.mark();
     }
     // block order as in gemm_f32.hip: 32 blocks are resident per XCD; for the wide GEMMs (QKV 9, fc1 12 column blocks)
     // groups of 8 row panels keep a W slab shared by 8 panels instead of ~3: +5..6% (split 3), +7..10% (split 1),
@@ -788,13 +788,13 @@ template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool A_PL = false, bool O_P
 static int launch_hb(const float* A, int64_t lda, const uint16_t* Whi, const uint16_t* Wlo, const float* bias,
                      const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale,
                      int scale_cols, HbPlanes pl, hipStream_t stream) {
-    static bool configured = false;
+    static DeviceOnce configured;
     auto kern = gemm_bf16_kernel<ACT, HAS_RES, SPLIT, FMT, A_PL, O_PL>;
     constexpr int lds = HbCfg<SPLIT>::LDS;
-    if (!configured) {
+    if (configured.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm_bf16: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
+        configured.mark();
     }
     const unsigned grid = xcd_panel_grid((M + HB_BM - 1) / HB_BM, N / HB_BN);
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + 0.5 * HbCfg<SPLIT>::NPL * (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);

@@ -139,13 +139,13 @@ static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const flo
                           int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
                           const uint8_t* zero_rows, hipStream_t stream) {
     using Cfg = GemmCfg<NT>;
-    static bool configured = false;
+    static DeviceOnce configured;
     auto kern = gemm_f32_kernel<ACT, HAS_RES, ZROWS, NT>;
-    if (!configured) {
+    if (configured.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured = true;
+        configured.mark();
     }
     // Block order (speed/traffic only): 64 blocks are resident per XCD.  With more than 8 column blocks per row panel a
     // whole-panel order keeps only 64/nb panels in flight and re-streams W (7-9 MB > the 4 MB L2) for each of them;

@@ -289,11 +289,11 @@ extern "C" int rnamsm_row_logits(const float* q, const float* k, int64_t ld, flo
     RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0, "row_logits: bad shape R=%d C=%d H=%d", R, C, H);
     RNAMSM_CHECK_ARG(ld >= (int64_t)H * HEAD_DIM && ld % 4 == 0 && aligned16(q) && aligned16(k),
                      "row_logits: q/k must be 16-byte aligned with ld %% 4 == 0");
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce configured;
+    if (configured.pending()) {
         int rc = set_lds(row_logits_kernel, ROWLOGITS_LDS_BYTES, "row_logits");
         if (rc) return rc;
-        configured = true;
+        configured.mark();
     }
     const RowSplit sp = choose_row_split(R, C, H);
     const unsigned tiles_c = (C + BM - 1) / BM;
@@ -359,12 +359,12 @@ extern "C" int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, 
     KernelTimer timer(TC_ROW_APPLY, 2.0 * H * C * C * R * HEAD_DIM, 4.0 * (2.0 * R * C * H * HEAD_DIM + (double)H * C * C), s);
 #define RA_GO2(AL_, OUT_, VT_)                                                                                    \
     do {                                                                                                          \
-        static bool cfg_ = false;                                                                                 \
+        static DeviceOnce cfg_;                                                                                 \
         constexpr int lds_ = VT_ ? ROWAPPLY_VT_LDS_BYTES : ROWAPPLY_LDS_BYTES;                                     \
-        if (!cfg_) {                                                                                              \
+        if (cfg_.pending()) {                                                                                              \
             int rc = set_lds(row_apply_kernel<AL_, OUT_, VT_>, lds_, "row_apply");                               \
             if (rc) return rc;                                                                                    \
-            cfg_ = true;                                                                                          \
+            cfg_.mark();                                                                                          \
         }                                                                                                         \
         hipLaunchKernelGGL((row_apply_kernel<AL_, OUT_, VT_>), dim3(grid), dim3(GEMM_THREADS), lds_, s, probs,    \
                            v, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo);                                             \

@@ -598,21 +598,21 @@ extern "C" int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, c
 #define RL_GO(SP_, FMT_)                                                                                            \
     do {                                                                                                            \
         if (big) {                                                                                                  \
-            static bool cfgx_ = false;                                                                              \
-            if (!cfgx_) {                                                                                           \
+            static DeviceOnce cfgx_;                                                                              \
+            if (cfgx_.pending()) {                                                                                           \
                 int rc = set_lds16(row_logits16x_kernel<SP_, FMT_>, R16LCfg<SP_>::LDS, "row_logits16x");           \
                 if (rc) return rc;                                                                                  \
-                cfgx_ = true;                                                                                       \
+                cfgx_.mark();                                                                                       \
             }                                                                                                       \
             hipLaunchKernelGGL((row_logits16x_kernel<SP_, FMT_>), dim3(grid), dim3(512), R16LCfg<SP_>::LDS, s, q_hi, q_lo,  \
                                k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale);              \
             break;                                                                                                  \
         }                                                                                                           \
-        static bool cfg_ = false;                                                                                   \
-        if (!cfg_) {                                                                                                \
+        static DeviceOnce cfg_;                                                                                   \
+        if (cfg_.pending()) {                                                                                                \
             int rc = set_lds16(row_logits16_kernel<SP_, FMT_>, R16Cfg<SP_>::LDS, "row_logits16");                  \
             if (rc) return rc;                                                                                      \
-            cfg_ = true;                                                                                            \
+            cfg_.mark();                                                                                            \
         }                                                                                                           \
         hipLaunchKernelGGL((row_logits16_kernel<SP_, FMT_>), dim3(grid), dim3(R16_THREADS), R16Cfg<SP_>::LDS, s, q_hi, \
                            q_lo, k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale);            \
@@ -648,21 +648,21 @@ extern "C" int rnamsm_row_apply16(const uint16_t* p_hi, const uint16_t* p_lo, in
 #define RA_GO(SP_, FMT_, OUT_)                                                                                      \
     do {                                                                                                            \
         if (big) {                                                                                                  \
-            static bool cfgx_ = false;                                                                              \
-            if (!cfgx_) {                                                                                           \
+            static DeviceOnce cfgx_;                                                                              \
+            if (cfgx_.pending()) {                                                                                           \
                 int rc = set_lds16(row_apply16x_kernel<SP_, FMT_, OUT_>, R16XCfg<SP_>::LDS, "row_apply16x");       \
                 if (rc) return rc;                                                                                  \
-                cfgx_ = true;                                                                                       \
+                cfgx_.mark();                                                                                       \
             }                                                                                                       \
             hipLaunchKernelGGL((row_apply16x_kernel<SP_, FMT_, OUT_>), dim3(grid), dim3(R16X_THREADS), R16XCfg<SP_>::LDS, \
                                s, p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale);   \
             break;                                                                                                  \
         }                                                                                                           \
-        static bool cfg_ = false;                                                                                   \
-        if (!cfg_) {                                                                                                \
+        static DeviceOnce cfg_;                                                                                   \
+        if (cfg_.pending()) {                                                                                                \
             int rc = set_lds16(row_apply16_kernel<SP_, FMT_, OUT_>, R16Cfg<SP_>::LDS, "row_apply16");              \
             if (rc) return rc;                                                                                      \
-            cfg_ = true;                                                                                            \
+            cfg_.mark();                                                                                            \
         }                                                                                                           \
         hipLaunchKernelGGL((row_apply16_kernel<SP_, FMT_, OUT_>), dim3(grid), dim3(R16_THREADS), R16Cfg<SP_>::LDS, s, p_hi, \
                            p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale);                \

@@ -144,8 +144,10 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
     save_dir.mkdir(parents=True, exist_ok=True)
     rng = np.random.RandomState(42)
     mine = sharding.shard_indices(len(ids), rank, world)
-    local = {}
     written: List[str] = []
+    # the library launches on the calling thread's current device: make it this rank's GPU on the main thread and on
+    # the reader thread (whose greedy sub-sampling runs on the device)
+    torch.cuda.set_device(device)
 
     def write(rna_id: str, emb: np.ndarray, atp: np.ndarray) -> None:
         np.save(save_dir / f"{rna_id}_atp.npy", atp)
@@ -153,10 +155,24 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
         written.append(rna_id)
 
     def read(idx: int) -> np.ndarray:
+        torch.cuda.set_device(device)
         return load_msa_tokens(files[ids[idx]], alphabet, cfg.data.max_seqs_per_msa, cfg.data.sample_method, device=device)
 
-    writer = _AsyncNpyWriter(device) if async_io and not (gather_to_rank0 and world > 1) else None
+    gathering = gather_to_rank0 and world > 1
+    writer = _AsyncNpyWriter(device) if async_io and (not gathering or rank == 0) else None
     reader = ThreadPoolExecutor(1, thread_name_prefix="rnamsm-msa-reader") if async_io else None
+
+    def emit(rna_id: str, emb: torch.Tensor, atp: torch.Tensor) -> None:
+        if writer is not None:
+            writer.submit([(save_dir / f"{rna_id}_atp.npy", atp), (save_dir / f"{rna_id}_emb.npy", emb)],
+                          lambda r=rna_id: written.append(r))
+        else:
+            write(rna_id, emb.cpu().numpy(), atp.cpu().numpy())
+
+    # gather_to_rank0: outputs travel to rank 0 one ROUND (one MSA per rank) at a time, round k's RCCL transfers
+    # overlapping round k+1's forward, and are handed to the writer as they arrive -- at most one round is resident
+    gatherer = sharding.RoundGatherer(len(ids), on_item=lambda i, ts: emit(ids[i], ts[0], ts[1]), tensors_per_item=2,
+                                      dst=0, device=device) if gathering else None
     try:
         with torch.no_grad():
             pending = reader.submit(read, mine[0]) if reader and len(mine) else None
@@ -169,24 +185,17 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                 out = model.forward_one(torch.from_numpy(tokens).to(device))
                 if int(out["err"].item()) != 0:
                     raise IndexError(f"{rna_id}: token or position index out of range")
-                if gather_to_rank0 and world > 1:
-                    local[idx] = (out["emb"], out["atp"])
-                elif writer is not None:
-                    writer.submit([(save_dir / f"{rna_id}_atp.npy", out["atp"]), (save_dir / f"{rna_id}_emb.npy", out["emb"])],
-                                  lambda r=rna_id: written.append(r))
+                if gatherer is not None:
+                    gatherer.submit(idx, (out["emb"], out["atp"]))
                 else:
-                    write(rna_id, out["emb"].cpu().numpy(), out["atp"].cpu().numpy())
+                    emit(rna_id, out["emb"], out["atp"])
+            if gatherer is not None:
+                gatherer.finish()
     finally:
         if reader is not None:
             reader.shutdown(wait=True)
         if writer is not None:
             writer.close()
-    if gather_to_rank0 and world > 1:
-        everything = sharding.gather_arrays(local, len(ids), dst=0)
-        if rank == 0:
-            for idx in sorted(everything):
-                emb, atp = everything[idx]
-                write(ids[idx], emb.cpu().numpy(), atp.cpu().numpy())
     if rank == 0:
         print(f"Done! Generated files are saved at {save_dir}")
     return written

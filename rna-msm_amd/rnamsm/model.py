@@ -81,6 +81,7 @@ class MSATransformer(nn.Module):
         self.compute_logits = False
         # Arithmetic of the Linear GEMMs in the C++ driver: "f32" (exact, default), "bf16" or "bf16x3" (include/rnamsm.h).
         self.gemm_dtype = "f32"
+        self.check_finite = True          # 16-bit modes: verify the outputs are finite, fall back to f32 per MSA otherwise
         self._planes = None
 
     # ------------------------------------------------------------------ reference API
@@ -194,6 +195,16 @@ class MSATransformer(nn.Module):
             raise RuntimeError(
                 "Using model with MSA position embedding trained on maximum MSA "
                 f"depth of 1024, but received {R} alignments.")                       # model.py:355-359
+        dev = tokens2d.device
+        if self.embed_tokens.weight.device != dev:
+            raise _lib.RnamsmError(f"tokens are on {dev} but the model is on {self.embed_tokens.weight.device}")
+        # the library launches on the calling thread's current device / stream: enter the operands' device (a worker
+        # thread, or a model on cuda:1, would otherwise launch on device 0 against pointers of another GPU)
+        with torch.cuda.device(dev):
+            return self._forward_one_on_device(tokens2d, has_padding)
+
+    def _forward_one_on_device(self, tokens2d: torch.Tensor, has_padding: Optional[bool]) -> Dict[str, torch.Tensor]:
+        R, C = tokens2d.shape
         lib = _lib.load()
         dims, ptrs, _ = self._packed_weights()
         dev = tokens2d.device
@@ -214,6 +225,19 @@ class MSATransformer(nn.Module):
                                       row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
                                       err.data_ptr(), int(has_padding), dtype, planes,
                                       torch.cuda.current_stream().cuda_stream))
+        if dtype != _lib.F32 and self.check_finite:
+            # f16x3 / bf16 operands live in 16-bit planes: fp16 overflows above 65504 (-> inf/NaN downstream).  The
+            # synthetic weights stay far inside; a real checkpoint is not known to, so the outputs are checked (one
+            # reduction over emb, ~1 us) and the MSA is redone on the exact path rather than written out as NaN
+            if not bool(torch.isfinite(emb).all()):
+                import warnings
+                warnings.warn(f"gemm_dtype={self.gemm_dtype!r} produced non-finite outputs (operand outside the 16-bit "
+                              "range); this MSA is recomputed on the exact fp32 path")
+                mode, self.gemm_dtype = self.gemm_dtype, "f32"
+                try:
+                    return self._forward_one_on_device(tokens2d, has_padding)
+                finally:
+                    self.gemm_dtype = mode
         return {"row_attn": row_attn, "repr": rep, "emb": emb, "atp": atp, "err": err}
 
     def _forward_layerwise(self, tokens2d: torch.Tensor, repr_layers: Iterable[int], has_padding: bool = False):
@@ -251,7 +275,9 @@ class MSATransformer(nn.Module):
         # padding_mask is batch-global in the reference (model.py:346-348); masks of un-padded elements are all-false
         has_padding = bool((tokens == self.vocab.pad_idx).any())
         need_logits = self.compute_logits if need_logits is None else need_logits
-        repr_set = set(repr_layers)
+        # the reference keeps `set(repr_layers)` as given (model.py:369) and fills an entry only when a layer index
+        # matches (:371, :393, :400): indices outside 0..num_layers -- negative ones included -- select nothing
+        repr_set = set(i for i in repr_layers if 0 <= i <= self.num_layers)
         want = set(repr_set)
         if need_logits:
             repr_set = repr_set | {self.num_layers}

@@ -6,6 +6,7 @@ otherwise -- there is no eager fallback.
 """
 from __future__ import annotations
 
+import functools
 import math
 from typing import Optional, Tuple
 
@@ -19,6 +20,33 @@ HEAD_DIM = 64
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def _first_tensor(args):
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            return a
+        if isinstance(a, (tuple, list)):
+            t = _first_tensor(a)
+            if t is not None:
+                return t
+    return None
+
+
+def _on_operand_device(fn):
+    """The library launches on the calling thread's CURRENT device and stream.  A worker thread (the CLI's MSA reader)
+    or a model on cuda:1 has operands elsewhere, so every op enters the device of its first tensor operand first;
+    `_stream()` then is that device's current stream."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        t = _first_tensor(args)
+        if t is None:
+            t = _first_tensor(tuple(kwargs.values()))
+        if t is None or not t.is_cuda:
+            return fn(*args, **kwargs)            # the op itself raises the "no CPU path" error
+        with torch.cuda.device(t.device):
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _dev(t: torch.Tensor, name: str, dtype=torch.float32) -> int:
@@ -36,6 +64,7 @@ def _rowmajor(t: torch.Tensor, name: str) -> int:
     return t.stride(0)
 
 
+@_on_operand_device
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     D = x.shape[-1]
@@ -46,6 +75,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return y.view(x.shape)
 
 
+@_on_operand_device
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
            residual: Optional[torch.Tensor] = None, scale: float = 1.0, scale_cols: int = 0,
            out: Optional[torch.Tensor] = None, zero_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -63,6 +93,7 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+@_on_operand_device
 def split_bf16(w: torch.Tensor, want_lo: bool = True, fmt: int = 0):
     """fp32 tensor -> (hi, lo) 16-bit planes (fmt 0 = bf16, 1 = fp16) as int16 tensors of the same shape
     (lo = half(w - hi), None if not wanted)."""
@@ -74,6 +105,7 @@ def split_bf16(w: torch.Tensor, want_lo: bool = True, fmt: int = 0):
     return hi, lo
 
 
+@_on_operand_device
 def linear_bf16(a: torch.Tensor, w_hi: torch.Tensor, w_lo: Optional[torch.Tensor], bias: Optional[torch.Tensor] = None,
                 act: int = ACT_NONE, residual: Optional[torch.Tensor] = None, scale: float = 1.0, scale_cols: int = 0,
                 out: Optional[torch.Tensor] = None, split: int = 3, fmt: int = 0) -> torch.Tensor:
@@ -90,6 +122,7 @@ def linear_bf16(a: torch.Tensor, w_hi: torch.Tensor, w_lo: Optional[torch.Tensor
     return out
 
 
+@_on_operand_device
 def row_logits(q: torch.Tensor, k: torch.Tensor, R: int, C: int, H: int) -> Tuple[torch.Tensor, int]:
     """q, k: [R*C, *] views with row stride ld; returns (partial [nsplit,H,C,C], nsplit)."""
     lib = _lib.load()
@@ -102,6 +135,7 @@ def row_logits(q: torch.Tensor, k: torch.Tensor, R: int, C: int, H: int) -> Tupl
     return partial, nsplit
 
 
+@_on_operand_device
 def softmax_rows(partial: torch.Tensor, out: Optional[torch.Tensor] = None,
                  key_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     nsplit, H, C, _ = partial.shape
@@ -112,6 +146,7 @@ def softmax_rows(partial: torch.Tensor, out: Optional[torch.Tensor] = None,
     return probs
 
 
+@_on_operand_device
 def row_apply(probs: torch.Tensor, v: torch.Tensor, R: int, C: int, H: int,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     ctx = torch.empty(R * C, H * HEAD_DIM, device=v.device, dtype=torch.float32) if out is None else out
@@ -120,6 +155,7 @@ def row_apply(probs: torch.Tensor, v: torch.Tensor, R: int, C: int, H: int,
     return ctx
 
 
+@_on_operand_device
 def col_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, R: int, C: int, H: int,
              out: Optional[torch.Tensor] = None, pad_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     ctx = torch.empty(R * C, H * HEAD_DIM, device=v.device, dtype=torch.float32) if out is None else out
@@ -137,6 +173,7 @@ def _pl(t: Optional[torch.Tensor], name: str):
     return None if t is None else _dev(t, name, torch.int16)
 
 
+@_on_operand_device
 def linear_planes(a, w, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
                   scale: float = 1.0, scale_cols: int = 0, out: Optional[torch.Tensor] = None, out_planes: bool = False,
                   fmt: int = 0):
@@ -162,6 +199,7 @@ def linear_planes(a, w, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE
     return (o_hi, o_lo) if out_planes else out
 
 
+@_on_operand_device
 def row_logits16(q, k, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0) -> Tuple[torch.Tensor, int]:
     """q, k: (hi, lo) plane views [R*C, *] with row stride ld (halves); returns (partial [nsplit,H,C,C] fp32, nsplit);
     scale multiplies the fp32 logits (q is expected UNSCALED)."""
@@ -174,6 +212,7 @@ def row_logits16(q, k, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0)
     return partial, nsplit
 
 
+@_on_operand_device
 def softmax_rows_planes(partial: torch.Tensor, split: int = 3, fmt: int = 0, key_mask: Optional[torch.Tensor] = None,
                         plane_scale: float = 1.0):
     """softmax_rows that also returns P * plane_scale as planes (hi, lo | None) [H*C, ldp], ldp = C rounded up to 64,
@@ -189,6 +228,7 @@ def softmax_rows_planes(partial: torch.Tensor, split: int = 3, fmt: int = 0, key
     return probs, (p_hi, p_lo)
 
 
+@_on_operand_device
 def row_apply16(p, v, R: int, C: int, H: int, fmt: int = 0, out_scale: float = 1.0) -> torch.Tensor:
     """p: (hi, lo) planes [H*C, ldp]; v: (hi, lo) plane views [R*C, *]; returns out_scale * P v, fp32 [R*C, H*64]."""
     ctx = torch.empty(R * C, H * HEAD_DIM, device=v[0].device, dtype=torch.float32)
@@ -199,12 +239,14 @@ def row_apply16(p, v, R: int, C: int, H: int, fmt: int = 0, out_scale: float = 1
     return ctx
 
 
+@_on_operand_device
 def zero_plane_rows(pl, mask: torch.Tensor, ncols: int) -> None:
     """In place: zero the first ncols halves of the plane rows flagged in mask (uint8 [T]) -- q *= 1 - padding_mask."""
     _lib.check(_lib.load().rnamsm_zero_plane_rows(_pl(pl[0], "hi"), _pl(pl[1], "lo"), _dev(mask, "mask", torch.uint8),
                                                   pl[0].shape[0], ncols, _rowmajor(pl[0], "hi"), _stream()))
 
 
+@_on_operand_device
 def col_attn16(q, k, v, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0,
                pad_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q, k, v: (hi, lo) plane views [R*C, *] with a common row stride; returns softmax(scale * q k^T) v, fp32
@@ -220,6 +262,7 @@ def col_attn16(q, k, v, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0
     return ctx
 
 
+@_on_operand_device
 def embed_ln(tokens: torch.Tensor, embed_tokens: torch.Tensor, embed_positions: torch.Tensor, row_pos: torch.Tensor,
              gamma: torch.Tensor, beta: torch.Tensor, pad_idx: int, eps: float = 1e-5) -> torch.Tensor:
     """tokens int64 [R,C] -> x [R*C, D]; raises on token / position ids outside the tables."""
@@ -237,6 +280,7 @@ def embed_ln(tokens: torch.Tensor, embed_tokens: torch.Tensor, embed_positions: 
     return out
 
 
+@_on_operand_device
 def pack_outputs(x_final: torch.Tensor, probs_all: torch.Tensor, C: int) -> Tuple[torch.Tensor, torch.Tensor]:
     NL, H = probs_all.shape[0], probs_all.shape[1]
     D = x_final.shape[-1]
@@ -247,6 +291,7 @@ def pack_outputs(x_final: torch.Tensor, probs_all: torch.Tensor, C: int) -> Tupl
     return emb, atp
 
 
+@_on_operand_device
 def contact_head(row_attn: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """row_attn [NL, H, C, C] (or [NL*H, C, C]) -> contacts [C-1, C-1] (modules.py:344-366)."""
     C = row_attn.shape[-1]
@@ -260,6 +305,7 @@ def contact_head(row_attn: torch.Tensor, weight: torch.Tensor, bias: torch.Tenso
     return out
 
 
+@_on_operand_device
 def greedy_select(msa_u8: torch.Tensor, num_seqs: int, mode: str = "max") -> torch.Tensor:
     """msa uint8 [N, L] on the device -> int32 [num_seqs] ascending row indices (utils/align.py:128-148)."""
     if mode not in ("max", "min"):

@@ -5,14 +5,24 @@ reference's own scale-out is one process per GPU over a list of ids (utils/distr
 process per GPU with torch.distributed; the only data-path communication is the output gather
 (emb [L,768] + atp [120,L,L] per MSA) to rank 0, done with point-to-point sends so that on MI355X every peer uses
 its own direct xGMI link to rank 0 (no ring).  With backend "nccl" this is RCCL; the same code runs on "gloo"
-for the CPU tests (tests/test_sharding.py).
+(which moves host memory: payloads are staged through the host) for the CPU tests (tests/test_sharding.py).
+
+`RoundGatherer` is the one gather implementation (the CLI, bench.py and `gather_arrays` all use it).  It works in
+ROUNDS of `world` items -- round k holds items k*world .. k*world+world-1, one per rank -- so that at most one round of
+outputs is resident on the destination at a time (atp is 126 MB per L=512 MSA: gathering a whole id list first would
+exhaust rank 0's HBM), and it issues round k's transfers on a side stream behind an event, so they overlap the forward
+of round k+1.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+
+_DTYPES = (torch.float32, torch.float64, torch.int64, torch.int32, torch.uint8, torch.bfloat16, torch.float16,
+           torch.int16)
+_MAXD = 4
 
 
 def shard_indices(num_items: int, rank: int, world_size: int) -> List[int]:
@@ -27,68 +37,168 @@ def owner_of(index: int, world_size: int) -> int:
     return index % world_size
 
 
-def gather_arrays(local: Dict[int, Sequence[torch.Tensor]], num_items: int, dst: int = 0,
-                  group: Optional[dist.ProcessGroup] = None) -> Optional[Dict[int, List[torch.Tensor]]]:
-    """Gather per-item tensor tuples to `dst`.
+def default_wire_device(group: Optional[dist.ProcessGroup] = None) -> torch.device:
+    """Memory the backend moves: the current HIP device under RCCL ("nccl"), host memory otherwise.  Never derived
+    from the payload, so a rank that owns no item still enters the collectives with the right kind of tensor."""
+    if dist.is_initialized() and dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
-    `local` maps the global item index (as assigned by shard_indices) to that item's tensors -- all items carry the
-    same number of tensors, shapes may differ per item (L varies).  Shapes travel first as one small int64 message
-    per peer, then the payloads as batched isend/irecv.  Returns {index: [tensors]} on dst, None elsewhere."""
+
+class RoundGatherer:
+    """Streams per-item tensor tuples to `dst`, one round of `world` items at a time.
+
+    Every rank calls `submit(index, tensors)` for each of its items in ascending order (its k-th call is item
+    k*world + rank) and `finish()` once at the end.  On `dst`, `on_item(index, tensors)` is called for every item of
+    the job -- its own and the received ones -- in ascending index order, one round behind the submissions (round k is
+    delivered when round k+1 is submitted, or by finish()), with tensors on `device`; nothing is retained afterwards.
+    Items may differ in shape (L varies per MSA): a small int64 header travels ahead of each payload.
+    `tensors_per_item` is static so that ranks owning nothing agree without a collective."""
+
+    def __init__(self, num_items: int, on_item: Optional[Callable[[int, List[torch.Tensor]], None]] = None,
+                 tensors_per_item: int = 2, dst: int = 0, group: Optional[dist.ProcessGroup] = None,
+                 device: Optional[torch.device] = None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.dst = dst
+        self.num_items = num_items
+        self.n_tensors = tensors_per_item
+        self.on_item = on_item
+        self.wire = default_wire_device(group)
+        self.device = torch.device(device) if device is not None else self.wire
+        self.num_rounds = (num_items + self.world - 1) // self.world
+        self._round = 0
+        self._inflight = None            # (round, works, keepalive, [(index, tensors)])
+        self._side = torch.cuda.Stream(self.wire) if (self.world > 1 and self.wire.type == "cuda") else None
+        self.bytes_received = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _has_item(self, rnd: int, rank: int) -> bool:
+        return rnd * self.world + rank < self.num_items
+
+    def _header(self, tensors: Sequence[torch.Tensor]) -> torch.Tensor:
+        h = torch.zeros(self.n_tensors, _MAXD + 2, dtype=torch.int64)
+        for b, t in enumerate(tensors):
+            if t.dim() > _MAXD:
+                raise ValueError(f"gather supports tensors of up to {_MAXD} dimensions")
+            h[b, 0] = _DTYPES.index(t.dtype)
+            h[b, 1] = t.dim()
+            for a, n in enumerate(t.shape):
+                h[b, 2 + a] = n
+        return h
+
+    def _retire(self) -> None:
+        """Complete the round in flight: wait for its transfers, hand its items to on_item (dst), drop the buffers."""
+        if self._inflight is None:
+            return
+        _, works, keep, items = self._inflight
+        self._inflight = None
+        for w in works:
+            w.wait()
+        if self._side is not None:
+            torch.cuda.current_stream(self.wire).wait_stream(self._side)
+        if self.rank == self.dst and self.on_item is not None:
+            for index, tensors in sorted(items, key=lambda it: it[0]):
+                self.on_item(index, [t if t.device == self.device else t.to(self.device) for t in tensors])
+        del keep, items
+
+    def _post_round(self, rnd: int, own: Optional[Sequence[torch.Tensor]]) -> None:
+        index = rnd * self.world + self.rank
+        works, keep, items = [], [], []
+        if self.world == 1:
+            self._inflight = (rnd, works, keep, [(index, list(own))])
+            return
+        ev = None
+        if self._side is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.wire))      # the payload is complete once this event has fired
+
+        def comm():
+            if self.rank != self.dst:
+                if own is None:
+                    return
+                payload = [t.contiguous().to(self.wire) for t in own]
+                hdr = self._header(payload).to(self.wire)
+                if self._side is not None:
+                    for t in payload:
+                        t.record_stream(self._side)
+                keep.extend([hdr] + payload)
+                works.append(dist.isend(hdr, self.dst, group=self.group))
+                works.extend(dist.isend(t, self.dst, group=self.group) for t in payload)
+                return
+            if own is not None:
+                items.append((index, list(own)))
+            for peer in range(self.world):
+                if peer == self.dst or not self._has_item(rnd, peer):
+                    continue
+                hdr = torch.zeros(self.n_tensors, _MAXD + 2, dtype=torch.int64, device=self.wire)
+                dist.recv(hdr, src=peer, group=self.group)
+                h = hdr.cpu()
+                bufs = []
+                for b in range(self.n_tensors):
+                    nd = int(h[b, 1])
+                    buf = torch.empty(tuple(int(v) for v in h[b, 2:2 + nd]), dtype=_DTYPES[int(h[b, 0])], device=self.wire)
+                    works.append(dist.irecv(buf, peer, group=self.group))
+                    bufs.append(buf)
+                    self.bytes_received += buf.numel() * buf.element_size()
+                items.append((rnd * self.world + peer, bufs))
+
+        if self._side is not None:
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                comm()
+        else:
+            comm()
+        self._inflight = (rnd, works, keep, items)
+
+    # ------------------------------------------------------------------ API
+    def submit(self, index: int, tensors: Sequence[torch.Tensor]) -> None:
+        if index != self._round * self.world + self.rank or index >= self.num_items:
+            raise ValueError(f"rank {self.rank} submitted item {index} in round {self._round}: items must arrive in "
+                             f"ascending order of shard_indices({self.num_items}, {self.rank}, {self.world})")
+        if len(tensors) != self.n_tensors:
+            raise ValueError(f"expected {self.n_tensors} tensors per item, got {len(tensors)}")
+        self._retire()
+        self._post_round(self._round, tensors)
+        self._round += 1
+
+    def finish(self) -> None:
+        """Drains: a rank whose shard is shorter (or empty) still takes part in the remaining rounds on `dst`."""
+        mine = len(shard_indices(self.num_items, self.rank, self.world))
+        if self._round != mine:
+            raise RuntimeError(f"rank {self.rank} submitted {self._round} of its {mine} items before finish()")
+        if self.rank == self.dst:
+            while self._round < self.num_rounds:           # rounds in which dst has no item of its own
+                self._retire()
+                self._post_round(self._round, None)
+                self._round += 1
+        self._retire()
+
+
+def gather_arrays(local: Dict[int, Sequence[torch.Tensor]], num_items: int, dst: int = 0,
+                  group: Optional[dist.ProcessGroup] = None, device: Optional[torch.device] = None,
+                  tensors_per_item: Optional[int] = None) -> Optional[Dict[int, List[torch.Tensor]]]:
+    """Gather per-item tensor tuples to `dst` in one call (small jobs and tests; the CLI streams through
+    RoundGatherer directly so that only one round is ever resident).
+
+    `local` maps the global item index (as assigned by shard_indices) to that item's tensors; shapes may differ per
+    item.  Returns {index: [tensors]} on dst, None elsewhere.  `tensors_per_item` must be given when some rank may own
+    nothing (it cannot be inferred there)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    if world == 1:
-        return {i: list(ts) for i, ts in local.items()}
     mine = shard_indices(num_items, rank, world)
     assert sorted(local) == mine, f"rank {rank} holds {sorted(local)} but owns {mine}"
-    any_t = next(iter(local.values()))[0] if local else None
-    device = any_t.device if any_t is not None else torch.device("cpu")
-    n_tensors = len(next(iter(local.values()))) if local else 0
-    # every rank must agree on tensors-per-item and dtype even when it owns nothing
-    meta = torch.tensor([n_tensors], dtype=torch.int64, device=device)
-    dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
-    n_tensors = int(meta.item())
-    MAXD = 4
-
-    def shape_msg(items):
-        m = torch.zeros(len(items), n_tensors, MAXD + 1, dtype=torch.int64)
-        for a, idx in enumerate(items):
-            for b, t in enumerate(local[idx]):
-                m[a, b, 0] = t.dim()
-                m[a, b, 1:1 + t.dim()] = torch.tensor(t.shape, dtype=torch.int64)
-        return m.to(device)
-
-    if rank != dst:
-        if not mine:
-            return None
-        dist.send(shape_msg(mine), dst=dst, group=group)
-        ops = [dist.P2POp(dist.isend, t.contiguous(), dst, group) for idx in mine for t in local[idx]]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        return None
-
-    out: Dict[int, List[torch.Tensor]] = {i: list(ts) for i, ts in local.items()}
-    dtype = any_t.dtype if any_t is not None else torch.float32
-    ops, pending = [], []
-    for peer in range(world):
-        if peer == dst:
-            continue
-        theirs = shard_indices(num_items, peer, world)
-        if not theirs:
-            continue
-        m = torch.zeros(len(theirs), n_tensors, MAXD + 1, dtype=torch.int64, device=device)
-        dist.recv(m, src=peer, group=group)
-        m = m.cpu()
-        for a, idx in enumerate(theirs):
-            bufs = []
-            for b in range(n_tensors):
-                nd = int(m[a, b, 0])
-                buf = torch.empty(tuple(int(v) for v in m[a, b, 1:1 + nd]), dtype=dtype, device=device)
-                ops.append(dist.P2POp(dist.irecv, buf, peer, group))
-                bufs.append(buf)
-            pending.append((idx, bufs))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-    for idx, bufs in pending:
-        out[idx] = bufs
-    return out
+    if tensors_per_item is None:
+        if not local:
+            raise ValueError("tensors_per_item is required on a rank that owns no item")
+        tensors_per_item = len(next(iter(local.values())))
+    out: Dict[int, List[torch.Tensor]] = {}
+    if device is None and local:
+        device = next(iter(local.values()))[0].device
+    g = RoundGatherer(num_items, on_item=lambda i, ts: out.__setitem__(i, list(ts)), tensors_per_item=tensors_per_item,
+                      dst=dst, group=group, device=device)
+    for idx in mine:
+        g.submit(idx, local[idx])
+    g.finish()
+    return out if rank == dst else None

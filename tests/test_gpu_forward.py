@@ -300,3 +300,44 @@ def test_forward_shape_sweep_against_oracle_all_fp32_grade_modes(model, R, C):
             assert np.abs(out["atp"].cpu().numpy() - atp.numpy()).max() < atp_tol, mode
     finally:
         m.gemm_dtype = "f32"
+
+
+def test_forward_and_ops_run_on_their_operands_device_from_a_worker_thread(model):
+    """the library launches on the calling thread's current device.  The CLI's reader thread (greedy
+    sub-sampling) and a model on a non-default device must still launch where their tensors live: forward_one and the ops
+    enter the operands' device themselves.  With one GPU this checks the threaded call; with two or more it runs the
+    same MSA on the LAST device from a thread whose current device is 0 and expects bit-identical outputs."""
+    import copy
+    from concurrent.futures import ThreadPoolExecutor
+    from rnamsm import msa
+    m, _ = model
+    toks_np = synthetic.make_tokens(9, 70, 5)
+    want = m.forward_one(torch.from_numpy(toks_np).to("cuda:0"))
+    sel_want = msa.greedy_select(toks_np, 4, "max")
+    n_dev = torch.cuda.device_count()
+    dev = torch.device("cuda", n_dev - 1)
+    m2 = m if n_dev == 1 else copy.deepcopy(m).to(dev)
+
+    def work():
+        assert torch.cuda.current_device() == 0                  # a fresh thread starts on device 0
+        out = m2.forward_one(torch.from_numpy(toks_np).to(dev))
+        sel = msa.greedy_select_device(toks_np, 4, "max", dev)
+        return out["emb"].cpu(), out["atp"].cpu(), sel
+
+    with ThreadPoolExecutor(1) as ex:
+        emb, atp, sel = ex.submit(work).result()
+    assert torch.equal(emb, want["emb"].cpu()) and torch.equal(atp, want["atp"].cpu())
+    assert np.array_equal(sel, sel_want)
+    if n_dev > 1:
+        with pytest.raises(Exception, match="model is on"):
+            m.forward_one(torch.from_numpy(toks_np).to(dev))      # tokens and weights on different GPUs: loud failure
+
+
+def test_repr_layers_outside_the_model_select_nothing_like_the_reference(model):
+    """model.py:369-401 keeps set(repr_layers) as given: an index that matches no layer (negative ones included) simply
+    produces no entry."""
+    m, _ = model
+    toks = torch.from_numpy(synthetic.make_tokens(3, 9, 1)).to("cuda:0")[None]
+    res = m(toks, repr_layers=[-1, 10, 11])
+    assert sorted(res["representations"]) == [10]
+    assert m(toks, repr_layers=[-1])["representations"] == {}

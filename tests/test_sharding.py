@@ -34,7 +34,7 @@ def _worker(rank, world, port, n_items, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         local = {i: _item(i) for i in sharding.shard_indices(n_items, rank, world)}
-        out = sharding.gather_arrays(local, n_items, dst=0)
+        out = sharding.gather_arrays(local, n_items, dst=0, tensors_per_item=2)   # (2, 1): rank 1 owns nothing
         if rank == 0:
             ok = sorted(out) == list(range(n_items)) and all(
                 all(torch.equal(a, b) for a, b in zip(out[i], _item(i))) for i in range(n_items))
@@ -45,21 +45,71 @@ def _worker(rank, world, port, n_items, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_items", [(2, 5), (2, 1), (2, 8)])
-def test_gather_to_rank0_over_gloo(world, n_items):
+def _run(target, world, *args):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert all(results)
+    return results
+
+
+@pytest.mark.parametrize("world,n_items", [(2, 5), (2, 1), (2, 8), (3, 4)])
+def test_gather_to_rank0_over_gloo(world, n_items):
+    assert all(_run(_worker, world, n_items))
+
+
+def _stream_worker(rank, world, port, n_items, dst, q):
+    """The CLI's use of RoundGatherer: submit after every forward, items delivered on dst in index order one round
+    behind, never more than one round resident."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seen, log = [], []
+
+        def on_item(idx, tensors):
+            seen.append(idx)
+            log.append(all(torch.equal(a, b) for a, b in zip(tensors, _item(idx))))
+
+        g = sharding.RoundGatherer(n_items, on_item=on_item, tensors_per_item=2, dst=dst)
+        ok = True
+        for k, idx in enumerate(sharding.shard_indices(n_items, rank, world)):
+            g.submit(idx, _item(idx))
+            if rank == dst:                                      # round k is in flight, rounds < k delivered, nothing else
+                ok = ok and seen == list(range(min(n_items, k * world)))
+        with pytest.raises(ValueError):
+            g.submit(n_items + 5, _item(0))                      # out of order / not this rank's item
+        g.finish()
+        if rank == dst:
+            q.put(ok and seen == list(range(n_items)) and all(log) and g._inflight is None)
+        else:
+            q.put(seen == [] and g._inflight is None)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_items,dst", [(2, 7, 0), (2, 6, 1), (3, 5, 0), (3, 1, 2), (2, 0, 0)])
+def test_round_gatherer_streams_in_rounds(world, n_items, dst):
+    assert all(_run(_stream_worker, world, n_items, dst))
+
+
+def test_round_gatherer_single_process_delivers_in_order():
+    seen = []
+    g = sharding.RoundGatherer(3, on_item=lambda i, ts: seen.append((i, len(ts))), tensors_per_item=2)
+    for i in range(3):
+        g.submit(i, _item(i))
+        assert [s[0] for s in seen] == list(range(i))            # one round behind
+    g.finish()
+    assert seen == [(0, 2), (1, 2), (2, 2)]
+    with pytest.raises(ValueError):
+        sharding.RoundGatherer(2, tensors_per_item=2).submit(0, _item(0)[:1])
 
 
 def test_single_process_gather_is_identity():
