@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RNAMSM_VERSION 100 /* major*10000 + minor*100 + patch */
+#define RNAMSM_VERSION 200 /* major*10000 + minor*100 + patch */
 
 typedef enum {
     RNAMSM_OK = 0,
@@ -120,6 +120,21 @@ int rnamsm_row_logits(const float* q, const float* k, int64_t ld, float* partial
  *   logit replaced by -10000 first (masked_fill with padding_mask[:, 0], modules.py:781-785). */
 int rnamsm_softmax_rows(const float* partial, int nsplit, float* probs, int H, int C,
                         const uint8_t* key_mask, void* stream);
+
+/* K4 / K5 with padding on the reference's CHUNKED path (RowSelfAttention._batched_forward, modules.py:717-750, taken when
+ * R*C > max_tokens_per_msa): the rows are processed in chunks of max_rows = max(1, max_tokens_per_msa / C) (:724), every
+ * chunk's logits are filled with -10000 where the chunk's OWN first row is <pad> (:727-737 slice the mask per chunk,
+ * :781-785 use its row 0) and the filled slabs are added in chunk order (:738).  With padding this differs from the direct
+ * path: a pad on a chunk-starting row masks that key column, and an all-padded chunk start shifts every logit by -10000.
+ *   rnamsm_row_chunks            number of chunks, 0 when the reference takes the direct path (R*C <= max_tokens_per_msa)
+ *   rnamsm_row_logits_chunked    rnamsm_row_logits with one partial slab per chunk: partial [nchunks, H, C, C]
+ *   rnamsm_softmax_rows_chunked  probs = softmax_j( sum_c (pad_mask[c*rows_per_chunk, j] ? -10000 : partial[c,h,i,j]) );
+ *                                pad_mask uint8 [R, C] (rnamsm_pad_mask). */
+int rnamsm_row_chunks(int R, int C, int max_tokens_per_msa);
+int rnamsm_row_logits_chunked(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H,
+                              int head_dim, int rows_per_chunk, int dtype, void* stream);
+int rnamsm_softmax_rows_chunked(const float* partial, int nchunks, float* probs, int H, int C,
+                                const uint8_t* pad_mask, int rows_per_chunk, void* stream);
 
 /* K6 -- RowSelfAttention.compute_attention_update's contraction (modules.py:797-798):
  *   ctx[r,i,h,:] = sum_j probs[h,i,j] * v[r,j,h,:]
@@ -229,13 +244,17 @@ enum { /* per layer, offset RNAMSM_W_GLOBAL_COUNT + layer * RNAMSM_W_LAYER_COUNT
     RNAMSM_W_LAYER_COUNT
 };
 
-size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int C);
+/* max_tokens_per_msa: the reference's chunking budget (MSATransformer.max_tokens_per_msa_, model.py:418-428).  Without
+ * padding chunking only re-orders sums and the value is ignored; with has_padding and R*C > max_tokens_per_msa the row
+ * attention reproduces the chunked path's per-chunk mask fill (above; the partial-slab region grows to one slab per
+ * chunk and, in the 16-bit modes, that MSA runs on the exact-fp32 kernels).  0 = never chunk. */
+size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int C, int has_padding, int max_tokens_per_msa);
 /* tokens int64 [R,C]; weights: host array of (RNAMSM_W_GLOBAL_COUNT + L*RNAMSM_W_LAYER_COUNT)
  * device pointers; workspace >= rnamsm_forward_workspace_bytes; row_attn [L,H,C,C] (full, with
  * <cls>), repr [R*C, D] (after emb_layer_norm_after), emb [C-1, D], atp [L*H, C-1, C-1]; all four are
  * required outputs.  has_padding != 0: the MSA contains <pad> tokens; the driver builds the padding mask and applies
- * the reference's direct-path mask semantics (§8 f2): zeroed embeddings and q at padded tokens, -10000 on keys whose
- * first-row token is <pad> (row attention) and on padded keys (column attention). */
+ * the reference's mask semantics (§8 f2): zeroed embeddings and q at padded tokens, -10000 on keys whose first-row token
+ * is <pad> (row attention; per row chunk when R*C > max_tokens_per_msa) and on padded keys (column attention). */
 /* weight_planes (host array, may be NULL when dtype == RNAMSM_F32): for every layer 12 device pointers to bf16 planes
  * from rnamsm_split_bf16, in the order {row_wqkv, row_wo, col_wqkv, col_wo, fc1_w, fc2_w} x {hi, lo} (lo may be
  * NULL for RNAMSM_BF16). */
@@ -243,7 +262,8 @@ size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int 
 int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
                    int R, int C, void* workspace, size_t workspace_bytes,
                    float* row_attn, float* repr, float* emb, float* atp,
-                   int* err_flag, int has_padding, int dtype, const uint16_t* const* weight_planes, void* stream);
+                   int* err_flag, int has_padding, int max_tokens_per_msa, int dtype,
+                   const uint16_t* const* weight_planes, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's
  * roofline block; adds two event records per launch while enabled, nothing when disabled).

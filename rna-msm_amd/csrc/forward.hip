@@ -22,7 +22,7 @@ struct Layout {
     size_t x, xn, wide, part, mask, pplanes, total;
 };
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-Layout make_layout(const rnamsm_model_dims& d, int R, int C) {
+Layout make_layout(const rnamsm_model_dims& d, int R, int C, int nchunks) {
     const size_t T = (size_t)R * C, D = d.embed_dim;
     Layout l;
     size_t off = 0;
@@ -31,7 +31,9 @@ Layout make_layout(const rnamsm_model_dims& d, int R, int C) {
     l.wide = off; off += align256(T * (size_t)(3 * D + D > (size_t)d.ffn_dim ? 4 * D : d.ffn_dim) * 4);
     {
         const size_t a = rnamsm_row_logits_workspace_bytes(R, C, d.num_heads), b = rnamsm_row_logits16_workspace_bytes(R, C, d.num_heads);
-        l.part = off; off += align256(a > b ? a : b);
+        const size_t c = (size_t)nchunks * d.num_heads * C * C * sizeof(float);      // one slab per reference row chunk (f2)
+        const size_t ab = a > b ? a : b;
+        l.part = off; off += align256(ab > c ? ab : c);
     }
     l.mask = off; off += align256(T);
     l.pplanes = off; off += align256((size_t)d.num_heads * C * (size_t)((C + 63) / 64 * 64) * 4);   // P hi + lo planes (K5' -> K6')
@@ -40,9 +42,10 @@ Layout make_layout(const rnamsm_model_dims& d, int R, int C) {
 }
 }  // namespace
 
-extern "C" size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int C) {
+extern "C" size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int C, int has_padding,
+                                                 int max_tokens_per_msa) {
     if (!dims || R <= 0 || C <= 0) return 0;
-    return make_layout(*dims, R, C).total;
+    return make_layout(*dims, R, C, has_padding ? rnamsm_row_chunks(R, C, max_tokens_per_msa) : 0).total;
 }
 
 #define FWD(call)                   \
@@ -53,7 +56,7 @@ extern "C" size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, 
 
 extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
                               int R, int C, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
-                              float* emb, float* atp, int* err_flag, int has_padding, int dtype,
+                              float* emb, float* atp, int* err_flag, int has_padding, int max_tokens_per_msa, int dtype,
                               const uint16_t* const* weight_planes, void* stream) {
     RNAMSM_CHECK_ARG(dtype >= RNAMSM_F32 && dtype <= RNAMSM_F16X3, "forward: unknown dtype %d", dtype);
     RNAMSM_CHECK_ARG(dtype == RNAMSM_F32 || weight_planes, "forward: bf16 modes need weight_planes");
@@ -67,7 +70,10 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         return fail(RNAMSM_ERR_INVALID,
                     "Using model with MSA position embedding trained on maximum MSA depth of 1024, but received %d alignments.", R);
     RNAMSM_CHECK_ARG(C <= d.num_positions - d.pad_idx - 1, "forward: C=%d exceeds the positional table", C);
-    const Layout lay = make_layout(d, R, C);
+    // padded AND above the reference's token budget: its chunked path fills the key mask per row chunk (modules.py:717-750)
+    const int nchunks = has_padding ? rnamsm_row_chunks(R, C, max_tokens_per_msa) : 0;
+    const int rows_per_chunk = nchunks ? (max_tokens_per_msa / C > 1 ? max_tokens_per_msa / C : 1) : 0;
+    const Layout lay = make_layout(d, R, C, nchunks);
     RNAMSM_CHECK_ARG(workspace_bytes >= lay.total, "forward: workspace too small (%zu < %zu)", workspace_bytes, lay.total);
     RNAMSM_CHECK_ARG(aligned16(workspace), "forward: workspace must be 16-byte aligned");
 
@@ -101,6 +107,8 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     // A operands of the QKV / fc1 / fc2 GEMMs), so those GEMMs stage plain 16-B copies.  The planes overlay the fp32
     // buffers they replace (2 x 2 B per element).
     // (a padded batch with the "attn16" knob off keeps the fp32 attention kernels and the masked fp32 QKV GEMM)
+    // (per-chunk mask fills exist in the fp32 row kernels only: such an MSA takes the exact path as a whole)
+    if (nchunks) dtype = RNAMSM_F32;
     const bool planes = dtype != RNAMSM_F32 && (!has_padding || tuning().attn16 != 0);
     const int split = dtype == RNAMSM_BF16 ? 1 : 3, fmt = dtype == RNAMSM_F16X3 ? 1 : 0;
     uint16_t* xn_hi = reinterpret_cast<uint16_t*>(xn);
@@ -161,8 +169,13 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             else
                 FWD(linear(l, 0, xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
                            RNAMSM_ACT_NONE, row_scale, D, mask));
-            FWD(rnamsm_row_logits(qkv, qkv + D, ldq, part, R, C, H, 64, f32, stream));
-            FWD(rnamsm_softmax_rows(part, nsplit, probs, H, C, mask, stream));
+            if (nchunks) {
+                FWD(rnamsm_row_logits_chunked(qkv, qkv + D, ldq, part, R, C, H, 64, rows_per_chunk, f32, stream));
+                FWD(rnamsm_softmax_rows_chunked(part, nchunks, probs, H, C, mask, rows_per_chunk, stream));
+            } else {
+                FWD(rnamsm_row_logits(qkv, qkv + D, ldq, part, R, C, H, 64, f32, stream));
+                FWD(rnamsm_softmax_rows(part, nsplit, probs, H, C, mask, stream));
+            }
             FWD(rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, ctx_hi, ctx_lo, fmt, f32, stream));
         }
         if (planes)

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
                                                            float* __restrict__ probs, int64_t rows, int C,
                                                            const uint8_t* __restrict__ key_mask,
                                                            uint16_t* __restrict__ p_hi, uint16_t* __restrict__ p_lo,
-                                                           int64_t ldp, float plane_scale) {
+                                                           int64_t ldp, float plane_scale, int64_t mask_slab_stride) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -116,10 +116,19 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
         float s = -INFINITY;
         if (j < C) {
             const float* p = partial + row * C + j;
-            s = p[0];
-            for (int sp = 1; sp < nsplit; ++sp) s += p[(int64_t)sp * slab];
-            // f2: masked_fill(padding_mask[:, 0], -10000) on the key axis (modules.py:781-785)
-            if (key_mask && key_mask[j]) s = -10000.f;
+            if (mask_slab_stride == 0) {
+                s = p[0];
+                for (int sp = 1; sp < nsplit; ++sp) s += p[(int64_t)sp * slab];
+                // f2: masked_fill(padding_mask[:, 0], -10000) on the key axis (modules.py:781-785)
+                if (key_mask && key_mask[j]) s = -10000.f;
+            } else {
+                // f2 on the reference's chunked path (_batched_forward, modules.py:717-750): every slab is one row chunk,
+                // filled with -10000 where the chunk's OWN first row is padded (:727-737), then `attns += attn_weights`
+                // in chunk order -- masks of slab sp start at key_mask + sp * mask_slab_stride
+                s = key_mask[j] ? -10000.f : p[0];
+                for (int sp = 1; sp < nsplit; ++sp)
+                    s += key_mask[(int64_t)sp * mask_slab_stride + j] ? -10000.f : p[(int64_t)sp * slab];
+            }
         }
         v[e] = s;
         mx = fmaxf(mx, s);
@@ -281,8 +290,28 @@ extern "C" size_t rnamsm_row_logits_workspace_bytes(int R, int C, int H) {
     return (size_t)choose_row_split(R, C, H).nsplit * H * C * C * sizeof(float);
 }
 
+static int row_logits_launch(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H,
+                             int head_dim, int dtype, void* stream, int rows_per_chunk);
+
 extern "C" int rnamsm_row_logits(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H,
                                  int head_dim, int dtype, void* stream) {
+    return row_logits_launch(q, k, ld, partial, R, C, H, head_dim, dtype, stream, 0);
+}
+
+extern "C" int rnamsm_row_chunks(int R, int C, int max_tokens_per_msa) {
+    if (R <= 0 || C <= 0 || max_tokens_per_msa <= 0 || (int64_t)R * C <= max_tokens_per_msa) return 0;
+    const int max_rows = max_tokens_per_msa / C > 1 ? max_tokens_per_msa / C : 1;      // modules.py:724
+    return (R + max_rows - 1) / max_rows;
+}
+
+extern "C" int rnamsm_row_logits_chunked(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H,
+                                         int head_dim, int rows_per_chunk, int dtype, void* stream) {
+    RNAMSM_CHECK_ARG(rows_per_chunk >= 1, "row_logits_chunked: rows_per_chunk must be >= 1 (got %d)", rows_per_chunk);
+    return row_logits_launch(q, k, ld, partial, R, C, H, head_dim, dtype, stream, rows_per_chunk);
+}
+
+static int row_logits_launch(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H,
+                             int head_dim, int dtype, void* stream, int rows_per_chunk) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "row_logits: only RNAMSM_F32 is implemented");
     RNAMSM_CHECK_ARG(q && k && partial, "row_logits: null pointer");
     RNAMSM_CHECK_ARG(head_dim == HEAD_DIM, "row_logits: head_dim must be 64 (got %d)", head_dim);
@@ -295,7 +324,11 @@ extern "C" int rnamsm_row_logits(const float* q, const float* k, int64_t ld, flo
         if (rc) return rc;
         configured.mark();
     }
-    const RowSplit sp = choose_row_split(R, C, H);
+    RowSplit sp = choose_row_split(R, C, H);
+    if (rows_per_chunk > 0) {       // slabs = the reference's row chunks (f2 on the chunked path)
+        sp.rows_per_split = rows_per_chunk;
+        sp.nsplit = (R + rows_per_chunk - 1) / rows_per_chunk;
+    }
     const unsigned tiles_c = (C + BM - 1) / BM;
     const unsigned grid = xcd_panel_grid((unsigned)(H * sp.nsplit), tiles_c * tiles_c);
     KernelTimer timer(TC_ROW_LOGITS, 2.0 * H * C * C * R * HEAD_DIM,
@@ -307,7 +340,8 @@ extern "C" int rnamsm_row_logits(const float* q, const float* k, int64_t ld, flo
 }
 
 static int softmax_rows_launch(const float* partial, int nsplit, float* probs, int H, int C, const uint8_t* key_mask,
-                               uint16_t* p_hi, uint16_t* p_lo, int64_t ldp, float plane_scale, int fmt, void* stream) {
+                               uint16_t* p_hi, uint16_t* p_lo, int64_t ldp, float plane_scale, int fmt, void* stream,
+                               int64_t mask_slab_stride = 0) {
     RNAMSM_CHECK_ARG(partial && probs, "softmax_rows: null pointer");
     RNAMSM_CHECK_ARG(nsplit >= 1 && H > 0 && C > 0 && C <= 64 * SOFTMAX_MAX_PER_LANE,
                      "softmax_rows: bad shape nsplit=%d H=%d C=%d (C <= %d)", nsplit, H, C, 64 * SOFTMAX_MAX_PER_LANE);
@@ -318,11 +352,11 @@ static int softmax_rows_launch(const float* partial, int nsplit, float* probs, i
     const dim3 grid((unsigned)((rows + 3) / 4));
     KernelTimer timer(TC_SOFTMAX, 0.0, 4.0 * (double)(nsplit + 1) * H * C * C + (p_hi ? (p_lo ? 4.0 : 2.0) * rows * ldp : 0.0), s);
     if (!p_hi)
-        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale);
+        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride);
     else if (fmt == 0)
-        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale);
+        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride);
     else
-        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale);
+        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride);
     RNAMSM_CHECK_LAUNCH("softmax_rows");
     return RNAMSM_OK;
 }
@@ -330,6 +364,13 @@ static int softmax_rows_launch(const float* partial, int nsplit, float* probs, i
 extern "C" int rnamsm_softmax_rows(const float* partial, int nsplit, float* probs, int H, int C,
                                    const uint8_t* key_mask, void* stream) {
     return softmax_rows_launch(partial, nsplit, probs, H, C, key_mask, nullptr, nullptr, 0, 1.f, 0, stream);
+}
+
+extern "C" int rnamsm_softmax_rows_chunked(const float* partial, int nchunks, float* probs, int H, int C,
+                                           const uint8_t* pad_mask, int rows_per_chunk, void* stream) {
+    RNAMSM_CHECK_ARG(pad_mask && rows_per_chunk >= 1, "softmax_rows_chunked: pad_mask [R, C] and rows_per_chunk >= 1 are required");
+    return softmax_rows_launch(partial, nchunks, probs, H, C, pad_mask, nullptr, nullptr, 0, 1.f, 0, stream,
+                               (int64_t)rows_per_chunk * C);
 }
 
 extern "C" int rnamsm_softmax_rows_planes(const float* partial, int nsplit, float* probs, uint16_t* p_hi, uint16_t* p_lo,

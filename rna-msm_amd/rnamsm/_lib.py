@@ -50,6 +50,10 @@ _SIGNATURES = {
     "rnamsm_row_logits_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rnamsm_row_logits": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rnamsm_softmax_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rnamsm_row_chunks": (c_int, [c_int, c_int, c_int]),
+    "rnamsm_row_logits_chunked": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_void_p]),
+    "rnamsm_softmax_rows_chunked": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "rnamsm_row_apply": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                  c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rnamsm_col_attn_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
@@ -71,9 +75,10 @@ _SIGNATURES = {
     "rnamsm_contact_head": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "rnamsm_greedy_select_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rnamsm_greedy_select": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "rnamsm_forward_workspace_bytes": (c_size_t, [POINTER(ModelDims), c_int, c_int]),
+    "rnamsm_forward_workspace_bytes": (c_size_t, [POINTER(ModelDims), c_int, c_int, c_int, c_int]),
     "rnamsm_forward": (c_int, [POINTER(ModelDims), POINTER(c_void_p), c_void_p, c_int, c_int, c_void_p, c_size_t,
-                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p), c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_void_p),
+                               c_void_p]),
     "rnamsm_timing_enable": (c_int, [c_int]),
     "rnamsm_timing_collect": (c_int, []),
     "rnamsm_timing_get": (c_int, [c_int, POINTER(c_char_p), POINTER(ctypes.c_longlong), POINTER(ctypes.c_double),

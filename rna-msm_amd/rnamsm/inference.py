@@ -117,8 +117,8 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
-    if device.index is None and world > 1:
-        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", rank)))
+    if device.index is None:          # "cuda": this rank's GPU under a launcher, else the process's current device
+        device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", rank)) if world > 1 else torch.cuda.current_device())
     alphabet = RNAAlphabet.from_architecture(cfg.data.architecture)
     if rank == 0:
         print(f"Maximum Number of MSA Seqs:{cfg.data.max_seqs_per_msa}")

@@ -86,8 +86,9 @@ class MSATransformer(nn.Module):
 
     # ------------------------------------------------------------------ reference API
     def max_tokens_per_msa_(self, value: int) -> None:
-        """Kept for interface parity (model.py:418-428).  The reference uses it to bound memory by chunking;
-        the HIP kernels tile internally, so results are identical for every value."""
+        """model.py:418-428.  The reference uses it to bound memory by chunking; the HIP kernels tile internally, so
+        without padding results are identical for every value.  With padding the reference's chunked row attention fills
+        its key mask per row chunk (modules.py:717-750), which is reproduced (rnamsm_row_logits_chunked)."""
         self.max_tokens_per_msa = value
         for layer in self.layers:
             layer.row_self_attention.layer.max_tokens_per_msa = value
@@ -209,7 +210,12 @@ class MSATransformer(nn.Module):
         dims, ptrs, _ = self._packed_weights()
         dev = tokens2d.device
         NL, H, D = self.num_layers, self.num_attention_heads, self.embed_dim
-        ws_bytes = lib.rnamsm_forward_workspace_bytes(ctypes.byref(dims), R, C)
+        toks = tokens2d.to(torch.int64).contiguous()
+        if has_padding is None:       # padding_mask = tokens.eq(pad); None when nothing is padded (model.py:346-348)
+            has_padding = bool((toks == self.vocab.pad_idx).any())
+        # the token budget matters only with padding (the chunked row path fills its key mask per chunk)
+        max_tokens = min(int(self.max_tokens_per_msa), 2 ** 31 - 1) if has_padding else 0
+        ws_bytes = lib.rnamsm_forward_workspace_bytes(ctypes.byref(dims), R, C, int(has_padding), max_tokens)
         ws = self._get_workspace(ws_bytes, dev)
         row_attn = torch.empty(NL, H, C, C, device=dev, dtype=torch.float32)
         rep = torch.empty(R, C, D, device=dev, dtype=torch.float32)
@@ -218,12 +224,9 @@ class MSATransformer(nn.Module):
         err = torch.zeros(1, device=dev, dtype=torch.int32)
         dtype = _lib.DTYPES[self.gemm_dtype]
         planes = self._weight_planes() if dtype != _lib.F32 else None
-        toks = tokens2d.to(torch.int64).contiguous()
-        if has_padding is None:       # padding_mask = tokens.eq(pad); None when nothing is padded (model.py:346-348)
-            has_padding = bool((toks == self.vocab.pad_idx).any())
         _lib.check(lib.rnamsm_forward(ctypes.byref(dims), ptrs, toks.data_ptr(), R, C, ws.data_ptr(), ws.numel(),
                                       row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
-                                      err.data_ptr(), int(has_padding), dtype, planes,
+                                      err.data_ptr(), int(has_padding), max_tokens, dtype, planes,
                                       torch.cuda.current_stream().cuda_stream))
         if dtype != _lib.F32 and self.check_finite:
             # f16x3 / bf16 operands live in 16-bit planes: fp16 overflows above 65504 (-> inf/NaN downstream).  The

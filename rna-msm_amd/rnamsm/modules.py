@@ -7,7 +7,7 @@ nn.Linear / nn.LayerNorm children only HOLD parameters (for state_dict compatibi
 operator computes anything -- every forward goes through rnamsm.ops to the HIP kernels.
 
 Scope: inference, one MSA per call (B = 1; the model loops over a batch).  Padding masks follow the
-reference's direct (un-chunked) path (§8 f2).  Training-mode dropout and `self_attn_mask` raise instead of silently
+reference's direct path, or its chunked path when R*C > max_tokens_per_msa (§8 f2).  Training-mode dropout and `self_attn_mask` raise instead of silently
 doing something else.
 """
 from __future__ import annotations
@@ -61,8 +61,9 @@ class _AxialAttentionBase(nn.Module):
         self.dropout = dropout
         self.head_dim = embed_dim // num_heads
         self.scaling = self.head_dim ** -0.5
-        # Accepted for interface compatibility.  The reference chunks rows/columns above this token budget
-        # (_batched_forward); the kernels tile internally and produce the same sums, so the value changes nothing.
+        # The reference chunks rows/columns above this token budget (_batched_forward).  The kernels tile internally and
+        # produce the same sums, so without padding the value changes nothing; WITH padding the chunked row path fills
+        # its key mask per chunk, which RowSelfAttention reproduces.
         self.max_tokens_per_msa = max_tokens_per_msa
         self.k_proj = nn.Linear(embed_dim, embed_dim)
         self.v_proj = nn.Linear(embed_dim, embed_dim)
@@ -106,8 +107,15 @@ class RowSelfAttention(_AxialAttentionBase):
         H = self.num_heads
         # padded tokens: q = 0 (modules.py:767-772); keys whose FIRST-row token is <pad>: logit -10000 (:781-785)
         qkv = self._qkv(x2, self.align_scaling(x), zero_rows=mask)
-        partial, _ = ops.row_logits(qkv[:, :D], qkv[:, D:2 * D], R, C, H)
-        probs = ops.softmax_rows(partial, key_mask=None if mask is None else mask[:C])
+        # with padding AND R*C above the token budget the reference sums row chunks that were each filled from their
+        # own first row (_batched_forward, modules.py:717-750): reproduced; without padding chunking is a re-ordering
+        nchunks, rows_per_chunk = ops.row_chunks(R, C, self.max_tokens_per_msa) if mask is not None else (0, 0)
+        if nchunks:
+            partial, _ = ops.row_logits(qkv[:, :D], qkv[:, D:2 * D], R, C, H, rows_per_chunk=rows_per_chunk)
+            probs = ops.softmax_rows(partial, chunk_pad_mask=mask, rows_per_chunk=rows_per_chunk)
+        else:
+            partial, _ = ops.row_logits(qkv[:, :D], qkv[:, D:2 * D], R, C, H)
+            probs = ops.softmax_rows(partial, key_mask=None if mask is None else mask[:C])
         ctx = ops.row_apply(probs, qkv[:, 2 * D:], R, C, H)
         res2 = None if _residual is None else _residual.contiguous().view(R * C, D)
         out = self._project_out(ctx, res2)

@@ -123,23 +123,44 @@ def linear_bf16(a: torch.Tensor, w_hi: torch.Tensor, w_lo: Optional[torch.Tensor
 
 
 @_on_operand_device
-def row_logits(q: torch.Tensor, k: torch.Tensor, R: int, C: int, H: int) -> Tuple[torch.Tensor, int]:
-    """q, k: [R*C, *] views with row stride ld; returns (partial [nsplit,H,C,C], nsplit)."""
+def row_logits(q: torch.Tensor, k: torch.Tensor, R: int, C: int, H: int, rows_per_chunk: int = 0) -> Tuple[torch.Tensor, int]:
+    """q, k: [R*C, *] views with row stride ld; returns (partial [nsplit,H,C,C], nsplit).  rows_per_chunk > 0: one slab
+    per reference row chunk (the padded, chunked path: rnamsm_row_logits_chunked)."""
     lib = _lib.load()
-    nsplit = lib.rnamsm_row_logits_nsplit(R, C, H)
+    nsplit = (R + rows_per_chunk - 1) // rows_per_chunk if rows_per_chunk > 0 else lib.rnamsm_row_logits_nsplit(R, C, H)
     partial = torch.empty(nsplit, H, C, C, device=q.device, dtype=torch.float32)
     ld = _rowmajor(q, "q")
     assert _rowmajor(k, "k") == ld
-    _lib.check(lib.rnamsm_row_logits(_dev(q, "q"), _dev(k, "k"), ld, _dev(partial, "partial"), R, C, H, HEAD_DIM, F32,
-                                     _stream()))
+    if rows_per_chunk > 0:
+        _lib.check(lib.rnamsm_row_logits_chunked(_dev(q, "q"), _dev(k, "k"), ld, _dev(partial, "partial"), R, C, H, HEAD_DIM,
+                                                 rows_per_chunk, F32, _stream()))
+    else:
+        _lib.check(lib.rnamsm_row_logits(_dev(q, "q"), _dev(k, "k"), ld, _dev(partial, "partial"), R, C, H, HEAD_DIM, F32,
+                                         _stream()))
     return partial, nsplit
+
+
+def row_chunks(R: int, C: int, max_tokens_per_msa: int):
+    """(number of row chunks, rows per chunk) of the reference's _batched_forward (modules.py:717-750), (0, 0) when it
+    takes the direct path."""
+    mt = min(int(max_tokens_per_msa), 2 ** 31 - 1)
+    n = _lib.load().rnamsm_row_chunks(R, C, mt)
+    return (n, max(1, mt // C)) if n else (0, 0)
 
 
 @_on_operand_device
 def softmax_rows(partial: torch.Tensor, out: Optional[torch.Tensor] = None,
-                 key_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 key_mask: Optional[torch.Tensor] = None, chunk_pad_mask: Optional[torch.Tensor] = None,
+                 rows_per_chunk: int = 0) -> torch.Tensor:
+    """key_mask uint8 [C]: direct-path fill.  chunk_pad_mask uint8 [R*C] + rows_per_chunk: the chunked path's per-chunk
+    fill (slab c is masked by row c*rows_per_chunk of the padding mask)."""
     nsplit, H, C, _ = partial.shape
     probs = torch.empty(H, C, C, device=partial.device, dtype=torch.float32) if out is None else out
+    if chunk_pad_mask is not None:
+        _lib.check(_lib.load().rnamsm_softmax_rows_chunked(_dev(partial, "partial"), nsplit, _dev(probs, "probs"), H, C,
+                                                           _dev(chunk_pad_mask, "chunk_pad_mask", torch.uint8),
+                                                           rows_per_chunk, _stream()))
+        return probs
     _lib.check(_lib.load().rnamsm_softmax_rows(_dev(partial, "partial"), nsplit, _dev(probs, "probs"), H, C,
                                                None if key_mask is None else _dev(key_mask, "key_mask", torch.uint8),
                                                _stream()))

@@ -308,6 +308,45 @@ def test_padding_mask_kernel_semantics(dev):
     assert rel_l2(ctx, want_ctx) < 5e-6
 
 
+@pytest.mark.parametrize("R,C,max_tokens", [(9, 13, 13 * 2), (9, 13, 1), (70, 33, 33 * 16), (6, 140, 140 * 4)])
+def test_chunked_path_padding_mask_kernels(dev, R, C, max_tokens):
+    """SURVEY §8 f2 "chunk quirk" at kernel level (modules.py:717-750): rnamsm_row_logits_chunked emits one slab per
+    reference row chunk and rnamsm_softmax_rows_chunked fills every slab with -10000 where the chunk's own first row is
+    padded before adding the slabs in chunk order.  Checked against that arithmetic in fp64 (logits without an
+    all-padded chunk start: there -10000 lands in the sum and fp32 quantises it, see the model-level test)."""
+    from rnamsm import ops
+    H = 2
+    D = 64 * H
+    rng = np.random.RandomState(R + C)
+    pad = torch.from_numpy(rng.rand(R, C) < 0.15)
+    pad[0, C // 2] = True
+    nchunks, rpc = ops.row_chunks(R, C, max_tokens)
+    assert nchunks == -(-R // max(1, max_tokens // C)) and rpc == max(1, max_tokens // C)
+    assert ops.row_chunks(R, C, R * C) == (0, 0)                      # at the budget: the reference's direct path
+    mask = pad.to(torch.uint8).contiguous().view(-1).to(dev)
+    x, w, b = _rand("cp.x", (R * C, D)), _rand("cp.w", (3 * D, D), 0.1), _rand("cp.b", (3 * D,), 0.1)
+    qkv = ops.linear(x.to(dev), w.to(dev), b.to(dev), scale=0.25, scale_cols=D, zero_rows=mask)
+    want = x.double() @ w.double().t() + b.double()
+    want[:, :D] *= 0.25
+    want[pad.view(-1), :D] = 0
+    q, k = (want[:, i * D:(i + 1) * D].view(R, C, H, 64) for i in range(2))
+    partial, n = ops.row_logits(qkv[:, :D], qkv[:, D:2 * D], R, C, H, rows_per_chunk=rpc)
+    assert n == nchunks and partial.shape == (nchunks, H, C, C)
+    logits = 0
+    for c in range(nchunks):
+        s = slice(c * rpc, (c + 1) * rpc)
+        wc = torch.einsum("rihd,rjhd->hij", q[s], k[s])
+        assert rel_l2(partial[c].cpu(), wc) < 3e-6                     # slab c is chunk c's logits
+        logits = logits + wc.masked_fill(pad[c * rpc][None, None, :], -10000)
+    probs = ops.softmax_rows(partial, chunk_pad_mask=mask, rows_per_chunk=rpc).cpu()
+    assert np.abs(probs.numpy() - torch.softmax(logits, -1).numpy()).max() < 3e-4   # fp32 quantisation of n * -10000 sums
+    masked_anywhere = torch.stack([pad[c * rpc] for c in range(nchunks)]).any(0)
+    assert float(probs[:, :, masked_anywhere].max()) == 0.0            # a pad on ANY chunk-starting row kills the key
+    direct = ops.softmax_rows(ops.row_logits(qkv[:, :D], qkv[:, D:2 * D], R, C, H)[0], key_mask=mask[:C]).cpu()
+    if bool((masked_anywhere & ~pad[0]).any()):
+        assert float((probs - direct).abs().max()) > 1e-3              # ... which the direct semantics do not do
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 128, 64), (300, 384, 128), (1025, 768, 768), (513, 768, 3072)])
 def test_gemm_16bit_matrix_core_modes(dev, M, N, K):
     """rnamsm_gemm_bf16 (include/rnamsm.h): stated error of each operand mode vs fp64 -- bf16 (2^-9 operands),

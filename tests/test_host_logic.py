@@ -158,7 +158,7 @@ def test_library_exports_every_symbol_declared_in_the_header(lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rnamsm_version() == 100
+    assert lib.rnamsm_version() == 200         # ABI 2: rnamsm_forward takes max_tokens_per_msa (f2, chunked path)
 
 
 def test_ctypes_signatures_match_the_header_prototypes():
@@ -196,7 +196,7 @@ def test_library_validates_arguments_without_a_gpu(lib):
     assert lib.rnamsm_row_logits_workspace_bytes(256, 512, 12) == 8 * 12 * 512 * 512 * 4
     dims = _lib.ModelDims(10, 768, 12, 3072, 12, 1026, 1, 1e-5)
     import ctypes
-    need = lib.rnamsm_forward_workspace_bytes(ctypes.byref(dims), 256, 512)
+    need = lib.rnamsm_forward_workspace_bytes(ctypes.byref(dims), 256, 512, 0, 0)
     T = 256 * 512
     assert lib.rnamsm_row_logits16_nsplit(256, 512, 12, 3) == 16    # 256x256 tiles, one block per CU: 12 * 16 * 4 = 3 rounds
     assert lib.rnamsm_row_logits16_nsplit(256, 512, 12, 1) == 8     # plain bf16 stays on the 128x128 kernel
