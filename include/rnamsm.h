@@ -209,6 +209,10 @@ size_t rnamsm_contact_head_workspace_bytes(int C, int nch);
 int rnamsm_contact_head(const float* row_attn, const float* weight, const float* bias, float* contacts,
                         void* workspace, size_t workspace_bytes, int C, int nch, void* stream);
 
+/* a10 -- head-averaged attention weights of the generic MultiheadAttention (msm/multihead_attention.py:389-397,
+ * need_weights=True without need_head_weights): out[i] = mean_h probs[h, i], probs [H, n] fp32, out [n]. */
+int rnamsm_head_mean(const float* probs, float* out, int H, int64_t n, void* stream);
+
 /* f3 -- greedy max/min mean-Hamming row sub-sampling (MSA.greedy_select, utils/align.py:128-148, via
  * select_diverse "diversity-max" / "diversity-min", :165-181): msa uint8 [N, L] (any per-character code, e.g. the raw
  * bytes or token ids), keeps row 0, returns the num_seqs selected row indices in ascending order.  Performs the
@@ -217,6 +221,11 @@ int rnamsm_contact_head(const float* row_attn, const float* weight, const float*
 size_t rnamsm_greedy_select_workspace_bytes(int N, int L, int num_seqs);
 int rnamsm_greedy_select(const uint8_t* msa, int N, int L, int num_seqs, int minimise, int* out_indices,
                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* f3 -- sequence weights for `sample-pretrained` sub-sampling (MSA.weights, utils/align.py:250-253, consumed by
+ * MSA.sample_weights, :150-163): weights[i] = 1 / #{ j : hamming(msa[i], msa[j]) / L < seqid_cutoff } as float64 (the row
+ * itself counts), msa uint8 [N, L].  The random draw itself stays on the host (numpy's generator is the contract). */
+int rnamsm_msa_weights(const uint8_t* msa, int N, int L, double seqid_cutoff, double* weights, void* stream);
 
 /* Whole forward, K0..K10 for one MSA, driven from C++ so that one call enqueues every launch
  * (MSATransformer.forward, model.py:338-416, with repr_layers=[num_layers], need_head_weights=True,

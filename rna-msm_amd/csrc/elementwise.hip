@@ -116,6 +116,16 @@ __global__ __launch_bounds__(256) void pad_mask_kernel(const int64_t* __restrict
     if (i < n) mask[i] = tokens[i] == pad_idx;
 }
 
+// a10: head-averaged attention weights, attn_weights.mean(dim=0) over [H, ...] (msm/multihead_attention.py:394-397)
+__global__ __launch_bounds__(256) void head_mean_kernel(const float* __restrict__ probs, float* __restrict__ out, int H,
+                                                        int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = probs[i];
+    for (int h = 1; h < H; ++h) s += probs[(int64_t)h * n + i];
+    out[i] = s / (float)H;
+}
+
 // f2 in the 16-bit modes: q *= 1 - padding_mask (modules.py:767-772) on q planes the QKV GEMM has already written: one
 // wave per flagged token row zeroes its first `ncols` halves in the hi (and lo) plane; unflagged rows are not touched.
 __global__ __launch_bounds__(256) void zero_plane_rows_kernel(uint16_t* __restrict__ hi, uint16_t* __restrict__ lo,
@@ -193,6 +203,14 @@ extern "C" int rnamsm_pad_mask(const int64_t* tokens, uint8_t* mask, int64_t n, 
     hipLaunchKernelGGL(pad_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        tokens, mask, n, pad_idx);
     RNAMSM_CHECK_LAUNCH("pad_mask");
+    return RNAMSM_OK;
+}
+
+extern "C" int rnamsm_head_mean(const float* probs, float* out, int H, int64_t n, void* stream) {
+    RNAMSM_CHECK_ARG(probs && out && H > 0 && n > 0, "head_mean: bad arguments");
+    hipLaunchKernelGGL(head_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       probs, out, H, n);
+    RNAMSM_CHECK_LAUNCH("head_mean");
     return RNAMSM_OK;
 }
 

@@ -136,9 +136,47 @@ __global__ void greedy_init_kernel(double* lut, int L, uint8_t* taken, int* chos
     if (n == 0) chosen[0] = 0;
 }
 
+// MSA.weights (utils/align.py:250-253) for `sample-pretrained` sub-sampling (:150-163):
+//   weights[i] = 1 / #{ j : hamming(i, j) / L < seqid_cutoff }   (pdist "hamming" in float64, the row itself included).
+// One block per row i (staged in LDS); each group of G lanes (G = power of two >= min(L, 64)) counts the mismatches of one
+// row j, so short alignments keep all lanes busy; the comparison is the reference's: (double)m / (double)L < cutoff.
+// O(N^2 L) byte compares out of L2 -- 1e4 rows x 512 columns is ~50 G compares, well under a second.
+__global__ __launch_bounds__(256) void msa_weights_kernel(const uint8_t* __restrict__ msa, int N, int L, double cutoff,
+                                                          int G, double* __restrict__ weights) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t srow[];
+    __shared__ int total;
+    const int i = blockIdx.x;
+    for (int c = threadIdx.x; c < L; c += 256) srow[c] = msa[(int64_t)i * L + c];
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    const int groups = 256 / G, g = threadIdx.x / G, gl = threadIdx.x % G;
+    int mine = 0;
+    for (int j = g; j < N; j += groups) {
+        const uint8_t* b = msa + (int64_t)j * L;
+        int m = 0;
+        for (int c = gl; c < L; c += G) m += srow[c] != b[c];
+        for (int off = G >> 1; off > 0; off >>= 1) m += __shfl_xor(m, off, 64);
+        if (gl == 0 && (double)m / (double)L < cutoff) ++mine;
+    }
+    if (gl == 0 && mine) atomicAdd(&total, mine);        // integer count: order-independent
+    __syncthreads();
+    if (threadIdx.x == 0) weights[i] = 1.0 / (double)total;
+}
+
 }  // namespace rnamsm
 
 using namespace rnamsm;
+
+extern "C" int rnamsm_msa_weights(const uint8_t* msa, int N, int L, double seqid_cutoff, double* weights, void* stream) {
+    RNAMSM_CHECK_ARG(msa && weights, "msa_weights: null pointer");
+    RNAMSM_CHECK_ARG(N > 0 && L > 0 && L <= 65536, "msa_weights: bad shape N=%d L=%d", N, L);
+    int G = 1;
+    while (G < L && G < 64) G <<= 1;
+    hipLaunchKernelGGL(msa_weights_kernel, dim3((unsigned)N), dim3(256), (size_t)L, static_cast<hipStream_t>(stream), msa, N,
+                       L, seqid_cutoff, G, weights);
+    RNAMSM_CHECK_LAUNCH("msa_weights");
+    return RNAMSM_OK;
+}
 
 static size_t greedy_ws(int N, int L, int num_seqs, size_t* o_score, size_t* o_chosen, size_t* o_taken, size_t* o_hist) {
     size_t off = ((size_t)L + 1) * 8;      // lut: m / L

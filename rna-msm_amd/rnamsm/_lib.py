@@ -9,7 +9,7 @@ import ctypes
 import os
 
 import torch  # noqa: F401  (load order: see rnamsm/__init__.py)
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librnamsm_hip.so")
@@ -69,12 +69,14 @@ _SIGNATURES = {
     "rnamsm_col_attn16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                   c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rnamsm_zero_plane_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "rnamsm_head_mean": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "rnamsm_pad_mask": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rnamsm_pack_outputs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rnamsm_contact_head_workspace_bytes": (c_size_t, [c_int, c_int]),
     "rnamsm_contact_head": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "rnamsm_greedy_select_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rnamsm_greedy_select": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rnamsm_msa_weights": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
     "rnamsm_forward_workspace_bytes": (c_size_t, [POINTER(ModelDims), c_int, c_int, c_int, c_int]),
     "rnamsm_forward": (c_int, [POINTER(ModelDims), POINTER(c_void_p), c_void_p, c_int, c_int, c_void_p, c_size_t,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_void_p),

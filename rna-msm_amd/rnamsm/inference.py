@@ -155,8 +155,14 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
         written.append(rna_id)
 
     def read(idx: int) -> np.ndarray:
+        """Reader + row sub-sampling + crop of one alignment.  All randomness of the CLI lives here, drawn from ONE stream
+        in the reference's order -- per item `sample-pretrained`'s weighted draw (dataset.py:88-90), then the crop
+        (dataset.py:147) -- seeded 42 like the reference's global numpy state (RNA_MSM_Inference.py:17), so a single
+        process reproduces the reference's choices; under sharding every rank draws for its own items."""
         torch.cuda.set_device(device)
-        return load_msa_tokens(files[ids[idx]], alphabet, cfg.data.max_seqs_per_msa, cfg.data.sample_method, device=device)
+        tokens = load_msa_tokens(files[ids[idx]], alphabet, cfg.data.max_seqs_per_msa, cfg.data.sample_method, device=device,
+                                 rng=rng)
+        return crop_tokens(tokens, cfg.data.max_seqlen, rng)
 
     gathering = gather_to_rank0 and world > 1
     writer = _AsyncNpyWriter(device) if async_io and (not gathering or rank == 0) else None
@@ -181,7 +187,6 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                 tokens = pending.result() if reader else read(idx)
                 if reader and n + 1 < len(mine):
                     pending = reader.submit(read, mine[n + 1])       # parsed while the GPU runs this MSA
-                tokens = crop_tokens(tokens, cfg.data.max_seqlen, rng)
                 out = model.forward_one(torch.from_numpy(tokens).to(device))
                 if int(out["err"].item()) != 0:
                     raise IndexError(f"{rna_id}: token or position index out of range")

@@ -216,15 +216,23 @@ class AxialTransformerLayer(nn.Module):
 
 
 class MultiheadAttention(_AxialAttentionBase):
-    """Generic 1-D self-attention entry point (SURVEY.md §8 f4); mirrors the self-attention path of the reference's
-    fairseq-style MultiheadAttention (msm/multihead_attention.py:66-397: q*scaling -> bmm -> softmax -> bmm ->
-    out_proj) and loads its q_proj / k_proj / v_proj / out_proj state_dict.
+    """Generic 1-D self-attention entry point (SURVEY.md §8 a10 / f4); mirrors the self-attention path of the reference's
+    fairseq-style MultiheadAttention (msm/multihead_attention.py:66-397: q*scaling -> bmm -> key_padding_mask -> softmax
+    -> bmm -> out_proj) with its signature and DEFAULTS, and loads its q_proj / k_proj / v_proj / out_proj state_dict.
 
-    forward(query[T,B,E], key, value) with key/value the same tensor as query -> (attn[T,B,E], None).  In this
-    layout it IS the fused column-attention kernel with R := T and C := B (every batch element attends along T),
-    so T <= 1024 and head_dim 64.  Everything outside plain eval-mode self-attention raises: masks, incremental
-    state, bias_kv / zero_attn, cross-attention, and the averaged attention weights (the fused kernel never forms
-    the [B*H,T,T] probabilities)."""
+    forward(query[T,B,E], key, value, key_padding_mask=None, need_weights=True, need_head_weights=False) with key / value
+    the same tensor as query -> (attn[T,B,E], weights):
+      * need_weights (the reference's default, and what its only caller passes, msm/modules.py:123-131): weights are the
+        head-averaged probabilities [B,T,T] (:394-397), or the per-head ones [H,B,T,T] with need_head_weights (:389-393).
+        The probabilities are materialised per batch element by the tied-row kernels with one alignment row
+        (R := 1, C := T: K4 logits, K5 softmax with the key mask, K6 apply), T <= 1024;
+      * need_weights=False: the fused column-attention kernel with R := T and C := B (every batch element attends along
+        T; the probabilities never exist), weights = None;
+      * key_padding_mask [B,T] (:360-369): masked keys get probability 0.  The reference fills -inf, the kernels -10000
+        (exp underflows to 0 in fp32 either way); a query whose keys are ALL masked is NaN in the reference and a
+        uniform distribution here.
+    Raises for what is outside eval-mode self-attention: attn_mask, incremental state, static_kv, before_softmax,
+    bias_kv / zero_attn, cross-attention, dropout in training."""
 
     def __init__(self, embed_dim, num_heads, kdim=None, vdim=None, dropout=0.0, bias=True, add_bias_kv=False,
                  add_zero_attn=False, self_attention=False, encoder_decoder_attention=False):
@@ -236,19 +244,45 @@ class MultiheadAttention(_AxialAttentionBase):
         self.embed_dim = embed_dim
         self.self_attention = True
 
-    def forward(self, query, key=None, value=None, key_padding_mask=None, incremental_state=None, need_weights=False,
+    def forward(self, query, key=None, value=None, key_padding_mask=None, incremental_state=None, need_weights=True,
                 static_kv=False, attn_mask=None, before_softmax=False, need_head_weights=False):
-        if key_padding_mask is not None or attn_mask is not None or incremental_state is not None or static_kv:
-            raise NotImplementedError("masks / incremental decoding are not implemented")
-        if need_weights or need_head_weights or before_softmax:
-            raise NotImplementedError("attention weights are never materialised by the fused kernel")
+        if attn_mask is not None or incremental_state is not None or static_kv:
+            raise NotImplementedError("attn_mask / incremental decoding are not implemented")
+        if before_softmax:
+            raise NotImplementedError("before_softmax is not implemented")
         if (key is not None and key is not query) or (value is not None and value is not query):
             raise NotImplementedError("only self-attention (key = value = query) is implemented")
+        if need_head_weights:
+            need_weights = True                                         # msm/multihead_attention.py:184-185
         _check_inference(self, self.dropout)
         if query.dim() != 3:
             raise ValueError(f"expected query of shape [T, B, E], got {tuple(query.shape)}")
         T, B, E = query.shape
+        H = self.num_heads
+        kpm = None
+        if key_padding_mask is not None:
+            if tuple(key_padding_mask.shape) != (B, T):
+                raise ValueError(f"expected key_padding_mask of shape [{B}, {T}], got {tuple(key_padding_mask.shape)}")
+            kpm = key_padding_mask.to(device=query.device, dtype=torch.uint8).contiguous()
         x2 = query.contiguous().view(T * B, E)
-        qkv = self._qkv(x2, self.scaling)
-        ctx = ops.col_attn(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], T, B, self.num_heads)
-        return self._project_out(ctx, None).view(T, B, E), None
+        qkv = self._qkv(x2, self.scaling)                               # [T*B, 3E], token (t, b) = row t*B + b
+        if not need_weights:
+            # fused: R := T, C := B; its pad mask is indexed like the tokens, [T, B]
+            mask = None if kpm is None or T == 1 else kpm.t().contiguous().view(-1)
+            ctx = ops.col_attn(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], T, B, H, pad_mask=mask)
+            return self._project_out(ctx, None).view(T, B, E), None
+        if T > 1024:
+            raise NotImplementedError("need_weights materialises [H, T, T] per batch element with kernels built for T <= 1024")
+        qkv3 = qkv.view(T, B, 3 * E)
+        ctx = torch.empty(T, B, E, device=query.device, dtype=torch.float32)
+        probs = torch.empty(B, H, T, T, device=query.device, dtype=torch.float32)
+        for b in range(B):                                              # one "alignment" of a single row per element
+            qb = qkv3[:, b]                                             # [T, 3E] view, row stride B*3E
+            partial, _ = ops.row_logits(qb[:, :E], qb[:, E:2 * E], 1, T, H)
+            ops.softmax_rows(partial, out=probs[b], key_mask=None if kpm is None else kpm[b])
+            ops.row_apply(probs[b], qb[:, 2 * E:], 1, T, H, out=ctx[:, b])
+        out = self._project_out(ctx.view(T * B, E), None).view(T, B, E)
+        weights = probs.permute(1, 0, 2, 3)                             # [H, B, T, T]  (:389-393)
+        if not need_head_weights:
+            weights = ops.head_mean(weights)                            # [B, T, T]     (:394-397)
+        return out, weights

@@ -2,7 +2,8 @@
 
 Replaces MSA.from_fasta (utils/align.py:291-317) + A2MDataset.__getitem__ (dataset.py:80-92) for this
 path.  Row sub-sampling: the reference defaults to the external `hhfilter` binary (utils/align.py:68-102),
-which is not available offline; supported here are `first` (keep the first N rows) and the reference's
+which is not available offline; supported here are `first` (keep the first N rows), the reference's weighted random
+`sample-pretrained` (utils/align.py:150-163; weights on the device, the draw by numpy's generator) and its
 greedy `diversity-max` / `diversity-min` (utils/align.py:128-148), on the HIP device when one is given
 (rnamsm_greedy_select) or on the host -- index-identical to the reference either way.
 """
@@ -77,10 +78,42 @@ def greedy_select_device(tokens: np.ndarray, num_seqs: int, mode: str, device) -
     return ops.greedy_select(u8, num_seqs, mode).cpu().numpy().astype(np.int64)
 
 
+def msa_weights(tokens: np.ndarray, seqid_cutoff: float = 0.2, device=None) -> np.ndarray:
+    """MSA.weights (utils/align.py:250-253): 1 / number of rows within `seqid_cutoff` normalised Hamming distance (the
+    row itself included), float64 [N].  The distances are over the alignment columns (no <cls>); with `device` the O(N^2 L)
+    comparison runs on the GPU (rnamsm_msa_weights) -- same integers, same float64 comparison, identical weights."""
+    body = np.ascontiguousarray((tokens[:, 1:] if tokens.shape[1] > 1 else tokens).astype(np.uint8))
+    if device is not None:
+        import torch
+        from . import ops
+        return ops.msa_weights(torch.from_numpy(body).to(device), seqid_cutoff).cpu().numpy()
+    n = body.shape[0]
+    counts = np.zeros(n, dtype=np.int64)
+    step = max(1, (1 << 24) // max(1, n * body.shape[1]))
+    for i0 in range(0, n, step):
+        dist = (body[i0:i0 + step, None, :] != body[None, :, :]).mean(-1)       # pdist(.., "hamming") = mismatches / L
+        counts[i0:i0 + step] = (dist < seqid_cutoff).sum(1)
+    return 1 / counts
+
+
+def sample_weights(tokens: np.ndarray, num_seqs: int, rng=None, seqid_cutoff: float = 0.2, device=None) -> np.ndarray:
+    """Row indices drawn like MSA.sample_weights (utils/align.py:150-163): row 0 plus num_seqs - 1 of the others without
+    replacement with probability proportional to their sequence weight, ascending.  `rng`: a numpy RandomState; None =
+    numpy's global one, which is what the reference draws from (seeded by seed_everything(42), RNA_MSM_Inference.py:17)."""
+    depth = tokens.shape[0]
+    if depth <= num_seqs:
+        return np.arange(depth)
+    rng = np.random if rng is None else rng
+    w = msa_weights(tokens, seqid_cutoff, device)[1:]
+    w = w / w.sum()
+    idx = rng.choice(depth - 1, size=num_seqs - 1, replace=False, p=w) + 1
+    return np.append(0, np.sort(idx))
+
+
 def load_msa_tokens(path: Union[str, Path], alphabet: RNAAlphabet, max_seqs_per_msa: int = 512,
-                    sample_method: str = "hhfilter", device=None) -> np.ndarray:
-    """.a2m_msa2 file -> int64 tokens [R <= max_seqs, L+1].  With `device` (a HIP device) the greedy sub-sampling
-    runs on the GPU."""
+                    sample_method: str = "hhfilter", device=None, rng=None) -> np.ndarray:
+    """.a2m_msa2 file -> int64 tokens [R <= max_seqs, L+1].  With `device` (a HIP device) the sub-sampling arithmetic
+    (greedy selection, sequence weights) runs on the GPU.  `rng` feeds `sample-pretrained` (see sample_weights)."""
     if sample_method not in SAMPLE_METHODS:
         raise AssertionError(f"unknown sample_method {sample_method!r}")
     records = read_fasta_records(path)
@@ -94,6 +127,8 @@ def load_msa_tokens(path: Union[str, Path], alphabet: RNAAlphabet, max_seqs_per_
         if device is not None:
             return tokens[greedy_select_device(tokens, max_seqs_per_msa, mode, device)]
         return tokens[greedy_select(tokens, max_seqs_per_msa, mode)]
+    if sample_method == "sample-pretrained":
+        return tokens[sample_weights(tokens, max_seqs_per_msa, rng, device=device)]
     raise NotImplementedError(
-        f"sample_method={sample_method!r} needs the external hhfilter binary / random weights of the reference; "
-        "pre-filter the alignment or pass data.sample_method=first | diversity-max | diversity-min")
+        f"sample_method={sample_method!r} needs the external hhfilter binary of the reference (utils/align.py:68-102); "
+        "pre-filter the alignment or pass data.sample_method=first | diversity-max | diversity-min | sample-pretrained")

@@ -313,6 +313,16 @@ def pack_outputs(x_final: torch.Tensor, probs_all: torch.Tensor, C: int) -> Tupl
 
 
 @_on_operand_device
+def head_mean(probs: torch.Tensor) -> torch.Tensor:
+    """probs [H, ...] fp32 -> mean over the head axis [...] (msm/multihead_attention.py:394-397)."""
+    probs = probs.contiguous()
+    H = probs.shape[0]
+    out = torch.empty(probs.shape[1:], device=probs.device, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_head_mean(_dev(probs, "probs"), _dev(out, "out"), H, out.numel(), _stream()))
+    return out
+
+
+@_on_operand_device
 def contact_head(row_attn: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """row_attn [NL, H, C, C] (or [NL*H, C, C]) -> contacts [C-1, C-1] (modules.py:344-366)."""
     C = row_attn.shape[-1]
@@ -338,6 +348,16 @@ def greedy_select(msa_u8: torch.Tensor, num_seqs: int, mode: str = "max") -> tor
     _lib.check(lib.rnamsm_greedy_select(_dev(msa_u8.contiguous(), "msa", torch.uint8), N, L, num_seqs,
                                         1 if mode == "min" else 0, _dev(out, "out", torch.int32), ws.data_ptr(),
                                         ws.numel(), _stream()))
+    return out
+
+
+@_on_operand_device
+def msa_weights(msa_u8: torch.Tensor, seqid_cutoff: float = 0.2) -> torch.Tensor:
+    """msa uint8 [N, L] on the device -> float64 [N] sequence weights (MSA.weights, utils/align.py:250-253)."""
+    N, L = msa_u8.shape
+    out = torch.empty(N, dtype=torch.float64, device=msa_u8.device)
+    _lib.check(_lib.load().rnamsm_msa_weights(_dev(msa_u8.contiguous(), "msa", torch.uint8), N, L, float(seqid_cutoff),
+                                              _dev(out, "weights", torch.float64), _stream()))
     return out
 
 

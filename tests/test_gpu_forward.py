@@ -366,8 +366,14 @@ def test_padded_batch_on_the_chunked_path_matches_reference_fixture(model, mode)
                     d = np.abs(res["row_attentions"][b].cpu().numpy() - g[f"row_attentions_{tag}"][b])
                     # element 1 on the chunked path carries -10000 in its logits (fp32 step 9.8e-4): one step of slack
                     # on the max, the mean stays ~13x below the distance between the two semantics (8.6e-6)
-                    tol = 1e-3 if (tag == "chunked" and b == 1) else 1e-4
-                    assert d.max() < tol and d.mean() < 2e-6, (tag, layers, b, d.max(), d.mean())
+                    if tag == "chunked" and b == 1:
+                        # ... and the flips are then amplified layer by layer: the overall mean stays below the distance
+                        # between the two semantics (8.6e-6); layers 0 and 1, before the amplification, pin the semantics
+                        # sharply (direct vs chunked differ by mean 8.1e-6 at layer 1; the oracle reproduces 2.6e-8)
+                        assert d.max() < 1e-3 and d.mean() < 6e-6, (layers, d.max(), d.mean())
+                        assert d[0].max() < 2e-6 and d[1].mean() < 1e-6, (layers, d[0].max(), d[1].mean())
+                    else:
+                        assert d.max() < 1e-4 and d.mean() < 2e-6, (tag, layers, b, d.max(), d.mean())
                     assert rel_l2(res["representations"][10][b].cpu().numpy(), g[f"rep10_{tag}"][b]) < 1e-4
         other = np.abs(res["row_attentions"][0].cpu().numpy() - g["row_attentions_chunked"][0]).max()
         assert other > 0.5                                               # direct output is NOT the chunked one

@@ -244,13 +244,31 @@ def test_generic_mha_matches_reference_fixture(dev, name):
                         strict=True)
     mha = mha.eval().to(dev)
     x = torch.from_numpy(synthetic.normal(f"mha:{name}", 11, (T, B, E)).astype(np.float32)).to(dev)
+    # the reference's defaults (need_weights=True): head-averaged probabilities next to the output
     y, w = mha(x, x, x)
-    assert w is None and y.shape == (T, B, E)
+    assert y.shape == (T, B, E) and w.shape == (B, T, T)
     assert rel_l2(y.cpu(), g["out"]) < TOL_REL
+    assert np.abs(w.cpu().numpy() - g["avg_weights"]).max() < TOL_PROB
+    # need_weights=False: the fused kernel, no probabilities
+    y2, w2 = mha(x, x, x, need_weights=False)
+    assert w2 is None and rel_l2(y2.cpu(), g["out"]) < TOL_REL
+    # key_padding_mask + weights, as msm/modules.py:123-131 calls it (fixture from the reference with both set)
+    gm = golden(f"mha_masks_{name}.npz")
+    kpm = torch.from_numpy(gm["key_padding_mask"]).to(dev)
+    assert rel_l2(y.cpu(), gm["out_default"]) < TOL_REL and np.abs(w.cpu().numpy() - gm["avg_weights_default"]).max() < TOL_PROB
+    y3, w3 = mha(x, x, x, key_padding_mask=kpm, need_weights=True)
+    assert rel_l2(y3.cpu(), gm["out_masked"]) < TOL_REL
+    assert np.abs(w3.cpu().numpy() - gm["avg_weights_masked"]).max() < TOL_PROB
+    y4, w4 = mha(x, x, x, key_padding_mask=kpm, need_head_weights=True)
+    assert w4.shape == (H, B, T, T) and torch.equal(y4, y3)
+    assert np.abs(w4.cpu().numpy() - gm["head_weights_masked"]).max() < TOL_PROB
+    assert float(w4[:, 0, :, T - 5:].max()) == 0.0 and float(w4[:, B - 1, :, 3].max()) == 0.0
+    y5, w5 = mha(x, x, x, key_padding_mask=kpm, need_weights=False)              # fused kernel with the key mask
+    assert w5 is None and rel_l2(y5.cpu(), gm["out_masked"]) < TOL_REL
     with pytest.raises(NotImplementedError):
-        mha(x, x, x, need_weights=True)
-    with pytest.raises(NotImplementedError):
-        mha(x, x, x, key_padding_mask=torch.zeros(B, T, dtype=torch.bool, device=dev))
+        mha(x, x, x, attn_mask=torch.zeros(T, T, device=dev))
+    with pytest.raises(ValueError):
+        mha(x, x, x, key_padding_mask=torch.zeros(T, B, dtype=torch.bool, device=dev))
 
 
 def test_greedy_select_on_device_equals_host_and_reference(dev):
@@ -278,6 +296,28 @@ def test_greedy_select_on_device_equals_host_and_reference(dev):
             want = msa.greedy_select(toks, K, mode)
             got = msa.greedy_select_device(toks, K, mode, dev)
             assert np.array_equal(got, want), (N, L, K, mode)
+
+
+def test_msa_weights_on_device_equal_host_and_reference(dev):
+    """§8 f3, `sample-pretrained` (utils/align.py:150-163, 250-253): rnamsm_msa_weights gives the reference's float64
+    sequence weights bit for bit (fixture: the shipped 1176-row alignment), so the weighted draw picks the same rows; and
+    equals the host implementation on shapes that exercise every lane-group width (L = 3 .. 300)."""
+    import os
+    from conftest import GOLDEN
+    from rnamsm import msa
+    from rnamsm.alphabet import RNAAlphabet
+    g = golden("msa_weights_2DRB_1.npz")
+    path = os.path.join(GOLDEN, "2DRB_1.a2m_msa2")
+    a = RNAAlphabet()
+    toks = msa.load_msa_tokens(path, a, None)
+    assert np.array_equal(msa.msa_weights(toks, float(g["seqid_cutoff"]), device=dev), g["weights"])
+    got = msa.load_msa_tokens(path, a, 512, "sample-pretrained", device=dev, rng=np.random.RandomState(42))
+    assert np.array_equal(got, g["tokens_seed42_n512"])
+    rng = np.random.RandomState(5)
+    for N, L, cut in ((40, 3, 0.4), (257, 16, 0.2), (600, 33, 0.3), (300, 300, 0.25), (1000, 64, 0.2)):
+        t = np.concatenate([np.zeros((N, 1), np.int64), rng.choice([4, 5, 6, 7, 10], size=(N, L), p=[.4, .3, .1, .1, .1])], 1)
+        t[rng.randint(0, N, N // 4)] = t[1]                           # clusters of identical rows
+        assert np.array_equal(msa.msa_weights(t, cut, device=dev), msa.msa_weights(t, cut)), (N, L)
 
 
 def test_padding_mask_kernel_semantics(dev):

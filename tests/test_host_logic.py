@@ -85,6 +85,23 @@ def test_row_subsampling_matches_reference_greedy_select():
         msa.load_msa_tokens(path, a, 16, "nonsense")
 
 
+def test_sample_pretrained_subsampling_matches_reference_weights_and_draws():
+    """utils/align.py:150-163, 250-253 on the shipped 1176-row alignment: the sequence weights are the reference's bit for
+    bit, and with numpy's generator in the same state (the reference draws from the global one, seeded by
+    seed_everything) the weighted draw picks the reference's rows."""
+    g = golden("msa_weights_2DRB_1.npz")
+    path = os.path.join(GOLDEN, "2DRB_1.a2m_msa2")
+    a = RNAAlphabet()
+    toks = msa.load_msa_tokens(path, a, None)
+    assert np.array_equal(msa.msa_weights(toks, float(g["seqid_cutoff"])), g["weights"])
+    for seed, n in ((42, 512), (7, 64)):
+        got = msa.load_msa_tokens(path, a, n, "sample-pretrained", rng=np.random.RandomState(seed))
+        assert np.array_equal(got, g[f"tokens_seed{seed}_n{n}"]) and (got[0] == toks[0]).all()
+    np.random.seed(7)                                                   # rng=None draws from numpy's global state
+    assert np.array_equal(msa.load_msa_tokens(path, a, 64, "sample-pretrained"), g["tokens_seed7_n64"])
+    assert np.array_equal(msa.sample_weights(toks[:10], 10), np.arange(10))
+
+
 def test_synthetic_generators_are_pure_functions():
     t1, t2 = synthetic.make_tokens(7, 19, 3), synthetic.make_tokens(7, 19, 3)
     assert np.array_equal(t1, t2) and (t1[:, 0] == 0).all() and set(np.unique(t1[:, 1:])) <= {4, 5, 6, 7, 8, 10}
