@@ -194,10 +194,11 @@ def test_ctypes_signatures_match_the_header_prototypes():
         if "*" in decl or decl.endswith("]"):
             return "ptr"
         base = decl.rsplit(" ", 1)[0] if " " in decl else decl
-        return {"int64_t": "i64", "long long": "i64", "size_t": "size", "int": "int", "float": "float"}[base.replace("const ", "")]
+        return {"int64_t": "i64", "long long": "i64", "size_t": "size", "int": "int", "float": "float",
+                "double": "double"}[base.replace("const ", "")]
 
     ctype_class = {ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr", ctypes.c_int64: "i64", ctypes.c_longlong: "i64",
-                   ctypes.c_size_t: "size", ctypes.c_int: "int", ctypes.c_float: "float"}
+                   ctypes.c_size_t: "size", ctypes.c_int: "int", ctypes.c_float: "float", ctypes.c_double: "double"}
     for name, params in protos.items():
         params = params.strip()
         want = [] if params in ("", "void") else [klass(x) for x in params.split(",")]
