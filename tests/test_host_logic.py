@@ -264,3 +264,19 @@ def test_mask_and_repeat_matches_reference_semantics():
         want = toks.clone(); want[0, c] = 99
         assert torch.equal(out[i], want)
     assert torch.equal(toks, torch.arange(3 * 7).view(3, 7))          # the input is not modified
+
+
+def test_argument_validation_layer_under_address_and_ub_sanitizers():
+    """SURVEY.md §5 (CPU-side hygiene): a HOST-ONLY build of every entry point (`--offload-host-only`: no device code)
+    with -fsanitize=address,undefined, driven by tests/abi/abi_driver.c with null, misaligned, out-of-range and extreme
+    arguments -- every call is refused by the entry checks or is a pure host function, so no GPU is needed.  The make
+    target builds the library and the driver and runs it; a sanitizer report or a failed expectation fails the run."""
+    import shutil
+    import subprocess
+    if shutil.which(os.environ.get("HIPCC", "hipcc")) is None:
+        pytest.skip("hipcc not on PATH")
+    p = subprocess.run(["make", "-C", os.path.join(ROOT, "rna-msm_amd", "csrc"), "-j8", "check-asan"], capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "ABI driver:" in p.stdout and " 0 failed" in p.stdout
+    assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr
