@@ -134,11 +134,16 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().attn16 = value;
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "col_dma")) {
+        rnamsm::tuning().col_dma = value != 0;
+        return RNAMSM_OK;
+    }
     return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: unknown parameter %s", name ? name : "(null)");
 }
 extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "gemm16_dma")) return rnamsm::tuning().gemm16_dma;
     if (name && !strcmp(name, "attn16")) return rnamsm::tuning().attn16;
+    if (name && !strcmp(name, "col_dma")) return rnamsm::tuning().col_dma;
     if (name && !strcmp(name, "row_vt")) return rnamsm::tuning().row_vt;
     if (name && !strcmp(name, "gemm_tile")) return rnamsm::tuning().gemm_tile;
     if (name && !strcmp(name, "gemm_group")) return rnamsm::tuning().gemm_group;

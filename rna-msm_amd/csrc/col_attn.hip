@@ -17,7 +17,7 @@
 //   (the k index of MFMA step t is key (t&3)+8(t>>2)+4*half -- the accumulator's own row map), and (c) O^T also has
 //   the query row on the lane, so the online-softmax rescale is a per-lane scalar multiply.
 // Roofline: MFMA-bound: 4*R*R*64 flops per (c,h) vs 4*R*256 B of q,k,v,ctx (64 flop/B at R=256).
-#include "half16.h"
+#include "tile16.h"
 
 namespace rnamsm {
 
@@ -228,6 +228,196 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------- K7, LDS-DMA variant
+// Same arithmetic as col_attn_kernel, tile for tile (32 keys, the same MFMA and softmax sequence: outputs are
+// bit-identical), different data path.  A block's main loop at R = 256 is shorter than the fixed cost around it (strided
+// q rows, first chunk, output stores), which only OTHER resident blocks hide -- so this variant is built for occupancy:
+//   * K/V chunks are staged by global_load_lds_dwordx4 (no staging registers, no ds_write, no address VALU per element);
+//     a DMA writes lanes linearly, so rows are unpadded 256-B lines and the bank spread is an XOR swizzle applied to the
+//     SOURCE chunk and to the READ: physical 16-B chunk = logical ^ (row & 15) -- the 16 lanes of a ds_read_b128 group
+//     hold rows distinct mod 16 (K fragments), and a 32-lane ds_read_b32 group covers 8 chunks that share bit 3 (V);
+//   * 32-key chunks (one tile per barrier): 2 x 16 KB of LDS per block instead of 70 KB;
+//   * <= 168 registers: three blocks per CU instead of two.
+constexpr int CD_JC = 32;
+constexpr int CD_ROWB = 256;                     // bytes per LDS row (64 floats)
+constexpr int CD_TILE = CD_JC * CD_ROWB;         // one operand chunk
+constexpr int CD_BUF = 2 * CD_TILE;              // K chunk then V chunk
+constexpr int CD_LDS_BYTES = 2 * CD_BUF;         // double buffered: 32 KB
+
+template <bool MASKED, int OUT>
+__global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
+    float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask,
+    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo) {
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+
+    const unsigned iblocks = (R + CA_ROWS - 1) / CA_ROWS;
+    unsigned prob, ib;
+    if (!xcd_panel_map(blockIdx.x, (unsigned)C * H, iblocks, prob, ib)) return;
+    const int c = prob / H, h = prob % H;
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int irow0 = ib * CA_ROWS + wave * 32;
+    const bool active = irow0 < R;                           // wave-uniform
+    const int64_t col_off = (int64_t)c * ld + h * CA_HD;
+
+    f32x4 qf[8];
+    {
+        const int qi = min(irow0 + li, R - 1);
+        const float* qp = q + (int64_t)qi * C * ld + col_off + 4 * lh;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = *reinterpret_cast<const f32x4*>(qp + 8 * kk);
+    }
+
+    // DMA map: one wave instruction = 4 key rows x 256 B (lane -> row lane/16, physical chunk lane%16); a chunk is 8 such
+    // groups per operand, wave w moves groups w and w+4.  Keys past R are clamped (scores masked to -inf, V meets P = 0).
+    const int drow = lane >> 4, dchunk = lane & 15;
+    auto issue = [&](int ch, int buf) {
+        char* base = smem_b + buf * CD_BUF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int g = wave + 4 * j, row = 4 * g + drow;
+            const int64_t off = (int64_t)min(ch * CD_JC + row, R - 1) * C * ld + col_off + ((dchunk ^ (row & 15)) << 2);
+            __builtin_amdgcn_global_load_lds((gptr_t)(k + off), (lptr_t)(base + g * 4 * CD_ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(v + off), (lptr_t)(base + CD_TILE + g * 4 * CD_ROWB), 16, 0, 0);
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // V value of MFMA step t (key (t&3)+8(t>>2)+4*half), head-dim tile dt, for this lane's column li
+    auto vread = [&](const char* Vc, int t, int dt) -> float {
+        const int jl = (t & 3) + 8 * (t >> 2) + 4 * lh;
+        return *reinterpret_cast<const float*>(Vc + jl * CD_ROWB + (li & 3) * 4 + (((8 * dt + (li >> 2)) ^ (jl & 15)) << 4));
+    };
+
+    // One 32-key tile, order pinned.  The V values are fetched in two halves (steps 0-7 under the QK^T MFMAs, steps 8-15
+    // under the first half of the PV MFMAs) so that the tile peaks at ~130 live registers and three blocks fit a CU.
+    auto tile = [&](const char* Kc, const char* Vc, int jbase) {
+        f32x4 kf[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            kf[kk] = *reinterpret_cast<const f32x4*>(Kc + li * CD_ROWB + (((2 * kk + lh) ^ (li & 15)) << 4));
+        f32x16 s;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) s[t] = 0.f;
+        float va[16], vb[16];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            va[2 * t] = vread(Vc, t, 0);
+            va[2 * t + 1] = vread(Vc, t, 1);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = mfma32(kf[kk][e], qf[kk][e], s);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);     // 2 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int limit = R - jbase;
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            s[t] = ((t & 3) + 8 * (t >> 2) + 4 * lh < limit) ? s[t] : -INFINITY;
+        if (MASKED) {       // f2: masked_fill(padding_mask, -10000) on padded keys of this column (modules.py:911-915)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = jbase + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                if (j < R && pad_mask[(int64_t)j * C + c]) s[t] = -10000.f;
+            }
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            s[t] = __expf(s[t] - m_new);
+            psum += s[t];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            vb[2 * t] = vread(Vc, 8 + t, 0);
+            vb[2 * t + 1] = vread(Vc, 8 + t, 1);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            o0 = mfma32(va[2 * t], s[t], o0);
+            o1 = mfma32(va[2 * t + 1], s[t], o1);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            o0 = mfma32(vb[2 * t], s[8 + t], o0);
+            o1 = mfma32(vb[2 * t + 1], s[8 + t], o1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    const int nch = (R + CD_JC - 1) / CD_JC;
+    issue(0, 0);
+    for (int ch = 0; ch < nch; ++ch) {
+        wait_dma_then_barrier<0>();      // chunk ch has landed (every wave's share) and the other buffer is free again
+        if (ch + 1 < nch) issue(ch + 1, (ch + 1) & 1);
+        if (active) {
+            const char* Kc = smem_b + (ch & 1) * CD_BUF;
+            tile(Kc, Kc + CD_TILE, ch * CD_JC);
+        }
+    }
+
+    if (active) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.f / l_tot;
+        const int i = irow0 + li;
+        if (i < R) {
+            const int64_t ooff = ((int64_t)i * C + c) * ldc + h * CA_HD + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 a = f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+                const f32x4 b = f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+                if (OUT == 0) {
+                    *reinterpret_cast<f32x4*>(ctx + ooff + 8 * g) = a;
+                    *reinterpret_cast<f32x4*>(ctx + ooff + 32 + 8 * g) = b;
+                } else {
+                    typedef typename Half16<(OUT > 0 ? OUT - 1 : 0)>::T Hh;
+                    typedef Hh H4 __attribute__((ext_vector_type(4)));
+                    H4 ah, al, bh, bl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ah[e] = (Hh)a[e]; al[e] = (Hh)(a[e] - (float)ah[e]);
+                        bh[e] = (Hh)b[e]; bl[e] = (Hh)(b[e] - (float)bh[e]);
+                    }
+                    *reinterpret_cast<H4*>(ctx_hi + ooff + 8 * g) = ah;
+                    *reinterpret_cast<H4*>(ctx_hi + ooff + 32 + 8 * g) = bh;
+                    if (ctx_lo) {
+                        *reinterpret_cast<H4*>(ctx_lo + ooff + 8 * g) = al;
+                        *reinterpret_cast<H4*>(ctx_lo + ooff + 32 + 8 * g) = bl;
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace rnamsm
 
 using namespace rnamsm;
@@ -248,22 +438,29 @@ extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float
     const unsigned iblocks = (R + CA_ROWS - 1) / CA_ROWS;
     const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
     KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)R * R * CA_HD, 4.0 * 4.0 * R * C * H * CA_HD, s);
-#define CA_GO(M_, OUT_)                                                                                             \
+#define CA_GO2(KERN_, LDS_, M_, OUT_)                                                                               \
     do {                                                                                                            \
-        static DeviceOnce cfg_;                                                                                   \
-        if (cfg_.pending()) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn_kernel<M_, OUT_>),            \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, CA_LDS_BYTES);           \
+        static DeviceOnce cfg_;                                                                                     \
+        if (cfg_.pending()) {                                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN_<M_, OUT_>),                      \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_);                   \
             if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
             cfg_.mark();                                                                                            \
         }                                                                                                           \
-        hipLaunchKernelGGL((col_attn_kernel<M_, OUT_>), dim3(grid), dim3(CA_THREADS), CA_LDS_BYTES, s, q, k, v, ld, ctx, \
-                           ldc, R, C, H, pad_mask, ctx_hi, ctx_lo);                                                 \
+        hipLaunchKernelGGL((KERN_<M_, OUT_>), dim3(grid), dim3(CA_THREADS), LDS_, s, q, k, v, ld, ctx, ldc, R, C, H, \
+                           pad_mask, ctx_hi, ctx_lo);                                                               \
+    } while (0)
+    // "col_dma" (default 1): the LDS-DMA, three-blocks-per-CU variant; 0 = the register-staged kernel (bit-identical)
+#define CA_GO(M_, OUT_)                                                                                             \
+    do {                                                                                                            \
+        if (tuning().col_dma) CA_GO2(col_attn_dma_kernel, CD_LDS_BYTES, M_, OUT_);                                  \
+        else CA_GO2(col_attn_kernel, CA_LDS_BYTES, M_, OUT_);                                                       \
     } while (0)
     if (pad_mask) CA_GO(true, 0);
     else if (!ctx_hi) CA_GO(false, 0);
     else if (plane_fmt == 0) CA_GO(false, 1);
     else CA_GO(false, 2);
+#undef CA_GO2
 #undef CA_GO
     RNAMSM_CHECK_LAUNCH("col_attn");
     return RNAMSM_OK;
