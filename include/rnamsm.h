@@ -297,6 +297,9 @@ void rnamsm_timing_reset(void);
  *                 tile: each output element sums its K products in the same order.
  *   "row_vt"      fp32 rnamsm_row_apply: 1 (default) = the V tile is transposed while it is staged (ds_read_b128
  *                 fragments), 0 = staged as it lies in memory.  Speed only, results bit-identical.
+ *   "col_dma"     fp32 rnamsm_col_attn_fused: 1 = K/V chunks staged by LDS-DMA, 32-key chunks, three blocks per CU;
+ *                 0 = register-staged 64-key chunks, two blocks per CU; -1 (default) = chosen from the shape.  Speed only
+ *                 (the two kernels run the same arithmetic per 32-key tile; results agree to fp32 rounding).
  *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit
  *                 matrix cores in the mode's operand format (K4'..K7'), 0 = they stay on the exact-fp32 kernels,
  *                 2 = as 1 but the row kernels keep 128x128 tiles for every C (A/B of the 256x256-tile kernels).

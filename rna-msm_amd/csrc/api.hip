@@ -135,7 +135,7 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         return RNAMSM_OK;
     }
     if (name && !strcmp(name, "col_dma")) {
-        rnamsm::tuning().col_dma = value != 0;
+        rnamsm::tuning().col_dma = value < 0 ? -1 : (value != 0);
         return RNAMSM_OK;
     }
     return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: unknown parameter %s", name ? name : "(null)");

@@ -450,10 +450,14 @@ extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float
         hipLaunchKernelGGL((KERN_<M_, OUT_>), dim3(grid), dim3(CA_THREADS), LDS_, s, q, k, v, ld, ctx, ldc, R, C, H, \
                            pad_mask, ctx_hi, ctx_lo);                                                               \
     } while (0)
-    // "col_dma" (default 1): the LDS-DMA, three-blocks-per-CU variant; 0 = the register-staged kernel (bit-identical)
+    // "col_dma": 1 = the LDS-DMA, three-blocks-per-CU variant, 0 = the register-staged kernel, -1 (default) = by shape.
+    // Measured in one process (tools/col_attn_ab.py): R=256 C=512 +4 %, R=1024 +2 %, R=512 C=36 equal, R <= 128 4-10 %
+    // SLOWER (four tiles per block: the barrier per tile costs more than the third resident block buys); the masked
+    // instance is 4-20 % faster at every shape (the register-staged one spills).
+    const bool use_dma = tuning().col_dma < 0 ? (pad_mask != nullptr || R >= 192) : tuning().col_dma != 0;
 #define CA_GO(M_, OUT_)                                                                                             \
     do {                                                                                                            \
-        if (tuning().col_dma) CA_GO2(col_attn_dma_kernel, CD_LDS_BYTES, M_, OUT_);                                  \
+        if (use_dma) CA_GO2(col_attn_dma_kernel, CD_LDS_BYTES, M_, OUT_);                                           \
         else CA_GO2(col_attn_kernel, CA_LDS_BYTES, M_, OUT_);                                                       \
     } while (0)
     if (pad_mask) CA_GO(true, 0);

@@ -282,12 +282,12 @@ using namespace rnamsm;
 
 extern "C" int rnamsm_row_logits_nsplit(int R, int C, int H) {
     if (R <= 0 || C <= 0 || H <= 0) return 0;
-    return choose_row_split(R, C, H).nsplit;
+    return choose_row_split(R, C, H, 128, 512, ROW_LOGITS_F32_MAX_ROWS).nsplit;
 }
 
 extern "C" size_t rnamsm_row_logits_workspace_bytes(int R, int C, int H) {
     if (R <= 0 || C <= 0 || H <= 0) return 0;
-    return (size_t)choose_row_split(R, C, H).nsplit * H * C * C * sizeof(float);
+    return (size_t)choose_row_split(R, C, H, 128, 512, ROW_LOGITS_F32_MAX_ROWS).nsplit * H * C * C * sizeof(float);
 }
 
 static int row_logits_launch(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H,
@@ -324,7 +324,7 @@ static int row_logits_launch(const float* q, const float* k, int64_t ld, float* 
         if (rc) return rc;
         configured.mark();
     }
-    RowSplit sp = choose_row_split(R, C, H);
+    RowSplit sp = choose_row_split(R, C, H, 128, 512, ROW_LOGITS_F32_MAX_ROWS);
     if (rows_per_chunk > 0) {       // slabs = the reference's row chunks (f2 on the chunked path)
         sp.rows_per_split = rows_per_chunk;
         sp.nsplit = (R + rows_per_chunk - 1) / rows_per_chunk;

@@ -12,12 +12,20 @@ struct RowSplit {
 // 256 CUs x 2 resident blocks, subject to >= 4 rows (8 K tiles) per split.
 // tile / slots: output tile edge and resident block slots of the kernel that consumes the split (128 / 512 for the
 // 128x128 kernels with two blocks per CU, 256 / 256 for the 256x256 16-bit kernel with one).
-inline RowSplit choose_row_split(int R, int C, int H, int tile = 128, int slots = 512) {
+// max_rows (0 = no limit): upper bound on the rows of one split, i.e. on the length max_rows * 64 of an fp32 accumulation
+// chain.  The exact-fp32 MFMA adds its products one after the other (an fmaf chain), so a slab of r rows is a chain of
+// 64 r terms and its rounding error grows with r, while the slabs themselves are added pairwise-like by K5.  Measured
+// against an fp64 truth at M=256 x L=512 (tools/error_sources.py): chains of 4096 / 2048 / 1024 / 512 / 256 terms leave
+// the 10-layer embedding 1.26e-4 / 7.1e-5 / 4.1e-5 / 3.2e-5 / 3.1e-5 from the truth -- the reference's own CPU arithmetic
+// (blocked sgemm) sits at 3.2e-5.  The fp32 kernel therefore caps a split at 8 rows (512 terms).
+inline RowSplit choose_row_split(int R, int C, int H, int tile = 128, int slots = 512, int max_rows = 0) {
     const long tiles = (long)((C + tile - 1) / tile) * ((C + tile - 1) / tile) * H;
-    int best_ns = 1;
+    const int min_ns = max_rows > 0 ? (R + max_rows - 1) / max_rows : 1;
+    int best_ns = min_ns;
     double best_score = -1.0;
-    const int max_ns = R / 4 > 1 ? (R / 4 < 64 ? R / 4 : 64) : 1;
-    for (int ns = 1; ns <= max_ns; ++ns) {
+    int max_ns = R / 4 > 1 ? (R / 4 < 64 ? R / 4 : 64) : 1;
+    if (max_ns < min_ns) max_ns = min_ns;
+    for (int ns = min_ns; ns <= max_ns; ++ns) {
         const int rps = (R + ns - 1) / ns;
         const int real_ns = (R + rps - 1) / rps;
         const long blocks = tiles * real_ns;
@@ -34,5 +42,7 @@ inline RowSplit choose_row_split(int R, int C, int H, int tile = 128, int slots 
     s.nsplit = (R + s.rows_per_split - 1) / s.rows_per_split;
     return s;
 }
+
+constexpr int ROW_LOGITS_F32_MAX_ROWS = 8;     // fp32 row_logits: <= 512-term accumulation chains (see above)
 
 }  // namespace rnamsm

@@ -49,4 +49,4 @@ for R, C in ((256, 512), (128, 256), (64, 128), (512, 36), (1024, 1024), (100, 3
         outs[knob] = ctx
         res[knob] = med
     print(f"        masked: regs-staged {res[0]:.3f} ms   lds-dma {res[1]:.3f} ms   bit-identical {torch.equal(outs[0], outs[1])}", flush=True)
-_lib.check(lib.rnamsm_set_param(b"col_dma", 1))
+_lib.check(lib.rnamsm_set_param(b"col_dma", -1))
