@@ -569,7 +569,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo, int64_t lda, const uint16_t* __restrict__ Whi,
     const uint16_t* __restrict__ Wlo, const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout,
     int64_t ldc, int M, int N, int K, float scale, int scale_cols, uint16_t* __restrict__ Ohi, uint16_t* __restrict__ Olo,
-    int group) {
+    int group, unsigned total_tiles, int stagger_cycles) {
     using Cfg = HsCfg<SPLIT, BK>;
     constexpr int NPL = Cfg::NPL, ROWB = Cfg::ROWB, PLANE = Cfg::PLANE, KS = Cfg::KS;
     constexpr int NMF = 8 * (SPLIT == 3 ? 3 : 1);          // MFMAs per k step per wave
@@ -579,11 +579,22 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
 
     const unsigned nb = N / HX_BN, mp = (M + HX_BM - 1) / HX_BM;
-    unsigned mpanel, nblk;
-    if (!xcd_panel_map_grouped(blockIdx.x, mp, nb, (unsigned)group, mpanel, nblk)) return;
-    const int m0 = mpanel * HX_BM, n0 = nblk * HX_BN;
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wv >> 2, wn = wv & 3, li = lane & 31, lh = lane >> 5;
+    // Persistent form: gridDim.x blocks (one per CU) walk the output tiles in launch order, block b taking virtual ids
+    // b, b + gridDim.x, ... (gridDim.x % 8 == 0 keeps the XCD affinity of xcd_panel_map_grouped).  A tile's stores then
+    // drain while the block already accumulates its next tile, and a start offset per block (stagger_cycles x (b/8 % 4))
+    // spreads the CUs' store bursts over the tile period instead of letting all 256 CUs write at once.
+    if (stagger_cycles > 0) {
+        const unsigned ph = (blockIdx.x >> 3) & 3;
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (long long)stagger_cycles * ph) __builtin_amdgcn_s_sleep(8);
+    }
+    for (unsigned vid = blockIdx.x; vid < total_tiles; vid += gridDim.x) {
+    unsigned mpanel, nblk;
+    if (!xcd_panel_map_grouped(vid, mp, nb, (unsigned)group, mpanel, nblk)) continue;
+    const int m0 = mpanel * HX_BM, n0 = nblk * HX_BN;
+    __syncthreads();                 // every wave has finished reading the previous tile's epilogue staging
 
     // DMA map: a wave instruction covers RPI rows; lane -> (row RPI*g + lane / chunks-per-row, physical chunk lane %
     // chunks-per-row), fetching the logical chunk the read-side swizzle expects there.  g = wv + 8j.
@@ -689,6 +700,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
         hb_epilogue<ACT, HAS_RES, SPLIT, FMT, O_PL>(reinterpret_cast<f32x16(&)[2][2]>(acc[2 * p]), smem_b,
                                                     m0 + wm * 128 + p * 64, n0 + wn * 64, wv, lane, li, lh, bias, residual,
                                                     ldr, Cout, ldc, M, scale, scale_cols, Ohi, Olo);
+    }   // persistent tile loop
 }
 
 template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL, int BK>
@@ -707,10 +719,14 @@ static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
     // groups of 8 row panels keep a W slab shared by 8 panels instead of ~3: +5..6% (split 3), +7..10% (split 1),
     // measured in one process; the 3-column-block GEMMs (out_proj, fc2) are neutral to slightly worse and stay ungrouped
     const int group = tuning().gemm_group > 0 ? tuning().gemm_group : (N / HX_BN > 4 ? 8 : 1);
-    const unsigned grid = xcd_panel_grid_grouped((M + HX_BM - 1) / HX_BM, N / HX_BN, (unsigned)group);
+    const unsigned total = xcd_panel_grid_grouped((M + HX_BM - 1) / HX_BM, N / HX_BN, (unsigned)group);
+    // "gemm16_persist" = number of persistent blocks (0 = one block per tile, hardware dispatch); "gemm16_stagger" =
+    // start offset step in cycles
+    const unsigned pb = tuning().gemm16_persist > 0 ? (unsigned)tuning().gemm16_persist : 0u;
+    const unsigned grid = pb && pb < total ? pb : total;
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 2.0 * HxCfg<SPLIT>::NPL * ((double)M * K + (double)N * K) + 4.0 * (double)M * N * (HAS_RES ? 2 : 1), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, a_lo, lda, Whi, Wlo, bias, residual, ldr, Cout,
-                       ldc, M, N, K, scale, scale_cols, o_hi, o_lo, group);
+                       ldc, M, N, K, scale, scale_cols, o_hi, o_lo, group, total, pb ? tuning().gemm16_stagger : 0);
     RNAMSM_CHECK_LAUNCH("gemm16_swp");
     return RNAMSM_OK;
 }
