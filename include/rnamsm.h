@@ -297,6 +297,9 @@ void rnamsm_timing_reset(void);
  *                 tile: each output element sums its K products in the same order.
  *   "row_vt"      fp32 rnamsm_row_apply: 1 (default) = the V tile is transposed while it is staged (ds_read_b128
  *                 fragments), 0 = staged as it lies in memory.  Speed only, results bit-identical.
+ *   "gemm16_persist" / "gemm16_stagger"  256x256 16-bit GEMM: number of persistent blocks that walk the output tiles
+ *                 (default 256 = one per CU; 0 = one block per tile) and a per-block start offset in cycles (default 0;
+ *                 measured: no effect).  Speed only, results bit-identical.
  *   "col_dma"     fp32 rnamsm_col_attn_fused: 1 = K/V chunks staged by LDS-DMA, 32-key chunks, three blocks per CU;
  *                 0 = register-staged 64-key chunks, two blocks per CU; -1 (default) = chosen from the shape.  Speed only
  *                 (the two kernels run the same arithmetic per 32-key tile; results agree to fp32 rounding).

@@ -110,29 +110,52 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     const int64_t slab = rows * C;
     float v[SOFTMAX_MAX_PER_LANE];
     float mx = -INFINITY;
+    // slab-major: every slab iteration issues up to 17 independent loads per lane (the fp32 path sums 32+ slabs: one
+    // dependent load per iteration left the kernel latency-bound at 3 TB/s); each element still adds its slabs in slab order
+    const float* prow = partial + row * C;
+    if (mask_slab_stride == 0) {
 #pragma unroll
-    for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
-        const int j = lane + 64 * e;
-        float s = -INFINITY;
-        if (j < C) {
-            const float* p = partial + row * C + j;
-            if (mask_slab_stride == 0) {
-                s = p[0];
-                for (int sp = 1; sp < nsplit; ++sp) s += p[(int64_t)sp * slab];
-                // f2: masked_fill(padding_mask[:, 0], -10000) on the key axis (modules.py:781-785)
-                if (key_mask && key_mask[j]) s = -10000.f;
-            } else {
-                // f2 on the reference's chunked path (_batched_forward, modules.py:717-750): every slab is one row chunk,
-                // filled with -10000 where the chunk's OWN first row is padded (:727-737), then `attns += attn_weights`
-                // in chunk order -- masks of slab sp start at key_mask + sp * mask_slab_stride
-                s = key_mask[j] ? -10000.f : p[0];
-                for (int sp = 1; sp < nsplit; ++sp)
-                    s += key_mask[(int64_t)sp * mask_slab_stride + j] ? -10000.f : p[(int64_t)sp * slab];
+        for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+            const int j = lane + 64 * e;
+            v[e] = j < C ? prow[j] : -INFINITY;
+        }
+        for (int sp = 1; sp < nsplit; ++sp) {
+            const float* ps = prow + (int64_t)sp * slab;
+#pragma unroll
+            for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+                const int j = lane + 64 * e;
+                if (j < C) v[e] += ps[j];
             }
         }
-        v[e] = s;
-        mx = fmaxf(mx, s);
+        // f2: masked_fill(padding_mask[:, 0], -10000) on the key axis (modules.py:781-785)
+        if (key_mask) {
+#pragma unroll
+            for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+                const int j = lane + 64 * e;
+                if (j < C && key_mask[j]) v[e] = -10000.f;
+            }
+        }
+    } else {
+        // f2 on the reference's chunked path (_batched_forward, modules.py:717-750): every slab is one row chunk,
+        // filled with -10000 where the chunk's OWN first row is padded (:727-737), then `attns += attn_weights`
+        // in chunk order -- masks of slab sp start at key_mask + sp * mask_slab_stride
+#pragma unroll
+        for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+            const int j = lane + 64 * e;
+            v[e] = j < C ? (key_mask[j] ? -10000.f : prow[j]) : -INFINITY;
+        }
+        for (int sp = 1; sp < nsplit; ++sp) {
+            const float* ps = prow + (int64_t)sp * slab;
+            const uint8_t* ms = key_mask + (int64_t)sp * mask_slab_stride;
+#pragma unroll
+            for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+                const int j = lane + 64 * e;
+                if (j < C) v[e] += ms[j] ? -10000.f : ps[j];
+            }
+        }
     }
+#pragma unroll
+    for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) mx = fmaxf(mx, v[e]);
     mx = wave_max(mx);
     float sum = 0.f;
 #pragma unroll
