@@ -79,10 +79,24 @@ class MSATransformer(nn.Module):
         self._workspace = None
         self._lm_pad = None
         self.compute_logits = False
-        # Arithmetic of the Linear GEMMs in the C++ driver: "f32" (exact, default), "bf16" or "bf16x3" (include/rnamsm.h).
+        # Arithmetic of the contractions: "f32" (exact, default), "f16x3", "bf16x3" or "bf16" (include/rnamsm.h) -- for the
+        # C++ driver and, through the property below, for every mirror module of the layer-wise path
         self.gemm_dtype = "f32"
         self.check_finite = True          # 16-bit modes: verify the outputs are finite, fall back to f32 per MSA otherwise
         self._planes = None
+
+    @property
+    def gemm_dtype(self) -> str:
+        return self._gemm_dtype
+
+    @gemm_dtype.setter
+    def gemm_dtype(self, mode: str) -> None:
+        if mode not in _lib.DTYPES:
+            raise ValueError(f"gemm_dtype must be one of {tuple(_lib.DTYPES)}, got {mode!r}")
+        object.__setattr__(self, "_gemm_dtype", mode)
+        for m in self.modules():
+            if m is not self and hasattr(m, "gemm_dtype"):
+                m.gemm_dtype = mode
 
     # ------------------------------------------------------------------ reference API
     def max_tokens_per_msa_(self, value: int) -> None:

@@ -52,6 +52,40 @@ class _PackedQKV:
         return self._w, self._b
 
 
+GEMM_DTYPES = ("f32", "f16x3", "bf16x3", "bf16")
+
+
+def _mode_of(module: nn.Module):
+    """(split, fmt) of a module's `gemm_dtype`: None for the exact-fp32 path, else (1 | 3, 0 = bf16 | 1 = fp16)."""
+    mode = getattr(module, "gemm_dtype", "f32")
+    if mode not in GEMM_DTYPES:
+        raise ValueError(f"gemm_dtype must be one of {GEMM_DTYPES}, got {mode!r}")
+    return None if mode == "f32" else (1 if mode == "bf16" else 3, 1 if mode == "f16x3" else 0)
+
+
+class _WeightPlanes:
+    """16-bit hi(/lo) planes of a weight tensor (rnamsm_split_bf16), rebuilt when the tensor or the format changes."""
+
+    def __init__(self):
+        self._key = None
+        self._planes = None
+
+    def get(self, weight: torch.Tensor, split: int, fmt: int):
+        key = (weight.data_ptr(), weight._version, split, fmt)
+        if key != self._key:
+            self._planes = ops.split_bf16(weight.detach().contiguous(), want_lo=split == 3, fmt=fmt)
+            self._key = key
+        return self._planes
+
+
+def _act_planes(x2: torch.Tensor, split: int, fmt: int):
+    return ops.split_bf16(x2, want_lo=split == 3, fmt=fmt)
+
+
+def _cols(planes, a: int, b: int):
+    return tuple(None if p is None else p[:, a:b] for p in planes)
+
+
 class _AxialAttentionBase(nn.Module):
     def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0.0, max_tokens_per_msa: int = 2 ** 16):
         super().__init__()
@@ -70,6 +104,10 @@ class _AxialAttentionBase(nn.Module):
         self.q_proj = nn.Linear(embed_dim, embed_dim)
         self.out_proj = nn.Linear(embed_dim, embed_dim)
         self._packed = _PackedQKV()
+        # arithmetic of the contractions: "f32" (exact, default) or a 16-bit matrix-core mode -- the same kernels and
+        # operand formats rnamsm_forward uses for model.gemm_dtype (MSATransformer sets it on every module)
+        self.gemm_dtype = "f32"
+        self._wqkv_planes, self._wo_planes = _WeightPlanes(), _WeightPlanes()
 
     def _qkv(self, x2: torch.Tensor, q_scale: float, zero_rows=None) -> torch.Tensor:
         w, b = self._packed.get(self.q_proj, self.k_proj, self.v_proj)
@@ -77,7 +115,17 @@ class _AxialAttentionBase(nn.Module):
         return ops.linear(x2, w, b, scale=q_scale, scale_cols=D, zero_rows=zero_rows)   # [T, 3D] = q*scale | k | v
 
     def _project_out(self, ctx: torch.Tensor, residual: Optional[torch.Tensor]) -> torch.Tensor:
+        mode = _mode_of(self)
+        if mode is not None:
+            split, fmt = mode
+            return ops.linear_planes(_act_planes(ctx, split, fmt), self._wo_planes.get(self.out_proj.weight, split, fmt),
+                                     self.out_proj.bias.detach(), residual=residual, fmt=fmt)
         return ops.linear(ctx, self.out_proj.weight.detach(), self.out_proj.bias.detach(), residual=residual)
+
+    def _qkv_planes(self, x2: torch.Tensor, split: int, fmt: int):
+        """q | k | v as 16-bit planes [T, 3D] (q UNSCALED: the 16-bit attention kernels scale the fp32 logits)."""
+        w, b = self._packed.get(self.q_proj, self.k_proj, self.v_proj)
+        return ops.linear_planes(_act_planes(x2, split, fmt), self._wqkv_planes.get(w, split, fmt), b, out_planes=True, fmt=fmt)
 
     @staticmethod
     def _mask_bytes(self_attn_mask, self_attn_padding_mask, R: int, C: int):
@@ -105,6 +153,20 @@ class RowSelfAttention(_AxialAttentionBase):
         x2, R, C, D = _tokens_2d(x)
         mask = self._mask_bytes(self_attn_mask, self_attn_padding_mask, R, C)
         H = self.num_heads
+        res2 = None if _residual is None else _residual.contiguous().view(R * C, D)
+        mode = _mode_of(self)
+        if mode is not None and not (mask is not None and ops.row_chunks(R, C, self.max_tokens_per_msa)[0]):
+            # 16-bit matrix-core mode (the chunked+padded case stays on the exact kernels, like rnamsm_forward)
+            split, fmt = mode
+            qkv = self._qkv_planes(x2, split, fmt)
+            q, k, v = _cols(qkv, 0, D), _cols(qkv, D, 2 * D), _cols(qkv, 2 * D, 3 * D)
+            if mask is not None:
+                ops.zero_plane_rows(qkv, mask, D)                          # q *= 1 - padding_mask
+            partial, _ = ops.row_logits16(q, k, R, C, H, fmt=fmt, scale=self.align_scaling(x))
+            probs, p_pl = ops.softmax_rows_planes(partial, split=split, fmt=fmt, plane_scale=4096.0,
+                                                  key_mask=None if mask is None else mask[:C])
+            ctx = ops.row_apply16(p_pl, v, R, C, H, fmt=fmt, out_scale=1.0 / 4096.0)
+            return self._project_out(ctx, res2).view(R, C, 1, D), probs.view(H, 1, C, C)
         # padded tokens: q = 0 (modules.py:767-772); keys whose FIRST-row token is <pad>: logit -10000 (:781-785)
         qkv = self._qkv(x2, self.align_scaling(x), zero_rows=mask)
         # with padding AND R*C above the token budget the reference sums row chunks that were each filled from their
@@ -117,7 +179,6 @@ class RowSelfAttention(_AxialAttentionBase):
             partial, _ = ops.row_logits(qkv[:, :D], qkv[:, D:2 * D], R, C, H)
             probs = ops.softmax_rows(partial, key_mask=None if mask is None else mask[:C])
         ctx = ops.row_apply(probs, qkv[:, 2 * D:], R, C, H)
-        res2 = None if _residual is None else _residual.contiguous().view(R * C, D)
         out = self._project_out(ctx, res2)
         return out.view(R, C, 1, D), probs.view(H, 1, C, C)
 
@@ -134,10 +195,17 @@ class ColumnSelfAttention(_AxialAttentionBase):
         x2, R, C, D = _tokens_2d(x)
         mask = self._mask_bytes(self_attn_mask, self_attn_padding_mask, R, C)
         H = self.num_heads
+        res2 = None if _residual is None else _residual.contiguous().view(R * C, D)
+        mode = _mode_of(self)
+        if mode is not None:
+            split, fmt = mode
+            qkv = self._qkv_planes(x2, split, fmt)
+            ctx = ops.col_attn16(_cols(qkv, 0, D), _cols(qkv, D, 2 * D), _cols(qkv, 2 * D, 3 * D), R, C, H, fmt=fmt,
+                                 scale=self.scaling, pad_mask=mask if R > 1 else None)
+            return self._project_out(ctx, res2).view(R, C, 1, D), None
         qkv = self._qkv(x2, self.scaling)
         # R == 1 reduces to ctx = v; padded keys get score -10000 (modules.py:911-915)
         ctx = ops.col_attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], R, C, H, pad_mask=mask if R > 1 else None)
-        res2 = None if _residual is None else _residual.contiguous().view(R * C, D)
         out = self._project_out(ctx, res2)
         return out.view(R, C, 1, D), None
 
@@ -154,11 +222,21 @@ class FeedForwardNetwork(nn.Module):
         self.activation_dropout = activation_dropout
         self.fc1 = nn.Linear(embedding_dim, ffn_embedding_dim)
         self.fc2 = nn.Linear(ffn_embedding_dim, embedding_dim)
+        self.gemm_dtype = "f32"
+        self._w1_planes, self._w2_planes = _WeightPlanes(), _WeightPlanes()
 
     def forward(self, x, _residual=None):
         _check_inference(self, self.activation_dropout)
         shape = x.shape
         x2 = x.contiguous().view(-1, shape[-1])
+        mode = _mode_of(self)
+        if mode is not None:     # hidden activation kept as 16-bit planes between the two GEMMs, as in rnamsm_forward
+            split, fmt = mode
+            h = ops.linear_planes(_act_planes(x2, split, fmt), self._w1_planes.get(self.fc1.weight, split, fmt),
+                                  self.fc1.bias.detach(), act=ACT_GELU_ERF, out_planes=True, fmt=fmt)
+            res2 = None if _residual is None else _residual.contiguous().view(-1, shape[-1])
+            return ops.linear_planes(h, self._w2_planes.get(self.fc2.weight, split, fmt), self.fc2.bias.detach(),
+                                     residual=res2, fmt=fmt).view(shape)
         h = ops.linear(x2, self.fc1.weight.detach(), self.fc1.bias.detach(), act=ACT_GELU_ERF)
         res2 = None if _residual is None else _residual.contiguous().view(-1, shape[-1])
         return ops.linear(h, self.fc2.weight.detach(), self.fc2.bias.detach(), act=ACT_NONE, residual=res2).view(shape)
@@ -265,6 +343,9 @@ class MultiheadAttention(_AxialAttentionBase):
                 raise ValueError(f"expected key_padding_mask of shape [{B}, {T}], got {tuple(key_padding_mask.shape)}")
             kpm = key_padding_mask.to(device=query.device, dtype=torch.uint8).contiguous()
         x2 = query.contiguous().view(T * B, E)
+        mode = _mode_of(self)
+        if mode is not None:
+            return self._forward16(x2, T, B, E, kpm, need_weights, need_head_weights, *mode)
         qkv = self._qkv(x2, self.scaling)                               # [T*B, 3E], token (t, b) = row t*B + b
         if not need_weights:
             # fused: R := T, C := B; its pad mask is indexed like the tokens, [T, B]
@@ -285,4 +366,31 @@ class MultiheadAttention(_AxialAttentionBase):
         weights = probs.permute(1, 0, 2, 3)                             # [H, B, T, T]  (:389-393)
         if not need_head_weights:
             weights = ops.head_mean(weights)                            # [B, T, T]     (:394-397)
+        return out, weights
+
+    def _forward16(self, x2, T, B, E, kpm, need_weights, need_head_weights, split, fmt):
+        """The same two routes on the 16-bit kernels (operands as hi(/lo) planes, q unscaled, fp32 softmax)."""
+        H = self.num_heads
+        qkv = self._qkv_planes(x2, split, fmt)                          # planes [T*B, 3E]
+        if not need_weights:
+            mask = None if kpm is None or T == 1 else kpm.t().contiguous().view(-1)
+            ctx = ops.col_attn16(_cols(qkv, 0, E), _cols(qkv, E, 2 * E), _cols(qkv, 2 * E, 3 * E), T, B, H, fmt=fmt,
+                                 scale=self.scaling, pad_mask=mask)
+            return self._project_out(ctx, None).view(T, B, E), None
+        if T > 1024:
+            raise NotImplementedError("need_weights materialises [H, T, T] per batch element with kernels built for T <= 1024")
+        qkv3 = tuple(None if p is None else p.view(T, B, 3 * E) for p in qkv)
+        ctx = torch.empty(T, B, E, device=x2.device, dtype=torch.float32)
+        probs = torch.empty(B, H, T, T, device=x2.device, dtype=torch.float32)
+        for b in range(B):
+            qb = tuple(None if p is None else p[:, b] for p in qkv3)   # [T, 3E] plane views, row stride B*3E
+            partial, _ = ops.row_logits16(_cols(qb, 0, E), _cols(qb, E, 2 * E), 1, T, H, fmt=fmt, scale=self.scaling)
+            pb, p_pl = ops.softmax_rows_planes(partial, split=split, fmt=fmt, plane_scale=4096.0,
+                                               key_mask=None if kpm is None else kpm[b])
+            probs[b] = pb
+            ctx[:, b] = ops.row_apply16(p_pl, _cols(qb, 2 * E, 3 * E), 1, T, H, fmt=fmt, out_scale=1.0 / 4096.0)
+        out = self._project_out(ctx.view(T * B, E), None).view(T, B, E)
+        weights = probs.permute(1, 0, 2, 3)
+        if not need_head_weights:
+            weights = ops.head_mean(weights)
         return out, weights

@@ -76,6 +76,18 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 @_on_operand_device
+def layernorm_split(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, split: int = 3, fmt: int = 0):
+    """LayerNorm whose output goes straight into 16-bit planes (hi, lo | None) [T, D]: the A operand of a 16-bit GEMM."""
+    D = x.shape[-1]
+    x2 = x.contiguous().view(-1, D)
+    hi = torch.empty(x2.shape, dtype=torch.int16, device=x2.device)
+    lo = torch.empty(x2.shape, dtype=torch.int16, device=x2.device) if split == 3 else None
+    _lib.check(_lib.load().rnamsm_layernorm_split(_dev(x2, "x"), _dev(gamma, "gamma"), _dev(beta, "beta"), hi.data_ptr(),
+                                                  None if lo is None else lo.data_ptr(), x2.shape[0], D, eps, fmt, _stream()))
+    return hi, lo
+
+
+@_on_operand_device
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
            residual: Optional[torch.Tensor] = None, scale: float = 1.0, scale_cols: int = 0,
            out: Optional[torch.Tensor] = None, zero_rows: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -265,6 +265,13 @@ def test_generic_mha_matches_reference_fixture(dev, name):
     assert float(w4[:, 0, :, T - 5:].max()) == 0.0 and float(w4[:, B - 1, :, 3].max()) == 0.0
     y5, w5 = mha(x, x, x, key_padding_mask=kpm, need_weights=False)              # fused kernel with the key mask
     assert w5 is None and rel_l2(y5.cpu(), gm["out_masked"]) < TOL_REL
+    # the same entry point in the fp32-grade 16-bit mode (f16x3: operands as fp16 hi/lo planes)
+    mha.gemm_dtype = "f16x3"
+    y6, w6 = mha(x, x, x, key_padding_mask=kpm, need_head_weights=True)
+    assert rel_l2(y6.cpu(), gm["out_masked"]) < 2e-5 and np.abs(w6.cpu().numpy() - gm["head_weights_masked"]).max() < 2e-5
+    y7, w7 = mha(x, x, x, key_padding_mask=kpm, need_weights=False)
+    assert w7 is None and rel_l2(y7.cpu(), gm["out_masked"]) < 2e-5
+    mha.gemm_dtype = "f32"
     with pytest.raises(NotImplementedError):
         mha(x, x, x, attn_mask=torch.zeros(T, T, device=dev))
     with pytest.raises(ValueError):
