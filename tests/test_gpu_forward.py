@@ -397,9 +397,11 @@ def test_module_path_runs_the_16bit_modes_like_the_driver(model, mode):
         fast = m.forward_one(toks)
         res = m(toks[None], repr_layers=[0, 5, 10], need_head_weights=True)           # layer-wise
         assert sorted(res["representations"]) == [0, 5, 10]
-        tol = 1e-6 if mode != "bf16" else 1e-5
+        # same kernels, same plane values; the paths may pick different tile variants for a producer (fused plane
+        # epilogue vs split pass), so agreement is to the mode's rounding, amplified over ten layers, not bitwise
+        tol, atol = (2e-5, 1e-4) if mode != "bf16" else (2e-2, 2e-1)
         assert rel_l2(res["representations"][10][0].cpu().numpy(), fast["repr"].cpu().numpy()) < tol
-        assert np.abs(res["row_attentions"][0].cpu().numpy() - fast["row_attn"].cpu().numpy()).max() < 10 * tol
+        assert np.abs(res["row_attentions"][0].cpu().numpy() - fast["row_attn"].cpu().numpy()).max() < atol
         emb_tol, atp_tol = {"f16x3": (1e-4, 1e-4), "bf16x3": (1e-4, 1e-3), "bf16": (5e-2, 3e-1)}[mode]
         assert rel_l2(res["representations"][10][0, 0, 1:].cpu().numpy(), g["emb"]) < emb_tol
         atp = res["row_attentions"][0][..., 1:, 1:].reshape(-1, 32, 32).cpu().numpy()
