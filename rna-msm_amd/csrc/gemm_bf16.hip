@@ -99,7 +99,7 @@ __device__ __forceinline__ void hb_epilogue(f32x16 (&acc)[2][2], char* smem_b, i
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = min(gm0 + er + 4 * i, M - 1);
-            res[i] = *reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn);
+            res[i] = epi_load(reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn));
         }
     }
     __syncthreads();
@@ -138,17 +138,17 @@ __device__ __forceinline__ void hb_epilogue(f32x16 (&acc)[2][2], char* smem_b, i
                     lo[e] = (H)(ov[i][e] - (float)hi[e]);
                 }
                 const int64_t o = (int64_t)(gm0 + er + 4 * i) * ldc + gn;
-                *reinterpret_cast<H4*>(Ohi + o) = hi;
-                if (SPLIT == 3) *reinterpret_cast<H4*>(Olo + o) = lo;
+                epi_store(reinterpret_cast<H4*>(Ohi + o), hi);
+                if (SPLIT == 3) epi_store(reinterpret_cast<H4*>(Olo + o), lo);
             }
         }
     } else if (gm0 + 64 <= M) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
+        for (int i = 0; i < 16; ++i) epi_store(reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn), ov[i]);
     } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            if (gm0 + er + 4 * i < M) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn) = ov[i];
+            if (gm0 + er + 4 * i < M) epi_store(reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn), ov[i]);
     }
 }
 

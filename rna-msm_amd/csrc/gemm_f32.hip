@@ -92,7 +92,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int row = min(gm0 + er + RPP * i, M - 1);
-            res[i] = *reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn);
+            res[i] = epi_load(reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn));
         }
     }
     __syncthreads();                                              // every wave has finished reading operand tiles
@@ -126,11 +126,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     }
     if (m0 + BM <= M) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + RPP * i) * ldc + gn) = ov[i];
+        for (int i = 0; i < NP; ++i) epi_store(reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + RPP * i) * ldc + gn), ov[i]);
     } else {
 #pragma unroll
         for (int i = 0; i < NP; ++i)
-            if (gm0 + er + RPP * i < M) *reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + RPP * i) * ldc + gn) = ov[i];
+            if (gm0 + er + RPP * i < M) epi_store(reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + RPP * i) * ldc + gn), ov[i]);
     }
 }
 

@@ -12,7 +12,7 @@ import torch  # noqa: F401  (load order: see rnamsm/__init__.py)
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librnamsm_hip.so")
+LIB_PATH = os.environ.get("RNAMSM_LIB_PATH") or os.path.join(_HERE, "librnamsm_hip.so")    # override: A/B builds only
 
 RNAMSM_OK = 0
 F32, BF16, BF16X3, F16X3 = 0, 1, 2, 3

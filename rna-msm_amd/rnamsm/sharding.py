@@ -110,7 +110,7 @@ class RoundGatherer:
             self._inflight = (rnd, works, keep, [(index, list(own))])
             return
         ev = None
-        if self._side is not None:
+        if self._side is not None and self.rank != self.dst and own is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.wire))      # the payload is complete once this event has fired
 
@@ -118,13 +118,17 @@ class RoundGatherer:
             if self.rank != self.dst:
                 if own is None:
                     return
+                # the header (shapes: known now) travels at once; the payload sends are queued behind the event, i.e.
+                # behind this item's forward.  dst can therefore read the header, post its receives and go on launching
+                # its next forward without waiting for anybody's kernels.
                 payload = [t.contiguous().to(self.wire) for t in own]
                 hdr = self._header(payload).to(self.wire)
-                if self._side is not None:
-                    for t in payload:
-                        t.record_stream(self._side)
                 keep.extend([hdr] + payload)
                 works.append(dist.isend(hdr, self.dst, group=self.group))
+                if ev is not None:
+                    self._side.wait_event(ev)
+                    for t in payload:
+                        t.record_stream(self._side)
                 works.extend(dist.isend(t, self.dst, group=self.group) for t in payload)
                 return
             if own is not None:
@@ -146,7 +150,6 @@ class RoundGatherer:
 
         if self._side is not None:
             with torch.cuda.stream(self._side):
-                self._side.wait_event(ev)
                 comm()
         else:
             comm()

@@ -2,7 +2,7 @@
 """Fold rocprofv3 --pmc counter_collection CSVs (gpurun_out/pmc*/) into profiles/<tag>_pmc_*.csv and <tag>_pmc_summary.json.
 HBM-side bytes: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced streaming read
 (MI355X_MICROARCH.md §HBM) and is doubled."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 tag = sys.argv[1]
 pre = sys.argv[2] if len(sys.argv) > 2 else "pmc"          # gpurun_out/<pre>1..4
 out = {}
@@ -10,7 +10,7 @@ for d, name in ((pre + "1", "fetch_size"), (pre + "2", "write_size"), (pre + "3"
     files = glob.glob(f"gpurun_out/{d}/*/*counter_collection.csv")
     if not files:
         continue
-    rows = list(csv.DictReader(open(files[0])))
+    rows = list(csv.DictReader(open(max(files, key=os.path.getmtime))))       # the newest pass in that directory
     agg = collections.OrderedDict()
     for r in rows:
         key = (r["Kernel_Name"], r["Counter_Name"], r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"])
