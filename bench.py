@@ -242,43 +242,49 @@ def run_rank(args) -> int:
         per_step = world                                          # weak scaling: one MSA per GPU per step
         warm_items = world
         distinct = world * (args.warmup + args.steps)
-    mine_all = sharding.shard_indices(distinct, rank, world)
-    toks = {i: torch.from_numpy(synthetic.make_tokens(M, L, i)).to(dev) for i in mine_all}
-
     def step_items(step_no):
-        """Global item indices of one step, and the index of the MSA (token set) behind each."""
+        """(position within the step, index of the MSA / token set) of one step's items."""
         if batch:
             return [(i, i) for i in range(per_step)]
         return [(r, step_no * world + r) for r in range(world)]
+
+    # token sets this rank will touch (item g = step * per_step + position belongs to rank g % world)
+    mine_all = sorted({msa for k in range(args.warmup + args.steps) for pos, msa in step_items(k)
+                       if sharding.owner_of((k if batch else 0) * per_step + pos, world) == rank})
+    toks = {i: torch.from_numpy(synthetic.make_tokens(M, L, i)).to(dev) for i in mine_all}
 
     gather = world > 1 and not args.no_gather
     digest = torch.zeros((), dtype=torch.int64, device=dev)
     delivered = [0]
 
-    def on_item(base, index, tensors):
+    def on_item(index, tensors):
         nonlocal digest
         delivered[0] += 1
         if args.digest:
             for t in tensors:
-                digest = digest + (base + index + 1) * t.contiguous().view(torch.int32).to(torch.int64).sum()
+                digest = digest + (index + 1) * t.contiguous().view(torch.int32).to(torch.int64).sum()
 
-    def run_step(step_no, items=None, use_gather=True):
-        """One step: forward of this rank's MSAs (+ gather to rank 0)."""
-        items = step_items(step_no) if items is None else items
-        base = step_no * 1000003
+    def run_steps(first_step, nsteps, items_of=None, use_gather=True):
+        """`nsteps` steps: forward of this rank's MSAs, every output handed to ONE RoundGatherer that spans all the steps
+        (global item index = step * items-per-step + position), so round k's transfers to rank 0 overlap the forwards of
+        round k+1 across step boundaries as well; finish() drains the last round inside the timed region."""
+        per = [items_of(first_step + k) if items_of else step_items(first_step + k) for k in range(nsteps)]
+        n_items = sum(len(it) for it in per)
         g = None
         if (gather and use_gather) or (args.digest and world == 1):
-            g = sharding.RoundGatherer(len(items), on_item=lambda i, ts: on_item(base, i, ts), tensors_per_item=2,
-                                       dst=0, device=dev)
-        for pos, msa in items:
-            if sharding.owner_of(pos, world) != rank:
-                continue
-            out = model.forward_one(toks[msa], has_padding=False)
-            if g is not None:
-                g.submit(pos, (out["emb"], out["atp"]))
+            g = sharding.RoundGatherer(n_items, on_item=on_item, tensors_per_item=2, dst=0, device=dev)
+        base = 0
+        for items in per:
+            for pos, msa in items:
+                if sharding.owner_of(base + pos, world) != rank:
+                    continue
+                out = model.forward_one(toks[msa], has_padding=False)
+                if g is not None:
+                    g.submit(base + pos, (out["emb"], out["atp"]))
+            base += len(items)
         if g is not None:
             g.finish()
-        return len(items)
+        return n_items
 
     def sync_all():
         torch.cuda.synchronize()
@@ -296,40 +302,33 @@ def run_rank(args) -> int:
         return float(t.item())
 
     # ---- warm-up (untimed), then the headline loop: exactly K steps, timing hooks off
-    for w in range(args.warmup):
-        run_step(w, items=step_items(w)[:warm_items] if batch else None)
+    if args.warmup:
+        run_steps(0, args.warmup, items_of=(lambda k: step_items(k)[:warm_items]) if batch else None)
     sync_all()
     digest.zero_()
     delivered[0] = 0
-    msas_timed = 0
     lib.rnamsm_timing_enable(0)
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        msas_timed += run_step(args.warmup + k if not batch else k)
+    msas_timed = run_steps(0 if batch else args.warmup, args.steps)
     sync_all()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     headline_digest = int(digest.item()) if args.digest else None
     headline_delivered = delivered[0]
 
     # ---- roofline pass: the same work with HIP-event pairs around every launch (no gather: kernels only)
-    roof_items = None
-    roof_steps = args.steps
-    if batch:
-        roof_items = step_items(0)[:max(world, min(per_step, 8 * world))]
-        roof_steps = 1
+    roof_steps = 1 if batch else args.steps
+    roof_of = (lambda k: step_items(0)[:max(world, min(per_step, 8 * world))]) if batch else None
     sync_all()
     lib.rnamsm_timing_reset()
     lib.rnamsm_timing_enable(1)
     t1 = time.perf_counter()
-    roof_msas = 0
-    for k in range(roof_steps):
-        roof_msas += run_step(args.warmup + k if not batch else 0, items=roof_items, use_gather=False)
+    run_steps(0 if batch else args.warmup, roof_steps, items_of=roof_of, use_gather=False)
     sync_all()
     roof_elapsed = time.perf_counter() - t1
     lib.rnamsm_timing_enable(0)
     timings = _lib.kernel_timings()
-    roof_local = max(1, len([1 for k in range(roof_steps) for pos, _ in (roof_items or step_items(0))
-                             if sharding.owner_of(pos, world) == rank]))
+    roof_local = max(1, sum(1 for k in range(roof_steps) for pos, _ in (roof_of(k) if roof_of else step_items(0))
+                            if sharding.owner_of(pos, world) == rank))
 
     # ---- extra modes (N = 1, default workload): every contraction on the 16-bit matrix cores
     fast = bf16_mode = None
@@ -451,7 +450,7 @@ def run_rank(args) -> int:
         }
         if args.digest:
             result["output_digest"] = {"value": headline_digest, "items": headline_delivered,
-                                       "what": "sum over gathered outputs of (step*1000003 + item + 1) * sum(int32 bit patterns), mod 2^64"}
+                                       "what": "sum over gathered outputs of (global item index + 1) * sum(int32 bit patterns), mod 2^64"}
         if fast is not None:
             result["fast_mode"] = fast
             result["bf16_mode"] = bf16_mode

@@ -129,24 +129,32 @@ class RoundGatherer:
                     self._side.wait_event(ev)
                     for t in payload:
                         t.record_stream(self._side)
-                works.extend(dist.isend(t, self.dst, group=self.group) for t in payload)
+                works.extend(dist.batch_isend_irecv([dist.P2POp(dist.isend, t, self.dst, self.group) for t in payload]))
                 return
             if own is not None:
                 items.append((index, list(own)))
-            for peer in range(self.world):
-                if peer == self.dst or not self._has_item(rnd, peer):
-                    continue
+            # ALL headers first (they are already on their way: peers send them before their kernels finish), THEN one
+            # grouped post of every payload receive: the receives of different peers run concurrently, each on its own
+            # xGMI link, and nothing this rank has to read on the host is queued behind a payload
+            peers = [p for p in range(self.world) if p != self.dst and self._has_item(rnd, p)]
+            headers = []
+            for peer in peers:
                 hdr = torch.zeros(self.n_tensors, _MAXD + 2, dtype=torch.int64, device=self.wire)
                 dist.recv(hdr, src=peer, group=self.group)
+                headers.append(hdr)
+            ops = []
+            for peer, hdr in zip(peers, headers):
                 h = hdr.cpu()
                 bufs = []
                 for b in range(self.n_tensors):
                     nd = int(h[b, 1])
                     buf = torch.empty(tuple(int(v) for v in h[b, 2:2 + nd]), dtype=_DTYPES[int(h[b, 0])], device=self.wire)
-                    works.append(dist.irecv(buf, peer, group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, buf, peer, self.group))
                     bufs.append(buf)
                     self.bytes_received += buf.numel() * buf.element_size()
                 items.append((rnd * self.world + peer, bufs))
+            if ops:
+                works.extend(dist.batch_isend_irecv(ops))
 
         if self._side is not None:
             with torch.cuda.stream(self._side):
