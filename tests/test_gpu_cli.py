@@ -73,3 +73,62 @@ def test_async_io_pipeline_writes_the_same_files(tmp_path):
         assert outs[True][name] == outs[False][name], name
     emb = np.load(tmp_path / "async" / "results" / "rnaA_emb.npy")
     assert emb.shape == (35, 768) and emb.dtype == np.float32
+
+
+def _gather_worker(rank, world, port, root):
+    """One rank of the CLI loop with gather_to_rank0 (both ranks on device 0, gloo: payloads staged through the host)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["LOCAL_RANK"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rnamsm.config import Config
+        from rnamsm.inference import extract_feat
+        from rnamsm.model import MSATransformer
+        state = synthetic.make_state_dict(seed=0)
+        model = MSATransformer(num_layers=10)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+        cfg = Config()
+        cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = str(root), "results", "rna_id.txt"
+        cfg.data.sample_method, cfg.data.max_seqs_per_msa, cfg.data.device = "first", 64, "cuda:0"
+        written = extract_feat(cfg, model=model, gather_to_rank0=True)
+        assert (len(written) == 5) if rank == 0 else (written == [])     # only rank 0 writes
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cli_gather_to_rank0_streams_rounds_and_writes_the_same_files(tmp_path):
+    """with gather_to_rank0 the outputs travel to rank 0 one ROUND at a time (RoundGatherer) and leave through
+    the async writer as they arrive -- five ids over two ranks (three rounds, the last with an item-less rank), files
+    byte-identical to the single-process loop."""
+    import socket
+    import torch.multiprocessing as mp
+    from rnamsm.config import Config
+    from rnamsm.inference import extract_feat
+    from rnamsm.model import MSATransformer
+    ids = ["rnaC", "rnaA", "rnaD", "rnaB", "rnaE"]
+    roots = {}
+    for name in ("single", "gathered"):
+        root = tmp_path / name
+        (root / "results").mkdir(parents=True)
+        lines = open(os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2")).read().splitlines()
+        for n, i in enumerate(ids):
+            (root / "results" / f"{i}.a2m_msa2").write_text("\n".join(lines[: 2 * (6 + 7 * n)]) + "\n")
+        (root / "rna_id.txt").write_text("\n".join(ids) + "\n")
+        roots[name] = root
+    state = synthetic.make_state_dict(seed=0)
+    model = MSATransformer(num_layers=10)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    cfg = Config()
+    cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = str(roots["single"]), "results", "rna_id.txt"
+    cfg.data.sample_method, cfg.data.max_seqs_per_msa = "first", 64
+    extract_feat(cfg, model=model)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gather_worker, args=(2, port, roots["gathered"]), nprocs=2, join=True)
+    a = {f.name: f.read_bytes() for f in sorted((roots["single"] / "results").glob("*.npy"))}
+    b = {f.name: f.read_bytes() for f in sorted((roots["gathered"] / "results").glob("*.npy"))}
+    assert len(a) == 10 and a.keys() == b.keys()
+    for name in a:
+        assert a[name] == b[name], name
