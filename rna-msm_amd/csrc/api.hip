@@ -134,6 +134,10 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().attn16 = value;
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "gemm16_mfma16")) {
+        rnamsm::tuning().gemm16_mfma16 = value != 0;
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "gemm16_persist")) {
         if (value < 0 || value % 8 != 0) return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: gemm16_persist must be a non-negative multiple of 8");
         rnamsm::tuning().gemm16_persist = value;
@@ -155,6 +159,7 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "attn16")) return rnamsm::tuning().attn16;
     if (name && !strcmp(name, "col_dma")) return rnamsm::tuning().col_dma;
     if (name && !strcmp(name, "gemm16_persist")) return rnamsm::tuning().gemm16_persist;
+    if (name && !strcmp(name, "gemm16_mfma16")) return rnamsm::tuning().gemm16_mfma16;
     if (name && !strcmp(name, "gemm16_stagger")) return rnamsm::tuning().gemm16_stagger;
     if (name && !strcmp(name, "row_vt")) return rnamsm::tuning().row_vt;
     if (name && !strcmp(name, "gemm_tile")) return rnamsm::tuning().gemm_tile;

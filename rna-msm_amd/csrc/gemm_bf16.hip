@@ -731,6 +731,228 @@ static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
     return RNAMSM_OK;
 }
 
+// ---- 256x256 tile, plain bf16, 16x16x32 MFMAs ------------------------------------------------------------------------
+// The loop of gemm16_swp_kernel<.., SPLIT 1, BK 64> with v_mfma_f32_16x16x32_bf16 instead of 32x32x16: the same flops per
+// cycle on paper, but the chip holds a higher clock on the 16x16 shape under sustained matrix load (MI355X_MICROARCH.md,
+// DVFS give-back item 7: ~1.12-1.15x the FLOP/s of the 32x32 loop at equal cycles) -- and everything else in the kernel
+// (DMA issue, LDS reads) speeds up with the clock.  Same tiles, same DMA map and swizzle (the 16 lanes of a ds_read_b128
+// group hold rows distinct mod 16 and two k-groups: 16 distinct 16-B slots), wave tile 128x64 = 8x4 MFMA tiles (128
+// accumulator VGPRs), a k-step is 32 deep: 32 MFMAs of 16 cycles against 12 fragment reads.  Products are identical to the
+// 32x32 kernel's and are summed in a different order inside a k-step: results agree to fp32 rounding (exact on integers).
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+template <int ACT, bool HAS_RES, bool O_PL>
+__device__ __forceinline__ void hq_epilogue(f32x4a (&acc)[8][4], int p, char* smem_b, int gm0, int gnb, int wv, int lane,
+                                            const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout,
+                                            int64_t ldc, int M, float scale, int scale_cols, uint16_t* __restrict__ Ohi) {
+    constexpr int LDE = 64 + 4;
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int gn = gnb + ec;                                  // gm0 / gnb: global origin of this wave's 64x64 slab
+    f32x4 res[16];
+    if (HAS_RES) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = min(gm0 + er + 4 * i, M - 1);
+            res[i] = epi_load(reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn));
+        }
+    }
+    __syncthreads();
+    float* stage = reinterpret_cast<float*>(smem_b) + wv * (64 * LDE);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int col = gnb + nt * 16 + fr;
+        const float b = bias ? bias[col] : 0.f;
+        const float sc = col < scale_cols ? scale : 1.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {                     // accumulator element j = row 4*fq + j of the 16x16 tile
+                f32x2 v = f32x2{(acc[4 * p + mt][nt][j] + b) * sc, (acc[4 * p + mt][nt][j + 1] + b) * sc};
+                if (ACT == RNAMSM_ACT_GELU_ERF) v = gelu_erf2(v);
+                stage[(mt * 16 + 4 * fq + j) * LDE + nt * 16 + fr] = v[0];
+                stage[(mt * 16 + 4 * fq + j + 1) * LDE + nt * 16 + fr] = v[1];
+            }
+    }
+    f32x4 ov[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        ov[i] = *reinterpret_cast<const f32x4*>(&stage[(er + 4 * i) * LDE + ec]);
+        if (HAS_RES) ov[i] += res[i];
+    }
+    if (O_PL) {
+        typedef typename Half16<0>::T H;
+        typedef H H4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (gm0 + er + 4 * i < M) {
+                H4 hi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hi[e] = (H)ov[i][e];
+                epi_store(reinterpret_cast<H4*>(Ohi + (int64_t)(gm0 + er + 4 * i) * ldc + gn), hi);
+            }
+        }
+    } else if (gm0 + 64 <= M) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) epi_store(reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn), ov[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (gm0 + er + 4 * i < M) epi_store(reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn), ov[i]);
+    }
+}
+
+template <int ACT, bool HAS_RES, bool O_PL>
+__global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16_kernel(
+    const uint16_t* __restrict__ Ahi, int64_t lda, const uint16_t* __restrict__ Whi, const float* __restrict__ bias,
+    const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
+    uint16_t* __restrict__ Ohi, int group, unsigned total_tiles) {
+    using Cfg = HsCfg<1, 64>;
+    constexpr int BK = 64, ROWB = Cfg::ROWB, PLANE = Cfg::PLANE, KS = 2;     // two 32-deep k-steps per tile
+    typedef typename Half16<0>::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+
+    const unsigned nb = N / HX_BN, mp = (M + HX_BM - 1) / HX_BM;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv >> 2, wn = wv & 3, fr = lane & 15, fq = lane >> 4;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    for (unsigned vid = blockIdx.x; vid < total_tiles; vid += gridDim.x) {
+    unsigned mpanel, nblk;
+    if (!xcd_panel_map_grouped(vid, mp, nb, (unsigned)group, mpanel, nblk)) continue;
+    const int m0 = mpanel * HX_BM, n0 = nblk * HX_BN;
+    __syncthreads();                 // every wave has finished reading the previous tile's epilogue staging
+
+    // DMA map of gemm16_swp_kernel<BK 64>: a wave instruction covers 8 rows of 128 B
+    const int drow = lane >> 3;
+    const int dchunk = (lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7);      // (row >> 1) & 7, row = 8g + lane/8
+    int64_t aoff[Cfg::IPW], woff[Cfg::IPW];
+#pragma unroll
+    for (int j = 0; j < Cfg::IPW; ++j) {
+        const int row = Cfg::RPI * (wv + 8 * j) + drow;
+        int m = m0 + row;
+        m = m < M ? m : M - 1;
+        aoff[j] = (int64_t)m * lda + dchunk * 8;
+        woff[j] = (int64_t)(n0 + row) * K + dchunk * 8;
+    }
+    auto issue = [&](int kt, int buf) {
+        char* base = smem_b + buf * Cfg::BUF;
+#pragma unroll
+        for (int j = 0; j < Cfg::IPW; ++j) {
+            const int loff = (Cfg::RPI * (wv + 8 * j)) * ROWB;
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ahi + aoff[j] + kt * BK), (lptr_t)(base + loff), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Whi + woff[j] + kt * BK), (lptr_t)(base + PLANE + loff), 16, 0, 0);
+        }
+    };
+    // lane (row fr, k-group fq) of a 16-row tile reads logical chunk 4*ks + fq of its row; (row >> 1) & 7 = (fr >> 1) & 7.
+    // A tile is consumed in four micro-steps u = (k-step ks = u >> 1, row half h = u & 1) of 16 MFMAs: the A fragments of
+    // one half (4 x V8) ping-pong by micro-step, the B fragments of a k-step (4 x V8) by k-step -- 64 fragment registers
+    // instead of the 96 of two whole k-step sets, which with 128 accumulators would not fit 256.
+    V8 ah[2][4], bq[2][4];
+    auto load_a = [&](const char* buf, int ks, int h, V8 (&a)[4]) {
+        const int chunk = ((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const V8*>(buf + (wm * 128 + (4 * h + t) * 16 + fr) * ROWB + chunk);
+    };
+    auto load_b = [&](const char* buf, int ks, V8 (&b)[4]) {
+        const int chunk = ((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const V8*>(buf + PLANE + (wn * 64 + t * 16 + fr) * ROWB + chunk);
+    };
+    f32x4a acc[8][4];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4a{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](int h, const V8 (&a)[4], const V8 (&b)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[4 * h + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[4 * h + mt][nt], 0, 0, 0);
+    };
+    (void)KS;
+
+    const int nk = K / BK;
+    issue(0, 0);
+    wait_dma_then_barrier<0>();
+    issue(nk > 1 ? 1 : 0, 1);
+    load_a(smem_b, 0, 0, ah[0]);
+    load_b(smem_b, 0, bq[0]);
+#define HQ_PIN(NDS_)                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < NDS_; ++i_) {                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+    }                                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 16 - NDS_, 0);                        \
+    __builtin_amdgcn_sched_barrier(0)
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const char* cur = smem_b + (kt & 1) * Cfg::BUF;
+        const char* nxt = smem_b + ((kt & 1) ^ 1) * Cfg::BUF;
+        load_a(cur, 0, 1, ah[1]);                             // u0 computes, u1's A half arriving
+        mma(0, ah[0], bq[0]);
+        HQ_PIN(4);
+        load_a(cur, 1, 0, ah[0]);                             // u1 computes, u2's A half and k-step 1's B arriving
+        load_b(cur, 1, bq[1]);
+        mma(1, ah[1], bq[0]);
+        HQ_PIN(8);
+        load_a(cur, 1, 1, ah[1]);                             // u2 computes, u3's A half arriving: the last reads of `cur`
+        mma(0, ah[0], bq[1]);
+        HQ_PIN(4);
+        wait_dma_then_barrier<0>();                           // all waves done reading `cur`; tile kt+1 has landed
+        const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;         // clamped: the last reload is never read
+        issue(k2, kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(nxt, 0, 0, ah[0]);                             // u3 computes, the next tile's u0 operands arriving
+        load_b(nxt, 0, bq[0]);
+        mma(1, ah[1], bq[1]);
+        HQ_PIN(8);
+    }
+    {
+        const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
+        load_a(cur, 0, 1, ah[1]);
+        mma(0, ah[0], bq[0]);
+        HQ_PIN(4);
+        load_a(cur, 1, 0, ah[0]);
+        load_b(cur, 1, bq[1]);
+        mma(1, ah[1], bq[0]);
+        HQ_PIN(8);
+        load_a(cur, 1, 1, ah[1]);
+        mma(0, ah[0], bq[1]);
+        HQ_PIN(4);
+        mma(1, ah[1], bq[1]);
+    }
+#undef HQ_PIN
+    wait_dma_then_barrier<0>();
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        hq_epilogue<ACT, HAS_RES, O_PL>(acc, p, smem_b, m0 + wm * 128 + p * 64, n0 + wn * 64, wv, lane, bias, residual, ldr,
+                                        Cout, ldc, M, scale, scale_cols, Ohi);
+    }   // persistent tile loop
+}
+
+template <int ACT, bool HAS_RES, bool O_PL>
+static int launch_hq(const uint16_t* Whi, const float* bias, const float* residual, int64_t ldr, float* Cout, int64_t ldc,
+                     int64_t lda, int M, int N, int K, float scale, int scale_cols, const uint16_t* a_hi, uint16_t* o_hi,
+                     hipStream_t stream) {
+    static DeviceOnce configured;
+    auto kern = gemm16_q16_kernel<ACT, HAS_RES, O_PL>;
+    constexpr int lds = HsCfg<1, 64>::LDS;
+    if (configured.pending()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_q16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured.mark();
+    }
+    const int group = tuning().gemm_group > 0 ? tuning().gemm_group : (N / HX_BN > 4 ? 8 : 1);
+    const unsigned total = xcd_panel_grid_grouped((M + HX_BM - 1) / HX_BM, N / HX_BN, (unsigned)group);
+    const unsigned pb = tuning().gemm16_persist > 0 ? (unsigned)tuning().gemm16_persist : 0u;
+    const unsigned grid = pb && pb < total ? pb : total;
+    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * N * (HAS_RES ? 2 : 1), stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, lda, Whi, bias, residual, ldr, Cout, ldc, M, N, K,
+                       scale, scale_cols, o_hi, group, total);
+    RNAMSM_CHECK_LAUNCH("gemm16_q16");
+    return RNAMSM_OK;
+}
+
 // LayerNorm whose output goes straight into 16-bit hi/lo planes (the A operand of the following matrix-core GEMM):
 // same arithmetic as layernorm_kernel (elementwise.hip), only the store differs.
 template <int FMT>
@@ -866,10 +1088,17 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
     ((SP_ == 1 && tuning().gemm16_dma != 4 && K % 64 == 0)                                                             \
          ? launch_hs<ACT_, RES_, SP_, FMT_, OPL_, (SP_ == 1 ? 64 : 32)>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s) \
          : launch_hs<ACT_, RES_, SP_, FMT_, OPL_, 32>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s))
+#define HQ_GO(ACT_, RES_, OPL_) \
+    launch_hq<ACT_, RES_, OPL_>(W_hi, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, O_hi, s)
 #define HD_GO(ACT_, RES_, SP_, FMT_, OPL_) \
     launch_hd<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
 #define HB_ACT_RES(SP_, FMT_)                                                                                       \
     do {                                                                                                            \
+        if (SP_ == 1 && A_hi && tuning().gemm16_mfma16 && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= 2048 && K % 64 == 0) { /* 16x16x32 */ \
+            if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HQ_GO(RNAMSM_ACT_GELU_ERF, false, true)                    \
+                                                        : HQ_GO(RNAMSM_ACT_NONE, false, true);                       \
+            return residual ? HQ_GO(RNAMSM_ACT_NONE, true, false) : HQ_GO(RNAMSM_ACT_NONE, false, false);            \
+        }                                                                                                           \
         if (A_hi && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= 2048) {   /* software-pipelined fragments */    \
             if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HS_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true)        \
                                                         : HS_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, true);           \
@@ -900,6 +1129,7 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
     HB_ACT_RES(1, 0);
 #undef HB_ACT_RES
 #undef HD_GO
+#undef HQ_GO
 #undef HS_GO
 #undef HX_GO
 #undef HB_GO
