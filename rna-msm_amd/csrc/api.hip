@@ -135,7 +135,7 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         return RNAMSM_OK;
     }
     if (name && !strcmp(name, "gemm16_mfma16")) {
-        rnamsm::tuning().gemm16_mfma16 = value != 0;
+        rnamsm::tuning().gemm16_mfma16 = value < 0 ? 0 : (value > 2 ? 2 : value);
         return RNAMSM_OK;
     }
     if (name && !strcmp(name, "gemm16_persist")) {

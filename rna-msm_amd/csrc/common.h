@@ -49,7 +49,7 @@ struct Tuning {
     int gemm16_dma = 3;            // plane-input 16-bit GEMMs: 0 register staging, 1 LDS-DMA 128x128, 2 LDS-DMA 256x256,
                                    // 3 = LDS-DMA 256x256 with software-pipelined fragments, BK = 64 for split 1 (default),
                                    // 4 = the same with BK = 32 for every split
-    int gemm16_mfma16 = 1;         // plain-bf16 256x256 GEMM: 1 = v_mfma_f32_16x16x32_bf16 (gemm16_q16_kernel), 0 = 32x32x16
+    int gemm16_mfma16 = 1;         // plain-bf16 256x256 GEMM: 1 = v_mfma_f32_16x16x32_bf16 (gemm16_q16_kernel) for wide N, 2 = always, 0 = 32x32x16
     int gemm16_persist = 256;      // 256x256 16-bit GEMM: > 0 = that many persistent blocks walk the tiles (256 = one per CU; +1-5%, tools/gemm16_persist_ab.py), 0 = one block per tile
     int gemm16_stagger = 0;        // ... and block b starts (b/8 % 4) x this many cycles late (spreads the store bursts)
     int gemm_group = 0;            // fp32 GEMM: row panels per XCD group of the block order (xcd_panel_map_grouped); 0 = by shape
