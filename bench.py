@@ -254,6 +254,23 @@ def run_rank(args) -> int:
     toks = {i: torch.from_numpy(synthetic.make_tokens(M, L, i)).to(dev) for i in mine_all}
 
     gather = world > 1 and not args.no_gather
+    gather_failure = None
+    if gather:
+        # Probe the gather once, outside the timed region (this also builds the point-to-point communicators): if the
+        # fabric refuses it the bench still measures the sharded compute and says so, instead of dying in the timed loop.
+        ok = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
+        try:
+            probe = sharding.RoundGatherer(world, tensors_per_item=2, dst=0, device=dev)
+            probe.submit(rank, (torch.full((3, 5), float(rank), device=dev), torch.zeros(2, 4, 4, device=dev)))
+            probe.finish()
+            torch.cuda.synchronize()
+        except Exception as e:                                        # noqa: BLE001
+            ok.zero_()
+            gather_failure = f"{type(e).__name__}: {e}"
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0:
+            gather = False
+            gather_failure = gather_failure or "a peer failed in the probe"
     digest = torch.zeros((), dtype=torch.int64, device=dev)
     delivered = [0]
 
@@ -404,7 +421,7 @@ def run_rank(args) -> int:
         if world == 1:
             gather_note = "none (single GPU)"
         elif not gather:
-            gather_note = "disabled by flag"
+            gather_note = "disabled by flag" if gather_failure is None else f"failed in the probe, compute only: {gather_failure}"
         else:
             gather_note = (f"rnamsm.sharding.RoundGatherer: emb+atp of every MSA to rank 0 over "
                            f"{'RCCL point-to-point' if args.backend == 'nccl' else args.backend + ' (host-staged)'}, "
