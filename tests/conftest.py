@@ -33,3 +33,22 @@ def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+_LETTER = {4: "A", 5: "G", 6: "C", 7: "U", 8: "X", 10: "-"}
+
+
+def write_full_2drb1_a2m(directory) -> str:
+    """BASELINE configs[0]'s alignment at full depth as an .a2m_msa2 file, rebuilt from the token matrix the reference's
+    reader produced for the shipped results/2DRB_1.a2m_msa2 (tokens_2DRB_1_full.npz: 1176 rows x 35 columns)."""
+    toks = golden("tokens_2DRB_1_full.npz")["all_tokens"]
+    path = os.path.join(str(directory), "2DRB_1.a2m_msa2")
+    with open(path, "w") as f:
+        for i, row in enumerate(toks):
+            f.write(f">seq{i}\n" + "".join(_LETTER[int(t)] for t in row[1:]) + "\n")
+    return path
+
+
+@pytest.fixture(scope="session")
+def full_2drb1_a2m(tmp_path_factory):
+    return write_full_2drb1_a2m(tmp_path_factory.mktemp("a2m"))

@@ -121,13 +121,13 @@ def test_every_baseline_config_against_fp64_truth(model, label, make):
         assert e[k] <= 1.5 * e_ref16[k], ("bf16", k, e, e_ref16)
 
 
-def test_configs0_through_the_reader_and_device_subsampling(model):
+def test_configs0_through_the_reader_and_device_subsampling(model, full_2drb1_a2m):
     """configs[0] end to end on the device side: the shipped 1176-row alignment file -> reader -> device greedy
     sub-sampling (512 rows) -> forward, equal to the forward of the reference's own 512 selected rows (bit-identical:
     same tokens, deterministic kernels)."""
     from rnamsm.alphabet import RNAAlphabet
     from rnamsm.msa import load_msa_tokens
-    toks = load_msa_tokens(os.path.join(GOLDEN, "2DRB_1.a2m_msa2"), RNAAlphabet(), 512, "diversity-max", device=DEV)
+    toks = load_msa_tokens(full_2drb1_a2m, RNAAlphabet(), 512, "diversity-max", device=DEV)
     want = _tokens_2drb1()
     assert np.array_equal(toks, want)
     a = hip_outputs(model, toks, "f32")

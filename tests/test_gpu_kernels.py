@@ -278,7 +278,7 @@ def test_generic_mha_matches_reference_fixture(dev, name):
         mha(x, x, x, key_padding_mask=torch.zeros(T, B, dtype=torch.bool, device=dev))
 
 
-def test_greedy_select_on_device_equals_host_and_reference(dev):
+def test_greedy_select_on_device_equals_host_and_reference(dev, full_2drb1_a2m):
     """device greedy max/min-Hamming sub-sampling picks exactly the reference's rows (fixture from
     MSA.greedy_select) and exactly the host implementation's rows on larger random alignments with many ties."""
     import os
@@ -292,7 +292,7 @@ def test_greedy_select_on_device_equals_host_and_reference(dev):
     assert np.array_equal(msa.load_msa_tokens(path, a, 16, "diversity-min", device=dev), g["diversity_min_16"])
     # the shipped alignment at the CLI default (BASELINE configs[0]): 1176 rows -> 512.  Candidates tie in their mismatch
     # totals here and the winner depends on numpy's pairwise summation order (a running sum differs from step 46 on)
-    full = os.path.join(GOLDEN, "2DRB_1.a2m_msa2")
+    full = full_2drb1_a2m
     assert np.array_equal(msa.load_msa_tokens(full, a, 512, "diversity-max", device=dev),
                           golden("tokens_2DRB_1_full.npz")["diversity_max_512"])
     rng = np.random.RandomState(3)
@@ -305,7 +305,7 @@ def test_greedy_select_on_device_equals_host_and_reference(dev):
             assert np.array_equal(got, want), (N, L, K, mode)
 
 
-def test_msa_weights_on_device_equal_host_and_reference(dev):
+def test_msa_weights_on_device_equal_host_and_reference(dev, full_2drb1_a2m):
     """§8 f3, `sample-pretrained` (utils/align.py:150-163, 250-253): rnamsm_msa_weights gives the reference's float64
     sequence weights bit for bit (fixture: the shipped 1176-row alignment), so the weighted draw picks the same rows; and
     equals the host implementation on shapes that exercise every lane-group width (L = 3 .. 300)."""
@@ -314,7 +314,7 @@ def test_msa_weights_on_device_equal_host_and_reference(dev):
     from rnamsm import msa
     from rnamsm.alphabet import RNAAlphabet
     g = golden("msa_weights_2DRB_1.npz")
-    path = os.path.join(GOLDEN, "2DRB_1.a2m_msa2")
+    path = full_2drb1_a2m
     a = RNAAlphabet()
     toks = msa.load_msa_tokens(path, a, None)
     assert np.array_equal(msa.msa_weights(toks, float(g["seqid_cutoff"]), device=dev), g["weights"])

@@ -85,12 +85,12 @@ def test_row_subsampling_matches_reference_greedy_select():
         msa.load_msa_tokens(path, a, 16, "nonsense")
 
 
-def test_sample_pretrained_subsampling_matches_reference_weights_and_draws():
+def test_sample_pretrained_subsampling_matches_reference_weights_and_draws(full_2drb1_a2m):
     """utils/align.py:150-163, 250-253 on the shipped 1176-row alignment: the sequence weights are the reference's bit for
     bit, and with numpy's generator in the same state (the reference draws from the global one, seeded by
     seed_everything) the weighted draw picks the reference's rows."""
     g = golden("msa_weights_2DRB_1.npz")
-    path = os.path.join(GOLDEN, "2DRB_1.a2m_msa2")
+    path = full_2drb1_a2m
     a = RNAAlphabet()
     toks = msa.load_msa_tokens(path, a, None)
     assert np.array_equal(msa.msa_weights(toks, float(g["seqid_cutoff"])), g["weights"])

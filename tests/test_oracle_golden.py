@@ -213,14 +213,14 @@ def test_generic_mha_weights_and_key_padding_mask_match_reference(name):
     assert float(w[:, 0, :, T - 5:].max()) == 0.0 and float(w[:, B - 1, :, 3].max()) == 0.0
 
 
-def test_full_2drb1_alignment_tokens_and_default_subsampling_bit_exact():
-    """BASELINE configs[0] at full depth: the shipped 1176-row alignment through the reader, then `diversity-max` to the
-    CLI default of 512 rows (utils/align.py:128-148) -- tokens bit-exact with the reference's."""
+def test_full_2drb1_alignment_tokens_and_default_subsampling_bit_exact(full_2drb1_a2m):
+    """BASELINE configs[0] at full depth: the shipped 1176-row alignment (rebuilt from the reference reader's token matrix)
+    through the reader, then `diversity-max` to the CLI default of 512 rows (utils/align.py:128-148) -- tokens bit-exact
+    with the reference's."""
     g = golden("tokens_2DRB_1_full.npz")
-    text = open(os.path.join(GOLDEN, "2DRB_1.a2m_msa2")).read()
-    toks = TO.encode_msa(text)
+    toks = TO.encode_msa(open(full_2drb1_a2m).read())
     assert toks.shape == tuple(g["depth_seqlen"]) == (1176, 36)
-    assert np.array_equal(toks[:512], g["first_512"])
+    assert np.array_equal(toks, g["all_tokens"].astype(np.int64)) and np.array_equal(toks[:512], g["first_512"])
     from rnamsm.msa import greedy_select
     sel = greedy_select(toks, 512, "max")
     assert np.array_equal(toks[sel], g["diversity_max_512"])
