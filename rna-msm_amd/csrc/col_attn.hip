@@ -125,9 +125,11 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
         // ---- online softmax; keys >= R (last tile only) are masked branch-free.  __expf = v_exp_f32(x*log2e):
         // relative error <= ~2e-6 for the |x| <= 20 that matter, 100x inside the parity bar.
         const int limit = R - jbase;
+        if (limit < 32) {        // block-uniform: only a ragged last tile holds keys >= R (32 compare/select per lane saved elsewhere)
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-            s[t] = ((t & 3) + 8 * (t >> 2) + 4 * lh < limit) ? s[t] : -INFINITY;
+            for (int t = 0; t < 16; ++t)
+                s[t] = ((t & 3) + 8 * (t >> 2) + 4 * lh < limit) ? s[t] : -INFINITY;
+        }
         if (MASKED) {       // f2: masked_fill(padding_mask, -10000) on padded keys of this column (modules.py:911-915)
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -323,9 +325,11 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
         }
         __builtin_amdgcn_sched_barrier(0);
         const int limit = R - jbase;
+        if (limit < 32) {        // block-uniform: only a ragged last tile holds keys >= R (32 compare/select per lane saved elsewhere)
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-            s[t] = ((t & 3) + 8 * (t >> 2) + 4 * lh < limit) ? s[t] : -INFINITY;
+            for (int t = 0; t < 16; ++t)
+                s[t] = ((t & 3) + 8 * (t >> 2) + 4 * lh < limit) ? s[t] : -INFINITY;
+        }
         if (MASKED) {       // f2: masked_fill(padding_mask, -10000) on padded keys of this column (modules.py:911-915)
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -450,11 +454,11 @@ extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float
         hipLaunchKernelGGL((KERN_<M_, OUT_>), dim3(grid), dim3(CA_THREADS), LDS_, s, q, k, v, ld, ctx, ldc, R, C, H, \
                            pad_mask, ctx_hi, ctx_lo);                                                               \
     } while (0)
-    // "col_dma": 1 = the LDS-DMA, three-blocks-per-CU variant, 0 = the register-staged kernel, -1 (default) = by shape.
-    // Measured in one process (tools/col_attn_ab.py): R=256 C=512 +4 %, R=1024 +2 %, R=512 C=36 equal, R <= 128 4-10 %
-    // SLOWER (four tiles per block: the barrier per tile costs more than the third resident block buys); the masked
-    // instance is 4-20 % faster at every shape (the register-staged one spills).
-    const bool use_dma = tuning().col_dma < 0 ? (pad_mask != nullptr || R >= 192) : tuning().col_dma != 0;
+    // "col_dma": 1 = the LDS-DMA, three-blocks-per-CU variant, 0 = the register-staged kernel, -1 (default) = the former.
+    // Measured in one process (tools/col_attn_ab.py, after the key-range masking was confined to the ragged last tile):
+    // R=256 C=512 +11 %, R=128 C=256 +5 %, R=1024 +2 %, R=100 C=300 +3 %, R=64 / R=512 C=36 equal; the masked instance
+    // +10-20 % at every shape (the register-staged one spills).  Outputs bit-identical.
+    const bool use_dma = tuning().col_dma != 0;
 #define CA_GO(M_, OUT_)                                                                                             \
     do {                                                                                                            \
         if (use_dma) CA_GO2(col_attn_dma_kernel, CD_LDS_BYTES, M_, OUT_);                                           \
