@@ -18,6 +18,7 @@
 //   the query row on the lane, so the online-softmax rescale is a per-lane scalar multiply.
 // Roofline: MFMA-bound: 4*R*R*64 flops per (c,h) vs 4*R*256 B of q,k,v,ctx (64 flop/B at R=256).
 #include "tile16.h"
+#include <type_traits>
 
 namespace rnamsm {
 
@@ -247,6 +248,13 @@ constexpr int CD_TILE = CD_JC * CD_ROWB;         // one operand chunk
 constexpr int CD_BUF = 2 * CD_TILE;              // K chunk then V chunk
 constexpr int CD_LDS_BYTES = 2 * CD_BUF;         // double buffered: 32 KB
 
+// index of the V lane base for MFMA step t / head-dim tile dt (the swizzle constant K = j0 ^ 8 dt takes the values
+// {0..3, 8..11}), and the row of step t inside the 32-key tile without its lane-half part
+__host__ __device__ constexpr int cd_vidx(int t, int dt) {
+    return ((((t & 3) + 8 * ((t >> 2) & 1)) ^ (8 * dt)) & 3) + 4 * (((((t & 3) + 8 * ((t >> 2) & 1)) ^ (8 * dt)) >> 3) & 1);
+}
+__host__ __device__ constexpr int cd_vrow(int t) { return (t & 3) + 8 * (t >> 2); }
+
 template <bool MASKED, int OUT>
 __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
@@ -275,15 +283,33 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
 
     // DMA map: one wave instruction = 4 key rows x 256 B (lane -> row lane/16, physical chunk lane%16); a chunk is 8 such
     // groups per operand, wave w moves groups w and w+4.  Keys past R are clamped (scores masked to -inf, V meets P = 0).
+    // The per-lane source offsets of chunk 0 are kept; a full chunk adds ch * 32 rows to them (one 64-bit mad each).
     const int drow = lane >> 4, dchunk = lane & 15;
+    const int64_t row_bytes = (int64_t)C * ld;                           // elements between consecutive alignment rows
+    int64_t doff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 4 * (wave + 4 * j) + drow;
+        doff[j] = (int64_t)row * row_bytes + col_off + ((dchunk ^ (row & 15)) << 2);
+    }
     auto issue = [&](int ch, int buf) {
         char* base = smem_b + buf * CD_BUF;
+        if ((ch + 1) * CD_JC <= R) {                                     // block-uniform: every key of the chunk exists
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int g = wave + 4 * j, row = 4 * g + drow;
-            const int64_t off = (int64_t)min(ch * CD_JC + row, R - 1) * C * ld + col_off + ((dchunk ^ (row & 15)) << 2);
-            __builtin_amdgcn_global_load_lds((gptr_t)(k + off), (lptr_t)(base + g * 4 * CD_ROWB), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(v + off), (lptr_t)(base + CD_TILE + g * 4 * CD_ROWB), 16, 0, 0);
+            for (int j = 0; j < 2; ++j) {
+                const int64_t off = doff[j] + (int64_t)(ch * CD_JC) * row_bytes;
+                const int g = wave + 4 * j;
+                __builtin_amdgcn_global_load_lds((gptr_t)(k + off), (lptr_t)(base + g * 4 * CD_ROWB), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(v + off), (lptr_t)(base + CD_TILE + g * 4 * CD_ROWB), 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int g = wave + 4 * j, row = 4 * g + drow;
+                const int64_t off = (int64_t)min(ch * CD_JC + row, R - 1) * row_bytes + col_off + ((dchunk ^ (row & 15)) << 2);
+                __builtin_amdgcn_global_load_lds((gptr_t)(k + off), (lptr_t)(base + g * 4 * CD_ROWB), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(v + off), (lptr_t)(base + CD_TILE + g * 4 * CD_ROWB), 16, 0, 0);
+            }
         }
     };
 
@@ -292,40 +318,55 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
     for (int t = 0; t < 16; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
-    // V value of MFMA step t (key (t&3)+8(t>>2)+4*half), head-dim tile dt, for this lane's column li
-    auto vread = [&](const char* Vc, int t, int dt) -> float {
-        const int jl = (t & 3) + 8 * (t >> 2) + 4 * lh;
-        return *reinterpret_cast<const float*>(Vc + jl * CD_ROWB + (li & 3) * 4 + (((8 * dt + (li >> 2)) ^ (jl & 15)) << 4));
-    };
+    // LDS read addresses.  The swizzle XORs a lane term with a per-read constant, which no immediate offset can express; the
+    // constants take only 8 values per operand, so 8 + 8 lane bases are formed once and every read of the loop is
+    // base + immediate (row, buffer) -- the address arithmetic was a third of the tile's VALU instructions.
+    //   K fragment kk of row li:  chunk (2kk + lh) ^ (li & 15) = [(li & 15) ^ lh] ^ 2kk
+    //   V value (step t, d tile): row jl = (t&3) + 8(t>>2) + 4 lh, chunk [(li>>2) ^ 4 lh] ^ [j0 ^ 8 dt], j0 = (t&3) + 8((t>>2)&1)
+    const char* kb[8];
+    const char* vb8[8];
+    {
+        const int lk = (li & 15) ^ lh, lv = (li >> 2) ^ (lh << 2);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) kb[kk] = smem_b + li * CD_ROWB + ((lk ^ (2 * kk)) << 4);
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int K = (x & 3) + 8 * (x >> 2);
+            vb8[x] = smem_b + CD_TILE + lh * 4 * CD_ROWB + (li & 3) * 4 + ((lv ^ K) << 4);
+        }
+    }
+    // V value of MFMA step t (key (t&3)+8(t>>2)+4*half), head-dim tile dt, buffer BUF: base + immediate
+#define CD_VREAD(BUF_, t_, dt_) \
+    (*reinterpret_cast<const float*>(vb8[cd_vidx(t_, dt_)] + (BUF_) * CD_BUF + cd_vrow(t_) * CD_ROWB))
 
-    // One 32-key tile, order pinned.  The V values are fetched in two halves (steps 0-7 under the QK^T MFMAs, steps 8-15
-    // under the first half of the PV MFMAs) so that the tile peaks at ~130 live registers and three blocks fit a CU.
-    auto tile = [&](const char* Kc, const char* Vc, int jbase) {
+    // One 32-key tile, order pinned.  V values travel in quarters of 8 (steps 4q..4q+3, both head-dim tiles) that ping-pong:
+    // quarter 0 under the QK^T MFMAs, quarter q+1 under the PV MFMAs of quarter q -- 16 live V registers instead of 32.
+    auto tile = [&](auto bufc, int jbase) {
+        constexpr int BUF = decltype(bufc)::value;
         f32x4 kf[8];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
-            kf[kk] = *reinterpret_cast<const f32x4*>(Kc + li * CD_ROWB + (((2 * kk + lh) ^ (li & 15)) << 4));
+        for (int kk = 0; kk < 8; ++kk) kf[kk] = *reinterpret_cast<const f32x4*>(kb[kk] + BUF * CD_BUF);
         f32x16 s;
 #pragma unroll
         for (int t = 0; t < 16; ++t) s[t] = 0.f;
-        float va[16], vb[16];
+        float vq[2][8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            va[2 * t] = vread(Vc, t, 0);
-            va[2 * t + 1] = vread(Vc, t, 1);
+        for (int t = 0; t < 4; ++t) {
+            vq[0][2 * t] = CD_VREAD(BUF, t, 0);
+            vq[0][2 * t + 1] = CD_VREAD(BUF, t, 1);
         }
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
             for (int e = 0; e < 4; ++e) s = mfma32(kf[kk][e], qf[kk][e], s);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);     // 2 MFMA
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);     // 4 MFMA
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
         }
         __builtin_amdgcn_sched_barrier(0);
         const int limit = R - jbase;
-        if (limit < 32) {        // block-uniform: only a ragged last tile holds keys >= R (32 compare/select per lane saved elsewhere)
+        if (limit < 32) {        // block-uniform: only a ragged last tile holds keys >= R
 #pragma unroll
             for (int t = 0; t < 16; ++t)
                 s[t] = ((t & 3) + 8 * (t >> 2) + 4 * lh < limit) ? s[t] : -INFINITY;
@@ -354,39 +395,43 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
         for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            vb[2 * t] = vread(Vc, 8 + t, 0);
-            vb[2 * t + 1] = vread(Vc, 8 + t, 1);
-        }
+        for (int qd = 0; qd < 4; ++qd) {
+            if (qd < 3) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            o0 = mfma32(va[2 * t], s[t], o0);
-            o1 = mfma32(va[2 * t + 1], s[t], o1);
-        }
+                for (int t = 0; t < 4; ++t) {
+                    vq[(qd + 1) & 1][2 * t] = CD_VREAD(BUF, 4 * (qd + 1) + t, 0);
+                    vq[(qd + 1) & 1][2 * t + 1] = CD_VREAD(BUF, 4 * (qd + 1) + t, 1);
+                }
+            }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int t = 0; t < 4; ++t) {
+                o0 = mfma32(vq[qd & 1][2 * t], s[4 * qd + t], o0);
+                o1 = mfma32(vq[qd & 1][2 * t + 1], s[4 * qd + t], o1);
+            }
+            if (qd < 3) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            o0 = mfma32(vb[2 * t], s[8 + t], o0);
-            o1 = mfma32(vb[2 * t + 1], s[8 + t], o1);
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     };
 
     const int nch = (R + CD_JC - 1) / CD_JC;
     issue(0, 0);
-    for (int ch = 0; ch < nch; ++ch) {
+    for (int ch = 0; ch < nch; ch += 2) {                     // unrolled by two: the buffer index is a compile-time constant
         wait_dma_then_barrier<0>();      // chunk ch has landed (every wave's share) and the other buffer is free again
-        if (ch + 1 < nch) issue(ch + 1, (ch + 1) & 1);
-        if (active) {
-            const char* Kc = smem_b + (ch & 1) * CD_BUF;
-            tile(Kc, Kc + CD_TILE, ch * CD_JC);
+        if (ch + 1 < nch) issue(ch + 1, 1);
+        if (active) tile(std::integral_constant<int, 0>{}, ch * CD_JC);
+        if (ch + 1 < nch) {
+            wait_dma_then_barrier<0>();
+            if (ch + 2 < nch) issue(ch + 2, 0);
+            if (active) tile(std::integral_constant<int, 1>{}, (ch + 1) * CD_JC);
         }
     }
+#undef CD_VREAD
 
     if (active) {
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
