@@ -240,13 +240,13 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
 //     a DMA writes lanes linearly, so rows are unpadded 256-B lines and the bank spread is an XOR swizzle applied to the
 //     SOURCE chunk and to the READ: physical 16-B chunk = logical ^ (row & 15) -- the 16 lanes of a ds_read_b128 group
 //     hold rows distinct mod 16 (K fragments), and a 32-lane ds_read_b32 group covers 8 chunks that share bit 3 (V);
-//   * 32-key chunks (one tile per barrier), three buffers: 48 KB of LDS per block instead of 70 KB;
+//   * 32-key chunks (one tile per barrier): 2 x 16 KB of LDS per block instead of 70 KB;
 //   * <= 168 registers: three blocks per CU instead of two.
 constexpr int CD_JC = 32;
 constexpr int CD_ROWB = 256;                     // bytes per LDS row (64 floats)
 constexpr int CD_TILE = CD_JC * CD_ROWB;         // one operand chunk
 constexpr int CD_BUF = 2 * CD_TILE;              // K chunk then V chunk
-constexpr int CD_LDS_BYTES = 3 * CD_BUF;         // three chunk buffers: 48 KB (three blocks per CU: 144 KB)
+constexpr int CD_LDS_BYTES = 2 * CD_BUF;         // double buffered: 32 KB
 
 // index of the V lane base for MFMA step t / head-dim tile dt (the swizzle constant K = j0 ^ 8 dt takes the values
 // {0..3, 8..11}), and the row of step t inside the 32-key tile without its lane-half part
@@ -419,24 +419,18 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
         }
     };
 
-    // Three chunk buffers: chunk ch+2 is requested while chunk ch is consumed, so a chunk has two tiles (~4 us) to land
-    // and the wait before a tile leaves the newest request in flight (vmcnt(4): a wave issues 4 DMAs per chunk).  The
-    // buffer being refilled was last read two barriers ago.  Unrolled by three: buffer indices are compile-time constants.
     const int nch = (R + CD_JC - 1) / CD_JC;
     issue(0, 0);
-    if (nch > 1) issue(1, 1);
-#define CD_STEP(B_, CH_)                                                                       \
-    if ((CH_) < nch) {                                                                         \
-        if ((CH_) + 1 < nch) wait_dma_then_barrier<4>(); else wait_dma_then_barrier<0>();      \
-        if ((CH_) + 2 < nch) issue((CH_) + 2, ((B_) + 2) % 3);                                 \
-        if (active) tile(std::integral_constant<int, B_>{}, (CH_) * CD_JC);                    \
+    for (int ch = 0; ch < nch; ch += 2) {                     // unrolled by two: the buffer index is a compile-time constant
+        wait_dma_then_barrier<0>();      // chunk ch has landed (every wave's share) and the other buffer is free again
+        if (ch + 1 < nch) issue(ch + 1, 1);
+        if (active) tile(std::integral_constant<int, 0>{}, ch * CD_JC);
+        if (ch + 1 < nch) {
+            wait_dma_then_barrier<0>();
+            if (ch + 2 < nch) issue(ch + 2, 0);
+            if (active) tile(std::integral_constant<int, 1>{}, (ch + 1) * CD_JC);
+        }
     }
-    for (int ch = 0; ch < nch; ch += 3) {
-        CD_STEP(0, ch)
-        CD_STEP(1, ch + 1)
-        CD_STEP(2, ch + 2)
-    }
-#undef CD_STEP
 #undef CD_VREAD
 
     if (active) {
