@@ -117,9 +117,14 @@ __global__ __launch_bounds__(C16_THREADS, JC == 32 ? 3 : 2) void col_attn16_kern
         for (int kk = 0; kk < 4; ++kk) s = mma16<SPLIT, FMT>(kf[kk], qf[kk], s);
         // ---- online softmax (fp32): keys >= R masked branch-free; __expf = v_exp_f32(x * log2e)
         const int limit = R - jbase;
+        if (limit < 32) {        // block-uniform: only a ragged last tile holds keys >= R
 #pragma unroll
-        for (int t = 0; t < 16; ++t)
-            s[t] = ((t & 3) + 8 * (t >> 2) + 4 * lh < limit) ? s[t] * scale : -INFINITY;
+            for (int t = 0; t < 16; ++t)
+                s[t] = ((t & 3) + 8 * (t >> 2) + 4 * lh < limit) ? s[t] * scale : -INFINITY;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s[t] *= scale;
+        }
         if (MASKED) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
