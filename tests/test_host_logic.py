@@ -3,6 +3,7 @@ behaviour, the C-ABI library (loads, exports every symbol of include/rnamsm.h, v
 and the no-fallback rule (ops refuse CPU tensors)."""
 import json
 import os
+import sys
 import re
 import subprocess
 
@@ -14,6 +15,7 @@ from conftest import GOLDEN, ROOT, golden
 from rnamsm import msa, synthetic
 from rnamsm.alphabet import RNAAlphabet
 from rnamsm.config import Config, parse_overrides
+from oracle import tokenizer_oracle as TO
 
 
 @pytest.fixture(scope="module")
@@ -284,3 +286,66 @@ def test_argument_validation_layer_under_address_and_ub_sanitizers():
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "ABI driver:" in p.stdout and " 0 failed" in p.stdout
     assert "ERROR: AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr
+
+
+def test_bench_launcher_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` started directly spawns its two ranks from a parent that never touches the GPU; on this
+    GPU-less container every rank refuses to run (there is no CPU path) and the launcher must return non-zero instead of
+    hanging or printing a result line."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a GPU-less host")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0
+    assert "no CPU path" in p.stderr and not any(ln.startswith("{") for ln in p.stdout.splitlines())
+
+
+def test_reader_agrees_with_the_oracle_on_random_alignments():
+    """Differential test of the product's reader/tokenizer (byte LUT, own FASTA parser) against the oracle's restatement
+    (regex clean-up + digitize, the reference's method) on random a2m text: every character class (upper-case residues,
+    T, IUPAC codes, lower-case / '.' / '*' insertions, gaps), multi-line records, blank lines, descriptions with spaces --
+    token matrices bit-identical, and the same exception type on invalid characters and ragged rows."""
+    from hypothesis import given, settings, strategies as st
+    from rnamsm.msa import read_fasta_records
+    a = RNAAlphabet()
+    keep = "ACGUX-TRYKMSWBDHVN"
+    drop = "acgu.*nxz"
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.integers(1, 6), st.integers(1, 40), st.randoms(use_true_random=False), st.sampled_from(["ok", "bad_char", "ragged"]))
+    def run(rows, cols, rnd, kind):
+        seqs = []
+        for r in range(rows):
+            s = "".join(rnd.choice(keep) for _ in range(cols))
+            pieces = []
+            for ch in s:                                           # sprinkle insertions that the reader must drop
+                if rnd.random() < 0.2:
+                    pieces.append(rnd.choice(drop))
+                pieces.append(ch)
+            seqs.append("".join(pieces))
+        if kind == "bad_char":
+            r = rnd.randrange(rows)
+            seqs[r] = seqs[r][:1] + rnd.choice("EFIJLOPQZ@5") + seqs[r][1:]
+        if kind == "ragged" and rows > 1:
+            seqs[-1] = seqs[-1] + "A"
+        text = ""
+        for r, s in enumerate(seqs):
+            cut = rnd.randrange(1, len(s) + 1)
+            text += f">seq{r} some description\\n{s[:cut]}\\n" + (f"{s[cut:]}\\n" if cut < len(s) else "") + ("\\n" if rnd.random() < 0.3 else "")
+        try:
+            want = TO.encode_msa(text)
+            err = None
+        except (AssertionError, ValueError) as e:
+            want, err = None, type(e)
+        recs = read_fasta_records(text, is_text=True)
+        if err is None:
+            got = a.encode_a2m_records([s for _, s in recs])
+            assert got.dtype == np.int64 and np.array_equal(got, want)
+        else:
+            with pytest.raises(err):
+                a.encode_a2m_records([s for _, s in recs])
+
+    run()
