@@ -302,6 +302,8 @@ void rnamsm_timing_reset(void);
  *                 measured: no effect).  Speed only, results bit-identical.
  *   "gemm16_mfma16"  plain-bf16 256x256 GEMM: 1 (default) = the 16x16x32-MFMA kernel for N > 1024, 2 = for every N,
  *                 0 = the 32x32x16 kernel.  Results agree to fp32 rounding (the k order inside a step differs).
+ *   "row16_max_rows"  hi/lo modes of rnamsm_row_logits16: cap on the rows of one partial slab (default 32, 0 = none).
+ *                 Shorter fp32 accumulation chains; changes results at the rounding level (and the slab count).
  *   "col_dma"     fp32 rnamsm_col_attn_fused: 1 = K/V chunks staged by LDS-DMA, 32-key chunks, three blocks per CU;
  *                 0 = register-staged 64-key chunks, two blocks per CU; -1 (default) = chosen from the shape.  Speed only
  *                 (the two kernels run the same arithmetic per 32-key tile; results agree to fp32 rounding).

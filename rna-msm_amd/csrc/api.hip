@@ -148,6 +148,11 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm16_stagger = value;
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "row16_max_rows")) {
+        if (value < 0 || value > 1024) return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: row16_max_rows must be in [0, 1024]");
+        rnamsm::tuning().row16_max_rows = value;
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "col_dma")) {
         rnamsm::tuning().col_dma = value < 0 ? -1 : (value != 0);
         return RNAMSM_OK;
@@ -158,6 +163,7 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "gemm16_dma")) return rnamsm::tuning().gemm16_dma;
     if (name && !strcmp(name, "attn16")) return rnamsm::tuning().attn16;
     if (name && !strcmp(name, "col_dma")) return rnamsm::tuning().col_dma;
+    if (name && !strcmp(name, "row16_max_rows")) return rnamsm::tuning().row16_max_rows;
     if (name && !strcmp(name, "gemm16_persist")) return rnamsm::tuning().gemm16_persist;
     if (name && !strcmp(name, "gemm16_mfma16")) return rnamsm::tuning().gemm16_mfma16;
     if (name && !strcmp(name, "gemm16_stagger")) return rnamsm::tuning().gemm16_stagger;

@@ -565,17 +565,27 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 // cfg3 in one process, split 3 0.40 -> 0.34 ms, but plain bf16 0.166 -> 0.185 ms (its 128x128 kernel already runs
 // 64-deep tiles of whole cache lines with two blocks per CU), so split 1 stays on 128x128.  "attn16" = 2 forces 128x128.
 static inline bool row_logits16_big(int C, bool split3) { return split3 && C >= 256 && tuning().attn16 != 2; }
+// row split of the 16-bit logits kernels; the hi/lo modes cap a slab's rows ("row16_max_rows", see row_split.h and DESIGN 3.2)
+static inline RowSplit row_split16(int R, int C, int H, bool big, bool split3) {
+    const int cap = split3 ? tuning().row16_max_rows : 0;
+    return big ? choose_row_split(R, C, H, 256, 256, cap) : choose_row_split(R, C, H, 128, 512, cap);
+}
 
 extern "C" int rnamsm_row_logits16_nsplit(int R, int C, int H, int split) {
     if (R <= 0 || C <= 0 || H <= 0) return 0;
-    return (row_logits16_big(C, split == 3) ? choose_row_split(R, C, H, 256, 256) : choose_row_split(R, C, H)).nsplit;
+    return row_split16(R, C, H, row_logits16_big(C, split == 3), split == 3).nsplit;
 }
 
 extern "C" size_t rnamsm_row_logits16_workspace_bytes(int R, int C, int H) {
     if (R <= 0 || C <= 0 || H <= 0) return 0;
     // the larger of the two tilings, so a workspace stays valid when the "attn16" knob flips
-    const int a = choose_row_split(R, C, H, 256, 256).nsplit, b = choose_row_split(R, C, H).nsplit;
-    return (size_t)(a > b ? a : b) * H * C * C * sizeof(float);
+    int n = 1;
+    for (int big = 0; big < 2; ++big)
+        for (int s3 = 0; s3 < 2; ++s3) {
+            const int v = row_split16(R, C, H, big != 0, s3 != 0).nsplit;
+            n = v > n ? v : n;
+        }
+    return (size_t)n * H * C * C * sizeof(float);
 }
 
 extern "C" int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
@@ -590,7 +600,7 @@ extern "C" int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, c
                      "row_logits16: planes must be 16-byte aligned with ld %% 8 == 0");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool big = row_logits16_big(C, q_lo != nullptr);
-    const RowSplit sp = big ? choose_row_split(R, C, H, 256, 256) : choose_row_split(R, C, H);
+    const RowSplit sp = row_split16(R, C, H, big, q_lo != nullptr);
     const unsigned tiles_c = big ? (C + 255) / 256 : (C + 127) / 128;
     const unsigned grid = xcd_panel_grid((unsigned)(H * sp.nsplit), tiles_c * tiles_c);
     KernelTimer timer(TC_ROW_LOGITS, 2.0 * H * C * C * R * 64,
