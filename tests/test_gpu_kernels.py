@@ -556,3 +556,34 @@ def test_integration_md_ctypes_stub_runs_and_matches_the_mirror_module(dev):
     want, want_p = m(x)
     got, got_p = ns["row_self_attention_forward"](m, x)
     assert torch.equal(got, want) and torch.equal(got_p, want_p)
+
+
+def test_generic_mha_edge_shapes_against_oracle(dev):
+    """Edge shapes of the MHA entry point in every route (fused, weights, masked; fp32 and f16x3): a single position (T = 1:
+    the softmax over one key is 1, weights are all ones), a single batch element, T crossing the 128-row tile edge."""
+    from rnamsm import modules as M
+    for T, B, E, H in ((1, 3, 128, 2), (2, 1, 128, 2), (130, 2, 128, 2)):
+        state = synthetic.make_state_dict(seed=5, embed_dim=E, num_layers=1, num_heads=H)
+        prefix = "layers.0.row_self_attention.layer"
+        mha = M.MultiheadAttention(E, H, self_attention=True)
+        mha.load_state_dict({k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in state.items() if k.startswith(prefix + ".")},
+                            strict=True)
+        mha = mha.eval().to(dev)
+        x = torch.from_numpy(synthetic.normal(f"mhae:{T}", 5, (T, B, E)).astype(np.float32))
+        kpm = torch.zeros(B, T, dtype=torch.bool)
+        if T > 2:
+            kpm[0, T - 3:] = True
+        st = O.to_torch_params(state, torch.float64)
+        want, wts = O.multihead_self_attention(x.double(), st, prefix, H, key_padding_mask=kpm if T > 2 else None,
+                                               return_weights=True)
+        for mode, tol in (("f32", 5e-6), ("f16x3", 2e-5)):
+            mha.gemm_dtype = mode
+            kw = dict(key_padding_mask=kpm.to(dev)) if T > 2 else {}
+            y, w = mha(x.to(dev), **kw)                                   # default: head-averaged weights
+            assert rel_l2(y.cpu(), want) < tol and np.abs(w.cpu().numpy() - wts.mean(0).numpy()).max() < 5 * tol, (T, mode)
+            y2, w2 = mha(x.to(dev), need_weights=False, **kw)             # fused kernel
+            assert w2 is None and rel_l2(y2.cpu(), want) < tol, (T, mode)
+            y3, w3 = mha(x.to(dev), need_head_weights=True, **kw)
+            assert w3.shape == (H, B, T, T) and np.abs(w3.cpu().numpy() - wts.numpy()).max() < 5 * tol, (T, mode)
+            if T == 1:
+                assert float((w3 - 1).abs().max()) == 0.0
