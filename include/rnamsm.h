@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RNAMSM_VERSION 200 /* major*10000 + minor*100 + patch */
+#define RNAMSM_VERSION 201 /* major*10000 + minor*100 + patch */
 
 typedef enum {
     RNAMSM_OK = 0,
@@ -156,6 +156,13 @@ int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_
                           const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt,
                           int dtype, void* stream);
 
+/* K7 restricted to the query rows [0, q_rows) of every column (keys / values: all R rows): what the LAST layer needs when
+ * only alignment row 0 of the final representation is wanted (rnamsm_forward without RNAMSM_OUT_REPR).  Row i of ctx is
+ * written for i < q_rows only and equals rnamsm_col_attn_fused's row i bit for bit. */
+int rnamsm_col_attn_fused_queries(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc,
+                                  int R, int C, int H, int head_dim, int q_rows, const uint8_t* pad_mask, int dtype,
+                                  void* stream);
+
 /* K4' / K5' / K6' / K7' -- the attention contractions of the 16-bit modes (same reference lines as K4..K7).  Operands
  * are 16-bit planes in HBM, addressed like their fp32 counterparts (element (r,c,h,d) = plane[(r*C+c)*ld + h*64 + d],
  * ld in halves): q/k/v as written by rnamsm_gemm_bf16's plane epilogue (O_hi/O_lo over the fused [T,3D] QKV output),
@@ -268,10 +275,18 @@ size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int 
  * from rnamsm_split_bf16, in the order {row_wqkv, row_wo, col_wqkv, col_wo, fc1_w, fc2_w} x {hi, lo} (lo may be
  * NULL for RNAMSM_BF16). */
 #define RNAMSM_PLANES_PER_LAYER 12
+/* outputs: RNAMSM_OUT_REPR = the whole final representation repr [R*C, D] is wanted (MSATransformer.forward's
+ * representations[num_layers]).  Without it only what extract_feat writes is produced -- emb (alignment row 0) and atp
+ * (RNA_MSM_Inference.py:151-166) -- and the last layer stops computing the other rows once its tied row attention is done:
+ * K and V of the last column attention still cover every row, but its queries, out_proj, the last FFN and the final
+ * LayerNorm run on row 0's C tokens only (~5 % of the forward at M=256 L=512).  emb and atp are bit-identical either
+ * way; repr then holds valid data in its first C rows only.  (Exact path without padding; otherwise the flag is ignored
+ * and everything is computed.) */
+#define RNAMSM_OUT_REPR 1
 int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
                    int R, int C, void* workspace, size_t workspace_bytes,
                    float* row_attn, float* repr, float* emb, float* atp,
-                   int* err_flag, int has_padding, int max_tokens_per_msa, int dtype,
+                   int* err_flag, int has_padding, int max_tokens_per_msa, int outputs, int dtype,
                    const uint16_t* const* weight_planes, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's

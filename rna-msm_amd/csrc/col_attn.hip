@@ -36,12 +36,12 @@ template <bool MASKED, int OUT>
 __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask,
-    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo) {
+    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                    // [2][CA_JC][CA_LDD]
     float* Vs = smem + 2 * CA_TILE;      // [2][CA_JC][CA_LDD]
 
-    const unsigned iblocks = (R + CA_ROWS - 1) / CA_ROWS;
+    const unsigned iblocks = (q_rows + CA_ROWS - 1) / CA_ROWS;       // query rows [0, q_rows) only (q_rows == R: all)
     unsigned prob, ib;
     if (!xcd_panel_map(blockIdx.x, (unsigned)C * H, iblocks, prob, ib)) return;
     const int c = prob / H, h = prob % H;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int irow0 = ib * CA_ROWS + wave * 32;              // first query row of this wave
-    const bool active = irow0 < R;                           // wave-uniform
+    const bool active = irow0 < q_rows;                      // wave-uniform
     const int64_t col_off = (int64_t)c * ld + h * CA_HD;     // + r*C*ld selects the alignment row
 
     // Q fragment: lane (i, half) holds q[i][8kk + 4*half + s], kk = 0..7, s = 0..3 (B operand of S^T = K Q^T)
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.f / l_tot;
         const int i = irow0 + li;
-        if (i < R) {
+        if (i < q_rows) {
             const int64_t ooff = ((int64_t)i * C + c) * ldc + h * CA_HD + 4 * lh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {      // registers 4g..4g+3 are head dims 8g + 4*half + {0..3}
@@ -259,10 +259,10 @@ template <bool MASKED, int OUT>
 __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask,
-    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo) {
+    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
 
-    const unsigned iblocks = (R + CA_ROWS - 1) / CA_ROWS;
+    const unsigned iblocks = (q_rows + CA_ROWS - 1) / CA_ROWS;       // query rows [0, q_rows) only (q_rows == R: all)
     unsigned prob, ib;
     if (!xcd_panel_map(blockIdx.x, (unsigned)C * H, iblocks, prob, ib)) return;
     const int c = prob / H, h = prob % H;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int irow0 = ib * CA_ROWS + wave * 32;
-    const bool active = irow0 < R;                           // wave-uniform
+    const bool active = irow0 < q_rows;                      // wave-uniform
     const int64_t col_off = (int64_t)c * ld + h * CA_HD;
 
     f32x4 qf[8];
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         const float inv = 1.f / l_tot;
         const int i = irow0 + li;
-        if (i < R) {
+        if (i < q_rows) {
             const int64_t ooff = ((int64_t)i * C + c) * ldc + h * CA_HD + 4 * lh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -471,9 +471,26 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
 
 using namespace rnamsm;
 
+static int col_attn_launch(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,
+                           int H, int head_dim, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt,
+                           int dtype, void* stream, int q_rows);
+
 extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_t ld, float* ctx,
                                      int64_t ldc, int R, int C, int H, int head_dim, const uint8_t* pad_mask,
                                      uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt, int dtype, void* stream) {
+    return col_attn_launch(q, k, v, ld, ctx, ldc, R, C, H, head_dim, pad_mask, ctx_hi, ctx_lo, plane_fmt, dtype, stream, R);
+}
+
+extern "C" int rnamsm_col_attn_fused_queries(const float* q, const float* k, const float* v, int64_t ld, float* ctx,
+                                             int64_t ldc, int R, int C, int H, int head_dim, int q_rows,
+                                             const uint8_t* pad_mask, int dtype, void* stream) {
+    RNAMSM_CHECK_ARG(q_rows >= 1 && q_rows <= R, "col_attn_queries: q_rows must be in [1, R] (got %d, R=%d)", q_rows, R);
+    return col_attn_launch(q, k, v, ld, ctx, ldc, R, C, H, head_dim, pad_mask, nullptr, nullptr, 0, dtype, stream, q_rows);
+}
+
+static int col_attn_launch(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,
+                           int H, int head_dim, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt,
+                           int dtype, void* stream, int q_rows) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "col_attn: only RNAMSM_F32 is implemented");
     RNAMSM_CHECK_ARG(q && k && v && (ctx || ctx_hi), "col_attn: null pointer");
     RNAMSM_CHECK_ARG(head_dim == CA_HD, "col_attn: head_dim must be 64 (got %d)", head_dim);
@@ -484,9 +501,9 @@ extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float
     RNAMSM_CHECK_ARG(ctx_hi ? (!pad_mask && (reinterpret_cast<uintptr_t>(ctx_hi) & 7u) == 0 && (plane_fmt == 0 || plane_fmt == 1))
                             : aligned16(ctx), "col_attn: output alignment / plane format (plane output has no masked variant)");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const unsigned iblocks = (R + CA_ROWS - 1) / CA_ROWS;
+    const unsigned iblocks = (q_rows + CA_ROWS - 1) / CA_ROWS;
     const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
-    KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)R * R * CA_HD, 4.0 * 4.0 * R * C * H * CA_HD, s);
+    KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)q_rows * R * CA_HD, 4.0 * (2.0 * R + 2.0 * q_rows) * C * H * CA_HD, s);
 #define CA_GO2(KERN_, LDS_, M_, OUT_)                                                                               \
     do {                                                                                                            \
         static DeviceOnce cfg_;                                                                                     \
@@ -497,7 +514,7 @@ extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float
             cfg_.mark();                                                                                            \
         }                                                                                                           \
         hipLaunchKernelGGL((KERN_<M_, OUT_>), dim3(grid), dim3(CA_THREADS), LDS_, s, q, k, v, ld, ctx, ldc, R, C, H, \
-                           pad_mask, ctx_hi, ctx_lo);                                                               \
+                           pad_mask, ctx_hi, ctx_lo, q_rows);                                                       \
     } while (0)
     // "col_dma": 1 = the LDS-DMA, three-blocks-per-CU variant, 0 = the register-staged kernel, -1 (default) = the former.
     // Measured in one process (tools/col_attn_ab.py, after the key-range masking was confined to the ragged last tile):

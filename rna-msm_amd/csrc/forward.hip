@@ -56,8 +56,8 @@ extern "C" size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, 
 
 extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
                               int R, int C, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
-                              float* emb, float* atp, int* err_flag, int has_padding, int max_tokens_per_msa, int dtype,
-                              const uint16_t* const* weight_planes, void* stream) {
+                              float* emb, float* atp, int* err_flag, int has_padding, int max_tokens_per_msa, int outputs,
+                              int dtype, const uint16_t* const* weight_planes, void* stream) {
     RNAMSM_CHECK_ARG(dtype >= RNAMSM_F32 && dtype <= RNAMSM_F16X3, "forward: unknown dtype %d", dtype);
     RNAMSM_CHECK_ARG(dtype == RNAMSM_F32 || weight_planes, "forward: bf16 modes need weight_planes");
     RNAMSM_CHECK_ARG(dims && weights && tokens && workspace && row_attn && repr && emb && atp, "forward: null pointer");
@@ -182,6 +182,30 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             FWD(linear_pl(l, 1, ctx_hi, ctx_lo, D, W[RNAMSM_WL_ROW_BO], x, D, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE, 1.f, 0));
         else
             FWD(linear(l, 1, ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
+        if (l == NL - 1 && !(outputs & RNAMSM_OUT_REPR) && dtype == RNAMSM_F32 && !has_padding && R > 1) {
+            // Only emb (alignment row 0 of the final representation) and the maps are wanted, and the maps are complete:
+            // from here on every row but row 0 is dead.  The last column attention still needs K and V of all rows
+            // (LayerNorm + the k|v two thirds of the QKV GEMM over all T tokens), but its queries, its out_proj, the FFN
+            // and the final LayerNorm run on row 0's C tokens (the first C rows of every [T, .] buffer).  Same kernels,
+            // same per-element arithmetic: emb is bit-identical to the full forward's.
+            const int64_t Tq = C;
+            FWD(rnamsm_layernorm(x, W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B], xn, T, D, d.ln_eps, stream));
+            FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_COL_WQKV] + (size_t)D * D, W[RNAMSM_WL_COL_BQKV] + D, nullptr, 0,
+                                         qkv + D, ldq, T, 2 * D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream));     // k | v
+            FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, Tq, D, D,
+                                         RNAMSM_ACT_NONE, col_scale, D, nullptr, f32, stream));                          // q, row 0
+            FWD(rnamsm_col_attn_fused_queries(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, 1, nullptr, f32, stream));
+            FWD(rnamsm_gemm_bias_act_res(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], x, D, x, D, Tq, D, D,
+                                         RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream));
+            FWD(rnamsm_layernorm(x, W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B], xn, Tq, D, d.ln_eps, stream));
+            FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], nullptr, 0, hidden, F, Tq, F, D,
+                                         RNAMSM_ACT_GELU_ERF, 1.f, 0, nullptr, f32, stream));
+            FWD(rnamsm_gemm_bias_act_res(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], x, D, x, D, Tq, D, F,
+                                         RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream));
+            FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, Tq, D, d.ln_eps, stream));
+            FWD(rnamsm_pack_outputs(repr, row_attn, emb, atp, C, D, NL, H, stream));
+            return RNAMSM_OK;
+        }
         // ---- column attention block
         FWD(ln_for_gemm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
         if (attn16) {

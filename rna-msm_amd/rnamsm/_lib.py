@@ -18,6 +18,7 @@ RNAMSM_OK = 0
 F32, BF16, BF16X3, F16X3 = 0, 1, 2, 3
 DTYPES = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3, "f16x3": F16X3}
 ACT_NONE, ACT_GELU_ERF = 0, 1
+OUT_REPR = 1
 
 # index tables of rnamsm_forward's weight-pointer array (include/rnamsm.h)
 W_GLOBAL = ("embed_tokens", "embed_positions", "row_pos", "ln_before_g", "ln_before_b", "ln_after_g", "ln_after_b")
@@ -79,8 +80,10 @@ _SIGNATURES = {
     "rnamsm_msa_weights": (c_int, [c_void_p, c_int, c_int, c_double, c_void_p, c_void_p]),
     "rnamsm_forward_workspace_bytes": (c_size_t, [POINTER(ModelDims), c_int, c_int, c_int, c_int]),
     "rnamsm_forward": (c_int, [POINTER(ModelDims), POINTER(c_void_p), c_void_p, c_int, c_int, c_void_p, c_size_t,
-                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_void_p),
-                               c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                               POINTER(c_void_p), c_void_p]),
+    "rnamsm_col_attn_fused_queries": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
+                                              c_int, c_int, c_void_p, c_int, c_void_p]),
     "rnamsm_timing_enable": (c_int, [c_int]),
     "rnamsm_timing_collect": (c_int, []),
     "rnamsm_timing_get": (c_int, [c_int, POINTER(c_char_p), POINTER(ctypes.c_longlong), POINTER(ctypes.c_double),

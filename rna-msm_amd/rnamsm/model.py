@@ -198,9 +198,12 @@ class MSATransformer(nn.Module):
         return out[:, :V].contiguous().view(*features.shape[:-1], V)
 
     # ------------------------------------------------------------------ forward
-    def forward_one(self, tokens2d: torch.Tensor, has_padding: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+    def forward_one(self, tokens2d: torch.Tensor, has_padding: Optional[bool] = None,
+                    need_repr: bool = True) -> Dict[str, torch.Tensor]:
         """One MSA through the C++ driver (rnamsm_forward): tokens int64 [R, C] on the HIP device ->
-        {"row_attn" [NL,H,C,C], "repr" [R,C,D], "emb" [C-1,D], "atp" [NL*H,C-1,C-1]}."""
+        {"row_attn" [NL,H,C,C], "repr" [R,C,D], "emb" [C-1,D], "atp" [NL*H,C-1,C-1]}.
+        need_repr=False: only what the CLI writes (emb, atp; bit-identical) -- the last layer then skips the rows the
+        outputs do not depend on and "repr" holds alignment row 0 only ([1, C, D])."""
         if self.training:
             raise NotImplementedError("rnamsm implements the inference path only: call .eval()")
         if not tokens2d.is_cuda:
@@ -216,9 +219,10 @@ class MSATransformer(nn.Module):
         # the library launches on the calling thread's current device / stream: enter the operands' device (a worker
         # thread, or a model on cuda:1, would otherwise launch on device 0 against pointers of another GPU)
         with torch.cuda.device(dev):
-            return self._forward_one_on_device(tokens2d, has_padding)
+            return self._forward_one_on_device(tokens2d, has_padding, need_repr)
 
-    def _forward_one_on_device(self, tokens2d: torch.Tensor, has_padding: Optional[bool]) -> Dict[str, torch.Tensor]:
+    def _forward_one_on_device(self, tokens2d: torch.Tensor, has_padding: Optional[bool],
+                               need_repr: bool = True) -> Dict[str, torch.Tensor]:
         R, C = tokens2d.shape
         lib = _lib.load()
         dims, ptrs, _ = self._packed_weights()
@@ -240,7 +244,7 @@ class MSATransformer(nn.Module):
         planes = self._weight_planes() if dtype != _lib.F32 else None
         _lib.check(lib.rnamsm_forward(ctypes.byref(dims), ptrs, toks.data_ptr(), R, C, ws.data_ptr(), ws.numel(),
                                       row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
-                                      err.data_ptr(), int(has_padding), max_tokens, dtype, planes,
+                                      err.data_ptr(), int(has_padding), max_tokens, _lib.OUT_REPR if need_repr else 0, dtype, planes,
                                       torch.cuda.current_stream().cuda_stream))
         if dtype != _lib.F32 and self.check_finite:
             # f16x3 / bf16 operands live in 16-bit planes: fp16 overflows above 65504 (-> inf/NaN downstream).  The
@@ -252,10 +256,11 @@ class MSATransformer(nn.Module):
                               "range); this MSA is recomputed on the exact fp32 path")
                 mode, self.gemm_dtype = self.gemm_dtype, "f32"
                 try:
-                    return self._forward_one_on_device(tokens2d, has_padding)
+                    return self._forward_one_on_device(tokens2d, has_padding, need_repr)
                 finally:
                     self.gemm_dtype = mode
-        return {"row_attn": row_attn, "repr": rep, "emb": emb, "atp": atp, "err": err}
+        pruned = not need_repr and dtype == _lib.F32 and not has_padding and R > 1       # rnamsm_forward's condition
+        return {"row_attn": row_attn, "repr": rep[:1] if pruned else rep, "emb": emb, "atp": atp, "err": err}
 
     def _forward_layerwise(self, tokens2d: torch.Tensor, repr_layers: Iterable[int], has_padding: bool = False):
         """Module-by-module path (same HIP kernels, launched from Python) used when intermediate

@@ -85,6 +85,8 @@ int main(void) {
     REFUSED(rnamsm_col_attn_fused(buf, buf, buf, 64, buf, 64, 4, 4, 1, 32, NULL, NULL, NULL, 0, 0, NULL));
     REFUSED(rnamsm_col_attn_fused(NULL, buf, buf, 2304, buf, 768, 4, 4, 12, 64, NULL, NULL, NULL, 0, 0, NULL));
     REFUSED(rnamsm_col_attn_fused(buf, buf, buf, 2304, buf, 768, 5000, 4, 12, 64, NULL, NULL, NULL, 0, 0, NULL));
+    REFUSED(rnamsm_col_attn_fused_queries(buf, buf, buf, 2304, buf, 768, 4, 4, 12, 64, 0, NULL, 0, NULL));
+    REFUSED(rnamsm_col_attn_fused_queries(buf, buf, buf, 2304, buf, 768, 4, 4, 12, 64, 5, NULL, 0, NULL));
     REFUSED(rnamsm_row_logits16(NULL, NULL, halves, NULL, 2304, buf, 4, 4, 12, 64, 1.f, 0, NULL));
     REFUSED(rnamsm_row_apply16(NULL, NULL, 64, halves, NULL, 2304, buf, 768, 4, 4, 12, 64, 1.f, NULL, NULL, 0, NULL));
     REFUSED(rnamsm_col_attn16(NULL, NULL, halves, NULL, halves, NULL, 2304, buf, 768, 4, 4, 12, 64, 1.f, NULL, NULL, NULL, 0, NULL));
@@ -102,19 +104,19 @@ int main(void) {
     REFUSED(rnamsm_greedy_select(bytes, 8, 70000, 4, 0, ints, buf, 1 << 16, NULL));
     REFUSED(rnamsm_msa_weights(NULL, 8, 8, 0.2, (double*)buf, NULL));
     REFUSED(rnamsm_msa_weights(bytes, 0, 8, 0.2, (double*)buf, NULL));
-    REFUSED(rnamsm_forward(NULL, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 0, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 9, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 3, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 1025, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 0, NULL, NULL));
+    REFUSED(rnamsm_forward(NULL, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 9, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 3, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 1025, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL));
     EXPECT(strstr(rnamsm_last_error(), "maximum MSA depth of 1024") != NULL);             /* model.py:355-359 */
-    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 1, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 0, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4000, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 0, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 64, 128, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 0, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 1, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4000, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 64, 128, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL));
     EXPECT(strstr(rnamsm_last_error(), "workspace too small") != NULL);
     {
         rnamsm_model_dims bad = dims;
         bad.embed_dim = 700;
-        REFUSED(rnamsm_forward(&bad, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 0, NULL, NULL));
+        REFUSED(rnamsm_forward(&bad, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL));
     }
 
     /* parameter parsing and timing bookkeeping */

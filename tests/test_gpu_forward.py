@@ -417,3 +417,26 @@ def test_module_path_runs_the_16bit_modes_like_the_driver(model, mode):
     assert m.layers[0].feed_forward_layer.layer.gemm_dtype == "f32"
     with pytest.raises(ValueError):
         m.gemm_dtype = "fp8"
+
+
+@pytest.mark.parametrize("R,C", [(8, 17), (64, 128), (33, 131), (256, 512), (2, 5)])
+def test_outputs_only_forward_is_bit_identical_and_skips_dead_rows(model, R, C):
+    """rnamsm_forward without RNAMSM_OUT_REPR (what the CLI asks for): after the last tied row attention only alignment
+    row 0 of the final representation is alive, so the last column attention's queries / out_proj, the last FFN and the
+    final LayerNorm run on row 0's C tokens only (K and V still cover every row).  emb and atp must be BIT-IDENTICAL to the
+    full forward's; the full representation is simply not produced."""
+    m, _ = model
+    toks = torch.from_numpy(synthetic.make_tokens(R, C, 11)).to("cuda:0")
+    full = m.forward_one(toks, has_padding=False)
+    lean = m.forward_one(toks, has_padding=False, need_repr=False)
+    assert torch.equal(lean["emb"], full["emb"]) and torch.equal(lean["atp"], full["atp"])
+    assert torch.equal(lean["row_attn"], full["row_attn"])
+    assert lean["repr"].shape == (1, C, 768) and torch.equal(lean["repr"][0], full["repr"][0])
+    # padded MSAs and the 16-bit modes ignore the flag (everything is computed): still the same outputs
+    try:
+        m.gemm_dtype = "f16x3"
+        a = m.forward_one(toks, has_padding=False)
+        b = m.forward_one(toks, has_padding=False, need_repr=False)
+        assert torch.equal(a["emb"], b["emb"]) and b["repr"].shape == (R, C, 768)
+    finally:
+        m.gemm_dtype = "f32"
