@@ -54,7 +54,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-gather", action="store_true", help="skip the output gather to rank 0 (N > 1)")
     ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "f16x3", "bf16x3", "bf16"],
                     help="arithmetic of the contractions for the headline value (default: exact fp32)")
-    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16x3 / bf16 measurements")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16x3 / bf16 / outputs-only measurements")
+    ap.add_argument("--outputs-only", action="store_true",
+                    help="headline on the outputs-only forward (rnamsm_forward without RNAMSM_OUT_REPR: what the CLI runs; the "
+                         "last layer skips the rows emb/atp do not depend on).  Default: the complete forward.")
     ap.add_argument("--digest", action="store_true",
                     help="report an order-independent bit digest of every gathered output (N=1 and N=2 must agree)")
     ap.add_argument("--backend", default=os.environ.get("RNAMSM_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
@@ -320,7 +323,7 @@ def run_rank(args) -> int:
             for pos, msa in items:
                 if sharding.owner_of(base + pos, world) != rank:
                     continue
-                out = model.forward_one(toks[msa], has_padding=False)
+                out = model.forward_one(toks[msa], has_padding=False, need_repr=not args.outputs_only)
                 if g is not None:
                     g.submit(base + pos, (out["emb"], out["atp"]))
             base += len(items)
@@ -373,7 +376,7 @@ def run_rank(args) -> int:
                             if sharding.owner_of(pos, world) == rank))
 
     # ---- extra modes (N = 1, default workload): every contraction on the 16-bit matrix cores
-    fast = bf16_mode = None
+    fast = bf16_mode = outputs_only = None
     first = toks[mine_all[0]]
     if args.gemm_dtype == "f32" and not args.no_fast_mode and world == 1 and not batch:
         ref = model.forward_one(first)
@@ -420,6 +423,23 @@ def run_rank(args) -> int:
                     "attention": "16-bit kernels (row_logits16 / row_apply16 / col_attn16, same operand format)",
                     "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in tim2.items()}}
 
+        # the CLI's forward: only emb + atp are wanted, so the last layer skips the rows they do not depend on (bit-identical
+        # outputs, checked here); never the headline unless --outputs-only is given
+        lean = model.forward_one(first, has_padding=False, need_repr=False)
+        lean_same = bool(torch.equal(lean["emb"], ref_emb) and torch.equal(lean["atp"], ref_atp))
+        for i in mine_all[:args.warmup]:
+            model.forward_one(toks[i], has_padding=False, need_repr=False)
+        sync_all()
+        t3 = time.perf_counter()
+        for i in mine_all[args.warmup:]:
+            model.forward_one(toks[i], has_padding=False, need_repr=False)
+        sync_all()
+        el3 = time.perf_counter() - t3
+        outputs_only = {"value": args.steps * M * L / el3, "unit": "MSA-residues/s", "ms_per_step": 1e3 * el3 / args.steps,
+                        "emb_and_atp_bit_identical_to_the_complete_forward": lean_same,
+                        "what": "rnamsm_forward without RNAMSM_OUT_REPR (the CLI's call): after the last tied row attention only "
+                                "alignment row 0 feeds emb, so the last column attention's queries/out_proj, the last FFN and the "
+                                "final LayerNorm run on row 0's tokens only; K/V of that attention still cover every row"}
         fast = measure_mode("f16x3", 3.0)
         fast["f32_path_reordering_noise"] = {"emb_rel_l2": noise_emb, "atp_max_abs": noise_atp,
                                              "what": "exact path vs itself with alignment rows 1.. permuted"}
@@ -495,7 +515,10 @@ def run_rank(args) -> int:
         if args.digest:
             result["output_digest"] = {"value": headline_digest, "items": headline_delivered,
                                        "what": "sum over gathered outputs of (global item index + 1) * sum(int32 bit patterns), mod 2^64"}
+        if args.outputs_only:
+            result["config"]["workload"] += " -- OUTPUTS-ONLY forward (--outputs-only): the last layer computes alignment row 0 only"
         if fast is not None:
+            result["outputs_only_mode"] = outputs_only
             result["fast_mode"] = fast
             result["bf16_mode"] = bf16_mode
         if not args.no_cpu_baseline and world == 1:
