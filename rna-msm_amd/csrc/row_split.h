@@ -15,7 +15,7 @@ struct RowSplit {
 // max_rows (0 = no limit): upper bound on the rows of one split, i.e. on the length max_rows * 64 of an fp32 accumulation
 // chain.  The exact-fp32 MFMA adds its products one after the other (an fmaf chain), so a slab of r rows is a chain of
 // 64 r terms and its rounding error grows with r, while the slabs themselves are added pairwise-like by K5.  Measured
-// against an fp64 truth at M=256 x L=512 (tools/error_sources.py): chains of 4096 / 2048 / 1024 / 512 / 256 terms leave
+// against an fp64 truth at M=256 x L=512 (tests/analysis/error_sources.py): chains of 4096 / 2048 / 1024 / 512 / 256 terms leave
 // the 10-layer embedding 1.26e-4 / 7.1e-5 / 4.1e-5 / 3.2e-5 / 3.1e-5 from the truth -- the reference's own CPU arithmetic
 // (blocked sgemm) sits at 3.2e-5.  The fp32 kernel therefore caps a split at 8 rows (512 terms).
 inline RowSplit choose_row_split(int R, int C, int H, int tile = 128, int slots = 512, int max_rows = 0) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """f16x3: distance from the fp64 truth as a function of the row_logits16 slab cap (knob row16_max_rows)."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (os.path.join(ROOT, "rna-msm_amd"), ROOT, os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch

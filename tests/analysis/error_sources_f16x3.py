@@ -2,7 +2,7 @@
 """Which part of the f16x3 mode sets its distance from the fp64 truth?  Layer-wise path with f16x3 switched on for one
 module class at a time (the others exact fp32)."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (os.path.join(ROOT, "rna-msm_amd"), ROOT, os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch

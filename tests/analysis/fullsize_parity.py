@@ -4,7 +4,7 @@ host cores (all ten layers, ~6 min of CPU time, ~20 GB of RAM), for the exact pa
 path's own re-ordering noise.  Prints one JSON line.  The oracle is fp32 on the CPU, i.e. a different summation order of
 the same arithmetic: at this depth the synthetic problem amplifies that alone to ~1e-4 / ~1e-3."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from rnamsm import synthetic

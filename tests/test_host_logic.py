@@ -257,6 +257,12 @@ def test_no_cpu_fallback_exists():
                 assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("SURVEY", ""), os.path.join(dirpath, f)
     for f in ("RNA_MSM_Inference.py",):
         assert "oracle" not in open(os.path.join(ROOT, f)).read()
+    # ... and neither does any helper under tools/ (diagnostics that need the oracle live in tests/analysis/)
+    for f in sorted(os.listdir(os.path.join(ROOT, "tools"))):
+        path = os.path.join(ROOT, "tools", f)
+        if os.path.isfile(path):
+            text = open(path).read()
+            assert "import oracle" not in text and "from oracle" not in text and "import truth" not in text, path
 
 
 def test_mask_and_repeat_matches_reference_semantics():
