@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RNAMSM_VERSION 201 /* major*10000 + minor*100 + patch */
+#define RNAMSM_VERSION 202 /* major*10000 + minor*100 + patch */
 
 typedef enum {
     RNAMSM_OK = 0,
@@ -69,6 +69,36 @@ int rnamsm_embed_ln(const int64_t* tokens, const float* embed_tokens, const floa
  * biased variance.  x, y [T, D] contiguous (y may alias x). */
 int rnamsm_layernorm(const float* x, const float* gamma, const float* beta, float* y,
                      int64_t T, int D, float eps, void* stream);
+
+/* K1 folded into the Linear that consumes it (NormalizedResidualBlock, modules.py:385-401: layer(LayerNorm(x)) with
+ * layer's first op a Linear -- q/k/v projections modules.py:760-766, 794, 896-905; fc1 modules.py:424):
+ *   LN(x) W^T + b  =  rstd[m] * ( sum_k x[m,k] Wg[n,k]  -  mean[m] * c[n] ) + d[n]
+ *   Wg = W * gamma (per input feature k),  c[n] = sum_k Wg[n,k],  d[n] = b[n] + sum_k W[n,k] * beta[k]
+ * so the GEMM reads the residual stream itself: no normalised copy of it is written or re-read (806 MB per LayerNorm at
+ * M=256 L=512) and LayerNorm is no launch at all.  The statistics come from whoever wrote x: `row_partials`
+ * [M, K/32, 2] holds (sum x, sum x^2) of every row per 32-feature slab; mean = sum / K, biased variance =
+ * E[x^2] - mean^2 in fp32 (meant for rows whose |mean| is not much larger than their spread, like a residual stream).
+ * Results agree with LayerNorm -> Linear to fp32 rounding (different association; against an fp64 truth the two are
+ * equally far from it: tests/analysis/ln_fold_numerics.py, tests/test_gpu_fullsize.py).
+ *   rnamsm_ln_fold_weights     one-time preparation: Wg [N,K], c [N], d [N] from W [N,K], bias [N] (or NULL), gamma, beta [K]
+ *                              (c and d are accumulated in double; c sums the ROUNDED Wg the GEMM will multiply)
+ *   rnamsm_row_partials        row_partials of x [T, D] as it lies in memory (D % 32 == 0, D <= 1024): for an x that did
+ *                              not come out of rnamsm_gemm_residual_stats (the embedding)
+ *   rnamsm_gemm_residual_stats Cout = A W^T + bias + residual (K8: out_proj / fc2 + the residual add, modules.py:396) and
+ *                              row_partials [M, N/32, 2] of the Cout it stores; requirements of rnamsm_gemm_bias_act_res
+ *   rnamsm_gemm_lnfold         Cout[m,n] = act( (rstd[m] * (sum_k X[m,k] Wg[n,k] - mean[m] c[n]) + d[n]) * (n < scale_cols ? scale : 1) )
+ *                              X [M,K] row stride ldx; row_partials [M, K/32, 2] (K % 64 == 0) or NULL = the block sums the
+ *                              rows it stages itself (self-contained, ~2.6 % slower); eps = ln_eps; requirements of
+ *                              rnamsm_gemm_bias_act_res, scale_cols % 4 == 0 */
+int rnamsm_ln_fold_weights(const float* W, const float* bias, const float* gamma, const float* beta, float* Wg,
+                           float* cvec, float* dvec, int N, int K, void* stream);
+int rnamsm_row_partials(const float* x, float* row_partials, int64_t T, int D, void* stream);
+int rnamsm_gemm_residual_stats(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
+                               int64_t ldr, float* Cout, int64_t ldc, int64_t M, int N, int K, float* row_partials,
+                               int dtype, void* stream);
+int rnamsm_gemm_lnfold(const float* X, int64_t ldx, const float* Wg, const float* cvec, const float* dvec,
+                       float ln_eps, const float* row_partials, float* Cout, int64_t ldc, int64_t M, int N, int K,
+                       int act, float scale, int scale_cols, int dtype, void* stream);
 
 /* K2/K3/K8 -- nn.Linear with fused epilogue (modules.py:760-766, 794-799, 896-905, 923, 424-426, 396):
  *   Cout[m,n] = act( (sum_k A[m,k]*W[n,k] + bias[n]) * (n < scale_cols ? scale : 1) ) + residual[m,n]
@@ -275,6 +305,10 @@ size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int 
  * from rnamsm_split_bf16, in the order {row_wqkv, row_wo, col_wqkv, col_wo, fc1_w, fc2_w} x {hi, lo} (lo may be
  * NULL for RNAMSM_BF16). */
 #define RNAMSM_PLANES_PER_LAYER 12
+/* ln_folded (host array, may be NULL = separate LayerNorm launches): for every layer 9 device pointers from
+ * rnamsm_ln_fold_weights, {Wg, c, d} for {row QKV [3D,D] with the row LayerNorm, column QKV with the column LayerNorm,
+ * fc1 [F,D] with the FFN LayerNorm}.  Used by the exact path on MSAs without padding (knob "ln_fold"). */
+#define RNAMSM_FOLDED_PER_LAYER 9
 /* outputs: RNAMSM_OUT_REPR = the whole final representation repr [R*C, D] is wanted (MSATransformer.forward's
  * representations[num_layers]).  Without it only what extract_feat writes is produced -- emb (alignment row 0) and atp
  * (RNA_MSM_Inference.py:151-166) -- and the last layer stops computing the other rows once its tied row attention is done:
@@ -287,7 +321,7 @@ int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, c
                    int R, int C, void* workspace, size_t workspace_bytes,
                    float* row_attn, float* repr, float* emb, float* atp,
                    int* err_flag, int has_padding, int max_tokens_per_msa, int outputs, int dtype,
-                   const uint16_t* const* weight_planes, void* stream);
+                   const uint16_t* const* weight_planes, const float* const* ln_folded, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's
  * roofline block; adds two event records per launch while enabled, nothing when disabled).
@@ -322,6 +356,9 @@ void rnamsm_timing_reset(void);
  *   "col_dma"     fp32 rnamsm_col_attn_fused: 1 = K/V chunks staged by LDS-DMA, 32-key chunks, three blocks per CU;
  *                 0 = register-staged 64-key chunks, two blocks per CU; -1 (default) = chosen from the shape.  Speed only
  *                 (the two kernels run the same arithmetic per 32-key tile; results agree to fp32 rounding).
+ *   "ln_fold"     rnamsm_forward with ln_folded given: 1 (default) = LayerNorm folded into the QKV / fc1 GEMMs, row sums
+ *                 left by the out_proj / fc2 epilogues; 2 = folded, every GEMM sums the rows it stages itself; 0 = separate
+ *                 LayerNorm launches (all three agree to fp32 rounding).
  *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit
  *                 matrix cores in the mode's operand format (K4'..K7'), 0 = they stay on the exact-fp32 kernels,
  *                 2 = as 1 but the row kernels keep 128x128 tiles for every C (A/B of the 256x256-tile kernels).

@@ -58,6 +58,65 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     }
 }
 
+// K1 folded into the consuming GEMM (gemm_f32.hip FOLD = 2): the row partial sums [T, D/32, 2] = (sum x, sum x^2) per
+// 32-column slab, in the format the residual GEMM epilogues leave them -- for a residual stream that did not come out of
+// one (the embedding, K0).  One wave per row; the 8 lanes of a slab add up on the DPP path.
+__device__ __forceinline__ float sum8_dpp_e(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    return v;
+}
+__global__ __launch_bounds__(256) void row_partials_kernel(const float* __restrict__ x, float2* __restrict__ partials,
+                                                           int64_t T, int D) {
+    const int lane = threadIdx.x & 63;
+    const int nvec = D / 4, nslots = D / 32;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += stride) {
+#pragma unroll
+        for (int e = 0; e < LN_MAX_VEC; ++e) {
+            const int vi = lane + 64 * e;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (vi < nvec) v = *reinterpret_cast<const f32x4*>(x + row * D + 4 * vi);
+            const float ps = sum8_dpp_e((v[0] + v[1]) + (v[2] + v[3]));
+            const float pq = sum8_dpp_e(fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3]))));
+            if ((lane & 7) == 0 && vi < nvec) partials[row * nslots + vi / 8] = float2{ps, pq};
+        }
+    }
+}
+
+// K1 folded into the consuming GEMM (gemm_f32.hip FOLD): one-time weight preparation, one wave per output feature n.
+//   Wg[n,k] = W[n,k] * gamma[k]   (one fp32 rounding)
+//   c[n]    = sum_k Wg[n,k]       (of the ROUNDED products, in double: it has to cancel what the GEMM accumulates)
+//   d[n]    = bias[n] + sum_k W[n,k] * beta[k]   (double)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void ln_fold_weights_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ Wg,
+                                                              float* __restrict__ cvec, float* __restrict__ dvec, int N,
+                                                              int K) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    double c = 0.0, d = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const float w = W[(int64_t)n * K + k];
+        const float wg = w * gamma[k];
+        Wg[(int64_t)n * K + k] = wg;
+        c += (double)wg;
+        d += (double)w * (double)beta[k];
+    }
+    c = wave_sum_f64(c);
+    d = wave_sum_f64(d);
+    if (lane == 0) {
+        cvec[n] = (float)c;
+        dvec[n] = (float)((bias ? (double)bias[n] : 0.0) + d);
+    }
+}
+
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict__ tokens,
                                                        const float* __restrict__ embed_tokens,
                                                        const float* __restrict__ embed_positions,
@@ -176,6 +235,27 @@ extern "C" int rnamsm_layernorm(const float* x, const float* gamma, const float*
     hipLaunchKernelGGL(layernorm_kernel, dim3(rows_grid(T)), dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma,
                        beta, y, T, D, eps);
     RNAMSM_CHECK_LAUNCH("layernorm");
+    return RNAMSM_OK;
+}
+
+extern "C" int rnamsm_row_partials(const float* x, float* row_partials, int64_t T, int D, void* stream) {
+    RNAMSM_CHECK_ARG(x && row_partials, "row_partials: null pointer");
+    RNAMSM_CHECK_ARG(T > 0 && D > 0 && D % 32 == 0 && D <= 256 * LN_MAX_VEC, "row_partials: need D %% 32 == 0, D <= 1024 (D=%d)", D);
+    RNAMSM_CHECK_ARG(aligned16(x) && aligned16(row_partials), "row_partials: 16-byte alignment");
+    KernelTimer timer(TC_LAYERNORM, 0.0, 4.0 * T * D + 0.25 * T * D, static_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(row_partials_kernel, dim3(rows_grid(T)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       reinterpret_cast<float2*>(row_partials), T, D);
+    RNAMSM_CHECK_LAUNCH("row_partials");
+    return RNAMSM_OK;
+}
+
+extern "C" int rnamsm_ln_fold_weights(const float* W, const float* bias, const float* gamma, const float* beta, float* Wg,
+                                      float* cvec, float* dvec, int N, int K, void* stream) {
+    RNAMSM_CHECK_ARG(W && gamma && beta && Wg && cvec && dvec, "ln_fold_weights: null pointer");
+    RNAMSM_CHECK_ARG(N > 0 && K > 0, "ln_fold_weights: bad shape N=%d K=%d", N, K);
+    hipLaunchKernelGGL(ln_fold_weights_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), W,
+                       bias, gamma, beta, Wg, cvec, dvec, N, K);
+    RNAMSM_CHECK_LAUNCH("ln_fold_weights");
     return RNAMSM_OK;
 }
 

@@ -1,6 +1,7 @@
 // Whole-forward driver: one C call enqueues K0..K10 for one MSA on the caller's stream
 // (MSATransformer.forward, model.py:338-416, with AxialTransformerLayer.forward, modules.py:242-267, and
-// NormalizedResidualBlock.forward, modules.py:385-401, unrolled into 13 launches per layer).
+// NormalizedResidualBlock.forward, modules.py:385-401, unrolled into 13 launches per layer, 10 with
+// LayerNorm folded into the GEMMs).
 //
 // HBM layout of the workspace (T = R*C tokens, D = embed dim, F = 4D):
 //   x      [T, D]    residual stream, updated in place by the out_proj / fc2 epilogues (K8)
@@ -9,6 +10,10 @@
 //                    the FFN hidden activation [T, F] overlays both (they are never live together)
 //   part   [nsplit, H, C, C]  row-logit partial slabs (K4 -> K5)
 //   pplanes [2][H*C, ldp]     row-attention probabilities as 16-bit hi / lo planes (16-bit modes, K5' -> K6')
+//   rowsum [T, D/32, 2]  (sum x, sum x^2) of every token per 32-feature slab, left by whatever wrote x last (K0 via
+//                    rnamsm_row_partials, then the out_proj / fc2 epilogues): with LayerNorm folded into the consuming
+//                    GEMM (ln_folded given, exact path, no padding) xn is never touched -- the QKV / fc1 GEMMs read x and
+//                    take each row's (mean, rstd) from these sums
 // In the 16-bit modes the same regions hold 16-bit planes instead: xn = LayerNorm hi|lo, the QKV slot of wide = q|k|v
 // hi plane [T,3D] then lo plane [T,3D] (2 x 2 B = the fp32 footprint), ctx = context hi|lo, hidden = GELU hi|lo.
 // cfg3 (R=256, C=512): 403 MB + 403 MB + 1.61 GB + 75 MB; cfg5 (R=C=1024): 19.3 GB -- one 288 GB HBM3E stack set
@@ -19,7 +24,7 @@ using namespace rnamsm;
 
 namespace {
 struct Layout {
-    size_t x, xn, wide, part, mask, pplanes, total;
+    size_t x, xn, wide, part, mask, pplanes, rowsum, total;
 };
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 Layout make_layout(const rnamsm_model_dims& d, int R, int C, int nchunks) {
@@ -37,6 +42,7 @@ Layout make_layout(const rnamsm_model_dims& d, int R, int C, int nchunks) {
     }
     l.mask = off; off += align256(T);
     l.pplanes = off; off += align256((size_t)d.num_heads * C * (size_t)((C + 63) / 64 * 64) * 4);   // P hi + lo planes (K5' -> K6')
+    l.rowsum = off; off += align256(T * (D / 32) * 2 * sizeof(float));   // (sum x, sum x^2) per token and 32-feature slab
     l.total = off;
     return l;
 }
@@ -57,7 +63,8 @@ extern "C" size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, 
 extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
                               int R, int C, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
                               float* emb, float* atp, int* err_flag, int has_padding, int max_tokens_per_msa, int outputs,
-                              int dtype, const uint16_t* const* weight_planes, void* stream) {
+                              int dtype, const uint16_t* const* weight_planes, const float* const* ln_folded,
+                              void* stream) {
     RNAMSM_CHECK_ARG(dtype >= RNAMSM_F32 && dtype <= RNAMSM_F16X3, "forward: unknown dtype %d", dtype);
     RNAMSM_CHECK_ARG(dtype == RNAMSM_F32 || weight_planes, "forward: bf16 modes need weight_planes");
     RNAMSM_CHECK_ARG(dims && weights && tokens && workspace && row_attn && repr && emb && atp, "forward: null pointer");
@@ -136,6 +143,32 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         return rnamsm_gemm_bf16(nullptr, lda, P[0], P[1], bias, res, ldr, out, ldc, T, N, K, act, scale, scale_cols, split,
                                 fmt, ahi, alo, ohi, olo, stream);
     };
+    // Exact path without padding, folded weights given: the three LayerNorms of a layer are applied inside the GEMMs they
+    // feed (gemm_f32.hip FOLD) -- norm() is then no launch at all, lin_normed() reads x itself and res_linear() (the GEMMs
+    // that write x) leaves the row sums the next lin_normed() normalises with.
+    const bool fold = ln_folded && dtype == RNAMSM_F32 && !has_padding && tuning().ln_fold != 0;
+    float* rowsum = reinterpret_cast<float*>(ws + lay.rowsum);
+    auto norm = [&](const float* g, const float* b, int64_t rows) -> int {
+        if (fold) return RNAMSM_OK;
+        return rnamsm_layernorm(x, g, b, xn, rows, D, d.ln_eps, stream);
+    };
+    // x[:rows] += A W^T + bias on the exact path
+    auto res_linear = [&](const float* A, int64_t lda, const float* Wf, const float* bias, int64_t rows, int K) -> int {
+        if (fold && tuning().ln_fold == 1)
+            return rnamsm_gemm_residual_stats(A, lda, Wf, bias, x, D, x, D, rows, D, K, rowsum, f32, stream);
+        return rnamsm_gemm_bias_act_res(A, lda, Wf, bias, x, D, x, D, rows, D, K, RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream);
+    };
+    // columns n_ofs .. n_ofs + N - 1 of the Linear in folded slot fslot (0 row QKV, 1 column QKV, 2 fc1) over `rows` tokens
+    auto lin_normed = [&](int layer, int fslot, const float* Wf, const float* bias, int n_ofs, float* out, int64_t ldc,
+                          int64_t rows, int N, int act, float scale, int scale_cols) -> int {
+        if (fold) {
+            const float* const* Fp = ln_folded + (size_t)layer * RNAMSM_FOLDED_PER_LAYER + 3 * fslot;
+            return rnamsm_gemm_lnfold(x, D, Fp[0] + (size_t)n_ofs * D, Fp[1] + n_ofs, Fp[2] + n_ofs, d.ln_eps, tuning().ln_fold == 1 ? rowsum : nullptr, out, ldc, rows, N, D,
+                                      act, scale, scale_cols, f32, stream);
+        }
+        return rnamsm_gemm_bias_act_res(xn, D, Wf + (size_t)n_ofs * D, bias + n_ofs, nullptr, 0, out, ldc, rows, N, D, act, scale,
+                                        scale_cols, nullptr, f32, stream);
+    };
     const float row_scale = (1.0f / sqrtf(64.0f)) / sqrtf((float)R);     // align_scaling, modules.py:713-715
     const float col_scale = 1.0f / sqrtf(64.0f);                         // modules.py:839
 
@@ -147,11 +180,12 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     FWD(rnamsm_embed_ln(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
                         G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, R, C, D, d.vocab, d.num_positions,
                         d.pad_idx, d.ln_eps, err_flag, stream));
+    if (fold && tuning().ln_fold == 1) FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
     for (int l = 0; l < NL; ++l) {
         const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
         float* probs = row_attn + (int64_t)l * H * C * C;
         // ---- tied row attention block
-        FWD(ln_for_gemm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
+        if (!fold) FWD(ln_for_gemm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
         if (attn16) {
             // q stays unscaled in the planes; the scaling multiplies the fp32 logits (see include/rnamsm.h)
             FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
@@ -166,6 +200,8 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             if (planes)
                 FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
                               RNAMSM_ACT_NONE, row_scale, D));
+            else if (fold)
+                FWD(lin_normed(l, 0, nullptr, nullptr, 0, qkv, ldq, T, 3 * D, RNAMSM_ACT_NONE, row_scale, D));
             else
                 FWD(linear(l, 0, xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
                            RNAMSM_ACT_NONE, row_scale, D, mask));
@@ -181,7 +217,8 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         if (planes)
             FWD(linear_pl(l, 1, ctx_hi, ctx_lo, D, W[RNAMSM_WL_ROW_BO], x, D, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE, 1.f, 0));
         else
-            FWD(linear(l, 1, ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
+            FWD(dtype == RNAMSM_F32 ? res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], T, D)
+                                    : linear(l, 1, ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
         if (l == NL - 1 && !(outputs & RNAMSM_OUT_REPR) && dtype == RNAMSM_F32 && !has_padding && R > 1) {
             // Only emb (alignment row 0 of the final representation) and the maps are wanted, and the maps are complete:
             // from here on every row but row 0 is dead.  The last column attention still needs K and V of all rows
@@ -189,25 +226,20 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             // and the final LayerNorm run on row 0's C tokens (the first C rows of every [T, .] buffer).  Same kernels,
             // same per-element arithmetic: emb is bit-identical to the full forward's.
             const int64_t Tq = C;
-            FWD(rnamsm_layernorm(x, W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B], xn, T, D, d.ln_eps, stream));
-            FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_COL_WQKV] + (size_t)D * D, W[RNAMSM_WL_COL_BQKV] + D, nullptr, 0,
-                                         qkv + D, ldq, T, 2 * D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream));     // k | v
-            FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, Tq, D, D,
-                                         RNAMSM_ACT_NONE, col_scale, D, nullptr, f32, stream));                          // q, row 0
+            FWD(norm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B], T));
+            FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], D, qkv + D, ldq, T, 2 * D, RNAMSM_ACT_NONE, 1.f, 0));   // k | v
+            FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], 0, qkv, ldq, Tq, D, RNAMSM_ACT_NONE, col_scale, D));  // q, row 0
             FWD(rnamsm_col_attn_fused_queries(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, 1, nullptr, f32, stream));
-            FWD(rnamsm_gemm_bias_act_res(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], x, D, x, D, Tq, D, D,
-                                         RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream));
-            FWD(rnamsm_layernorm(x, W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B], xn, Tq, D, d.ln_eps, stream));
-            FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], nullptr, 0, hidden, F, Tq, F, D,
-                                         RNAMSM_ACT_GELU_ERF, 1.f, 0, nullptr, f32, stream));
-            FWD(rnamsm_gemm_bias_act_res(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], x, D, x, D, Tq, D, F,
-                                         RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream));
+            FWD(res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], Tq, D));
+            FWD(norm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B], Tq));
+            FWD(lin_normed(l, 2, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], 0, hidden, F, Tq, F, RNAMSM_ACT_GELU_ERF, 1.f, 0));
+            FWD(res_linear(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], Tq, F));
             FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, Tq, D, d.ln_eps, stream));
             FWD(rnamsm_pack_outputs(repr, row_attn, emb, atp, C, D, NL, H, stream));
             return RNAMSM_OK;
         }
         // ---- column attention block
-        FWD(ln_for_gemm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
+        if (!fold) FWD(ln_for_gemm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
         if (attn16) {
             FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
                           RNAMSM_ACT_NONE, 1.f, 0));
@@ -217,6 +249,8 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             if (planes)
                 FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
                               RNAMSM_ACT_NONE, col_scale, D));
+            else if (fold)
+                FWD(lin_normed(l, 1, nullptr, nullptr, 0, qkv, ldq, T, 3 * D, RNAMSM_ACT_NONE, col_scale, D));
             else
                 FWD(linear(l, 2, xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
                            RNAMSM_ACT_NONE, col_scale, D, nullptr));
@@ -225,19 +259,24 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         if (planes)
             FWD(linear_pl(l, 3, ctx_hi, ctx_lo, D, W[RNAMSM_WL_COL_BO], x, D, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE, 1.f, 0));
         else
-            FWD(linear(l, 3, ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
+            FWD(dtype == RNAMSM_F32 ? res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], T, D)
+                                    : linear(l, 3, ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
         // ---- feed-forward block
-        FWD(ln_for_gemm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
+        if (!fold) FWD(ln_for_gemm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
         if (planes) {
             FWD(linear_pl(l, 4, xn_hi, xn_lo, D, W[RNAMSM_WL_FC1_B], nullptr, 0, nullptr, hid_hi, hid_lo, F, F, D,
                           RNAMSM_ACT_GELU_ERF, 1.f, 0));
             FWD(linear_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, D, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE,
                           1.f, 0));
         } else {
-            FWD(linear(l, 4, xn, D, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], nullptr, 0, hidden, F, F, D,
-                       RNAMSM_ACT_GELU_ERF, 1.f, 0, nullptr));
-            FWD(linear(l, 5, hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], x, D, x, D, D, F, RNAMSM_ACT_NONE, 1.f, 0,
-                       nullptr));
+            if (fold)
+                FWD(lin_normed(l, 2, nullptr, nullptr, 0, hidden, F, T, F, RNAMSM_ACT_GELU_ERF, 1.f, 0));
+            else
+                FWD(linear(l, 4, xn, D, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], nullptr, 0, hidden, F, F, D,
+                           RNAMSM_ACT_GELU_ERF, 1.f, 0, nullptr));
+            FWD(dtype == RNAMSM_F32 ? res_linear(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], T, F)
+                                    : linear(l, 5, hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], x, D, x, D, D, F, RNAMSM_ACT_NONE, 1.f, 0,
+                                             nullptr));
         }
     }
     FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));

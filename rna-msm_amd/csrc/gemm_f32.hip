@@ -3,6 +3,19 @@
 // Reference call sites: modules.py:760-766 (q,k proj + q scaling), :794,:799 (v, out proj), :896-905, :923 (column),
 // :424-426 (fc1 + GELU, fc2), :396 (residual add).
 //
+// FOLD (K1 fused, modules.py:387 + the Linear that consumes it): the GEMM reads the residual stream x itself and
+// LayerNorm is applied to the ACCUMULATORS,
+//   LN(x) W^T + b = rstd_m * ( sum_k x[m,k] Wg[n,k]  -  mean_m * c[n] ) + d[n],
+//   Wg = W * gamma (columnwise),  c[n] = sum_k Wg[n,k],  d[n] = b[n] + sum_k W[n,k] beta[k]   (rnamsm_ln_fold_weights)
+// so the normalised copy of x is never written or read (806 MB per LayerNorm at cfg3) and LayerNorm is no launch at all:
+// the statistics come from whoever WROTE x.  STATS: the residual epilogue (out_proj / fc2, which produce the residual
+// stream) leaves per row and 32-column slab the partial (sum x, sum x^2) of what it stores: row_partials [M, N/32, 2];
+// FOLD = 2: the consuming block adds the K/32 partials of each of its 128 rows once, before its K loop, and keeps
+// (mean, rstd) in LDS for the epilogue (biased variance as E[x^2] - mean^2 in fp32).  FOLD = 1 is the self-contained
+// form (no partials given): the block sums x and x^2 of the rows it stages while the tiles go to LDS -- measured: those
+// ~50 VALU instructions per K tile are NOT hidden under the MFMAs (+2.6 % kernel time, as much as the LayerNorm launch
+// they replace), which is why the forward uses the partial sums.
+//
 // Roofline: MFMA-bound.  2*M*N*K flops against v_mfma_f32_32x32x2_f32's 157.3 TFLOP/s; per 128x128x32 K tile a CU
 // issues 256 MFMAs (4096 cycles per SIMD) while 32 KB arrive from L2 (8 B/clk/CU).  Two blocks are resident per CU
 // (73.7 KB LDS, <=128 VGPRs each) so one block's barrier / staging bubbles are covered by the other's MFMAs.
@@ -20,15 +33,25 @@ struct GemmCfg {
     static constexpr int BN_ = 64 * NT;
     static constexpr int TILE_W = BN_ * LDK;                         // floats in one W tile
     static constexpr int LDS_BYTES = 2 * (TILE_KC + TILE_W) * 4;     // double-buffered A and W tiles
+    static constexpr int LDS_FOLD = LDS_BYTES + BM * 8;              // FOLD: + (mean, rstd) of the block's 128 rows
     static constexpr int LDE = 32 * NT + 4;                          // padded row stride of the epilogue staging tile
     static_assert(4 * 64 * LDE * 4 <= LDS_BYTES, "epilogue staging must fit the operand buffers");
 };
 
-template <int ACT, bool HAS_RES, bool ZROWS, int NT>
+// lanes i and i^1, i^2, 7-i: the three steps of a sum over aligned groups of 8 lanes on the DPP path (no LDS traffic)
+__device__ __forceinline__ float sum8_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    return v;
+}
+
+template <int ACT, bool HAS_RES, bool ZROWS, int NT, int FOLD = 0, bool STATS = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc,
-    int M, int N, int K, float scale, int scale_cols, const uint8_t* __restrict__ zero_rows, int group) {
+    int M, int N, int K, float scale, int scale_cols, const uint8_t* __restrict__ zero_rows, int group,
+    const float* __restrict__ fold_c, float ln_eps, float* row_partials) {
     using Cfg = GemmCfg<NT>;
     constexpr int BN_ = Cfg::BN_, TILE_W = Cfg::TILE_W;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -42,6 +65,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
 
     const WaveCoord w = wave_coord();
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+
+    if (FOLD == 2 && threadIdx.x < BM) {
+        // (mean, rstd) of row m0 + tid from the K/32 slab sums its producer left; visible to the epilogue through the
+        // barriers of the K loop
+        const int nslots = K / 32;                                   // even: K % 64 == 0 is checked by the launcher
+        const f32x4* pp = reinterpret_cast<const f32x4*>(row_partials + (int64_t)min(m0 + (int)threadIdx.x, M - 1) * nslots * 2);
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < nslots / 2; ++j) {
+            const f32x4 v = pp[j];
+            a += v[0]; b += v[1];
+            a += v[2]; b += v[3];
+        }
+        const float mean = a / (float)K;
+        const float var = fmaxf(b / (float)K - mean * mean, 0.f);
+        reinterpret_cast<float2*>(smem + Cfg::LDS_BYTES / 4)[threadIdx.x] = float2{mean, rsqrtf(var + ln_eps)};
+    }
 
     // per-thread global row pointers (A rows clamped: a clamped row only feeds its own discarded output row)
     const float* ap[4];
@@ -59,6 +98,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     zero_acc<NT>(acc);
 
     f32x4 sa[4], sw[2 * NT];             // staging registers of one K tile: thread -> (row tid/8 + 32 i, 16-B chunk tid%8)
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // FOLD: sum x, sum x^2 of this thread's part of 4 rows
     pipelined_kloop<true, 4 + 2 * NT, 1, NT>(
         K / BK, As, Ws, TILE_KC, TILE_W, acc, w,
         [&](int kt, auto) {
@@ -74,7 +114,31 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
             for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&at[(r0 + 32 * i) * LDK + c4 * 4]) = sa[i];
 #pragma unroll
             for (int i = 0; i < 2 * NT; ++i) *reinterpret_cast<f32x4*>(&wt[(r0 + 32 * i) * LDK + c4 * 4]) = sw[i];
+            if (FOLD == 1) {                                       // every K tile passes here exactly once
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s1[i] += (sa[i][0] + sa[i][1]) + (sa[i][2] + sa[i][3]);
+                    s2[i] = fmaf(sa[i][0], sa[i][0], fmaf(sa[i][1], sa[i][1], fmaf(sa[i][2], sa[i][2], fmaf(sa[i][3], sa[i][3], s2[i]))));
+                }
+            }
         });
+    if (FOLD == 1) {
+        // the 8 lanes tid%8 = 0..7 hold the eight 96-feature parts of a row: butterfly over them, biased variance as
+        // E[x^2] - mean^2 (fp32; fine while |mean| is not >> the row's spread, as for a residual stream)
+        float2* sst = reinterpret_cast<float2*>(smem + Cfg::LDS_BYTES / 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float a = s1[i], b = s2[i];
+#pragma unroll
+            for (int off = 1; off < 8; off <<= 1) {
+                a += __shfl_xor(a, off, 64);
+                b += __shfl_xor(b, off, 64);
+            }
+            const float mean = a / (float)K;
+            const float var = fmaxf(b / (float)K - mean * mean, 0.f);
+            if (c4 == 0) sst[r0 + 32 * i] = float2{mean, rsqrtf(var + ln_eps)};
+        }
+    }
 
     // ---- epilogue.  The accumulator layout (one row x 32 columns per register and lane half) would give 32 NT
     // 4-byte-per-lane stores per wave, and store tails are issue-bound; instead each wave transposes its 64 x 32NT tile
@@ -95,19 +159,31 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
             res[i] = epi_load(reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn));
         }
     }
+    f32x4 fc4, fd4;
+    if (FOLD) {
+        fc4 = *reinterpret_cast<const f32x4*>(fold_c + gn);
+        fd4 = *reinterpret_cast<const f32x4*>(bias + gn);
+    }
     __syncthreads();                                              // every wave has finished reading operand tiles
+    float2 st[NP];                                                // FOLD: (mean, rstd) of this lane's rows
+    if (FOLD) {
+        const float2* sst = reinterpret_cast<const float2*>(smem + Cfg::LDS_BYTES / 4);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) st[i] = sst[w.wm * 64 + er + RPP * i];
+    }
     float* stage = smem + wv * (64 * LDE);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = n0 + w.wn * 32 * NT + nt * 32 + w.li;
-        const float b = bias ? bias[col] : 0.f;
-        const float sc = col < scale_cols ? scale : 1.f;
+        const float b = (!FOLD && bias) ? bias[col] : 0.f;
+        const float sc = (!FOLD && col < scale_cols) ? scale : 1.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {                    // pairs: the GELU runs on the packed-fp32 VALU
-                f32x2 v = f32x2{(acc[mt][nt][t] + b) * sc, (acc[mt][nt][t + 1] + b) * sc};
-                if (ACT == RNAMSM_ACT_GELU_ERF) v = gelu_erf2(v);
+                f32x2 v = FOLD ? f32x2{acc[mt][nt][t], acc[mt][nt][t + 1]}      // raw sums: LN is applied per row below
+                               : f32x2{(acc[mt][nt][t] + b) * sc, (acc[mt][nt][t + 1] + b) * sc};
+                if (!FOLD && ACT == RNAMSM_ACT_GELU_ERF) v = gelu_erf2(v);
                 stage[(mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * w.lh) * LDE + nt * 32 + w.li] = v[0];
                 stage[(mt * 32 + ((t + 1) & 3) + 8 * ((t + 1) >> 2) + 4 * w.lh) * LDE + nt * 32 + w.li] = v[1];
             }
@@ -120,7 +196,23 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     for (int i = 0; i < NP; ++i) {
         const int r = er + RPP * i;
         ov[i] = *reinterpret_cast<const f32x4*>(&stage[r * LDE + ec]);
+        if (FOLD) {
+            const float fs = gn < scale_cols ? scale : 1.f;      // scale_cols % 4 == 0: a lane's 4 columns share it
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[i][e] = fmaf(st[i].y, fmaf(-st[i].x, fc4[e], ov[i][e]), fd4[e]) * fs;
+            if (ACT == RNAMSM_ACT_GELU_ERF) {
+                const f32x2 g0 = gelu_erf2(f32x2{ov[i][0], ov[i][1]}), g1 = gelu_erf2(f32x2{ov[i][2], ov[i][3]});
+                ov[i] = f32x4{g0[0], g0[1], g1[0], g1[1]};
+            }
+        }
         if (HAS_RES) ov[i] += res[i];
+        if (STATS) {
+            // what this lane stores of row r: 4 of the 32 columns its group of 8 lanes covers
+            const float ps = sum8_dpp((ov[i][0] + ov[i][1]) + (ov[i][2] + ov[i][3]));
+            const float pq = sum8_dpp(fmaf(ov[i][0], ov[i][0], fmaf(ov[i][1], ov[i][1], fmaf(ov[i][2], ov[i][2], ov[i][3] * ov[i][3]))));
+            if ((lane & 7) == 0 && gm0 + r < M)
+                reinterpret_cast<float2*>(row_partials)[(int64_t)(gm0 + r) * (N / 32) + gn / 32] = float2{ps, pq};
+        }
         // f2: q *= 1 - padding_mask (modules.py:767-772): padded tokens get q = 0 (the scaled columns are q)
         if (ZROWS && gn < scale_cols && zero_rows[min(gm0 + r, M - 1)]) ov[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -134,16 +226,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     }
 }
 
-template <int ACT, bool HAS_RES, bool ZROWS, int NT>
+template <int ACT, bool HAS_RES, bool ZROWS, int NT, int FOLD = 0, bool STATS = false>
 static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                           int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
-                          const uint8_t* zero_rows, hipStream_t stream) {
+                          const uint8_t* zero_rows, hipStream_t stream, const float* fold_c = nullptr,
+                          float ln_eps = 0.f, float* row_partials = nullptr) {
     using Cfg = GemmCfg<NT>;
     static DeviceOnce configured;
-    auto kern = gemm_f32_kernel<ACT, HAS_RES, ZROWS, NT>;
+    auto kern = gemm_f32_kernel<ACT, HAS_RES, ZROWS, NT, FOLD, STATS>;
     if (configured.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FOLD ? Cfg::LDS_FOLD : Cfg::LDS_BYTES);
         if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured.mark();
     }
@@ -156,8 +249,8 @@ static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const flo
     const unsigned grid = xcd_panel_grid_grouped((M + BM - 1) / BM, nb, (unsigned)group);
     // algorithmic work: 2MNK flops; bytes = A + W + C once (+ residual read)
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), Cfg::LDS_BYTES, stream, A, lda, W, bias, residual, ldr,
-                       Cout, ldc, M, N, K, scale, scale_cols, zero_rows, group);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), FOLD ? Cfg::LDS_FOLD : Cfg::LDS_BYTES, stream, A, lda, W, bias,
+                       residual, ldr, Cout, ldc, M, N, K, scale, scale_cols, zero_rows, group, fold_c, ln_eps, row_partials);
     RNAMSM_CHECK_LAUNCH("gemm_f32");
     return RNAMSM_OK;
 }
@@ -191,9 +284,71 @@ static int launch_gemm(const float* A, int64_t lda, const float* W, const float*
                                                   zero_rows, stream);
 }
 
+template <int ACT, int FOLD>
+static int launch_gemm_fold(const float* X, int64_t ldx, const float* Wg, const float* cvec, const float* dvec,
+                            float ln_eps, const float* row_partials, float* Cout, int64_t ldc, int M, int N, int K,
+                            float scale, int scale_cols, hipStream_t stream) {
+    float* rp = const_cast<float*>(row_partials);                  // read-only in the FOLD kernels
+    if (half_width_tiles_win(M, N))
+        return launch_gemm_nt<ACT, false, false, 1, FOLD>(X, ldx, Wg, dvec, nullptr, 0, Cout, ldc, M, N, K, scale, scale_cols,
+                                                          nullptr, stream, cvec, ln_eps, rp);
+    return launch_gemm_nt<ACT, false, false, 2, FOLD>(X, ldx, Wg, dvec, nullptr, 0, Cout, ldc, M, N, K, scale, scale_cols,
+                                                      nullptr, stream, cvec, ln_eps, rp);
+}
+
+// residual GEMM that also leaves the row partial sums of what it stores (the producer side of the folded LayerNorm)
+static int launch_gemm_res_stats(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
+                                 int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float* row_partials,
+                                 hipStream_t stream) {
+    if (half_width_tiles_win(M, N))
+        return launch_gemm_nt<RNAMSM_ACT_NONE, true, false, 1, 0, true>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, 1.f, 0,
+                                                                        nullptr, stream, nullptr, 0.f, row_partials);
+    return launch_gemm_nt<RNAMSM_ACT_NONE, true, false, 2, 0, true>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, 1.f, 0,
+                                                                    nullptr, stream, nullptr, 0.f, row_partials);
+}
+
 }  // namespace rnamsm
 
 using namespace rnamsm;
+
+extern "C" int rnamsm_gemm_residual_stats(const float* A, int64_t lda, const float* W, const float* bias,
+                                          const float* residual, int64_t ldr, float* Cout, int64_t ldc, int64_t M, int N,
+                                          int K, float* row_partials, int dtype, void* stream) {
+    if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "gemm_residual_stats: only RNAMSM_F32 is implemented");
+    RNAMSM_CHECK_ARG(A && W && Cout && residual && row_partials, "gemm_residual_stats: null pointer");
+    RNAMSM_CHECK_ARG(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "gemm_residual_stats: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    RNAMSM_CHECK_ARG(N % BN == 0 && K % BK == 0, "gemm_residual_stats: need N %% 128 == 0 and K %% 32 == 0 (N=%d K=%d)", N, K);
+    RNAMSM_CHECK_ARG(lda >= K && lda % 4 == 0 && ldc >= N && ldc % 4 == 0 && ldr >= N && ldr % 4 == 0,
+                     "gemm_residual_stats: bad leading dimension");
+    RNAMSM_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(Cout) && aligned16(residual) && aligned16(row_partials),
+                     "gemm_residual_stats: 16-byte alignment");
+    return launch_gemm_res_stats(A, lda, W, bias, residual, ldr, Cout, ldc, (int)M, N, K, row_partials,
+                                 static_cast<hipStream_t>(stream));
+}
+
+extern "C" int rnamsm_gemm_lnfold(const float* X, int64_t ldx, const float* Wg, const float* cvec, const float* dvec,
+                                  float ln_eps, const float* row_partials, float* Cout, int64_t ldc, int64_t M, int N,
+                                  int K, int act, float scale, int scale_cols, int dtype, void* stream) {
+    if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "gemm_lnfold: only RNAMSM_F32 is implemented");
+    RNAMSM_CHECK_ARG(X && Wg && cvec && dvec && Cout, "gemm_lnfold: null pointer");
+    RNAMSM_CHECK_ARG(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "gemm_lnfold: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    RNAMSM_CHECK_ARG(N % BN == 0 && K % BK == 0, "gemm_lnfold: need N %% 128 == 0 and K %% 32 == 0 (N=%d K=%d)", N, K);
+    RNAMSM_CHECK_ARG(ldx >= K && ldx % 4 == 0 && ldc >= N && ldc % 4 == 0, "gemm_lnfold: bad leading dimension ldx=%lld ldc=%lld",
+                     (long long)ldx, (long long)ldc);
+    RNAMSM_CHECK_ARG(aligned16(X) && aligned16(Wg) && aligned16(cvec) && aligned16(dvec) && aligned16(Cout),
+                     "gemm_lnfold: 16-byte alignment");
+    RNAMSM_CHECK_ARG(ln_eps >= 0.f, "gemm_lnfold: negative eps");
+    RNAMSM_CHECK_ARG(!row_partials || (K % 64 == 0 && aligned16(row_partials)),
+                     "gemm_lnfold: row_partials needs K %% 64 == 0 and 16-byte alignment");
+    RNAMSM_CHECK_ARG(scale_cols >= 0 && scale_cols % 4 == 0, "gemm_lnfold: scale_cols must be a multiple of 4");
+    RNAMSM_CHECK_ARG(act == RNAMSM_ACT_NONE || act == RNAMSM_ACT_GELU_ERF, "gemm_lnfold: unknown activation %d", act);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define RNAMSM_FOLD_DISPATCH(ACT_, FOLD_) \
+    launch_gemm_fold<ACT_, FOLD_>(X, ldx, Wg, cvec, dvec, ln_eps, row_partials, Cout, ldc, (int)M, N, K, scale, scale_cols, s)
+    if (act == RNAMSM_ACT_GELU_ERF) return row_partials ? RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_GELU_ERF, 2) : RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_GELU_ERF, 1);
+    return row_partials ? RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_NONE, 2) : RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_NONE, 1);
+#undef RNAMSM_FOLD_DISPATCH
+}
 
 extern "C" int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float* W, const float* bias,
                                         const float* residual, int64_t ldr, float* Cout, int64_t ldc, int64_t M,

@@ -84,6 +84,10 @@ class MSATransformer(nn.Module):
         self.gemm_dtype = "f32"
         self.check_finite = True          # 16-bit modes: verify the outputs are finite, fall back to f32 per MSA otherwise
         self._planes = None
+        self._folded = None
+        # exact path, MSAs without padding: LayerNorm is applied inside the QKV / fc1 GEMMs (include/rnamsm.h, K1 folded);
+        # False keeps the separate LayerNorm launches (same results to fp32 rounding)
+        self.fold_layernorm = True
 
     @property
     def gemm_dtype(self) -> str:
@@ -171,6 +175,27 @@ class MSATransformer(nn.Module):
         self._planes = (self._pack_key, arr, tensors, fmt)
         return arr
 
+    def _folded_weights(self):
+        """LayerNorm folded into the Linear it feeds (rnamsm_ln_fold_weights): per layer {Wg, c, d} for the row QKV, the
+        column QKV and fc1, built once per weight version.  rnamsm_forward's `ln_folded` table."""
+        dims, ptrs, keep = self._packed_weights()
+        if self._folded is not None and self._folded[0] is self._pack_key:
+            return self._folded[1]
+        ng, nl = len(_lib.W_GLOBAL), len(_lib.W_LAYER)
+        ix = _lib.W_LAYER.index
+        triples = [("row_ln_g", "row_ln_b", "row_wqkv", "row_bqkv"), ("col_ln_g", "col_ln_b", "col_wqkv", "col_bqkv"),
+                   ("ffn_ln_g", "ffn_ln_b", "fc1_w", "fc1_b")]
+        tensors, addrs = [], []
+        for layer in range(self.num_layers):
+            base = ng + layer * nl
+            for g, b, w, bias in triples:
+                out = ops.ln_fold_weights(keep[base + ix(w)], keep[base + ix(bias)], keep[base + ix(g)], keep[base + ix(b)])
+                tensors += list(out)
+                addrs += [t.data_ptr() for t in out]
+        arr = (ctypes.c_void_p * len(addrs))(*addrs)
+        self._folded = (self._pack_key, arr, tensors)
+        return arr
+
     def _get_workspace(self, nbytes: int, device) -> torch.Tensor:
         if self._workspace is None or self._workspace.numel() < nbytes or self._workspace.device != device:
             self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -242,10 +267,11 @@ class MSATransformer(nn.Module):
         err = torch.zeros(1, device=dev, dtype=torch.int32)
         dtype = _lib.DTYPES[self.gemm_dtype]
         planes = self._weight_planes() if dtype != _lib.F32 else None
+        folded = self._folded_weights() if (dtype == _lib.F32 and not has_padding and self.fold_layernorm) else None
         _lib.check(lib.rnamsm_forward(ctypes.byref(dims), ptrs, toks.data_ptr(), R, C, ws.data_ptr(), ws.numel(),
                                       row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
                                       err.data_ptr(), int(has_padding), max_tokens, _lib.OUT_REPR if need_repr else 0, dtype, planes,
-                                      torch.cuda.current_stream().cuda_stream))
+                                      folded, torch.cuda.current_stream().cuda_stream))
         if dtype != _lib.F32 and self.check_finite:
             # f16x3 / bf16 operands live in 16-bit planes: fp16 overflows above 65504 (-> inf/NaN downstream).  The
             # synthetic weights stay far inside; a real checkpoint is not known to, so the outputs are checked (one

@@ -64,6 +64,15 @@ def _rowmajor(t: torch.Tensor, name: str) -> int:
     return t.stride(0)
 
 
+def set_param(name: str, value: int) -> None:
+    """rnamsm_set_param: in-process A/B knobs (include/rnamsm.h lists them)."""
+    _lib.check(_lib.load().rnamsm_set_param(name.encode(), int(value)))
+
+
+def get_param(name: str) -> int:
+    return int(_lib.load().rnamsm_get_param(name.encode()))
+
+
 @_on_operand_device
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -102,6 +111,66 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         None if residual is None else _dev(residual, "residual"), 0 if residual is None else _rowmajor(residual, "residual"),
         _dev(out, "out"), _rowmajor(out, "out"), M, N, K, act, scale, scale_cols,
         None if zero_rows is None else _dev(zero_rows, "zero_rows", torch.uint8), F32, _stream()))
+    return out
+
+
+@_on_operand_device
+def ln_fold_weights(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """LayerNorm(gamma, beta) folded into the Linear (w [N,K], bias) that consumes it: (Wg [N,K], c [N], d [N]) with
+    LN(x) w^T + bias = rstd * (x Wg^T - mean * c) + d  (include/rnamsm.h, K1 folded)."""
+    w = w.contiguous()
+    N, K = w.shape
+    wg = torch.empty_like(w)
+    c = torch.empty(N, device=w.device, dtype=torch.float32)
+    d = torch.empty(N, device=w.device, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_ln_fold_weights(_dev(w, "w"), None if bias is None else _dev(bias, "bias"),
+                                                  _dev(gamma, "gamma"), _dev(beta, "beta"), wg.data_ptr(), c.data_ptr(),
+                                                  d.data_ptr(), N, K, _stream()))
+    return wg, c, d
+
+
+@_on_operand_device
+def row_partials(x: torch.Tensor) -> torch.Tensor:
+    """(sum x, sum x^2) of every row of x [T, D] per 32-feature slab: [T, D/32, 2], the statistics format of the folded
+    LayerNorm (include/rnamsm.h, K1 folded)."""
+    D = x.shape[-1]
+    x2 = x.contiguous().view(-1, D)
+    out = torch.empty(x2.shape[0], D // 32, 2, device=x2.device, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_row_partials(_dev(x2, "x"), out.data_ptr(), x2.shape[0], D, _stream()))
+    return out
+
+
+@_on_operand_device
+def linear_residual_stats(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], residual: torch.Tensor,
+                          out: Optional[torch.Tensor] = None):
+    """(out, row_partials): out = a @ w.T + bias + residual (may be in place: out = residual) and the row partial sums
+    [M, N/32, 2] of the stored out -- the producer side of the folded LayerNorm."""
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    part = torch.empty(M, N // 32, 2, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_gemm_residual_stats(
+        _dev(a, "a"), _rowmajor(a, "a"), _dev(w.contiguous(), "w"), None if bias is None else _dev(bias, "bias"),
+        _dev(residual, "residual"), _rowmajor(residual, "residual"), _dev(out, "out"), _rowmajor(out, "out"), M, N, K,
+        part.data_ptr(), F32, _stream()))
+    return out, part
+
+
+@_on_operand_device
+def linear_lnfold(x: torch.Tensor, wg: torch.Tensor, c: torch.Tensor, d: torch.Tensor, partials: Optional[torch.Tensor] = None,
+                  eps: float = 1e-5, act: int = ACT_NONE, scale: float = 1.0, scale_cols: int = 0,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act((rstd * (x @ wg.T - mean * c) + d) * (col < scale_cols ? scale : 1)) = act(Linear(LayerNorm(x)) ...): the GEMM
+    reads x itself; (wg, c, d) from ln_fold_weights; each row's (mean, rstd) from `partials` [M, K/32, 2] (row_partials /
+    linear_residual_stats), or summed by the GEMM itself when None."""
+    M, K = x.shape
+    N = wg.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_gemm_lnfold(_dev(x, "x"), _rowmajor(x, "x"), _dev(wg, "wg"), _dev(c, "c"), _dev(d, "d"),
+                                              eps, None if partials is None else _dev(partials, "partials"), _dev(out, "out"),
+                                              _rowmajor(out, "out"), M, N, K, act, scale, scale_cols, F32, _stream()))
     return out
 
 

@@ -58,6 +58,23 @@ int main(void) {
     REFUSED(rnamsm_layernorm(NULL, buf, buf, buf, 8, 768, 1e-5f, NULL));
     REFUSED(rnamsm_layernorm(buf, buf, buf, buf, 8, 770, 1e-5f, NULL));
     REFUSED(rnamsm_layernorm(buf, buf, buf, buf, 8, 1 << 20, 1e-5f, NULL));
+    /* K1 folded */
+    REFUSED(rnamsm_row_partials(NULL, buf, 8, 768, NULL));
+    REFUSED(rnamsm_row_partials(buf, buf, 8, 770, NULL));
+    REFUSED(rnamsm_row_partials(buf, buf, 0, 768, NULL));
+    REFUSED(rnamsm_gemm_residual_stats(buf, 64, buf, buf, NULL, 128, buf, 128, 8, 128, 64, buf, 0, NULL));   /* no residual */
+    REFUSED(rnamsm_gemm_residual_stats(buf, 64, buf, buf, buf, 128, buf, 128, 8, 128, 64, NULL, 0, NULL));   /* no partials */
+    REFUSED(rnamsm_gemm_residual_stats(buf, 64, buf, buf, buf, 128, buf, 128, 8, 100, 64, buf, 0, NULL));    /* N % 128 */
+    REFUSED(rnamsm_gemm_residual_stats(buf, 64, buf, buf, buf, 128, buf, 128, 8, 128, 64, buf, 2, NULL));    /* dtype */
+    REFUSED(rnamsm_gemm_lnfold(buf, 96, buf, buf, buf, 1e-5f, buf, buf, 128, 8, 128, 96, 0, 1.f, 0, 0, NULL));   /* partials: K % 64 */
+    REFUSED(rnamsm_ln_fold_weights(NULL, buf, buf, buf, buf, buf, buf, 128, 64, NULL));
+    REFUSED(rnamsm_ln_fold_weights(buf, buf, buf, buf, buf, buf, buf, 0, 64, NULL));
+    REFUSED(rnamsm_gemm_lnfold(NULL, 64, buf, buf, buf, 1e-5f, NULL, buf, 128, 8, 128, 64, 0, 1.f, 0, 0, NULL));
+    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, 1e-5f, NULL, buf, 128, 8, 100, 64, 0, 1.f, 0, 0, NULL));   /* N % 128 */
+    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, 1e-5f, NULL, buf, 128, 8, 128, 64, 0, 1.f, 6, 0, NULL));    /* scale_cols % 4 */
+    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, 1e-5f, NULL, buf, 128, 8, 128, 64, 7, 1.f, 0, 0, NULL));    /* activation */
+    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, 1e-5f, NULL, buf, 128, 8, 128, 64, 0, 1.f, 0, 1, NULL));    /* dtype */
+    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, -1.f, NULL, buf, 128, 8, 128, 64, 0, 1.f, 0, 0, NULL));     /* eps */
     REFUSED(rnamsm_layernorm_split(buf, buf, buf, NULL, NULL, 8, 768, 1e-5f, 0, NULL));
     REFUSED(rnamsm_gemm_bias_act_res(NULL, 0, NULL, NULL, NULL, 0, NULL, 0, 4, 128, 32, 0, 1.f, 0, NULL, 0, NULL));
     REFUSED(rnamsm_gemm_bias_act_res(buf, 32, buf, NULL, NULL, 0, buf, 100, 4, 100, 32, 0, 1.f, 0, NULL, 0, NULL));
@@ -104,19 +121,19 @@ int main(void) {
     REFUSED(rnamsm_greedy_select(bytes, 8, 70000, 4, 0, ints, buf, 1 << 16, NULL));
     REFUSED(rnamsm_msa_weights(NULL, 8, 8, 0.2, (double*)buf, NULL));
     REFUSED(rnamsm_msa_weights(bytes, 0, 8, 0.2, (double*)buf, NULL));
-    REFUSED(rnamsm_forward(NULL, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 9, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 3, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 1025, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL));
+    REFUSED(rnamsm_forward(NULL, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 9, NULL, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 3, NULL, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 1025, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL));
     EXPECT(strstr(rnamsm_last_error(), "maximum MSA depth of 1024") != NULL);             /* model.py:355-359 */
-    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 1, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4000, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 64, 128, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 1, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4000, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 64, 128, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL));
     EXPECT(strstr(rnamsm_last_error(), "workspace too small") != NULL);
     {
         rnamsm_model_dims bad = dims;
         bad.embed_dim = 700;
-        REFUSED(rnamsm_forward(&bad, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL));
+        REFUSED(rnamsm_forward(&bad, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL));
     }
 
     /* parameter parsing and timing bookkeeping */

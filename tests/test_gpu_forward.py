@@ -116,9 +116,16 @@ def test_layerwise_path_equals_driver_and_exposes_intermediate_layers(model):
     probe = g["probe_row0_layers_0_1_5"]
     for slot, layer in enumerate((0, 1, 5)):
         assert rel_l2(res["representations"][layer][0, 0].cpu().numpy(), probe[slot]) < 1e-4
-    fast = m.forward_one(toks)
+    try:
+        m.fold_layernorm = False          # the modules run LayerNorm as its own launch: compare like with like ...
+        fast = m.forward_one(toks)
+    finally:
+        m.fold_layernorm = True
     assert rel_l2(res["representations"][10][0].cpu().numpy(), fast["repr"].cpu().numpy()) < 1e-6
     assert np.abs(res["row_attentions"][0].cpu().numpy() - fast["row_attn"].cpu().numpy()).max() < 1e-6
+    fold = m.forward_one(toks)            # ... and the driver's default (LayerNorm folded into the GEMMs) to rounding
+    assert rel_l2(fold["repr"].cpu().numpy(), fast["repr"].cpu().numpy()) < 1e-5
+    assert np.abs(fold["row_attn"].cpu().numpy() - fast["row_attn"].cpu().numpy()).max() < 2e-5
 
 
 def test_cfg2_shape_against_oracle(model):
@@ -440,3 +447,50 @@ def test_outputs_only_forward_is_bit_identical_and_skips_dead_rows(model, R, C):
         assert torch.equal(a["emb"], b["emb"]) and b["repr"].shape == (R, C, 768)
     finally:
         m.gemm_dtype = "f32"
+
+
+@pytest.mark.parametrize("R,C", [(8, 17), (64, 128), (33, 131), (1, 9), (130, 40)])
+def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model, R, C):
+    """K1 folded is the exact path's default on MSAs without padding: the QKV / fc1 GEMMs read the residual stream and
+    apply (mean, rstd) to their accumulators.  Against the same forward with separate LayerNorm launches (the `ln_fold`
+    knob and MSATransformer.fold_layernorm both switch it) the outputs agree to fp32 rounding, and against the oracle the
+    folded forward is no further away than the unfolded one (x1.5)."""
+    from rnamsm import ops
+    m, state = model
+    tokens = synthetic.make_tokens(R, C, 5)
+    toks = torch.from_numpy(tokens).to("cuda:0")
+    fold = m.forward_one(toks, has_padding=False)
+    try:
+        ops.set_param("ln_fold", 0)
+        plain = m.forward_one(toks, has_padding=False)
+    finally:
+        ops.set_param("ln_fold", 1)
+    try:
+        m.fold_layernorm = False
+        plain2 = m.forward_one(toks, has_padding=False)
+    finally:
+        m.fold_layernorm = True
+    assert torch.equal(plain["emb"], plain2["emb"]) and torch.equal(plain["atp"], plain2["atp"])
+    assert not torch.equal(fold["emb"], plain["emb"])                        # the folded path really ran
+    try:
+        ops.set_param("ln_fold", 2)                                          # folded, every GEMM sums its rows itself
+        self_sum = m.forward_one(toks, has_padding=False)
+    finally:
+        ops.set_param("ln_fold", 1)
+    assert rel_l2(self_sum["emb"].cpu().numpy(), fold["emb"].cpu().numpy()) < 2e-5
+    assert rel_l2(fold["emb"].cpu().numpy(), plain["emb"].cpu().numpy()) < 2e-5
+    assert np.abs(fold["atp"].cpu().numpy() - plain["atp"].cpu().numpy()).max() < 1e-4
+    res = O.forward(torch.from_numpy(tokens), O.to_torch_params(state, torch.float64))
+    o_emb, o_atp = O.pack_outputs(res)
+    e_fold, e_plain = rel_l2(fold["emb"].cpu().numpy(), o_emb.numpy()), rel_l2(plain["emb"].cpu().numpy(), o_emb.numpy())
+    assert e_fold < 1.5 * e_plain + 1e-7, (e_fold, e_plain)
+    # padded MSAs keep the separate launches (and their exact reference mask semantics): the flag is simply not used
+    ptoks = toks.clone()
+    ptoks[-1, -2:] = 1
+    a = m.forward_one(ptoks)
+    try:
+        ops.set_param("ln_fold", 0)
+        b = m.forward_one(ptoks)
+    finally:
+        ops.set_param("ln_fold", 1)
+    assert torch.equal(a["emb"], b["emb"]) and torch.equal(a["atp"], b["atp"])

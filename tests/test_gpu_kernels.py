@@ -51,6 +51,76 @@ def test_gemm_plain(dev, M, N, K):
     assert np.abs(y.numpy() - want.numpy()).max() < 1e-4 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K,act,scale_cols", [(7, 128, 128, 0, 0), (300, 2304, 768, 0, 768), (1025, 3072, 768, 1, 0),
+                                                  (4100, 768, 256, 1, 256), (129, 256, 1024, 0, 128)])
+def test_layernorm_folded_into_the_gemm(dev, M, N, K, act, scale_cols):
+    """K1 folded (include/rnamsm.h): rstd * (x Wg^T - mean c) + d  ==  Linear(LayerNorm(x)) -- against fp64, and as close
+    to it as the separate LayerNorm -> GEMM launches are; with the row statistics taken from the partial sums
+    (rnamsm_row_partials) and summed by the GEMM itself.  x carries a row offset of the size of its spread
+    (|mean| ~ std), more than the residual stream's, so the mean * c cancellation is exercised."""
+    from rnamsm import ops
+    x = (_rand("lf.x", (M, K), 2.0) + _rand("lf.m", (M, 1), 2.0)).to(dev)
+    w, b = _rand("lf.w", (N, K), 0.05).to(dev), _rand("lf.b", (N,), 0.1).to(dev)
+    g, be = (1 + 0.1 * _rand("lf.g", (K,))).to(dev), (0.1 * _rand("lf.be", (K,))).to(dev)
+    wg, c, d = ops.ln_fold_weights(w, b, g, be)
+    assert torch.equal(wg, w * g)                                             # one fp32 rounding per element
+    assert rel_l2(c.cpu(), (w * g).double().sum(1).cpu()) < 1e-7
+    assert rel_l2(d.cpu(), (b.double() + w.double() @ be.double()).cpu()) < 1e-7
+    xd = x.double()
+    part = ops.row_partials(x)
+    assert part.shape == (M, K // 32, 2)
+    slabs = xd.view(M, K // 32, 32)
+    assert rel_l2(part[..., 0].cpu(), slabs.sum(-1).cpu()) < 1e-6 and rel_l2(part[..., 1].cpu(), (slabs ** 2).sum(-1).cpu()) < 1e-6
+    ref = ops.linear(ops.layernorm(x, g, be), w, b, act=act, scale=0.125, scale_cols=scale_cols)
+    want = O.layer_norm(xd, g.double(), be.double()) @ w.double().t() + b.double()
+    want[:, :scale_cols] *= 0.125
+    if act:
+        want = O.gelu_erf(want)
+    e_ref = rel_l2(ref.cpu(), want.cpu())
+    for stats in (part, None):                                                # from the partial sums / summed in the GEMM
+        y = ops.linear_lnfold(x, wg, c, d, stats, act=act, scale=0.125, scale_cols=scale_cols)
+        e_fold = rel_l2(y.cpu(), want.cpu())
+        assert e_fold < 3e-6 and e_fold < 2.0 * e_ref + 2e-7, (stats is None, e_fold, e_ref)
+        assert float((y.double() - want).abs().max()) < 1e-4 * float(want.abs().max())
+        # bit-identical under either tile width and any block order (each element: same K order, same epilogue arithmetic)
+        try:
+            ops.set_param("gemm_tile", 2)
+            assert torch.equal(ops.linear_lnfold(x, wg, c, d, stats, act=act, scale=0.125, scale_cols=scale_cols), y)
+            ops.set_param("gemm_tile", 1)
+            assert torch.equal(ops.linear_lnfold(x, wg, c, d, stats, act=act, scale=0.125, scale_cols=scale_cols), y)
+        finally:
+            ops.set_param("gemm_tile", 0)
+        # a sub-range of output features (what the outputs-only forward does with k|v and q): same bits
+        if N >= 256:
+            sub = ops.linear_lnfold(x, wg[128:], c[128:], d[128:], stats, act=act, scale=0.125, scale_cols=max(0, scale_cols - 128))
+            assert torch.equal(sub, y[:, 128:])
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 128, 64), (300, 768, 768), (1025, 768, 3072), (200, 256, 96)])
+def test_residual_gemm_leaves_the_row_sums_of_what_it_stores(dev, M, N, K):
+    """rnamsm_gemm_residual_stats (out_proj / fc2 + residual add): the output is bit-identical to the plain residual GEMM's
+    and row_partials [M, N/32, 2] are the (sum, sum of squares) of the stored values per 32-column slab -- under both tile
+    widths, in place (Cout = residual) as the forward runs it."""
+    from rnamsm import ops
+    a, w, b = _rand("rs.a", (M, K)).to(dev), _rand("rs.w", (N, K), 0.05).to(dev), _rand("rs.b", (N,), 0.1).to(dev)
+    res = (_rand("rs.r", (M, N), 2.0) + 1.5).to(dev)
+    plain = ops.linear(a, w, b, residual=res)
+    for tile in (1, 2, 0):
+        try:
+            ops.set_param("gemm_tile", tile)
+            x = res.clone()
+            out, part = ops.linear_residual_stats(a, w, b, x, out=x)
+        finally:
+            ops.set_param("gemm_tile", 0)
+        assert out.data_ptr() == x.data_ptr() and torch.equal(out, plain)
+        slabs = out.double().view(M, N // 32, 32)
+        assert rel_l2(part[..., 0].cpu(), slabs.sum(-1).cpu()) < 1e-6
+        assert rel_l2(part[..., 1].cpu(), (slabs ** 2).sum(-1).cpu()) < 1e-6
+        # the slab sums are those of rnamsm_row_partials on the stored tensor, up to the order of 32 additions
+        again = ops.row_partials(out)
+        assert rel_l2(part.cpu(), again.cpu()) < 1e-6
+
+
 def test_gemm_is_exact_on_integers(dev):
     """Exact-integer data: every product and partial sum is representable, so the MFMA path must be bit-exact, and an
     asymmetric W catches a transposed or permuted tile (cdna_hip_programming.md §3)."""
