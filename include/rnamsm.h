@@ -357,8 +357,9 @@ void rnamsm_timing_reset(void);
  *                 0 = register-staged 64-key chunks, two blocks per CU; -1 (default) = chosen from the shape.  Speed only
  *                 (the two kernels run the same arithmetic per 32-key tile; results agree to fp32 rounding).
  *   "ln_fold"     rnamsm_forward with ln_folded given: 1 (default) = LayerNorm folded into the QKV / fc1 GEMMs, row sums
- *                 left by the out_proj / fc2 epilogues; 2 = folded, every GEMM sums the rows it stages itself; 0 = separate
- *                 LayerNorm launches (all three agree to fp32 rounding).
+ *                 left by the out_proj / fc2 epilogues, for MSAs of R*C >= 16384 tokens (below that the separate launches
+ *                 are faster); 3 = for every shape; 2 = folded, every GEMM sums the rows it stages itself; 0 = separate
+ *                 LayerNorm launches (all agree to fp32 rounding).
  *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit
  *                 matrix cores in the mode's operand format (K4'..K7'), 0 = they stay on the exact-fp32 kernels,
  *                 2 = as 1 but the row kernels keep 128x128 tiles for every C (A/B of the 256x256-tile kernels).

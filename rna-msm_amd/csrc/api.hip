@@ -135,7 +135,7 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         return RNAMSM_OK;
     }
     if (name && !strcmp(name, "ln_fold")) {
-        rnamsm::tuning().ln_fold = value < 0 ? 0 : (value > 2 ? 2 : value);
+        rnamsm::tuning().ln_fold = value < 0 ? 0 : (value > 3 ? 3 : value);
         return RNAMSM_OK;
     }
     if (name && !strcmp(name, "gemm16_mfma16")) {

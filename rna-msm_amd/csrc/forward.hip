@@ -146,7 +146,12 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     // Exact path without padding, folded weights given: the three LayerNorms of a layer are applied inside the GEMMs they
     // feed (gemm_f32.hip FOLD) -- norm() is then no launch at all, lin_normed() reads x itself and res_linear() (the GEMMs
     // that write x) leaves the row sums the next lin_normed() normalises with.
-    const bool fold = ln_folded && dtype == RNAMSM_F32 && !has_padding && tuning().ln_fold != 0;
+    // Measured (tools/ln_fold_ab.py): -1.0 % at M = L = 1024, -0.6 % at M=256 L=512, +-0 at 128x256, +1.3 % at 64x128 (the
+    // folded epilogues cost there what the small LayerNorm launches save) -- hence the token threshold of mode 1.
+    const int fold_mode = tuning().ln_fold;          // 0 off, 1 by shape, 2 GEMMs sum their own rows, 3 always
+    const bool fold = ln_folded && dtype == RNAMSM_F32 && !has_padding &&
+                      (fold_mode >= 2 || (fold_mode == 1 && (int64_t)R * C >= 16384));
+    const bool fold_sums = fold && fold_mode != 2;   // row sums travel from the residual epilogues to the consumers
     float* rowsum = reinterpret_cast<float*>(ws + lay.rowsum);
     auto norm = [&](const float* g, const float* b, int64_t rows) -> int {
         if (fold) return RNAMSM_OK;
@@ -154,7 +159,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     };
     // x[:rows] += A W^T + bias on the exact path
     auto res_linear = [&](const float* A, int64_t lda, const float* Wf, const float* bias, int64_t rows, int K) -> int {
-        if (fold && tuning().ln_fold == 1)
+        if (fold_sums)
             return rnamsm_gemm_residual_stats(A, lda, Wf, bias, x, D, x, D, rows, D, K, rowsum, f32, stream);
         return rnamsm_gemm_bias_act_res(A, lda, Wf, bias, x, D, x, D, rows, D, K, RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream);
     };
@@ -163,7 +168,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
                           int64_t rows, int N, int act, float scale, int scale_cols) -> int {
         if (fold) {
             const float* const* Fp = ln_folded + (size_t)layer * RNAMSM_FOLDED_PER_LAYER + 3 * fslot;
-            return rnamsm_gemm_lnfold(x, D, Fp[0] + (size_t)n_ofs * D, Fp[1] + n_ofs, Fp[2] + n_ofs, d.ln_eps, tuning().ln_fold == 1 ? rowsum : nullptr, out, ldc, rows, N, D,
+            return rnamsm_gemm_lnfold(x, D, Fp[0] + (size_t)n_ofs * D, Fp[1] + n_ofs, Fp[2] + n_ofs, d.ln_eps, fold_sums ? rowsum : nullptr, out, ldc, rows, N, D,
                                       act, scale, scale_cols, f32, stream);
         }
         return rnamsm_gemm_bias_act_res(xn, D, Wf + (size_t)n_ofs * D, bias + n_ofs, nullptr, 0, out, ldc, rows, N, D, act, scale,
@@ -180,7 +185,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     FWD(rnamsm_embed_ln(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
                         G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, R, C, D, d.vocab, d.num_positions,
                         d.pad_idx, d.ln_eps, err_flag, stream));
-    if (fold && tuning().ln_fold == 1) FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
+    if (fold_sums) FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
     for (int l = 0; l < NL; ++l) {
         const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
         float* probs = row_attn + (int64_t)l * H * C * C;

@@ -66,20 +66,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     const WaveCoord w = wave_coord();
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
 
+    // FOLD = 2: the K/32 slab sums of row m0 + tid (threads 0..127), requested first and added up after tile 0 has been
+    // staged (their latency hides behind the first operand tile's)
+    constexpr int PV = FOLD == 2 ? 16 : 1;                          // K <= 1024: at most 32 slabs = 16 float4
+    f32x4 pv[PV];
     if (FOLD == 2 && threadIdx.x < BM) {
-        // (mean, rstd) of row m0 + tid from the K/32 slab sums its producer left; visible to the epilogue through the
-        // barriers of the K loop
-        const int nslots = K / 32;                                   // even: K % 64 == 0 is checked by the launcher
-        const f32x4* pp = reinterpret_cast<const f32x4*>(row_partials + (int64_t)min(m0 + (int)threadIdx.x, M - 1) * nslots * 2);
-        float a = 0.f, b = 0.f;
-        for (int j = 0; j < nslots / 2; ++j) {
-            const f32x4 v = pp[j];
-            a += v[0]; b += v[1];
-            a += v[2]; b += v[3];
-        }
-        const float mean = a / (float)K;
-        const float var = fmaxf(b / (float)K - mean * mean, 0.f);
-        reinterpret_cast<float2*>(smem + Cfg::LDS_BYTES / 4)[threadIdx.x] = float2{mean, rsqrtf(var + ln_eps)};
+        const f32x4* pp = reinterpret_cast<const f32x4*>(row_partials + (int64_t)min(m0 + (int)threadIdx.x, M - 1) * (K / 32) * 2);
+#pragma unroll
+        for (int j = 0; j < PV; ++j)
+            if (j < K / 64) pv[j] = pp[j];
     }
 
     // per-thread global row pointers (A rows clamped: a clamped row only feeds its own discarded output row)
@@ -120,6 +115,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
                     s1[i] += (sa[i][0] + sa[i][1]) + (sa[i][2] + sa[i][3]);
                     s2[i] = fmaf(sa[i][0], sa[i][0], fmaf(sa[i][1], sa[i][1], fmaf(sa[i][2], sa[i][2], fmaf(sa[i][3], sa[i][3], s2[i]))));
                 }
+            }
+        },
+        [&]() {
+            if (FOLD == 2 && threadIdx.x < BM) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int j = 0; j < PV; ++j)
+                    if (j < K / 64) {
+                        a += pv[j][0]; b += pv[j][1];
+                        a += pv[j][2]; b += pv[j][3];
+                    }
+                const float mean = a / (float)K;
+                const float var = fmaxf(b / (float)K - mean * mean, 0.f);
+                reinterpret_cast<float2*>(smem + Cfg::LDS_BYTES / 4)[threadIdx.x] = float2{mean, rsqrtf(var + ln_eps)};
             }
         });
     if (FOLD == 1) {
@@ -338,8 +347,8 @@ extern "C" int rnamsm_gemm_lnfold(const float* X, int64_t ldx, const float* Wg, 
     RNAMSM_CHECK_ARG(aligned16(X) && aligned16(Wg) && aligned16(cvec) && aligned16(dvec) && aligned16(Cout),
                      "gemm_lnfold: 16-byte alignment");
     RNAMSM_CHECK_ARG(ln_eps >= 0.f, "gemm_lnfold: negative eps");
-    RNAMSM_CHECK_ARG(!row_partials || (K % 64 == 0 && aligned16(row_partials)),
-                     "gemm_lnfold: row_partials needs K %% 64 == 0 and 16-byte alignment");
+    RNAMSM_CHECK_ARG(!row_partials || (K % 64 == 0 && K <= 1024 && aligned16(row_partials)),
+                     "gemm_lnfold: row_partials needs K %% 64 == 0, K <= 1024 and 16-byte alignment");
     RNAMSM_CHECK_ARG(scale_cols >= 0 && scale_cols % 4 == 0, "gemm_lnfold: scale_cols must be a multiple of 4");
     RNAMSM_CHECK_ARG(act == RNAMSM_ACT_NONE || act == RNAMSM_ACT_GELU_ERF, "gemm_lnfold: unknown activation %d", act);
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -178,15 +178,23 @@ __device__ __forceinline__ void kstep(int kt, bool do_store, bool do_load, bool 
 //            (64 MFMAs) of latency cover for first-touch HBM reads at +32 VGPRs.
 // `load(kt, SetTag<S>)` / `store(buf, SetTag<S>)` address the caller's staging registers by a compile-time set index
 // (runtime-indexed register arrays would go to scratch), hence the x2 unrolled loops.
-template <bool B_KC, int NV, int DEPTH, int NT = 2, int NWR = 0, class LoadFn, class StoreFn>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `after_first_tile()` runs once, after tile 0 is in LDS and tile 1's loads are in flight and before the first barrier: the
+// place for one-time work whose own global loads were issued before the loop (they return ahead of tile 0's) and whose
+// LDS results the epilogue needs.
+template <bool B_KC, int NV, int DEPTH, int NT = 2, int NWR = 0, class LoadFn, class StoreFn, class HookFn = NoHook>
 __device__ __forceinline__ void pipelined_kloop(int nk, float* As, float* Bs, int a_tile, int b_tile,
-                                                f32x16 (&acc)[2][NT], const WaveCoord& w, LoadFn load, StoreFn store) {
+                                                f32x16 (&acc)[2][NT], const WaveCoord& w, LoadFn load, StoreFn store,
+                                                HookFn after_first_tile = HookFn{}) {
     static_assert(DEPTH == 1 || DEPTH == 2, "prefetch depth");
     constexpr int S_ODD = DEPTH == 2 ? 1 : 0;       // set of odd tiles
     load(0, SetTag<0>{});
     store(0, SetTag<0>{});
     if (nk > 1) load(1, SetTag<S_ODD>{});
     if (DEPTH == 2 && nk > 2) load(2, SetTag<0>{});
+    after_first_tile();
     __syncthreads();
     FragT<NT> f0, f1;
     frag_load<B_KC, NT>(As, Bs, 0, w, f0);

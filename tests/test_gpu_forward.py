@@ -123,7 +123,12 @@ def test_layerwise_path_equals_driver_and_exposes_intermediate_layers(model):
         m.fold_layernorm = True
     assert rel_l2(res["representations"][10][0].cpu().numpy(), fast["repr"].cpu().numpy()) < 1e-6
     assert np.abs(res["row_attentions"][0].cpu().numpy() - fast["row_attn"].cpu().numpy()).max() < 1e-6
-    fold = m.forward_one(toks)            # ... and the driver's default (LayerNorm folded into the GEMMs) to rounding
+    from rnamsm import ops
+    try:
+        ops.set_param("ln_fold", 3)       # ... and the driver with LayerNorm folded into the GEMMs to rounding
+        fold = m.forward_one(toks)
+    finally:
+        ops.set_param("ln_fold", 1)
     assert rel_l2(fold["repr"].cpu().numpy(), fast["repr"].cpu().numpy()) < 1e-5
     assert np.abs(fold["row_attn"].cpu().numpy() - fast["row_attn"].cpu().numpy()).max() < 2e-5
 
@@ -451,16 +456,17 @@ def test_outputs_only_forward_is_bit_identical_and_skips_dead_rows(model, R, C):
 
 @pytest.mark.parametrize("R,C", [(8, 17), (64, 128), (33, 131), (1, 9), (130, 40)])
 def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model, R, C):
-    """K1 folded is the exact path's default on MSAs without padding: the QKV / fc1 GEMMs read the residual stream and
-    apply (mean, rstd) to their accumulators.  Against the same forward with separate LayerNorm launches (the `ln_fold`
-    knob and MSATransformer.fold_layernorm both switch it) the outputs agree to fp32 rounding, and against the oracle the
-    folded forward is no further away than the unfolded one (x1.5)."""
+    """K1 folded (the exact path's default on MSAs of >= 16384 tokens without padding; forced here with knob 3): the QKV /
+    fc1 GEMMs read the residual stream and apply (mean, rstd) to their accumulators.  Against the same forward with
+    separate LayerNorm launches (the `ln_fold` knob and MSATransformer.fold_layernorm both switch it) the outputs agree to
+    fp32 rounding, and against the oracle the folded forward is no further away than the unfolded one (x1.5)."""
     from rnamsm import ops
     m, state = model
     tokens = synthetic.make_tokens(R, C, 5)
     toks = torch.from_numpy(tokens).to("cuda:0")
-    fold = m.forward_one(toks, has_padding=False)
     try:
+        ops.set_param("ln_fold", 3)                                          # folded at every shape (default: >= 16384 tokens)
+        fold = m.forward_one(toks, has_padding=False)
         ops.set_param("ln_fold", 0)
         plain = m.forward_one(toks, has_padding=False)
     finally:
@@ -487,10 +493,30 @@ def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model,
     # padded MSAs keep the separate launches (and their exact reference mask semantics): the flag is simply not used
     ptoks = toks.clone()
     ptoks[-1, -2:] = 1
-    a = m.forward_one(ptoks)
     try:
+        ops.set_param("ln_fold", 3)
+        a = m.forward_one(ptoks)
         ops.set_param("ln_fold", 0)
         b = m.forward_one(ptoks)
     finally:
         ops.set_param("ln_fold", 1)
     assert torch.equal(a["emb"], b["emb"]) and torch.equal(a["atp"], b["atp"])
+    # the default picks by size: below 16384 tokens the separate launches (they are faster there), from there on the fold
+    dflt = m.forward_one(toks, has_padding=False)
+    assert torch.equal(dflt["emb"], (fold if R * C >= 16384 else plain)["emb"])
+
+
+def test_folded_layernorm_is_the_default_from_16384_tokens(model):
+    from rnamsm import ops
+    m, _ = model
+    toks = torch.from_numpy(synthetic.make_tokens(128, 128, 2)).to("cuda:0")
+    dflt = m.forward_one(toks, has_padding=False)
+    try:
+        ops.set_param("ln_fold", 3)
+        forced = m.forward_one(toks, has_padding=False)
+        ops.set_param("ln_fold", 0)
+        plain = m.forward_one(toks, has_padding=False)
+    finally:
+        ops.set_param("ln_fold", 1)
+    assert torch.equal(dflt["emb"], forced["emb"]) and torch.equal(dflt["atp"], forced["atp"])
+    assert not torch.equal(dflt["emb"], plain["emb"]) and rel_l2(dflt["emb"].cpu().numpy(), plain["emb"].cpu().numpy()) < 2e-5
