@@ -180,14 +180,18 @@ __device__ __forceinline__ void kstep(int kt, bool do_store, bool do_load, bool 
 // (runtime-indexed register arrays would go to scratch), hence the x2 unrolled loops.
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
+    __device__ __forceinline__ void operator()(int) const {}
 };
 // `after_first_tile()` runs once, after tile 0 is in LDS and tile 1's loads are in flight and before the first barrier: the
 // place for one-time work whose own global loads were issued before the loop (they return ahead of tile 0's) and whose
 // LDS results the epilogue needs.
-template <bool B_KC, int NV, int DEPTH, int NT = 2, int NWR = 0, class LoadFn, class StoreFn, class HookFn = NoHook>
+// `after_tiles(done)` runs after every pair of K tiles (done = tiles finished so far, even, or nk at the very end): the
+// place to fold the accumulators into a second set at fixed K boundaries (row_logits: bounded fp32 accumulation chains).
+template <bool B_KC, int NV, int DEPTH, int NT = 2, int NWR = 0, class LoadFn, class StoreFn, class HookFn = NoHook,
+          class TilesFn = NoHook>
 __device__ __forceinline__ void pipelined_kloop(int nk, float* As, float* Bs, int a_tile, int b_tile,
                                                 f32x16 (&acc)[2][NT], const WaveCoord& w, LoadFn load, StoreFn store,
-                                                HookFn after_first_tile = HookFn{}) {
+                                                HookFn after_first_tile = HookFn{}, TilesFn after_tiles = TilesFn{}) {
     static_assert(DEPTH == 1 || DEPTH == 2, "prefetch depth");
     constexpr int S_ODD = DEPTH == 2 ? 1 : 0;       // set of odd tiles
     load(0, SetTag<0>{});
@@ -202,6 +206,7 @@ __device__ __forceinline__ void pipelined_kloop(int nk, float* As, float* Bs, in
     for (; kt + 2 + DEPTH < nk; kt += 2) {           // both steps are full: (kt + 1) + 1 + DEPTH < nk
         kstep<B_KC, NV, DEPTH, S_ODD, true, NT, NWR>(kt, true, true, true, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
         kstep<B_KC, NV, DEPTH, 0, true, NT, NWR>(kt + 1, true, true, true, As, Bs, a_tile, b_tile, acc, w, f0, f1, load, store);
+        after_tiles(kt + 2);
     }
 #pragma unroll 1
     for (; kt < nk; kt += 2) {                       // kt even: tile kt+1 is odd -> set S_ODD
@@ -210,6 +215,7 @@ __device__ __forceinline__ void pipelined_kloop(int nk, float* As, float* Bs, in
         if (kt + 1 < nk)
             kstep<B_KC, NV, DEPTH, 0, false, NT, NWR>(kt + 1, kt + 2 < nk, kt + 2 + DEPTH < nk, kt + 2 < nk, As, Bs, a_tile,
                                                  b_tile, acc, w, f0, f1, load, store);
+        after_tiles(kt + 2 < nk ? kt + 2 : nk);
     }
 }
 

@@ -27,9 +27,14 @@ constexpr int ROWAPPLY_VT_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;
 // ---------------------------------------------------------------------------------------------- K4
 // grid.x = xcd-mapped (panel = (head, split), inner = tiles_i * tiles_j): the 16 tiles of one (head, split) share
 // the same q/k row range, so they are placed on one XCD and re-read it from that L2.
+// chain_tiles: after every chain_tiles K tiles (= chain_tiles / 2 alignment rows) the MFMA accumulators are added into a
+// second register set and restarted, so no fp32 accumulation chain is longer than chain_tiles * 32 terms however many
+// rows the block's slab covers (row_split.h: the accuracy of the exact path hangs on it); the chain sums are added in
+// order.  A slab of 32 rows in four chains replaces four slabs of 8 rows: a quarter of the slab writes here and of the
+// slab reads in K5, and four times the K loop per block prologue / epilogue.
 __global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int64_t ld, float* __restrict__ partial,
-    int R, int C, int H, int nsplit, int rows_per_split) {
+    int R, int C, int H, int nsplit, int rows_per_split, int chain_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;
     float* Ks = smem + 2 * TILE_KC;
@@ -54,8 +59,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
         koff[s] = (int64_t)j * ld + h * HEAD_DIM + c4 * 4;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], total[2][2];
     zero_acc(acc);
+    zero_acc(total);
 
     const int nk = (r_end - r_begin) * (HEAD_DIM / BK);      // K tile kt = (row r_begin + kt/2, d half kt&1)
     auto tile_base = [&](int kt) -> int64_t {
@@ -76,6 +82,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
         [&](int buf, auto) {
             stage_store_kc(Qs + buf * TILE_KC, sq);
             stage_store_kc(Ks + buf * TILE_KC, sk);
+        },
+        NoHook{},
+        [&](int done) {
+            if (done % chain_tiles == 0 || done == nk) {      // chain_tiles is even, `done` walks the even numbers
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        total[mt][nt] += acc[mt][nt];
+#pragma unroll
+                        for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
+                    }
+            }
         });
 
     float* out = partial + ((int64_t)split * H + h) * C * C;
@@ -87,7 +106,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int i = i0 + acc_row(w, mt, t);
-                if (i < C && j < C) out[(int64_t)i * C + j] = acc[mt][nt][t];
+                if (i < C && j < C) out[(int64_t)i * C + j] = total[mt][nt][t];
             }
     }
 }
@@ -360,7 +379,8 @@ static int row_logits_launch(const float* q, const float* k, int64_t ld, float* 
     KernelTimer timer(TC_ROW_LOGITS, 2.0 * H * C * C * R * HEAD_DIM,
                       4.0 * (2.0 * R * C * H * HEAD_DIM + (double)sp.nsplit * H * C * C), static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(row_logits_kernel, dim3(grid), dim3(GEMM_THREADS), ROWLOGITS_LDS_BYTES,
-                       static_cast<hipStream_t>(stream), q, k, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split);
+                       static_cast<hipStream_t>(stream), q, k, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split,
+                       ROW_LOGITS_F32_CHAIN_ROWS * (HEAD_DIM / BK));
     RNAMSM_CHECK_LAUNCH("row_logits");
     return RNAMSM_OK;
 }

@@ -17,7 +17,7 @@ struct RowSplit {
 // 64 r terms and its rounding error grows with r, while the slabs themselves are added pairwise-like by K5.  Measured
 // against an fp64 truth at M=256 x L=512 (tests/analysis/error_sources.py): chains of 4096 / 2048 / 1024 / 512 / 256 terms leave
 // the 10-layer embedding 1.26e-4 / 7.1e-5 / 4.1e-5 / 3.2e-5 / 3.1e-5 from the truth -- the reference's own CPU arithmetic
-// (blocked sgemm) sits at 3.2e-5.  The fp32 kernel therefore caps a split at 8 rows (512 terms).
+// (blocked sgemm) sits at 3.2e-5.  The fp32 kernel therefore keeps every chain at 8 rows (512 terms).
 inline RowSplit choose_row_split(int R, int C, int H, int tile = 128, int slots = 512, int max_rows = 0) {
     const long tiles = (long)((C + tile - 1) / tile) * ((C + tile - 1) / tile) * H;
     const int min_ns = max_rows > 0 ? (R + max_rows - 1) / max_rows : 1;
@@ -43,6 +43,9 @@ inline RowSplit choose_row_split(int R, int C, int H, int tile = 128, int slots 
     return s;
 }
 
-constexpr int ROW_LOGITS_F32_MAX_ROWS = 8;     // fp32 row_logits: <= 512-term accumulation chains (see above)
+// fp32 row_logits: the kernel restarts its accumulators every CHAIN_ROWS rows (<= 512-term chains, see above) and adds
+// the chain sums in order, so a slab may cover MAX_ROWS rows (four chains) without lengthening any chain.
+constexpr int ROW_LOGITS_F32_CHAIN_ROWS = 8;
+constexpr int ROW_LOGITS_F32_MAX_ROWS = 32;
 
 }  // namespace rnamsm

@@ -37,7 +37,7 @@ int main(void) {
     EXPECT(rnamsm_device_count() >= 0);
 
     /* pure host functions, at ordinary and extreme shapes (integer arithmetic under UBSan) */
-    EXPECT(rnamsm_row_logits_nsplit(256, 512, 12) == 32);     /* 8-row slabs: 512-term fp32 chains */
+    EXPECT(rnamsm_row_logits_nsplit(256, 512, 12) == 8);      /* 32-row slabs, accumulated as four 512-term fp32 chains */
     EXPECT(rnamsm_row_logits_nsplit(0, 512, 12) == 0 && rnamsm_row_logits_nsplit(-5, -5, -5) == 0);
     EXPECT(rnamsm_row_logits_nsplit(1024, 1025, 12) >= 1);
     EXPECT(rnamsm_row_logits_workspace_bytes(1024, 1025, 12) >= (size_t)12 * 1025 * 1025 * 4);

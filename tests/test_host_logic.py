@@ -212,12 +212,13 @@ def test_ctypes_signatures_match_the_header_prototypes():
 
 def test_library_validates_arguments_without_a_gpu(lib):
     from rnamsm import _lib
-    # deterministic function of the shape; fp32 slabs are capped at 8 rows = 512-term accumulation chains (row_split.h)
-    assert lib.rnamsm_row_logits_nsplit(256, 512, 12) == 32
-    assert lib.rnamsm_row_logits_workspace_bytes(256, 512, 12) == 32 * 12 * 512 * 512 * 4
+    # deterministic function of the shape; an fp32 slab covers at most 32 rows, which the kernel accumulates as four chains
+    # of 8 rows = 512 terms (row_split.h)
+    assert lib.rnamsm_row_logits_nsplit(256, 512, 12) == 8
+    assert lib.rnamsm_row_logits_workspace_bytes(256, 512, 12) == 8 * 12 * 512 * 512 * 4
     for R in (1, 7, 8, 9, 100, 512, 1024):
         n = lib.rnamsm_row_logits_nsplit(R, 36, 12)
-        assert n >= (R + 7) // 8 and -(-R // n) <= 8, (R, n)
+        assert n >= (R + 31) // 32 and -(-R // n) <= 32, (R, n)
     dims = _lib.ModelDims(10, 768, 12, 3072, 12, 1026, 1, 1e-5)
     import ctypes
     need = lib.rnamsm_forward_workspace_bytes(ctypes.byref(dims), 256, 512, 0, 0)
@@ -226,7 +227,7 @@ def test_library_validates_arguments_without_a_gpu(lib):
     assert lib.rnamsm_row_logits16_nsplit(256, 512, 12, 1) == 8     # plain bf16 stays on the 128x128 kernel
     assert lib.rnamsm_row_logits16_nsplit(256, 100, 12, 3) == 37     # small C: 128x128 tiles, split by block count only
     assert lib.rnamsm_row_logits16_workspace_bytes(256, 512, 12) == 16 * 12 * 512 * 512 * 4
-    assert need >= T * 768 * 4 * 6 + 32 * 12 * 512 * 512 * 4 + T and need < T * 768 * 4 * 7.2
+    assert need >= T * 768 * 4 * 6 + 16 * 12 * 512 * 512 * 4 + T and need < T * 768 * 4 * 7.2
     rc = lib.rnamsm_gemm_bias_act_res(None, 0, None, None, None, 0, None, 0, 4, 128, 32, 0, 1.0, 0, None, 0, None)
     assert rc == -1 and b"null pointer" in lib.rnamsm_last_error()
     rc = lib.rnamsm_gemm_bias_act_res(16, 32, 16, None, None, 0, 16, 100, 4, 100, 32, 0, 1.0, 0, None, 0, None)
