@@ -76,7 +76,7 @@ int rnamsm_layernorm(const float* x, const float* gamma, const float* beta, floa
  *   Wg = W * gamma (per input feature k),  c[n] = sum_k Wg[n,k],  d[n] = b[n] + sum_k W[n,k] * beta[k]
  * so the GEMM reads the residual stream itself: no normalised copy of it is written or re-read (806 MB per LayerNorm at
  * M=256 L=512) and LayerNorm is no launch at all.  The statistics come from whoever wrote x: `row_partials`
- * [M, K/32, 2] holds (sum x, sum x^2) of every row per 32-feature slab; mean = sum / K, biased variance =
+ * [K/32, M, 2] (slab-major) holds (sum x, sum x^2) of every row per 32-feature slab; mean = sum / K, biased variance =
  * E[x^2] - mean^2 in fp32 (meant for rows whose |mean| is not much larger than their spread, like a residual stream).
  * Results agree with LayerNorm -> Linear to fp32 rounding (different association; against an fp64 truth the two are
  * equally far from it: tests/analysis/ln_fold_numerics.py, tests/test_gpu_fullsize.py).
@@ -85,20 +85,22 @@ int rnamsm_layernorm(const float* x, const float* gamma, const float* beta, floa
  *   rnamsm_row_partials        row_partials of x [T, D] as it lies in memory (D % 32 == 0, D <= 1024): for an x that did
  *                              not come out of rnamsm_gemm_residual_stats (the embedding)
  *   rnamsm_gemm_residual_stats Cout = A W^T + bias + residual (K8: out_proj / fc2 + the residual add, modules.py:396) and
- *                              row_partials [M, N/32, 2] of the Cout it stores; requirements of rnamsm_gemm_bias_act_res
+ *                              row_partials [N/32, M, 2] of the Cout it stores; requirements of rnamsm_gemm_bias_act_res
  *   rnamsm_gemm_lnfold         Cout[m,n] = act( (rstd[m] * (sum_k X[m,k] Wg[n,k] - mean[m] c[n]) + d[n]) * (n < scale_cols ? scale : 1) )
- *                              X [M,K] row stride ldx; row_partials [M, K/32, 2] (K % 64 == 0) or NULL = the block sums the
+ *                              X [M,K] row stride ldx; row_partials [K/32, M, 2] (K <= 1024) or NULL = the block sums the
  *                              rows it stages itself (self-contained, ~2.6 % slower); eps = ln_eps; requirements of
- *                              rnamsm_gemm_bias_act_res, scale_cols % 4 == 0 */
+ *                              rnamsm_gemm_bias_act_res, scale_cols % 4 == 0
+ * partials_ld = rows per slab of the row_partials buffer (>= M: a GEMM over the first M rows of a longer buffer, as the
+ * outputs-only forward runs them, addresses it with the buffer's own slab stride) */
 int rnamsm_ln_fold_weights(const float* W, const float* bias, const float* gamma, const float* beta, float* Wg,
                            float* cvec, float* dvec, int N, int K, void* stream);
 int rnamsm_row_partials(const float* x, float* row_partials, int64_t T, int D, void* stream);
 int rnamsm_gemm_residual_stats(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                                int64_t ldr, float* Cout, int64_t ldc, int64_t M, int N, int K, float* row_partials,
-                               int dtype, void* stream);
+                               int64_t partials_ld, int dtype, void* stream);
 int rnamsm_gemm_lnfold(const float* X, int64_t ldx, const float* Wg, const float* cvec, const float* dvec,
-                       float ln_eps, const float* row_partials, float* Cout, int64_t ldc, int64_t M, int N, int K,
-                       int act, float scale, int scale_cols, int dtype, void* stream);
+                       float ln_eps, const float* row_partials, int64_t partials_ld, float* Cout, int64_t ldc,
+                       int64_t M, int N, int K, int act, float scale, int scale_cols, int dtype, void* stream);
 
 /* K2/K3/K8 -- nn.Linear with fused epilogue (modules.py:760-766, 794-799, 896-905, 923, 424-426, 396):
  *   Cout[m,n] = act( (sum_k A[m,k]*W[n,k] + bias[n]) * (n < scale_cols ? scale : 1) ) + residual[m,n]
@@ -357,7 +359,7 @@ void rnamsm_timing_reset(void);
  *                 0 = register-staged 64-key chunks, two blocks per CU; -1 (default) = chosen from the shape.  Speed only
  *                 (the two kernels run the same arithmetic per 32-key tile; results agree to fp32 rounding).
  *   "ln_fold"     rnamsm_forward with ln_folded given: 1 (default) = LayerNorm folded into the QKV / fc1 GEMMs, row sums
- *                 left by the out_proj / fc2 epilogues, for MSAs of R*C >= 16384 tokens (below that the separate launches
+ *                 left by the out_proj / fc2 epilogues, for MSAs of R*C >= 4096 tokens (below that the separate launches
  *                 are faster); 3 = for every shape; 2 = folded, every GEMM sums the rows it stages itself; 0 = separate
  *                 LayerNorm launches (all agree to fp32 rounding).
  *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit

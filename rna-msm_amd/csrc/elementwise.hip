@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     }
 }
 
-// K1 folded into the consuming GEMM (gemm_f32.hip FOLD = 2): the row partial sums [T, D/32, 2] = (sum x, sum x^2) per
-// 32-column slab, in the format the residual GEMM epilogues leave them -- for a residual stream that did not come out of
+// K1 folded into the consuming GEMM (gemm_f32.hip FOLD = 2): the row partial sums [D/32, T, 2] = (sum x, sum x^2) per
+// 32-column slab (slab-major), in the format the residual GEMM epilogues leave them -- for a residual stream that did not come out of
 // one (the embedding, K0).  One wave per row; the 8 lanes of a slab add up on the DPP path.
 __device__ __forceinline__ float sum8_dpp_e(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -70,7 +70,7 @@ __device__ __forceinline__ float sum8_dpp_e(float v) {
 __global__ __launch_bounds__(256) void row_partials_kernel(const float* __restrict__ x, float2* __restrict__ partials,
                                                            int64_t T, int D) {
     const int lane = threadIdx.x & 63;
-    const int nvec = D / 4, nslots = D / 32;
+    const int nvec = D / 4;
     const int64_t stride = (int64_t)gridDim.x * 4;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += stride) {
 #pragma unroll
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void row_partials_kernel(const float* __restri
             if (vi < nvec) v = *reinterpret_cast<const f32x4*>(x + row * D + 4 * vi);
             const float ps = sum8_dpp_e((v[0] + v[1]) + (v[2] + v[3]));
             const float pq = sum8_dpp_e(fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3]))));
-            if ((lane & 7) == 0 && vi < nvec) partials[row * nslots + vi / 8] = float2{ps, pq};
+            if ((lane & 7) == 0 && vi < nvec) partials[(int64_t)(vi / 8) * T + row] = float2{ps, pq};
         }
     }
 }

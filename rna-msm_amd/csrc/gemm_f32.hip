@@ -9,7 +9,9 @@
 //   Wg = W * gamma (columnwise),  c[n] = sum_k Wg[n,k],  d[n] = b[n] + sum_k W[n,k] beta[k]   (rnamsm_ln_fold_weights)
 // so the normalised copy of x is never written or read (806 MB per LayerNorm at cfg3) and LayerNorm is no launch at all:
 // the statistics come from whoever WROTE x.  STATS: the residual epilogue (out_proj / fc2, which produce the residual
-// stream) leaves per row and 32-column slab the partial (sum x, sum x^2) of what it stores: row_partials [M, N/32, 2];
+// stream) leaves per row and 32-column slab the partial (sum x, sum x^2) of what it stores: row_partials [N/32, M, 2]
+// (slab-major: a wave's 64 rows of one slab are 512 contiguous bytes -- row-major 8-byte pieces cost a read-modify-write
+// each and made this epilogue 50 us per launch slower);
 // FOLD = 2: the consuming block adds the K/32 partials of each of its 128 rows once, before its K loop, and keeps
 // (mean, rstd) in LDS for the epilogue (biased variance as E[x^2] - mean^2 in fp32).  FOLD = 1 is the self-contained
 // form (no partials given): the block sums x and x^2 of the rows it stages while the tiles go to LDS -- measured: those
@@ -51,7 +53,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc,
     int M, int N, int K, float scale, int scale_cols, const uint8_t* __restrict__ zero_rows, int group,
-    const float* __restrict__ fold_c, float ln_eps, float* row_partials) {
+    const float* __restrict__ fold_c, float ln_eps, float* row_partials, int64_t pld) {
     using Cfg = GemmCfg<NT>;
     constexpr int BN_ = Cfg::BN_, TILE_W = Cfg::TILE_W;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -68,13 +70,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
 
     // FOLD = 2: the K/32 slab sums of row m0 + tid (threads 0..127), requested first and added up after tile 0 has been
     // staged (their latency hides behind the first operand tile's)
-    constexpr int PV = FOLD == 2 ? 16 : 1;                          // K <= 1024: at most 32 slabs = 16 float4
-    f32x4 pv[PV];
+    constexpr int PV = FOLD == 2 ? 32 : 1;                          // K <= 1024: at most 32 slabs
+    float2 pv[PV];
     if (FOLD == 2 && threadIdx.x < BM) {
-        const f32x4* pp = reinterpret_cast<const f32x4*>(row_partials + (int64_t)min(m0 + (int)threadIdx.x, M - 1) * (K / 32) * 2);
+        const float2* pp = reinterpret_cast<const float2*>(row_partials) + min(m0 + (int)threadIdx.x, M - 1);
 #pragma unroll
-        for (int j = 0; j < PV; ++j)
-            if (j < K / 64) pv[j] = pp[j];
+        for (int j = 0; j < PV; ++j) pv[j] = pp[(int64_t)min(j, K / 32 - 1) * pld];      // branch-free; extra slots are not added
     }
 
     // per-thread global row pointers (A rows clamped: a clamped row only feeds its own discarded output row)
@@ -122,9 +123,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
                 float a = 0.f, b = 0.f;
 #pragma unroll
                 for (int j = 0; j < PV; ++j)
-                    if (j < K / 64) {
-                        a += pv[j][0]; b += pv[j][1];
-                        a += pv[j][2]; b += pv[j][3];
+                    if (j < K / 32) {
+                        a += pv[j].x;
+                        b += pv[j].y;
                     }
                 const float mean = a / (float)K;
                 const float var = fmaxf(b / (float)K - mean * mean, 0.f);
@@ -168,31 +169,38 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
             res[i] = epi_load(reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn));
         }
     }
-    f32x4 fc4, fd4;
-    if (FOLD) {
-        fc4 = *reinterpret_cast<const f32x4*>(fold_c + gn);
-        fd4 = *reinterpret_cast<const f32x4*>(bias + gn);
-    }
     __syncthreads();                                              // every wave has finished reading operand tiles
-    float2 st[NP];                                                // FOLD: (mean, rstd) of this lane's rows
+    // FOLD: (mean, rstd) of the 32 rows this lane's accumulators belong to (acc_row: (t&3) + 8(t>>2) + 4 lh + 32 mt); the
+    // two lane halves read two addresses per instruction (broadcast), and the fold runs where the bias add does, ahead
+    // of the GELU and of the transpose
+    float2 st[FOLD ? 32 : 1];
     if (FOLD) {
-        const float2* sst = reinterpret_cast<const float2*>(smem + Cfg::LDS_BYTES / 4);
+        const float2* sst = reinterpret_cast<const float2*>(smem + Cfg::LDS_BYTES / 4) + w.wm * 64 + 4 * w.lh;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) st[i] = sst[w.wm * 64 + er + RPP * i];
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) st[mt * 16 + t] = sst[mt * 32 + (t & 3) + 8 * (t >> 2)];
     }
     float* stage = smem + wv * (64 * LDE);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = n0 + w.wn * 32 * NT + nt * 32 + w.li;
-        const float b = (!FOLD && bias) ? bias[col] : 0.f;
-        const float sc = (!FOLD && col < scale_cols) ? scale : 1.f;
+        const float b = bias ? bias[col] : 0.f;                   // FOLD: d[n]
+        const float sc = col < scale_cols ? scale : 1.f;
+        const float fc = FOLD ? fold_c[col] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {                    // pairs: the GELU runs on the packed-fp32 VALU
-                f32x2 v = FOLD ? f32x2{acc[mt][nt][t], acc[mt][nt][t + 1]}      // raw sums: LN is applied per row below
-                               : f32x2{(acc[mt][nt][t] + b) * sc, (acc[mt][nt][t + 1] + b) * sc};
-                if (!FOLD && ACT == RNAMSM_ACT_GELU_ERF) v = gelu_erf2(v);
+                f32x2 v;
+                if (FOLD) {
+                    const float2 s0 = st[mt * 16 + t], s1 = st[mt * 16 + t + 1];
+                    v = f32x2{fmaf(s0.y, fmaf(-s0.x, fc, acc[mt][nt][t]), b) * sc,
+                              fmaf(s1.y, fmaf(-s1.x, fc, acc[mt][nt][t + 1]), b) * sc};
+                } else {
+                    v = f32x2{(acc[mt][nt][t] + b) * sc, (acc[mt][nt][t + 1] + b) * sc};
+                }
+                if (ACT == RNAMSM_ACT_GELU_ERF) v = gelu_erf2(v);
                 stage[(mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * w.lh) * LDE + nt * 32 + w.li] = v[0];
                 stage[(mt * 32 + ((t + 1) & 3) + 8 * ((t + 1) >> 2) + 4 * w.lh) * LDE + nt * 32 + w.li] = v[1];
             }
@@ -205,25 +213,38 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     for (int i = 0; i < NP; ++i) {
         const int r = er + RPP * i;
         ov[i] = *reinterpret_cast<const f32x4*>(&stage[r * LDE + ec]);
-        if (FOLD) {
-            const float fs = gn < scale_cols ? scale : 1.f;      // scale_cols % 4 == 0: a lane's 4 columns share it
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ov[i][e] = fmaf(st[i].y, fmaf(-st[i].x, fc4[e], ov[i][e]), fd4[e]) * fs;
-            if (ACT == RNAMSM_ACT_GELU_ERF) {
-                const f32x2 g0 = gelu_erf2(f32x2{ov[i][0], ov[i][1]}), g1 = gelu_erf2(f32x2{ov[i][2], ov[i][3]});
-                ov[i] = f32x4{g0[0], g0[1], g1[0], g1[1]};
-            }
-        }
         if (HAS_RES) ov[i] += res[i];
-        if (STATS) {
-            // what this lane stores of row r: 4 of the 32 columns its group of 8 lanes covers
-            const float ps = sum8_dpp((ov[i][0] + ov[i][1]) + (ov[i][2] + ov[i][3]));
-            const float pq = sum8_dpp(fmaf(ov[i][0], ov[i][0], fmaf(ov[i][1], ov[i][1], fmaf(ov[i][2], ov[i][2], ov[i][3] * ov[i][3]))));
-            if ((lane & 7) == 0 && gm0 + r < M)
-                reinterpret_cast<float2*>(row_partials)[(int64_t)(gm0 + r) * (N / 32) + gn / 32] = float2{ps, pq};
-        }
         // f2: q *= 1 - padding_mask (modules.py:767-772): padded tokens get q = 0 (the scaled columns are q)
         if (ZROWS && gn < scale_cols && zero_rows[min(gm0 + r, M - 1)]) ov[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (STATS) {
+        // What this lane stores of row r: 4 of the 32 columns its group of 8 lanes covers.  A second pass over the finished
+        // values (an LDS write inside the read loop above would order every later read of the staging tile behind it); the
+        // group sums are parked in the 4 padding columns of the row's staging slot (2 floats per 32-column slab, never
+        // read as data) ...
+        float ps[NP], pq[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            ps[i] = (ov[i][0] + ov[i][1]) + (ov[i][2] + ov[i][3]);
+            pq[i] = fmaf(ov[i][0], ov[i][0], fmaf(ov[i][1], ov[i][1], fmaf(ov[i][2], ov[i][2], ov[i][3] * ov[i][3])));
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            ps[i] = sum8_dpp(ps[i]);
+            pq[i] = sum8_dpp(pq[i]);
+        }
+        if ((lane & 7) == 0) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                *reinterpret_cast<float2*>(&stage[(er + RPP * i) * LDE + 32 * NT + 2 * (ec / 32)]) = float2{ps[i], pq[i]};
+        }
+        // ... and leave lane = row: one 512-byte run per slab (slab-major [N/32, M, 2]) instead of 8-byte pieces
+        float2* pout = reinterpret_cast<float2*>(row_partials) + (int64_t)((n0 + w.wn * 32 * NT) / 32) * pld + gm0 + lane;
+#pragma unroll
+        for (int sl = 0; sl < NT; ++sl) {
+            const float2 pr = *reinterpret_cast<const float2*>(&stage[lane * LDE + 32 * NT + 2 * sl]);
+            if (gm0 + lane < M) pout[(int64_t)sl * pld] = pr;
+        }
     }
     if (m0 + BM <= M) {
 #pragma unroll
@@ -239,7 +260,7 @@ template <int ACT, bool HAS_RES, bool ZROWS, int NT, int FOLD = 0, bool STATS = 
 static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                           int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
                           const uint8_t* zero_rows, hipStream_t stream, const float* fold_c = nullptr,
-                          float ln_eps = 0.f, float* row_partials = nullptr) {
+                          float ln_eps = 0.f, float* row_partials = nullptr, int64_t pld = 0) {
     using Cfg = GemmCfg<NT>;
     static DeviceOnce configured;
     auto kern = gemm_f32_kernel<ACT, HAS_RES, ZROWS, NT, FOLD, STATS>;
@@ -259,7 +280,7 @@ static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const flo
     // algorithmic work: 2MNK flops; bytes = A + W + C once (+ residual read)
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), FOLD ? Cfg::LDS_FOLD : Cfg::LDS_BYTES, stream, A, lda, W, bias,
-                       residual, ldr, Cout, ldc, M, N, K, scale, scale_cols, zero_rows, group, fold_c, ln_eps, row_partials);
+                       residual, ldr, Cout, ldc, M, N, K, scale, scale_cols, zero_rows, group, fold_c, ln_eps, row_partials, pld);
     RNAMSM_CHECK_LAUNCH("gemm_f32");
     return RNAMSM_OK;
 }
@@ -295,25 +316,25 @@ static int launch_gemm(const float* A, int64_t lda, const float* W, const float*
 
 template <int ACT, int FOLD>
 static int launch_gemm_fold(const float* X, int64_t ldx, const float* Wg, const float* cvec, const float* dvec,
-                            float ln_eps, const float* row_partials, float* Cout, int64_t ldc, int M, int N, int K,
-                            float scale, int scale_cols, hipStream_t stream) {
+                            float ln_eps, const float* row_partials, int64_t pld, float* Cout, int64_t ldc, int M, int N,
+                            int K, float scale, int scale_cols, hipStream_t stream) {
     float* rp = const_cast<float*>(row_partials);                  // read-only in the FOLD kernels
     if (half_width_tiles_win(M, N))
         return launch_gemm_nt<ACT, false, false, 1, FOLD>(X, ldx, Wg, dvec, nullptr, 0, Cout, ldc, M, N, K, scale, scale_cols,
-                                                          nullptr, stream, cvec, ln_eps, rp);
+                                                          nullptr, stream, cvec, ln_eps, rp, pld);
     return launch_gemm_nt<ACT, false, false, 2, FOLD>(X, ldx, Wg, dvec, nullptr, 0, Cout, ldc, M, N, K, scale, scale_cols,
-                                                      nullptr, stream, cvec, ln_eps, rp);
+                                                      nullptr, stream, cvec, ln_eps, rp, pld);
 }
 
 // residual GEMM that also leaves the row partial sums of what it stores (the producer side of the folded LayerNorm)
 static int launch_gemm_res_stats(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                                  int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float* row_partials,
-                                 hipStream_t stream) {
+                                 int64_t pld, hipStream_t stream) {
     if (half_width_tiles_win(M, N))
         return launch_gemm_nt<RNAMSM_ACT_NONE, true, false, 1, 0, true>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, 1.f, 0,
-                                                                        nullptr, stream, nullptr, 0.f, row_partials);
+                                                                        nullptr, stream, nullptr, 0.f, row_partials, pld);
     return launch_gemm_nt<RNAMSM_ACT_NONE, true, false, 2, 0, true>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, 1.f, 0,
-                                                                    nullptr, stream, nullptr, 0.f, row_partials);
+                                                                    nullptr, stream, nullptr, 0.f, row_partials, pld);
 }
 
 }  // namespace rnamsm
@@ -322,7 +343,7 @@ using namespace rnamsm;
 
 extern "C" int rnamsm_gemm_residual_stats(const float* A, int64_t lda, const float* W, const float* bias,
                                           const float* residual, int64_t ldr, float* Cout, int64_t ldc, int64_t M, int N,
-                                          int K, float* row_partials, int dtype, void* stream) {
+                                          int K, float* row_partials, int64_t partials_ld, int dtype, void* stream) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "gemm_residual_stats: only RNAMSM_F32 is implemented");
     RNAMSM_CHECK_ARG(A && W && Cout && residual && row_partials, "gemm_residual_stats: null pointer");
     RNAMSM_CHECK_ARG(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "gemm_residual_stats: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
@@ -331,13 +352,14 @@ extern "C" int rnamsm_gemm_residual_stats(const float* A, int64_t lda, const flo
                      "gemm_residual_stats: bad leading dimension");
     RNAMSM_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(Cout) && aligned16(residual) && aligned16(row_partials),
                      "gemm_residual_stats: 16-byte alignment");
-    return launch_gemm_res_stats(A, lda, W, bias, residual, ldr, Cout, ldc, (int)M, N, K, row_partials,
+    RNAMSM_CHECK_ARG(partials_ld >= M, "gemm_residual_stats: partials_ld (rows per slab of row_partials) must be >= M");
+    return launch_gemm_res_stats(A, lda, W, bias, residual, ldr, Cout, ldc, (int)M, N, K, row_partials, partials_ld,
                                  static_cast<hipStream_t>(stream));
 }
 
 extern "C" int rnamsm_gemm_lnfold(const float* X, int64_t ldx, const float* Wg, const float* cvec, const float* dvec,
-                                  float ln_eps, const float* row_partials, float* Cout, int64_t ldc, int64_t M, int N,
-                                  int K, int act, float scale, int scale_cols, int dtype, void* stream) {
+                                  float ln_eps, const float* row_partials, int64_t partials_ld, float* Cout, int64_t ldc,
+                                  int64_t M, int N, int K, int act, float scale, int scale_cols, int dtype, void* stream) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "gemm_lnfold: only RNAMSM_F32 is implemented");
     RNAMSM_CHECK_ARG(X && Wg && cvec && dvec && Cout, "gemm_lnfold: null pointer");
     RNAMSM_CHECK_ARG(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "gemm_lnfold: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
@@ -347,13 +369,13 @@ extern "C" int rnamsm_gemm_lnfold(const float* X, int64_t ldx, const float* Wg, 
     RNAMSM_CHECK_ARG(aligned16(X) && aligned16(Wg) && aligned16(cvec) && aligned16(dvec) && aligned16(Cout),
                      "gemm_lnfold: 16-byte alignment");
     RNAMSM_CHECK_ARG(ln_eps >= 0.f, "gemm_lnfold: negative eps");
-    RNAMSM_CHECK_ARG(!row_partials || (K % 64 == 0 && K <= 1024 && aligned16(row_partials)),
-                     "gemm_lnfold: row_partials needs K %% 64 == 0, K <= 1024 and 16-byte alignment");
+    RNAMSM_CHECK_ARG(!row_partials || (K <= 1024 && (reinterpret_cast<uintptr_t>(row_partials) & 7u) == 0 && partials_ld >= M),
+                     "gemm_lnfold: row_partials needs K <= 1024, 8-byte alignment and partials_ld >= M");
     RNAMSM_CHECK_ARG(scale_cols >= 0 && scale_cols % 4 == 0, "gemm_lnfold: scale_cols must be a multiple of 4");
     RNAMSM_CHECK_ARG(act == RNAMSM_ACT_NONE || act == RNAMSM_ACT_GELU_ERF, "gemm_lnfold: unknown activation %d", act);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define RNAMSM_FOLD_DISPATCH(ACT_, FOLD_) \
-    launch_gemm_fold<ACT_, FOLD_>(X, ldx, Wg, cvec, dvec, ln_eps, row_partials, Cout, ldc, (int)M, N, K, scale, scale_cols, s)
+    launch_gemm_fold<ACT_, FOLD_>(X, ldx, Wg, cvec, dvec, ln_eps, row_partials, partials_ld, Cout, ldc, (int)M, N, K, scale, scale_cols, s)
     if (act == RNAMSM_ACT_GELU_ERF) return row_partials ? RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_GELU_ERF, 2) : RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_GELU_ERF, 1);
     return row_partials ? RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_NONE, 2) : RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_NONE, 1);
 #undef RNAMSM_FOLD_DISPATCH

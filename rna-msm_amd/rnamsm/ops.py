@@ -131,11 +131,11 @@ def ln_fold_weights(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.
 
 @_on_operand_device
 def row_partials(x: torch.Tensor) -> torch.Tensor:
-    """(sum x, sum x^2) of every row of x [T, D] per 32-feature slab: [T, D/32, 2], the statistics format of the folded
-    LayerNorm (include/rnamsm.h, K1 folded)."""
+    """(sum x, sum x^2) of every row of x [T, D] per 32-feature slab, slab-major: [D/32, T, 2], the statistics format of
+    the folded LayerNorm (include/rnamsm.h, K1 folded)."""
     D = x.shape[-1]
     x2 = x.contiguous().view(-1, D)
-    out = torch.empty(x2.shape[0], D // 32, 2, device=x2.device, dtype=torch.float32)
+    out = torch.empty(D // 32, x2.shape[0], 2, device=x2.device, dtype=torch.float32)
     _lib.check(_lib.load().rnamsm_row_partials(_dev(x2, "x"), out.data_ptr(), x2.shape[0], D, _stream()))
     return out
 
@@ -144,16 +144,16 @@ def row_partials(x: torch.Tensor) -> torch.Tensor:
 def linear_residual_stats(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], residual: torch.Tensor,
                           out: Optional[torch.Tensor] = None):
     """(out, row_partials): out = a @ w.T + bias + residual (may be in place: out = residual) and the row partial sums
-    [M, N/32, 2] of the stored out -- the producer side of the folded LayerNorm."""
+    [N/32, M, 2] of the stored out -- the producer side of the folded LayerNorm."""
     M, K = a.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, device=a.device, dtype=torch.float32)
-    part = torch.empty(M, N // 32, 2, device=a.device, dtype=torch.float32)
+    part = torch.empty(N // 32, M, 2, device=a.device, dtype=torch.float32)
     _lib.check(_lib.load().rnamsm_gemm_residual_stats(
         _dev(a, "a"), _rowmajor(a, "a"), _dev(w.contiguous(), "w"), None if bias is None else _dev(bias, "bias"),
         _dev(residual, "residual"), _rowmajor(residual, "residual"), _dev(out, "out"), _rowmajor(out, "out"), M, N, K,
-        part.data_ptr(), F32, _stream()))
+        part.data_ptr(), M, F32, _stream()))
     return out, part
 
 
@@ -162,14 +162,16 @@ def linear_lnfold(x: torch.Tensor, wg: torch.Tensor, c: torch.Tensor, d: torch.T
                   eps: float = 1e-5, act: int = ACT_NONE, scale: float = 1.0, scale_cols: int = 0,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act((rstd * (x @ wg.T - mean * c) + d) * (col < scale_cols ? scale : 1)) = act(Linear(LayerNorm(x)) ...): the GEMM
-    reads x itself; (wg, c, d) from ln_fold_weights; each row's (mean, rstd) from `partials` [M, K/32, 2] (row_partials /
-    linear_residual_stats), or summed by the GEMM itself when None."""
+    reads x itself; (wg, c, d) from ln_fold_weights; each row's (mean, rstd) from `partials` [K/32, M, 2] (row_partials /
+    linear_residual_stats; it may cover more rows than x: x = the first M rows of a longer stream), or summed by the GEMM
+    itself when None."""
     M, K = x.shape
     N = wg.shape[0]
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
     _lib.check(_lib.load().rnamsm_gemm_lnfold(_dev(x, "x"), _rowmajor(x, "x"), _dev(wg, "wg"), _dev(c, "c"), _dev(d, "d"),
-                                              eps, None if partials is None else _dev(partials, "partials"), _dev(out, "out"),
+                                              eps, None if partials is None else _dev(partials, "partials"),
+                                              M if partials is None else partials.shape[1], _dev(out, "out"),
                                               _rowmajor(out, "out"), M, N, K, act, scale, scale_cols, F32, _stream()))
     return out
 

@@ -456,7 +456,7 @@ def test_outputs_only_forward_is_bit_identical_and_skips_dead_rows(model, R, C):
 
 @pytest.mark.parametrize("R,C", [(8, 17), (64, 128), (33, 131), (1, 9), (130, 40)])
 def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model, R, C):
-    """K1 folded (the exact path's default on MSAs of >= 16384 tokens without padding; forced here with knob 3): the QKV /
+    """K1 folded (the exact path's default on MSAs of >= 4096 tokens without padding; forced here with knob 3): the QKV /
     fc1 GEMMs read the residual stream and apply (mean, rstd) to their accumulators.  Against the same forward with
     separate LayerNorm launches (the `ln_fold` knob and MSATransformer.fold_layernorm both switch it) the outputs agree to
     fp32 rounding, and against the oracle the folded forward is no further away than the unfolded one (x1.5)."""
@@ -465,7 +465,7 @@ def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model,
     tokens = synthetic.make_tokens(R, C, 5)
     toks = torch.from_numpy(tokens).to("cuda:0")
     try:
-        ops.set_param("ln_fold", 3)                                          # folded at every shape (default: >= 16384 tokens)
+        ops.set_param("ln_fold", 3)                                          # folded at every shape (default: >= 4096 tokens)
         fold = m.forward_one(toks, has_padding=False)
         ops.set_param("ln_fold", 0)
         plain = m.forward_one(toks, has_padding=False)
@@ -501,15 +501,15 @@ def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model,
     finally:
         ops.set_param("ln_fold", 1)
     assert torch.equal(a["emb"], b["emb"]) and torch.equal(a["atp"], b["atp"])
-    # the default picks by size: below 16384 tokens the separate launches (they are faster there), from there on the fold
+    # the default picks by size: below 4096 tokens the separate launches (they are faster there), from there on the fold
     dflt = m.forward_one(toks, has_padding=False)
-    assert torch.equal(dflt["emb"], (fold if R * C >= 16384 else plain)["emb"])
+    assert torch.equal(dflt["emb"], (fold if R * C >= 4096 else plain)["emb"])
 
 
-def test_folded_layernorm_is_the_default_from_16384_tokens(model):
+def test_folded_layernorm_is_the_default_from_4096_tokens(model):
     from rnamsm import ops
     m, _ = model
-    toks = torch.from_numpy(synthetic.make_tokens(128, 128, 2)).to("cuda:0")
+    toks = torch.from_numpy(synthetic.make_tokens(64, 64, 2)).to("cuda:0")
     dflt = m.forward_one(toks, has_padding=False)
     try:
         ops.set_param("ln_fold", 3)

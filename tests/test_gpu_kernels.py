@@ -68,8 +68,8 @@ def test_layernorm_folded_into_the_gemm(dev, M, N, K, act, scale_cols):
     assert rel_l2(d.cpu(), (b.double() + w.double() @ be.double()).cpu()) < 1e-7
     xd = x.double()
     part = ops.row_partials(x)
-    assert part.shape == (M, K // 32, 2)
-    slabs = xd.view(M, K // 32, 32)
+    assert part.shape == (K // 32, M, 2)                                      # slab-major
+    slabs = xd.view(M, K // 32, 32).transpose(0, 1)
     assert rel_l2(part[..., 0].cpu(), slabs.sum(-1).cpu()) < 1e-6 and rel_l2(part[..., 1].cpu(), (slabs ** 2).sum(-1).cpu()) < 1e-6
     ref = ops.linear(ops.layernorm(x, g, be), w, b, act=act, scale=0.125, scale_cols=scale_cols)
     want = O.layer_norm(xd, g.double(), be.double()) @ w.double().t() + b.double()
@@ -96,10 +96,36 @@ def test_layernorm_folded_into_the_gemm(dev, M, N, K, act, scale_cols):
             assert torch.equal(sub, y[:, 128:])
 
 
+def test_folded_gemm_over_the_first_rows_of_a_longer_stream(dev):
+    """The outputs-only forward runs its last q projection / FFN over alignment row 0 only: the first C rows of x, with
+    the row sums of all T rows lying slab-major in one buffer (partials_ld = T).  Same bits as the full-length GEMM's
+    first rows; a producer over the first rows writes into that layout too."""
+    from rnamsm import ops
+    T, Mq, D, N = 700, 140, 256, 384
+    x = (_rand("ls.x", (T, D), 2.0) + 0.7).to(dev)
+    w, b = _rand("ls.w", (N, D), 0.05).to(dev), _rand("ls.b", (N,), 0.1).to(dev)
+    g, be = (1 + 0.1 * _rand("ls.g", (D,))).to(dev), (0.1 * _rand("ls.be", (D,))).to(dev)
+    wg, c, d = ops.ln_fold_weights(w, b, g, be)
+    part = ops.row_partials(x)                                             # [D/32, T, 2]
+    full = ops.linear_lnfold(x, wg, c, d, part)
+    head = ops.linear_lnfold(x[:Mq], wg, c, d, part)                       # partials_ld = T > M = Mq
+    assert torch.equal(head, full[:Mq])
+    # producer over the first Mq rows, writing into the T-row layout: only those rows' sums change
+    from rnamsm import _lib
+    a, wo, bo = _rand("ls.a", (Mq, D)).to(dev), _rand("ls.wo", (D, D), 0.05).to(dev), _rand("ls.bo", (D,), 0.1).to(dev)
+    x2, part2 = x.clone(), part.clone()
+    _lib.check(_lib.load().rnamsm_gemm_residual_stats(a.data_ptr(), D, wo.data_ptr(), bo.data_ptr(), x2.data_ptr(), D,
+                                                      x2.data_ptr(), D, Mq, D, D, part2.data_ptr(), T, 0,
+                                                      torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(x2[Mq:], x[Mq:]) and torch.equal(part2[:, Mq:], part[:, Mq:])
+    assert rel_l2(part2[:, :Mq].cpu(), ops.row_partials(x2[:Mq].contiguous()).cpu()) < 1e-6
+    assert rel_l2(x2[:Mq].cpu(), (x[:Mq].double() + a.double() @ wo.double().t() + bo.double()).cpu()) < 2e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(5, 128, 64), (300, 768, 768), (1025, 768, 3072), (200, 256, 96)])
 def test_residual_gemm_leaves_the_row_sums_of_what_it_stores(dev, M, N, K):
     """rnamsm_gemm_residual_stats (out_proj / fc2 + residual add): the output is bit-identical to the plain residual GEMM's
-    and row_partials [M, N/32, 2] are the (sum, sum of squares) of the stored values per 32-column slab -- under both tile
+    and row_partials [N/32, M, 2] are the (sum, sum of squares) of the stored values per 32-column slab -- under both tile
     widths, in place (Cout = residual) as the forward runs it."""
     from rnamsm import ops
     a, w, b = _rand("rs.a", (M, K)).to(dev), _rand("rs.w", (N, K), 0.05).to(dev), _rand("rs.b", (N,), 0.1).to(dev)
@@ -113,7 +139,8 @@ def test_residual_gemm_leaves_the_row_sums_of_what_it_stores(dev, M, N, K):
         finally:
             ops.set_param("gemm_tile", 0)
         assert out.data_ptr() == x.data_ptr() and torch.equal(out, plain)
-        slabs = out.double().view(M, N // 32, 32)
+        slabs = out.double().view(M, N // 32, 32).transpose(0, 1)
+        assert part.shape == (N // 32, M, 2)
         assert rel_l2(part[..., 0].cpu(), slabs.sum(-1).cpu()) < 1e-6
         assert rel_l2(part[..., 1].cpu(), (slabs ** 2).sum(-1).cpu()) < 1e-6
         # the slab sums are those of rnamsm_row_partials on the stored tensor, up to the order of 32 additions
