@@ -358,6 +358,8 @@ void rnamsm_timing_reset(void);
  *   "col_dma"     fp32 rnamsm_col_attn_fused: 1 = K/V chunks staged by LDS-DMA, 32-key chunks, three blocks per CU;
  *                 0 = register-staged 64-key chunks, two blocks per CU; -1 (default) = chosen from the shape.  Speed only
  *                 (the two kernels run the same arithmetic per 32-key tile; results agree to fp32 rounding).
+ *   "greedy_fused"  rnamsm_greedy_select: 1 (default) = one launch per step (one wave per row) for alignments of up to 3072
+ *                 rows, three launches per step (one thread per row) above; 2 = always one; 0 = always three.  Same indices.
  *   "ln_fold"     rnamsm_forward with ln_folded given: 1 (default) = LayerNorm folded into the QKV / fc1 GEMMs, row sums
  *                 left by the out_proj / fc2 epilogues, for MSAs of R*C >= 4096 tokens (below that the separate launches
  *                 are faster); 3 = for every shape; 2 = folded, every GEMM sums the rows it stages itself; 0 = separate

@@ -134,6 +134,10 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().attn16 = value;
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "greedy_fused")) {
+        rnamsm::tuning().greedy_fused = value < 0 ? 0 : (value > 2 ? 2 : value);
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "ln_fold")) {
         rnamsm::tuning().ln_fold = value < 0 ? 0 : (value > 3 ? 3 : value);
         return RNAMSM_OK;
@@ -167,6 +171,7 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "gemm16_dma")) return rnamsm::tuning().gemm16_dma;
     if (name && !strcmp(name, "attn16")) return rnamsm::tuning().attn16;
     if (name && !strcmp(name, "ln_fold")) return rnamsm::tuning().ln_fold;
+    if (name && !strcmp(name, "greedy_fused")) return rnamsm::tuning().greedy_fused;
     if (name && !strcmp(name, "col_dma")) return rnamsm::tuning().col_dma;
     if (name && !strcmp(name, "row16_max_rows")) return rnamsm::tuning().row16_max_rows;
     if (name && !strcmp(name, "gemm16_persist")) return rnamsm::tuning().gemm16_persist;

@@ -13,7 +13,10 @@
 // history of every candidate at every step in exactly that order (pairwise_mean below), from a (L+1)-entry table of
 // m / L, so the selected indices are bit-identical to the reference's (tests: the shipped 1176-row 2DRB_1 alignment ->
 // 512 rows, where a plain running sum goes a different way at step 46).
-// Roofline: HBM/L2-bound; per step N*L bytes of compares + 2*step*N bytes of history, three small launches.
+// Roofline: HBM/L2-bound; per step N*L bytes of compares + 2*step*N bytes of history.  The steps are sequential (step s
+// compares against the row step s-1 picked), so for alignments of a few thousand rows the cost is the per-step latency:
+// there ONE launch per step (greedy_step_kernel: distances, re-reduced means, block argmax, and the grid-wide argmax by
+// whichever block finishes last) replaces three; deeper alignments keep the three kernels (one thread per row).
 #include "common.h"
 
 namespace rnamsm {
@@ -77,6 +80,143 @@ __global__ __launch_bounds__(256) void greedy_score_kernel(const uint16_t* __res
     score[row] = minimise ? -mean : mean;          // argmin as argmax of the negated value
 }
 
+// ---- one launch per step ---------------------------------------------------------------------------------------
+// One WAVE per row (four rows per block): the distance to the last pick over 64 lanes, then the row's score -- numpy's
+// pairwise sum over its distance history, evaluated in numpy's exact order but with its independent pieces side by side:
+// the recursion's leaves (<= 128 terms each, <= 32 of them) go to the wave's eight 8-lane groups, a leaf's eight
+// interleaved accumulators r[0..7] to the eight lanes of a group, and the leaf sums are then added along the recursion
+// tree.  The history is kept row-major here ([N][S], one row's steps contiguous: a wave reads 128-byte runs).
+__device__ __forceinline__ bool greedy_better(double v, int i, double bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+template <int DEPTH>
+__device__ __forceinline__ double greedy_combine(int n, const double* __restrict__ leaf, int& k) {
+    if (n <= 128 || DEPTH == 0) return leaf[k++];
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    constexpr int D1 = DEPTH > 0 ? DEPTH - 1 : 0;
+    const double lo = greedy_combine<D1>(n2, leaf, k);
+    const double hi = greedy_combine<D1>(n - n2, leaf, k);
+    return lo + hi;
+}
+
+// grid = ceil(N / 4).  blk_v / blk_i: one candidate per block; *counter: blocks finished this step (reset by the last).
+__global__ __launch_bounds__(256) void greedy_step_kernel(const uint8_t* __restrict__ msa, int N, int L, int S, int* chosen,
+                                                          int step, uint16_t* __restrict__ hist,
+                                                          const double* __restrict__ lut, uint8_t* taken, int minimise,
+                                                          double* blk_v, int* blk_i, unsigned* counter) {
+    __shared__ int s_off[4][32], s_len[4][32];       // n <= 2047 terms: a split piece has >= 64 terms, so <= 32 leaves
+    __shared__ double s_leaf[4][32];
+    __shared__ double sv[4];
+    __shared__ int si[4];
+    __shared__ int last_block;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wv;
+    double v = -INFINITY;
+    int bi = 0x7fffffff;
+    if (row < N) {                                                   // wave-uniform
+        // ---- Hamming distance to the row picked last
+        const uint8_t* a = msa + (int64_t)row * L;
+        const uint8_t* b = msa + (int64_t)chosen[step - 1] * L;
+        int m = 0;
+        if ((L & 3) == 0 && ((reinterpret_cast<uintptr_t>(msa)) & 3u) == 0) {
+            const uint32_t* a4 = reinterpret_cast<const uint32_t*>(a);
+            const uint32_t* b4 = reinterpret_cast<const uint32_t*>(b);
+            for (int c = lane; c < L / 4; c += 64) {
+                const uint32_t x = a4[c] ^ b4[c];
+                m += __popc((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);      // bytes that differ
+            }
+        } else {
+            for (int c = lane; c < L; c += 64) m += a[c] != b[c];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m += __shfl_xor(m, off, 64);
+        uint16_t* h = hist + (int64_t)row * S;
+        if (lane == 0) h[step - 1] = (uint16_t)m;
+        if (!taken[row]) {
+            // term i of the row's history; the newest one comes from the register (the store above need not be visible)
+            auto term = [&](int i) -> double { return lut[i == step - 1 ? m : (int)h[i]]; };
+            // ---- leaves of numpy's recursion over n = step terms, in depth-first (= left to right) order
+            int nleaf = 0, maxlen = 0;
+            {
+                int so[8], sn[8], sp = 1;
+                so[0] = 0; sn[0] = step;
+                while (sp) {
+                    --sp;
+                    const int o = so[sp], n = sn[sp];
+                    if (n <= 128) {
+                        if (lane == 0) { s_off[wv][nleaf] = o; s_len[wv][nleaf] = n; }
+                        maxlen = n > maxlen ? n : maxlen;
+                        ++nleaf;
+                    } else {
+                        int n2 = n / 2;
+                        n2 -= n2 % 8;
+                        so[sp] = o + n2; sn[sp] = n - n2; ++sp;      // right half is popped after ...
+                        so[sp] = o; sn[sp] = n2; ++sp;               // ... the left half
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int g = lane >> 3, j = lane & 7;
+            for (int base = 0; base < nleaf; base += 8) {
+                const int k = base + g;
+                const int o = k < nleaf ? s_off[wv][k] : 0, n = k < nleaf ? s_len[wv][k] : 0;
+                const int full = n >= 8 ? n - n % 8 : 0;
+                double r = full ? term(o + j) : 0.0;                 // r[j] = a[j]
+                for (int i = 8; i < maxlen; i += 8)
+                    if (i < full) r += term(o + i + j);              // r[j] += a[i + j]
+                double res = r + __shfl_xor(r, 1, 64);               // (r0+r1), (r2+r3), ...
+                res = res + __shfl_xor(res, 2, 64);                  // (r0+r1)+(r2+r3), ...
+                res = res + __shfl_xor(res, 4, 64);                  // ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7))
+                if (n < 8) res = 0.0;                                // n < 8: plain sequential sum from 0
+                for (int i = 0; i < 7; ++i)
+                    if (full + i < n) res += term(o + full + i);     // the n % 8 trailing terms, one after the other
+                if (j == 0 && k < nleaf) s_leaf[wv][k] = res;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int k = 0;
+            const double mean = greedy_combine<5>(step, s_leaf[wv], k) / (double)step;
+            v = minimise ? -mean : mean;                             // argmin as argmax of the negated value
+            bi = row;
+        }
+    }
+    if (lane == 0) { sv[wv] = v; si[wv] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 4; ++q)
+            if (greedy_better(sv[q], si[q], v, bi)) { v = sv[q]; bi = si[q]; }
+        __hip_atomic_store(&blk_v[blockIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&blk_i[blockIdx.x], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // release the candidate, take a ticket; whoever draws the last one has (acquire) every block's candidate
+        const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_block = ticket == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last_block) return;
+    v = -INFINITY;
+    bi = 0x7fffffff;
+    for (int q = threadIdx.x; q < (int)gridDim.x; q += 256) {
+        const double ov = __hip_atomic_load(&blk_v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int oi = __hip_atomic_load(&blk_i[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (greedy_better(ov, oi, v, bi)) { v = ov; bi = oi; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (greedy_better(ov, oi, v, bi)) { v = ov; bi = oi; }
+    }
+    __syncthreads();                                   // sv / si of the block phase have been consumed
+    if (lane == 0) { sv[wv] = v; si[wv] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int q = 1; q < 4; ++q)
+            if (greedy_better(sv[q], si[q], v, bi)) { v = sv[q]; bi = si[q]; }
+        chosen[step] = bi;
+        taken[bi] = 1;
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // single block: argmax with first-index tie-break, records the pick
 __global__ __launch_bounds__(1024) void greedy_pick_kernel(const double* __restrict__ score, int N, int* chosen,
                                                            int step, uint8_t* taken) {
@@ -129,8 +269,9 @@ __global__ __launch_bounds__(1024) void greedy_compact_kernel(const uint8_t* __r
     }
 }
 
-__global__ void greedy_init_kernel(double* lut, int L, uint8_t* taken, int* chosen, int N) {
+__global__ void greedy_init_kernel(double* lut, int L, uint8_t* taken, int* chosen, int N, unsigned* counter) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0 && counter) *counter = 0u;
     if (n < N) taken[n] = n == 0;
     if (n <= L) lut[n] = (double)n / (double)L;      // cdist 'hamming': mismatches / L, one IEEE division
     if (n == 0) chosen[0] = 0;
@@ -178,19 +319,27 @@ extern "C" int rnamsm_msa_weights(const uint8_t* msa, int N, int L, double seqid
     return RNAMSM_OK;
 }
 
-static size_t greedy_ws(int N, int L, int num_seqs, size_t* o_score, size_t* o_chosen, size_t* o_taken, size_t* o_hist) {
+struct GreedyWs {
+    size_t score, chosen, taken, hist, blk_v, blk_i, counter, total;
+};
+static GreedyWs greedy_ws(int N, int L, int num_seqs) {
+    GreedyWs w;
     size_t off = ((size_t)L + 1) * 8;      // lut: m / L
-    *o_score = off;  off += (size_t)N * 8;
-    *o_chosen = off; off += ((size_t)num_seqs * 4 + 7) & ~(size_t)7;
-    *o_taken = off;  off += ((size_t)N + 7) & ~(size_t)7;
-    *o_hist = off;   off += ((size_t)(num_seqs > 1 ? num_seqs - 1 : 0) * (size_t)N * 2 + 7) & ~(size_t)7;
-    return off;
+    w.score = off;  off += (size_t)N * 8;
+    w.chosen = off; off += ((size_t)num_seqs * 4 + 7) & ~(size_t)7;
+    w.taken = off;  off += ((size_t)N + 7) & ~(size_t)7;
+    w.hist = off;   off += ((size_t)(num_seqs > 1 ? num_seqs - 1 : 0) * (size_t)N * 2 + 7) & ~(size_t)7;
+    const size_t nblk = ((size_t)N + 3) / 4;
+    w.blk_v = off;  off += nblk * 8;
+    w.blk_i = off;  off += (nblk * 4 + 7) & ~(size_t)7;
+    w.counter = off; off += 8;
+    w.total = off;
+    return w;
 }
 
 extern "C" size_t rnamsm_greedy_select_workspace_bytes(int N, int L, int num_seqs) {
     if (N <= 0 || L <= 0 || num_seqs <= 0) return 0;
-    size_t a, b, c, d;
-    return greedy_ws(N, L, num_seqs, &a, &b, &c, &d);
+    return greedy_ws(N, L, num_seqs).total;
 }
 
 extern "C" int rnamsm_greedy_select(const uint8_t* msa, int N, int L, int num_seqs, int minimise, int* out_indices,
@@ -198,23 +347,34 @@ extern "C" int rnamsm_greedy_select(const uint8_t* msa, int N, int L, int num_se
     RNAMSM_CHECK_ARG(msa && out_indices && workspace, "greedy_select: null pointer");
     RNAMSM_CHECK_ARG(N > 0 && L > 0 && num_seqs > 0 && num_seqs <= N, "greedy_select: bad shape N=%d L=%d num_seqs=%d", N, L, num_seqs);
     RNAMSM_CHECK_ARG(L < 65536 && num_seqs <= 2048, "greedy_select: L=%d must be < 65536 and num_seqs=%d <= 2048", L, num_seqs);
-    size_t o_score, o_chosen, o_taken, o_hist;
-    const size_t need = greedy_ws(N, L, num_seqs, &o_score, &o_chosen, &o_taken, &o_hist);
-    RNAMSM_CHECK_ARG(workspace_bytes >= need && (reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, "greedy_select: workspace too small or misaligned");
+    const GreedyWs w = greedy_ws(N, L, num_seqs);
+    RNAMSM_CHECK_ARG(workspace_bytes >= w.total && (reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, "greedy_select: workspace too small or misaligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(workspace);
     double* lut = reinterpret_cast<double*>(ws);
-    double* score = reinterpret_cast<double*>(ws + o_score);
-    int* chosen = reinterpret_cast<int*>(ws + o_chosen);
-    uint8_t* taken = reinterpret_cast<uint8_t*>(ws + o_taken);
-    uint16_t* hist = reinterpret_cast<uint16_t*>(ws + o_hist);
+    double* score = reinterpret_cast<double*>(ws + w.score);
+    int* chosen = reinterpret_cast<int*>(ws + w.chosen);
+    uint8_t* taken = reinterpret_cast<uint8_t*>(ws + w.taken);
+    uint16_t* hist = reinterpret_cast<uint16_t*>(ws + w.hist);
+    unsigned* counter = reinterpret_cast<unsigned*>(ws + w.counter);
     const int n_init = N > L + 1 ? N : L + 1;
-    hipLaunchKernelGGL(greedy_init_kernel, dim3((n_init + 255) / 256), dim3(256), 0, s, lut, L, taken, chosen, N);
-    for (int step = 1; step < num_seqs; ++step) {
-        hipLaunchKernelGGL(greedy_dist_kernel, dim3((N + 3) / 4), dim3(256), 0, s, msa, N, L, chosen, step, hist);
-        hipLaunchKernelGGL(greedy_score_kernel, dim3((N + 255) / 256), dim3(256), 0, s, hist, N, step, lut, taken, score,
-                           minimise);
-        hipLaunchKernelGGL(greedy_pick_kernel, dim3(1), dim3(1024), 0, s, score, N, chosen, step, taken);
+    hipLaunchKernelGGL(greedy_init_kernel, dim3((n_init + 255) / 256), dim3(256), 0, s, lut, L, taken, chosen, N, counter);
+    // one wave per row pays while the rows are few (measured, L = 1024: N = 2048 19 ms vs 32 ms; N = 8192 50 vs 37 ms;
+    // 2DRB_1's 1176 x 35 -> 512: 7.1 vs 9.6 ms): beyond ~3000 rows one THREAD per row re-reduces the history cheaper
+    if (tuning().greedy_fused == 2 || (tuning().greedy_fused == 1 && N <= 3072)) {
+        const int S = num_seqs - 1;                    // history row-major [N][S] on this path
+        double* blk_v = reinterpret_cast<double*>(ws + w.blk_v);
+        int* blk_i = reinterpret_cast<int*>(ws + w.blk_i);
+        for (int step = 1; step < num_seqs; ++step)
+            hipLaunchKernelGGL(greedy_step_kernel, dim3((N + 3) / 4), dim3(256), 0, s, msa, N, L, S, chosen, step, hist, lut,
+                               taken, minimise, blk_v, blk_i, counter);
+    } else {
+        for (int step = 1; step < num_seqs; ++step) {
+            hipLaunchKernelGGL(greedy_dist_kernel, dim3((N + 3) / 4), dim3(256), 0, s, msa, N, L, chosen, step, hist);
+            hipLaunchKernelGGL(greedy_score_kernel, dim3((N + 255) / 256), dim3(256), 0, s, hist, N, step, lut, taken, score,
+                               minimise);
+            hipLaunchKernelGGL(greedy_pick_kernel, dim3(1), dim3(1024), 0, s, score, N, chosen, step, taken);
+        }
     }
     hipLaunchKernelGGL(greedy_compact_kernel, dim3(1), dim3(1024), 0, s, taken, N, out_indices);
     RNAMSM_CHECK_LAUNCH("greedy_select");

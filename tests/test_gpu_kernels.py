@@ -400,6 +400,25 @@ def test_greedy_select_on_device_equals_host_and_reference(dev, full_2drb1_a2m):
             want = msa.greedy_select(toks, K, mode)
             got = msa.greedy_select_device(toks, K, mode, dev)
             assert np.array_equal(got, want), (N, L, K, mode)
+            # both launch schemes (one launch per step with a wave per row; three with a thread per row) on every case,
+            # whatever the default picks by depth
+            from rnamsm import ops
+            for scheme in (0, 2):
+                try:
+                    ops.set_param("greedy_fused", scheme)
+                    assert np.array_equal(msa.greedy_select_device(toks, K, mode, dev), want), (N, L, K, mode, scheme)
+                finally:
+                    ops.set_param("greedy_fused", 1)
+    # a history deeper than one leaf of numpy's pairwise recursion in every piece: 1023 steps (the model's limit)
+    N, L = 1100, 24
+    toks = np.concatenate([np.zeros((N, 1), np.int64), rng.choice([4, 5, 6, 7, 10], size=(N, L))], 1)
+    want = msa.greedy_select(toks, 1024, "max")
+    for scheme in (0, 2):
+        try:
+            ops.set_param("greedy_fused", scheme)
+            assert np.array_equal(msa.greedy_select_device(toks, 1024, "max", dev), want), scheme
+        finally:
+            ops.set_param("greedy_fused", 1)
 
 
 def test_msa_weights_on_device_equal_host_and_reference(dev, full_2drb1_a2m):
