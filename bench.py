@@ -474,6 +474,10 @@ def run_rank(args) -> int:
                            f"{'RCCL point-to-point' if args.backend == 'nccl' else args.backend + ' (host-staged)'}, "
                            f"round k overlapping the forward of round k+1; {headline_delivered} MSAs delivered in the timed region")
         base_cfg = "configs[3]" if batch else "configs[2]"
+        if batch and (M, L) != (128, 256):
+            base_cfg = "configs[3] at another MSA shape"
+        elif not batch and (M, L) != (256, 512):         # --num-seqs / --seq-len given: name the BASELINE config of that shape
+            base_cfg = {(64, 128): "configs[1] shape", (1024, 1024): "configs[4] shape"}.get((M, L), "custom shape")
         result = {
             "metric": f"MSA-residues/sec forward (emb+attn-map), M={M} L={L}",
             "value": residues / elapsed,
