@@ -448,7 +448,9 @@ def run_rank(args) -> int:
                                  ".bfloat16() arithmetic against an fp64 truth at every BASELINE size "
                                  "(profiles/r02_fullsize_parity.json)")
 
-    finite = bool(torch.isfinite(model.forward_one(first)["emb"]).all())
+    probe_out = model.forward_one(first)
+    finite = bool(torch.isfinite(probe_out["emb"]).all())
+    err_word = int(probe_out["err"].item())       # 0: tokens in range (bit 0) and the folded LayerNorm's precondition held (bit 1)
     if rank == 0:
         residues = msas_timed * M * L
         g = timings["gemm_f32"]
@@ -498,7 +500,7 @@ def run_rank(args) -> int:
                        "backend": ("nccl (RCCL)" if args.backend == "nccl" else args.backend) if world > 1 else "none",
                        "devices": "all ranks on device 0 (test hook)" if args.one_device and world > 1 else "one per rank",
                        "warmup_note": (f"a warm-up step is a pass over the first {warm_items} MSAs of the batch" if batch else "full steps")},
-            "outputs_finite": finite,
+            "outputs_finite": finite, "err_word": err_word,
             "model_tflops": flops_per_msa(M, L) * msas_timed / elapsed / 1e12,
             "roofline": {"bound": "mfma", "kernel": gemm_kernel,
                          "achieved": gemm_tflops, "peak": peak, "unit": flop_unit,

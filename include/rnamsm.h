@@ -59,7 +59,7 @@ int rnamsm_device_count(void);
  *   pos(r,c) = (#non-pad tokens in tok[r,0..c]) * (tok[r,c] != pad) + pad_idx.
  * tokens int64 [R,C]; embed_tokens [V,D]; embed_positions [P,D]; row_pos [>=R] (the
  * (1,1024,1,1) msa_position_embedding); out [R*C, D].  Token ids outside [0,V) or positions
- * outside [0,P) set *err_flag (device int, may be NULL) to 1 and are clamped. */
+ * outside [0,P) set bit 0 of *err_flag (device int, may be NULL; value 1) and are clamped. */
 int rnamsm_embed_ln(const int64_t* tokens, const float* embed_tokens, const float* embed_positions,
                     const float* row_pos, const float* gamma, const float* beta, float* out,
                     int R, int C, int D, int vocab, int num_positions, int pad_idx, float eps,
@@ -76,31 +76,40 @@ int rnamsm_layernorm(const float* x, const float* gamma, const float* beta, floa
  *   Wg = W * gamma (per input feature k),  c[n] = sum_k Wg[n,k],  d[n] = b[n] + sum_k W[n,k] * beta[k]
  * so the GEMM reads the residual stream itself: no normalised copy of it is written or re-read (806 MB per LayerNorm at
  * M=256 L=512) and LayerNorm is no launch at all.  The statistics come from whoever wrote x: `row_partials`
- * [K/32, M, 2] (slab-major) holds (sum x, sum x^2) of every row per 32-feature slab; mean = sum / K, biased variance =
- * E[x^2] - mean^2 in fp32 (meant for rows whose |mean| is not much larger than their spread, like a residual stream).
- * Results agree with LayerNorm -> Linear to fp32 rounding (different association; against an fp64 truth the two are
- * equally far from it: tests/analysis/ln_fold_numerics.py, tests/test_gpu_fullsize.py).
+ * [K/32, M, 2] (slab-major) holds, per row and 32-feature slab, the slab's sum and its sum of squares about the slab's own
+ * mean; rnamsm_row_stats_from_partials combines them into (mean, rstd) per row as in Chan et al. (M2 = sum of slab M2 +
+ * sum of 32 (slab mean - mean)^2), so the biased variance never comes from a difference of large numbers.  What the fold itself costs is the subtraction of
+ * mean * c[n] from the accumulated x.Wg: a row whose |mean| is much larger than its spread loses log2(|mean| / spread)
+ * bits there (a residual stream is nowhere near: the synthetic model's rows sit below 1).  `cond_flag` (device int, may be
+ * NULL) gets bit 1 (value 2) OR-ed in when a row has mean^2 > 1024 (var + eps) -- by rnamsm_row_stats_from_partials, or by
+ * rnamsm_gemm_lnfold when it sums the rows itself; rnamsm_forward passes its err_flag and
+ * the Python mirror then redoes that MSA with separate LayerNorm launches.  Results agree with LayerNorm -> Linear to fp32
+ * rounding (different association; against an fp64 truth the two are equally far from it:
+ * tests/analysis/ln_fold_numerics.py, tests/test_gpu_fullsize.py).
  *   rnamsm_ln_fold_weights     one-time preparation: Wg [N,K], c [N], d [N] from W [N,K], bias [N] (or NULL), gamma, beta [K]
  *                              (c and d are accumulated in double; c sums the ROUNDED Wg the GEMM will multiply)
  *   rnamsm_row_partials        row_partials of x [T, D] as it lies in memory (D % 32 == 0, D <= 1024): for an x that did
  *                              not come out of rnamsm_gemm_residual_stats (the embedding)
  *   rnamsm_gemm_residual_stats Cout = A W^T + bias + residual (K8: out_proj / fc2 + the residual add, modules.py:396) and
  *                              row_partials [N/32, M, 2] of the Cout it stores; requirements of rnamsm_gemm_bias_act_res
+ *   rnamsm_row_stats_from_partials  row_stats [M, 2] = (mean, rstd) of the first M rows from row_partials [K/32, partials_ld, 2]
  *   rnamsm_gemm_lnfold         Cout[m,n] = act( (rstd[m] * (sum_k X[m,k] Wg[n,k] - mean[m] c[n]) + d[n]) * (n < scale_cols ? scale : 1) )
- *                              X [M,K] row stride ldx; row_partials [K/32, M, 2] (K <= 1024) or NULL = the block sums the
- *                              rows it stages itself (self-contained, ~2.6 % slower); eps = ln_eps; requirements of
+ *                              X [M,K] row stride ldx; row_stats [M, 2] or NULL = the block sums the rows it stages itself
+ *                              (self-contained, variance as E[x^2] - mean^2, ~2.6 % slower); eps = ln_eps; requirements of
  *                              rnamsm_gemm_bias_act_res, scale_cols % 4 == 0
- * partials_ld = rows per slab of the row_partials buffer (>= M: a GEMM over the first M rows of a longer buffer, as the
- * outputs-only forward runs them, addresses it with the buffer's own slab stride) */
+ * partials_ld = rows per slab of the row_partials buffer (>= M: a GEMM over the first M rows of a longer stream, as the
+ * outputs-only forward runs them, addresses the buffer with its own slab stride) */
 int rnamsm_ln_fold_weights(const float* W, const float* bias, const float* gamma, const float* beta, float* Wg,
                            float* cvec, float* dvec, int N, int K, void* stream);
 int rnamsm_row_partials(const float* x, float* row_partials, int64_t T, int D, void* stream);
 int rnamsm_gemm_residual_stats(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                                int64_t ldr, float* Cout, int64_t ldc, int64_t M, int N, int K, float* row_partials,
                                int64_t partials_ld, int dtype, void* stream);
+int rnamsm_row_stats_from_partials(const float* row_partials, int64_t partials_ld, int64_t M, int K, float eps,
+                                   float* row_stats, int* cond_flag, void* stream);
 int rnamsm_gemm_lnfold(const float* X, int64_t ldx, const float* Wg, const float* cvec, const float* dvec,
-                       float ln_eps, const float* row_partials, int64_t partials_ld, float* Cout, int64_t ldc,
-                       int64_t M, int N, int K, int act, float scale, int scale_cols, int dtype, void* stream);
+                       float ln_eps, const float* row_stats, int* cond_flag, float* Cout, int64_t ldc, int64_t M,
+                       int N, int K, int act, float scale, int scale_cols, int dtype, void* stream);
 
 /* K2/K3/K8 -- nn.Linear with fused epilogue (modules.py:760-766, 794-799, 896-905, 923, 424-426, 396):
  *   Cout[m,n] = act( (sum_k A[m,k]*W[n,k] + bias[n]) * (n < scale_cols ? scale : 1) ) + residual[m,n]
@@ -361,7 +370,7 @@ void rnamsm_timing_reset(void);
  *   "greedy_fused"  rnamsm_greedy_select: 1 (default) = one launch per step (one wave per row) for alignments of up to 3072
  *                 rows, three launches per step (one thread per row) above; 2 = always one; 0 = always three.  Same indices.
  *   "ln_fold"     rnamsm_forward with ln_folded given: 1 (default) = LayerNorm folded into the QKV / fc1 GEMMs, row sums
- *                 left by the out_proj / fc2 epilogues, for MSAs of R*C >= 4096 tokens (below that the separate launches
+ *                 left by the out_proj / fc2 epilogues, for MSAs of R*C >= 18432 tokens (below that the separate launches
  *                 are faster); 3 = for every shape; 2 = folded, every GEMM sums the rows it stages itself; 0 = separate
  *                 LayerNorm launches (all agree to fp32 rounding).
  *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit

@@ -58,7 +58,7 @@ struct Tuning {
     int col_dma = -1;              // fp32 col_attn: 1 = LDS-DMA staging, 32-key chunks, 3 blocks/CU; 0 = register-staged kernel; -1 = by shape
     int row16_max_rows = 32;       // hi/lo modes: cap on the rows of one row_logits16 slab (0 = none): accuracy, DESIGN 3.2
     int ln_fold = 1;               // rnamsm_forward with ln_folded: 1 = LayerNorm applied inside the consuming GEMM (row sums from the producers'
-                                   // epilogues) when R*C >= 4096, 3 = for every shape, 2 = every GEMM sums its rows itself (A/B), 0 = separate launches
+                                   // epilogues) when R*C >= 18432, 3 = for every shape, 2 = every GEMM sums its rows itself (A/B), 0 = separate launches
     int greedy_fused = 1;          // rnamsm_greedy_select: 1 = one launch per step (fused distance / score / argmax) up to 3072 rows, 2 = always, 0 = three launches
     int attn16 = 1;                // 16-bit modes of rnamsm_forward: 1 = attention contractions on the 16-bit matrix cores too, 0 = fp32 attention
 };

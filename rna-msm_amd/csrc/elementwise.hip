@@ -58,8 +58,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, const fl
     }
 }
 
-// K1 folded into the consuming GEMM (gemm_f32.hip FOLD = 2): the row partial sums [D/32, T, 2] = (sum x, sum x^2) per
-// 32-column slab (slab-major), in the format the residual GEMM epilogues leave them -- for a residual stream that did not come out of
+// K1 folded into the consuming GEMM (gemm_f32.hip FOLD = 2): the row partial sums [D/32, T, 2] = (sum x, sum (x - slab mean)^2)
+// per 32-column slab (slab-major), in the format the residual GEMM epilogues leave them -- for a residual stream that did not come out of
 // one (the embedding, K0).  One wave per row; the 8 lanes of a slab add up on the DPP path.
 __device__ __forceinline__ float sum8_dpp_e(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
@@ -79,10 +79,36 @@ __global__ __launch_bounds__(256) void row_partials_kernel(const float* __restri
             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
             if (vi < nvec) v = *reinterpret_cast<const f32x4*>(x + row * D + 4 * vi);
             const float ps = sum8_dpp_e((v[0] + v[1]) + (v[2] + v[3]));
-            const float pq = sum8_dpp_e(fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3]))));
+            const float mb = ps * (1.f / 32.f);                          // second moment about the slab's own mean
+            const float d0 = v[0] - mb, d1 = v[1] - mb, d2 = v[2] - mb, d3 = v[3] - mb;
+            const float pq = sum8_dpp_e(fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3))));
             if ((lane & 7) == 0 && vi < nvec) partials[(int64_t)(vi / 8) * T + row] = float2{ps, pq};
         }
     }
+}
+
+// (mean, rstd) of every row from its slab partials, one thread per row (the K/32 loads of consecutive rows coalesce):
+// Chan et al.'s combination -- M2 = sum of the slabs' M2 + sum of 32 (slab mean - mean)^2 -- so the variance never comes
+// from a difference of large numbers.  Rows whose |mean| is more than 32x their spread are reported in *cond_flag (bit 1):
+// the fold's own subtraction of mean * c[n] loses more than 5 bits on them.
+__global__ __launch_bounds__(256) void row_stats_from_partials_kernel(const float2* __restrict__ partials, int64_t pld, int64_t M,
+                                                                      int K, float eps, float2* __restrict__ stats,
+                                                                      int* cond_flag) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    const int ns = K / 32;
+    float a = 0.f;
+    for (int j = 0; j < ns; ++j) a += partials[(int64_t)j * pld + row].x;
+    const float mean = a / (float)K;
+    float m2 = 0.f;
+    for (int j = 0; j < ns; ++j) {
+        const float2 p = partials[(int64_t)j * pld + row];
+        const float dm = fmaf(p.x, 1.f / 32.f, -mean);
+        m2 += fmaf(32.f * dm, dm, p.y);
+    }
+    const float var = m2 / (float)K;
+    stats[row] = float2{mean, rsqrtf(var + eps)};
+    if (cond_flag && mean * mean > 1024.f * (var + eps)) atomicOr(cond_flag, 2);
 }
 
 // K1 folded into the consuming GEMM (gemm_f32.hip FOLD): one-time weight preparation, one wave per output feature n.
@@ -246,6 +272,20 @@ extern "C" int rnamsm_row_partials(const float* x, float* row_partials, int64_t 
     hipLaunchKernelGGL(row_partials_kernel, dim3(rows_grid(T)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
                        reinterpret_cast<float2*>(row_partials), T, D);
     RNAMSM_CHECK_LAUNCH("row_partials");
+    return RNAMSM_OK;
+}
+
+extern "C" int rnamsm_row_stats_from_partials(const float* row_partials, int64_t partials_ld, int64_t M, int K, float eps,
+                                              float* row_stats, int* cond_flag, void* stream) {
+    RNAMSM_CHECK_ARG(row_partials && row_stats, "row_stats_from_partials: null pointer");
+    RNAMSM_CHECK_ARG(M > 0 && K > 0 && K % 32 == 0 && partials_ld >= M && eps >= 0.f,
+                     "row_stats_from_partials: need K %% 32 == 0 and partials_ld >= M (M=%lld K=%d)", (long long)M, K);
+    RNAMSM_CHECK_ARG((reinterpret_cast<uintptr_t>(row_partials) & 7u) == 0 && (reinterpret_cast<uintptr_t>(row_stats) & 7u) == 0,
+                     "row_stats_from_partials: 8-byte alignment");
+    hipLaunchKernelGGL(row_stats_from_partials_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const float2*>(row_partials), partials_ld, M, K, eps,
+                       reinterpret_cast<float2*>(row_stats), cond_flag);
+    RNAMSM_CHECK_LAUNCH("row_stats_from_partials");
     return RNAMSM_OK;
 }
 

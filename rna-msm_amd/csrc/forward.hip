@@ -10,7 +10,7 @@
 //                    the FFN hidden activation [T, F] overlays both (they are never live together)
 //   part   [nsplit, H, C, C]  row-logit partial slabs (K4 -> K5)
 //   pplanes [2][H*C, ldp]     row-attention probabilities as 16-bit hi / lo planes (16-bit modes, K5' -> K6')
-//   rowsum [D/32, T, 2]  (sum x, sum x^2) of every token per 32-feature slab (slab-major), left by whatever wrote x last (K0 via
+//   rowsum [D/32, T, 2]  (sum x, sum (x - slab mean)^2) of every token per 32-feature slab (slab-major), left by whatever wrote x last (K0 via
 //                    rnamsm_row_partials, then the out_proj / fc2 epilogues): with LayerNorm folded into the consuming
 //                    GEMM (ln_folded given, exact path, no padding) xn is never touched -- the QKV / fc1 GEMMs read x and
 //                    take each row's (mean, rstd) from these sums
@@ -24,7 +24,7 @@ using namespace rnamsm;
 
 namespace {
 struct Layout {
-    size_t x, xn, wide, part, mask, pplanes, rowsum, total;
+    size_t x, xn, wide, part, mask, pplanes, rowsum, stats, total;
 };
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 Layout make_layout(const rnamsm_model_dims& d, int R, int C, int nchunks) {
@@ -42,7 +42,8 @@ Layout make_layout(const rnamsm_model_dims& d, int R, int C, int nchunks) {
     }
     l.mask = off; off += align256(T);
     l.pplanes = off; off += align256((size_t)d.num_heads * C * (size_t)((C + 63) / 64 * 64) * 4);   // P hi + lo planes (K5' -> K6')
-    l.rowsum = off; off += align256(T * (D / 32) * 2 * sizeof(float));   // (sum x, sum x^2) per token and 32-feature slab
+    l.rowsum = off; off += align256(T * (D / 32) * 2 * sizeof(float));   // (sum, centred sum of squares) per token and 32-feature slab
+    l.stats = off; off += align256(T * 2 * sizeof(float));            // (mean, rstd) per token, combined from rowsum
     l.total = off;
     return l;
 }
@@ -146,22 +147,26 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     // Exact path without padding, folded weights given: the three LayerNorms of a layer are applied inside the GEMMs they
     // feed (gemm_f32.hip FOLD) -- norm() is then no launch at all, lin_normed() reads x itself and res_linear() (the GEMMs
     // that write x) leaves the row sums the next lin_normed() normalises with.
-    // Measured (tools/ln_fold_ab.py, whole forward): -0.7 % at M = L = 1024, -0.75 % at M=256 L=512, -0.9 % at 128x256,
-    // -0.8 % at 512x36, -0.45 % at 64x128, +0.3 % at 32x64, +1 % at 16x33 (a launch there is one tile deep: the folded
-    // epilogue is on the critical path and the LayerNorm launches were nearly free) -- hence the token threshold of mode 1.
+    // Measured (tools/ln_fold_ab.py, whole forward): -1.4 % at M = L = 1024, -1.25 % at M=256 L=512, -0.5 % at 128x256 and at
+    // 512x36 (18432 tokens); +3 % at 128x128, +1.8 % at 100x100 and 64x128 (launches there are a tile or two deep: the folded
+    // epilogues and the 30 small statistics launches sit on the critical path while the LayerNorm launches were nearly
+    // free) -- hence the token threshold of mode 1.
     const int fold_mode = tuning().ln_fold;          // 0 off, 1 by shape, 2 GEMMs sum their own rows, 3 always
     const bool fold = ln_folded && dtype == RNAMSM_F32 && !has_padding &&
-                      (fold_mode >= 2 || (fold_mode == 1 && (int64_t)R * C >= 4096));
+                      (fold_mode >= 2 || (fold_mode == 1 && (int64_t)R * C >= 18432));
     const bool fold_sums = fold && fold_mode != 2;   // row sums travel from the residual epilogues to the consumers
     float* rowsum = reinterpret_cast<float*>(ws + lay.rowsum);
     auto norm = [&](const float* g, const float* b, int64_t rows) -> int {
         if (fold) return RNAMSM_OK;
         return rnamsm_layernorm(x, g, b, xn, rows, D, d.ln_eps, stream);
     };
-    // x[:rows] += A W^T + bias on the exact path
+    float* stats = reinterpret_cast<float*>(ws + lay.stats);
+    // x[:rows] += A W^T + bias on the exact path; folded: + the rows' slab sums, combined into (mean, rstd) right away
     auto res_linear = [&](const float* A, int64_t lda, const float* Wf, const float* bias, int64_t rows, int K) -> int {
-        if (fold_sums)
-            return rnamsm_gemm_residual_stats(A, lda, Wf, bias, x, D, x, D, rows, D, K, rowsum, T, f32, stream);
+        if (fold_sums) {
+            FWD(rnamsm_gemm_residual_stats(A, lda, Wf, bias, x, D, x, D, rows, D, K, rowsum, T, f32, stream));
+            return rnamsm_row_stats_from_partials(rowsum, T, rows, D, d.ln_eps, stats, err_flag, stream);
+        }
         return rnamsm_gemm_bias_act_res(A, lda, Wf, bias, x, D, x, D, rows, D, K, RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream);
     };
     // columns n_ofs .. n_ofs + N - 1 of the Linear in folded slot fslot (0 row QKV, 1 column QKV, 2 fc1) over `rows` tokens
@@ -169,7 +174,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
                           int64_t rows, int N, int act, float scale, int scale_cols) -> int {
         if (fold) {
             const float* const* Fp = ln_folded + (size_t)layer * RNAMSM_FOLDED_PER_LAYER + 3 * fslot;
-            return rnamsm_gemm_lnfold(x, D, Fp[0] + (size_t)n_ofs * D, Fp[1] + n_ofs, Fp[2] + n_ofs, d.ln_eps, fold_sums ? rowsum : nullptr, T, out, ldc, rows, N, D,
+            return rnamsm_gemm_lnfold(x, D, Fp[0] + (size_t)n_ofs * D, Fp[1] + n_ofs, Fp[2] + n_ofs, d.ln_eps, fold_sums ? stats : nullptr, err_flag, out, ldc, rows, N, D,
                                       act, scale, scale_cols, f32, stream);
         }
         return rnamsm_gemm_bias_act_res(xn, D, Wf + (size_t)n_ofs * D, bias + n_ofs, nullptr, 0, out, ldc, rows, N, D, act, scale,
@@ -186,7 +191,10 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     FWD(rnamsm_embed_ln(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
                         G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, R, C, D, d.vocab, d.num_positions,
                         d.pad_idx, d.ln_eps, err_flag, stream));
-    if (fold_sums) FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
+    if (fold_sums) {
+        FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
+        FWD(rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream));
+    }
     for (int l = 0; l < NL; ++l) {
         const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
         float* probs = row_attn + (int64_t)l * H * C * C;

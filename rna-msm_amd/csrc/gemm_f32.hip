@@ -9,11 +9,12 @@
 //   Wg = W * gamma (columnwise),  c[n] = sum_k Wg[n,k],  d[n] = b[n] + sum_k W[n,k] beta[k]   (rnamsm_ln_fold_weights)
 // so the normalised copy of x is never written or read (806 MB per LayerNorm at cfg3) and LayerNorm is no launch at all:
 // the statistics come from whoever WROTE x.  STATS: the residual epilogue (out_proj / fc2, which produce the residual
-// stream) leaves per row and 32-column slab the partial (sum x, sum x^2) of what it stores: row_partials [N/32, M, 2]
+// stream) leaves per row and 32-column slab the partial sums of what it stores: row_partials [N/32, M, 2]
 // (slab-major: a wave's 64 rows of one slab are 512 contiguous bytes -- row-major 8-byte pieces cost a read-modify-write
 // each and made this epilogue 50 us per launch slower);
-// FOLD = 2: the consuming block adds the K/32 partials of each of its 128 rows once, before its K loop, and keeps
-// (mean, rstd) in LDS for the epilogue (biased variance as E[x^2] - mean^2 in fp32).  FOLD = 1 is the self-contained
+// (sum x, sum (x - slab mean)^2); rnamsm_row_stats_from_partials (elementwise.hip, one thread per row) combines a row's
+// K/32 partials into (mean, rstd) -- Chan et al.: no difference of large numbers anywhere -- and FOLD = 2, the consuming
+// block, reads its 128 rows' pairs into LDS for the epilogue.  FOLD = 1 is the self-contained
 // form (no partials given): the block sums x and x^2 of the rows it stages while the tiles go to LDS -- measured: those
 // ~50 VALU instructions per K tile are NOT hidden under the MFMAs (+2.6 % kernel time, as much as the LayerNorm launch
 // they replace), which is why the forward uses the partial sums.
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc,
     int M, int N, int K, float scale, int scale_cols, const uint8_t* __restrict__ zero_rows, int group,
-    const float* __restrict__ fold_c, float ln_eps, float* row_partials, int64_t pld) {
+    const float* __restrict__ fold_c, float ln_eps, float* row_partials, int64_t pld, int* fold_flag) {
     using Cfg = GemmCfg<NT>;
     constexpr int BN_ = Cfg::BN_, TILE_W = Cfg::TILE_W;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -68,15 +69,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     const WaveCoord w = wave_coord();
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
 
-    // FOLD = 2: the K/32 slab sums of row m0 + tid (threads 0..127), requested first and added up after tile 0 has been
-    // staged (their latency hides behind the first operand tile's)
-    constexpr int PV = FOLD == 2 ? 32 : 1;                          // K <= 1024: at most 32 slabs
-    float2 pv[PV];
-    if (FOLD == 2 && threadIdx.x < BM) {
-        const float2* pp = reinterpret_cast<const float2*>(row_partials) + min(m0 + (int)threadIdx.x, M - 1);
-#pragma unroll
-        for (int j = 0; j < PV; ++j) pv[j] = pp[(int64_t)min(j, K / 32 - 1) * pld];      // branch-free; extra slots are not added
-    }
+    // FOLD = 2: (mean, rstd) of row m0 + tid (threads 0..127) from rnamsm_row_stats_from_partials, requested first and put
+    // into LDS after tile 0 has been staged (the latency hides behind the first operand tile's)
+    float2 pst = float2{0.f, 0.f};
+    if (FOLD == 2 && threadIdx.x < BM) pst = reinterpret_cast<const float2*>(row_partials)[min(m0 + (int)threadIdx.x, M - 1)];
 
     // per-thread global row pointers (A rows clamped: a clamped row only feeds its own discarded output row)
     const float* ap[4];
@@ -119,18 +115,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
             }
         },
         [&]() {
-            if (FOLD == 2 && threadIdx.x < BM) {
-                float a = 0.f, b = 0.f;
-#pragma unroll
-                for (int j = 0; j < PV; ++j)
-                    if (j < K / 32) {
-                        a += pv[j].x;
-                        b += pv[j].y;
-                    }
-                const float mean = a / (float)K;
-                const float var = fmaxf(b / (float)K - mean * mean, 0.f);
-                reinterpret_cast<float2*>(smem + Cfg::LDS_BYTES / 4)[threadIdx.x] = float2{mean, rsqrtf(var + ln_eps)};
-            }
+            if (FOLD == 2 && threadIdx.x < BM) reinterpret_cast<float2*>(smem + Cfg::LDS_BYTES / 4)[threadIdx.x] = pst;
         });
     if (FOLD == 1) {
         // the 8 lanes tid%8 = 0..7 hold the eight 96-feature parts of a row: butterfly over them, biased variance as
@@ -147,6 +132,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
             const float mean = a / (float)K;
             const float var = fmaxf(b / (float)K - mean * mean, 0.f);
             if (c4 == 0) sst[r0 + 32 * i] = float2{mean, rsqrtf(var + ln_eps)};
+            if (c4 == 0 && fold_flag && n0 == 0 && m0 + r0 + 32 * i < M && mean * mean > 1024.f * (var + ln_eps)) atomicOr(fold_flag, 2);
         }
     }
 
@@ -224,14 +210,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
         // read as data) ...
         float ps[NP], pq[NP];
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            ps[i] = (ov[i][0] + ov[i][1]) + (ov[i][2] + ov[i][3]);
-            pq[i] = fmaf(ov[i][0], ov[i][0], fmaf(ov[i][1], ov[i][1], fmaf(ov[i][2], ov[i][2], ov[i][3] * ov[i][3])));
-        }
+        for (int i = 0; i < NP; ++i) ps[i] = sum8_dpp((ov[i][0] + ov[i][1]) + (ov[i][2] + ov[i][3]));      // slab sum
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            ps[i] = sum8_dpp(ps[i]);
-            pq[i] = sum8_dpp(pq[i]);
+        for (int i = 0; i < NP; ++i) {                            // sum of squares about the SLAB's mean: nothing to cancel
+            const float mb = ps[i] * (1.f / 32.f);
+            const float d0 = ov[i][0] - mb, d1 = ov[i][1] - mb, d2 = ov[i][2] - mb, d3 = ov[i][3] - mb;
+            pq[i] = sum8_dpp(fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3))));
         }
         if ((lane & 7) == 0) {
 #pragma unroll
@@ -260,7 +244,7 @@ template <int ACT, bool HAS_RES, bool ZROWS, int NT, int FOLD = 0, bool STATS = 
 static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                           int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
                           const uint8_t* zero_rows, hipStream_t stream, const float* fold_c = nullptr,
-                          float ln_eps = 0.f, float* row_partials = nullptr, int64_t pld = 0) {
+                          float ln_eps = 0.f, float* row_partials = nullptr, int64_t pld = 0, int* fold_flag = nullptr) {
     using Cfg = GemmCfg<NT>;
     static DeviceOnce configured;
     auto kern = gemm_f32_kernel<ACT, HAS_RES, ZROWS, NT, FOLD, STATS>;
@@ -280,7 +264,7 @@ static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const flo
     // algorithmic work: 2MNK flops; bytes = A + W + C once (+ residual read)
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), FOLD ? Cfg::LDS_FOLD : Cfg::LDS_BYTES, stream, A, lda, W, bias,
-                       residual, ldr, Cout, ldc, M, N, K, scale, scale_cols, zero_rows, group, fold_c, ln_eps, row_partials, pld);
+                       residual, ldr, Cout, ldc, M, N, K, scale, scale_cols, zero_rows, group, fold_c, ln_eps, row_partials, pld, fold_flag);
     RNAMSM_CHECK_LAUNCH("gemm_f32");
     return RNAMSM_OK;
 }
@@ -316,14 +300,14 @@ static int launch_gemm(const float* A, int64_t lda, const float* W, const float*
 
 template <int ACT, int FOLD>
 static int launch_gemm_fold(const float* X, int64_t ldx, const float* Wg, const float* cvec, const float* dvec,
-                            float ln_eps, const float* row_partials, int64_t pld, float* Cout, int64_t ldc, int M, int N,
-                            int K, float scale, int scale_cols, hipStream_t stream) {
+                            float ln_eps, const float* row_partials, int64_t pld, int* fold_flag, float* Cout, int64_t ldc,
+                            int M, int N, int K, float scale, int scale_cols, hipStream_t stream) {
     float* rp = const_cast<float*>(row_partials);                  // read-only in the FOLD kernels
     if (half_width_tiles_win(M, N))
         return launch_gemm_nt<ACT, false, false, 1, FOLD>(X, ldx, Wg, dvec, nullptr, 0, Cout, ldc, M, N, K, scale, scale_cols,
-                                                          nullptr, stream, cvec, ln_eps, rp, pld);
+                                                          nullptr, stream, cvec, ln_eps, rp, pld, fold_flag);
     return launch_gemm_nt<ACT, false, false, 2, FOLD>(X, ldx, Wg, dvec, nullptr, 0, Cout, ldc, M, N, K, scale, scale_cols,
-                                                      nullptr, stream, cvec, ln_eps, rp, pld);
+                                                      nullptr, stream, cvec, ln_eps, rp, pld, fold_flag);
 }
 
 // residual GEMM that also leaves the row partial sums of what it stores (the producer side of the folded LayerNorm)
@@ -358,8 +342,8 @@ extern "C" int rnamsm_gemm_residual_stats(const float* A, int64_t lda, const flo
 }
 
 extern "C" int rnamsm_gemm_lnfold(const float* X, int64_t ldx, const float* Wg, const float* cvec, const float* dvec,
-                                  float ln_eps, const float* row_partials, int64_t partials_ld, float* Cout, int64_t ldc,
-                                  int64_t M, int N, int K, int act, float scale, int scale_cols, int dtype, void* stream) {
+                                  float ln_eps, const float* row_stats, int* cond_flag, float* Cout, int64_t ldc, int64_t M,
+                                  int N, int K, int act, float scale, int scale_cols, int dtype, void* stream) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "gemm_lnfold: only RNAMSM_F32 is implemented");
     RNAMSM_CHECK_ARG(X && Wg && cvec && dvec && Cout, "gemm_lnfold: null pointer");
     RNAMSM_CHECK_ARG(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "gemm_lnfold: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
@@ -369,15 +353,14 @@ extern "C" int rnamsm_gemm_lnfold(const float* X, int64_t ldx, const float* Wg, 
     RNAMSM_CHECK_ARG(aligned16(X) && aligned16(Wg) && aligned16(cvec) && aligned16(dvec) && aligned16(Cout),
                      "gemm_lnfold: 16-byte alignment");
     RNAMSM_CHECK_ARG(ln_eps >= 0.f, "gemm_lnfold: negative eps");
-    RNAMSM_CHECK_ARG(!row_partials || (K <= 1024 && (reinterpret_cast<uintptr_t>(row_partials) & 7u) == 0 && partials_ld >= M),
-                     "gemm_lnfold: row_partials needs K <= 1024, 8-byte alignment and partials_ld >= M");
+    RNAMSM_CHECK_ARG(!row_stats || (reinterpret_cast<uintptr_t>(row_stats) & 7u) == 0, "gemm_lnfold: row_stats must be 8-byte aligned");
     RNAMSM_CHECK_ARG(scale_cols >= 0 && scale_cols % 4 == 0, "gemm_lnfold: scale_cols must be a multiple of 4");
     RNAMSM_CHECK_ARG(act == RNAMSM_ACT_NONE || act == RNAMSM_ACT_GELU_ERF, "gemm_lnfold: unknown activation %d", act);
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define RNAMSM_FOLD_DISPATCH(ACT_, FOLD_) \
-    launch_gemm_fold<ACT_, FOLD_>(X, ldx, Wg, cvec, dvec, ln_eps, row_partials, partials_ld, Cout, ldc, (int)M, N, K, scale, scale_cols, s)
-    if (act == RNAMSM_ACT_GELU_ERF) return row_partials ? RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_GELU_ERF, 2) : RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_GELU_ERF, 1);
-    return row_partials ? RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_NONE, 2) : RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_NONE, 1);
+    launch_gemm_fold<ACT_, FOLD_>(X, ldx, Wg, cvec, dvec, ln_eps, row_stats, 0, cond_flag, Cout, ldc, (int)M, N, K, scale, scale_cols, s)
+    if (act == RNAMSM_ACT_GELU_ERF) return row_stats ? RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_GELU_ERF, 2) : RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_GELU_ERF, 1);
+    return row_stats ? RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_NONE, 2) : RNAMSM_FOLD_DISPATCH(RNAMSM_ACT_NONE, 1);
 #undef RNAMSM_FOLD_DISPATCH
 }
 

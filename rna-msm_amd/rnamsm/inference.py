@@ -187,9 +187,7 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                 tokens = pending.result() if reader else read(idx)
                 if reader and n + 1 < len(mine):
                     pending = reader.submit(read, mine[n + 1])       # parsed while the GPU runs this MSA
-                out = model.forward_one(torch.from_numpy(tokens).to(device), need_repr=False)   # emb + atp are all that is written
-                if int(out["err"].item()) != 0:
-                    raise IndexError(f"{rna_id}: token or position index out of range")
+                out = model.checked_forward_one(torch.from_numpy(tokens).to(device), need_repr=False, what=rna_id)   # emb + atp are all that is written
                 if gatherer is not None:
                     gatherer.submit(idx, (out["emb"], out["atp"]))
                 else:

@@ -246,6 +246,31 @@ class MSATransformer(nn.Module):
         with torch.cuda.device(dev):
             return self._forward_one_on_device(tokens2d, has_padding, need_repr)
 
+    ERR_INDEX, ERR_FOLD = 1, 2            # bits of forward_one's "err": token / position index out of range; a row whose
+                                          # |mean| is so far above its spread that the folded LayerNorm loses > 5 bits
+
+    def checked_forward_one(self, tokens2d: torch.Tensor, has_padding: Optional[bool] = None, need_repr: bool = True,
+                            what: str = "MSA") -> Dict[str, torch.Tensor]:
+        """forward_one + the error word read back (one device sync): raises IndexError for out-of-range tokens like the
+        reference's embedding lookup would; an MSA that trips the folded LayerNorm's precondition (rnamsm.h, K1 folded) is
+        computed again with separate LayerNorm launches -- the caller never sees the difference."""
+        out = self.forward_one(tokens2d, has_padding, need_repr)
+        err = int(out["err"].item())
+        if err & self.ERR_INDEX:
+            raise IndexError(f"{what}: token or position index out of range")
+        if err & self.ERR_FOLD:
+            import warnings
+            warnings.warn(f"{what}: a token row's mean exceeds 32x its spread; LayerNorm is applied in its own launches for "
+                          "this MSA instead of inside the GEMMs")
+            keep, self.fold_layernorm = self.fold_layernorm, False
+            try:
+                out = self.forward_one(tokens2d, has_padding, need_repr)
+            finally:
+                self.fold_layernorm = keep
+            if int(out["err"].item()) & self.ERR_INDEX:
+                raise IndexError(f"{what}: token or position index out of range")
+        return out
+
     def _forward_one_on_device(self, tokens2d: torch.Tensor, has_padding: Optional[bool],
                                need_repr: bool = True) -> Dict[str, torch.Tensor]:
         R, C = tokens2d.shape
@@ -334,9 +359,7 @@ class MSATransformer(nn.Module):
         fast = repr_set <= {self.num_layers}
         for b in range(B):
             if fast:
-                out = self.forward_one(tokens[b], has_padding)
-                if int(out["err"].item()) != 0:
-                    raise IndexError("token or position index out of range")
+                out = self.checked_forward_one(tokens[b], has_padding)
                 if self.num_layers in repr_set:
                     reps[self.num_layers].append(out["repr"].unsqueeze(0))
                 atts.append(out["row_attn"].unsqueeze(0))

@@ -131,8 +131,8 @@ def ln_fold_weights(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.
 
 @_on_operand_device
 def row_partials(x: torch.Tensor) -> torch.Tensor:
-    """(sum x, sum x^2) of every row of x [T, D] per 32-feature slab, slab-major: [D/32, T, 2], the statistics format of
-    the folded LayerNorm (include/rnamsm.h, K1 folded)."""
+    """(sum x, sum (x - slab mean)^2) of every row of x [T, D] per 32-feature slab, slab-major: [D/32, T, 2], the statistics
+    format of the folded LayerNorm (include/rnamsm.h, K1 folded)."""
     D = x.shape[-1]
     x2 = x.contiguous().view(-1, D)
     out = torch.empty(D // 32, x2.shape[0], 2, device=x2.device, dtype=torch.float32)
@@ -158,21 +158,36 @@ def linear_residual_stats(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch
 
 
 @_on_operand_device
-def linear_lnfold(x: torch.Tensor, wg: torch.Tensor, c: torch.Tensor, d: torch.Tensor, partials: Optional[torch.Tensor] = None,
+def row_stats_from_partials(partials: torch.Tensor, K: int, rows: Optional[int] = None, eps: float = 1e-5,
+                            cond_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(mean, rstd) [rows, 2] of the first `rows` rows from their slab partials [K/32, M, 2] (Chan et al.'s combination).
+    cond_flag (int32 [1]): bit 1 is set when a row's mean^2 exceeds 1024 (var + eps) -- the folded GEMM then loses more than
+    5 bits to cancellation and the caller should use layernorm + linear for that input."""
+    M = partials.shape[1]
+    rows = M if rows is None else rows
+    stats = torch.empty(rows, 2, device=partials.device, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_row_stats_from_partials(_dev(partials, "partials"), M, rows, K, eps, stats.data_ptr(),
+                                                          None if cond_flag is None else _dev(cond_flag, "cond_flag", torch.int32),
+                                                          _stream()))
+    return stats
+
+
+@_on_operand_device
+def linear_lnfold(x: torch.Tensor, wg: torch.Tensor, c: torch.Tensor, d: torch.Tensor, stats: Optional[torch.Tensor] = None,
                   eps: float = 1e-5, act: int = ACT_NONE, scale: float = 1.0, scale_cols: int = 0,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, cond_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act((rstd * (x @ wg.T - mean * c) + d) * (col < scale_cols ? scale : 1)) = act(Linear(LayerNorm(x)) ...): the GEMM
-    reads x itself; (wg, c, d) from ln_fold_weights; each row's (mean, rstd) from `partials` [K/32, M, 2] (row_partials /
-    linear_residual_stats; it may cover more rows than x: x = the first M rows of a longer stream), or summed by the GEMM
-    itself when None."""
+    reads x itself; (wg, c, d) from ln_fold_weights; (mean, rstd) of row m = stats[m] (row_stats_from_partials; stats may
+    cover more rows than x), or summed by the GEMM itself when None (which then also reports the precondition in cond_flag)."""
     M, K = x.shape
     N = wg.shape[0]
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
     _lib.check(_lib.load().rnamsm_gemm_lnfold(_dev(x, "x"), _rowmajor(x, "x"), _dev(wg, "wg"), _dev(c, "c"), _dev(d, "d"),
-                                              eps, None if partials is None else _dev(partials, "partials"),
-                                              M if partials is None else partials.shape[1], _dev(out, "out"),
-                                              _rowmajor(out, "out"), M, N, K, act, scale, scale_cols, F32, _stream()))
+                                              eps, None if stats is None else _dev(stats, "stats"),
+                                              None if cond_flag is None else _dev(cond_flag, "cond_flag", torch.int32),
+                                              _dev(out, "out"), _rowmajor(out, "out"), M, N, K, act, scale, scale_cols, F32,
+                                              _stream()))
     return out
 
 

@@ -66,17 +66,18 @@ int main(void) {
     REFUSED(rnamsm_gemm_residual_stats(buf, 64, buf, buf, buf, 128, buf, 128, 8, 128, 64, NULL, 8, 0, NULL));   /* no partials */
     REFUSED(rnamsm_gemm_residual_stats(buf, 64, buf, buf, buf, 128, buf, 128, 8, 100, 64, buf, 8, 0, NULL));    /* N % 128 */
     REFUSED(rnamsm_gemm_residual_stats(buf, 64, buf, buf, buf, 128, buf, 128, 8, 128, 64, buf, 8, 2, NULL));    /* dtype */
-    REFUSED(rnamsm_gemm_lnfold(buf, 2048, buf, buf, buf, 1e-5f, buf, 8, buf, 128, 8, 128, 2048, 0, 1.f, 0, 0, NULL));   /* partials: K <= 1024 */
-    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, 1e-5f, buf, 4, buf, 128, 8, 128, 64, 0, 1.f, 0, 0, NULL));       /* partials_ld < M */
     REFUSED(rnamsm_gemm_residual_stats(buf, 64, buf, buf, buf, 128, buf, 128, 8, 128, 64, buf, 4, 0, NULL));          /* partials_ld < M */
+    REFUSED(rnamsm_row_stats_from_partials(NULL, 8, 8, 768, 1e-5f, buf, NULL, NULL));
+    REFUSED(rnamsm_row_stats_from_partials(buf, 4, 8, 768, 1e-5f, buf, NULL, NULL));          /* partials_ld < M */
+    REFUSED(rnamsm_row_stats_from_partials(buf, 8, 8, 770, 1e-5f, buf, NULL, NULL));          /* K % 32 */
     REFUSED(rnamsm_ln_fold_weights(NULL, buf, buf, buf, buf, buf, buf, 128, 64, NULL));
     REFUSED(rnamsm_ln_fold_weights(buf, buf, buf, buf, buf, buf, buf, 0, 64, NULL));
-    REFUSED(rnamsm_gemm_lnfold(NULL, 64, buf, buf, buf, 1e-5f, NULL, 0, buf, 128, 8, 128, 64, 0, 1.f, 0, 0, NULL));
-    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, 1e-5f, NULL, 0, buf, 128, 8, 100, 64, 0, 1.f, 0, 0, NULL));   /* N % 128 */
-    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, 1e-5f, NULL, 0, buf, 128, 8, 128, 64, 0, 1.f, 6, 0, NULL));    /* scale_cols % 4 */
-    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, 1e-5f, NULL, 0, buf, 128, 8, 128, 64, 7, 1.f, 0, 0, NULL));    /* activation */
-    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, 1e-5f, NULL, 0, buf, 128, 8, 128, 64, 0, 1.f, 0, 1, NULL));    /* dtype */
-    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, -1.f, NULL, 0, buf, 128, 8, 128, 64, 0, 1.f, 0, 0, NULL));     /* eps */
+    REFUSED(rnamsm_gemm_lnfold(NULL, 64, buf, buf, buf, 1e-5f, NULL, NULL, buf, 128, 8, 128, 64, 0, 1.f, 0, 0, NULL));
+    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, 1e-5f, NULL, NULL, buf, 128, 8, 100, 64, 0, 1.f, 0, 0, NULL));   /* N % 128 */
+    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, 1e-5f, NULL, NULL, buf, 128, 8, 128, 64, 0, 1.f, 6, 0, NULL));    /* scale_cols % 4 */
+    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, 1e-5f, NULL, NULL, buf, 128, 8, 128, 64, 7, 1.f, 0, 0, NULL));    /* activation */
+    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, 1e-5f, NULL, NULL, buf, 128, 8, 128, 64, 0, 1.f, 0, 1, NULL));    /* dtype */
+    REFUSED(rnamsm_gemm_lnfold(buf, 64, buf, buf, buf, -1.f, NULL, NULL, buf, 128, 8, 128, 64, 0, 1.f, 0, 0, NULL));     /* eps */
     REFUSED(rnamsm_layernorm_split(buf, buf, buf, NULL, NULL, 8, 768, 1e-5f, 0, NULL));
     REFUSED(rnamsm_gemm_bias_act_res(NULL, 0, NULL, NULL, NULL, 0, NULL, 0, 4, 128, 32, 0, 1.f, 0, NULL, 0, NULL));
     REFUSED(rnamsm_gemm_bias_act_res(buf, 32, buf, NULL, NULL, 0, buf, 100, 4, 100, 32, 0, 1.f, 0, NULL, 0, NULL));

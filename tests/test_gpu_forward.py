@@ -456,7 +456,7 @@ def test_outputs_only_forward_is_bit_identical_and_skips_dead_rows(model, R, C):
 
 @pytest.mark.parametrize("R,C", [(8, 17), (64, 128), (33, 131), (1, 9), (130, 40)])
 def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model, R, C):
-    """K1 folded (the exact path's default on MSAs of >= 4096 tokens without padding; forced here with knob 3): the QKV /
+    """K1 folded (the exact path's default on MSAs of >= 18432 tokens without padding; forced here with knob 3): the QKV /
     fc1 GEMMs read the residual stream and apply (mean, rstd) to their accumulators.  Against the same forward with
     separate LayerNorm launches (the `ln_fold` knob and MSATransformer.fold_layernorm both switch it) the outputs agree to
     fp32 rounding, and against the oracle the folded forward is no further away than the unfolded one (x1.5)."""
@@ -465,7 +465,7 @@ def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model,
     tokens = synthetic.make_tokens(R, C, 5)
     toks = torch.from_numpy(tokens).to("cuda:0")
     try:
-        ops.set_param("ln_fold", 3)                                          # folded at every shape (default: >= 4096 tokens)
+        ops.set_param("ln_fold", 3)                                          # folded at every shape (default: >= 18432 tokens)
         fold = m.forward_one(toks, has_padding=False)
         ops.set_param("ln_fold", 0)
         plain = m.forward_one(toks, has_padding=False)
@@ -485,7 +485,8 @@ def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model,
         ops.set_param("ln_fold", 1)
     assert rel_l2(self_sum["emb"].cpu().numpy(), fold["emb"].cpu().numpy()) < 2e-5
     assert rel_l2(fold["emb"].cpu().numpy(), plain["emb"].cpu().numpy()) < 2e-5
-    assert np.abs(fold["atp"].cpu().numpy() - plain["atp"].cpu().numpy()).max() < 1e-4
+    # two samples of fp32 noise: each is ~6e-5 (max-abs) from the fp64 truth at the deepest of these shapes
+    assert np.abs(fold["atp"].cpu().numpy() - plain["atp"].cpu().numpy()).max() < 2e-4
     res = O.forward(torch.from_numpy(tokens), O.to_torch_params(state, torch.float64))
     o_emb, o_atp = O.pack_outputs(res)
     e_fold, e_plain = rel_l2(fold["emb"].cpu().numpy(), o_emb.numpy()), rel_l2(plain["emb"].cpu().numpy(), o_emb.numpy())
@@ -501,15 +502,15 @@ def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model,
     finally:
         ops.set_param("ln_fold", 1)
     assert torch.equal(a["emb"], b["emb"]) and torch.equal(a["atp"], b["atp"])
-    # the default picks by size: below 4096 tokens the separate launches (they are faster there), from there on the fold
+    # the default picks by size: below 18432 tokens the separate launches (they are faster there), from there on the fold
     dflt = m.forward_one(toks, has_padding=False)
-    assert torch.equal(dflt["emb"], (fold if R * C >= 4096 else plain)["emb"])
+    assert torch.equal(dflt["emb"], (fold if R * C >= 18432 else plain)["emb"])
 
 
-def test_folded_layernorm_is_the_default_from_4096_tokens(model):
+def test_folded_layernorm_is_the_default_from_18432_tokens(model):
     from rnamsm import ops
     m, _ = model
-    toks = torch.from_numpy(synthetic.make_tokens(64, 64, 2)).to("cuda:0")
+    toks = torch.from_numpy(synthetic.make_tokens(144, 128, 2)).to("cuda:0")
     dflt = m.forward_one(toks, has_padding=False)
     try:
         ops.set_param("ln_fold", 3)
@@ -520,3 +521,29 @@ def test_folded_layernorm_is_the_default_from_4096_tokens(model):
         ops.set_param("ln_fold", 1)
     assert torch.equal(dflt["emb"], forced["emb"]) and torch.equal(dflt["atp"], forced["atp"])
     assert not torch.equal(dflt["emb"], plain["emb"]) and rel_l2(dflt["emb"].cpu().numpy(), plain["emb"].cpu().numpy()) < 2e-5
+
+
+def test_forward_falls_back_when_the_folded_layernorm_precondition_fails(model):
+    """A model whose residual stream carries a huge common offset (here: the embedding LayerNorm's bias set to 300, its
+    weight to 0.05) trips bit 1 of the forward's err word on the folded path; checked_forward_one then redoes the MSA with
+    separate LayerNorm launches and returns exactly what the unfolded forward returns.  The stock model never trips it."""
+    import warnings
+    from rnamsm.model import MSATransformer
+    m, state = model
+    toks = torch.from_numpy(synthetic.make_tokens(64, 96, 4)).to("cuda:0")
+    assert int(m.forward_one(toks, has_padding=False)["err"].item()) == 0
+    bad = MSATransformer(num_layers=2)
+    sd = {k: torch.from_numpy(v).clone() for k, v in synthetic.make_state_dict(seed=0, num_layers=2).items()}
+    sd["emb_layer_norm_before.bias"] = torch.full_like(sd["emb_layer_norm_before.bias"], 300.0)
+    sd["emb_layer_norm_before.weight"] = torch.full_like(sd["emb_layer_norm_before.weight"], 0.05)
+    bad.load_state_dict(sd, strict=True)
+    bad = bad.eval().to("cuda:0")
+    assert int(bad.forward_one(toks, has_padding=False)["err"].item()) & bad.ERR_FOLD
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = bad.checked_forward_one(toks, has_padding=False)
+    assert any("LayerNorm" in str(x.message) for x in w)
+    bad.fold_layernorm = False
+    want = bad.forward_one(toks, has_padding=False)
+    assert int(want["err"].item()) == 0
+    assert torch.equal(got["emb"], want["emb"]) and torch.equal(got["atp"], want["atp"])

@@ -70,14 +70,18 @@ def test_layernorm_folded_into_the_gemm(dev, M, N, K, act, scale_cols):
     part = ops.row_partials(x)
     assert part.shape == (K // 32, M, 2)                                      # slab-major
     slabs = xd.view(M, K // 32, 32).transpose(0, 1)
-    assert rel_l2(part[..., 0].cpu(), slabs.sum(-1).cpu()) < 1e-6 and rel_l2(part[..., 1].cpu(), (slabs ** 2).sum(-1).cpu()) < 1e-6
+    centred = ((slabs - slabs.mean(-1, keepdim=True)) ** 2).sum(-1)            # about the SLAB's mean (Chan-combined later)
+    assert rel_l2(part[..., 0].cpu(), slabs.sum(-1).cpu()) < 1e-6 and rel_l2(part[..., 1].cpu(), centred.cpu()) < 1e-5
     ref = ops.linear(ops.layernorm(x, g, be), w, b, act=act, scale=0.125, scale_cols=scale_cols)
     want = O.layer_norm(xd, g.double(), be.double()) @ w.double().t() + b.double()
     want[:, :scale_cols] *= 0.125
     if act:
         want = O.gelu_erf(want)
     e_ref = rel_l2(ref.cpu(), want.cpu())
-    for stats in (part, None):                                                # from the partial sums / summed in the GEMM
+    st = ops.row_stats_from_partials(part, K)
+    assert rel_l2(st[:, 0].cpu(), xd.mean(1).cpu()) < 1e-6
+    assert rel_l2(st[:, 1].cpu(), torch.rsqrt(xd.var(1, unbiased=False) + 1e-5).cpu()) < 1e-6
+    for stats in (st, None):                                                  # from the partial sums / summed in the GEMM
         y = ops.linear_lnfold(x, wg, c, d, stats, act=act, scale=0.125, scale_cols=scale_cols)
         e_fold = rel_l2(y.cpu(), want.cpu())
         assert e_fold < 3e-6 and e_fold < 2.0 * e_ref + 2e-7, (stats is None, e_fold, e_ref)
@@ -96,6 +100,36 @@ def test_layernorm_folded_into_the_gemm(dev, M, N, K, act, scale_cols):
             assert torch.equal(sub, y[:, 128:])
 
 
+def test_folded_layernorm_statistics_are_robust_and_its_precondition_is_reported(dev):
+    """(mean, rstd) come from per-slab centred sums combined as in Chan et al.: rows with a huge common offset still get
+    the right variance (E[x^2] - mean^2 in fp32 would return noise for them).  What cannot be rescued is the fold's own
+    subtraction of mean * c[n]: such rows set bit 1 of cond_flag so that the caller falls back to LayerNorm + Linear, and
+    ordinary rows (|mean| up to ~30x the spread) leave it clear."""
+    from rnamsm import ops
+    M, K, N = 256, 768, 256
+    base = _rand("rob.x", (M, K))
+    w, b = _rand("rob.w", (N, K), 0.05).to(dev), _rand("rob.b", (N,), 0.1).to(dev)
+    g, be = (1 + 0.1 * _rand("rob.g", (K,))).to(dev), (0.1 * _rand("rob.be", (K,))).to(dev)
+    wg, c, d = ops.ln_fold_weights(w, b, g, be)
+    for offset, flagged, tol in ((0.0, False, 3e-6), (10.0, False, 3e-5), (1000.0, True, None)):
+        x = (base + offset).to(dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        part = ops.row_partials(x)
+        st = ops.row_stats_from_partials(part, K, cond_flag=flag)
+        # the statistics against fp64: fine even at offset 1000 (spread 1)
+        xd = x.double()
+        assert rel_l2(st[:, 1].cpu(), torch.rsqrt(xd.var(1, unbiased=False) + 1e-5).cpu()) < 1e-4, offset
+        assert bool(flag.item() & 2) == flagged, (offset, int(flag.item()))
+        y = ops.linear_lnfold(x, wg, c, d, st)
+        if tol is not None:
+            want = O.layer_norm(xd, g.double(), be.double()) @ w.double().t() + b.double()
+            assert rel_l2(y.cpu(), want.cpu()) < tol, (offset, rel_l2(y.cpu(), want.cpu()))
+        flag.zero_()
+        ops.linear_lnfold(x, wg, c, d, None, cond_flag=flag)                   # the self-summing form reports it itself
+        assert bool(flag.item() & 2) == flagged, (offset, int(flag.item()))
+    # the forward hands its err word to the folded GEMMs: a healthy model leaves it 0 (checked on every bench / CLI run)
+
+
 def test_folded_gemm_over_the_first_rows_of_a_longer_stream(dev):
     """The outputs-only forward runs its last q projection / FFN over alignment row 0 only: the first C rows of x, with
     the row sums of all T rows lying slab-major in one buffer (partials_ld = T).  Same bits as the full-length GEMM's
@@ -107,9 +141,11 @@ def test_folded_gemm_over_the_first_rows_of_a_longer_stream(dev):
     g, be = (1 + 0.1 * _rand("ls.g", (D,))).to(dev), (0.1 * _rand("ls.be", (D,))).to(dev)
     wg, c, d = ops.ln_fold_weights(w, b, g, be)
     part = ops.row_partials(x)                                             # [D/32, T, 2]
-    full = ops.linear_lnfold(x, wg, c, d, part)
-    head = ops.linear_lnfold(x[:Mq], wg, c, d, part)                       # partials_ld = T > M = Mq
+    st = ops.row_stats_from_partials(part, D)                              # [T, 2]
+    full = ops.linear_lnfold(x, wg, c, d, st)
+    head = ops.linear_lnfold(x[:Mq], wg, c, d, st)                         # statistics of all T rows, GEMM over the first Mq
     assert torch.equal(head, full[:Mq])
+    assert torch.equal(ops.row_stats_from_partials(part, D, rows=Mq), st[:Mq])      # partials_ld = T > M = Mq
     # producer over the first Mq rows, writing into the T-row layout: only those rows' sums change
     from rnamsm import _lib
     a, wo, bo = _rand("ls.a", (Mq, D)).to(dev), _rand("ls.wo", (D, D), 0.05).to(dev), _rand("ls.bo", (D,), 0.1).to(dev)
@@ -142,7 +178,7 @@ def test_residual_gemm_leaves_the_row_sums_of_what_it_stores(dev, M, N, K):
         slabs = out.double().view(M, N // 32, 32).transpose(0, 1)
         assert part.shape == (N // 32, M, 2)
         assert rel_l2(part[..., 0].cpu(), slabs.sum(-1).cpu()) < 1e-6
-        assert rel_l2(part[..., 1].cpu(), (slabs ** 2).sum(-1).cpu()) < 1e-6
+        assert rel_l2(part[..., 1].cpu(), ((slabs - slabs.mean(-1, keepdim=True)) ** 2).sum(-1).cpu()) < 1e-5
         # the slab sums are those of rnamsm_row_partials on the stored tensor, up to the order of 32 additions
         again = ops.row_partials(out)
         assert rel_l2(part.cpu(), again.cpu()) < 1e-6

@@ -41,14 +41,16 @@ for tag, K in (("out_proj", D), ("fc2", F)):
     print(f"{tag:9s} plain {r['plain']:.4f} ms   + row sums {r['stats']:.4f} ms   ({1e3 * (r['stats'] - r['plain']):+.1f} us)")
 xn = ops.layernorm(x, g, be)
 part = ops.row_partials(x)
+st = ops.row_stats_from_partials(part, D)
 for tag, N, act, sc in (("qkv", 3 * D, ACT_NONE, D), ("fc1", F, ACT_GELU_ERF, 0), ("fc1 no act", F, ACT_NONE, 0), ("qkv gelu", 3 * D, ACT_GELU_ERF, 0)):
     w, b = torch.randn(N, D, device=dev) * 0.04, torch.randn(N, device=dev)
     wg, c, d = ops.ln_fold_weights(w, b, g, be)
     out = torch.empty(T, N, device=dev)
     r = bench({"plain": lambda: ops.linear(xn, w, b, act=act, scale=0.125, scale_cols=sc, out=out),
-               "fold": lambda: ops.linear_lnfold(x, wg, c, d, part, act=act, scale=0.125, scale_cols=sc, out=out),
+               "fold": lambda: ops.linear_lnfold(x, wg, c, d, st, act=act, scale=0.125, scale_cols=sc, out=out),
                "self": lambda: ops.linear_lnfold(x, wg, c, d, None, act=act, scale=0.125, scale_cols=sc, out=out)})
     print(f"{tag:9s} plain {r['plain']:.4f} ms   folded {r['fold']:.4f} ms ({1e3 * (r['fold'] - r['plain']):+.1f} us)   "
           f"folded, own sums {r['self']:.4f} ms ({1e3 * (r['self'] - r['plain']):+.1f} us)")
-ln = bench({"layernorm": lambda: ops.layernorm(x, g, be, out=xn), "row_partials": lambda: ops.row_partials(x)})
-print(f"layernorm {ln['layernorm']:.4f} ms   row_partials {ln['row_partials']:.4f} ms")
+ln = bench({"layernorm": lambda: ops.layernorm(x, g, be, out=xn), "row_partials": lambda: ops.row_partials(x),
+            "finalize": lambda: ops.row_stats_from_partials(part, D)})
+print(f"layernorm {ln['layernorm']:.4f} ms   row_partials {ln['row_partials']:.4f} ms   row_stats_from_partials {ln['finalize']:.4f} ms")
