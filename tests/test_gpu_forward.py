@@ -538,10 +538,15 @@ def test_forward_falls_back_when_the_folded_layernorm_precondition_fails(model):
     sd["emb_layer_norm_before.weight"] = torch.full_like(sd["emb_layer_norm_before.weight"], 0.05)
     bad.load_state_dict(sd, strict=True)
     bad = bad.eval().to("cuda:0")
-    assert int(bad.forward_one(toks, has_padding=False)["err"].item()) & bad.ERR_FOLD
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        got = bad.checked_forward_one(toks, has_padding=False)
+    from rnamsm import ops
+    try:
+        ops.set_param("ln_fold", 3)               # fold at this (small) size too
+        assert int(bad.forward_one(toks, has_padding=False)["err"].item()) & bad.ERR_FOLD
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = bad.checked_forward_one(toks, has_padding=False)
+    finally:
+        ops.set_param("ln_fold", 1)
     assert any("LayerNorm" in str(x.message) for x in w)
     bad.fold_layernorm = False
     want = bad.forward_one(toks, has_padding=False)
