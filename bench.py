@@ -511,7 +511,12 @@ def run_rank(args) -> int:
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"]),
                          "measured_in": f"separate pass after the headline loop, HIP-event pairs on the launch stream, "
-                                        f"{roof_local} MSA(s) on rank 0 in {roof_elapsed:.3f} s"},
+                                        f"{roof_local} MSA(s) on rank 0 in {roof_elapsed:.3f} s",
+                         "note": ("flops counted = 2MNK of the Linear layers only; these launches also carry the three "
+                                  "LayerNorms of every layer (applied to the accumulators of the QKV / fc1 GEMMs, row statistics "
+                                  "left by the out_proj / fc2 epilogues: no LayerNorm launches) -- un-fused the same kernel "
+                                  "measures 0.900 and the step is 1.25 % slower (DESIGN 3.4b)")
+                                 if (args.gemm_dtype == "f32" and M * L >= 18432) else None},
             "attention_mfma": {"kernels": "row_logits+row_apply+col_attn", "achieved": attn_fl / (attn_ms * 1e-3) / 1e12 if attn_ms else 0.0,
                                "peak": peak, "unit": flop_unit,
                                "frac": (attn_fl / (attn_ms * 1e-3) / 1e12 / peak) if attn_ms else 0.0},
