@@ -117,7 +117,8 @@ int rnamsm_gemm_lnfold(const float* X, int64_t ldx, const float* Wg, const float
  * residual [M,N] row stride ldr or NULL; Cout [M,N] row stride ldc (may alias residual).
  * Requires N % 128 == 0, K % 32 == 0, lda/ldr/ldc % 4 == 0 and 16-byte aligned pointers.
  * zero_rows (uint8 [M], may be NULL): rows flagged 1 get 0 in the scaled columns -- the reference's
- * `q *= 1 - padding_mask` (modules.py:767-772). */
+ * `q *= 1 - padding_mask` (modules.py:767-772).
+ * dtype: RNAMSM_F32 only (RNAMSM_ERR_UNSUPPORTED otherwise); the 16-bit modes of the same Linear are rnamsm_gemm_bf16. */
 int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float* W, const float* bias,
                              const float* residual, int64_t ldr, float* Cout, int64_t ldc,
                              int64_t M, int N, int K, int act, float scale, int scale_cols,
@@ -181,7 +182,9 @@ int rnamsm_softmax_rows_chunked(const float* partial, int nchunks, float* probs,
  *   ctx[r,i,h,:] = sum_j probs[h,i,j] * v[r,j,h,:]
  * v addressed like q/k above; ctx element (r,i,h,d) at ctx[(r*C+i)*ldc + h*64 + d].
  * With ctx_hi given the context is written instead as 16-bit hi (+ lo if non-NULL) planes with the same indexing
- * (plane_fmt 0 = bf16, 1 = fp16): the pre-split A operand of rnamsm_gemm_bf16 for the following out_proj. */
+ * (plane_fmt 0 = bf16, 1 = fp16): the pre-split A operand of rnamsm_gemm_bf16 for the following out_proj.
+ * dtype: RNAMSM_F32 only; the 16-bit modes are rnamsm_row_apply16 (and rnamsm_row_logits16 / rnamsm_softmax_rows_planes for
+ * K4 / K5, whose fp32 entry points rnamsm_row_logits[_chunked] likewise take RNAMSM_F32 only). */
 int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc,
                      int R, int C, int H, int head_dim, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt,
                      int dtype, void* stream);
@@ -191,7 +194,8 @@ int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, float* ctx,
  * (q already scaled by dh^-0.5).  The [H,C,R,R] probabilities are never written (the reference
  * computes and discards them).  R == 1 degenerates to ctx = v (modules.py:882-894).
  * pad_mask (uint8 [R, C], may be NULL): scores of keys flagged 1 are replaced by -10000 (modules.py:911-915).
- * ctx_hi / ctx_lo / plane_fmt: optional 16-bit plane output as for rnamsm_row_apply (not with pad_mask). */
+ * ctx_hi / ctx_lo / plane_fmt: optional 16-bit plane output as for rnamsm_row_apply (not with pad_mask).
+ * dtype: RNAMSM_F32 only; the 16-bit modes are rnamsm_col_attn16. */
 int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_t ld,
                           float* ctx, int64_t ldc, int R, int C, int H, int head_dim,
                           const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt,
@@ -199,7 +203,8 @@ int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_
 
 /* K7 restricted to the query rows [0, q_rows) of every column (keys / values: all R rows): what the LAST layer needs when
  * only alignment row 0 of the final representation is wanted (rnamsm_forward without RNAMSM_OUT_REPR).  Row i of ctx is
- * written for i < q_rows only and equals rnamsm_col_attn_fused's row i bit for bit. */
+ * written for i < q_rows only and equals rnamsm_col_attn_fused's row i bit for bit.
+ * dtype: RNAMSM_F32 only. */
 int rnamsm_col_attn_fused_queries(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc,
                                   int R, int C, int H, int head_dim, int q_rows, const uint8_t* pad_mask, int dtype,
                                   void* stream);
