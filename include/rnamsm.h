@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RNAMSM_VERSION 202 /* major*10000 + minor*100 + patch */
+#define RNAMSM_VERSION 203 /* major*10000 + minor*100 + patch */
 
 typedef enum {
     RNAMSM_OK = 0,
@@ -137,6 +137,23 @@ int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_hi, const ui
                      const float* residual, int64_t ldr, float* Cout, int64_t ldc, int64_t M, int N, int K,
                      int act, float scale, int scale_cols, int split, int fmt,
                      const uint16_t* A_hi, const uint16_t* A_lo, uint16_t* O_hi, uint16_t* O_lo, void* stream);
+/* K1 folded in the 16-bit modes (same scheme as rnamsm_gemm_lnfold / rnamsm_gemm_residual_stats above; 256x256-tile kernels:
+ * M >= 2048, N % 256 == 0, K % 64 == 0):
+ *   rnamsm_gemm16_lnfold          O planes = act( (rstd[m] (sum_k X[m,k] Wg[n,k] - mean[m] c[n]) + d[n]) * colscale ): X planes hold
+ *                                 the RAW residual stream, Wg planes = rnamsm_split_bf16(W * gamma), c[n] = the row sums of the
+ *                                 Wg planes' values (hi + lo), d = bias + W beta; row_stats [M,2] from
+ *                                 rnamsm_row_stats_from_partials.  Output as planes (the QKV / fc1 shapes).
+ *   rnamsm_gemm16_residual_stats  x[m,:] += A W^T + bias in place (fp32 residual stream, out_proj / fc2), the new x written
+ *                                 once more as 16-bit planes X_hi/X_lo [M, ldp] (the next rnamsm_gemm16_lnfold's operand) and
+ *                                 its slab sums left in row_partials [N/32, partials_ld, 2]. */
+int rnamsm_gemm16_lnfold(const uint16_t* X_hi, const uint16_t* X_lo, int64_t ldx, const uint16_t* Wg_hi,
+                         const uint16_t* Wg_lo, const float* cvec, const float* dvec, const float* row_stats,
+                         uint16_t* O_hi, uint16_t* O_lo, int64_t ldo, int64_t M, int N, int K, int act, float scale,
+                         int scale_cols, int split, int fmt, void* stream);
+int rnamsm_gemm16_residual_stats(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, const uint16_t* W_hi,
+                                 const uint16_t* W_lo, const float* bias, float* x, int64_t ldx, int64_t M, int N,
+                                 int K, int split, int fmt, uint16_t* X_hi, uint16_t* X_lo, int64_t ldp,
+                                 float* row_partials, int64_t partials_ld, void* stream);
 /* LayerNorm (K1) whose output is written as 16-bit hi/lo planes [T, D] (lo may be NULL), the pre-split A operand of
  * rnamsm_gemm_bf16: with A_hi/A_lo given (row stride lda halves) A is ignored and no conversion runs in the GEMM;
  * with O_hi/O_lo given (fc1: GELU; QKV: no activation; never with a residual) the result is written as planes with row stride ldc for the next
@@ -325,6 +342,10 @@ size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int 
  * rnamsm_ln_fold_weights, {Wg, c, d} for {row QKV [3D,D] with the row LayerNorm, column QKV with the column LayerNorm,
  * fc1 [F,D] with the FFN LayerNorm}.  Used by the exact path on MSAs without padding (knob "ln_fold"). */
 #define RNAMSM_FOLDED_PER_LAYER 9
+/* ln_folded16 (host array, may be NULL): the same for the 16-bit modes (planes end to end, "attn16" on, no padding): for
+ * every layer 12 device pointers {Wg_hi, Wg_lo (NULL for RNAMSM_BF16), c, d} for {row QKV, column QKV, fc1}; Wg planes =
+ * rnamsm_split_bf16(W * gamma) in the mode's format, c = row sums of the plane values (rnamsm_gemm16_lnfold). */
+#define RNAMSM_FOLDED16_PER_LAYER 12
 /* outputs: RNAMSM_OUT_REPR = the whole final representation repr [R*C, D] is wanted (MSATransformer.forward's
  * representations[num_layers]).  Without it only what extract_feat writes is produced -- emb (alignment row 0) and atp
  * (RNA_MSM_Inference.py:151-166) -- and the last layer stops computing the other rows once its tied row attention is done:
@@ -337,7 +358,8 @@ int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, c
                    int R, int C, void* workspace, size_t workspace_bytes,
                    float* row_attn, float* repr, float* emb, float* atp,
                    int* err_flag, int has_padding, int max_tokens_per_msa, int outputs, int dtype,
-                   const uint16_t* const* weight_planes, const float* const* ln_folded, void* stream);
+                   const uint16_t* const* weight_planes, const float* const* ln_folded,
+                   const void* const* ln_folded16, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's
  * roofline block; adds two event records per launch while enabled, nothing when disabled).
@@ -376,8 +398,9 @@ void rnamsm_timing_reset(void);
  *                 rows, three launches per step (one thread per row) above; 2 = always one; 0 = always three.  Same indices.
  *   "ln_fold"     rnamsm_forward with ln_folded given: 1 (default) = LayerNorm folded into the QKV / fc1 GEMMs, row sums
  *                 left by the out_proj / fc2 epilogues, for MSAs of R*C >= 18432 tokens (below that the separate launches
- *                 are faster); 3 = for every shape; 2 = folded, every GEMM sums the rows it stages itself; 0 = separate
- *                 LayerNorm launches (all agree to fp32 rounding).
+ *                 are faster); 3 = for every shape, and in the 16-bit modes too (ln_folded16; measured neutral there, hence
+ *                 not the default); 2 = folded, every GEMM sums the rows it stages itself; 0 = separate LayerNorm launches
+ *                 (all agree to fp32 rounding, resp. to the 16-bit mode's rounding).
  *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit
  *                 matrix cores in the mode's operand format (K4'..K7'), 0 = they stay on the exact-fp32 kernels,
  *                 2 = as 1 but the row kernels keep 128x128 tiles for every C (A/B of the 256x256-tile kernels).

@@ -65,7 +65,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
                               int R, int C, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
                               float* emb, float* atp, int* err_flag, int has_padding, int max_tokens_per_msa, int outputs,
                               int dtype, const uint16_t* const* weight_planes, const float* const* ln_folded,
-                              void* stream) {
+                              const void* const* ln_folded16, void* stream) {
     RNAMSM_CHECK_ARG(dtype >= RNAMSM_F32 && dtype <= RNAMSM_F16X3, "forward: unknown dtype %d", dtype);
     RNAMSM_CHECK_ARG(dtype == RNAMSM_F32 || weight_planes, "forward: bf16 modes need weight_planes");
     RNAMSM_CHECK_ARG(dims && weights && tokens && workspace && row_attn && repr && emb && atp, "forward: null pointer");
@@ -156,11 +156,31 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
                       (fold_mode >= 2 || (fold_mode == 1 && (int64_t)R * C >= 18432));
     const bool fold_sums = fold && fold_mode != 2;   // row sums travel from the residual epilogues to the consumers
     float* rowsum = reinterpret_cast<float*>(ws + lay.rowsum);
+    float* stats = reinterpret_cast<float*>(ws + lay.stats);
+    // 16-bit modes (planes end to end, 16-bit attention, no padding): the same fold on the 256x256 matrix-core kernels --
+    // the residual GEMMs also write the new x as planes and its slab sums, the QKV / fc1 GEMMs read those planes
+    // (rnamsm_gemm16_residual_stats / rnamsm_gemm16_lnfold); rnamsm_layernorm_split is no launch at all.
+    // Measured (tools/ln_fold_ab.py with DTYPE=bf16 / f16x3): the LayerNorm launches disappear (cfg3 bf16: 3.2 -> 0.25 ms,
+    // 1024^2: 26.9 -> 2.2 ms) and the GEMMs take exactly that much longer (28.6 -> 30.9 ms, 223.6 -> 245.7 ms; f16x3 the
+    // same picture): with one 256x256 block per CU nothing hides an epilogue, and the extra plane writes sit in the
+    // HBM-bound out_proj.  Net +-0.2 %, so the 16-bit modes fold only on request (knob "ln_fold" = 3).
+    const bool fold16 = ln_folded16 && attn16 && !has_padding && D % 256 == 0 && F % 256 == 0 && T >= 2048 && fold_mode == 3;
+    auto lin16_fold = [&](int layer, int fslot, uint16_t* ohi, uint16_t* olo, int64_t ldo, int N, int act) -> int {
+        const void* const* Fp = ln_folded16 + (size_t)layer * RNAMSM_FOLDED16_PER_LAYER + 4 * fslot;
+        return rnamsm_gemm16_lnfold(xn_hi, xn_lo, D, static_cast<const uint16_t*>(Fp[0]), static_cast<const uint16_t*>(Fp[1]),
+                                    static_cast<const float*>(Fp[2]), static_cast<const float*>(Fp[3]), stats, ohi, olo, ldo, T, N,
+                                    D, act, 1.f, 0, split, fmt, stream);
+    };
+    // x += A W^T + bias, the new x once more as the xn planes, its slab sums -> (mean, rstd)
+    auto res16_fold = [&](int layer, int slot, const uint16_t* ahi, const uint16_t* alo, int64_t lda, const float* bias, int K) -> int {
+        const uint16_t* const* P = weight_planes + (size_t)layer * RNAMSM_PLANES_PER_LAYER + 2 * slot;
+        FWD(rnamsm_gemm16_residual_stats(ahi, alo, lda, P[0], P[1], bias, x, D, T, D, K, split, fmt, xn_hi, xn_lo, D, rowsum, T, stream));
+        return rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream);
+    };
     auto norm = [&](const float* g, const float* b, int64_t rows) -> int {
         if (fold) return RNAMSM_OK;
         return rnamsm_layernorm(x, g, b, xn, rows, D, d.ln_eps, stream);
     };
-    float* stats = reinterpret_cast<float*>(ws + lay.stats);
     // x[:rows] += A W^T + bias on the exact path; folded: + the rows' slab sums, combined into (mean, rstd) right away
     auto res_linear = [&](const float* A, int64_t lda, const float* Wf, const float* bias, int64_t rows, int K) -> int {
         if (fold_sums) {
@@ -191,6 +211,11 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     FWD(rnamsm_embed_ln(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
                         G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, R, C, D, d.vocab, d.num_positions,
                         d.pad_idx, d.ln_eps, err_flag, stream));
+    if (fold16) {                                    // K0's output as planes, with its statistics
+        FWD(rnamsm_split_bf16(x, xn_hi, xn_lo, T * D, fmt, stream));
+        FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
+        FWD(rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream));
+    }
     if (fold_sums) {
         FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
         FWD(rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream));
@@ -199,11 +224,14 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
         float* probs = row_attn + (int64_t)l * H * C * C;
         // ---- tied row attention block
-        if (!fold) FWD(ln_for_gemm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
+        if (!fold && !fold16) FWD(ln_for_gemm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
         if (attn16) {
             // q stays unscaled in the planes; the scaling multiplies the fp32 logits (see include/rnamsm.h)
-            FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
-                          RNAMSM_ACT_NONE, 1.f, 0));
+            if (fold16)
+                FWD(lin16_fold(l, 0, qkv_hi, qkv_lo, ldq, 3 * D, RNAMSM_ACT_NONE));
+            else
+                FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
+                              RNAMSM_ACT_NONE, 1.f, 0));
             if (mask) FWD(rnamsm_zero_plane_rows(qkv_hi, qkv_lo, mask, T, D, ldq, stream));      // q *= 1 - padding_mask
             FWD(rnamsm_row_logits16(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), ldq, part, R, C, H, 64, row_scale, fmt, stream));
             FWD(rnamsm_softmax_rows_planes(part, rnamsm_row_logits16_nsplit(R, C, H, split), probs, p_hi, p_lo, ldp, 4096.f, H, C,
@@ -228,7 +256,9 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             }
             FWD(rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, ctx_hi, ctx_lo, fmt, f32, stream));
         }
-        if (planes)
+        if (fold16)
+            FWD(res16_fold(l, 1, ctx_hi, ctx_lo, D, W[RNAMSM_WL_ROW_BO], D));
+        else if (planes)
             FWD(linear_pl(l, 1, ctx_hi, ctx_lo, D, W[RNAMSM_WL_ROW_BO], x, D, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE, 1.f, 0));
         else
             FWD(dtype == RNAMSM_F32 ? res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], T, D)
@@ -253,10 +283,13 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             return RNAMSM_OK;
         }
         // ---- column attention block
-        if (!fold) FWD(ln_for_gemm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
+        if (!fold && !fold16) FWD(ln_for_gemm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
         if (attn16) {
-            FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
-                          RNAMSM_ACT_NONE, 1.f, 0));
+            if (fold16)
+                FWD(lin16_fold(l, 1, qkv_hi, qkv_lo, ldq, 3 * D, RNAMSM_ACT_NONE));
+            else
+                FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
+                              RNAMSM_ACT_NONE, 1.f, 0));
             FWD(rnamsm_col_attn16(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C,
                                   H, 64, col_scale, mask, ctx_hi, ctx_lo, fmt, stream));
         } else {
@@ -270,14 +303,23 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
                            RNAMSM_ACT_NONE, col_scale, D, nullptr));
             FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, mask, ctx_hi, ctx_lo, fmt, f32, stream));
         }
-        if (planes)
+        if (fold16)
+            FWD(res16_fold(l, 3, ctx_hi, ctx_lo, D, W[RNAMSM_WL_COL_BO], D));
+        else if (planes)
             FWD(linear_pl(l, 3, ctx_hi, ctx_lo, D, W[RNAMSM_WL_COL_BO], x, D, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE, 1.f, 0));
         else
             FWD(dtype == RNAMSM_F32 ? res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], T, D)
                                     : linear(l, 3, ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
         // ---- feed-forward block
-        if (!fold) FWD(ln_for_gemm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
-        if (planes) {
+        if (!fold && !fold16) FWD(ln_for_gemm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
+        if (fold16) {
+            FWD(lin16_fold(l, 2, hid_hi, hid_lo, F, F, RNAMSM_ACT_GELU_ERF));
+            if (l + 1 < NL)
+                FWD(res16_fold(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], F));
+            else      // the last fc2 feeds the final LayerNorm kernel, which reads the fp32 stream
+                FWD(linear_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, D, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE,
+                              1.f, 0));
+        } else if (planes) {
             FWD(linear_pl(l, 4, xn_hi, xn_lo, D, W[RNAMSM_WL_FC1_B], nullptr, 0, nullptr, hid_hi, hid_lo, F, F, D,
                           RNAMSM_ACT_GELU_ERF, 1.f, 0));
             FWD(linear_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, D, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE,

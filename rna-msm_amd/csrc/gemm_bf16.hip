@@ -83,6 +83,85 @@ __device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, typename 
     }
 }
 
+// K1 folded into the 16-bit GEMMs (the scheme of gemm_f32.hip FOLD / STATS).  Runtime switches of the two
+// 256x256 kernels (null pointers = the plain epilogue):
+//   consumer (QKV / fc1; A planes = the RAW residual stream, W planes = W * gamma): stats [M, 2] = (mean, rstd) per row,
+//     c [N] = row sums of the Wg planes, `bias` carries d [N]:  out = act((rstd (acc - mean c) + d) * colscale)
+//   producer (out_proj / fc2 + residual): besides the fp32 residual stream it writes the same values as 16-bit planes
+//     xhi / xlo [M, ldx] (the next consumer's A operand: LayerNorm never runs as a launch) and leaves the slab sums
+//     partials [N/32, pld, 2] (sum, sum of squares about the slab mean) for rnamsm_row_stats_from_partials.
+struct Fold16 {
+    const float* c = nullptr;
+    const float2* stats = nullptr;
+    float2* partials = nullptr;
+    int64_t pld = 0;
+    uint16_t* xhi = nullptr;
+    uint16_t* xlo = nullptr;
+    int64_t ldx = 0;
+};
+__device__ __forceinline__ float sum8_dpp16(float v) {      // sum over aligned groups of 8 lanes (i^1, i^2, 7-i), no LDS
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    return v;
+}
+// second half of both epilogues (row-per-lane layout: lane -> row er + 4 i, columns ec .. ec + 3 of the wave's 64x64 slab)
+template <int ACT, int SPLIT, int FMT>
+__device__ __forceinline__ void fold16_rows(f32x4 (&ov)[16], const Fold16& fa, const float2 (&st)[16], const f32x4& c4,
+                                            const f32x4& d4, float fs) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[i][e] = fmaf(st[i].y, fmaf(-st[i].x, c4[e], ov[i][e]), d4[e]) * fs;
+        if (ACT == RNAMSM_ACT_GELU_ERF) {
+            const f32x2 g0 = gelu_erf2(f32x2{ov[i][0], ov[i][1]}), g1 = gelu_erf2(f32x2{ov[i][2], ov[i][3]});
+            ov[i] = f32x4{g0[0], g0[1], g1[0], g1[1]};
+        }
+    }
+}
+template <int SPLIT, int FMT>
+__device__ __forceinline__ void fold16_produce(const f32x4 (&ov)[16], const Fold16& fa, float* stage, int lane, int er, int ec,
+                                               int gm0, int gn, int gnb, int M) {
+    constexpr int LDE = 64 + 4;
+    typedef typename Half16<FMT>::T H;
+    typedef H H4 __attribute__((ext_vector_type(4)));
+    // the stored residual stream once more as planes
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (gm0 + er + 4 * i < M) {
+            H4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[e] = (H)ov[i][e];
+                lo[e] = (H)(ov[i][e] - (float)hi[e]);
+            }
+            const int64_t o = (int64_t)(gm0 + er + 4 * i) * fa.ldx + gn;
+            epi_store(reinterpret_cast<H4*>(fa.xhi + o), hi);
+            if (SPLIT == 3) epi_store(reinterpret_cast<H4*>(fa.xlo + o), lo);
+        }
+    }
+    // slab sums of the fp32 values (8 lanes = 32 columns of a row), parked in the staging rows' padding, then lane = row
+    float ps[16], pq[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ps[i] = sum8_dpp16((ov[i][0] + ov[i][1]) + (ov[i][2] + ov[i][3]));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float mb = ps[i] * (1.f / 32.f);
+        const float d0 = ov[i][0] - mb, d1 = ov[i][1] - mb, d2 = ov[i][2] - mb, d3 = ov[i][3] - mb;
+        pq[i] = sum8_dpp16(fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, d3 * d3))));
+    }
+    if ((lane & 7) == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<float2*>(&stage[(er + 4 * i) * LDE + 64 + 2 * (ec / 32)]) = float2{ps[i], pq[i]};
+    }
+    float2* pout = fa.partials + (int64_t)(gnb / 32) * fa.pld + gm0 + lane;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const float2 pr = *reinterpret_cast<const float2*>(&stage[lane * LDE + 64 + 2 * sl]);
+        if (gm0 + lane < M) pout[(int64_t)sl * fa.pld] = pr;
+    }
+}
+
 // Epilogue shared by the 16-bit GEMM kernels: identical to gemm_f32.hip (the 32x32 accumulator map does not depend on
 // the operand dtype); O_PL writes 16-bit planes for the next GEMM instead of fp32.
 template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
@@ -90,10 +169,11 @@ __device__ __forceinline__ void hb_epilogue(f32x16 (&acc)[2][2], char* smem_b, i
                                             int lane, int li, int lh, const float* __restrict__ bias,
                                             const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M,
                                             float scale, int scale_cols, uint16_t* __restrict__ Ohi,
-                                            uint16_t* __restrict__ Olo) {
+                                            uint16_t* __restrict__ Olo, const Fold16& fa = Fold16{}) {
     constexpr int LDE = 64 + 4;
     const int er = lane >> 4, ec = (lane & 15) * 4;
     const int gn = gnb + ec;                                  // gm0 / gnb: global origin of this wave's 64x64 slab
+    const bool fold = !HAS_RES && fa.stats != nullptr;        // uniform
     f32x4 res[16];
     if (HAS_RES) {
 #pragma unroll
@@ -102,19 +182,27 @@ __device__ __forceinline__ void hb_epilogue(f32x16 (&acc)[2][2], char* smem_b, i
             res[i] = epi_load(reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn));
         }
     }
+    float2 st[16];
+    f32x4 c4, d4;
+    if (fold) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = fa.stats[min(gm0 + er + 4 * i, M - 1)];
+        c4 = *reinterpret_cast<const f32x4*>(fa.c + gn);
+        d4 = *reinterpret_cast<const f32x4*>(bias + gn);
+    }
     __syncthreads();
     float* stage = reinterpret_cast<float*>(smem_b) + wv * (64 * LDE);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = gnb + nt * 32 + li;
-        const float b = bias ? bias[col] : 0.f;
-        const float sc = col < scale_cols ? scale : 1.f;
+        const float b = (!fold && bias) ? bias[col] : 0.f;
+        const float sc = (!fold && col < scale_cols) ? scale : 1.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {                    // pairs: the GELU runs on the packed-fp32 VALU
-                f32x2 v = f32x2{(acc[mt][nt][t] + b) * sc, (acc[mt][nt][t + 1] + b) * sc};
-                if (ACT == RNAMSM_ACT_GELU_ERF) v = gelu_erf2(v);
+                f32x2 v = f32x2{(acc[mt][nt][t] + b) * sc, (acc[mt][nt][t + 1] + b) * sc};   // fold: the raw sums
+                if (ACT == RNAMSM_ACT_GELU_ERF && !fold) v = gelu_erf2(v);
                 stage[(mt * 32 + (t & 3) + 8 * (t >> 2) + 4 * lh) * LDE + nt * 32 + li] = v[0];
                 stage[(mt * 32 + ((t + 1) & 3) + 8 * ((t + 1) >> 2) + 4 * lh) * LDE + nt * 32 + li] = v[1];
             }
@@ -125,6 +213,8 @@ __device__ __forceinline__ void hb_epilogue(f32x16 (&acc)[2][2], char* smem_b, i
         ov[i] = *reinterpret_cast<const f32x4*>(&stage[(er + 4 * i) * LDE + ec]);
         if (HAS_RES) ov[i] += res[i];
     }
+    if (fold) fold16_rows<ACT, SPLIT, FMT>(ov, fa, st, c4, d4, gn < scale_cols ? scale : 1.f);
+    if (HAS_RES && fa.partials) fold16_produce<SPLIT, FMT>(ov, fa, stage, lane, er, ec, gm0, gn, gnb, M);
     if (O_PL) {      // 4 values -> 4 halves hi (+ 4 halves lo): 8-byte stores into the planes
         typedef typename Half16<FMT>::T H;
         typedef H H4 __attribute__((ext_vector_type(4)));
@@ -569,7 +659,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo, int64_t lda, const uint16_t* __restrict__ Whi,
     const uint16_t* __restrict__ Wlo, const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout,
     int64_t ldc, int M, int N, int K, float scale, int scale_cols, uint16_t* __restrict__ Ohi, uint16_t* __restrict__ Olo,
-    int group, unsigned total_tiles, int stagger_cycles) {
+    int group, unsigned total_tiles, int stagger_cycles, Fold16 fa) {
     using Cfg = HsCfg<SPLIT, BK>;
     constexpr int NPL = Cfg::NPL, ROWB = Cfg::ROWB, PLANE = Cfg::PLANE, KS = Cfg::KS;
     constexpr int NMF = 8 * (SPLIT == 3 ? 3 : 1);          // MFMAs per k step per wave
@@ -699,14 +789,15 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     for (int p = 0; p < 2; ++p)
         hb_epilogue<ACT, HAS_RES, SPLIT, FMT, O_PL>(reinterpret_cast<f32x16(&)[2][2]>(acc[2 * p]), smem_b,
                                                     m0 + wm * 128 + p * 64, n0 + wn * 64, wv, lane, li, lh, bias, residual,
-                                                    ldr, Cout, ldc, M, scale, scale_cols, Ohi, Olo);
+                                                    ldr, Cout, ldc, M, scale, scale_cols, Ohi, Olo, fa);
     }   // persistent tile loop
 }
 
 template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL, int BK>
 static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias, const float* residual, int64_t ldr,
                      float* Cout, int64_t ldc, int64_t lda, int M, int N, int K, float scale, int scale_cols,
-                     const uint16_t* a_hi, const uint16_t* a_lo, uint16_t* o_hi, uint16_t* o_lo, hipStream_t stream) {
+                     const uint16_t* a_hi, const uint16_t* a_lo, uint16_t* o_hi, uint16_t* o_lo, hipStream_t stream,
+                     const Fold16& fa = Fold16{}) {
     static DeviceOnce configured;
     auto kern = gemm16_swp_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL, BK>;
     constexpr int lds = HsCfg<SPLIT, BK>::LDS;
@@ -726,7 +817,7 @@ static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
     const unsigned grid = pb && pb < total ? pb : total;
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 2.0 * HxCfg<SPLIT>::NPL * ((double)M * K + (double)N * K) + 4.0 * (double)M * N * (HAS_RES ? 2 : 1), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, a_lo, lda, Whi, Wlo, bias, residual, ldr, Cout,
-                       ldc, M, N, K, scale, scale_cols, o_hi, o_lo, group, total, pb ? tuning().gemm16_stagger : 0);
+                       ldc, M, N, K, scale, scale_cols, o_hi, o_lo, group, total, pb ? tuning().gemm16_stagger : 0, fa);
     RNAMSM_CHECK_LAUNCH("gemm16_swp");
     return RNAMSM_OK;
 }
@@ -743,11 +834,13 @@ typedef float f32x4a __attribute__((ext_vector_type(4)));
 template <int ACT, bool HAS_RES, bool O_PL>
 __device__ __forceinline__ void hq_epilogue(f32x4a (&acc)[8][4], int p, char* smem_b, int gm0, int gnb, int wv, int lane,
                                             const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout,
-                                            int64_t ldc, int M, float scale, int scale_cols, uint16_t* __restrict__ Ohi) {
+                                            int64_t ldc, int M, float scale, int scale_cols, uint16_t* __restrict__ Ohi,
+                                            const Fold16& fa = Fold16{}) {
     constexpr int LDE = 64 + 4;
     const int er = lane >> 4, ec = (lane & 15) * 4;
     const int fr = lane & 15, fq = lane >> 4;
     const int gn = gnb + ec;                                  // gm0 / gnb: global origin of this wave's 64x64 slab
+    const bool fold = !HAS_RES && fa.stats != nullptr;        // uniform
     f32x4 res[16];
     if (HAS_RES) {
 #pragma unroll
@@ -756,19 +849,27 @@ __device__ __forceinline__ void hq_epilogue(f32x4a (&acc)[8][4], int p, char* sm
             res[i] = epi_load(reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn));
         }
     }
+    float2 st[16];
+    f32x4 c4, d4;
+    if (fold) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) st[i] = fa.stats[min(gm0 + er + 4 * i, M - 1)];
+        c4 = *reinterpret_cast<const f32x4*>(fa.c + gn);
+        d4 = *reinterpret_cast<const f32x4*>(bias + gn);
+    }
     __syncthreads();
     float* stage = reinterpret_cast<float*>(smem_b) + wv * (64 * LDE);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int col = gnb + nt * 16 + fr;
-        const float b = bias ? bias[col] : 0.f;
-        const float sc = col < scale_cols ? scale : 1.f;
+        const float b = (!fold && bias) ? bias[col] : 0.f;
+        const float sc = (!fold && col < scale_cols) ? scale : 1.f;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; j += 2) {                     // accumulator element j = row 4*fq + j of the 16x16 tile
                 f32x2 v = f32x2{(acc[4 * p + mt][nt][j] + b) * sc, (acc[4 * p + mt][nt][j + 1] + b) * sc};
-                if (ACT == RNAMSM_ACT_GELU_ERF) v = gelu_erf2(v);
+                if (ACT == RNAMSM_ACT_GELU_ERF && !fold) v = gelu_erf2(v);
                 stage[(mt * 16 + 4 * fq + j) * LDE + nt * 16 + fr] = v[0];
                 stage[(mt * 16 + 4 * fq + j + 1) * LDE + nt * 16 + fr] = v[1];
             }
@@ -779,6 +880,7 @@ __device__ __forceinline__ void hq_epilogue(f32x4a (&acc)[8][4], int p, char* sm
         ov[i] = *reinterpret_cast<const f32x4*>(&stage[(er + 4 * i) * LDE + ec]);
         if (HAS_RES) ov[i] += res[i];
     }
+    if (fold) fold16_rows<ACT, 1, 0>(ov, fa, st, c4, d4, gn < scale_cols ? scale : 1.f);
     if (O_PL) {
         typedef typename Half16<0>::T H;
         typedef H H4 __attribute__((ext_vector_type(4)));
@@ -805,7 +907,7 @@ template <int ACT, bool HAS_RES, bool O_PL>
 __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16_kernel(
     const uint16_t* __restrict__ Ahi, int64_t lda, const uint16_t* __restrict__ Whi, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
-    uint16_t* __restrict__ Ohi, int group, unsigned total_tiles) {
+    uint16_t* __restrict__ Ohi, int group, unsigned total_tiles, Fold16 fa) {
     using Cfg = HsCfg<1, 64>;
     constexpr int BK = 64, ROWB = Cfg::ROWB, PLANE = Cfg::PLANE, KS = 2;     // two 32-deep k-steps per tile
     typedef typename Half16<0>::V8 V8;
@@ -926,14 +1028,14 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16_kernel(
 #pragma unroll
     for (int p = 0; p < 2; ++p)
         hq_epilogue<ACT, HAS_RES, O_PL>(acc, p, smem_b, m0 + wm * 128 + p * 64, n0 + wn * 64, wv, lane, bias, residual, ldr,
-                                        Cout, ldc, M, scale, scale_cols, Ohi);
+                                        Cout, ldc, M, scale, scale_cols, Ohi, fa);
     }   // persistent tile loop
 }
 
 template <int ACT, bool HAS_RES, bool O_PL>
 static int launch_hq(const uint16_t* Whi, const float* bias, const float* residual, int64_t ldr, float* Cout, int64_t ldc,
                      int64_t lda, int M, int N, int K, float scale, int scale_cols, const uint16_t* a_hi, uint16_t* o_hi,
-                     hipStream_t stream) {
+                     hipStream_t stream, const Fold16& fa = Fold16{}) {
     static DeviceOnce configured;
     auto kern = gemm16_q16_kernel<ACT, HAS_RES, O_PL>;
     constexpr int lds = HsCfg<1, 64>::LDS;
@@ -948,7 +1050,7 @@ static int launch_hq(const uint16_t* Whi, const float* bias, const float* residu
     const unsigned grid = pb && pb < total ? pb : total;
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * N * (HAS_RES ? 2 : 1), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, lda, Whi, bias, residual, ldr, Cout, ldc, M, N, K,
-                       scale, scale_cols, o_hi, group, total);
+                       scale, scale_cols, o_hi, group, total, fa);
     RNAMSM_CHECK_LAUNCH("gemm16_q16");
     return RNAMSM_OK;
 }
@@ -1134,6 +1236,73 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
 #undef HS_GO
 #undef HX_GO
 #undef HB_GO
+}
+
+// K1 folded, 16-bit modes: the two entry points of the 256x256 kernels with Fold16 set.
+extern "C" int rnamsm_gemm16_lnfold(const uint16_t* X_hi, const uint16_t* X_lo, int64_t ldx, const uint16_t* Wg_hi,
+                                    const uint16_t* Wg_lo, const float* cvec, const float* dvec, const float* row_stats,
+                                    uint16_t* O_hi, uint16_t* O_lo, int64_t ldo, int64_t M, int N, int K, int act, float scale,
+                                    int scale_cols, int split, int fmt, void* stream) {
+    RNAMSM_CHECK_ARG(X_hi && Wg_hi && cvec && dvec && row_stats && O_hi, "gemm16_lnfold: null pointer");
+    RNAMSM_CHECK_ARG(split == 1 || (split == 3 && X_lo && Wg_lo && O_lo), "gemm16_lnfold: split must be 1, or 3 with lo planes");
+    RNAMSM_CHECK_ARG((fmt == 0) || (fmt == 1 && split == 3), "gemm16_lnfold: fmt 0 (bf16) or 1 (fp16, split 3 only)");
+    RNAMSM_CHECK_ARG(M >= 2048 && M <= INT32_MAX && N > 0 && N % HX_BN == 0 && K > 0 && K % 64 == 0,
+                     "gemm16_lnfold: the 256x256 kernels need M >= 2048, N %% 256 == 0, K %% 64 == 0 (M=%lld N=%d K=%d)", (long long)M, N, K);
+    RNAMSM_CHECK_ARG(ldx >= K && ldx % 8 == 0 && ldo >= N && ldo % 4 == 0 && scale_cols >= 0 && scale_cols % 4 == 0,
+                     "gemm16_lnfold: bad leading dimension / scale_cols");
+    RNAMSM_CHECK_ARG(aligned16(X_hi) && (!X_lo || aligned16(X_lo)) && aligned16(Wg_hi) && (!Wg_lo || aligned16(Wg_lo)) &&
+                     aligned16(cvec) && aligned16(dvec) && (reinterpret_cast<uintptr_t>(row_stats) & 7u) == 0 &&
+                     (reinterpret_cast<uintptr_t>(O_hi) & 7u) == 0 && (!O_lo || (reinterpret_cast<uintptr_t>(O_lo) & 7u) == 0),
+                     "gemm16_lnfold: alignment");
+    RNAMSM_CHECK_ARG(act == RNAMSM_ACT_NONE || act == RNAMSM_ACT_GELU_ERF, "gemm16_lnfold: unknown activation %d", act);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int m = (int)M;
+    Fold16 fa;
+    fa.c = cvec;
+    fa.stats = reinterpret_cast<const float2*>(row_stats);
+#define LF_HS(ACT_, SP_, FMT_, BK_) \
+    launch_hs<ACT_, false, SP_, FMT_, true, BK_>(Wg_hi, Wg_lo, dvec, nullptr, 0, nullptr, ldo, ldx, m, N, K, scale, scale_cols, X_hi, X_lo, O_hi, O_lo, s, fa)
+#define LF_HQ(ACT_) launch_hq<ACT_, false, true>(Wg_hi, dvec, nullptr, 0, nullptr, ldo, ldx, m, N, K, scale, scale_cols, X_hi, O_hi, s, fa)
+    const bool gelu = act == RNAMSM_ACT_GELU_ERF;
+    if (split == 1) {
+        if (tuning().gemm16_mfma16 == 1 ? N / HX_BN > 4 : tuning().gemm16_mfma16 == 2)
+            return gelu ? LF_HQ(RNAMSM_ACT_GELU_ERF) : LF_HQ(RNAMSM_ACT_NONE);
+        return gelu ? LF_HS(RNAMSM_ACT_GELU_ERF, 1, 0, 64) : LF_HS(RNAMSM_ACT_NONE, 1, 0, 64);
+    }
+    if (fmt == 1) return gelu ? LF_HS(RNAMSM_ACT_GELU_ERF, 3, 1, 32) : LF_HS(RNAMSM_ACT_NONE, 3, 1, 32);
+    return gelu ? LF_HS(RNAMSM_ACT_GELU_ERF, 3, 0, 32) : LF_HS(RNAMSM_ACT_NONE, 3, 0, 32);
+#undef LF_HQ
+#undef LF_HS
+}
+
+extern "C" int rnamsm_gemm16_residual_stats(const uint16_t* A_hi, const uint16_t* A_lo, int64_t lda, const uint16_t* W_hi,
+                                            const uint16_t* W_lo, const float* bias, float* x, int64_t ldx, int64_t M, int N,
+                                            int K, int split, int fmt, uint16_t* X_hi, uint16_t* X_lo, int64_t ldp,
+                                            float* row_partials, int64_t partials_ld, void* stream) {
+    RNAMSM_CHECK_ARG(A_hi && W_hi && x && X_hi && row_partials, "gemm16_residual_stats: null pointer");
+    RNAMSM_CHECK_ARG(split == 1 || (split == 3 && A_lo && W_lo && X_lo), "gemm16_residual_stats: split must be 1, or 3 with lo planes");
+    RNAMSM_CHECK_ARG((fmt == 0) || (fmt == 1 && split == 3), "gemm16_residual_stats: fmt 0 (bf16) or 1 (fp16, split 3 only)");
+    RNAMSM_CHECK_ARG(M >= 2048 && M <= INT32_MAX && N > 0 && N % HX_BN == 0 && K > 0 && K % 64 == 0,
+                     "gemm16_residual_stats: the 256x256 kernel needs M >= 2048, N %% 256 == 0, K %% 64 == 0 (M=%lld N=%d K=%d)", (long long)M, N, K);
+    RNAMSM_CHECK_ARG(lda >= K && lda % 8 == 0 && ldx >= N && ldx % 4 == 0 && ldp >= N && ldp % 4 == 0 && partials_ld >= M,
+                     "gemm16_residual_stats: bad leading dimension");
+    RNAMSM_CHECK_ARG(aligned16(A_hi) && (!A_lo || aligned16(A_lo)) && aligned16(W_hi) && (!W_lo || aligned16(W_lo)) && aligned16(x) &&
+                     (reinterpret_cast<uintptr_t>(X_hi) & 7u) == 0 && (!X_lo || (reinterpret_cast<uintptr_t>(X_lo) & 7u) == 0) &&
+                     (reinterpret_cast<uintptr_t>(row_partials) & 7u) == 0, "gemm16_residual_stats: alignment");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int m = (int)M;
+    Fold16 fa;
+    fa.partials = reinterpret_cast<float2*>(row_partials);
+    fa.pld = partials_ld;
+    fa.xhi = X_hi;
+    fa.xlo = X_lo;
+    fa.ldx = ldp;
+#define RS_HS(SP_, FMT_, BK_) \
+    launch_hs<RNAMSM_ACT_NONE, true, SP_, FMT_, false, BK_>(W_hi, W_lo, bias, x, ldx, x, ldx, lda, m, N, K, 1.f, 0, A_hi, A_lo, nullptr, nullptr, s, fa)
+    if (split == 1) return RS_HS(1, 0, 64);
+    if (fmt == 1) return RS_HS(3, 1, 32);
+    return RS_HS(3, 0, 32);
+#undef RS_HS
 }
 
 extern "C" int rnamsm_layernorm_split(const float* x, const float* gamma, const float* beta, uint16_t* hi, uint16_t* lo,

@@ -85,6 +85,7 @@ class MSATransformer(nn.Module):
         self.check_finite = True          # 16-bit modes: verify the outputs are finite, fall back to f32 per MSA otherwise
         self._planes = None
         self._folded = None
+        self._folded16 = None
         # exact path, MSAs without padding: LayerNorm is applied inside the QKV / fc1 GEMMs (include/rnamsm.h, K1 folded);
         # False keeps the separate LayerNorm launches (same results to fp32 rounding)
         self.fold_layernorm = True
@@ -196,6 +197,34 @@ class MSATransformer(nn.Module):
         self._folded = (self._pack_key, arr, tensors)
         return arr
 
+    def _folded_planes(self):
+        """The folded LayerNorm weights of the 16-bit modes: per layer {Wg_hi, Wg_lo, c, d} for the row QKV, the column QKV and
+        fc1 -- Wg = W * gamma split into the mode's planes, c = the row sums of what the planes hold (the GEMM multiplies
+        those, so they are what has to cancel), d = bias + W beta.  rnamsm_forward's `ln_folded16` table."""
+        dims, ptrs, keep = self._packed_weights()
+        fmt = 1 if self.gemm_dtype == "f16x3" else 0
+        want_lo = self.gemm_dtype != "bf16"
+        if self._folded16 is not None and self._folded16[0] is self._pack_key and self._folded16[3] == (fmt, want_lo):
+            return self._folded16[1]
+        ng, nl = len(_lib.W_GLOBAL), len(_lib.W_LAYER)
+        ix = _lib.W_LAYER.index
+        triples = [("row_ln_g", "row_ln_b", "row_wqkv", "row_bqkv"), ("col_ln_g", "col_ln_b", "col_wqkv", "col_bqkv"),
+                   ("ffn_ln_g", "ffn_ln_b", "fc1_w", "fc1_b")]
+        ht = torch.float16 if fmt == 1 else torch.bfloat16
+        tensors, addrs = [], []
+        for layer in range(self.num_layers):
+            base = ng + layer * nl
+            for g, b, w, bias in triples:
+                wg32, _, d = ops.ln_fold_weights(keep[base + ix(w)], keep[base + ix(bias)], keep[base + ix(g)], keep[base + ix(b)])
+                hi, lo = ops.split_bf16(wg32, want_lo=want_lo, fmt=fmt)
+                held = hi.view(ht).double() if lo is None else hi.view(ht).double() + lo.view(ht).double()
+                c = held.sum(1).float().contiguous()
+                tensors += [hi, lo, c, d]
+                addrs += [hi.data_ptr(), 0 if lo is None else lo.data_ptr(), c.data_ptr(), d.data_ptr()]
+        arr = (ctypes.c_void_p * len(addrs))(*addrs)
+        self._folded16 = (self._pack_key, arr, tensors, (fmt, want_lo))
+        return arr
+
     def _get_workspace(self, nbytes: int, device) -> torch.Tensor:
         if self._workspace is None or self._workspace.numel() < nbytes or self._workspace.device != device:
             self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -293,10 +322,11 @@ class MSATransformer(nn.Module):
         dtype = _lib.DTYPES[self.gemm_dtype]
         planes = self._weight_planes() if dtype != _lib.F32 else None
         folded = self._folded_weights() if (dtype == _lib.F32 and not has_padding and self.fold_layernorm) else None
+        folded16 = self._folded_planes() if (dtype != _lib.F32 and not has_padding and self.fold_layernorm) else None
         _lib.check(lib.rnamsm_forward(ctypes.byref(dims), ptrs, toks.data_ptr(), R, C, ws.data_ptr(), ws.numel(),
                                       row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
                                       err.data_ptr(), int(has_padding), max_tokens, _lib.OUT_REPR if need_repr else 0, dtype, planes,
-                                      folded, torch.cuda.current_stream().cuda_stream))
+                                      folded, folded16, torch.cuda.current_stream().cuda_stream))
         if dtype != _lib.F32 and self.check_finite:
             # f16x3 / bf16 operands live in 16-bit planes: fp16 overflows above 65504 (-> inf/NaN downstream).  The
             # synthetic weights stay far inside; a real checkpoint is not known to, so the outputs are checked (one

@@ -319,6 +319,42 @@ def linear_planes(a, w, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE
 
 
 @_on_operand_device
+def linear_planes_lnfold(x, wg, c: torch.Tensor, d: torch.Tensor, stats: torch.Tensor, act: int = ACT_NONE, scale: float = 1.0,
+                         scale_cols: int = 0, fmt: int = 0):
+    """K1 folded, 16-bit modes: x = (hi, lo | None) planes of the RAW residual stream [M, K]; wg = planes of W * gamma;
+    c = row sums of the wg planes' values, d = bias + W beta; stats [M, 2].  Returns the output planes (hi, lo | None)."""
+    M, K = x[0].shape
+    N = wg[0].shape[0]
+    split = 1 if x[1] is None else 3
+    ohi = torch.empty(M, N, dtype=torch.int16, device=x[0].device)
+    olo = torch.empty(M, N, dtype=torch.int16, device=x[0].device) if split == 3 else None
+    _lib.check(_lib.load().rnamsm_gemm16_lnfold(_pl(x[0], "x_hi"), _pl(x[1], "x_lo"), _rowmajor(x[0], "x_hi"), _pl(wg[0], "wg_hi"),
+                                                _pl(wg[1], "wg_lo"), _dev(c, "c"), _dev(d, "d"), _dev(stats, "stats"),
+                                                ohi.data_ptr(), None if olo is None else olo.data_ptr(), N, M, N, K, act, scale,
+                                                scale_cols, split, fmt, _stream()))
+    return ohi, olo
+
+
+@_on_operand_device
+def linear_planes_residual_stats(a, w, bias: Optional[torch.Tensor], x: torch.Tensor, fmt: int = 0):
+    """x += a w^T + bias in place (fp32) on the 16-bit matrix cores; returns (x planes (hi, lo | None), row_partials
+    [N/32, M, 2]) of the new x -- the producer side of the folded LayerNorm in the 16-bit modes."""
+    M, K = a[0].shape
+    N = w[0].shape[0]
+    split = 1 if a[1] is None else 3
+    xhi = torch.empty(M, N, dtype=torch.int16, device=x.device)
+    xlo = torch.empty(M, N, dtype=torch.int16, device=x.device) if split == 3 else None
+    part = torch.empty(N // 32, M, 2, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_gemm16_residual_stats(_pl(a[0], "a_hi"), _pl(a[1], "a_lo"), _rowmajor(a[0], "a_hi"),
+                                                        _pl(w[0], "w_hi"), _pl(w[1], "w_lo"),
+                                                        None if bias is None else _dev(bias, "bias"), _dev(x, "x"),
+                                                        _rowmajor(x, "x"), M, N, K, split, fmt, xhi.data_ptr(),
+                                                        None if xlo is None else xlo.data_ptr(), N, part.data_ptr(), M,
+                                                        _stream()))
+    return (xhi, xlo), part
+
+
+@_on_operand_device
 def row_logits16(q, k, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0) -> Tuple[torch.Tensor, int]:
     """q, k: (hi, lo) plane views [R*C, *] with row stride ld (halves); returns (partial [nsplit,H,C,C] fp32, nsplit);
     scale multiplies the fp32 logits (q is expected UNSCALED)."""

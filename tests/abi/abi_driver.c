@@ -67,6 +67,11 @@ int main(void) {
     REFUSED(rnamsm_gemm_residual_stats(buf, 64, buf, buf, buf, 128, buf, 128, 8, 100, 64, buf, 8, 0, NULL));    /* N % 128 */
     REFUSED(rnamsm_gemm_residual_stats(buf, 64, buf, buf, buf, 128, buf, 128, 8, 128, 64, buf, 8, 2, NULL));    /* dtype */
     REFUSED(rnamsm_gemm_residual_stats(buf, 64, buf, buf, buf, 128, buf, 128, 8, 128, 64, buf, 4, 0, NULL));          /* partials_ld < M */
+    REFUSED(rnamsm_gemm16_lnfold(NULL, NULL, 768, halves, NULL, buf, buf, buf, halves, NULL, 2304, 4096, 2304, 768, 0, 1.f, 0, 1, 0, NULL));
+    REFUSED(rnamsm_gemm16_lnfold(halves, NULL, 768, halves, NULL, buf, buf, buf, halves, NULL, 2304, 100, 2304, 768, 0, 1.f, 0, 1, 0, NULL));    /* M < 2048 */
+    REFUSED(rnamsm_gemm16_lnfold(halves, NULL, 768, halves, NULL, buf, buf, buf, halves, NULL, 2304, 4096, 2304, 768, 0, 1.f, 0, 3, 0, NULL));   /* split 3 without lo */
+    REFUSED(rnamsm_gemm16_residual_stats(halves, NULL, 768, halves, NULL, buf, NULL, 768, 4096, 768, 768, 1, 0, halves, NULL, 768, buf, 4096, NULL));
+    REFUSED(rnamsm_gemm16_residual_stats(halves, NULL, 768, halves, NULL, buf, buf, 768, 4096, 768, 768, 1, 0, halves, NULL, 768, buf, 100, NULL)); /* partials_ld < M */
     REFUSED(rnamsm_row_stats_from_partials(NULL, 8, 8, 768, 1e-5f, buf, NULL, NULL));
     REFUSED(rnamsm_row_stats_from_partials(buf, 4, 8, 768, 1e-5f, buf, NULL, NULL));          /* partials_ld < M */
     REFUSED(rnamsm_row_stats_from_partials(buf, 8, 8, 770, 1e-5f, buf, NULL, NULL));          /* K % 32 */
@@ -124,19 +129,19 @@ int main(void) {
     REFUSED(rnamsm_greedy_select(bytes, 8, 70000, 4, 0, ints, buf, 1 << 16, NULL));
     REFUSED(rnamsm_msa_weights(NULL, 8, 8, 0.2, (double*)buf, NULL));
     REFUSED(rnamsm_msa_weights(bytes, 0, 8, 0.2, (double*)buf, NULL));
-    REFUSED(rnamsm_forward(NULL, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 9, NULL, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 3, NULL, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 1025, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL));
+    REFUSED(rnamsm_forward(NULL, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 9, NULL, NULL, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 3, NULL, NULL, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 1025, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL, NULL));
     EXPECT(strstr(rnamsm_last_error(), "maximum MSA depth of 1024") != NULL);             /* model.py:355-359 */
-    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 1, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4000, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL));
-    REFUSED(rnamsm_forward(&dims, weights, toks, 64, 128, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 1, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4000, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL, NULL));
+    REFUSED(rnamsm_forward(&dims, weights, toks, 64, 128, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL, NULL));
     EXPECT(strstr(rnamsm_last_error(), "workspace too small") != NULL);
     {
         rnamsm_model_dims bad = dims;
         bad.embed_dim = 700;
-        REFUSED(rnamsm_forward(&bad, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL));
+        REFUSED(rnamsm_forward(&bad, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL, NULL));
     }
 
     /* parameter parsing and timing bookkeeping */

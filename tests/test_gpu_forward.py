@@ -552,3 +552,30 @@ def test_forward_falls_back_when_the_folded_layernorm_precondition_fails(model):
     want = bad.forward_one(toks, has_padding=False)
     assert int(want["err"].item()) == 0
     assert torch.equal(got["emb"], want["emb"]) and torch.equal(got["atp"], want["atp"])
+
+
+@pytest.mark.parametrize("mode,emb_tol", [("f16x3", 2e-5), ("bf16x3", 2e-4), ("bf16", 0.08)])
+def test_folded_layernorm_in_the_16bit_modes(model, mode, emb_tol):
+    """Knob ln_fold = 3 also folds LayerNorm in the 16-bit modes (rnamsm_gemm16_lnfold / rnamsm_gemm16_residual_stats: the
+    residual GEMMs write the new x as planes + slab sums, the QKV / fc1 GEMMs read the raw planes).  Measured neutral in
+    speed, so not the default; against the same mode with rnamsm_layernorm_split launches the outputs agree to the mode's
+    rounding, and against the oracle the folded forward is no further away (x1.5)."""
+    from rnamsm import ops
+    m, state = model
+    tokens = synthetic.make_tokens(40, 64, 9)                 # 2560 tokens: the 256x256 kernels need >= 2048
+    toks = torch.from_numpy(tokens).to("cuda:0")
+    try:
+        m.gemm_dtype = mode
+        plain = m.forward_one(toks, has_padding=False)
+        ops.set_param("ln_fold", 3)
+        fold = m.forward_one(toks, has_padding=False)
+    finally:
+        ops.set_param("ln_fold", 1)
+        m.gemm_dtype = "f32"
+    assert int(fold["err"].item()) == 0
+    assert not torch.equal(fold["emb"], plain["emb"])
+    assert rel_l2(fold["emb"].cpu().numpy(), plain["emb"].cpu().numpy()) < emb_tol
+    res = O.forward(torch.from_numpy(tokens), O.to_torch_params(state, torch.float64))
+    o_emb, _ = O.pack_outputs(res)
+    e_fold, e_plain = rel_l2(fold["emb"].cpu().numpy(), o_emb.numpy()), rel_l2(plain["emb"].cpu().numpy(), o_emb.numpy())
+    assert e_fold < 1.5 * e_plain + 1e-7, (mode, e_fold, e_plain)

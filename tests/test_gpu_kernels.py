@@ -611,6 +611,61 @@ def test_plane_input_gemm_kernels_agree(dev, M, N, K):
         _lib.check(lib.rnamsm_set_param(b"gemm_group", 0))
 
 
+@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 0), (3, 1)])
+def test_layernorm_folded_into_the_16bit_gemms(dev, split, fmt):
+    """K1 folded in the 16-bit modes: a producer (out_proj shape: x += ctx W^T + b, new x also as planes + slab sums) feeding a
+    consumer (QKV shape with q scaling; fc1 shape with GELU) that reads the RAW x planes and applies (mean, rstd) to its
+    accumulators -- against fp64 LayerNorm -> Linear on the values the planes hold, and next to the unfused plane path
+    (rnamsm_layernorm_split + rnamsm_gemm_bf16)."""
+    from rnamsm import ops
+    from rnamsm._lib import ACT_GELU_ERF
+    M, D, F = 2304, 768, 1024
+    ht = torch.float16 if fmt == 1 else torch.bfloat16
+    eff = lambda pl: sum(p.view(ht).double() for p in pl if p is not None)
+    lo = split == 3
+    x0 = (_rand("f16.x", (M, D), 1.5) + 0.3).to(dev)
+    ctx = ops.split_bf16(_rand("f16.ctx", (M, D)).to(dev), want_lo=lo, fmt=fmt)
+    wo = ops.split_bf16(_rand("f16.wo", (D, D), 0.05).to(dev), want_lo=lo, fmt=fmt)
+    bo = _rand("f16.bo", (D,), 0.1).to(dev)
+    # ---- producer
+    x = x0.clone()
+    xpl, part = ops.linear_planes_residual_stats(ctx, wo, bo, x, fmt=fmt)
+    want_x = x0.double() + eff(ctx) @ eff(wo).t() + bo.double()
+    assert rel_l2(x.cpu(), want_x.cpu()) < (2e-6 if split == 1 else 4e-5 if fmt == 0 else 3e-6)
+    assert torch.equal(x, ops.linear_planes(ctx, wo, bo, residual=x0, fmt=fmt))          # the plain kernel's bits
+    assert rel_l2(eff(xpl).cpu(), x.double().cpu()) < (4e-3 if split == 1 else 2e-5 if fmt == 0 else 2e-7)      # planes of the new x
+    slabs = x.double().view(M, D // 32, 32).transpose(0, 1)
+    assert rel_l2(part[..., 0].cpu(), slabs.sum(-1).cpu()) < 1e-6
+    assert rel_l2(part[..., 1].cpu(), ((slabs - slabs.mean(-1, keepdim=True)) ** 2).sum(-1).cpu()) < 1e-5
+    st = ops.row_stats_from_partials(part, D)
+    # ---- consumers
+    g, be = (1 + 0.1 * _rand("f16.g", (D,))).to(dev), (0.1 * _rand("f16.be", (D,))).to(dev)
+    xv = eff(xpl)                                                             # what the consumer multiplies
+    mean, rstd = x.double().mean(1, keepdim=True), torch.rsqrt(x.double().var(1, unbiased=False, keepdim=True) + 1e-5)
+    for N, act, scale_cols in ((3 * D, 0, D), (F, ACT_GELU_ERF, 0)):
+        w, b = _rand(f"f16.w{N}", (N, D), 0.05).to(dev), _rand(f"f16.b{N}", (N,), 0.1).to(dev)
+        wg32, _, dvec = ops.ln_fold_weights(w, b, g, be)
+        wg = ops.split_bf16(wg32, want_lo=lo, fmt=fmt)
+        cvec = eff(wg).sum(1).float()                                        # of the plane values the GEMM multiplies
+        oh, ol = ops.linear_planes_lnfold(xpl, wg, cvec, dvec, st, act=act, scale=0.125, scale_cols=scale_cols, fmt=fmt)
+        want = rstd * (xv @ eff(wg).t() - mean * eff(wg).sum(1)) + dvec.double()
+        want[:, :scale_cols] *= 0.125
+        if act:
+            want = O.gelu_erf(want)
+        tol = 6e-3 if split == 1 else 4e-5 if fmt == 0 else 3e-6           # the output planes' own rounding
+        assert rel_l2(eff((oh, ol)).cpu(), want.cpu()) < tol, (N, rel_l2(eff((oh, ol)).cpu(), want.cpu()))
+        # and the mode's accuracy against exact LayerNorm -> Linear in fp64, next to the unfused plane path
+        exact = O.layer_norm(x.double(), g.double(), be.double()) @ w.double().t() + b.double()
+        exact[:, :scale_cols] *= 0.125
+        if act:
+            exact = O.gelu_erf(exact)
+        xn = ops.layernorm_split(x, g, be, split=split, fmt=fmt)
+        wpl = ops.split_bf16(w, want_lo=lo, fmt=fmt)
+        uh, ul = ops.linear_planes(xn, wpl, b, act=act, scale=0.125, scale_cols=scale_cols, out_planes=True, fmt=fmt)
+        e_fold, e_plain = rel_l2(eff((oh, ol)).cpu(), exact.cpu()), rel_l2(eff((uh, ul)).cpu(), exact.cpu())
+        assert e_fold < 1.5 * e_plain + 1e-6, (N, e_fold, e_plain)
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 2304, 96), (4100, 1280, 64), (1025, 768, 768), (129, 3072, 32)])
 def test_gemm_block_order_never_changes_results(dev, M, N, K):
     """rnamsm_set_param("gemm_group"): the XCD-aware block order (whole panels, groups of G panels, by-shape default)

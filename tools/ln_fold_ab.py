@@ -23,6 +23,8 @@ dev = torch.device("cuda:0")
 model = MSATransformer(num_layers=10)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(seed=0).items()}, strict=True)
 model = model.eval().to(dev)
+model.gemm_dtype = os.environ.get("DTYPE", "f32")      # f32 | f16x3 | bf16x3 | bf16
+model.check_finite = False
 toks = torch.from_numpy(synthetic.make_tokens(M, L, 0)).to(dev)
 lib = _lib.load()
 
@@ -69,4 +71,5 @@ d = (outs[ON]["emb"] - outs[0]["emb"]).double()
 res["emb rel-L2 fold vs separate"] = float(d.norm() / outs[0]["emb"].double().norm())
 res["atp max-abs fold vs separate"] = float((outs[ON]["atp"] - outs[0]["atp"]).abs().max())
 res["shape"] = [M, L]
+res["gemm_dtype"] = model.gemm_dtype
 print(json.dumps(res, indent=1))
