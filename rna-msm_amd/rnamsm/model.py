@@ -322,7 +322,9 @@ class MSATransformer(nn.Module):
         dtype = _lib.DTYPES[self.gemm_dtype]
         planes = self._weight_planes() if dtype != _lib.F32 else None
         folded = self._folded_weights() if (dtype == _lib.F32 and not has_padding and self.fold_layernorm) else None
-        folded16 = self._folded_planes() if (dtype != _lib.F32 and not has_padding and self.fold_layernorm) else None
+        # the 16-bit modes fold only on request (knob ln_fold = 3: measured neutral there): no tables otherwise
+        folded16 = self._folded_planes() if (dtype != _lib.F32 and not has_padding and self.fold_layernorm
+                                             and ops.get_param("ln_fold") == 3) else None
         _lib.check(lib.rnamsm_forward(ctypes.byref(dims), ptrs, toks.data_ptr(), R, C, ws.data_ptr(), ws.numel(),
                                       row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
                                       err.data_ptr(), int(has_padding), max_tokens, _lib.OUT_REPR if need_repr else 0, dtype, planes,
