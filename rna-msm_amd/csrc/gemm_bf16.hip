@@ -831,75 +831,79 @@ static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
 // accumulator VGPRs), a k-step is 32 deep: 32 MFMAs of 16 cycles against 12 fragment reads.  Products are identical to the
 // 32x32 kernel's and are summed in a different order inside a k-step: results agree to fp32 rounding (exact on integers).
 typedef float f32x4a __attribute__((ext_vector_type(4)));
-template <int ACT, bool HAS_RES, bool O_PL>
-__device__ __forceinline__ void hq_epilogue(f32x4a (&acc)[8][4], int p, char* smem_b, int gm0, int gnb, int wv, int lane,
-                                            const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout,
-                                            int64_t ldc, int M, float scale, int scale_cols, uint16_t* __restrict__ Ohi,
-                                            const Fold16& fa = Fold16{}) {
-    constexpr int LDE = 64 + 4;
-    const int er = lane >> 4, ec = (lane & 15) * 4;
+// Epilogue of the 16x16x32 kernel, straight from the accumulators (no LDS transpose, no barrier).  With the MFMA operands
+// swapped the tile comes out transposed in the registers, and with the W rows permuted by the DMA map lane (fr, fq) holds,
+// of row 16 mt + fr of the wave's 128 x 64 tile, the columns 8 fq .. 8 fq + 7 (tiles t = 0, 1) and 32 + 8 fq .. + 7
+// (t = 2, 3): two 16-byte (bf16) or four 16-byte (fp32) stores per row, the four fq lanes of a row writing 64 contiguous
+// bytes (128 for fp32) per instruction.  A what-if had put the LDS-transposed epilogue at 27 % (QKV) / 34 % (fc1) of the
+// launch.
+struct HqEpiRegs {               // what the epilogue reads from memory besides the residual: requested before the stores
+    f32x4 b4[4], c4[4];
+    float2 st[8];
+};
+template <bool HAS_RES>
+__device__ __forceinline__ void hq_epilogue_loads(HqEpiRegs& r, int gm0, int gnb, int lane, const float* __restrict__ bias,
+                                                  int M, const Fold16& fa) {
     const int fr = lane & 15, fq = lane >> 4;
-    const int gn = gnb + ec;                                  // gm0 / gnb: global origin of this wave's 64x64 slab
     const bool fold = !HAS_RES && fa.stats != nullptr;        // uniform
-    f32x4 res[16];
-    if (HAS_RES) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = min(gm0 + er + 4 * i, M - 1);
-            res[i] = epi_load(reinterpret_cast<const f32x4*>(residual + (int64_t)row * ldr + gn));
-        }
+    for (int t = 0; t < 4; ++t) {
+        const int col = gnb + 32 * (t >> 1) + 8 * fq + 4 * (t & 1);
+        r.b4[t] = bias ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};      // fold: d[n]
+        r.c4[t] = fold ? *reinterpret_cast<const f32x4*>(fa.c + col) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float2 st[16];
-    f32x4 c4, d4;
-    if (fold) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) st[i] = fa.stats[min(gm0 + er + 4 * i, M - 1)];
-        c4 = *reinterpret_cast<const f32x4*>(fa.c + gn);
-        d4 = *reinterpret_cast<const f32x4*>(bias + gn);
-    }
-    __syncthreads();
-    float* stage = reinterpret_cast<float*>(smem_b) + wv * (64 * LDE);
+    for (int mt = 0; mt < 8; ++mt) r.st[mt] = fold ? fa.stats[min(gm0 + mt * 16 + fr, M - 1)] : float2{0.f, 1.f};
+}
+template <int ACT, bool HAS_RES, bool O_PL>
+__device__ __forceinline__ void hq_epilogue(f32x4a (&acc)[8][4], const HqEpiRegs& r, int gm0, int gnb, int lane,
+                                            const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M, float scale,
+                                            int scale_cols, uint16_t* __restrict__ Ohi) {
+    const int fr = lane & 15, fq = lane >> 4;
+    // column of accumulator element e of tile t: gnb + 32 (t >> 1) + 8 fq + 4 (t & 1) + e
+    float fs[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int col = gnb + nt * 16 + fr;
-        const float b = (!fold && bias) ? bias[col] : 0.f;
-        const float sc = (!fold && col < scale_cols) ? scale : 1.f;
+    for (int t = 0; t < 4; ++t) fs[t] = gnb + 32 * (t >> 1) + 8 * fq + 4 * (t & 1) < scale_cols ? scale : 1.f;   // scale_cols % 4 == 0
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 8; ++mt) {
+        const int row = gm0 + mt * 16 + fr;
+        const int rowc = min(row, M - 1);
+        const float2 st = r.st[mt];                           // (0, 1) without the fold: v = (acc - 0 c) 1 + b
+        f32x4 v[4];
 #pragma unroll
-            for (int j = 0; j < 4; j += 2) {                     // accumulator element j = row 4*fq + j of the 16x16 tile
-                f32x2 v = f32x2{(acc[4 * p + mt][nt][j] + b) * sc, (acc[4 * p + mt][nt][j + 1] + b) * sc};
-                if (ACT == RNAMSM_ACT_GELU_ERF && !fold) v = gelu_erf2(v);
-                stage[(mt * 16 + 4 * fq + j) * LDE + nt * 16 + fr] = v[0];
-                stage[(mt * 16 + 4 * fq + j + 1) * LDE + nt * 16 + fr] = v[1];
-            }
-    }
-    f32x4 ov[16];
+        for (int t = 0; t < 4; ++t) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        ov[i] = *reinterpret_cast<const f32x4*>(&stage[(er + 4 * i) * LDE + ec]);
-        if (HAS_RES) ov[i] += res[i];
-    }
-    if (fold) fold16_rows<ACT, 1, 0>(ov, fa, st, c4, d4, gn < scale_cols ? scale : 1.f);
-    if (O_PL) {
-        typedef typename Half16<0>::T H;
-        typedef H H4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (gm0 + er + 4 * i < M) {
-                H4 hi;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hi[e] = (H)ov[i][e];
-                epi_store(reinterpret_cast<H4*>(Ohi + (int64_t)(gm0 + er + 4 * i) * ldc + gn), hi);
+            for (int e = 0; e < 4; ++e) v[t][e] = fmaf(st.y, fmaf(-st.x, r.c4[t][e], acc[mt][t][e]), r.b4[t][e]) * fs[t];
+            if (ACT == RNAMSM_ACT_GELU_ERF) {
+                const f32x2 g0 = gelu_erf2(f32x2{v[t][0], v[t][1]}), g1 = gelu_erf2(f32x2{v[t][2], v[t][3]});
+                v[t] = f32x4{g0[0], g0[1], g1[0], g1[1]};
             }
         }
-    } else if (gm0 + 64 <= M) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) epi_store(reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn), ov[i]);
-    } else {
+        for (int hlf = 0; hlf < 2; ++hlf) {                   // columns 8 fq .. + 7 of the tile's first / second 32
+            const int64_t o = (int64_t)row * ldc + gnb + 32 * hlf + 8 * fq;
+            if (HAS_RES) {
+                const float* rp = residual + (int64_t)rowc * ldr + gnb + 32 * hlf + 8 * fq;
+                v[2 * hlf] += epi_load(reinterpret_cast<const f32x4*>(rp));
+                v[2 * hlf + 1] += epi_load(reinterpret_cast<const f32x4*>(rp + 4));
+            }
+            if (row < M) {
+                if (O_PL) {
+                    typedef typename Half16<0>::T H;
+                    typedef H H8 __attribute__((ext_vector_type(8)));
+                    H8 hi;
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (gm0 + er + 4 * i < M) epi_store(reinterpret_cast<f32x4*>(Cout + (int64_t)(gm0 + er + 4 * i) * ldc + gn), ov[i]);
+                    for (int e = 0; e < 4; ++e) {
+                        hi[e] = (H)v[2 * hlf][e];
+                        hi[4 + e] = (H)v[2 * hlf + 1][e];
+                    }
+                    epi_store(reinterpret_cast<H8*>(Ohi + o), hi);
+                } else {
+                    epi_store(reinterpret_cast<f32x4*>(Cout + o), v[2 * hlf]);
+                    epi_store(reinterpret_cast<f32x4*>(Cout + o + 4), v[2 * hlf + 1]);
+                }
+            }
+        }
     }
 }
 
@@ -918,24 +922,41 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16_kernel(
     const int wm = wv >> 2, wn = wv & 3, fr = lane & 15, fq = lane >> 4;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    for (unsigned vid = blockIdx.x; vid < total_tiles; vid += gridDim.x) {
-    unsigned mpanel, nblk;
-    if (!xcd_panel_map_grouped(vid, mp, nb, (unsigned)group, mpanel, nblk)) continue;
-    const int m0 = mpanel * HX_BM, n0 = nblk * HX_BN;
-    __syncthreads();                 // every wave has finished reading the previous tile's epilogue staging
-
-    // DMA map of gemm16_swp_kernel<BK 64>: a wave instruction covers 8 rows of 128 B
+    // Persistent tile walk with the epilogue OFF the memory critical path.  The epilogue needs no LDS (hq_epilogue), so the
+    // next tile's first operand tile is requested BEFORE the current tile's stores: vector memory operations retire in
+    // order, and the first wait of the next tile then allows exactly the stores to stay in flight (vmcnt(HQ_STORES)) instead
+    // of draining them (a what-if: 27 % of the QKV launch, 34 % of fc1's, was the wait for the previous tile's stores).
+    constexpr int HQ_STORES = O_PL ? 16 : 32;                 // store instructions of one epilogue, per lane
     const int drow = lane >> 3;
     const int dchunk = (lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7);      // (row >> 1) & 7, row = 8g + lane/8
     int64_t aoff[Cfg::IPW], woff[Cfg::IPW];
+    auto find_tile = [&](unsigned& vid, int& m0, int& n0) -> bool {
+        for (; vid < total_tiles; vid += gridDim.x) {
+            unsigned mpanel, nblk;
+            if (xcd_panel_map_grouped(vid, mp, nb, (unsigned)group, mpanel, nblk)) {
+                m0 = mpanel * HX_BM;
+                n0 = nblk * HX_BN;
+                return true;
+            }
+        }
+        return false;
+    };
+    // DMA map of gemm16_swp_kernel<BK 64>: a wave instruction covers 8 rows of 128 B
+    auto set_offsets = [&](int m0, int n0) {
 #pragma unroll
-    for (int j = 0; j < Cfg::IPW; ++j) {
-        const int row = Cfg::RPI * (wv + 8 * j) + drow;
-        int m = m0 + row;
-        m = m < M ? m : M - 1;
-        aoff[j] = (int64_t)m * lda + dchunk * 8;
-        woff[j] = (int64_t)(n0 + row) * K + dchunk * 8;
-    }
+        for (int j = 0; j < Cfg::IPW; ++j) {
+            const int row = Cfg::RPI * (wv + 8 * j) + drow;
+            int m = m0 + row;
+            m = m < M ? m : M - 1;
+            aoff[j] = (int64_t)m * lda + dchunk * 8;
+            // W rows are PERMUTED on their way into LDS so that the (transposed) accumulators of a lane are 8 + 8 consecutive
+            // output columns: LDS row 64 g + 16 t + 4 a + b  <-  weight row 64 g + 32 (t >> 1) + 8 a + 4 (t & 1) + b
+            // (g = the wave column's 64-row group, t = the MFMA tile, 4 a + b = the tile row).  See hq_epilogue.
+            const int tt = (row >> 4) & 3, aa = (row >> 2) & 3;
+            const int wrow = (row & ~63) + 32 * (tt >> 1) + 8 * aa + 4 * (tt & 1) + (row & 3);
+            woff[j] = (int64_t)(n0 + wrow) * K + dchunk * 8;
+        }
+    };
     auto issue = [&](int kt, int buf) {
         char* base = smem_b + buf * Cfg::BUF;
 #pragma unroll
@@ -945,6 +966,13 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16_kernel(
             __builtin_amdgcn_global_load_lds((gptr_t)(Whi + woff[j] + kt * BK), (lptr_t)(base + PLANE + loff), 16, 0, 0);
         }
     };
+    unsigned vid = blockIdx.x;
+    int m0, n0;
+    if (!find_tile(vid, m0, n0)) return;
+    set_offsets(m0, n0);
+    issue(0, 0);
+    bool stores_in_flight = false;                            // uniform
+    for (;;) {
     // lane (row fr, k-group fq) of a 16-row tile reads logical chunk 4*ks + fq of its row; (row >> 1) & 7 = (fr >> 1) & 7.
     // A tile is consumed in four micro-steps u = (k-step ks = u >> 1, row half h = u & 1) of 16 MFMAs: the A fragments of
     // one half (4 x V8) ping-pong by micro-step, the B fragments of a k-step (4 x V8) by k-step -- 64 fragment registers
@@ -970,13 +998,17 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16_kernel(
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                acc[4 * h + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[4 * h + mt][nt], 0, 0, 0);
+                // operands swapped: the tile comes out TRANSPOSED in the registers -- lane (fr, fq) holds row fr, columns
+                // 4 fq .. 4 fq + 3 of the 16x16 tile -- so the epilogue stores row pieces straight from the accumulators
+                acc[4 * h + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt], a[mt], acc[4 * h + mt][nt], 0, 0, 0);
     };
     (void)KS;
 
     const int nk = K / BK;
-    issue(0, 0);
-    wait_dma_then_barrier<0>();
+    // tile 0 was requested before the previous tile's stores (or at kernel start): it has landed once at most those
+    // stores are still outstanding
+    if (stores_in_flight) wait_dma_then_barrier<HQ_STORES>();
+    else wait_dma_then_barrier<0>();
     issue(nk > 1 ? 1 : 0, 1);
     load_a(smem_b, 0, 0, ah[0]);
     load_b(smem_b, 0, bq[0]);
@@ -1024,11 +1056,39 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16_kernel(
         mma(1, ah[1], bq[1]);
     }
 #undef HQ_PIN
-    wait_dma_then_barrier<0>();
+    wait_dma_then_barrier<0>();                               // every wave is done with LDS; the clamped reload has landed
+    // what the epilogue reads (bias / fold vectors, row statistics) first, then the next tile's tile 0, then the stores
+    HqEpiRegs er;
+    hq_epilogue_loads<HAS_RES>(er, m0 + wm * 128, n0 + wn * 64, lane, bias, M, fa);
+    // ... and waited for HERE (a use, as far as hipcc can tell): with an LDS-DMA in flight it would otherwise wait vmcnt(0) at
+    // their first real use and drain the next tile's operands inside the epilogue
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
-        hq_epilogue<ACT, HAS_RES, O_PL>(acc, p, smem_b, m0 + wm * 128 + p * 64, n0 + wn * 64, wv, lane, bias, residual, ldr,
-                                        Cout, ldc, M, scale, scale_cols, Ohi, fa);
+    for (int t = 0; t < 4; ++t) {
+        asm volatile("" : "+v"(er.b4[t]));
+        asm volatile("" : "+v"(er.c4[t]));
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) asm volatile("" : "+v"(er.st[mt].x), "+v"(er.st[mt].y));
+    asm volatile("" ::: "memory");                            // ... and the requests below stay below
+    __builtin_amdgcn_sched_barrier(0);
+    const int em0 = m0 + wm * 128, en0 = n0 + wn * 64;
+    unsigned nvid = vid + gridDim.x;
+    int m1 = 0, n1 = 0;
+    const bool more = find_tile(nvid, m1, n1);
+    if (more) {
+        set_offsets(m1, n1);
+        issue(0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    hq_epilogue<ACT, HAS_RES, O_PL>(acc, er, em0, en0, lane, residual, ldr, Cout, ldc, M, scale, scale_cols, Ohi);
+    if (!more) break;
+    vid = nvid;
+    m0 = m1;
+    n0 = n1;
+    // the hoisted request pays only if exactly HQ_STORES vector memory instructions follow it: a residual adds loads, a
+    // ragged last row panel drops stores -- those tiles drain (vmcnt(0)) as before
+    stores_in_flight = !HAS_RES && em0 + 128 <= M;
+    if (!stores_in_flight) __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0), keep expcnt / lgkmcnt
     }   // persistent tile loop
 }
 
