@@ -666,6 +666,31 @@ def test_layernorm_folded_into_the_16bit_gemms(dev, split, fmt):
         assert e_fold < 1.5 * e_plain + 1e-6, (N, e_fold, e_plain)
 
 
+@pytest.mark.parametrize("M,N,K,act", [(16384, 2304, 768, 0), (9000, 3072, 768, 1), (2048, 1280, 64, 0)])
+def test_16x16x32_gemm_with_the_next_tile_requested_before_the_stores(dev, M, N, K, act):
+    """Plain-bf16 QKV / fc1 shapes run the 16x16x32-MFMA kernel whose persistent blocks request the next tile's first operands
+    BEFORE the current tile's 16 stores and then wait with vmcnt(16) (in-order retirement: everything but those stores).  A
+    miscount would let a wave read LDS ahead of its DMA -- rarely, and only with many tiles per block -- so: many tiles per
+    block (up to 9 at 256 blocks), a ragged last row panel (M = 9000: that tile drains instead), reruns bit-identical, and
+    the values against fp64 on what the planes hold."""
+    from rnamsm import ops
+    ht = torch.bfloat16
+    a = ops.split_bf16(_rand("hq.a", (M, K)).to(dev), want_lo=False)
+    w = ops.split_bf16(_rand("hq.w", (N, K), 0.05).to(dev), want_lo=False)
+    b = _rand("hq.b", (N,), 0.1).to(dev)
+    first = ops.linear_planes(a, w, b, act=act, scale=0.125, scale_cols=768 if not act else 0, out_planes=True)[0].clone()
+    for _ in range(25):
+        again = ops.linear_planes(a, w, b, act=act, scale=0.125, scale_cols=768 if not act else 0, out_planes=True)[0]
+        assert torch.equal(again, first)
+    rows = torch.cat([torch.arange(0, 512), torch.arange(M - 300, M)]).to(dev)      # first tiles and the ragged tail
+    want = a[0].view(ht)[rows].double() @ w[0].view(ht).double().t() + b.double()
+    if act:
+        want = O.gelu_erf(want)
+    else:
+        want[:, :768] *= 0.125
+    assert rel_l2(first.view(ht)[rows].double().cpu(), want.cpu()) < 6e-3
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 2304, 96), (4100, 1280, 64), (1025, 768, 768), (129, 3072, 32)])
 def test_gemm_block_order_never_changes_results(dev, M, N, K):
     """rnamsm_set_param("gemm_group"): the XCD-aware block order (whole panels, groups of G panels, by-shape default)
