@@ -53,3 +53,26 @@ def test_default_workload_runs_weak_scaling_through_the_same_gatherer():
 
 def test_a_dying_rank_fails_the_run_instead_of_hanging():
     _bench(["--gpus", "2", "--backend", "gloo", "--one-device"] + COMMON, env={"RNAMSM_BENCH_FAIL_RANK": "1"}, expect_rc=1)
+
+
+def test_the_drivers_torchrun_launch_takes_the_same_path():
+    """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`: bench.py then finds RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment
+    and must NOT launch ranks of its own.  Same workload, same digest as the self-launched run; one JSON line from rank 0."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device"] + COMMON
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    two = json.loads(lines[0])
+    one = _bench(["--gpus", "1"] + COMMON)
+    assert two["n_gpus"] == 2 and two["config"]["world_size_initialised"] == 2
+    assert two["output_digest"]["value"] == one["output_digest"]["value"]
