@@ -579,3 +579,31 @@ def test_folded_layernorm_in_the_16bit_modes(model, mode, emb_tol):
     o_emb, _ = O.pack_outputs(res)
     e_fold, e_plain = rel_l2(fold["emb"].cpu().numpy(), o_emb.numpy()), rel_l2(plain["emb"].cpu().numpy(), o_emb.numpy())
     assert e_fold < 1.5 * e_plain + 1e-7, (mode, e_fold, e_plain)
+
+
+@pytest.mark.parametrize("weight_std,bias_std,ln_std", [(0.08, 0.2, 0.3), (0.02, 0.5, 0.05), (0.12, 0.05, 0.5)])
+def test_folded_layernorm_across_weight_scales(weight_std, bias_std, ln_std):
+    """The fold's precondition (|row mean| not >> the row's spread) and its accuracy do not hang on the stock synthetic
+    scales: other weight / bias / LayerNorm-affine magnitudes (larger biases push the stream's row means up, larger gamma
+    spreads change c[n]) leave the error word clear and the folded forward as close to the fp64 oracle as the unfolded one."""
+    from rnamsm import ops
+    from rnamsm.model import MSATransformer
+    state = synthetic.make_state_dict(seed=3, num_layers=4, weight_std=weight_std, bias_std=bias_std, ln_std=ln_std)
+    m = MSATransformer(num_layers=4)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    m = m.eval().to("cuda:0")
+    tokens = synthetic.make_tokens(48, 70, 1)
+    toks = torch.from_numpy(tokens).to("cuda:0")
+    try:
+        ops.set_param("ln_fold", 3)
+        fold = m.forward_one(toks, has_padding=False)
+        ops.set_param("ln_fold", 0)
+        plain = m.forward_one(toks, has_padding=False)
+    finally:
+        ops.set_param("ln_fold", 1)
+    assert int(fold["err"].item()) == 0
+    res = O.forward(torch.from_numpy(tokens), O.to_torch_params(state, torch.float64), num_layers=4)
+    o_emb, o_atp = O.pack_outputs(res)
+    e_fold, e_plain = rel_l2(fold["emb"].cpu().numpy(), o_emb.numpy()), rel_l2(plain["emb"].cpu().numpy(), o_emb.numpy())
+    assert e_fold < 1.5 * e_plain + 2e-7 and e_fold < 1e-4, (e_fold, e_plain)
+    assert np.abs(fold["atp"].cpu().numpy() - o_atp.numpy()).max() < 2.0 * np.abs(plain["atp"].cpu().numpy() - o_atp.numpy()).max() + 1e-6
