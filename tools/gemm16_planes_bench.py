@@ -12,6 +12,8 @@ T = int(os.environ.get("T", 131072))
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 modes = {"bf16": (1, 0), "bf16x3": (3, 0), "f16x3": (3, 1)}
+if "MFMA16" in os.environ:
+    ops.set_param("gemm16_mfma16", int(os.environ["MFMA16"]))      # 0 / 1 / 2: which GEMMs take the 16x16x32 kernel
 
 
 def timed(fn, reps=5, rounds=7):
