@@ -253,11 +253,12 @@ class MSATransformer(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward_one(self, tokens2d: torch.Tensor, has_padding: Optional[bool] = None,
-                    need_repr: bool = True) -> Dict[str, torch.Tensor]:
+                    need_repr: bool = True, fold_layernorm: Optional[bool] = None) -> Dict[str, torch.Tensor]:
         """One MSA through the C++ driver (rnamsm_forward): tokens int64 [R, C] on the HIP device ->
         {"row_attn" [NL,H,C,C], "repr" [R,C,D], "emb" [C-1,D], "atp" [NL*H,C-1,C-1]}.
         need_repr=False: only what the CLI writes (emb, atp; bit-identical) -- the last layer then skips the rows the
-        outputs do not depend on and "repr" holds alignment row 0 only ([1, C, D])."""
+        outputs do not depend on and "repr" holds alignment row 0 only ([1, C, D]).
+        fold_layernorm: None = self.fold_layernorm; False = separate LayerNorm launches for this call."""
         if self.training:
             raise NotImplementedError("rnamsm implements the inference path only: call .eval()")
         if not tokens2d.is_cuda:
@@ -273,7 +274,8 @@ class MSATransformer(nn.Module):
         # the library launches on the calling thread's current device / stream: enter the operands' device (a worker
         # thread, or a model on cuda:1, would otherwise launch on device 0 against pointers of another GPU)
         with torch.cuda.device(dev):
-            return self._forward_one_on_device(tokens2d, has_padding, need_repr)
+            return self._forward_one_on_device(tokens2d, has_padding, need_repr,
+                                               self.fold_layernorm if fold_layernorm is None else fold_layernorm)
 
     ERR_INDEX, ERR_FOLD = 1, 2            # bits of forward_one's "err": token / position index out of range; a row whose
                                           # |mean| is so far above its spread that the folded LayerNorm loses > 5 bits
@@ -291,17 +293,15 @@ class MSATransformer(nn.Module):
             import warnings
             warnings.warn(f"{what}: a token row's mean exceeds 32x its spread; LayerNorm is applied in its own launches for "
                           "this MSA instead of inside the GEMMs")
-            keep, self.fold_layernorm = self.fold_layernorm, False
-            try:
-                out = self.forward_one(tokens2d, has_padding, need_repr)
-            finally:
-                self.fold_layernorm = keep
+            out = self.forward_one(tokens2d, has_padding, need_repr, fold_layernorm=False)
             if int(out["err"].item()) & self.ERR_INDEX:
                 raise IndexError(f"{what}: token or position index out of range")
         return out
 
     def _forward_one_on_device(self, tokens2d: torch.Tensor, has_padding: Optional[bool],
-                               need_repr: bool = True) -> Dict[str, torch.Tensor]:
+                               need_repr: bool = True, fold: bool = True,
+                               gemm_dtype: Optional[str] = None) -> Dict[str, torch.Tensor]:
+        gemm_dtype = gemm_dtype or self.gemm_dtype
         R, C = tokens2d.shape
         lib = _lib.load()
         dims, ptrs, _ = self._packed_weights()
@@ -319,11 +319,11 @@ class MSATransformer(nn.Module):
         emb = torch.empty(C - 1, D, device=dev, dtype=torch.float32)
         atp = torch.empty(NL * H, C - 1, C - 1, device=dev, dtype=torch.float32)
         err = torch.zeros(1, device=dev, dtype=torch.int32)
-        dtype = _lib.DTYPES[self.gemm_dtype]
+        dtype = _lib.DTYPES[gemm_dtype]
         planes = self._weight_planes() if dtype != _lib.F32 else None
-        folded = self._folded_weights() if (dtype == _lib.F32 and not has_padding and self.fold_layernorm) else None
+        folded = self._folded_weights() if (dtype == _lib.F32 and not has_padding and fold) else None
         # the 16-bit modes fold only on request (knob ln_fold = 3: measured neutral there): no tables otherwise
-        folded16 = self._folded_planes() if (dtype != _lib.F32 and not has_padding and self.fold_layernorm
+        folded16 = self._folded_planes() if (dtype != _lib.F32 and not has_padding and fold
                                              and ops.get_param("ln_fold") == 3) else None
         _lib.check(lib.rnamsm_forward(ctypes.byref(dims), ptrs, toks.data_ptr(), R, C, ws.data_ptr(), ws.numel(),
                                       row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
@@ -335,13 +335,9 @@ class MSATransformer(nn.Module):
             # reduction over emb, ~1 us) and the MSA is redone on the exact path rather than written out as NaN
             if not bool(torch.isfinite(emb).all()):
                 import warnings
-                warnings.warn(f"gemm_dtype={self.gemm_dtype!r} produced non-finite outputs (operand outside the 16-bit "
+                warnings.warn(f"gemm_dtype={gemm_dtype!r} produced non-finite outputs (operand outside the 16-bit "
                               "range); this MSA is recomputed on the exact fp32 path")
-                mode, self.gemm_dtype = self.gemm_dtype, "f32"
-                try:
-                    return self._forward_one_on_device(tokens2d, has_padding, need_repr)
-                finally:
-                    self.gemm_dtype = mode
+                return self._forward_one_on_device(tokens2d, has_padding, need_repr, fold, gemm_dtype="f32")
         pruned = not need_repr and dtype == _lib.F32 and not has_padding and R > 1       # rnamsm_forward's condition
         return {"row_attn": row_attn, "repr": rep[:1] if pruned else rep, "emb": emb, "atp": atp, "err": err}
 
