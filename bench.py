@@ -140,7 +140,7 @@ def flops_per_msa(M, L, D=768, layers=10):
     return layers * (32 * D * D + 4 * D * (M + L)) * M * L
 
 
-def pmc_traffic_per_launch(kernel_prefix="rnamsm::gemm_f32_kernel"):
+def pmc_traffic_per_launch(kernel_prefix="rnamsm::gemm_f32_kernel", tag=""):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r*_pmc_summary.json: FETCH_SIZE x2 per MI355X_MICROARCH.md §HBM, + WRITE_SIZE), launch-weighted over the
     kernel's template instances.  Counters cannot be collected inside a timed run, so this is the profile's figure for
@@ -148,7 +148,7 @@ def pmc_traffic_per_launch(kernel_prefix="rnamsm::gemm_f32_kernel"):
     import glob
     import re
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))
-                   if re.fullmatch(r"r\d+_pmc_summary\.json", os.path.basename(f)))
+                   if re.fullmatch(rf"r\d+_{tag}pmc_summary\.json", os.path.basename(f)))
     if not files:
         return None, None
     summ = json.load(open(files[-1]))
@@ -456,7 +456,8 @@ def run_rank(args) -> int:
         g = timings["gemm_f32"]
         mult = {"f32": 1.0, "bf16": 1.0, "bf16x3": 3.0, "f16x3": 3.0}[args.gemm_dtype]
         peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_dtype == "f32" else F16_MFMA_PEAK_TFLOPS
-        gemm_kernel = {"f32": "gemm_f32_kernel (nn.Linear, K2)", "bf16": "gemm16_swp_kernel<split 1, bf16> (nn.Linear, K2)",
+        gemm_kernel = {"f32": "gemm_f32_kernel (nn.Linear, K2)",
+                       "bf16": "gemm16_q16_kernel (QKV, fc1) + gemm16_swp_kernel<split 1, bf16> (out_proj, fc2) (nn.Linear, K2)",
                        "bf16x3": "gemm16_swp_kernel<split 3, bf16> (nn.Linear, K2)",
                        "f16x3": "gemm16_swp_kernel<split 3, fp16> (nn.Linear, K2)"}[args.gemm_dtype]
         flop_unit = "TFLOP/s" if mult == 1.0 else "TFLOP/s (executed MFMA flops = 3 x algorithmic)"
@@ -464,7 +465,12 @@ def run_rank(args) -> int:
         attn_ms = sum(timings[k]["ms"] for k in ("row_logits", "row_apply", "col_attn"))
         attn_fl = mult * sum(timings[k]["flops"] for k in ("row_logits", "row_apply", "col_attn"))
         kern_ms = sum(v["ms"] for v in timings.values())
-        traffic, traffic_src = pmc_traffic_per_launch() if (args.gemm_dtype == "f32" and (M, L) == (256, 512)) else (None, None)
+        traffic, traffic_src = None, None
+        if (M, L) == (256, 512):                   # the shape the committed PMC passes were collected on
+            traffic, traffic_src = {"f32": lambda: pmc_traffic_per_launch(),
+                                    "bf16": lambda: pmc_traffic_per_launch("rnamsm::gemm16_", "bf16_"),
+                                    "f16x3": lambda: pmc_traffic_per_launch("rnamsm::gemm16_", "f16x3_"),
+                                    "bf16x3": lambda: (None, None)}[args.gemm_dtype]()
         if world == 1:
             gather_note = "none (single GPU)"
         elif not gather:
