@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Randomised forward fuzz on the GPU against the oracle: random (R, C) with ragged edges around every kernel-selection
+threshold, random arithmetic mode, random `ln_fold` / `gemm_tile` / `col_dma` / `greedy_fused`-independent knobs, padded
+and unpadded MSAs, outputs-only or full.  Every case is judged against the fp64 truth (the oracle's code in float64 on
+the device, tests/truth.py) with the reference's own fp32 arithmetic (the CPU oracle) as the yardstick: the bar is
+emb rel-L2 1e-4 / atp max-abs 1e-4 (bf16x3: 2e-4 / 1e-3), or -- where the reference's fp32 forward is itself further
+than that from the truth (tall, narrow MSAs: tied logits of magnitude ~100 summed over many rows) -- three times (bf16x3: 5x)
+the reference's own error (measured there: the exact path is typically 10x CLOSER to the truth than the reference, whose
+blocked CPU sgemm strays up to 7e-3 on the maps at R = 300; the yardstick only has to tell noise from a wrong kernel).  Outputs-only must be bit-identical to the full forward, reruns bit-identical, all finite.
+Prints one line per case and a summary; exit code 1 on any violation.
+
+    python tests/analysis/fuzz_forward.py [cases [seed [max_tokens]]]
+    FUZZ_SHAPES=300x16,256x16 FUZZ_MODE=f16x3 FUZZ_KNOBS=attn16=0,ln_fold=0 python tests/analysis/fuzz_forward.py     (a targeted run)
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd"))
+
+import numpy as np
+import torch
+
+import truth
+from oracle import msm_oracle as O
+from rnamsm import ops, synthetic
+from rnamsm.model import MSATransformer
+
+EDGES = [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300]
+# (emb bar, atp bar, multiple of the reference's own fp32 error that is accepted where that is larger)
+TOL = {"f32": (1e-4, 1e-4, 3.0), "f16x3": (1e-4, 1e-4, 3.0), "bf16x3": (2e-4, 1e-3, 5.0)}
+KNOB_DEFAULTS = {"ln_fold": 1, "gemm_tile": 0, "col_dma": -1, "row_vt": 1, "attn16": 1}
+
+
+def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mode=None, model=None, log=print):
+    """Returns the number of violations."""
+    rng = np.random.default_rng(seed)
+    state = truth.state()
+    params = O.to_torch_params(state)
+    if model is None:
+        model = MSATransformer(num_layers=10)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+        model = model.eval().to("cuda:0")
+    fixed = list(fixed)
+    if fixed:
+        cases = len(fixed)
+    bad = 0
+    t_start = time.time()
+    try:
+        for case in range(cases):
+            while True:
+                R = int(rng.choice(EDGES)) if rng.random() < 0.6 else int(rng.integers(1, 200))
+                C = int(rng.choice(EDGES[1:])) if rng.random() < 0.6 else int(rng.integers(2, 301))
+                if R * C <= max_tokens:
+                    break
+            mode = str(rng.choice(["f32", "f32", "f16x3", "bf16x3"]))
+            knobs = {"ln_fold": int(rng.choice([0, 1, 2, 3])), "gemm_tile": int(rng.choice([0, 1, 2])),
+                     "col_dma": int(rng.choice([-1, 0, 1])), "row_vt": int(rng.choice([0, 1])), "attn16": int(rng.choice([0, 1, 1]))}
+            padded = rng.random() < 0.3 and R > 1 and C > 3
+            if fixed:
+                (R, C), padded = fixed[case], False
+                mode = fixed_mode or mode
+            knobs.update(fixed_knobs or {})
+            toks = synthetic.make_tokens(R, C, 1000 + case)
+            if padded:                                # trailing pad columns on some rows, a whole pad row at the end, stray pads
+                toks = toks.copy()
+                for r in range(1, R):
+                    if rng.random() < 0.4:
+                        toks[r, int(rng.integers(2, C)):] = 1
+                if R > 2 and rng.random() < 0.5:
+                    toks[R - 1, 1:] = 1
+                if rng.random() < 0.5:
+                    toks[0, int(rng.integers(1, C))] = 1      # a pad in the first row: that key is masked in the tied attention
+            for k, v in knobs.items():
+                ops.set_param(k, v)
+            model.gemm_dtype = mode
+            t = torch.from_numpy(toks).to("cuda:0")
+            t_emb, t_atp = truth.oracle_outputs(toks, torch.float64, "cuda:0")
+            ref_emb, ref_atp = O.pack_outputs(O.forward(torch.from_numpy(toks), params))
+            ref = truth.errors(torch.as_tensor(np.asarray(ref_emb)), torch.as_tensor(np.asarray(ref_atp)), t_emb, t_atp)
+            out = model.checked_forward_one(t)
+            got = truth.errors(out["emb"], out["atp"], t_emb, t_atp)
+            emb_err, atp_err = got["emb_rel_l2"], got["atp_max_abs"]
+            emb_bar = max(TOL[mode][0], TOL[mode][2] * ref["emb_rel_l2"])
+            atp_bar = max(TOL[mode][1], TOL[mode][2] * ref["atp_max_abs"])
+            lean = model.checked_forward_one(t, need_repr=False)
+            same = torch.equal(lean["emb"], out["emb"]) and torch.equal(lean["atp"], out["atp"])
+            again = model.checked_forward_one(t)
+            det = torch.equal(again["emb"], out["emb"]) and torch.equal(again["atp"], out["atp"])
+            finite = bool(torch.isfinite(out["emb"]).all() and torch.isfinite(out["atp"]).all())
+            ok = emb_err < emb_bar and atp_err < atp_bar and same and det and finite
+            bad += not ok
+            log(f"{'ok ' if ok else 'BAD'} case {case:3d} R={R:3d} C={C:3d} {mode:6s} padded={int(padded)} {knobs}  emb {emb_err:.2e} "
+                f"(ref {ref['emb_rel_l2']:.2e}) atp {atp_err:.2e} (ref {ref['atp_max_abs']:.2e}) outputs-only identical {same} "
+                f"rerun identical {det} finite {finite}")
+    finally:
+        for k, v in KNOB_DEFAULTS.items():
+            ops.set_param(k, v)
+        model.gemm_dtype = "f32"
+    log(f"{cases} cases, {bad} violations, {time.time() - t_start:.0f} s")
+    return bad
+
+
+if __name__ == "__main__":
+    fixed = [tuple(int(v) for v in sh.split("x")) for sh in os.environ.get("FUZZ_SHAPES", "").split(",") if sh]
+    fixed_knobs = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("FUZZ_KNOBS", "").split(",") if kv}
+    n = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+            int(sys.argv[3]) if len(sys.argv) > 3 else 6000, fixed, fixed_knobs, os.environ.get("FUZZ_MODE"),
+            log=lambda line: print(line, flush=True))
+    sys.exit(1 if n else 0)
