@@ -91,11 +91,20 @@ def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mod
             again = model.checked_forward_one(t)
             det = torch.equal(again["emb"], out["emb"]) and torch.equal(again["atp"], out["atp"])
             finite = bool(torch.isfinite(out["emb"]).all() and torch.isfinite(out["atp"]).all())
-            ok = emb_err < emb_bar and atp_err < atp_bar and same and det and finite
+            # every fourth case also through the mirror modules (MSATransformer.forward, layer by layer, as a B = 1 batch)
+            mod_ok, mod_note = True, ""
+            if case % 4 == 3:
+                res = model(t[None], repr_layers=[0, 10], need_head_weights=True)
+                m_emb = res["representations"][10][0, 0, 1:, :]
+                m_atp = res["row_attentions"][0][..., 1:, 1:].reshape(-1, C - 1, C - 1)
+                mod = truth.errors(m_emb, m_atp, t_emb, t_atp)
+                mod_ok = mod["emb_rel_l2"] < emb_bar and mod["atp_max_abs"] < atp_bar
+                mod_note = f" modules: emb {mod['emb_rel_l2']:.2e} atp {mod['atp_max_abs']:.2e}"
+            ok = emb_err < emb_bar and atp_err < atp_bar and same and det and finite and mod_ok
             bad += not ok
             log(f"{'ok ' if ok else 'BAD'} case {case:3d} R={R:3d} C={C:3d} {mode:6s} padded={int(padded)} {knobs}  emb {emb_err:.2e} "
                 f"(ref {ref['emb_rel_l2']:.2e}) atp {atp_err:.2e} (ref {ref['atp_max_abs']:.2e}) outputs-only identical {same} "
-                f"rerun identical {det} finite {finite}")
+                f"rerun identical {det} finite {finite}{mod_note}")
     finally:
         for k, v in KNOB_DEFAULTS.items():
             ops.set_param(k, v)
