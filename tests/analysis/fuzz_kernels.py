@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Randomised fuzz of the fp32 kernel entry points through rnamsm.ops against fp64 torch arithmetic: ragged row counts,
+strided operand / output views (leading dimensions larger than the row), every epilogue combination, random head counts.
+  * rnamsm_gemm_bias_act_res      M 1..700, N in 128 k, K in 32 k, lda / ldc / ldr padded, bias / GELU / residual
+                                  (also in place) / column scale / zero_rows, both tile widths
+  * rnamsm_gemm_lnfold (+ stats)  the same GEMM with LayerNorm folded in, against LayerNorm -> Linear in fp64
+  * rnamsm_row_logits + softmax_rows + row_apply,  rnamsm_col_attn_fused        q / k / v as column slices of one wide
+                                  activation (ld = 3 H 64 + padding), R 1..300, C 1..300, H 1..12, padded keys
+Exit code 1 on any violation.     python tests/analysis/fuzz_kernels.py [cases [seed]]
+"""
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd"))
+
+import numpy as np
+import torch
+
+from rnamsm import ops
+from rnamsm._lib import ACT_GELU_ERF, ACT_NONE
+
+DEV = "cuda:0"
+
+
+def strided(rows, cols, gen, pad):
+    """[rows, cols] view with row stride cols + pad into a larger buffer filled with NaN outside the view."""
+    buf = torch.full((rows, cols + pad), float("nan"), device=DEV)
+    view = buf[:, :cols]
+    view.copy_(torch.randn(rows, cols, device=DEV, generator=gen))
+    return view
+
+
+def rel(a, b):
+    return float((a.double() - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def fuzz_gemm(rng, gen):
+    M = int(rng.integers(1, 700))
+    N = 128 * int(rng.integers(1, 5))
+    K = 32 * int(rng.integers(1, 17))
+    a = strided(M, K, gen, 4 * int(rng.integers(0, 4)))
+    w = torch.randn(N, K, device=DEV, generator=gen) * 0.1
+    bias = torch.randn(N, device=DEV, generator=gen) if rng.random() < 0.8 else None
+    act = ACT_GELU_ERF if rng.random() < 0.4 else ACT_NONE
+    res_mode = int(rng.integers(0, 3))                  # 0 none, 1 separate, 2 in place
+    out = strided(M, N, gen, 4 * int(rng.integers(0, 4)))
+    residual = None if res_mode == 0 else (strided(M, N, gen, 4 * int(rng.integers(0, 4))) if res_mode == 1 else out)
+    res64 = None if residual is None else residual.double().clone()
+    scale_cols = 4 * int(rng.integers(0, N // 4 + 1)) if rng.random() < 0.5 else 0
+    scale = float(rng.uniform(0.05, 2.0))
+    zero_rows = (torch.rand(M, device=DEV, generator=gen) < 0.2).to(torch.uint8) if (rng.random() < 0.3 and act == ACT_NONE and res_mode == 0) else None
+    ops.set_param("gemm_tile", int(rng.integers(0, 3)))
+    want = a.double() @ w.double().T
+    if bias is not None:
+        want = want + bias.double()
+    if scale_cols:
+        want[:, :scale_cols] *= scale
+    if zero_rows is not None:
+        want[zero_rows.bool(), :scale_cols] = 0.0
+    if act == ACT_GELU_ERF:
+        want = torch.nn.functional.gelu(want)
+    if res64 is not None:
+        want = want + res64
+    ops.linear(a, w, bias, act=act, residual=residual, scale=scale, scale_cols=scale_cols, out=out, zero_rows=zero_rows)
+    err = rel(out, want)
+    return err < 2e-6, f"gemm M={M} N={N} K={K} act={act} res={res_mode} scale_cols={scale_cols} zero_rows={zero_rows is not None}: {err:.2e}"
+
+
+def fuzz_lnfold(rng, gen):
+    M = int(rng.integers(1, 700))
+    N = 128 * int(rng.integers(1, 5))
+    K = 32 * int(rng.integers(1, 17))
+    x = strided(M, K, gen, 4 * int(rng.integers(0, 4)))
+    x.mul_(float(rng.uniform(0.2, 3.0))).add_(float(rng.uniform(-1.0, 1.0)))
+    w = torch.randn(N, K, device=DEV, generator=gen) * 0.1
+    bias = torch.randn(N, device=DEV, generator=gen)
+    gamma = 1.0 + 0.1 * torch.randn(K, device=DEV, generator=gen)
+    beta = 0.1 * torch.randn(K, device=DEV, generator=gen)
+    act = ACT_GELU_ERF if rng.random() < 0.4 else ACT_NONE
+    wg, c, d = ops.ln_fold_weights(w, bias, gamma, beta)
+    stats = None
+    if rng.random() < 0.7:                               # the forward's form: statistics from the producers' partial sums
+        stats = ops.row_stats_from_partials(ops.row_partials(x.contiguous()), K)
+    ops.set_param("gemm_tile", int(rng.integers(0, 3)))
+    out = ops.linear_lnfold(x, wg, c, d, stats=stats, act=act)
+    ln = torch.nn.functional.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-5)
+    want = ln @ w.double().T + bias.double()
+    if act == ACT_GELU_ERF:
+        want = torch.nn.functional.gelu(want)
+    err = rel(out, want)
+    return err < 5e-6, f"lnfold M={M} N={N} K={K} act={act} stats={'partials' if stats is not None else 'self'}: {err:.2e}"
+
+
+def fuzz_row_attention(rng, gen):
+    H = int(rng.integers(1, 13))
+    while True:
+        R, C = int(rng.integers(1, 301)), int(rng.integers(1, 301))
+        if R * C <= 20000:
+            break
+    ld = 3 * 64 * H + 4 * int(rng.integers(0, 4))
+    buf = torch.randn(R * C, ld, device=DEV, generator=gen)
+    q, k, v = buf[:, :64 * H], buf[:, 64 * H:128 * H], buf[:, 128 * H:192 * H]
+    scaling = 0.125 / math.sqrt(R)
+    qs = (q * scaling).contiguous()
+    qv = buf.clone()
+    qv[:, :64 * H] = qs
+    q, k, v = qv[:, :64 * H], qv[:, 64 * H:128 * H], qv[:, 128 * H:192 * H]
+    partial, nsplit = ops.row_logits(q, k, R, C, H)
+    probs = ops.softmax_rows(partial)
+    ctx = ops.row_apply(probs, v, R, C, H)
+    q4 = q.double().reshape(R, C, H, 64)
+    k4 = k.double().reshape(R, C, H, 64)
+    v4 = v.double().reshape(R, C, H, 64)
+    logits = torch.einsum("rihd,rjhd->hij", q4, k4)
+    p = logits.softmax(-1)
+    want = torch.einsum("hij,rjhd->rihd", p, v4).reshape(R * C, H * 64)
+    e_p = float((probs.double() - p).abs().max())
+    e_c = rel(ctx, want)
+    return e_p < 2e-5 and e_c < 2e-5, f"row attention R={R} C={C} H={H} ld={ld} nsplit={nsplit}: probs {e_p:.2e} ctx {e_c:.2e}"
+
+
+def fuzz_col_attention(rng, gen):
+    H = int(rng.integers(1, 13))
+    while True:
+        R, C = int(rng.integers(1, 301)), int(rng.integers(1, 301))
+        if R * C <= 20000:
+            break
+    ld = 3 * 64 * H + 4 * int(rng.integers(0, 4))
+    buf = torch.randn(R * C, ld, device=DEV, generator=gen)
+    buf[:, :64 * H] *= 0.125 * 1.5
+    q, k, v = buf[:, :64 * H], buf[:, 64 * H:128 * H], buf[:, 128 * H:192 * H]
+    mask = None
+    if rng.random() < 0.4 and R > 1:
+        mask = (torch.rand(R * C, device=DEV, generator=gen) < 0.2)
+        mask.view(R, C)[0] = False                      # a column never loses all its keys in the reference's use
+        mask = mask.to(torch.uint8)
+    ops.set_param("col_dma", int(rng.integers(-1, 2)))
+    ctx = ops.col_attn(q, k, v, R, C, H, pad_mask=mask)
+    q4 = q.double().reshape(R, C, H, 64)
+    k4 = k.double().reshape(R, C, H, 64)
+    v4 = v.double().reshape(R, C, H, 64)
+    s = torch.einsum("ichd,jchd->hcij", q4, k4)
+    if mask is not None:
+        s = s.masked_fill(mask.view(R, C).bool().T[None, :, None, :], -10000.0)
+    if R == 1:
+        want = v.double()
+    else:
+        want = torch.einsum("hcij,jchd->ichd", s.softmax(-1), v4).reshape(R * C, H * 64)
+    err = rel(ctx, want)
+    return err < 2e-5, f"col attention R={R} C={C} H={H} ld={ld} masked={mask is not None}: {err:.2e}"
+
+
+def run(cases=40, seed=0, log=print):
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(seed)
+    bad = 0
+    try:
+        for case in range(cases):
+            for fn in (fuzz_gemm, fuzz_lnfold, fuzz_row_attention, fuzz_col_attention):
+                ok, note = fn(rng, gen)
+                bad += not ok
+                log(f"{'ok ' if ok else 'BAD'} {case:3d} {note}")
+    finally:
+        ops.set_param("gemm_tile", 0)
+        ops.set_param("col_dma", -1)
+    log(f"{4 * cases} kernel cases, {bad} violations")
+    return bad
+
+
+if __name__ == "__main__":
+    n = run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
+            log=lambda line: print(line, flush=True))
+    sys.exit(1 if n else 0)

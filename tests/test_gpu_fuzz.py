@@ -26,3 +26,13 @@ def test_tall_narrow_alignments_where_the_reference_itself_is_noisy():
     lines = []
     bad = fuzz_forward.run(fixed=[(300, 8), (257, 16), (400, 12)], fixed_mode="f32", fixed_knobs={"ln_fold": 1}, log=lines.append)
     assert bad == 0, "\n".join(lines)
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_seeded_kernel_fuzz_has_no_violation(seed):
+    """fp32 kernel entry points on strided views with ragged sizes and every epilogue combination vs fp64 torch arithmetic
+    (tests/analysis/fuzz_kernels.py)."""
+    import fuzz_kernels
+    lines = []
+    bad = fuzz_kernels.run(cases=20, seed=seed, log=lines.append)
+    assert bad == 0, "\n".join(line for line in lines if line.startswith("BAD"))
