@@ -6,6 +6,10 @@ strided operand / output views (leading dimensions larger than the row), every e
   * rnamsm_gemm_lnfold (+ stats)  the same GEMM with LayerNorm folded in, against LayerNorm -> Linear in fp64
   * rnamsm_row_logits + softmax_rows + row_apply,  rnamsm_col_attn_fused        q / k / v as column slices of one wide
                                   activation (ld = 3 H 64 + padding), R 1..300, C 1..300, H 1..12, padded keys
+  * rnamsm_gemm_bf16 (plane operands)  M 1..6000 (both sides of the 2048-row kernel switch), N in 128 k up to 1536, K in 64 k,
+                                  bf16 / bf16x3 / f16x3, every staging variant ("gemm16_dma" 0..4, "gemm16_mfma16", "gemm_group"),
+                                  fp32 output (+ residual) or plane output (+ GELU / column scale), against the fp64
+                                  product of the PLANE VALUES
 Exit code 1 on any violation.     python tests/analysis/fuzz_kernels.py [cases [seed]]
 """
 import math
@@ -152,21 +156,61 @@ def fuzz_col_attention(rng, gen):
     return err < 2e-5, f"col attention R={R} C={C} H={H} ld={ld} masked={mask is not None}: {err:.2e}"
 
 
+def fuzz_planes_gemm(rng, gen):
+    M = int(rng.integers(1, 6000)) if rng.random() < 0.7 else int(rng.choice([2047, 2048, 2049, 255, 256, 257, 4096]))
+    N = 128 * int(rng.integers(1, 13))
+    K = 64 * int(rng.integers(1, 9))
+    split, fmt = [(1, 0), (3, 0), (3, 1)][int(rng.integers(0, 3))]
+    ht = torch.float16 if fmt == 1 else torch.bfloat16
+    knobs = {"gemm16_dma": int(rng.integers(0, 5)), "gemm16_mfma16": int(rng.integers(0, 3)), "gemm_group": int(rng.choice([0, 1, 3, 8]))}
+    for k_, v_ in knobs.items():
+        ops.set_param(k_, v_)
+    a = ops.split_bf16(torch.randn(M, K, device=DEV, generator=gen), want_lo=split == 3, fmt=fmt)
+    w = ops.split_bf16(torch.randn(N, K, device=DEV, generator=gen) * 0.05, want_lo=split == 3, fmt=fmt)
+    bias = torch.randn(N, device=DEV, generator=gen) * 0.1 if rng.random() < 0.8 else None
+    eff = lambda pl: sum(p.view(ht).double() for p in pl if p is not None)
+    want = eff(a) @ eff(w).T
+    if bias is not None:
+        want = want + bias.double()
+    form = int(rng.integers(0, 4))                      # 0 fp32 out, 1 fp32 out + residual, 2 planes + GELU, 3 planes + column scale
+    if form <= 1:
+        residual = strided(M, N, gen, 4 * int(rng.integers(0, 4))) if form == 1 else None
+        out = strided(M, N, gen, 4 * int(rng.integers(0, 4)))
+        if residual is not None:
+            want = want + residual.double()
+        ops.linear_planes(a, w, bias, residual=residual, out=out, fmt=fmt)
+        err, tol = rel(out, want), (2e-6 if split == 1 else 4e-5 if fmt == 0 else 3e-6)
+    else:
+        scale_cols = 0
+        if form == 2:
+            oh, ol = ops.linear_planes(a, w, bias, act=ACT_GELU_ERF, out_planes=True, fmt=fmt)
+            want = torch.nn.functional.gelu(want)
+        else:
+            scale_cols = 4 * int(rng.integers(0, N // 4 + 1))
+            oh, ol = ops.linear_planes(a, w, bias, scale=0.25, scale_cols=scale_cols, out_planes=True, fmt=fmt)
+            want[:, :scale_cols] *= 0.25
+        err, tol = rel(eff((oh, ol)).float(), want), (6e-3 if split == 1 else 4e-5 if fmt == 0 else 3e-6)
+    return err < tol, f"planes gemm M={M} N={N} K={K} split={split} fmt={fmt} form={form} {knobs}: {err:.2e} (tol {tol:.0e})"
+
+
 def run(cases=40, seed=0, log=print):
     rng = np.random.default_rng(seed)
     gen = torch.Generator(device=DEV)
     gen.manual_seed(seed)
     bad = 0
+    DEFAULT_PLANE_KNOBS = {k_: ops.get_param(k_) for k_ in ("gemm16_dma", "gemm16_mfma16", "gemm_group")}
     try:
         for case in range(cases):
-            for fn in (fuzz_gemm, fuzz_lnfold, fuzz_row_attention, fuzz_col_attention):
+            for fn in (fuzz_gemm, fuzz_lnfold, fuzz_row_attention, fuzz_col_attention, fuzz_planes_gemm):
                 ok, note = fn(rng, gen)
                 bad += not ok
                 log(f"{'ok ' if ok else 'BAD'} {case:3d} {note}")
     finally:
         ops.set_param("gemm_tile", 0)
         ops.set_param("col_dma", -1)
-    log(f"{4 * cases} kernel cases, {bad} violations")
+        for k_, v_ in DEFAULT_PLANE_KNOBS.items():
+            ops.set_param(k_, v_)
+    log(f"{5 * cases} kernel cases, {bad} violations")
     return bad
 
 
