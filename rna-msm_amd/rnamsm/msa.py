@@ -20,18 +20,25 @@ SAMPLE_METHODS = ("hhfilter", "sample-pretrained", "diversity-max", "diversity-m
 
 
 def read_fasta_records(path_or_text: Union[str, Path], is_text: bool = False) -> List[Tuple[str, str]]:
+    """(description, sequence) records the way the reference's parser (Bio.SeqIO "fasta" = SimpleFastaParser) yields them:
+    lines split at newlines only, a record's lines right-stripped and joined, then blanks and carriage returns removed
+    (interior tabs stay and are invalid tokens, as there); text before the first '>' is skipped."""
     text = path_or_text if is_text else Path(path_or_text).read_text()
     records: List[Tuple[str, str]] = []
     header, parts = None, []
-    for raw in text.splitlines():
+
+    def close():
+        records.append((header, "".join(parts).replace(" ", "").replace("\r", "")))
+
+    for raw in text.split("\n"):
         if raw[:1] == ">":
             if header is not None:
-                records.append((header, "".join(parts)))
-            header, parts = raw[1:].strip(), []
+                close()
+            header, parts = raw[1:].rstrip(), []
         elif header is not None:
-            parts.append("".join(raw.split()))
+            parts.append(raw.rstrip())
     if header is not None:
-        records.append((header, "".join(parts)))
+        close()
     return records
 
 

@@ -50,12 +50,12 @@ def install():
                     line = line.rstrip("\n").rstrip("\r")
                     if line.startswith(">"):
                         if name is not None:
-                            yield types.SimpleNamespace(description=name, seq="".join(chunks))
-                        name, chunks = line[1:], []
+                            yield types.SimpleNamespace(description=name, seq="".join(chunks).replace(" ", "").replace("\r", ""))
+                        name, chunks = line[1:].rstrip(), []
                     elif name is not None:
-                        chunks.append(line.strip())
+                        chunks.append(line.rstrip())        # Bio.SeqIO.FastaIO.SimpleFastaParser: rstrip, join, drop ' ' and '\r'
                 if name is not None:
-                    yield types.SimpleNamespace(description=name, seq="".join(chunks))
+                    yield types.SimpleNamespace(description=name, seq="".join(chunks).replace(" ", "").replace("\r", ""))
             finally:
                 if close:
                     handle.close()
