@@ -10,6 +10,8 @@ strided operand / output views (leading dimensions larger than the row), every e
                                   bf16 / bf16x3 / f16x3, every staging variant ("gemm16_dma" 0..4, "gemm16_mfma16", "gemm_group"),
                                   fp32 output (+ residual) or plane output (+ GELU / column scale), against the fp64
                                   product of the PLANE VALUES
+  * rnamsm_greedy_select / rnamsm_msa_weights   random alignments built from a few mutated founders (ties everywhere), both
+                                  greedy schemes ("greedy_fused" 0 / 2), max and min: device rows == host rows, weights bit-equal
 Exit code 1 on any violation.     python tests/analysis/fuzz_kernels.py [cases [seed]]
 """
 import math
@@ -193,6 +195,27 @@ def fuzz_planes_gemm(rng, gen):
     return err < tol, f"planes gemm M={M} N={N} K={K} split={split} fmt={fmt} form={form} {knobs}: {err:.2e} (tol {tol:.0e})"
 
 
+def fuzz_subsampling(rng, gen):
+    from rnamsm.msa import greedy_select, greedy_select_device, msa_weights
+    N, L = int(rng.integers(2, 500)), int(rng.integers(1, 120))
+    founders = rng.integers(4, 11, size=(int(rng.integers(1, 6)), L))
+    rows = founders[rng.integers(0, founders.shape[0], size=N)].copy()
+    flips = rng.random((N, L)) < rng.uniform(0.0, 0.2)
+    rows[flips] = rng.integers(4, 11, size=int(flips.sum()))
+    tokens = np.concatenate([np.zeros((N, 1), dtype=np.int64), rows.astype(np.int64)], axis=1)
+    n = int(rng.integers(1, N + 2))
+    mode = "max" if rng.random() < 0.5 else "min"
+    fused = int(rng.choice([0, 2]))
+    ops.set_param("greedy_fused", fused)
+    got = greedy_select_device(tokens, n, mode, DEV)
+    want = greedy_select(tokens, n, mode)
+    ok = np.array_equal(got, want)
+    w_dev = msa_weights(tokens, 0.2, device=DEV)
+    w_host = msa_weights(tokens, 0.2)
+    ok_w = np.array_equal(w_dev, w_host)
+    return ok and ok_w, f"sub-sampling N={N} L={L} n={n} {mode} greedy_fused={fused}: rows equal {ok}, weights equal {ok_w}"
+
+
 def run(cases=40, seed=0, log=print):
     rng = np.random.default_rng(seed)
     gen = torch.Generator(device=DEV)
@@ -201,16 +224,17 @@ def run(cases=40, seed=0, log=print):
     DEFAULT_PLANE_KNOBS = {k_: ops.get_param(k_) for k_ in ("gemm16_dma", "gemm16_mfma16", "gemm_group")}
     try:
         for case in range(cases):
-            for fn in (fuzz_gemm, fuzz_lnfold, fuzz_row_attention, fuzz_col_attention, fuzz_planes_gemm):
+            for fn in (fuzz_gemm, fuzz_lnfold, fuzz_row_attention, fuzz_col_attention, fuzz_planes_gemm, fuzz_subsampling):
                 ok, note = fn(rng, gen)
                 bad += not ok
                 log(f"{'ok ' if ok else 'BAD'} {case:3d} {note}")
     finally:
         ops.set_param("gemm_tile", 0)
         ops.set_param("col_dma", -1)
+        ops.set_param("greedy_fused", 1)
         for k_, v_ in DEFAULT_PLANE_KNOBS.items():
             ops.set_param(k_, v_)
-    log(f"{5 * cases} kernel cases, {bad} violations")
+    log(f"{6 * cases} kernel cases, {bad} violations")
     return bad
 
 
