@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RNAMSM_VERSION 203 /* major*10000 + minor*100 + patch */
+#define RNAMSM_VERSION 204 /* major*10000 + minor*100 + patch */
 
 typedef enum {
     RNAMSM_OK = 0,
@@ -401,6 +401,10 @@ void rnamsm_timing_reset(void);
  *                 are faster); 3 = for every shape, and in the 16-bit modes too (ln_folded16; measured neutral there, hence
  *                 not the default); 2 = folded, every GEMM sums the rows it stages itself; 0 = separate LayerNorm launches
  *                 (all agree to fp32 rounding, resp. to the 16-bit mode's rounding).
+ *   "gemm_splitk" exact path of rnamsm_forward, fc2 (K = ffn_dim >= 2048) of MSAs with at most 64 output tiles (below ~1.4 k
+ *                 tokens): 1 (default) = four K ranges computed side by side into partial tiles of the workspace and added in
+ *                 range order with the bias and the residual (bit-identical reruns; results differ from the unsplit GEMM at
+ *                 the fp32 rounding level), 0 = never, 2 / 4 / 8 = that many ranges whenever tiles x ranges <= 512 (A/B).
  *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit
  *                 matrix cores in the mode's operand format (K4'..K7'), 0 = they stay on the exact-fp32 kernels,
  *                 2 = as 1 but the row kernels keep 128x128 tiles for every C (A/B of the 256x256-tile kernels).

@@ -142,6 +142,12 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().ln_fold = value < 0 ? 0 : (value > 3 ? 3 : value);
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "gemm_splitk")) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+            return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: gemm_splitk must be 0, 1, 2, 4 or 8");
+        rnamsm::tuning().gemm_splitk = value;
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "gemm16_mfma16")) {
         rnamsm::tuning().gemm16_mfma16 = value < 0 ? 0 : (value > 2 ? 2 : value);
         return RNAMSM_OK;
@@ -176,6 +182,7 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "row16_max_rows")) return rnamsm::tuning().row16_max_rows;
     if (name && !strcmp(name, "gemm16_persist")) return rnamsm::tuning().gemm16_persist;
     if (name && !strcmp(name, "gemm16_mfma16")) return rnamsm::tuning().gemm16_mfma16;
+    if (name && !strcmp(name, "gemm_splitk")) return rnamsm::tuning().gemm_splitk;
     if (name && !strcmp(name, "gemm16_stagger")) return rnamsm::tuning().gemm16_stagger;
     if (name && !strcmp(name, "row_vt")) return rnamsm::tuning().row_vt;
     if (name && !strcmp(name, "gemm_tile")) return rnamsm::tuning().gemm_tile;

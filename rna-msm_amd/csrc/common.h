@@ -54,6 +54,7 @@ struct Tuning {
     int gemm16_stagger = 0;        // ... and block b starts (b/8 % 4) x this many cycles late (spreads the store bursts)
     int gemm_group = 0;            // fp32 GEMM: row panels per XCD group of the block order (xcd_panel_map_grouped); 0 = by shape
     int gemm_tile = 0;             // fp32 GEMM block tile: 0 = by shape, 1 = always 128x128, 2 = always 128x64
+    int gemm_splitk = 1;           // rnamsm_forward, fc2 below ~1.4 k tokens: 1 = four K ranges + an ordered reduction (gemm_f32_splitk_factor), 0 = never, 2 / 4 / 8 = forced (A/B)
     int row_vt = 1;                // fp32 row_apply: 1 = V tile transposed while staged (b128 fragments), 0 = [k][n] tile
     int col_dma = -1;              // fp32 col_attn: 1 = LDS-DMA staging, 32-key chunks, 3 blocks/CU; 0 = register-staged kernel; -1 = by shape
     int row16_max_rows = 32;       // hi/lo modes: cap on the rows of one row_logits16 slab (0 = none): accuracy, DESIGN 3.2
@@ -225,5 +226,11 @@ static inline unsigned xcd_panel_grid_grouped(unsigned num_panels, unsigned inne
     const unsigned local = (num_panels + 7u) / 8u;                 // panels per XCD
     return ((local + G - 1u) / G) * G * 8u * inner;
 }
+
+// split-K form of the fp32 residual GEMM for small M (gemm_f32.hip): ks = gemm_f32_splitk_factor(M, N, K) > 1 K ranges,
+// partial tiles in `partials` ([ks][M][N] floats), then out = sum of the slabs in order + bias + residual.
+int gemm_f32_splitk_factor(int64_t M, int N, int K, bool by_shape_only = false);
+int gemm_f32_splitk(const float* A, int64_t lda, const float* W, const float* bias, const float* residual, int64_t ldr,
+                    float* Cout, int64_t ldc, int64_t M, int N, int K, int ks, float* partials, hipStream_t stream);
 
 }  // namespace rnamsm

@@ -24,7 +24,7 @@ using namespace rnamsm;
 
 namespace {
 struct Layout {
-    size_t x, xn, wide, part, mask, pplanes, rowsum, stats, total;
+    size_t x, xn, wide, part, mask, pplanes, rowsum, stats, splitk, total;
 };
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 Layout make_layout(const rnamsm_model_dims& d, int R, int C, int nchunks) {
@@ -44,6 +44,11 @@ Layout make_layout(const rnamsm_model_dims& d, int R, int C, int nchunks) {
     l.pplanes = off; off += align256((size_t)d.num_heads * C * (size_t)((C + 63) / 64 * 64) * 4);   // P hi + lo planes (K5' -> K6')
     l.rowsum = off; off += align256(T * (D / 32) * 2 * sizeof(float));   // (sum, centred sum of squares) per token and 32-feature slab
     l.stats = off; off += align256(T * 2 * sizeof(float));            // (mean, rstd) per token, combined from rowsum
+    {   // split-K partial tiles of fc2 at small token counts (gemm_f32_splitk): [ks][T][D] -- sized by shape alone, for the most
+        // ranges any knob value can ask for, so that a knob changed between the two calls cannot outgrow it
+        const size_t kt = (size_t)rnamsm::gemm_f32_splitk_factor((int64_t)T, (int)D, d.ffn_dim, true);
+        l.splitk = off; off += align256((kt > 1 ? kt * T : 0) * D * sizeof(float));
+    }
     l.total = off;
     return l;
 }
@@ -157,6 +162,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     const bool fold_sums = fold && fold_mode != 2;   // row sums travel from the residual epilogues to the consumers
     float* rowsum = reinterpret_cast<float*>(ws + lay.rowsum);
     float* stats = reinterpret_cast<float*>(ws + lay.stats);
+    float* splitk = reinterpret_cast<float*>(ws + lay.splitk);
     // 16-bit modes (planes end to end, 16-bit attention, no padding): the same fold on the 256x256 matrix-core kernels --
     // the residual GEMMs also write the new x as planes and its slab sums, the QKV / fc1 GEMMs read those planes
     // (rnamsm_gemm16_residual_stats / rnamsm_gemm16_lnfold); rnamsm_layernorm_split is no launch at all.
@@ -187,6 +193,10 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             FWD(rnamsm_gemm_residual_stats(A, lda, Wf, bias, x, D, x, D, rows, D, K, rowsum, T, f32, stream));
             return rnamsm_row_stats_from_partials(rowsum, T, rows, D, d.ln_eps, stats, err_flag, stream);
         }
+        // > 1 only for fc2 of small MSAs; decided by the WHOLE alignment's token count also where only the first `rows` are
+        // computed (outputs-only forward), so that those rows come out bit-identical to the full forward's
+        const int ks = rnamsm::gemm_f32_splitk_factor(T, D, K);
+        if (ks > 1) return rnamsm::gemm_f32_splitk(A, lda, Wf, bias, x, D, x, D, rows, D, K, ks, splitk, static_cast<hipStream_t>(stream));
         return rnamsm_gemm_bias_act_res(A, lda, Wf, bias, x, D, x, D, rows, D, K, RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream);
     };
     // columns n_ofs .. n_ofs + N - 1 of the Linear in folded slot fslot (0 row QKV, 1 column QKV, 2 fc1) over `rows` tokens

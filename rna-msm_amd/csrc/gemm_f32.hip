@@ -62,8 +62,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     float* Ws = smem + 2 * TILE_KC;      // [2][BN_][LDK]
 
     const unsigned nb = N / BN_, mp = (M + BM - 1) / BM;
+    // split-K (group >> 16 = number of K ranges; launch_gemm_splitk): the grid holds that many copies of the tile grid, copy s
+    // accumulates K range s (W keeps its row stride K) and stores its tile into partial slab s of Cout ([ks][M][ldc])
+    const int ksplit = group >> 16;
+    unsigned bid = blockIdx.x;
+    int kc = K;
+    if (ksplit) {
+        const unsigned per = gridDim.x / ksplit, s_ = bid / per;
+        bid -= s_ * per;
+        kc = K / ksplit;
+        A += (int64_t)s_ * kc;
+        W += (int64_t)s_ * kc;
+        Cout += (int64_t)s_ * M * ldc;
+    }
     unsigned mpanel, nblk;
-    if (!xcd_panel_map_grouped(blockIdx.x, mp, nb, (unsigned)group, mpanel, nblk)) return;
+    if (!xcd_panel_map_grouped(bid, mp, nb, (unsigned)(group & 0xffff), mpanel, nblk)) return;
     const int m0 = mpanel * BM, n0 = nblk * BN_;
 
     const WaveCoord w = wave_coord();
@@ -92,7 +105,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     f32x4 sa[4], sw[2 * NT];             // staging registers of one K tile: thread -> (row tid/8 + 32 i, 16-B chunk tid%8)
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};   // FOLD: sum x, sum x^2 of this thread's part of 4 rows
     pipelined_kloop<true, 4 + 2 * NT, 1, NT>(
-        K / BK, As, Ws, TILE_KC, TILE_W, acc, w,
+        kc / BK, As, Ws, TILE_KC, TILE_W, acc, w,
         [&](int kt, auto) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) sa[i] = *reinterpret_cast<const f32x4*>(ap[i] + kt * BK);
@@ -244,7 +257,8 @@ template <int ACT, bool HAS_RES, bool ZROWS, int NT, int FOLD = 0, bool STATS = 
 static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                           int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
                           const uint8_t* zero_rows, hipStream_t stream, const float* fold_c = nullptr,
-                          float ln_eps = 0.f, float* row_partials = nullptr, int64_t pld = 0, int* fold_flag = nullptr) {
+                          float ln_eps = 0.f, float* row_partials = nullptr, int64_t pld = 0, int* fold_flag = nullptr,
+                          int ksplit = 0) {
     using Cfg = GemmCfg<NT>;
     static DeviceOnce configured;
     auto kern = gemm_f32_kernel<ACT, HAS_RES, ZROWS, NT, FOLD, STATS>;
@@ -260,11 +274,12 @@ static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const flo
     // launch; same speed, the kernel is MFMA-bound).  N = 768 (6 column blocks) is already balanced and stays ungrouped.
     const int nb = N / Cfg::BN_;
     const int group = tuning().gemm_group > 0 ? tuning().gemm_group : (nb > 8 * (3 - NT) ? 8 : 1);
-    const unsigned grid = xcd_panel_grid_grouped((M + BM - 1) / BM, nb, (unsigned)group);
+    const unsigned grid = xcd_panel_grid_grouped((M + BM - 1) / BM, nb, (unsigned)group) * (ksplit > 1 ? ksplit : 1);
     // algorithmic work: 2MNK flops; bytes = A + W + C once (+ residual read)
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), FOLD ? Cfg::LDS_FOLD : Cfg::LDS_BYTES, stream, A, lda, W, bias,
-                       residual, ldr, Cout, ldc, M, N, K, scale, scale_cols, zero_rows, group, fold_c, ln_eps, row_partials, pld, fold_flag);
+                       residual, ldr, Cout, ldc, M, N, K, scale, scale_cols, zero_rows, group | (ksplit > 1 ? ksplit << 16 : 0), fold_c, ln_eps,
+                       row_partials, pld, fold_flag);
     RNAMSM_CHECK_LAUNCH("gemm_f32");
     return RNAMSM_OK;
 }
@@ -321,7 +336,55 @@ static int launch_gemm_res_stats(const float* A, int64_t lda, const float* W, co
                                                                     nullptr, stream, nullptr, 0.f, row_partials, pld);
 }
 
+// ---- split-K for small token counts (rnamsm_forward, fc2).  Below ~1.4 k tokens the K = 3072 GEMM has far fewer tiles than
+// the chip has CUs (T = 1024: 48 tiles of 96 K steps each): four copies of the tile grid each take K / 4 and leave fp32
+// partial tiles, and one elementwise pass adds the four slabs IN SLAB ORDER (reruns stay bit-identical), the bias and the
+// residual.  Measured per forward (tools/splitk_ab.py): 256 .. 1024 tokens 5.92 -> 5.52 ms (+7 %); with more tiles than
+// CUs / 4 the copies share CUs and the gain is gone (2048 tokens -1 %, 4096 -1 %), and two ranges never paid -- so: four
+// ranges while tiles * 4 <= 256, else none.  Knob "gemm_splitk": 0 = never, 1 = that rule, 2 / 4 / 8 = that many ranges
+// whenever tiles * ks <= 512 (A/B).
+int gemm_f32_splitk_factor(int64_t M, int N, int K, bool by_shape_only) {
+    const int knob = by_shape_only ? 8 : tuning().gemm_splitk;      // by_shape_only: the most the workspace may be asked for
+    if (knob == 0 || K < 2048 || N % BN) return 1;
+    const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);
+    if (knob == 1) return (tiles * 4 <= 256 && K % (4 * BK) == 0) ? 4 : 1;
+    for (int ks = knob; ks >= 2; ks >>= 1)
+        if (tiles * ks <= 512 && K % (ks * BK) == 0) return ks;
+    return 1;
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partials, int ks, int64_t slab,
+                                                            const float* __restrict__ bias, const float* residual, int64_t ldr,
+                                                            float* out, int64_t ldc, int64_t M, int N) {
+    const int n4 = N / 4;
+    const int64_t total = M * n4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / n4;
+        const int n = (int)(i - m * n4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(partials + m * N + n);
+        for (int s = 1; s < ks; ++s) v += *reinterpret_cast<const f32x4*>(partials + s * slab + m * N + n);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (residual) v += *reinterpret_cast<const f32x4*>(residual + m * ldr + n);
+        *reinterpret_cast<f32x4*>(out + m * ldc + n) = v;
+    }
+}
+
+int gemm_f32_splitk(const float* A, int64_t lda, const float* W, const float* bias, const float* residual, int64_t ldr,
+                    float* Cout, int64_t ldc, int64_t M, int N, int K, int ks, float* partials, hipStream_t stream) {
+    RNAMSM_CHECK_ARG(ks >= 2 && K % (ks * BK) == 0 && N % BN == 0 && partials, "gemm_splitk: bad split %d for K=%d N=%d", ks, K, N);
+    const int rc = launch_gemm_nt<RNAMSM_ACT_NONE, false, false, 2>(A, lda, W, nullptr, nullptr, 0, partials, N, (int)M, N, K, 1.f, 0,
+                                                                    nullptr, stream, nullptr, 0.f, nullptr, 0, nullptr, ks);
+    if (rc != RNAMSM_OK) return rc;
+    const int64_t total = M * (N / 4);
+    const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, partials, ks, M * (int64_t)N, bias, residual, ldr,
+                       Cout, ldc, M, N);
+    RNAMSM_CHECK_LAUNCH("splitk_reduce");
+    return RNAMSM_OK;
+}
+
 }  // namespace rnamsm
+
 
 using namespace rnamsm;
 

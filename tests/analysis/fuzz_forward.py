@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised forward fuzz on the GPU against the oracle: random (R, C) with ragged edges around every kernel-selection
-threshold, random arithmetic mode, random `ln_fold` / `gemm_tile` / `col_dma` / `greedy_fused`-independent knobs, padded
+threshold, random arithmetic mode, random `ln_fold` / `gemm_tile` / `gemm_splitk` / `col_dma` / `row_vt` / `attn16` knobs, padded
 and unpadded MSAs, outputs-only or full.  Every case is judged against the fp64 truth (the oracle's code in float64 on
 the device, tests/truth.py) with the reference's own fp32 arithmetic (the CPU oracle) as the yardstick: the bar is
 emb rel-L2 1e-4 / atp max-abs 1e-4 (bf16x3: 2e-4 / 1e-3), or -- where the reference's fp32 forward is itself further
@@ -33,7 +33,7 @@ EDGES = [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 1
 # (emb bar, atp bar, multiple of the reference's own fp32 error that is accepted where that is larger)
 TOL = {"f32": (1e-4, 1e-4, 3.0), "f16x3": (1e-4, 1e-4, 3.0), "bf16x3": (2e-4, 1e-3, 5.0),
        "bf16": (2e-2, 2e-2, 2.0)}         # plain bf16: yardstick = the oracle run in bfloat16 (what the reference's .bfloat16() does)
-KNOB_DEFAULTS = {"ln_fold": 1, "gemm_tile": 0, "col_dma": -1, "row_vt": 1, "attn16": 1}
+KNOB_DEFAULTS = {"ln_fold": 1, "gemm_tile": 0, "col_dma": -1, "row_vt": 1, "attn16": 1, "gemm_splitk": 1}
 
 
 def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mode=None, model=None, log=print):
@@ -59,7 +59,8 @@ def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mod
                     break
             mode = str(rng.choice(["f32", "f32", "f16x3", "bf16x3", "bf16"]))
             knobs = {"ln_fold": int(rng.choice([0, 1, 2, 3])), "gemm_tile": int(rng.choice([0, 1, 2])),
-                     "col_dma": int(rng.choice([-1, 0, 1])), "row_vt": int(rng.choice([0, 1])), "attn16": int(rng.choice([0, 1, 1]))}
+                     "col_dma": int(rng.choice([-1, 0, 1])), "row_vt": int(rng.choice([0, 1])), "attn16": int(rng.choice([0, 1, 1])),
+                     "gemm_splitk": int(rng.choice([0, 1, 1, 2, 4, 8]))}
             padded = rng.random() < 0.3 and R > 1 and C > 3
             if fixed:
                 (R, C), padded = fixed[case], False

@@ -116,14 +116,21 @@ def test_layerwise_path_equals_driver_and_exposes_intermediate_layers(model):
     probe = g["probe_row0_layers_0_1_5"]
     for slot, layer in enumerate((0, 1, 5)):
         assert rel_l2(res["representations"][layer][0, 0].cpu().numpy(), probe[slot]) < 1e-4
+    from rnamsm import ops
     try:
-        m.fold_layernorm = False          # the modules run LayerNorm as its own launch: compare like with like ...
+        m.fold_layernorm = False          # the modules run LayerNorm as its own launch and fc2 as one GEMM: like with like ...
+        ops.set_param("gemm_splitk", 0)
         fast = m.forward_one(toks)
+        ops.set_param("gemm_splitk", 1)   # ... and the driver's split-K fc2 of small MSAs to rounding
+        split = m.forward_one(toks)
     finally:
         m.fold_layernorm = True
+        ops.set_param("gemm_splitk", 1)
+    assert rel_l2(split["repr"].cpu().numpy(), fast["repr"].cpu().numpy()) < 5e-6
+    assert np.abs(split["row_attn"].cpu().numpy() - fast["row_attn"].cpu().numpy()).max() < 2e-5
+    assert not torch.equal(split["repr"], fast["repr"])           # 136 tokens: the split form is what ran
     assert rel_l2(res["representations"][10][0].cpu().numpy(), fast["repr"].cpu().numpy()) < 1e-6
     assert np.abs(res["row_attentions"][0].cpu().numpy() - fast["row_attn"].cpu().numpy()).max() < 1e-6
-    from rnamsm import ops
     try:
         ops.set_param("ln_fold", 3)       # ... and the driver with LayerNorm folded into the GEMMs to rounding
         fold = m.forward_one(toks)
