@@ -349,3 +349,138 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     FWD(rnamsm_pack_outputs(repr, row_attn, emb, atp, C, D, NL, H, stream));
     return RNAMSM_OK;
 }
+
+// ---- B same-shape, unpadded MSAs through one set of token-parallel launches (exact path).
+// Why: below ~4 k tokens a forward costs 5.5-6 ms whatever the alignment holds -- each of its ~140 dependent launches lasts a
+// block's serial time while most CUs idle.  LayerNorm, the six Linear GEMMs of a layer and the final LayerNorm
+// are per token: for a batch [B, R, C] they run ONCE over the B*R*C tokens (MSA-major, which is also the layout of the
+// representation the caller gets back); only the attention kernels, which couple the tokens of one MSA, and the
+// embedding (its row-position table is per MSA) are launched per MSA on that MSA's slice.  Same kernels, same per-element
+// arithmetic as rnamsm_forward on each MSA alone -- up to the two shape-dependent choices that change the rounding (split-K
+// of fc2 and the folded LayerNorm are decided by the batch's token count).
+namespace {
+struct BatchLayout {
+    size_t x, xn, wide, part, rowsum, stats, splitk, total;
+};
+BatchLayout make_batch_layout(const rnamsm_model_dims& d, int B, int R, int C) {
+    const size_t T = (size_t)B * R * C, D = d.embed_dim;
+    BatchLayout l;
+    size_t off = 0;
+    l.x = off;      off += align256(T * D * 4);
+    l.xn = off;     off += align256(T * D * 4);
+    l.wide = off;   off += align256(T * (size_t)(4 * D > (size_t)d.ffn_dim ? 4 * D : d.ffn_dim) * 4);
+    l.part = off;   off += align256(rnamsm_row_logits_workspace_bytes(R, C, d.num_heads));
+    l.rowsum = off; off += align256(T * (D / 32) * 2 * sizeof(float));
+    l.stats = off;  off += align256(T * 2 * sizeof(float));
+    const size_t kt = (size_t)rnamsm::gemm_f32_splitk_factor((int64_t)T, (int)D, d.ffn_dim, true);
+    l.splitk = off; off += align256((kt > 1 ? kt * T : 0) * D * sizeof(float));
+    l.total = off;
+    return l;
+}
+}  // namespace
+
+extern "C" size_t rnamsm_forward_batch_workspace_bytes(const rnamsm_model_dims* dims, int B, int R, int C) {
+    if (!dims || B <= 0 || R <= 0 || C <= 0) return 0;
+    return make_batch_layout(*dims, B, R, C).total;
+}
+
+extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens, int B,
+                                    int R, int C, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
+                                    float* emb, float* atp, int* err_flag, const float* const* ln_folded, void* stream) {
+    RNAMSM_CHECK_ARG(dims && weights && tokens && workspace && row_attn && repr && emb && atp, "forward_batch: null pointer");
+    const rnamsm_model_dims& d = *dims;
+    const int D = d.embed_dim, H = d.num_heads, F = d.ffn_dim, NL = d.num_layers;
+    RNAMSM_CHECK_ARG(D > 0 && H > 0 && D == H * 64, "forward_batch: embed_dim must be num_heads * 64 (D=%d H=%d)", D, H);
+    RNAMSM_CHECK_ARG(D % 128 == 0 && F % 128 == 0 && NL > 0, "forward_batch: embed_dim and ffn_dim must be multiples of 128");
+    RNAMSM_CHECK_ARG(B >= 1 && C >= 2 && R >= 1, "forward_batch: need B >= 1, R >= 1 and C >= 2 (got B=%d R=%d C=%d)", B, R, C);
+    if (R > 1024)   // model.py:355-359
+        return fail(RNAMSM_ERR_INVALID,
+                    "Using model with MSA position embedding trained on maximum MSA depth of 1024, but received %d alignments.", R);
+    RNAMSM_CHECK_ARG(C <= d.num_positions - d.pad_idx - 1, "forward_batch: C=%d exceeds the positional table", C);
+    const int64_t Tm = (int64_t)R * C, T = (int64_t)B * Tm;          // tokens of one MSA / of the batch
+    RNAMSM_CHECK_ARG(T <= INT32_MAX, "forward_batch: %lld tokens exceed the GEMM row range", (long long)T);
+    const BatchLayout lay = make_batch_layout(d, B, R, C);
+    RNAMSM_CHECK_ARG(workspace_bytes >= lay.total, "forward_batch: workspace too small (%zu < %zu)", workspace_bytes, lay.total);
+    RNAMSM_CHECK_ARG(aligned16(workspace), "forward_batch: workspace must be 16-byte aligned");
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    float* x = reinterpret_cast<float*>(ws + lay.x);
+    float* xn = reinterpret_cast<float*>(ws + lay.xn);
+    float* wide = reinterpret_cast<float*>(ws + lay.wide);
+    float* part = reinterpret_cast<float*>(ws + lay.part);
+    float* rowsum = reinterpret_cast<float*>(ws + lay.rowsum);
+    float* stats = reinterpret_cast<float*>(ws + lay.stats);
+    float* splitk = reinterpret_cast<float*>(ws + lay.splitk);
+    const int64_t ldq = 3 * (int64_t)D;
+    float* qkv = wide;                 // [T, 3D]
+    float* ctx = wide + T * ldq;       // [T, D]
+    float* hidden = wide;              // [T, F]
+    const float* const* G = weights;
+    const int f32 = RNAMSM_F32;
+    const int nsplit = rnamsm_row_logits_nsplit(R, C, H);
+    const int fold_mode = tuning().ln_fold;
+    const bool fold = ln_folded && (fold_mode == 3 || (fold_mode == 1 && T >= 18432));     // statistics from the producers only
+    const float row_scale = (1.0f / sqrtf(64.0f)) / sqrtf((float)R), col_scale = 1.0f / sqrtf(64.0f);
+
+    auto norm = [&](const float* g, const float* b) -> int {
+        return fold ? RNAMSM_OK : rnamsm_layernorm(x, g, b, xn, T, D, d.ln_eps, stream);
+    };
+    auto lin_normed = [&](int layer, int fslot, const float* Wf, const float* bias, float* out, int64_t ldc, int N, int act,
+                          float scale, int scale_cols) -> int {
+        if (fold) {
+            const float* const* Fp = ln_folded + (size_t)layer * RNAMSM_FOLDED_PER_LAYER + 3 * fslot;
+            return rnamsm_gemm_lnfold(x, D, Fp[0], Fp[1], Fp[2], d.ln_eps, stats, err_flag, out, ldc, T, N, D, act, scale,
+                                      scale_cols, f32, stream);
+        }
+        return rnamsm_gemm_bias_act_res(xn, D, Wf, bias, nullptr, 0, out, ldc, T, N, D, act, scale, scale_cols, nullptr, f32, stream);
+    };
+    auto res_linear = [&](const float* A, int64_t lda, const float* Wf, const float* bias, int K) -> int {
+        if (fold) {
+            FWD(rnamsm_gemm_residual_stats(A, lda, Wf, bias, x, D, x, D, T, D, K, rowsum, T, f32, stream));
+            return rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream);
+        }
+        const int ks = rnamsm::gemm_f32_splitk_factor(T, D, K);
+        if (ks > 1) return rnamsm::gemm_f32_splitk(A, lda, Wf, bias, x, D, x, D, T, D, K, ks, splitk, hs);
+        return rnamsm_gemm_bias_act_res(A, lda, Wf, bias, x, D, x, D, T, D, K, RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream);
+    };
+
+    for (int b = 0; b < B; ++b)        // K0 per MSA: the row-position table restarts with every alignment
+        FWD(rnamsm_embed_ln(tokens + b * Tm, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
+                            G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x + b * Tm * D, R, C, D, d.vocab, d.num_positions,
+                            d.pad_idx, d.ln_eps, err_flag, stream));
+    if (fold) {
+        FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
+        FWD(rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream));
+    }
+    for (int l = 0; l < NL; ++l) {
+        const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
+        // ---- tied row attention: projections over the batch, K4-K6 per MSA
+        FWD(norm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
+        FWD(lin_normed(l, 0, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, row_scale, D));
+        for (int b = 0; b < B; ++b) {
+            const float* q = qkv + b * Tm * ldq;
+            float* probs = row_attn + ((int64_t)b * NL + l) * H * C * C;
+            FWD(rnamsm_row_logits(q, q + D, ldq, part, R, C, H, 64, f32, stream));
+            FWD(rnamsm_softmax_rows(part, nsplit, probs, H, C, nullptr, stream));
+            FWD(rnamsm_row_apply(probs, q + 2 * D, ldq, ctx + b * Tm * D, D, R, C, H, 64, nullptr, nullptr, 0, f32, stream));
+        }
+        FWD(res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], D));
+        // ---- column attention
+        FWD(norm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
+        FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, col_scale, D));
+        for (int b = 0; b < B; ++b) {
+            const float* q = qkv + b * Tm * ldq;
+            FWD(rnamsm_col_attn_fused(q, q + D, q + 2 * D, ldq, ctx + b * Tm * D, D, R, C, H, 64, nullptr, nullptr, nullptr, 0, f32, stream));
+        }
+        FWD(res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], D));
+        // ---- feed-forward
+        FWD(norm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
+        FWD(lin_normed(l, 2, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], hidden, F, F, RNAMSM_ACT_GELU_ERF, 1.f, 0));
+        FWD(res_linear(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], F));
+    }
+    FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
+    for (int b = 0; b < B; ++b)
+        FWD(rnamsm_pack_outputs(repr + b * Tm * D, row_attn + (int64_t)b * NL * H * C * C, emb + (int64_t)b * (C - 1) * D,
+                                atp + (int64_t)b * NL * H * (C - 1) * (C - 1), C, D, NL, H, stream));
+    return RNAMSM_OK;
+}

@@ -82,6 +82,10 @@ class MSATransformer(nn.Module):
         # Arithmetic of the contractions: "f32" (exact, default), "f16x3", "bf16x3" or "bf16" (include/rnamsm.h) -- for the
         # C++ driver and, through the property below, for every mirror module of the layer-wise path
         self.gemm_dtype = "f32"
+        # forward(tokens[B,R,C]) with B > 1, no <pad>, exact path: MSAs are run together (rnamsm_forward_batch) in groups of
+        # at most batch_token_budget tokens -- pays below ~8 k tokens per MSA, where a lone forward leaves the chip idle
+        self.batch_small_msas = True
+        self.batch_token_budget = 32768
         self.check_finite = True          # 16-bit modes: verify the outputs are finite, fall back to f32 per MSA otherwise
         self._planes = None
         self._folded = None
@@ -277,6 +281,47 @@ class MSATransformer(nn.Module):
             return self._forward_one_on_device(tokens2d, has_padding, need_repr,
                                                self.fold_layernorm if fold_layernorm is None else fold_layernorm)
 
+    def forward_batch(self, tokens3d: torch.Tensor, fold_layernorm: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+        """B same-shape MSAs without <pad> through rnamsm_forward_batch (exact path): tokens [B,R,C] -> row_attn
+        [B,NL,H,C,C], repr [B,R,C,D], emb [B,C-1,D], atp [B,NL*H,C-1,C-1], err int32[1] (bits as in forward_one)."""
+        if self.training:
+            raise NotImplementedError("inference only (model.eval())")
+        if not tokens3d.is_cuda:
+            raise _lib.RnamsmError("tokens must be on the HIP device (no CPU path exists)")
+        assert tokens3d.ndim == 3
+        fold = self.fold_layernorm if fold_layernorm is None else fold_layernorm
+        with torch.cuda.device(tokens3d.device):
+            B, R, C = tokens3d.shape
+            lib = _lib.load()
+            dims, ptrs, _ = self._packed_weights()
+            dev = tokens3d.device
+            NL, H, D = self.num_layers, self.num_attention_heads, self.embed_dim
+            toks = tokens3d.to(torch.int64).contiguous()
+            ws_bytes = lib.rnamsm_forward_batch_workspace_bytes(ctypes.byref(dims), B, R, C)
+            ws = self._get_workspace(ws_bytes, dev)
+            row_attn = torch.empty(B, NL, H, C, C, device=dev, dtype=torch.float32)
+            rep = torch.empty(B, R, C, D, device=dev, dtype=torch.float32)
+            emb = torch.empty(B, C - 1, D, device=dev, dtype=torch.float32)
+            atp = torch.empty(B, NL * H, C - 1, C - 1, device=dev, dtype=torch.float32)
+            err = torch.zeros(1, device=dev, dtype=torch.int32)
+            folded = self._folded_weights() if fold else None
+            _lib.check(lib.rnamsm_forward_batch(ctypes.byref(dims), ptrs, toks.data_ptr(), B, R, C, ws.data_ptr(), ws.numel(),
+                                                row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
+                                                err.data_ptr(), folded, torch.cuda.current_stream().cuda_stream))
+        return {"row_attn": row_attn, "repr": rep, "emb": emb, "atp": atp, "err": err}
+
+    def checked_forward_batch(self, tokens3d: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """forward_batch + the error word (see checked_forward_one)."""
+        out = self.forward_batch(tokens3d)
+        err = int(out["err"].item())
+        if err & self.ERR_INDEX:
+            raise IndexError("batch: token or position index out of range")
+        if err & self.ERR_FOLD:
+            import warnings
+            warnings.warn("batch: a token row's mean exceeds 32x its spread; LayerNorm is applied in its own launches for this batch")
+            out = self.forward_batch(tokens3d, fold_layernorm=False)
+        return out
+
     ERR_INDEX, ERR_FOLD = 1, 2            # bits of forward_one's "err": token / position index out of range; a row whose
                                           # |mean| is so far above its spread that the folded LayerNorm loses > 5 bits
 
@@ -385,7 +430,18 @@ class MSATransformer(nn.Module):
         reps: Dict[int, List[torch.Tensor]] = {i: [] for i in repr_set}
         atts: List[torch.Tensor] = []
         fast = repr_set <= {self.num_layers}
-        for b in range(B):
+        done = 0
+        if fast and B > 1 and not has_padding and self.gemm_dtype == "f32" and self.batch_small_msas and not self.training:
+            # same-shape, unpadded MSAs of a few thousand tokens: their token-parallel launches are shared (rnamsm_forward_batch)
+            per = max(1, self.batch_token_budget // (R * C))
+            while per > 1 and B - done > 1:
+                n = min(per, B - done)
+                out = self.checked_forward_batch(tokens[done:done + n])
+                if self.num_layers in repr_set:
+                    reps[self.num_layers].append(out["repr"])
+                atts.append(out["row_attn"])
+                done += n
+        for b in range(done, B):
             if fast:
                 out = self.checked_forward_one(tokens[b], has_padding)
                 if self.num_layers in repr_set:
@@ -403,6 +459,7 @@ class MSATransformer(nn.Module):
             result["row_attentions"] = torch.cat(atts, 0)                           # [B, NL, H, C, C]
         if return_contacts:                                                         # model.py:412-414
             reg = self.contact_head.regression
+            maps = torch.cat(atts, 0)
             result["contacts"] = torch.stack(
-                [ops.contact_head(a[0], reg.weight.detach(), reg.bias.detach()) for a in atts], 0)
+                [ops.contact_head(maps[b], reg.weight.detach(), reg.bias.detach()) for b in range(B)], 0)
         return result

@@ -614,3 +614,59 @@ def test_folded_layernorm_across_weight_scales(weight_std, bias_std, ln_std):
     e_fold, e_plain = rel_l2(fold["emb"].cpu().numpy(), o_emb.numpy()), rel_l2(plain["emb"].cpu().numpy(), o_emb.numpy())
     assert e_fold < 1.5 * e_plain + 2e-7 and e_fold < 1e-4, (e_fold, e_plain)
     assert np.abs(fold["atp"].cpu().numpy() - o_atp.numpy()).max() < 2.0 * np.abs(plain["atp"].cpu().numpy() - o_atp.numpy()).max() + 1e-6
+
+
+@pytest.mark.parametrize("B,R,C", [(3, 8, 17), (5, 1, 9), (2, 37, 64), (4, 16, 33)])
+def test_batched_forward_of_same_shape_msas_equals_the_msas_one_by_one(model, B, R, C):
+    """rnamsm_forward_batch: the token-parallel launches of B unpadded same-shape MSAs are shared, attention runs per MSA.
+    Every MSA must come out as from rnamsm_forward alone -- bit-identical when the shape-dependent choices agree (fc2
+    split-K off, LayerNorm unfolded), to fp32 rounding otherwise -- and meet the bar against the oracle."""
+    from rnamsm import ops
+    m, state = model
+    toks = torch.from_numpy(np.stack([synthetic.make_tokens(R, C, 300 + b) for b in range(B)])).to("cuda:0")
+    try:
+        ops.set_param("gemm_splitk", 0)
+        ops.set_param("ln_fold", 0)
+        batch = m.checked_forward_batch(toks)
+        for b in range(B):
+            one = m.checked_forward_one(toks[b])
+            for key in ("emb", "atp", "row_attn"):
+                assert torch.equal(batch[key][b], one[key]), (key, b)
+            assert torch.equal(batch["repr"][b].reshape(R * C, -1), one["repr"].reshape(R * C, -1))
+    finally:
+        ops.set_param("gemm_splitk", 1)
+        ops.set_param("ln_fold", 1)
+    batch = m.checked_forward_batch(toks)                      # the defaults: split-K decided by the batch's token count
+    params = O.to_torch_params(state)
+    for b in range(B):
+        emb, atp = O.pack_outputs(O.forward(toks[b].cpu(), params))
+        assert rel_l2(batch["emb"][b].cpu().numpy(), np.asarray(emb)) < 1e-4
+        assert np.abs(batch["atp"][b].cpu().numpy() - np.asarray(atp)).max() < 1e-4
+    # MSATransformer.forward takes that route for B > 1 ...
+    res = m(toks, repr_layers=[10], need_head_weights=True, return_contacts=True)
+    assert torch.equal(res["representations"][10], batch["repr"]) and torch.equal(res["row_attentions"], batch["row_attn"])
+    try:
+        m.batch_small_msas = False                             # ... and agrees with the MSAs one by one to rounding
+        ref = m(toks, repr_layers=[10], need_head_weights=True, return_contacts=True)
+    finally:
+        m.batch_small_msas = True
+    assert rel_l2(res["representations"][10].cpu().numpy(), ref["representations"][10].cpu().numpy()) < 5e-6
+    assert np.abs(res["row_attentions"].cpu().numpy() - ref["row_attentions"].cpu().numpy()).max() < 2e-5
+    assert np.abs(res["contacts"].cpu().numpy() - ref["contacts"].cpu().numpy()).max() < 2e-5
+    assert rel_l2(res["logits"].cpu().numpy(), ref["logits"].cpu().numpy()) < 5e-6 if res["logits"] is not None else True
+
+
+def test_batched_forward_reports_bad_tokens_and_splits_large_batches(model):
+    m, _ = model
+    toks = torch.from_numpy(np.stack([synthetic.make_tokens(4, 9, b) for b in range(7)])).to("cuda:0")
+    try:
+        m.batch_token_budget = 3 * 36                         # groups of 3, 3 and a single MSA
+        res = m(toks, repr_layers=[10], need_head_weights=True)
+    finally:
+        m.batch_token_budget = 32768
+    whole = m.checked_forward_batch(toks)
+    assert rel_l2(res["representations"][10].cpu().numpy(), whole["repr"].cpu().numpy()) < 5e-6
+    bad = toks.clone()
+    bad[5, 2, 3] = 999
+    with pytest.raises(IndexError):
+        m.checked_forward_batch(bad)
