@@ -36,8 +36,12 @@ template <bool MASKED, int OUT>
 __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask,
-    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows) {
+    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows, int64_t qkv_bstride, int64_t ctx_bstride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    q += blockIdx.y * qkv_bstride;        // batched launch (rnamsm_forward_batch): MSA blockIdx.y, fp32 context, no mask
+    k += blockIdx.y * qkv_bstride;
+    v += blockIdx.y * qkv_bstride;
+    if (OUT == 0) ctx += blockIdx.y * ctx_bstride;
     float* Ks = smem;                    // [2][CA_JC][CA_LDD]
     float* Vs = smem + 2 * CA_TILE;      // [2][CA_JC][CA_LDD]
 
@@ -259,8 +263,12 @@ template <bool MASKED, int OUT>
 __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask,
-    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows) {
+    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows, int64_t qkv_bstride, int64_t ctx_bstride) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    q += blockIdx.y * qkv_bstride;        // batched launch (rnamsm_forward_batch): MSA blockIdx.y, fp32 context, no mask
+    k += blockIdx.y * qkv_bstride;
+    v += blockIdx.y * qkv_bstride;
+    if (OUT == 0) ctx += blockIdx.y * ctx_bstride;
 
     const unsigned iblocks = (q_rows + CA_ROWS - 1) / CA_ROWS;       // query rows [0, q_rows) only (q_rows == R: all)
     unsigned prob, ib;
@@ -473,7 +481,7 @@ using namespace rnamsm;
 
 static int col_attn_launch(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,
                            int H, int head_dim, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt,
-                           int dtype, void* stream, int q_rows);
+                           int dtype, void* stream, int q_rows, int batch = 1, int64_t qkv_bstride = 0, int64_t ctx_bstride = 0);
 
 extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_t ld, float* ctx,
                                      int64_t ldc, int R, int C, int H, int head_dim, const uint8_t* pad_mask,
@@ -490,8 +498,10 @@ extern "C" int rnamsm_col_attn_fused_queries(const float* q, const float* k, con
 
 static int col_attn_launch(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,
                            int H, int head_dim, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt,
-                           int dtype, void* stream, int q_rows) {
+                           int dtype, void* stream, int q_rows, int batch, int64_t qkv_bstride, int64_t ctx_bstride) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "col_attn: only RNAMSM_F32 is implemented");
+    RNAMSM_CHECK_ARG(batch == 1 || (!pad_mask && !ctx_hi && qkv_bstride % 4 == 0 && ctx_bstride % 4 == 0),
+                     "col_attn: a batched launch has no mask and writes fp32 context");
     RNAMSM_CHECK_ARG(q && k && v && (ctx || ctx_hi), "col_attn: null pointer");
     RNAMSM_CHECK_ARG(head_dim == CA_HD, "col_attn: head_dim must be 64 (got %d)", head_dim);
     RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0, "col_attn: bad shape R=%d C=%d H=%d", R, C, H);
@@ -503,7 +513,7 @@ static int col_attn_launch(const float* q, const float* k, const float* v, int64
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned iblocks = (q_rows + CA_ROWS - 1) / CA_ROWS;
     const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
-    KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)q_rows * R * CA_HD, 4.0 * (2.0 * R + 2.0 * q_rows) * C * H * CA_HD, s);
+    KernelTimer timer(TC_COL_ATTN, 4.0 * batch * C * H * (double)q_rows * R * CA_HD, 4.0 * batch * (2.0 * R + 2.0 * q_rows) * C * H * CA_HD, s);
 #define CA_GO2(KERN_, LDS_, M_, OUT_)                                                                               \
     do {                                                                                                            \
         static DeviceOnce cfg_;                                                                                     \
@@ -513,8 +523,8 @@ static int col_attn_launch(const float* q, const float* k, const float* v, int64
             if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
             cfg_.mark();                                                                                            \
         }                                                                                                           \
-        hipLaunchKernelGGL((KERN_<M_, OUT_>), dim3(grid), dim3(CA_THREADS), LDS_, s, q, k, v, ld, ctx, ldc, R, C, H, \
-                           pad_mask, ctx_hi, ctx_lo, q_rows);                                                       \
+        hipLaunchKernelGGL((KERN_<M_, OUT_>), dim3(grid, batch), dim3(CA_THREADS), LDS_, s, q, k, v, ld, ctx, ldc, R, C, H, \
+                           pad_mask, ctx_hi, ctx_lo, q_rows, qkv_bstride, ctx_bstride);                             \
     } while (0)
     // "col_dma": 1 = the LDS-DMA, three-blocks-per-CU variant, 0 = the register-staged kernel, -1 (default) = the former.
     // Measured in one process (tools/col_attn_ab.py, after the key-range masking was confined to the ragged last tile):
@@ -535,3 +545,12 @@ static int col_attn_launch(const float* q, const float* k, const float* v, int64
     RNAMSM_CHECK_LAUNCH("col_attn");
     return RNAMSM_OK;
 }
+
+namespace rnamsm {
+// K7 for `batch` same-shape MSAs in one launch (rnamsm_forward_batch): MSA b's q / k / v lie b * qkv_bstride elements on
+int col_attn_batched(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
+                     int batch, int64_t qkv_bstride, int64_t ctx_bstride, void* stream) {
+    return col_attn_launch(q, k, v, ld, ctx, ldc, R, C, H, CA_HD, nullptr, nullptr, nullptr, 0, RNAMSM_F32, stream, R, batch,
+                           qkv_bstride, ctx_bstride);
+}
+}  // namespace rnamsm

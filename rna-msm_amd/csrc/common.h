@@ -233,4 +233,15 @@ int gemm_f32_splitk_factor(int64_t M, int N, int K, bool by_shape_only = false);
 int gemm_f32_splitk(const float* A, int64_t lda, const float* W, const float* bias, const float* residual, int64_t ldr,
                     float* Cout, int64_t ldc, int64_t M, int N, int K, int ks, float* partials, hipStream_t stream);
 
+// the attention kernels of `batch` same-shape, unpadded MSAs in one launch each (gridDim.y = batch; MSA b's operands lie
+// b * stride elements further on): row_attn.hip, col_attn.hip; used by rnamsm_forward_batch
+int row_logits_batched(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H, int batch,
+                       int64_t qk_bstride, int64_t part_bstride, void* stream);
+int softmax_rows_batched(const float* partial, int nsplit, float* probs, int H, int C, int batch, int64_t part_bstride,
+                         int64_t probs_bstride, void* stream);
+int row_apply_batched(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H, int batch,
+                      int64_t probs_bstride, int64_t v_bstride, int64_t ctx_bstride, void* stream);
+int col_attn_batched(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
+                     int batch, int64_t qkv_bstride, int64_t ctx_bstride, void* stream);
+
 }  // namespace rnamsm

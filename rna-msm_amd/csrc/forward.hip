@@ -354,8 +354,9 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
 // Why: below ~4 k tokens a forward costs 5.5-6 ms whatever the alignment holds -- each of its ~140 dependent launches lasts a
 // block's serial time while most CUs idle.  LayerNorm, the six Linear GEMMs of a layer and the final LayerNorm
 // are per token: for a batch [B, R, C] they run ONCE over the B*R*C tokens (MSA-major, which is also the layout of the
-// representation the caller gets back); only the attention kernels, which couple the tokens of one MSA, and the
-// embedding (its row-position table is per MSA) are launched per MSA on that MSA's slice.  Same kernels, same per-element
+// representation the caller gets back); the attention kernels, which couple the tokens of one MSA, take the MSA
+// index from gridDim.y (one launch each for the whole batch); only the embedding (its row-position table is per MSA) and
+// the output packing are launched per MSA.  Same kernels, same per-element
 // arithmetic as rnamsm_forward on each MSA alone -- up to the two shape-dependent choices that change the rounding (split-K
 // of fc2 and the folded LayerNorm are decided by the batch's token count).
 namespace {
@@ -369,7 +370,7 @@ BatchLayout make_batch_layout(const rnamsm_model_dims& d, int B, int R, int C) {
     l.x = off;      off += align256(T * D * 4);
     l.xn = off;     off += align256(T * D * 4);
     l.wide = off;   off += align256(T * (size_t)(4 * D > (size_t)d.ffn_dim ? 4 * D : d.ffn_dim) * 4);
-    l.part = off;   off += align256(rnamsm_row_logits_workspace_bytes(R, C, d.num_heads));
+    l.part = off;   off += align256((size_t)B * rnamsm_row_logits_workspace_bytes(R, C, d.num_heads));   // every MSA's logit slabs
     l.rowsum = off; off += align256(T * (D / 32) * 2 * sizeof(float));
     l.stats = off;  off += align256(T * 2 * sizeof(float));
     const size_t kt = (size_t)rnamsm::gemm_f32_splitk_factor((int64_t)T, (int)D, d.ffn_dim, true);
@@ -457,21 +458,18 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
         // ---- tied row attention: projections over the batch, K4-K6 per MSA
         FWD(norm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
         FWD(lin_normed(l, 0, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, row_scale, D));
-        for (int b = 0; b < B; ++b) {
-            const float* q = qkv + b * Tm * ldq;
-            float* probs = row_attn + ((int64_t)b * NL + l) * H * C * C;
-            FWD(rnamsm_row_logits(q, q + D, ldq, part, R, C, H, 64, f32, stream));
-            FWD(rnamsm_softmax_rows(part, nsplit, probs, H, C, nullptr, stream));
-            FWD(rnamsm_row_apply(probs, q + 2 * D, ldq, ctx + b * Tm * D, D, R, C, H, 64, nullptr, nullptr, 0, f32, stream));
+        {   // K4-K6 of all B MSAs in one launch each (gridDim.y = B); the maps land in row_attn [B, NL, H, C, C]
+            const int64_t part_bs = (int64_t)nsplit * H * C * C, probs_bs = (int64_t)NL * H * C * C;
+            float* probs = row_attn + (int64_t)l * H * C * C;
+            FWD(rnamsm::row_logits_batched(qkv, qkv + D, ldq, part, R, C, H, B, Tm * ldq, part_bs, stream));
+            FWD(rnamsm::softmax_rows_batched(part, nsplit, probs, H, C, B, part_bs, probs_bs, stream));
+            FWD(rnamsm::row_apply_batched(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, B, probs_bs, Tm * ldq, Tm * D, stream));
         }
         FWD(res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], D));
         // ---- column attention
         FWD(norm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
         FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, col_scale, D));
-        for (int b = 0; b < B; ++b) {
-            const float* q = qkv + b * Tm * ldq;
-            FWD(rnamsm_col_attn_fused(q, q + D, q + 2 * D, ldq, ctx + b * Tm * D, D, R, C, H, 64, nullptr, nullptr, nullptr, 0, f32, stream));
-        }
+        FWD(rnamsm::col_attn_batched(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, B, Tm * ldq, Tm * D, stream));
         FWD(res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], D));
         // ---- feed-forward
         FWD(norm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));

@@ -34,10 +34,14 @@ constexpr int ROWAPPLY_VT_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;
 // slab reads in K5, and four times the K loop per block prologue / epilogue.
 __global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int64_t ld, float* __restrict__ partial,
-    int R, int C, int H, int nsplit, int rows_per_split, int chain_tiles) {
+    int R, int C, int H, int nsplit, int rows_per_split, int chain_tiles, int64_t qk_bstride, int64_t part_bstride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;
     float* Ks = smem + 2 * TILE_KC;
+    // batched launch (gridDim.y MSAs of the same shape, rnamsm_forward_batch): MSA blockIdx.y's operands and slabs
+    q += blockIdx.y * qk_bstride;
+    k += blockIdx.y * qk_bstride;
+    partial += blockIdx.y * part_bstride;
 
     const unsigned tiles_c = (C + BM - 1) / BM;
     unsigned panel, tile;
@@ -122,9 +126,12 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
                                                            float* __restrict__ probs, int64_t rows, int C,
                                                            const uint8_t* __restrict__ key_mask,
                                                            uint16_t* __restrict__ p_hi, uint16_t* __restrict__ p_lo,
-                                                           int64_t ldp, float plane_scale, int64_t mask_slab_stride) {
+                                                           int64_t ldp, float plane_scale, int64_t mask_slab_stride,
+                                                           int64_t part_bstride, int64_t probs_bstride) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    partial += blockIdx.y * part_bstride;        // batched launch: MSA blockIdx.y (fp32 probabilities only)
+    probs += blockIdx.y * probs_bstride;
     const int lane = threadIdx.x & 63;
     const int64_t slab = rows * C;
     float v[SOFTMAX_MAX_PER_LANE];
@@ -217,9 +224,13 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 template <bool ALIGNED, int OUT, bool VT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
     const float* __restrict__ probs, const float* __restrict__ v, int64_t ld, float* __restrict__ ctx, int64_t ldc,
-    int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo) {
+    int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int64_t probs_bstride, int64_t v_bstride,
+    int64_t ctx_bstride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ps = smem;                    // [2][BM][LDK]
+    probs += blockIdx.y * probs_bstride;         // batched launch: MSA blockIdx.y (fp32 context only)
+    v += blockIdx.y * v_bstride;
+    if (OUT == 0) ctx += blockIdx.y * ctx_bstride;
     float* Vs = smem + 2 * TILE_KC;      // [2][BK][LDN], or [2][BN][LDK] when VT
     constexpr int TILE_V = VT ? TILE_KC : TILE_NC;
 
@@ -336,7 +347,8 @@ extern "C" size_t rnamsm_row_logits_workspace_bytes(int R, int C, int H) {
 }
 
 static int row_logits_launch(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H,
-                             int head_dim, int dtype, void* stream, int rows_per_chunk);
+                             int head_dim, int dtype, void* stream, int rows_per_chunk, int batch = 1, int64_t qk_bstride = 0,
+                             int64_t part_bstride = 0);
 
 extern "C" int rnamsm_row_logits(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H,
                                  int head_dim, int dtype, void* stream) {
@@ -356,7 +368,8 @@ extern "C" int rnamsm_row_logits_chunked(const float* q, const float* k, int64_t
 }
 
 static int row_logits_launch(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H,
-                             int head_dim, int dtype, void* stream, int rows_per_chunk) {
+                             int head_dim, int dtype, void* stream, int rows_per_chunk, int batch, int64_t qk_bstride,
+                             int64_t part_bstride) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "row_logits: only RNAMSM_F32 is implemented");
     RNAMSM_CHECK_ARG(q && k && partial, "row_logits: null pointer");
     RNAMSM_CHECK_ARG(head_dim == HEAD_DIM, "row_logits: head_dim must be 64 (got %d)", head_dim);
@@ -376,18 +389,18 @@ static int row_logits_launch(const float* q, const float* k, int64_t ld, float* 
     }
     const unsigned tiles_c = (C + BM - 1) / BM;
     const unsigned grid = xcd_panel_grid((unsigned)(H * sp.nsplit), tiles_c * tiles_c);
-    KernelTimer timer(TC_ROW_LOGITS, 2.0 * H * C * C * R * HEAD_DIM,
-                      4.0 * (2.0 * R * C * H * HEAD_DIM + (double)sp.nsplit * H * C * C), static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(row_logits_kernel, dim3(grid), dim3(GEMM_THREADS), ROWLOGITS_LDS_BYTES,
+    KernelTimer timer(TC_ROW_LOGITS, 2.0 * batch * H * C * C * R * HEAD_DIM,
+                      4.0 * batch * (2.0 * R * C * H * HEAD_DIM + (double)sp.nsplit * H * C * C), static_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(row_logits_kernel, dim3(grid, batch), dim3(GEMM_THREADS), ROWLOGITS_LDS_BYTES,
                        static_cast<hipStream_t>(stream), q, k, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split,
-                       ROW_LOGITS_F32_CHAIN_ROWS * (HEAD_DIM / BK));
+                       ROW_LOGITS_F32_CHAIN_ROWS * (HEAD_DIM / BK), qk_bstride, part_bstride);
     RNAMSM_CHECK_LAUNCH("row_logits");
     return RNAMSM_OK;
 }
 
 static int softmax_rows_launch(const float* partial, int nsplit, float* probs, int H, int C, const uint8_t* key_mask,
                                uint16_t* p_hi, uint16_t* p_lo, int64_t ldp, float plane_scale, int fmt, void* stream,
-                               int64_t mask_slab_stride = 0) {
+                               int64_t mask_slab_stride = 0, int batch = 1, int64_t part_bstride = 0, int64_t probs_bstride = 0) {
     RNAMSM_CHECK_ARG(partial && probs, "softmax_rows: null pointer");
     RNAMSM_CHECK_ARG(nsplit >= 1 && H > 0 && C > 0 && C <= 64 * SOFTMAX_MAX_PER_LANE,
                      "softmax_rows: bad shape nsplit=%d H=%d C=%d (C <= %d)", nsplit, H, C, 64 * SOFTMAX_MAX_PER_LANE);
@@ -395,14 +408,14 @@ static int softmax_rows_launch(const float* partial, int nsplit, float* probs, i
                      "softmax_rows: plane stride must be C rounded up to a multiple of 64, fmt 0 (bf16) or 1 (fp16)");
     const int64_t rows = (int64_t)H * C;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((rows + 3) / 4));
+    const dim3 grid((unsigned)((rows + 3) / 4), batch);
     KernelTimer timer(TC_SOFTMAX, 0.0, 4.0 * (double)(nsplit + 1) * H * C * C + (p_hi ? (p_lo ? 4.0 : 2.0) * rows * ldp : 0.0), s);
     if (!p_hi)
-        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride);
+        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride);
     else if (fmt == 0)
-        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride);
+        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride);
     else
-        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride);
+        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride);
     RNAMSM_CHECK_LAUNCH("softmax_rows");
     return RNAMSM_OK;
 }
@@ -427,9 +440,9 @@ extern "C" int rnamsm_softmax_rows_planes(const float* partial, int nsplit, floa
     return softmax_rows_launch(partial, nsplit, probs, H, C, key_mask, p_hi, p_lo, ldp, plane_scale, fmt, stream);
 }
 
-extern "C" int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,
-                                int H, int head_dim, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt, int dtype,
-                                void* stream) {
+static int row_apply_launch(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,
+                            int H, int head_dim, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt, int dtype,
+                            void* stream, int batch, int64_t probs_bstride, int64_t v_bstride, int64_t ctx_bstride) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "row_apply: only RNAMSM_F32 is implemented");
     RNAMSM_CHECK_ARG(probs && v && (ctx || ctx_hi), "row_apply: null pointer");
     RNAMSM_CHECK_ARG(head_dim == HEAD_DIM, "row_apply: head_dim must be 64 (got %d)", head_dim);
@@ -441,9 +454,10 @@ extern "C" int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned tiles_i = (C + BM - 1) / BM, tiles_n = (R + 1) / 2;
     const unsigned grid = xcd_panel_grid((unsigned)H * tiles_n, tiles_i);
+    RNAMSM_CHECK_ARG(batch == 1 || (!ctx_hi && probs_bstride % 4 == 0), "row_apply: a batched launch writes fp32 context from 16-byte aligned maps");
     const bool al = C % 4 == 0 && C >= 4 && aligned16(probs);
     const int out = ctx_hi ? 1 + plane_fmt : 0;
-    KernelTimer timer(TC_ROW_APPLY, 2.0 * H * C * C * R * HEAD_DIM, 4.0 * (2.0 * R * C * H * HEAD_DIM + (double)H * C * C), s);
+    KernelTimer timer(TC_ROW_APPLY, 2.0 * batch * H * C * C * R * HEAD_DIM, 4.0 * batch * (2.0 * R * C * H * HEAD_DIM + (double)H * C * C), s);
 #define RA_GO2(AL_, OUT_, VT_)                                                                                    \
     do {                                                                                                          \
         static DeviceOnce cfg_;                                                                                 \
@@ -453,8 +467,8 @@ extern "C" int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, 
             if (rc) return rc;                                                                                    \
             cfg_.mark();                                                                                          \
         }                                                                                                         \
-        hipLaunchKernelGGL((row_apply_kernel<AL_, OUT_, VT_>), dim3(grid), dim3(GEMM_THREADS), lds_, s, probs,    \
-                           v, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo);                                             \
+        hipLaunchKernelGGL((row_apply_kernel<AL_, OUT_, VT_>), dim3(grid, batch), dim3(GEMM_THREADS), lds_, s, probs, \
+                           v, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, probs_bstride, v_bstride, ctx_bstride);          \
     } while (0)
 #define RA_GO(AL_, OUT_)                                                                                          \
     do {                                                                                                          \
@@ -470,3 +484,27 @@ extern "C" int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, 
     RNAMSM_CHECK_LAUNCH("row_apply");
     return RNAMSM_OK;
 }
+
+extern "C" int rnamsm_row_apply(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,
+                                int H, int head_dim, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt, int dtype,
+                                void* stream) {
+    return row_apply_launch(probs, v, ld, ctx, ldc, R, C, H, head_dim, ctx_hi, ctx_lo, plane_fmt, dtype, stream, 1, 0, 0, 0);
+}
+
+// K4-K6 for `batch` same-shape MSAs in one launch each (rnamsm_forward_batch): MSA b's operands lie b * stride elements on
+namespace rnamsm {
+int row_logits_batched(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H, int batch,
+                       int64_t qk_bstride, int64_t part_bstride, void* stream) {
+    return row_logits_launch(q, k, ld, partial, R, C, H, HEAD_DIM, RNAMSM_F32, stream, 0, batch, qk_bstride, part_bstride);
+}
+int softmax_rows_batched(const float* partial, int nsplit, float* probs, int H, int C, int batch, int64_t part_bstride,
+                         int64_t probs_bstride, void* stream) {
+    return softmax_rows_launch(partial, nsplit, probs, H, C, nullptr, nullptr, nullptr, 0, 1.f, 0, stream, 0, batch, part_bstride,
+                               probs_bstride);
+}
+int row_apply_batched(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H, int batch,
+                      int64_t probs_bstride, int64_t v_bstride, int64_t ctx_bstride, void* stream) {
+    return row_apply_launch(probs, v, ld, ctx, ldc, R, C, H, HEAD_DIM, nullptr, nullptr, 0, RNAMSM_F32, stream, batch, probs_bstride,
+                            v_bstride, ctx_bstride);
+}
+}  // namespace rnamsm
