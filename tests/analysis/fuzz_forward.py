@@ -105,6 +105,17 @@ def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mod
                 mod = truth.errors(m_emb, m_atp, t_emb, t_atp)
                 mod_ok = mod["emb_rel_l2"] < emb_bar and mod["atp_max_abs"] < atp_bar
                 mod_note = f" modules: emb {mod['emb_rel_l2']:.2e} atp {mod['atp_max_abs']:.2e}"
+            # every fourth unpadded exact-path case also as the first of a batch of three same-shape MSAs (rnamsm_forward_batch)
+            if case % 4 == 1 and not padded and mode == "f32" and 3 * R * C <= 3 * max_tokens:
+                t3 = torch.stack([t] + [torch.from_numpy(synthetic.make_tokens(R, C, 5000 + 7 * case + j)).to("cuda:0") for j in (1, 2)])
+                bat = model.checked_forward_batch(t3)
+                bt = truth.errors(bat["emb"][0], bat["atp"][0], t_emb, t_atp)
+                mod_ok = mod_ok and bt["emb_rel_l2"] < emb_bar and bt["atp_max_abs"] < atp_bar
+                one2 = model.checked_forward_one(t3[2])
+                d_e = float((bat["emb"][2] - one2["emb"]).norm() / one2["emb"].norm())
+                d_a = float((bat["atp"][2] - one2["atp"]).abs().max())
+                mod_ok = mod_ok and d_e < 2e-5 and d_a < 1e-4
+                mod_note += f" batch of 3: emb {bt['emb_rel_l2']:.2e} atp {bt['atp_max_abs']:.2e}, MSA 2 vs alone {d_e:.1e} / {d_a:.1e}"
             ok = emb_err < emb_bar and atp_err < atp_bar and same and det and finite and mod_ok
             bad += not ok
             log(f"{'ok ' if ok else 'BAD'} case {case:3d} R={R:3d} C={C:3d} {mode:6s} padded={int(padded)} {knobs}  emb {emb_err:.2e} "
