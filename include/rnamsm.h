@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RNAMSM_VERSION 205 /* major*10000 + minor*100 + patch */
+#define RNAMSM_VERSION 206 /* major*10000 + minor*100 + patch */
 
 typedef enum {
     RNAMSM_OK = 0,
@@ -361,19 +361,21 @@ int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, c
                    const uint16_t* const* weight_planes, const float* const* ln_folded,
                    const void* const* ln_folded16, void* stream);
 
-/* B same-shape MSAs WITHOUT padding through one set of token-parallel launches -- MSATransformer.forward(tokens[B,R,C])
- * (model.py:338-416) for such a batch, exact path.  Why it exists: below ~4 k tokens a forward costs 5.5-6 ms whatever the
+/* B same-shape MSAs -- ragged ones padded to one shape with <pad> -- through one set of token-parallel launches:
+ * MSATransformer.forward(tokens[B,R,C]) (model.py:338-416), exact path.  Why it exists: below ~4 k tokens a forward costs 5.5-6 ms whatever the
  * alignment holds (each of its ~140 dependent launches lasts one block's serial time on a mostly idle chip); LayerNorm, the
  * Linear GEMMs and the final LayerNorm are per token and run ONCE over the B*R*C tokens of the batch, only the embedding
  * (row positions restart per MSA) and the attention kernels (they couple the tokens of one MSA) are launched per MSA.
  * tokens int64 [B,R,C]; row_attn [B,L,H,C,C]; repr [B,R*C,D]; emb [B,C-1,D]; atp [B,L*H,C-1,C-1]; err_flag as in
- * rnamsm_forward; ln_folded as in rnamsm_forward or NULL.  Every MSA's outputs equal rnamsm_forward's on that MSA alone up
+ * rnamsm_forward; has_padding != 0: the batch contains <pad> and the reference's direct-path mask semantics apply (as in
+ * rnamsm_forward; the chunked path's per-chunk fill is not offered here -- callers keep R*C <= max_tokens_per_msa or use
+ * rnamsm_forward per MSA); ln_folded as in rnamsm_forward or NULL (ignored with padding).  Every MSA's outputs equal rnamsm_forward's on that MSA alone up
  * to fp32 rounding (bit-identical when the two shape-dependent choices agree: fc2 split-K and the folded LayerNorm are
  * decided by the batch's token count).  B*R*C must fit 31 bits. */
 size_t rnamsm_forward_batch_workspace_bytes(const rnamsm_model_dims* dims, int B, int R, int C);
 int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens, int B, int R, int C,
                          void* workspace, size_t workspace_bytes, float* row_attn, float* repr, float* emb, float* atp,
-                         int* err_flag, const float* const* ln_folded, void* stream);
+                         int* err_flag, int has_padding, const float* const* ln_folded, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's
  * roofline block; adds two event records per launch while enabled, nothing when disabled).

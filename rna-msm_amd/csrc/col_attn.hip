@@ -38,10 +38,11 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask,
     uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows, int64_t qkv_bstride, int64_t ctx_bstride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    q += blockIdx.y * qkv_bstride;        // batched launch (rnamsm_forward_batch): MSA blockIdx.y, fp32 context, no mask
+    q += blockIdx.y * qkv_bstride;        // batched launch (rnamsm_forward_batch): MSA blockIdx.y, fp32 context
     k += blockIdx.y * qkv_bstride;
     v += blockIdx.y * qkv_bstride;
     if (OUT == 0) ctx += blockIdx.y * ctx_bstride;
+    if (MASKED) pad_mask += blockIdx.y * ((int64_t)R * C);         // its own [R, C] mask
     float* Ks = smem;                    // [2][CA_JC][CA_LDD]
     float* Vs = smem + 2 * CA_TILE;      // [2][CA_JC][CA_LDD]
 
@@ -265,10 +266,11 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask,
     uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows, int64_t qkv_bstride, int64_t ctx_bstride) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
-    q += blockIdx.y * qkv_bstride;        // batched launch (rnamsm_forward_batch): MSA blockIdx.y, fp32 context, no mask
+    q += blockIdx.y * qkv_bstride;        // batched launch (rnamsm_forward_batch): MSA blockIdx.y, fp32 context
     k += blockIdx.y * qkv_bstride;
     v += blockIdx.y * qkv_bstride;
     if (OUT == 0) ctx += blockIdx.y * ctx_bstride;
+    if (MASKED) pad_mask += blockIdx.y * ((int64_t)R * C);         // its own [R, C] mask
 
     const unsigned iblocks = (q_rows + CA_ROWS - 1) / CA_ROWS;       // query rows [0, q_rows) only (q_rows == R: all)
     unsigned prob, ib;
@@ -500,8 +502,8 @@ static int col_attn_launch(const float* q, const float* k, const float* v, int64
                            int H, int head_dim, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt,
                            int dtype, void* stream, int q_rows, int batch, int64_t qkv_bstride, int64_t ctx_bstride) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "col_attn: only RNAMSM_F32 is implemented");
-    RNAMSM_CHECK_ARG(batch == 1 || (!pad_mask && !ctx_hi && qkv_bstride % 4 == 0 && ctx_bstride % 4 == 0),
-                     "col_attn: a batched launch has no mask and writes fp32 context");
+    RNAMSM_CHECK_ARG(batch == 1 || (!ctx_hi && qkv_bstride % 4 == 0 && ctx_bstride % 4 == 0),
+                     "col_attn: a batched launch writes fp32 context");
     RNAMSM_CHECK_ARG(q && k && v && (ctx || ctx_hi), "col_attn: null pointer");
     RNAMSM_CHECK_ARG(head_dim == CA_HD, "col_attn: head_dim must be 64 (got %d)", head_dim);
     RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0, "col_attn: bad shape R=%d C=%d H=%d", R, C, H);
@@ -547,10 +549,11 @@ static int col_attn_launch(const float* q, const float* k, const float* v, int64
 }
 
 namespace rnamsm {
-// K7 for `batch` same-shape MSAs in one launch (rnamsm_forward_batch): MSA b's q / k / v lie b * qkv_bstride elements on
+// K7 for `batch` same-shape MSAs in one launch (rnamsm_forward_batch): MSA b's q / k / v lie b * qkv_bstride elements on,
+// its padding mask (if any) b * R * C bytes on
 int col_attn_batched(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
-                     int batch, int64_t qkv_bstride, int64_t ctx_bstride, void* stream) {
-    return col_attn_launch(q, k, v, ld, ctx, ldc, R, C, H, CA_HD, nullptr, nullptr, nullptr, 0, RNAMSM_F32, stream, R, batch,
+                     int batch, int64_t qkv_bstride, int64_t ctx_bstride, const uint8_t* pad_mask, void* stream) {
+    return col_attn_launch(q, k, v, ld, ctx, ldc, R, C, H, CA_HD, pad_mask, nullptr, nullptr, 0, RNAMSM_F32, stream, R, batch,
                            qkv_bstride, ctx_bstride);
 }
 }  // namespace rnamsm

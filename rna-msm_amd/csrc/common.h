@@ -238,10 +238,10 @@ int gemm_f32_splitk(const float* A, int64_t lda, const float* W, const float* bi
 int row_logits_batched(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H, int batch,
                        int64_t qk_bstride, int64_t part_bstride, void* stream);
 int softmax_rows_batched(const float* partial, int nsplit, float* probs, int H, int C, int batch, int64_t part_bstride,
-                         int64_t probs_bstride, void* stream);
+                         int64_t probs_bstride, const uint8_t* key_mask, int64_t mask_bstride, void* stream);
 int row_apply_batched(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H, int batch,
                       int64_t probs_bstride, int64_t v_bstride, int64_t ctx_bstride, void* stream);
 int col_attn_batched(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
-                     int batch, int64_t qkv_bstride, int64_t ctx_bstride, void* stream);
+                     int batch, int64_t qkv_bstride, int64_t ctx_bstride, const uint8_t* pad_mask, void* stream);
 
 }  // namespace rnamsm

@@ -350,7 +350,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     return RNAMSM_OK;
 }
 
-// ---- B same-shape, unpadded MSAs through one set of token-parallel launches (exact path).
+// ---- B same-shape MSAs (ragged ones padded to one shape with <pad>) through one set of token-parallel launches (exact path).
 // Why: below ~4 k tokens a forward costs 5.5-6 ms whatever the alignment holds -- each of its ~140 dependent launches lasts a
 // block's serial time while most CUs idle.  LayerNorm, the six Linear GEMMs of a layer and the final LayerNorm
 // are per token: for a batch [B, R, C] they run ONCE over the B*R*C tokens (MSA-major, which is also the layout of the
@@ -361,7 +361,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
 // of fc2 and the folded LayerNorm are decided by the batch's token count).
 namespace {
 struct BatchLayout {
-    size_t x, xn, wide, part, rowsum, stats, splitk, total;
+    size_t x, xn, wide, part, rowsum, stats, splitk, mask, total;
 };
 BatchLayout make_batch_layout(const rnamsm_model_dims& d, int B, int R, int C) {
     const size_t T = (size_t)B * R * C, D = d.embed_dim;
@@ -375,6 +375,7 @@ BatchLayout make_batch_layout(const rnamsm_model_dims& d, int B, int R, int C) {
     l.stats = off;  off += align256(T * 2 * sizeof(float));
     const size_t kt = (size_t)rnamsm::gemm_f32_splitk_factor((int64_t)T, (int)D, d.ffn_dim, true);
     l.splitk = off; off += align256((kt > 1 ? kt * T : 0) * D * sizeof(float));
+    l.mask = off;   off += align256(T);              // padding mask uint8 [B, R, C]
     l.total = off;
     return l;
 }
@@ -387,7 +388,8 @@ extern "C" size_t rnamsm_forward_batch_workspace_bytes(const rnamsm_model_dims* 
 
 extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens, int B,
                                     int R, int C, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
-                                    float* emb, float* atp, int* err_flag, const float* const* ln_folded, void* stream) {
+                                    float* emb, float* atp, int* err_flag, int has_padding, const float* const* ln_folded,
+                                    void* stream) {
     RNAMSM_CHECK_ARG(dims && weights && tokens && workspace && row_attn && repr && emb && atp, "forward_batch: null pointer");
     const rnamsm_model_dims& d = *dims;
     const int D = d.embed_dim, H = d.num_heads, F = d.ffn_dim, NL = d.num_layers;
@@ -420,7 +422,15 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
     const int f32 = RNAMSM_F32;
     const int nsplit = rnamsm_row_logits_nsplit(R, C, H);
     const int fold_mode = tuning().ln_fold;
-    const bool fold = ln_folded && (fold_mode == 3 || (fold_mode == 1 && T >= 18432));     // statistics from the producers only
+    const bool fold = ln_folded && !has_padding && (fold_mode == 3 || (fold_mode == 1 && T >= 18432));   // statistics from the producers only
+    // f2: the batch contains <pad> (ragged MSAs padded to one shape): the reference's direct-path mask semantics as in
+    // rnamsm_forward -- zeroed embeddings (K0) and q (QKV epilogue) at padded tokens, -10000 on keys whose first-row token is
+    // <pad> (tied rows) and on padded keys (columns); every MSA reads its own [R, C] slice of the mask
+    uint8_t* mask = nullptr;
+    if (has_padding) {
+        mask = reinterpret_cast<uint8_t*>(ws + lay.mask);
+        FWD(rnamsm_pad_mask(tokens, mask, T, d.pad_idx, stream));
+    }
     const float row_scale = (1.0f / sqrtf(64.0f)) / sqrtf((float)R), col_scale = 1.0f / sqrtf(64.0f);
 
     auto norm = [&](const float* g, const float* b) -> int {
@@ -457,19 +467,23 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
         const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
         // ---- tied row attention: projections over the batch, K4-K6 per MSA
         FWD(norm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
-        FWD(lin_normed(l, 0, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, row_scale, D));
+        if (mask)     // q *= 1 - padding_mask (modules.py:767-772) in the epilogue
+            FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, T, 3 * D, D,
+                                         RNAMSM_ACT_NONE, row_scale, D, mask, f32, stream));
+        else
+            FWD(lin_normed(l, 0, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, row_scale, D));
         {   // K4-K6 of all B MSAs in one launch each (gridDim.y = B); the maps land in row_attn [B, NL, H, C, C]
             const int64_t part_bs = (int64_t)nsplit * H * C * C, probs_bs = (int64_t)NL * H * C * C;
             float* probs = row_attn + (int64_t)l * H * C * C;
             FWD(rnamsm::row_logits_batched(qkv, qkv + D, ldq, part, R, C, H, B, Tm * ldq, part_bs, stream));
-            FWD(rnamsm::softmax_rows_batched(part, nsplit, probs, H, C, B, part_bs, probs_bs, stream));
+            FWD(rnamsm::softmax_rows_batched(part, nsplit, probs, H, C, B, part_bs, probs_bs, mask, Tm, stream));
             FWD(rnamsm::row_apply_batched(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, B, probs_bs, Tm * ldq, Tm * D, stream));
         }
         FWD(res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], D));
         // ---- column attention
         FWD(norm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
         FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, col_scale, D));
-        FWD(rnamsm::col_attn_batched(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, B, Tm * ldq, Tm * D, stream));
+        FWD(rnamsm::col_attn_batched(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, B, Tm * ldq, Tm * D, mask, stream));
         FWD(res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], D));
         // ---- feed-forward
         FWD(norm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));

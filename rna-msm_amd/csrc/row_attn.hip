@@ -127,11 +127,12 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
                                                            const uint8_t* __restrict__ key_mask,
                                                            uint16_t* __restrict__ p_hi, uint16_t* __restrict__ p_lo,
                                                            int64_t ldp, float plane_scale, int64_t mask_slab_stride,
-                                                           int64_t part_bstride, int64_t probs_bstride) {
+                                                           int64_t part_bstride, int64_t probs_bstride, int64_t mask_bstride) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     partial += blockIdx.y * part_bstride;        // batched launch: MSA blockIdx.y (fp32 probabilities only)
     probs += blockIdx.y * probs_bstride;
+    if (key_mask) key_mask += blockIdx.y * mask_bstride;
     const int lane = threadIdx.x & 63;
     const int64_t slab = rows * C;
     float v[SOFTMAX_MAX_PER_LANE];
@@ -400,7 +401,8 @@ static int row_logits_launch(const float* q, const float* k, int64_t ld, float* 
 
 static int softmax_rows_launch(const float* partial, int nsplit, float* probs, int H, int C, const uint8_t* key_mask,
                                uint16_t* p_hi, uint16_t* p_lo, int64_t ldp, float plane_scale, int fmt, void* stream,
-                               int64_t mask_slab_stride = 0, int batch = 1, int64_t part_bstride = 0, int64_t probs_bstride = 0) {
+                               int64_t mask_slab_stride = 0, int batch = 1, int64_t part_bstride = 0, int64_t probs_bstride = 0,
+                               int64_t mask_bstride = 0) {
     RNAMSM_CHECK_ARG(partial && probs, "softmax_rows: null pointer");
     RNAMSM_CHECK_ARG(nsplit >= 1 && H > 0 && C > 0 && C <= 64 * SOFTMAX_MAX_PER_LANE,
                      "softmax_rows: bad shape nsplit=%d H=%d C=%d (C <= %d)", nsplit, H, C, 64 * SOFTMAX_MAX_PER_LANE);
@@ -411,11 +413,11 @@ static int softmax_rows_launch(const float* partial, int nsplit, float* probs, i
     const dim3 grid((unsigned)((rows + 3) / 4), batch);
     KernelTimer timer(TC_SOFTMAX, 0.0, 4.0 * (double)(nsplit + 1) * H * C * C + (p_hi ? (p_lo ? 4.0 : 2.0) * rows * ldp : 0.0), s);
     if (!p_hi)
-        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride);
+        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride);
     else if (fmt == 0)
-        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride);
+        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride);
     else
-        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride);
+        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride);
     RNAMSM_CHECK_LAUNCH("softmax_rows");
     return RNAMSM_OK;
 }
@@ -498,9 +500,9 @@ int row_logits_batched(const float* q, const float* k, int64_t ld, float* partia
     return row_logits_launch(q, k, ld, partial, R, C, H, HEAD_DIM, RNAMSM_F32, stream, 0, batch, qk_bstride, part_bstride);
 }
 int softmax_rows_batched(const float* partial, int nsplit, float* probs, int H, int C, int batch, int64_t part_bstride,
-                         int64_t probs_bstride, void* stream) {
-    return softmax_rows_launch(partial, nsplit, probs, H, C, nullptr, nullptr, nullptr, 0, 1.f, 0, stream, 0, batch, part_bstride,
-                               probs_bstride);
+                         int64_t probs_bstride, const uint8_t* key_mask, int64_t mask_bstride, void* stream) {
+    return softmax_rows_launch(partial, nsplit, probs, H, C, key_mask, nullptr, nullptr, 0, 1.f, 0, stream, 0, batch, part_bstride,
+                               probs_bstride, mask_bstride);
 }
 int row_apply_batched(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H, int batch,
                       int64_t probs_bstride, int64_t v_bstride, int64_t ctx_bstride, void* stream) {

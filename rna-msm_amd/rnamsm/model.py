@@ -281,9 +281,11 @@ class MSATransformer(nn.Module):
             return self._forward_one_on_device(tokens2d, has_padding, need_repr,
                                                self.fold_layernorm if fold_layernorm is None else fold_layernorm)
 
-    def forward_batch(self, tokens3d: torch.Tensor, fold_layernorm: Optional[bool] = None) -> Dict[str, torch.Tensor]:
-        """B same-shape MSAs without <pad> through rnamsm_forward_batch (exact path): tokens [B,R,C] -> row_attn
-        [B,NL,H,C,C], repr [B,R,C,D], emb [B,C-1,D], atp [B,NL*H,C-1,C-1], err int32[1] (bits as in forward_one)."""
+    def forward_batch(self, tokens3d: torch.Tensor, has_padding: Optional[bool] = None,
+                      fold_layernorm: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+        """B same-shape MSAs (ragged ones padded with <pad>; direct-path mask semantics) through rnamsm_forward_batch (exact
+        path): tokens [B,R,C] -> row_attn [B,NL,H,C,C], repr [B,R,C,D], emb [B,C-1,D], atp [B,NL*H,C-1,C-1], err int32[1]
+        (bits as in forward_one).  has_padding: None = look at the tokens."""
         if self.training:
             raise NotImplementedError("inference only (model.eval())")
         if not tokens3d.is_cuda:
@@ -297,6 +299,8 @@ class MSATransformer(nn.Module):
             dev = tokens3d.device
             NL, H, D = self.num_layers, self.num_attention_heads, self.embed_dim
             toks = tokens3d.to(torch.int64).contiguous()
+            if has_padding is None:
+                has_padding = bool((toks == self.vocab.pad_idx).any())
             ws_bytes = lib.rnamsm_forward_batch_workspace_bytes(ctypes.byref(dims), B, R, C)
             ws = self._get_workspace(ws_bytes, dev)
             row_attn = torch.empty(B, NL, H, C, C, device=dev, dtype=torch.float32)
@@ -304,22 +308,22 @@ class MSATransformer(nn.Module):
             emb = torch.empty(B, C - 1, D, device=dev, dtype=torch.float32)
             atp = torch.empty(B, NL * H, C - 1, C - 1, device=dev, dtype=torch.float32)
             err = torch.zeros(1, device=dev, dtype=torch.int32)
-            folded = self._folded_weights() if fold else None
+            folded = self._folded_weights() if (fold and not has_padding) else None
             _lib.check(lib.rnamsm_forward_batch(ctypes.byref(dims), ptrs, toks.data_ptr(), B, R, C, ws.data_ptr(), ws.numel(),
                                                 row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
-                                                err.data_ptr(), folded, torch.cuda.current_stream().cuda_stream))
+                                                err.data_ptr(), int(has_padding), folded, torch.cuda.current_stream().cuda_stream))
         return {"row_attn": row_attn, "repr": rep, "emb": emb, "atp": atp, "err": err}
 
-    def checked_forward_batch(self, tokens3d: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def checked_forward_batch(self, tokens3d: torch.Tensor, has_padding: Optional[bool] = None) -> Dict[str, torch.Tensor]:
         """forward_batch + the error word (see checked_forward_one)."""
-        out = self.forward_batch(tokens3d)
+        out = self.forward_batch(tokens3d, has_padding)
         err = int(out["err"].item())
         if err & self.ERR_INDEX:
             raise IndexError("batch: token or position index out of range")
         if err & self.ERR_FOLD:
             import warnings
             warnings.warn("batch: a token row's mean exceeds 32x its spread; LayerNorm is applied in its own launches for this batch")
-            out = self.forward_batch(tokens3d, fold_layernorm=False)
+            out = self.forward_batch(tokens3d, has_padding, fold_layernorm=False)
         return out
 
     ERR_INDEX, ERR_FOLD = 1, 2            # bits of forward_one's "err": token / position index out of range; a row whose
@@ -431,12 +435,15 @@ class MSATransformer(nn.Module):
         atts: List[torch.Tensor] = []
         fast = repr_set <= {self.num_layers}
         done = 0
-        if fast and B > 1 and not has_padding and self.gemm_dtype == "f32" and self.batch_small_msas and not self.training:
-            # same-shape, unpadded MSAs of a few thousand tokens: their token-parallel launches are shared (rnamsm_forward_batch)
+        chunked = has_padding and _lib.load().rnamsm_row_chunks(R, C, min(int(self.max_tokens_per_msa), 2 ** 31 - 1)) > 0
+        if fast and B > 1 and not chunked and self.gemm_dtype == "f32" and self.batch_small_msas and not self.training:
+            # MSAs of a few thousand tokens, same shape or padded to it: their token-parallel launches are shared
+            # (rnamsm_forward_batch); a padded batch above the reference's token budget keeps its per-chunk mask semantics
+            # (rnamsm_forward per MSA)
             per = max(1, self.batch_token_budget // (R * C))
             while per > 1 and B - done > 1:
                 n = min(per, B - done)
-                out = self.checked_forward_batch(tokens[done:done + n])
+                out = self.checked_forward_batch(tokens[done:done + n], has_padding)
                 if self.num_layers in repr_set:
                     reps[self.num_layers].append(out["repr"])
                 atts.append(out["row_attn"])

@@ -670,3 +670,45 @@ def test_batched_forward_reports_bad_tokens_and_splits_large_batches(model):
     bad[5, 2, 3] = 999
     with pytest.raises(IndexError):
         m.checked_forward_batch(bad)
+
+
+def test_padded_ragged_batch_through_the_batched_driver(model):
+    """f2 + batching: ragged MSAs padded to one shape share their launches (rnamsm_forward_batch with has_padding): the
+    reference's padded B = 2 fixture through that route, and random ragged batches against the same MSAs run one by one with
+    the same masks (bit-identical: same kernels, same per-element arithmetic)."""
+    from rnamsm import ops
+    m, _ = model
+    g = golden("forward_padded_b2.npz")
+    toks = torch.from_numpy(g["tokens"]).to("cuda:0")
+    out = m.checked_forward_batch(toks)
+    for b in range(2):
+        assert rel_l2(out["repr"][b].cpu().numpy(), g["rep10"][b]) < 1e-4
+        assert np.abs(out["row_attn"][b].cpu().numpy() - g["row_attentions"][b]).max() < 1e-4
+    res = m(toks, repr_layers=[10], need_head_weights=True)                    # MSATransformer.forward takes that route
+    assert torch.equal(res["representations"][10], out["repr"]) and torch.equal(res["row_attentions"], out["row_attn"])
+    rng = np.random.default_rng(5)
+    for B, R, C in ((3, 9, 21), (4, 33, 17), (2, 2, 130)):
+        t = np.stack([synthetic.make_tokens(R, C, 40 + b) for b in range(B)])
+        for b in range(B):                                                     # ragged: fewer rows / columns per element
+            r, c = int(rng.integers(1, R + 1)), int(rng.integers(2, C + 1))
+            t[b, r:, :] = 1
+            t[b, :, c:] = 1
+        t[0, 0, C // 2] = 1                                                    # a pad inside a first row: that key is masked
+        tt = torch.from_numpy(t).to("cuda:0")
+        try:
+            ops.set_param("gemm_splitk", 0)                                    # one shape-dependent choice: decided per launch
+            bat = m.checked_forward_batch(tt)
+            for b in range(B):
+                one = m.checked_forward_one(tt[b], has_padding=True)
+                assert torch.equal(bat["emb"][b], one["emb"]) and torch.equal(bat["atp"][b], one["atp"]), (B, R, C, b)
+                assert torch.equal(bat["repr"][b].reshape(R * C, -1), one["repr"].reshape(R * C, -1))
+        finally:
+            ops.set_param("gemm_splitk", 1)
+    # above the reference's token budget a padded batch keeps the per-chunk mask semantics: MSA by MSA
+    keep = m.max_tokens_per_msa
+    try:
+        m.max_tokens_per_msa_(64)
+        chunked = m(toks, repr_layers=[10], need_head_weights=True)
+    finally:
+        m.max_tokens_per_msa_(keep)
+    assert not torch.equal(chunked["row_attentions"], out["row_attn"])
