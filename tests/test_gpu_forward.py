@@ -642,6 +642,14 @@ def test_batched_forward_of_same_shape_msas_equals_the_msas_one_by_one(model, B,
         emb, atp = O.pack_outputs(O.forward(toks[b].cpu(), params))
         assert rel_l2(batch["emb"][b].cpu().numpy(), np.asarray(emb)) < 1e-4
         assert np.abs(batch["atp"][b].cpu().numpy() - np.asarray(atp)).max() < 1e-4
+    try:                                                       # LayerNorm folded into the batch's GEMMs (default from 18432 tokens)
+        ops.set_param("ln_fold", 3)
+        folded = m.checked_forward_batch(toks)
+    finally:
+        ops.set_param("ln_fold", 1)
+    assert not torch.equal(folded["emb"], batch["emb"])
+    assert rel_l2(folded["emb"].cpu().numpy(), batch["emb"].cpu().numpy()) < 1e-5
+    assert np.abs(folded["atp"].cpu().numpy() - batch["atp"].cpu().numpy()).max() < 5e-5
     # MSATransformer.forward takes that route for B > 1 ...
     res = m(toks, repr_layers=[10], need_head_weights=True, return_contacts=True)
     assert torch.equal(res["representations"][10], batch["repr"]) and torch.equal(res["row_attentions"], batch["row_attn"])
