@@ -376,7 +376,7 @@ def run_rank(args) -> int:
                             if sharding.owner_of(pos, world) == rank))
 
     # ---- extra modes (N = 1, default workload): every contraction on the 16-bit matrix cores
-    fast = bf16_mode = outputs_only = None
+    fast = bf16_mode = outputs_only = small_batches = None
     first = toks[mine_all[0]]
     if args.gemm_dtype == "f32" and not args.no_fast_mode and world == 1 and not batch:
         ref = model.forward_one(first)
@@ -440,6 +440,29 @@ def run_rank(args) -> int:
                         "what": "rnamsm_forward without RNAMSM_OUT_REPR (the CLI's call): after the last tied row attention only "
                                 "alignment row 0 feeds emb, so the last column attention's queries/out_proj, the last FFN and the "
                                 "final LayerNorm run on row 0's tokens only; K/V of that attention still cover every row"}
+        # small alignments leave the chip idle one at a time (a forward costs >= 5.5 ms however few tokens): B same-shape MSAs
+        # through rnamsm_forward_batch share every token-parallel launch (attention kernels batched over gridDim.y)
+        import numpy as _np
+        small_batches = {"what": "B same-shape MSAs one by one (rnamsm_forward each) vs one rnamsm_forward_batch call: ms per MSA "
+                                 "and MSA-residues/s, exact path; outputs agree to fp32 rounding (tests/test_gpu_forward.py)", "cases": []}
+        for sm, sl, sb in ((8, 64, 32), (16, 128, 16), (32, 128, 8)):
+            st = torch.from_numpy(_np.stack([synthetic.make_tokens(sm, sl, 900 + b) for b in range(sb)])).to(dev)
+            for _ in range(2):
+                model.forward_batch(st, has_padding=False)
+                model.forward_one(st[0], has_padding=False)
+            best = {"one": 1e9, "batch": 1e9}
+            for _ in range(3):
+                sync_all(); t4 = time.perf_counter()
+                for b in range(sb):
+                    model.forward_one(st[b], has_padding=False)
+                sync_all(); best["one"] = min(best["one"], (time.perf_counter() - t4) / sb)
+                sync_all(); t4 = time.perf_counter()
+                model.forward_batch(st, has_padding=False)
+                sync_all(); best["batch"] = min(best["batch"], (time.perf_counter() - t4) / sb)
+            small_batches["cases"].append({"num_seqs": sm, "seq_len": sl, "msas_per_batch": sb,
+                                           "ms_per_msa_one_by_one": 1e3 * best["one"], "ms_per_msa_batched": 1e3 * best["batch"],
+                                           "residues_per_s_one_by_one": sm * sl / best["one"],
+                                           "residues_per_s_batched": sm * sl / best["batch"]})
         fast = measure_mode("f16x3", 3.0)
         fast["f32_path_reordering_noise"] = {"emb_rel_l2": noise_emb, "atp_max_abs": noise_atp,
                                              "what": "exact path vs itself with alignment rows 1.. permuted"}
@@ -536,6 +559,7 @@ def run_rank(args) -> int:
             result["config"]["workload"] += " -- OUTPUTS-ONLY forward (--outputs-only): the last layer computes alignment row 0 only"
         if fast is not None:
             result["outputs_only_mode"] = outputs_only
+            result["small_msa_batches"] = small_batches
             result["fast_mode"] = fast
             result["bf16_mode"] = bf16_mode
         if not args.no_cpu_baseline and world == 1:
