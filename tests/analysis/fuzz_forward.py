@@ -116,6 +116,20 @@ def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mod
                 d_a = float((bat["atp"][2] - one2["atp"]).abs().max())
                 mod_ok = mod_ok and d_e < 2e-5 and d_a < 1e-4
                 mod_note += f" batch of 3: emb {bt['emb_rel_l2']:.2e} atp {bt['atp_max_abs']:.2e}, MSA 2 vs alone {d_e:.1e} / {d_a:.1e}"
+            # padded exact-path cases also as the first of a padded batch of two (rnamsm_forward_batch, has_padding)
+            if padded and mode == "f32" and R * C <= 16384:
+                other = synthetic.make_tokens(R, C, 7000 + case).copy()
+                other[int(rng.integers(1, R)):, :] = 1                       # a shallower alignment in the same frame
+                other[:, int(rng.integers(2, C)):] = 1
+                t2 = torch.stack([t, torch.from_numpy(other).to("cuda:0")])
+                bat = model.checked_forward_batch(t2)
+                d_e = float((bat["emb"][0] - out["emb"]).norm() / out["emb"].norm())
+                d_a = float((bat["atp"][0] - out["atp"]).abs().max())
+                one1 = model.checked_forward_one(t2[1])
+                d_e1 = float((bat["emb"][1] - one1["emb"]).norm() / one1["emb"].norm().clamp_min(1e-30))
+                d_a1 = float((bat["atp"][1] - one1["atp"]).abs().max())
+                mod_ok = mod_ok and max(d_e, d_e1) < 2e-5 and max(d_a, d_a1) < 1e-4
+                mod_note += f" padded batch of 2 vs alone: {d_e:.1e} / {d_a:.1e}, {d_e1:.1e} / {d_a1:.1e}"
             ok = emb_err < emb_bar and atp_err < atp_bar and same and det and finite and mod_ok
             bad += not ok
             log(f"{'ok ' if ok else 'BAD'} case {case:3d} R={R:3d} C={C:3d} {mode:6s} padded={int(padded)} {knobs}  emb {emb_err:.2e} "
