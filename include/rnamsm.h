@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RNAMSM_VERSION 206 /* major*10000 + minor*100 + patch */
+#define RNAMSM_VERSION 207 /* major*10000 + minor*100 + patch */
 
 typedef enum {
     RNAMSM_OK = 0,
@@ -369,13 +369,19 @@ int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, c
  * tokens int64 [B,R,C]; row_attn [B,L,H,C,C]; repr [B,R*C,D]; emb [B,C-1,D]; atp [B,L*H,C-1,C-1]; err_flag as in
  * rnamsm_forward; has_padding != 0: the batch contains <pad> and the reference's direct-path mask semantics apply (as in
  * rnamsm_forward; the chunked path's per-chunk fill is not offered here -- callers keep R*C <= max_tokens_per_msa or use
- * rnamsm_forward per MSA); ln_folded as in rnamsm_forward or NULL (ignored with padding).  Every MSA's outputs equal rnamsm_forward's on that MSA alone up
+ * rnamsm_forward per MSA); ln_folded as in rnamsm_forward or NULL (ignored with padding).
+ * true_rows (device int32 [B], or NULL = the reference's batch semantics): RAGGED batches -- alignments of different shapes
+ * padded into one [R, C] frame (rows and columns appended) that must come out as each would ALONE.  A padded element already
+ * equals its unpadded forward in everything (masked keys get probability exactly 0, padded queries are zeroed, padded values
+ * never reach a real token) except one number: the reference scales the tied logits by 1/sqrt(R) of the PADDED depth
+ * (align_scaling, modules.py:713-715).  With true_rows[b] = the real depth of MSA b that factor is applied per MSA, and
+ * emb[b, :C_b-1], atp[b, :, :C_b-1, :C_b-1] equal rnamsm_forward's outputs on the unpadded MSA b to fp32 rounding.  Every MSA's outputs equal rnamsm_forward's on that MSA alone up
  * to fp32 rounding (bit-identical when the two shape-dependent choices agree: fc2 split-K and the folded LayerNorm are
  * decided by the batch's token count).  B*R*C must fit 31 bits. */
 size_t rnamsm_forward_batch_workspace_bytes(const rnamsm_model_dims* dims, int B, int R, int C);
 int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens, int B, int R, int C,
                          void* workspace, size_t workspace_bytes, float* row_attn, float* repr, float* emb, float* atp,
-                         int* err_flag, int has_padding, const float* const* ln_folded, void* stream);
+                         int* err_flag, int has_padding, const int* true_rows, const float* const* ln_folded, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's
  * roofline block; adds two event records per launch while enabled, nothing when disabled).

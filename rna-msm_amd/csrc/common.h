@@ -244,4 +244,10 @@ int row_apply_batched(const float* probs, const float* v, int64_t ld, float* ctx
 int col_attn_batched(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
                      int batch, int64_t qkv_bstride, int64_t ctx_bstride, const uint8_t* pad_mask, void* stream);
 
+// ragged batches (elementwise.hip): per-token q scale (0 at <pad>, 1/sqrt(true depth of the token's MSA) elsewhere) and its
+// application to the q columns of a QKV activation
+int ragged_row_scale(const int64_t* tokens, int pad_idx, const int* true_rows, float* out, int64_t n, int64_t tokens_per_msa,
+                     hipStream_t stream);
+int scale_rows(float* x, int64_t ld, const float* row_scale, int64_t T, int ncols, hipStream_t stream);
+
 }  // namespace rnamsm

@@ -318,6 +318,46 @@ extern "C" int rnamsm_embed_ln(const int64_t* tokens, const float* embed_tokens,
     return RNAMSM_OK;
 }
 
+namespace rnamsm {
+// Ragged batches (rnamsm_forward_batch with true_rows): the q scale of the tied row attention per token --
+// 0 at <pad> (q *= 1 - padding_mask, modules.py:767-772), 1/sqrt(R_b) elsewhere, R_b = the TRUE depth of the token's MSA
+// (align_scaling, modules.py:713-715, as the MSA alone would get it; the reference itself would use the padded depth).
+__global__ __launch_bounds__(256) void ragged_row_scale_kernel(const int64_t* __restrict__ tokens, int pad_idx,
+                                                               const int* __restrict__ true_rows, float* __restrict__ out,
+                                                               int64_t n, int64_t tokens_per_msa) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int r = true_rows[t / tokens_per_msa];
+    out[t] = tokens[t] == pad_idx ? 0.f : 1.0f / sqrtf((float)(r > 0 ? r : 1));
+}
+// x[t, 0 .. ncols) *= row_scale[t]   (the q third of a QKV activation, row stride ld); one wave per row
+__global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ x, int64_t ld, const float* __restrict__ row_scale,
+                                                         int64_t T, int ncols) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    const float s = row_scale[row];
+    float* p = x + row * ld;
+    for (int c = (threadIdx.x & 63) * 4; c < ncols; c += 256) {
+        f32x4 v = *reinterpret_cast<f32x4*>(p + c);
+        v *= s;
+        *reinterpret_cast<f32x4*>(p + c) = v;
+    }
+}
+int ragged_row_scale(const int64_t* tokens, int pad_idx, const int* true_rows, float* out, int64_t n, int64_t tokens_per_msa,
+                     hipStream_t stream) {
+    hipLaunchKernelGGL(ragged_row_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tokens, pad_idx, true_rows,
+                       out, n, tokens_per_msa);
+    RNAMSM_CHECK_LAUNCH("ragged_row_scale");
+    return RNAMSM_OK;
+}
+int scale_rows(float* x, int64_t ld, const float* row_scale, int64_t T, int ncols, hipStream_t stream) {
+    RNAMSM_CHECK_ARG(x && row_scale && T > 0 && ncols > 0 && ncols % 4 == 0 && ld % 4 == 0 && aligned16(x), "scale_rows: bad arguments");
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, stream, x, ld, row_scale, T, ncols);
+    RNAMSM_CHECK_LAUNCH("scale_rows");
+    return RNAMSM_OK;
+}
+}  // namespace rnamsm
+
 extern "C" int rnamsm_pad_mask(const int64_t* tokens, uint8_t* mask, int64_t n, int pad_idx, void* stream) {
     RNAMSM_CHECK_ARG(tokens && mask && n > 0, "pad_mask: bad arguments");
     hipLaunchKernelGGL(pad_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),

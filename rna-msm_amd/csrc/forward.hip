@@ -361,7 +361,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
 // of fc2 and the folded LayerNorm are decided by the batch's token count).
 namespace {
 struct BatchLayout {
-    size_t x, xn, wide, part, rowsum, stats, splitk, mask, total;
+    size_t x, xn, wide, part, rowsum, stats, splitk, mask, qscale, total;
 };
 BatchLayout make_batch_layout(const rnamsm_model_dims& d, int B, int R, int C) {
     const size_t T = (size_t)B * R * C, D = d.embed_dim;
@@ -376,6 +376,7 @@ BatchLayout make_batch_layout(const rnamsm_model_dims& d, int B, int R, int C) {
     const size_t kt = (size_t)rnamsm::gemm_f32_splitk_factor((int64_t)T, (int)D, d.ffn_dim, true);
     l.splitk = off; off += align256((kt > 1 ? kt * T : 0) * D * sizeof(float));
     l.mask = off;   off += align256(T);              // padding mask uint8 [B, R, C]
+    l.qscale = off; off += align256(T * sizeof(float));   // ragged batches: per-token q scale
     l.total = off;
     return l;
 }
@@ -388,8 +389,8 @@ extern "C" size_t rnamsm_forward_batch_workspace_bytes(const rnamsm_model_dims* 
 
 extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens, int B,
                                     int R, int C, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
-                                    float* emb, float* atp, int* err_flag, int has_padding, const float* const* ln_folded,
-                                    void* stream) {
+                                    float* emb, float* atp, int* err_flag, int has_padding, const int* true_rows,
+                                    const float* const* ln_folded, void* stream) {
     RNAMSM_CHECK_ARG(dims && weights && tokens && workspace && row_attn && repr && emb && atp, "forward_batch: null pointer");
     const rnamsm_model_dims& d = *dims;
     const int D = d.embed_dim, H = d.num_heads, F = d.ffn_dim, NL = d.num_layers;
@@ -431,7 +432,12 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
         mask = reinterpret_cast<uint8_t*>(ws + lay.mask);
         FWD(rnamsm_pad_mask(tokens, mask, T, d.pad_idx, stream));
     }
-    const float row_scale = (1.0f / sqrtf(64.0f)) / sqrtf((float)R), col_scale = 1.0f / sqrtf(64.0f);
+    // true_rows (device int32 [B], ragged batches): every MSA's tied logits are scaled by ITS depth, so that a padded element
+    // comes out as its unpadded forward would (see ragged_row_scale); the q scaling then happens per token after the GEMM
+    const float col_scale = 1.0f / sqrtf(64.0f);
+    const float row_scale = true_rows ? col_scale : col_scale / sqrtf((float)R);
+    float* qscale = reinterpret_cast<float*>(ws + lay.qscale);
+    if (true_rows) FWD(rnamsm::ragged_row_scale(tokens, d.pad_idx, true_rows, qscale, T, Tm, hs));
 
     auto norm = [&](const float* g, const float* b) -> int {
         return fold ? RNAMSM_OK : rnamsm_layernorm(x, g, b, xn, T, D, d.ln_eps, stream);
@@ -467,7 +473,10 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
         const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
         // ---- tied row attention: projections over the batch, K4-K6 per MSA
         FWD(norm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
-        if (mask)     // q *= 1 - padding_mask (modules.py:767-772) in the epilogue
+        if (true_rows) {       // q = (x Wq^T + bq) dh^-1/2, then per token: 0 at <pad>, 1/sqrt(true depth) elsewhere
+            FWD(lin_normed(l, 0, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, row_scale, D));
+            FWD(rnamsm::scale_rows(qkv, ldq, qscale, T, D, hs));
+        } else if (mask)     // q *= 1 - padding_mask (modules.py:767-772) in the epilogue
             FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, T, 3 * D, D,
                                          RNAMSM_ACT_NONE, row_scale, D, mask, f32, stream));
         else

@@ -282,10 +282,12 @@ class MSATransformer(nn.Module):
                                                self.fold_layernorm if fold_layernorm is None else fold_layernorm)
 
     def forward_batch(self, tokens3d: torch.Tensor, has_padding: Optional[bool] = None,
-                      fold_layernorm: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+                      fold_layernorm: Optional[bool] = None, true_rows: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """B same-shape MSAs (ragged ones padded with <pad>; direct-path mask semantics) through rnamsm_forward_batch (exact
         path): tokens [B,R,C] -> row_attn [B,NL,H,C,C], repr [B,R,C,D], emb [B,C-1,D], atp [B,NL*H,C-1,C-1], err int32[1]
-        (bits as in forward_one).  has_padding: None = look at the tokens."""
+        (bits as in forward_one).  has_padding: None = look at the tokens.  true_rows (int32 [B] on the device): the real
+        depth of every element of a RAGGED batch -- each MSA's tied logits are then scaled by its own depth and the element comes
+        out as its unpadded forward would (forward_ragged); None = the reference's batch semantics (padded depth)."""
         if self.training:
             raise NotImplementedError("inference only (model.eval())")
         if not tokens3d.is_cuda:
@@ -311,20 +313,46 @@ class MSATransformer(nn.Module):
             folded = self._folded_weights() if (fold and not has_padding) else None
             _lib.check(lib.rnamsm_forward_batch(ctypes.byref(dims), ptrs, toks.data_ptr(), B, R, C, ws.data_ptr(), ws.numel(),
                                                 row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
-                                                err.data_ptr(), int(has_padding), folded, torch.cuda.current_stream().cuda_stream))
+                                                err.data_ptr(), int(has_padding),
+                                                None if true_rows is None else true_rows.to(dev, torch.int32).contiguous().data_ptr(),
+                                                folded, torch.cuda.current_stream().cuda_stream))
         return {"row_attn": row_attn, "repr": rep, "emb": emb, "atp": atp, "err": err}
 
-    def checked_forward_batch(self, tokens3d: torch.Tensor, has_padding: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+    def checked_forward_batch(self, tokens3d: torch.Tensor, has_padding: Optional[bool] = None,
+                              true_rows: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """forward_batch + the error word (see checked_forward_one)."""
-        out = self.forward_batch(tokens3d, has_padding)
+        out = self.forward_batch(tokens3d, has_padding, true_rows=true_rows)
         err = int(out["err"].item())
         if err & self.ERR_INDEX:
             raise IndexError("batch: token or position index out of range")
         if err & self.ERR_FOLD:
             import warnings
             warnings.warn("batch: a token row's mean exceeds 32x its spread; LayerNorm is applied in its own launches for this batch")
-            out = self.forward_batch(tokens3d, has_padding, fold_layernorm=False)
+            out = self.forward_batch(tokens3d, has_padding, fold_layernorm=False, true_rows=true_rows)
         return out
+
+    def forward_ragged(self, msas: List[torch.Tensor]) -> List[Dict[str, torch.Tensor]]:
+        """Alignments of DIFFERENT shapes ([R_b, C_b] int64 tokens without <pad>, column 0 = <cls>) in one launch set: padded into
+        one [max R, max C] frame and run as a ragged batch (rnamsm_forward_batch with true_rows).  Returns per MSA what
+        forward_one(need_repr=False) returns -- emb [C_b-1, D], atp [NL*H, C_b-1, C_b-1], row_attn [NL, H, C_b, C_b] -- equal to
+        the MSA's own forward to fp32 rounding.  Pays for alignments of a few thousand tokens and similar shapes (padding is
+        computed too)."""
+        B = len(msas)
+        R = max(int(t.shape[0]) for t in msas)
+        C = max(int(t.shape[1]) for t in msas)
+        dev = msas[0].device
+        frame = torch.full((B, R, C), self.vocab.pad_idx, dtype=torch.int64, device=dev)
+        for b, t in enumerate(msas):
+            frame[b, :t.shape[0], :t.shape[1]] = t
+        depths = torch.tensor([int(t.shape[0]) for t in msas], dtype=torch.int32, device=dev)
+        ragged = any(tuple(t.shape) != (R, C) for t in msas)
+        out = self.checked_forward_batch(frame, has_padding=ragged, true_rows=depths)
+        res = []
+        for b, t in enumerate(msas):
+            cb = int(t.shape[1])
+            res.append({"emb": out["emb"][b, :cb - 1], "atp": out["atp"][b, :, :cb - 1, :cb - 1],
+                        "row_attn": out["row_attn"][b, :, :, :cb, :cb], "err": out["err"]})
+        return res
 
     ERR_INDEX, ERR_FOLD = 1, 2            # bits of forward_one's "err": token / position index out of range; a row whose
                                           # |mean| is so far above its spread that the folded LayerNorm loses > 5 bits

@@ -720,3 +720,35 @@ def test_padded_ragged_batch_through_the_batched_driver(model):
     finally:
         m.max_tokens_per_msa_(keep)
     assert not torch.equal(chunked["row_attentions"], out["row_attn"])
+
+
+def test_ragged_batch_equals_every_alignment_alone(model):
+    """forward_ragged: alignments of different shapes share one launch set (padded into one frame, rnamsm_forward_batch with
+    true_rows): every MSA must come out as from its own unpadded forward -- the padded depth must not leak into the tied-row
+    scaling as it does in the reference's batch semantics -- to fp32 rounding, and meet the bar against the oracle."""
+    m, state = model
+    shapes = [(8, 17), (3, 9), (12, 17), (1, 30), (7, 25), (12, 30)]
+    msas = [torch.from_numpy(synthetic.make_tokens(r, c, 70 + i)).to("cuda:0") for i, (r, c) in enumerate(shapes)]
+    outs = m.forward_ragged(msas)
+    params = O.to_torch_params(state)
+    for t, got in zip(msas, outs):
+        one = m.checked_forward_one(t, need_repr=False)
+        assert got["emb"].shape == one["emb"].shape and got["atp"].shape == one["atp"].shape
+        assert rel_l2(got["emb"].cpu().numpy(), one["emb"].cpu().numpy()) < 1e-5
+        assert np.abs(got["atp"].cpu().numpy() - one["atp"].cpu().numpy()).max() < 2e-5
+        assert np.abs(got["row_attn"].cpu().numpy() - one["row_attn"].cpu().numpy()).max() < 2e-5
+        emb, atp = O.pack_outputs(O.forward(t.cpu(), params))
+        assert rel_l2(got["emb"].cpu().numpy(), np.asarray(emb)) < 1e-4
+        assert np.abs(got["atp"].cpu().numpy() - np.asarray(atp)).max() < 1e-4
+    # the reference's own batch semantics (no true_rows) differ for the shallower elements: that is what true_rows is for
+    frame = torch.full((2, 12, 17), 1, dtype=torch.int64, device="cuda:0")
+    frame[0, :8, :17] = msas[0]
+    frame[1] = msas[2]
+    ref_sem = m.checked_forward_batch(frame)
+    alone = m.checked_forward_one(msas[0], need_repr=False)
+    assert np.abs(ref_sem["atp"][0].cpu().numpy() - alone["atp"].cpu().numpy()).max() > 1e-3
+    # same shapes, no padding at all: forward_ragged is the plain batched forward
+    same = [torch.from_numpy(synthetic.make_tokens(5, 11, 90 + i)).to("cuda:0") for i in range(3)]
+    for t, got in zip(same, m.forward_ragged(same)):
+        one = m.checked_forward_one(t, need_repr=False)
+        assert rel_l2(got["emb"].cpu().numpy(), one["emb"].cpu().numpy()) < 1e-5
