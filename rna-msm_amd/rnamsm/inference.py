@@ -182,16 +182,48 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
     try:
         with torch.no_grad():
             pending = reader.submit(read, mine[0]) if reader and len(mine) else None
+            def deliver(idx: int, emb: torch.Tensor, atp: torch.Tensor) -> None:
+                if gatherer is not None:
+                    gatherer.submit(idx, (emb, atp))
+                else:
+                    emit(ids[idx], emb, atp)
+
+            # data.batch_small_msas: consecutive small alignments wait in `group` and go through ONE launch set
+            # (forward_ragged: padded into one frame, every MSA scaled by its own depth); a lone forward of a few hundred
+            # tokens costs 5.5 ms on a mostly idle chip.  Order of delivery = order of the id list either way.
+            batching = bool(getattr(cfg.data, "batch_small_msas", False)) and model.gemm_dtype == "f32"
+            group: List = []                                          # (idx, tokens on the device)
+
+            def flush() -> None:
+                if len(group) == 1:
+                    idx0, t0 = group[0]
+                    out = model.checked_forward_one(t0, need_repr=False, what=ids[idx0])
+                    deliver(idx0, out["emb"], out["atp"])
+                elif group:
+                    try:
+                        outs = model.forward_ragged([t for _, t in group])
+                    except IndexError:                                # name the offending alignment: one by one
+                        outs = [model.checked_forward_one(t, need_repr=False, what=ids[i]) for i, t in group]
+                    for (i, _), out in zip(group, outs):
+                        deliver(i, out["emb"].contiguous(), out["atp"].contiguous())
+                group.clear()
+
             for n, idx in enumerate(mine):
                 rna_id = ids[idx]
                 tokens = pending.result() if reader else read(idx)
                 if reader and n + 1 < len(mine):
                     pending = reader.submit(read, mine[n + 1])       # parsed while the GPU runs this MSA
+                if batching and tokens.size <= 1536 and not (tokens == alphabet.padding_idx).any():
+                    trial = [t.shape for _, t in group] + [tokens.shape]
+                    frame = len(trial) * max(s[0] for s in trial) * max(s[1] for s in trial)
+                    if frame > 16384 or frame > 2 * sum(s[0] * s[1] for s in trial) or len(group) == 32:
+                        flush()                                       # this one would waste too much padding: start a new frame
+                    group.append((idx, torch.from_numpy(tokens).to(device)))
+                    continue
+                flush()
                 out = model.checked_forward_one(torch.from_numpy(tokens).to(device), need_repr=False, what=rna_id)   # emb + atp are all that is written
-                if gatherer is not None:
-                    gatherer.submit(idx, (out["emb"], out["atp"]))
-                else:
-                    emit(rna_id, out["emb"], out["atp"])
+                deliver(idx, out["emb"], out["atp"])
+            flush()
             if gatherer is not None:
                 gatherer.finish()
     finally:

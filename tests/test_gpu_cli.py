@@ -132,3 +132,43 @@ def test_cli_gather_to_rank0_streams_rounds_and_writes_the_same_files(tmp_path):
     assert len(a) == 10 and a.keys() == b.keys()
     for name in a:
         assert a[name] == b[name], name
+
+
+def test_cli_batches_small_alignments_on_request(tmp_path):
+    """data.batch_small_msas=true: consecutive small alignments of the id list (different depths and lengths here) are padded
+    into one frame and run as a ragged batch; a large one in between flushes the group and runs alone.  Same files, same order,
+    values equal to the one-by-one run to fp32 rounding; an alignment with a bad character is still reported by name."""
+    from rnamsm.config import Config
+    from rnamsm.inference import extract_feat
+    from rnamsm.model import MSATransformer
+    state = synthetic.make_state_dict(seed=0)
+    model = MSATransformer(num_layers=10)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    records = open(os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2")).read().splitlines()
+    names, seqs = records[0::2], records[1::2]
+    ids = [f"rna{c}" for c in "ABCDEFGH"]
+    shapes = {"rnaA": (3, 20), "rnaB": (9, 35), "rnaC": (5, 28), "rnaD": (64, 35), "rnaE": (12, 30), "rnaF": (2, 12),
+              "rnaG": (7, 33), "rnaH": (1, 35)}                      # rnaD = 2240 tokens: not small, runs alone in between
+    outs = {}
+    for mode in (False, True):
+        root = tmp_path / ("batched" if mode else "plain")
+        (root / "results").mkdir(parents=True)
+        for i in ids:
+            depth, length = shapes[i]
+            text = "".join(f"{names[r]}\n{seqs[r][:length]}\n" for r in range(depth))
+            (root / "results" / f"{i}.a2m_msa2").write_text(text)
+        (root / "rna_id.txt").write_text("\n".join(ids) + "\n")
+        cfg = Config()
+        cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = str(root), "results", "rna_id.txt"
+        cfg.data.sample_method, cfg.data.max_seqs_per_msa, cfg.data.batch_small_msas = "first", 64, mode
+        assert extract_feat(cfg, model=model) == ids
+        outs[mode] = {f.name: np.load(f) for f in sorted((root / "results").glob("*.npy"))}
+    assert outs[True].keys() == outs[False].keys() and len(outs[True]) == 2 * len(ids)
+    for name, want in outs[False].items():
+        got = outs[True][name]
+        assert got.shape == want.shape and got.dtype == want.dtype and got.flags["C_CONTIGUOUS"], name
+        if name.endswith("_emb.npy"):
+            assert rel_l2(got, want) < 1e-5, name
+        else:
+            assert np.abs(got - want).max() < 2e-5, name
+    assert np.array_equal(outs[True]["rnaD_emb.npy"], outs[False]["rnaD_emb.npy"])       # the large one ran alone: same bits
