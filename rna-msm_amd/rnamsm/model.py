@@ -332,7 +332,7 @@ class MSATransformer(nn.Module):
         return out
 
     def forward_ragged(self, msas: List[torch.Tensor]) -> List[Dict[str, torch.Tensor]]:
-        """Alignments of DIFFERENT shapes ([R_b, C_b] int64 tokens without <pad>, column 0 = <cls>) in one launch set: padded into
+        """Alignments of DIFFERENT shapes ([R_b, C_b] int64 tokens, column 0 = <cls>) in one launch set: padded into
         one [max R, max C] frame and run as a ragged batch (rnamsm_forward_batch with true_rows).  Returns per MSA what
         forward_one(need_repr=False) returns -- emb [C_b-1, D], atp [NL*H, C_b-1, C_b-1], row_attn [NL, H, C_b, C_b] -- equal to
         the MSA's own forward to fp32 rounding.  Pays for alignments of a few thousand tokens and similar shapes (padding is
@@ -345,8 +345,9 @@ class MSATransformer(nn.Module):
         for b, t in enumerate(msas):
             frame[b, :t.shape[0], :t.shape[1]] = t
         depths = torch.tensor([int(t.shape[0]) for t in msas], dtype=torch.int32, device=dev)
-        ragged = any(tuple(t.shape) != (R, C) for t in msas)
-        out = self.checked_forward_batch(frame, has_padding=ragged, true_rows=depths)
+        # <pad> from the framing, or already inside an alignment (its masks then follow the reference's padding semantics)
+        has_padding = any(tuple(t.shape) != (R, C) for t in msas) or bool((frame == self.vocab.pad_idx).any())
+        out = self.checked_forward_batch(frame, has_padding=has_padding, true_rows=depths)
         res = []
         for b, t in enumerate(msas):
             cb = int(t.shape[1])
