@@ -224,3 +224,24 @@ def test_full_2drb1_alignment_tokens_and_default_subsampling_bit_exact(full_2drb
     from rnamsm.msa import greedy_select
     sel = greedy_select(toks, 512, "max")
     assert np.array_equal(toks[sel], g["diversity_max_512"])
+
+
+def test_a_padded_frame_differs_from_the_alignment_alone_only_through_the_padded_depth(full_state):
+    """What rnamsm_forward_batch's `true_rows` rests on, shown on the oracle (the reference's semantics, pinned above on its
+    padded fixture): an alignment framed with <pad> COLUMNS comes out as alone -- masked keys get probability exactly 0, padded
+    queries are zeroed, padded values reach no real token -- while <pad> ROWS change its outputs, because align_scaling divides
+    the tied logits by the square root of the PADDED depth (modules.py:713-715).  With that one factor put right (the HIP
+    ragged batch) the framed alignment equals the alignment alone (tests/test_gpu_forward.py)."""
+    params = O.to_torch_params(full_state)
+    toks = torch.from_numpy(synthetic.make_tokens(3, 9, 11))
+    alone = O.forward(toks, params)
+    wide = torch.full((3, 13), 1, dtype=torch.int64)
+    wide[:, :9] = toks
+    cols = O.forward(wide, params)
+    assert rel_l2(cols["representation"][:, :9], alone["representation"]) < 1e-5
+    assert np.abs(cols["row_attentions"][..., :9, :9].numpy() - alone["row_attentions"].numpy()).max() < 1e-5
+    assert float(cols["row_attentions"][..., :9, 9:].abs().max()) == 0.0            # padded keys: probability exactly 0
+    deep = torch.full((6, 9), 1, dtype=torch.int64)
+    deep[:3] = toks
+    rows = O.forward(deep, params)
+    assert np.abs(rows["row_attentions"].numpy() - alone["row_attentions"].numpy()).max() > 1e-2   # sqrt(6) instead of sqrt(3)
