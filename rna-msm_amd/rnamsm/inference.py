@@ -107,6 +107,22 @@ class _AsyncNpyWriter:
             raise self._err
 
 
+# data.batch_small_msas: which alignments wait for company, and when a group is full.  An alignment of up to SMALL_MSA_TOKENS
+# tokens is "small" (from ~2 k tokens on the padding of a ragged frame costs more than the shared launches return,
+# tools/ragged_batch_timing.py); a group's frame -- members x max rows x max columns -- stays within FRAME_TOKENS and within
+# twice the real tokens, and holds at most GROUP_MEMBERS alignments.
+SMALL_MSA_TOKENS, FRAME_TOKENS, GROUP_MEMBERS = 1536, 16384, 32
+
+
+def joins_group(group_shapes: List[tuple], shape: tuple) -> bool:
+    """Does a small alignment of `shape` (rows, columns) join the waiting group, or must the group be flushed first?"""
+    if len(group_shapes) >= GROUP_MEMBERS:
+        return False
+    trial = list(group_shapes) + [shape]
+    frame = len(trial) * max(s[0] for s in trial) * max(s[1] for s in trial)
+    return frame <= FRAME_TOKENS and frame <= 2 * sum(s[0] * s[1] for s in trial)
+
+
 def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_rank0: bool = False,
                  async_io: bool = True) -> List[str]:
     """async_io: read/tokenise the next alignment on a helper thread while the GPU runs the current one, and move the
@@ -213,10 +229,8 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                 tokens = pending.result() if reader else read(idx)
                 if reader and n + 1 < len(mine):
                     pending = reader.submit(read, mine[n + 1])       # parsed while the GPU runs this MSA
-                if batching and tokens.size <= 1536 and not (tokens == alphabet.padding_idx).any():
-                    trial = [t.shape for _, t in group] + [tokens.shape]
-                    frame = len(trial) * max(s[0] for s in trial) * max(s[1] for s in trial)
-                    if frame > 16384 or frame > 2 * sum(s[0] * s[1] for s in trial) or len(group) == 32:
+                if batching and tokens.size <= SMALL_MSA_TOKENS and not (tokens == alphabet.padding_idx).any():
+                    if not joins_group([tuple(t.shape) for _, t in group], tuple(tokens.shape)):
                         flush()                                       # this one would waste too much padding: start a new frame
                     group.append((idx, torch.from_numpy(tokens).to(device)))
                     continue
