@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RNAMSM_VERSION 207 /* major*10000 + minor*100 + patch */
+#define RNAMSM_VERSION 300 /* major*10000 + minor*100 + patch */
 
 typedef enum {
     RNAMSM_OK = 0,
@@ -225,6 +225,21 @@ int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_
 int rnamsm_col_attn_fused_queries(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc,
                                   int R, int C, int H, int head_dim, int q_rows, const uint8_t* pad_mask, int dtype,
                                   void* stream);
+
+/* K7's probabilities, materialised on request -- ColumnSelfAttention's second return value (modules.py:905-917 builds
+ * attn_probs [H, C, B, R, R]; :926-945 returns it; AxialTransformerLayer.forward hands it on, :253-267):
+ *   probs[((h*C + c)*R + i)*R + j] = softmax_j( scale * q[i,c,h,:] . k[j,c,h,:]   [-10000 where pad_mask[j*C + c]] )
+ * i.e. the reference's tensor for B = 1, contiguous.  The fused kernels above never form it (H*C*R*R floats: 1.6 GB per
+ * layer at R = 256, C = 512); callers that read it (rnamsm.modules.ColumnSelfAttention(return_probs=True)) pay for it
+ * here.  q, k addressed like rnamsm_col_attn_fused's; the fp32 form takes q as the QKV GEMM left it (already scaled by
+ * dh^-0.5: pass scale = 1), the plane form takes the 16-bit modes' unscaled q planes (scale = dh^-0.5; *_lo may be NULL
+ * together; fmt 0 = bf16, 1 = fp16; ld in halves).  R == 1 gives ones, as modules.py:882-891.
+ * dtype: RNAMSM_F32 only. */
+int rnamsm_col_attn_probs(const float* q, const float* k, int64_t ld, float* probs, int R, int C, int H, int head_dim,
+                          const uint8_t* pad_mask, float scale, int dtype, void* stream);
+int rnamsm_col_attn_probs16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
+                            int64_t ld, float* probs, int R, int C, int H, int head_dim, const uint8_t* pad_mask, int fmt,
+                            float scale, void* stream);
 
 /* K4' / K5' / K6' / K7' -- the attention contractions of the 16-bit modes (same reference lines as K4..K7).  Operands
  * are 16-bit planes in HBM, addressed like their fp32 counterparts (element (r,c,h,d) = plane[(r*C+c)*ld + h*64 + d],

@@ -100,6 +100,10 @@ _SIGNATURES = {
                                    c_int64, c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "rnamsm_col_attn_fused_queries": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                               c_int, c_int, c_void_p, c_int, c_void_p]),
+    "rnamsm_col_attn_probs": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float,
+                                      c_int, c_void_p]),
+    "rnamsm_col_attn_probs16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_int, c_float, c_void_p]),
     "rnamsm_timing_enable": (c_int, [c_int]),
     "rnamsm_timing_collect": (c_int, []),
     "rnamsm_timing_get": (c_int, [c_int, POINTER(c_char_p), POINTER(ctypes.c_longlong), POINTER(ctypes.c_double),

@@ -4,8 +4,10 @@ Same constructor keywords, `forward(tokens[B,R,C], repr_layers, need_head_weight
 result dict, `max_tokens_per_msa_`, and the 275-key state_dict (strict load of a Lightning
 `.ckpt['state_dict']`, RNA_MSM_Inference.py:133-135).  `lm_head.*` and `contact_head.*` parameters are
 held so that strict loading works.  `return_contacts=True` runs the contact head kernel (§8 f1).  The LM head
-(§8 f4) is computed on request (`need_logits=True` or `model.compute_logits = True`): the reference always
-computes it and its CLI always discards it, so by default "logits" is None.
+(§8 f4) runs by default, as in the reference (model.py:402: `x = self.lm_head(x)` on every forward; read by
+utils/likelihood.py:74,78) -- one [T,768]x[768,768] GEMM + LayerNorm + a 128-row GEMM, < 1 % of a forward.  Callers that
+never read "logits" (the CLI, bench.py -- the reference's CLI discards them too) pass `need_logits=False`
+(or set `model.compute_logits = False`) and get None.
 """
 from __future__ import annotations
 
@@ -65,7 +67,8 @@ class MSATransformer(nn.Module):
             AxialTransformerLayer(embedding_dim=embed_dim, ffn_embedding_dim=4 * embed_dim,
                                   num_attention_heads=num_attention_heads, dropout=dropout,
                                   attention_dropout=attention_dropout, activation_dropout=activation_dropout,
-                                  max_tokens_per_msa=max_tokens_per_msa)
+                                  max_tokens_per_msa=max_tokens_per_msa,
+                                  column_attention_probs=False)      # discarded by the model (model.py:390)
             for _ in range(num_layers)])
         self.contact_head = _ContactHeadParams(num_layers * num_attention_heads)
         # LearnedPositionalEmbedding table: max_seqlen + pad_idx + 1 rows (modules.py:277-283)
@@ -78,7 +81,7 @@ class MSATransformer(nn.Module):
         self._pack = None
         self._workspace = None
         self._lm_pad = None
-        self.compute_logits = False
+        self.compute_logits = True        # model.py:402; forward(need_logits=False) skips the LM head
         # Arithmetic of the contractions: "f32" (exact, default), "f16x3", "bf16x3" or "bf16" (include/rnamsm.h) -- for the
         # C++ driver and, through the property below, for every mirror module of the layer-wise path
         self.gemm_dtype = "f32"

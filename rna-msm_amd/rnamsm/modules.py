@@ -184,30 +184,43 @@ class RowSelfAttention(_AxialAttentionBase):
 
 
 class ColumnSelfAttention(_AxialAttentionBase):
-    """Column attention; mirrors modules.py:824-945.  forward(x[R,C,1,D]) -> (out[R,C,1,D], probs).
+    """Column attention; mirrors modules.py:824-945.  forward(x[R,C,1,D]) -> (out[R,C,1,D], probs[H,C,1,R,R]).
 
-    The reference returns the [H,C,1,R,R] probabilities and its only caller discards them
-    (model.py:390); they are 1.6 GB per layer at R=256, C=512 and the fused kernel never forms
-    them, so `probs` is None here."""
+    `out` always comes from the fused kernel, which never forms the probabilities.  The reference returns them
+    (modules.py:917-924, 926-945) and so does a stand-alone module (`return_probs=True`, the default): they are then
+    materialised by a second, HBM-bound launch (rnamsm_col_attn_probs; H*C*R*R floats -- 1.6 GB per layer at R=256,
+    C=512).  MSATransformer builds its layers with `return_probs=False` because the model discards them
+    (model.py:390); `probs` is None then."""
 
-    def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, _residual=None):
+    def __init__(self, embed_dim: int, num_heads: int, dropout: float = 0.0, max_tokens_per_msa: int = 2 ** 16,
+                 return_probs: bool = True):
+        super().__init__(embed_dim, num_heads, dropout=dropout, max_tokens_per_msa=max_tokens_per_msa)
+        self.return_probs = return_probs
+
+    def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, _residual=None, _want_probs: bool = True):
         _check_inference(self, self.dropout)
         x2, R, C, D = _tokens_2d(x)
         mask = self._mask_bytes(self_attn_mask, self_attn_padding_mask, R, C)
         H = self.num_heads
         res2 = None if _residual is None else _residual.contiguous().view(R * C, D)
+        want = self.return_probs and _want_probs
         mode = _mode_of(self)
         if mode is not None:
             split, fmt = mode
             qkv = self._qkv_planes(x2, split, fmt)
-            ctx = ops.col_attn16(_cols(qkv, 0, D), _cols(qkv, D, 2 * D), _cols(qkv, 2 * D, 3 * D), R, C, H, fmt=fmt,
+            q, k = _cols(qkv, 0, D), _cols(qkv, D, 2 * D)
+            ctx = ops.col_attn16(q, k, _cols(qkv, 2 * D, 3 * D), R, C, H, fmt=fmt,
                                  scale=self.scaling, pad_mask=mask if R > 1 else None)
-            return self._project_out(ctx, res2).view(R, C, 1, D), None
+            probs = ops.col_attn_probs16(q, k, R, C, H, fmt=fmt, scale=self.scaling,
+                                         pad_mask=mask if R > 1 else None).view(H, C, 1, R, R) if want else None
+            return self._project_out(ctx, res2).view(R, C, 1, D), probs
         qkv = self._qkv(x2, self.scaling)
         # R == 1 reduces to ctx = v; padded keys get score -10000 (modules.py:911-915)
         ctx = ops.col_attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], R, C, H, pad_mask=mask if R > 1 else None)
+        probs = ops.col_attn_probs(qkv[:, :D], qkv[:, D:2 * D], R, C, H,
+                                   pad_mask=mask if R > 1 else None).view(H, C, 1, R, R) if want else None
         out = self._project_out(ctx, res2)
-        return out.view(R, C, 1, D), None
+        return out.view(R, C, 1, D), probs
 
 
 class FeedForwardNetwork(nn.Module):
@@ -263,18 +276,20 @@ class NormalizedResidualBlock(nn.Module):
 
 
 class AxialTransformerLayer(nn.Module):
-    """row attention -> column attention -> FFN, each pre-LN + residual; mirrors modules.py:191-267."""
+    """row attention -> column attention -> FFN, each pre-LN + residual; mirrors modules.py:191-267.
+    forward(x, need_head_weights=True) -> (x, column_attn [H,C,1,R,R], row_attn [H,1,C,C]) as the reference."""
 
     def __init__(self, embedding_dim: int = 768, ffn_embedding_dim: int = 3072, num_attention_heads: int = 8,
                  dropout: float = 0.1, attention_dropout: float = 0.1, activation_dropout: float = 0.1,
-                 max_tokens_per_msa: int = 2 ** 14) -> None:
+                 max_tokens_per_msa: int = 2 ** 14, column_attention_probs: bool = True) -> None:
         super().__init__()
         self.embedding_dim = embedding_dim
         self.dropout_prob = dropout
         self.row_self_attention = self.build_residual(
             RowSelfAttention(embedding_dim, num_attention_heads, dropout=dropout, max_tokens_per_msa=max_tokens_per_msa))
         self.column_self_attention = self.build_residual(
-            ColumnSelfAttention(embedding_dim, num_attention_heads, dropout=dropout, max_tokens_per_msa=max_tokens_per_msa))
+            ColumnSelfAttention(embedding_dim, num_attention_heads, dropout=dropout, max_tokens_per_msa=max_tokens_per_msa,
+                                return_probs=column_attention_probs))
         self.feed_forward_layer = self.build_residual(
             FeedForwardNetwork(embedding_dim, ffn_embedding_dim, activation_dropout=activation_dropout,
                                max_tokens_per_msa=max_tokens_per_msa))
@@ -285,8 +300,11 @@ class AxialTransformerLayer(nn.Module):
     def forward(self, x, self_attn_mask=None, self_attn_padding_mask=None, need_head_weights: bool = False):
         x, row_attn = self.row_self_attention(x, self_attn_mask=self_attn_mask,
                                               self_attn_padding_mask=self_attn_padding_mask)
+        # the column probabilities are the second of the three return values (modules.py:253-267): formed only when they
+        # are returned, and not at all when the layer was built with column_attention_probs=False (MSATransformer)
         x, column_attn = self.column_self_attention(x, self_attn_mask=self_attn_mask,
-                                                    self_attn_padding_mask=self_attn_padding_mask)
+                                                    self_attn_padding_mask=self_attn_padding_mask,
+                                                    _want_probs=need_head_weights)
         x = self.feed_forward_layer(x)
         if need_head_weights:
             return x, column_attn, row_attn

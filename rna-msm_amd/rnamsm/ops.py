@@ -287,6 +287,20 @@ def col_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, R: int, C: int, 
     return ctx
 
 
+@_on_operand_device
+def col_attn_probs(q: torch.Tensor, k: torch.Tensor, R: int, C: int, H: int, pad_mask: Optional[torch.Tensor] = None,
+                   scale: float = 1.0) -> torch.Tensor:
+    """The probabilities the fused column attention never forms (reference modules.py:905-917), on request:
+    fp32 [H, C, R, R] = softmax_j(scale * q_i . k_j) per column and head; q as the QKV GEMM left it (already scaled)."""
+    probs = torch.empty(H, C, R, R, device=q.device, dtype=torch.float32)
+    ld = _rowmajor(q, "q")
+    assert _rowmajor(k, "k") == ld
+    _lib.check(_lib.load().rnamsm_col_attn_probs(_dev(q, "q"), _dev(k, "k"), ld, _dev(probs, "probs"), R, C, H, HEAD_DIM,
+                                                 None if pad_mask is None else _dev(pad_mask, "pad_mask", torch.uint8),
+                                                 scale, F32, _stream()))
+    return probs
+
+
 # ---- 16-bit attention contractions: operands are (hi, lo) int16 plane pairs, lo = None for plain bf16 ---------------
 def _pl(t: Optional[torch.Tensor], name: str):
     return None if t is None else _dev(t, name, torch.int16)
@@ -415,6 +429,20 @@ def col_attn16(q, k, v, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0
                                              None if pad_mask is None else _dev(pad_mask, "pad_mask", torch.uint8),
                                              None, None, fmt, _stream()))
     return ctx
+
+
+@_on_operand_device
+def col_attn_probs16(q, k, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0,
+                     pad_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """col_attn_probs for the 16-bit modes: q, k are (hi, lo | None) plane views (q UNSCALED)."""
+    probs = torch.empty(H, C, R, R, device=q[0].device, dtype=torch.float32)
+    ld = _rowmajor(q[0], "q_hi")
+    assert _rowmajor(k[0], "k_hi") == ld
+    _lib.check(_lib.load().rnamsm_col_attn_probs16(_pl(q[0], "q_hi"), _pl(q[1], "q_lo"), _pl(k[0], "k_hi"), _pl(k[1], "k_lo"),
+                                                   ld, _dev(probs, "probs"), R, C, H, HEAD_DIM,
+                                                   None if pad_mask is None else _dev(pad_mask, "pad_mask", torch.uint8),
+                                                   fmt, scale, _stream()))
+    return probs
 
 
 @_on_operand_device

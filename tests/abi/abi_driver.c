@@ -112,6 +112,13 @@ int main(void) {
     REFUSED(rnamsm_col_attn_fused(buf, buf, buf, 2304, buf, 768, 5000, 4, 12, 64, NULL, NULL, NULL, 0, 0, NULL));
     REFUSED(rnamsm_col_attn_fused_queries(buf, buf, buf, 2304, buf, 768, 4, 4, 12, 64, 0, NULL, 0, NULL));
     REFUSED(rnamsm_col_attn_fused_queries(buf, buf, buf, 2304, buf, 768, 4, 4, 12, 64, 5, NULL, 0, NULL));
+    REFUSED(rnamsm_col_attn_probs(NULL, buf, 2304, buf, 4, 4, 12, 64, NULL, 1.f, 0, NULL));
+    REFUSED(rnamsm_col_attn_probs(buf, buf, 2304, buf, 4, 4, 12, 32, NULL, 1.f, 0, NULL));
+    REFUSED(rnamsm_col_attn_probs(buf, buf, 2304, buf, 1025, 4, 12, 64, NULL, 1.f, 0, NULL));
+    REFUSED(rnamsm_col_attn_probs(buf, buf, 100, buf, 4, 4, 12, 64, NULL, 1.f, 0, NULL));
+    REFUSED(rnamsm_col_attn_probs(buf, buf, 2304, buf, 4, 4, 12, 64, NULL, 1.f, 1, NULL));
+    REFUSED(rnamsm_col_attn_probs16(halves, halves, halves, NULL, 2304, buf, 4, 4, 12, 64, NULL, 0, 1.f, NULL));
+    REFUSED(rnamsm_col_attn_probs16(halves, NULL, halves, NULL, 2304, buf, 4, 4, 12, 64, NULL, 2, 1.f, NULL));
     REFUSED(rnamsm_row_logits16(NULL, NULL, halves, NULL, 2304, buf, 4, 4, 12, 64, 1.f, 0, NULL));
     REFUSED(rnamsm_row_apply16(NULL, NULL, 64, halves, NULL, 2304, buf, 768, 4, 4, 12, 64, 1.f, NULL, NULL, 0, NULL));
     REFUSED(rnamsm_col_attn16(NULL, NULL, halves, NULL, halves, NULL, 2304, buf, 768, 4, 4, 12, 64, 1.f, NULL, NULL, NULL, 0, NULL));

@@ -275,6 +275,19 @@ def test_col_attention_kernel(dev, R, C, H):
     want = torch.einsum("hcij,jchd->ichd", p, v).reshape(R * C, D)
     assert rel_l2(ctx, want) < 5e-6
     assert np.abs(ctx.numpy() - want.numpy()).max() < 2e-5 * max(1.0, float(want.abs().max()))
+    # the probabilities on request (rnamsm_col_attn_probs: the reference's second return value, modules.py:917), without and
+    # with a padding mask (padded keys get -10000 before the softmax, modules.py:911-915), fp32 and plane operands
+    if R * R * C * H <= 4_000_000:
+        got = ops.col_attn_probs(gq[:, :D], gq[:, D:2 * D], R, C, H).cpu()
+        assert got.shape == (H, C, R, R) and np.abs(got.numpy() - p.numpy()).max() < 2e-6
+        pad = torch.from_numpy(synthetic.normal(f"colpad{R}_{C}", 3, (R, C)) > 0.8)
+        pad[0] = False                                               # keep one real key per column
+        w = torch.einsum("ichd,jchd->hcij", q, k).masked_fill(pad.t()[None, :, None, :], -10000)
+        got = ops.col_attn_probs(gq[:, :D], gq[:, D:2 * D], R, C, H, pad_mask=pad.to(torch.uint8).view(-1).to(dev)).cpu()
+        assert np.abs(got.numpy() - torch.softmax(w, -1).numpy()).max() < 2e-6
+        hi, lo = ops.split_bf16(g[:, :2 * D].contiguous(), fmt=1)       # unscaled q | k as fp16 hi/lo planes
+        got = ops.col_attn_probs16((hi[:, :D], lo[:, :D]), (hi[:, D:], lo[:, D:]), R, C, H, fmt=1, scale=0.125).cpu()
+        assert np.abs(got.numpy() - p.numpy()).max() < 5e-6
 
 
 def test_col_attention_online_softmax_rescale_is_exercised(dev):
@@ -349,8 +362,22 @@ def test_modules_match_reference_fixtures(dev, name):
     assert rel_l2(y.cpu()[:, :, 0], g["row_out"]) < TOL_REL
     assert np.abs(p.cpu().numpy()[:, 0] - g["row_probs"]).max() < TOL_PROB
     col = load(M.ColumnSelfAttention(D, H, max_tokens_per_msa=mt), "layers.0.column_self_attention.layer")
-    y, _ = col(x)
+    y, cp = col(x)
     assert rel_l2(y.cpu()[:, :, 0], g["col_out"]) < TOL_REL
+    # the second return value of the reference (modules.py:917-945): [H, C, B=1, R, R], materialised by rnamsm_col_attn_probs
+    assert cp.shape == (H, C, 1, R, R)
+    if "col_probs" in g:
+        assert np.abs(cp.cpu().numpy()[:, :, 0] - g["col_probs"]).max() < TOL_PROB
+    col.return_probs = False                                     # what MSATransformer's layers run: no second launch
+    y2, none = col(x)
+    assert none is None and torch.equal(y2, y)
+    col.return_probs = True
+    for mode in ("f16x3", "bf16"):                               # the plane form of the same kernel
+        col.gemm_dtype = mode
+        _, cp16 = col(x)
+        if "col_probs" in g:
+            assert np.abs(cp16.cpu().numpy()[:, :, 0] - g["col_probs"]).max() < (TOL_PROB if mode == "f16x3" else 5e-2)
+    col.gemm_dtype = "f32"
     if "ffn_out" in g:
         ff = load(M.FeedForwardNetwork(D, 4 * D, max_tokens_per_msa=mt), "layers.0.feed_forward_layer.layer")
         assert rel_l2(ff(x).cpu()[:, :, 0], g["ffn_out"]) < TOL_REL

@@ -181,7 +181,7 @@ def test_library_exports_every_symbol_declared_in_the_header(lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rnamsm_version() == 207         # ABI 2.1: rnamsm_forward takes max_tokens_per_msa (f2, chunked path) and outputs
+    assert lib.rnamsm_version() == 300         # ABI 3.0 (round 3): + rnamsm_col_attn_probs[16]; see the header's change notes
 
 
 def test_ctypes_signatures_match_the_header_prototypes():
