@@ -125,12 +125,20 @@ def launch_ranks(args) -> int:
     traffic would otherwise leave no scaling number at all), the sharded compute is measured once more without the
     gather and the result line says so."""
     deadline = float(os.environ.get("RNAMSM_BENCH_DEADLINE_S", "1500"))
-    rc = _run_ranks(args, [], {}, deadline)
-    if rc != 0 and not args.no_gather and os.environ.get("RNAMSM_BENCH_FAIL_RANK") is None:
-        print(f"bench.py: the {args.gpus}-rank run with the output gather ended with status {rc}; "
-              f"measuring the sharded compute without the gather", file=sys.stderr, flush=True)
-        rc = _run_ranks(args, ["--no-gather"], {"RNAMSM_BENCH_GATHER_NOTE": f"the run with the gather ended with status {rc}"},
-                        deadline)
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="rnamsm_bench_") as tmp:
+        notes = os.path.join(tmp, "failures.txt")                       # ranks append what went wrong (exception texts)
+        rc = _run_ranks(args, [], {"RNAMSM_BENCH_FAILURE_FILE": notes}, deadline)
+        if rc != 0 and not args.no_gather and os.environ.get("RNAMSM_BENCH_FAIL_RANK") is None:
+            why = ""
+            try:
+                why = " | ".join(dict.fromkeys(l.strip() for l in open(notes) if l.strip()))[:600]
+            except OSError:
+                pass
+            print(f"bench.py: the {args.gpus}-rank run with the output gather ended with status {rc} ({why or 'no exception text'}); "
+                  f"measuring the sharded compute without the gather", file=sys.stderr, flush=True)
+            note = f"the run with the gather ended with status {rc}" + (f": {why}" if why else "")
+            rc = _run_ranks(args, ["--no-gather"], {"RNAMSM_BENCH_GATHER_NOTE": note, "RNAMSM_BENCH_FAILURE_FILE": notes}, deadline)
     return rc
 
 
@@ -185,44 +193,85 @@ def host_cpu_info():
 
 
 def cpu_baseline(M, L, state):
-    """The oracle (port of the reference) on the host's cores.  torch's intra-op pool is swept over
-    {physical cores, 1/2, 1/4, 64, 32, 16, 8} on one layer of the M=64 x L=128 MSA (BASELINE configs[1]); at the best
-    setting: the complete 10-layer configs[1] forward, then ONE full layer of this bench's M x L MSA (embedding and
-    final LayerNorm included), x10 -- the ten layers are identical in cost -- which is `value`."""
+    """The oracle (port of the reference) on the host's cores, measured at the BENCHMARKED shape.
+    torch's intra-op pool is swept over {os.cpu_count(), physical cores, 1/2, 1/4, 1/8 of them} on ONE layer of the
+    M x L MSA of this bench (embedding and final LayerNorm included); at the fastest setting: one warm-up, then three
+    samples of that layer, `median_s` of them x 10 (the ten layers are identical in cost) = `value`.  Beside it the
+    complete 10-layer forward of BASELINE configs[1] (M=64 x L=128), which fits the time budget whole."""
+    import statistics
     import torch
     from oracle import msm_oracle as O
     from rnamsm import synthetic
     model, physical, logical = host_cpu_info()
     params = O.to_torch_params(state)
-    small = torch.from_numpy(synthetic.make_tokens(64, 128, 0))
+    toks = torch.from_numpy(synthetic.make_tokens(M, L, 0))
+    chunk = 32768 if M * L > 32768 else None                          # FFN hidden formed 32 k tokens at a time (memory only)
+
+    def one_layer():
+        t0 = time.perf_counter()
+        O.forward(toks, params, layers_to_run=1, ffn_token_chunk=chunk)
+        return time.perf_counter() - t0
+
     sweep = {}
     with torch.no_grad():
-        torch.set_num_threads(min(physical, logical))
-        O.forward(small, params, layers_to_run=1)                      # page the weights in, spin the pool up
-        for n in sorted({physical, physical // 2, physical // 4, 64, 32, 16, 8}, reverse=True):
-            if n < 1 or n > logical:
-                continue
+        candidates = sorted({logical, physical, physical // 2, physical // 4, physical // 8}, reverse=True)
+        candidates = [n for n in candidates if 1 <= n <= logical]
+        torch.set_num_threads(candidates[min(1, len(candidates) - 1)])
+        one_layer()                                                   # page the weights in, spin the pool up
+        for n in candidates:
             torch.set_num_threads(n)
-            O.forward(small, params, layers_to_run=1)
-            t0 = time.perf_counter()
-            O.forward(small, params, layers_to_run=1)
-            sweep[n] = time.perf_counter() - t0
+            sweep[n] = one_layer()
         best = min(sweep, key=sweep.get)
         torch.set_num_threads(best)
+        one_layer()                                                   # warm-up at the chosen setting
+        samples = [one_layer() for _ in range(3)]
+        med = statistics.median(samples)
+        small = torch.from_numpy(synthetic.make_tokens(64, 128, 0))
+        O.forward(small, params)
         t0 = time.perf_counter()
         O.forward(small, params)
         t_cfg1 = time.perf_counter() - t0
-        toks = torch.from_numpy(synthetic.make_tokens(M, L, 0))
-        t0 = time.perf_counter()
-        O.forward(toks, params, layers_to_run=1)
-        dt = time.perf_counter() - t0
-    return {"value": M * L / (10.0 * dt), "unit": "MSA-residues/s", "cores": best, "kind": "port",
+    return {"value": M * L / (10.0 * med), "unit": "MSA-residues/s", "cores": best, "kind": "port",
             "cpu_model": model, "physical_cores": physical, "logical_cpus": logical,
-            "thread_sweep_s_per_layer_M64_L128": {str(k): round(v, 4) for k, v in sweep.items()},
-            "configs1_full_forward": {"M": 64, "L": 128, "seconds": round(t_cfg1, 3), "residues_per_s": 64 * 128 / t_cfg1},
+            "thread_sweep_at_bench_shape": {"shape": [M, L], "seconds_per_layer": {str(k): round(v, 4) for k, v in sweep.items()}},
+            "samples": [round(v, 4) for v in samples], "median_s": round(med, 4),
+            "extrapolation": "one of ten identical layers (embedding + final LayerNorm included) timed, x 10",
+            "configs1_full_forward": {"M": 64, "L": 128, "seconds": round(t_cfg1, 3), "residues_per_s": 64 * 128 / t_cfg1,
+                                      "what": "complete 10-layer forward, no extrapolation"},
             "sample": f"oracle/msm_oracle.py on {model} ({physical} cores / {logical} threads), torch {torch.__version__} "
-                      f"CPU fp32 with {best} intra-op threads (fastest of the sweep): 1 of 10 layers of one M={M} L={L} "
-                      f"MSA in {dt:.2f} s, x10 extrapolated; the complete 10-layer M=64 L=128 forward took {t_cfg1:.2f} s"}
+                      f"CPU fp32 with {best} intra-op threads (fastest of a sweep on this shape): 1 of 10 layers of one M={M} "
+                      f"L={L} MSA, warm-up 1, median of 3 = {med:.2f} s, x10 extrapolated; the complete 10-layer M=64 L=128 "
+                      f"forward took {t_cfg1:.2f} s"}
+
+
+def mode_roofline(timings, mode, mult, steps):
+    """Roofline of a 16-bit mode, every launch priced against its OWN limit: bound = max(executed matrix flops / 2.5 PFLOP/s,
+    algorithmic bytes / 6.3 TB/s) per launch (csrc/common.h KernelTimer; in these modes out_proj, the LayerNorms and the
+    attention kernels are HBM-bound, QKV / fc1 matrix-bound), summed per kernel family; frac = bound time / measured
+    time.  The dominant family (the Linear GEMMs) is the block's headline; `all_kernels` is the whole step."""
+    g = timings["gemm_f32"]
+    per = {}
+    for k, v in timings.items():
+        if v["launches"]:
+            per[k] = {"ms_per_step": v["ms"] / steps, "bound_ms_per_step": v["bound_ms"] / steps,
+                      "frac": v["bound_ms"] / v["ms"] if v["ms"] > 0 else 0.0,
+                      "bound": "mfma" if v["mfma_bound_ms"] >= v["hbm_bound_ms"] else "hbm"}
+    tot_ms = sum(v["ms"] for v in timings.values())
+    tot_bound = sum(v["bound_ms"] for v in timings.values())
+    raw = mult * g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+    lim = mult * g["flops"] / (g["bound_ms"] * 1e-3) / 1e12 if g["bound_ms"] > 0 else 0.0
+    return {"bound": "per launch max(mfma, hbm)", "kernel": "16-bit Linear GEMMs (gemm16_q16_kernel / gemm16_swp_kernel; nn.Linear, K2)",
+            "achieved": raw, "peak": lim,
+            "unit": "TFLOP/s executed by the GEMM launches; peak = the same flops at every launch's own bound, "
+                    "max(flops / 2.5 PFLOP/s, algorithmic bytes / 6.3 TB/s)" + (" (executed = 3 x algorithmic)" if mult == 3.0 else ""),
+            "frac": raw / lim if lim > 0 else 0.0,
+            "gemm_ms_per_step": g["ms"] / steps, "gemm_bound_ms_per_step": g["bound_ms"] / steps,
+            "gemm_mfma_bound_ms": g["mfma_bound_ms"] / steps, "gemm_hbm_bound_ms": g["hbm_bound_ms"] / steps,
+            "gemm_frac_of_mfma_peak": raw / F16_MFMA_PEAK_TFLOPS, "gemm_algorithmic_tflops": raw / mult,
+            "peaks": {"mfma_tflops": F16_MFMA_PEAK_TFLOPS, "hbm_tbps": 6.3},
+            "all_kernels": {"ms_per_step": tot_ms / steps, "bound_ms_per_step": tot_bound / steps,
+                            "frac": tot_bound / tot_ms if tot_ms > 0 else 0.0},
+            "per_kernel": per, "mode": mode}
 
 
 # --------------------------------------------------------------------------------------------- one rank
@@ -241,11 +290,24 @@ def run_rank(args) -> int:
     dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        # a collective that does not complete within this ends the rank (RCCL watchdog) instead of parking it until the
+        # launcher's 25-minute deadline; the launcher then measures the compute-only curve
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("RNAMSM_BENCH_PG_TIMEOUT_S", "300")))
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=pg_timeout)
+
+    def note_failure(text):
+        path = os.environ.get("RNAMSM_BENCH_FAILURE_FILE")
+        if path:
+            try:
+                with open(path, "a") as f:
+                    f.write(text.replace("\n", " ")[:400] + "\n")
+            except OSError:
+                pass
 
     if os.environ.get("RNAMSM_BENCH_FAIL_RANK") == str(rank):       # test hook: a rank that dies must fail the whole run
         raise SystemExit(f"rank {rank}: RNAMSM_BENCH_FAIL_RANK")
@@ -295,12 +357,14 @@ def run_rank(args) -> int:
         except Exception as e:                                        # noqa: BLE001
             ok.zero_()
             gather_failure = f"{type(e).__name__}: {e}"
+            note_failure(f"rank {rank} gather probe: {gather_failure}")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if float(ok.item()) == 0.0:
             gather = False
             gather_failure = gather_failure or "a peer failed in the probe"
     digest = torch.zeros((), dtype=torch.int64, device=dev)
     delivered = [0]
+    last_gather = [None]
 
     def on_item(index, tensors):
         nonlocal digest
@@ -329,6 +393,7 @@ def run_rank(args) -> int:
             base += len(items)
         if g is not None:
             g.finish()
+            last_gather[0] = g
         return n_items
 
     def sync_all():
@@ -359,6 +424,27 @@ def run_rank(args) -> int:
     elapsed = max_over_ranks(time.perf_counter() - t0)
     headline_digest = int(digest.item()) if args.digest else None
     headline_delivered = delivered[0]
+    # ---- N > 1: what the gather cost.  Per rank: bytes received, host seconds blocked on transfers, milliseconds the compute
+    # stream stood waiting for the transfer stream (RoundGatherer.stats); and the same steps once more WITHOUT the gather
+    # (`compute_only_value`: max-over-ranks forward time only) so a first real multi-GPU run separates compute scaling from
+    # the gather's exposed time
+    gather_stats = compute_only = None
+    if world > 1:
+        st = last_gather[0].stats() if (gather and last_gather[0] is not None) else {}
+        mine = [st.get("bytes_received", 0.0), st.get("host_wait_s", 0.0), st.get("stream_wait_ms", 0.0)]
+        allst = [None] * world
+        dist.all_gather_object(allst, mine)
+        gather_stats = {"per_rank_bytes_received": [int(a[0]) for a in allst],
+                        "per_rank_host_wait_s": [round(a[1], 4) for a in allst],
+                        "per_rank_stream_wait_ms": [round(a[2], 3) for a in allst],
+                        "what": "RoundGatherer.stats() of the timed region: bytes into each rank (rank 0 is the sink), host seconds "
+                                "blocked in transfers, and ms the compute stream waited for the transfer stream (= the gather time "
+                                "NOT overlapped with the next forward)"}
+        sync_all()
+        tc = time.perf_counter()
+        run_steps(0 if batch else args.warmup, args.steps, use_gather=False)
+        sync_all()
+        compute_only = max_over_ranks(time.perf_counter() - tc)
 
     # ---- roofline pass: the same work with HIP-event pairs around every launch (no gather: kernels only)
     roof_steps = 1 if batch else args.steps
@@ -411,15 +497,10 @@ def run_rank(args) -> int:
             lib.rnamsm_timing_enable(0)
             tim2 = _lib.kernel_timings()
             model.gemm_dtype = "f32"
-            g2 = tim2["gemm_f32"]
-            raw = mult * g2["flops"] / (g2["ms"] * 1e-3) / 1e12 if g2["ms"] > 0 else 0.0
             return {"gemm_dtype": mode, "value": args.steps * M * L / el2, "unit": "MSA-residues/s",
                     "ms_per_step": 1e3 * el2 / args.steps,
                     "deviation_from_f32_path": {"emb_rel_l2": dev_emb, "atp_max_abs": dev_atp, "atp_mean_abs": dev_atp_mean},
-                    "roofline": {"bound": "mfma", "kernel": f"gemm16_swp_kernel<split {int(mult)}, {'fp16' if mode == 'f16x3' else 'bf16'}>",
-                                 "achieved": raw, "peak": F16_MFMA_PEAK_TFLOPS,
-                                 "unit": "TFLOP/s" + (" (executed MFMA flops = 3 x algorithmic)" if mult == 3.0 else ""),
-                                 "frac": raw / F16_MFMA_PEAK_TFLOPS, "algorithmic_tflops": raw / mult},
+                    "roofline": mode_roofline(tim2, mode, mult, args.steps),
                     "attention": "16-bit kernels (row_logits16 / row_apply16 / col_attn16, same operand format)",
                     "kernel_ms_per_step": {k: v["ms"] / args.steps for k, v in tim2.items()}}
 
@@ -529,9 +610,15 @@ def run_rank(args) -> int:
                        "backend": ("nccl (RCCL)" if args.backend == "nccl" else args.backend) if world > 1 else "none",
                        "devices": "all ranks on device 0 (test hook)" if args.one_device and world > 1 else "one per rank",
                        "warmup_note": (f"a warm-up step is a pass over the first {warm_items} MSAs of the batch" if batch else "full steps")},
+            "compute_only_value": (residues / compute_only) if compute_only else None,
+            "compute_only_ms_per_step": (1e3 * compute_only / args.steps) if compute_only else None,
+            "gather_stats": gather_stats,
             "outputs_finite": finite, "err_word": err_word,
             "model_tflops": flops_per_msa(M, L) * msas_timed / elapsed / 1e12,
-            "roofline": {"bound": "mfma", "kernel": gemm_kernel,
+            "roofline": (dict(mode_roofline(timings, args.gemm_dtype, mult, roof_local), traffic=traffic,
+                              traffic_unit="bytes/launch of the GEMM kernels (HBM-side, PMC)", traffic_source=traffic_src,
+                              algorithmic_bytes_per_launch=g["bytes"] / max(1, g["launches"]))
+                         if args.gemm_dtype != "f32" else None) or {"bound": "mfma", "kernel": gemm_kernel,
                          "achieved": gemm_tflops, "peak": peak, "unit": flop_unit,
                          "frac": gemm_tflops / peak,
                          "avg_launch_ms": g["ms"] / max(1, g["launches"]), "launches": g["launches"],

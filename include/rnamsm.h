@@ -124,6 +124,14 @@ int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float* W, const 
                              int64_t M, int N, int K, int act, float scale, int scale_cols,
                              const uint8_t* zero_rows, int dtype, void* stream);
 
+/* K2 with a per-row factor on the scaled columns (the general form of zero_rows):
+ *   Cout[m, n] = ((A W^T + bias)[m, n] * scale) * row_factor[m]   for n < scale_cols,   (A W^T + bias)[m, n] elsewhere.
+ * The QKV projection of a RAGGED batch (rnamsm_forward_batch with true_rows): a token's q is scaled by dh^-1/2 and by
+ * 1/sqrt(the true depth of ITS alignment) (align_scaling, modules.py:713-715) and zeroed at <pad> (q *= 1 - padding_mask,
+ * modules.py:767-772) -- row_factor (float [M], device) carries both.  No activation, no residual.  dtype: RNAMSM_F32 only. */
+int rnamsm_gemm_row_scaled(const float* A, int64_t lda, const float* W, const float* bias, float* Cout, int64_t ldc, int64_t M,
+                           int N, int K, float scale, int scale_cols, const float* row_factor, int dtype, void* stream);
+
 /* Linear on the bf16 matrix cores (fp32 accumulate, fp32 activations in HBM), same epilogue as above.
  *   split = 1: operands rounded to bf16 (mixed-precision mode, BASELINE config 4);
  *   split = 3: "bf16x3" -- both operands as hi + lo bf16 pairs, product = hi*hi + hi*lo + lo*hi (~2^-17 relative
@@ -309,7 +317,9 @@ int rnamsm_greedy_select(const uint8_t* msa, int N, int L, int num_seqs, int min
 
 /* f3 -- sequence weights for `sample-pretrained` sub-sampling (MSA.weights, utils/align.py:250-253, consumed by
  * MSA.sample_weights, :150-163): weights[i] = 1 / #{ j : hamming(msa[i], msa[j]) / L < seqid_cutoff } as float64 (the row
- * itself counts), msa uint8 [N, L].  The random draw itself stays on the host (numpy's generator is the contract). */
+ * itself counts), msa uint8 [N, L], L <= 32768.  The random draw itself stays on the host (numpy's generator is the
+ * contract).  The reference compares raw character bytes; any one-to-one recoding (the tokenizer's ids for A/C/G/U/X/-)
+ * gives the same distances. */
 int rnamsm_msa_weights(const uint8_t* msa, int N, int L, double seqid_cutoff, double* weights, void* stream);
 
 /* Whole forward, K0..K10 for one MSA, driven from C++ so that one call enqueues every launch
@@ -369,6 +379,11 @@ size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, int R, int 
  * way; repr then holds valid data in its first C rows only.  (Exact path without padding; otherwise the flag is ignored
  * and everything is computed.) */
 #define RNAMSM_OUT_REPR 1
+/* err_flag (device int, may be NULL) collects, OR-ed by the kernels: bit 0 a token / position index outside its table (K0,
+ * clamped); bit 1 the folded LayerNorm's precondition failed for some row (K1 folded; redo with ln_folded = NULL); bit 2
+ * (RNAMSM_ERR_NONFINITE) an emb / atp value is inf or NaN (K10 inspects every value it packs) -- in the 16-bit modes that is
+ * how an operand outside fp16 range shows, and the caller should redo the MSA with dtype RNAMSM_F32.  One word, one read. */
+#define RNAMSM_ERR_NONFINITE 4
 int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
                    int R, int C, void* workspace, size_t workspace_bytes,
                    float* row_attn, float* repr, float* emb, float* atp,
@@ -407,6 +422,11 @@ int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* const* weig
 int rnamsm_timing_enable(int on);
 int rnamsm_timing_collect(void);
 int rnamsm_timing_get(int category, const char** name, long long* launches, double* ms, double* flops, double* bytes);
+/* Roofline terms of the timed launches of a category: bound_ms = sum over launches of max(executed matrix flops / the dense
+ * peak of the launch's MFMA family, algorithmic bytes / the achievable HBM rate), plus both terms summed separately
+ * (peaks from MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 MFMA, 2.5 PFLOP/s bf16 / f16 MFMA, 6.3 TB/s HBM).  bound_ms / ms is
+ * the fraction of its own roofline a kernel family reached (bench.py's `roofline` of the 16-bit modes). */
+int rnamsm_timing_get_bound(int category, double* bound_ms, double* mfma_ms, double* hbm_ms);
 void rnamsm_timing_reset(void);
 
 /* Knobs for in-process A/B measurements.  Known names:

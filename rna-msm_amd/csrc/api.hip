@@ -25,12 +25,13 @@ int fail(int code, const char* fmt, ...) {
 namespace {
 struct Record {
     int category;
-    double flops, bytes;
+    double flops, bytes, mfma_s, hbm_s;
     hipEvent_t start, stop;
 };
 struct Totals {
     long long launches = 0;
     double ms = 0, flops = 0, bytes = 0;
+    double bound_ms = 0, mfma_ms = 0, hbm_ms = 0;      // sums over launches of max(mfma, hbm), mfma, hbm time at the peaks
 };
 std::mutex g_tmu;
 bool g_ton = false;
@@ -52,9 +53,9 @@ hipEvent_t take_event() {
 }  // namespace
 
 bool timing_enabled() { return g_ton; }
-void timing_begin(int category, double flops, double bytes, hipStream_t stream) {
+void timing_begin(int category, double flops, double bytes, double mfma_s, double hbm_s, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_tmu);
-    Record r{category, flops, bytes, take_event(), take_event()};
+    Record r{category, flops, bytes, mfma_s, hbm_s, take_event(), take_event()};
     (void)hipEventRecord(r.start, stream);
     g_pending.push_back(r);
 }
@@ -80,6 +81,9 @@ extern "C" int rnamsm_timing_collect(void) {
             t.ms += ms;
             t.flops += r.flops;
             t.bytes += r.bytes;
+            t.bound_ms += 1e3 * (r.mfma_s > r.hbm_s ? r.mfma_s : r.hbm_s);
+            t.mfma_ms += 1e3 * r.mfma_s;
+            t.hbm_ms += 1e3 * r.hbm_s;
         }
         g_free.push_back(r.start);
         g_free.push_back(r.stop);
@@ -97,6 +101,15 @@ extern "C" int rnamsm_timing_get(int category, const char** name, long long* lau
     if (ms) *ms = g_tot[category].ms;
     if (flops) *flops = g_tot[category].flops;
     if (bytes) *bytes = g_tot[category].bytes;
+    return RNAMSM_OK;
+}
+extern "C" int rnamsm_timing_get_bound(int category, double* bound_ms, double* mfma_ms, double* hbm_ms) {
+    using namespace rnamsm;
+    if (category < 0 || category >= TC_COUNT) return fail(RNAMSM_ERR_INVALID, "timing_get_bound: bad category %d", category);
+    std::lock_guard<std::mutex> lk(g_tmu);
+    if (bound_ms) *bound_ms = g_tot[category].bound_ms;
+    if (mfma_ms) *mfma_ms = g_tot[category].mfma_ms;
+    if (hbm_ms) *hbm_ms = g_tot[category].hbm_ms;
     return RNAMSM_OK;
 }
 extern "C" void rnamsm_timing_reset(void) {

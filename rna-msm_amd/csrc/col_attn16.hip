@@ -244,7 +244,8 @@ extern "C" int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, con
     const int npl = q_lo ? 2 : 1;
     const int jc = q_lo ? 32 : 64;
     const int lds = 2 * 2 * npl * jc * T16_ROWB;
-    KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)R * R * 64, (2.0 * npl * 3.0 + 4.0) * R * C * H * 64, s);
+    KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)R * R * 64, (2.0 * npl * 3.0 + (ctx_hi ? 2.0 * npl : 4.0)) * R * C * H * 64, s,
+                      PEAK_F16_MFMA_TFLOPS, q_lo ? 3.0 : 1.0);
 #define CA_GO(SP_, FMT_, OUT_)                                                                                      \
     do {                                                                                                            \
         if (pad_mask) CA_GO2(SP_, FMT_, OUT_, true); else CA_GO2(SP_, FMT_, OUT_, false);                           \

@@ -30,14 +30,25 @@ int fail(int code, const char* fmt, ...);
 enum TimingCategory {
     TC_GEMM = 0, TC_ROW_LOGITS, TC_SOFTMAX, TC_ROW_APPLY, TC_COL_ATTN, TC_LAYERNORM, TC_EMBED, TC_PACK, TC_COUNT
 };
+// Roofline terms of one launch (MI355X_MICROARCH.md): dense matrix peak of the instruction family it issues and the
+// HBM rate a streaming kernel can reach.  A launch's bound is max(executed flops / matrix peak, algorithmic bytes / HBM
+// rate); rnamsm_timing_get_bound sums it per category, so a mode's kernels are each priced against their OWN limit
+// (in the 16-bit modes out_proj, the LayerNorms and the attention kernels are HBM-bound, QKV / fc1 matrix-bound).
+constexpr double PEAK_F32_MFMA_TFLOPS = 157.3;     // v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+constexpr double PEAK_F16_MFMA_TFLOPS = 2500.0;    // dense bf16 / f16 MFMA
+constexpr double PEAK_HBM_TBPS = 6.3;              // measured float4 copy (8 TB/s spec)
 bool timing_enabled();
-void timing_begin(int category, double flops, double bytes, hipStream_t stream);
+void timing_begin(int category, double flops, double bytes, double mfma_s, double hbm_s, hipStream_t stream);
 void timing_end(hipStream_t stream);
 struct KernelTimer {   // brackets one launch with two hipEventRecord calls when timing is on
     hipStream_t s;
     bool on;
-    KernelTimer(int category, double flops, double bytes, hipStream_t stream) : s(stream), on(timing_enabled()) {
-        if (on) timing_begin(category, flops, bytes, s);
+    // flops / bytes: ALGORITHMIC work of the launch; peak_tflops: matrix peak of its MFMA family; flop_mult: executed MFMA
+    // flops per algorithmic flop (3 in the hi/lo-split modes)
+    KernelTimer(int category, double flops, double bytes, hipStream_t stream, double peak_tflops = PEAK_F32_MFMA_TFLOPS,
+                double flop_mult = 1.0)
+        : s(stream), on(timing_enabled()) {
+        if (on) timing_begin(category, flops, bytes, flop_mult * flops / (peak_tflops * 1e12), bytes / (PEAK_HBM_TBPS * 1e12), s);
     }
     ~KernelTimer() {
         if (on) timing_end(s);
@@ -244,10 +255,18 @@ int row_apply_batched(const float* probs, const float* v, int64_t ld, float* ctx
 int col_attn_batched(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
                      int batch, int64_t qkv_bstride, int64_t ctx_bstride, const uint8_t* pad_mask, void* stream);
 
-// ragged batches (elementwise.hip): per-token q scale (0 at <pad>, 1/sqrt(true depth of the token's MSA) elsewhere) and its
-// application to the q columns of a QKV activation
+// ragged batches (elementwise.hip): per-token q factor (0 at <pad>, 1/sqrt(true depth of the token's MSA) elsewhere), applied
+// to the q columns in the QKV GEMM's epilogue (rnamsm_gemm_row_scaled)
 int ragged_row_scale(const int64_t* tokens, int pad_idx, const int* true_rows, float* out, int64_t n, int64_t tokens_per_msa,
                      hipStream_t stream);
-int scale_rows(float* x, int64_t ld, const float* row_scale, int64_t T, int ncols, hipStream_t stream);
+
+// K0 / K10 of a batch of B same-shape alignments in ONE launch each (elementwise.hip; rnamsm_forward_batch): tokens [B,R,C] ->
+// x [B*R*C, D] (row positions restart per alignment); emb / atp of alignment b from x_final + b * x_bstride and
+// probs_all + b * probs_bstride.  pack_outputs sets bit 2 of *err_flag (RNAMSM_ERR_NONFINITE) when an output is inf / NaN.
+int embed_ln_batched(const int64_t* tokens, const float* embed_tokens, const float* embed_positions, const float* row_pos,
+                     const float* gamma, const float* beta, float* out, int B, int R, int C, int D, int vocab, int num_positions,
+                     int pad_idx, float eps, int* err_flag, hipStream_t stream);
+int pack_outputs_batched(const float* x_final, const float* probs_all, float* emb, float* atp, int C, int D, int num_layers, int H,
+                         int B, int64_t x_bstride, int64_t probs_bstride, int* err_flag, hipStream_t stream);
 
 }  // namespace rnamsm

@@ -149,14 +149,16 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
                                                        const float* __restrict__ row_pos,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ out, int R, int C, int D, int vocab,
-                                                       int num_positions, int pad_idx, float eps, int* err_flag) {
+                                                       int num_positions, int pad_idx, float eps, int* err_flag, int B) {
+    // tokens [B, R, C] -> out [B*R*C, D]: the row-position table restarts with every alignment (r = global row mod R)
     const int lane = threadIdx.x & 63;
     const int nvec = D / 4;
-    const int64_t T = (int64_t)R * C;
+    const int64_t T = (int64_t)B * R * C;
     const int64_t stride = (int64_t)gridDim.x * 4;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += stride) {
-        const int r = (int)(row / C), c = (int)(row % C);
-        const int64_t* trow = tokens + (int64_t)r * C;
+        const int64_t rg = row / C;
+        const int r = (int)(rg % R), c = (int)(row % C);
+        const int64_t* trow = tokens + rg * C;
         // pos = cumsum(tok != pad)[c] * (tok[c] != pad) + pad   (modules.py:288-290)
         int count = 0;
         for (int base = 0; base <= c; base += 64) {
@@ -225,22 +227,34 @@ __global__ __launch_bounds__(256) void zero_plane_rows_kernel(uint16_t* __restri
     }
 }
 
+// blockIdx.y = alignment of a batch (operands b * stride further on).  err_flag (may be null): bit 2 is set when an output
+// value is not finite -- in the 16-bit modes an operand outside fp16 range surfaces as inf / NaN here, and the host reads
+// this one word instead of reducing over the outputs (RNAMSM_ERR_NONFINITE).
 __global__ __launch_bounds__(256) void pack_outputs_kernel(const float* __restrict__ x_final,
                                                            const float* __restrict__ probs_all,
                                                            float* __restrict__ emb, float* __restrict__ atp, int C,
-                                                           int D, int64_t n_emb, int64_t n_atp) {
+                                                           int D, int64_t n_emb, int64_t n_atp, int64_t x_bstride,
+                                                           int64_t probs_bstride, int* err_flag) {
     const int L = C - 1;
+    x_final += blockIdx.y * x_bstride;
+    probs_all += blockIdx.y * probs_bstride;
+    emb += blockIdx.y * n_emb;
+    atp += blockIdx.y * n_atp;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_emb + n_atp; idx += stride) {
+        float v;
         if (idx < n_emb) {
             const int64_t cpos = idx / D, d = idx % D;                        // emb[c-1, d] = x_final[row 0, c, d]
-            emb[idx] = x_final[(cpos + 1) * D + d];
+            emb[idx] = v = x_final[(cpos + 1) * D + d];
         } else {
             const int64_t a = idx - n_emb;
             const int64_t j = a % L, i = (a / L) % L, ch = a / ((int64_t)L * L);
-            atp[a] = probs_all[(ch * C + (i + 1)) * C + (j + 1)];
+            atp[a] = v = probs_all[(ch * C + (i + 1)) * C + (j + 1)];
         }
+        bad |= !(fabsf(v) <= 3.4028234663852886e38f);                         // inf or NaN
     }
+    if (err_flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(err_flag, 4);
 }
 
 static unsigned rows_grid(int64_t rows) {
@@ -310,13 +324,34 @@ extern "C" int rnamsm_embed_ln(const int64_t* tokens, const float* embed_tokens,
                     "Using model with MSA position embedding trained on maximum MSA depth of 1024, but received %d alignments.", R);
     RNAMSM_CHECK_ARG(aligned16(embed_tokens) && aligned16(embed_positions) && aligned16(out) && aligned16(gamma) && aligned16(beta),
                      "embed_ln: 16-byte alignment");
-    KernelTimer timer(TC_EMBED, 0.0, 12.0 * R * C * D + 8.0 * R * C, static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid((int64_t)R * C)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       tokens, embed_tokens, embed_positions, row_pos, gamma, beta, out, R, C, D, vocab, num_positions,
-                       pad_idx, eps, err_flag);
+    return embed_ln_batched(tokens, embed_tokens, embed_positions, row_pos, gamma, beta, out, 1, R, C, D, vocab, num_positions,
+                            pad_idx, eps, err_flag, static_cast<hipStream_t>(stream));
+}
+
+namespace rnamsm {
+int embed_ln_batched(const int64_t* tokens, const float* embed_tokens, const float* embed_positions, const float* row_pos,
+                     const float* gamma, const float* beta, float* out, int B, int R, int C, int D, int vocab, int num_positions,
+                     int pad_idx, float eps, int* err_flag, hipStream_t stream) {
+    const int64_t T = (int64_t)B * R * C;
+    KernelTimer timer(TC_EMBED, 0.0, 12.0 * T * D + 8.0 * T, stream);
+    hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid(T)), dim3(256), 0, stream, tokens, embed_tokens, embed_positions, row_pos,
+                       gamma, beta, out, R, C, D, vocab, num_positions, pad_idx, eps, err_flag, B);
     RNAMSM_CHECK_LAUNCH("embed_ln");
     return RNAMSM_OK;
 }
+int pack_outputs_batched(const float* x_final, const float* probs_all, float* emb, float* atp, int C, int D, int num_layers, int H,
+                         int B, int64_t x_bstride, int64_t probs_bstride, int* err_flag, hipStream_t stream) {
+    const int64_t L = C - 1;
+    const int64_t n_emb = L * D, n_atp = (int64_t)num_layers * H * L * L;
+    const int64_t blocks = (n_emb + n_atp + 255) / 256;
+    const int64_t cap = B > 1 ? 2048 : 8192;
+    KernelTimer timer(TC_PACK, 0.0, 8.0 * B * (n_emb + n_atp), stream);
+    hipLaunchKernelGGL(pack_outputs_kernel, dim3((unsigned)(blocks < cap ? blocks : cap), (unsigned)B), dim3(256), 0, stream, x_final,
+                       probs_all, emb, atp, C, D, n_emb, n_atp, x_bstride, probs_bstride, err_flag);
+    RNAMSM_CHECK_LAUNCH("pack_outputs");
+    return RNAMSM_OK;
+}
+}  // namespace rnamsm
 
 namespace rnamsm {
 // Ragged batches (rnamsm_forward_batch with true_rows): the q scale of the tied row attention per token --
@@ -330,30 +365,11 @@ __global__ __launch_bounds__(256) void ragged_row_scale_kernel(const int64_t* __
     const int r = true_rows[t / tokens_per_msa];
     out[t] = tokens[t] == pad_idx ? 0.f : 1.0f / sqrtf((float)(r > 0 ? r : 1));
 }
-// x[t, 0 .. ncols) *= row_scale[t]   (the q third of a QKV activation, row stride ld); one wave per row
-__global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ x, int64_t ld, const float* __restrict__ row_scale,
-                                                         int64_t T, int ncols) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= T) return;
-    const float s = row_scale[row];
-    float* p = x + row * ld;
-    for (int c = (threadIdx.x & 63) * 4; c < ncols; c += 256) {
-        f32x4 v = *reinterpret_cast<f32x4*>(p + c);
-        v *= s;
-        *reinterpret_cast<f32x4*>(p + c) = v;
-    }
-}
 int ragged_row_scale(const int64_t* tokens, int pad_idx, const int* true_rows, float* out, int64_t n, int64_t tokens_per_msa,
                      hipStream_t stream) {
     hipLaunchKernelGGL(ragged_row_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tokens, pad_idx, true_rows,
                        out, n, tokens_per_msa);
     RNAMSM_CHECK_LAUNCH("ragged_row_scale");
-    return RNAMSM_OK;
-}
-int scale_rows(float* x, int64_t ld, const float* row_scale, int64_t T, int ncols, hipStream_t stream) {
-    RNAMSM_CHECK_ARG(x && row_scale && T > 0 && ncols > 0 && ncols % 4 == 0 && ld % 4 == 0 && aligned16(x), "scale_rows: bad arguments");
-    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, stream, x, ld, row_scale, T, ncols);
-    RNAMSM_CHECK_LAUNCH("scale_rows");
     return RNAMSM_OK;
 }
 }  // namespace rnamsm
@@ -390,12 +406,5 @@ extern "C" int rnamsm_pack_outputs(const float* x_final, const float* probs_all,
                                    int num_layers, int H, void* stream) {
     RNAMSM_CHECK_ARG(x_final && probs_all && emb && atp, "pack_outputs: null pointer");
     RNAMSM_CHECK_ARG(C >= 2 && D > 0 && num_layers > 0 && H > 0, "pack_outputs: bad shape C=%d D=%d", C, D);
-    const int64_t L = C - 1;
-    const int64_t n_emb = L * D, n_atp = (int64_t)num_layers * H * L * L;
-    const int64_t blocks = (n_emb + n_atp + 255) / 256;
-    KernelTimer timer(TC_PACK, 0.0, 8.0 * (n_emb + n_atp), static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(pack_outputs_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x_final, probs_all, emb, atp, C, D, n_emb, n_atp);
-    RNAMSM_CHECK_LAUNCH("pack_outputs");
-    return RNAMSM_OK;
+    return pack_outputs_batched(x_final, probs_all, emb, atp, C, D, num_layers, H, 1, 0, 0, nullptr, static_cast<hipStream_t>(stream));
 }

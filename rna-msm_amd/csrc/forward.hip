@@ -289,7 +289,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             FWD(lin_normed(l, 2, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], 0, hidden, F, Tq, F, RNAMSM_ACT_GELU_ERF, 1.f, 0));
             FWD(res_linear(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], Tq, F));
             FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, Tq, D, d.ln_eps, stream));
-            FWD(rnamsm_pack_outputs(repr, row_attn, emb, atp, C, D, NL, H, stream));
+            FWD(rnamsm::pack_outputs_batched(repr, row_attn, emb, atp, C, D, NL, H, 1, 0, 0, err_flag, static_cast<hipStream_t>(stream)));
             return RNAMSM_OK;
         }
         // ---- column attention block
@@ -346,7 +346,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         }
     }
     FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
-    FWD(rnamsm_pack_outputs(repr, row_attn, emb, atp, C, D, NL, H, stream));
+    FWD(rnamsm::pack_outputs_batched(repr, row_attn, emb, atp, C, D, NL, H, 1, 0, 0, err_flag, static_cast<hipStream_t>(stream)));
     return RNAMSM_OK;
 }
 
@@ -423,7 +423,9 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
     const int f32 = RNAMSM_F32;
     const int nsplit = rnamsm_row_logits_nsplit(R, C, H);
     const int fold_mode = tuning().ln_fold;
-    const bool fold = ln_folded && !has_padding && (fold_mode == 3 || (fold_mode == 1 && T >= 18432));   // statistics from the producers only
+    // statistics from the producers only; a ragged batch (true_rows) keeps the LayerNorm launches: its QKV GEMM carries the
+    // per-token q factor in the epilogue slot the fold would need
+    const bool fold = ln_folded && !has_padding && !true_rows && (fold_mode == 3 || (fold_mode == 1 && T >= 18432));
     // f2: the batch contains <pad> (ragged MSAs padded to one shape): the reference's direct-path mask semantics as in
     // rnamsm_forward -- zeroed embeddings (K0) and q (QKV epilogue) at padded tokens, -10000 on keys whose first-row token is
     // <pad> (tied rows) and on padded keys (columns); every MSA reads its own [R, C] slice of the mask
@@ -461,10 +463,10 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
         return rnamsm_gemm_bias_act_res(A, lda, Wf, bias, x, D, x, D, T, D, K, RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream);
     };
 
-    for (int b = 0; b < B; ++b)        // K0 per MSA: the row-position table restarts with every alignment
-        FWD(rnamsm_embed_ln(tokens + b * Tm, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
-                            G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x + b * Tm * D, R, C, D, d.vocab, d.num_positions,
-                            d.pad_idx, d.ln_eps, err_flag, stream));
+    // K0 of the whole batch in one launch (the row-position table restarts with every alignment: row index mod R)
+    FWD(rnamsm::embed_ln_batched(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
+                                 G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, B, R, C, D, d.vocab, d.num_positions, d.pad_idx,
+                                 d.ln_eps, err_flag, hs));
     if (fold) {
         FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
         FWD(rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream));
@@ -473,10 +475,10 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
         const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
         // ---- tied row attention: projections over the batch, K4-K6 per MSA
         FWD(norm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
-        if (true_rows) {       // q = (x Wq^T + bq) dh^-1/2, then per token: 0 at <pad>, 1/sqrt(true depth) elsewhere
-            FWD(lin_normed(l, 0, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, row_scale, D));
-            FWD(rnamsm::scale_rows(qkv, ldq, qscale, T, D, hs));
-        } else if (mask)     // q *= 1 - padding_mask (modules.py:767-772) in the epilogue
+        if (true_rows)         // q = ((x Wq^T + bq) dh^-1/2) * (0 at <pad>, 1/sqrt(true depth) elsewhere), per token, in the epilogue
+            FWD(rnamsm_gemm_row_scaled(xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, T, 3 * D, D, row_scale, D, qscale,
+                                       f32, stream));
+        else if (mask)     // q *= 1 - padding_mask (modules.py:767-772) in the epilogue
             FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, T, 3 * D, D,
                                          RNAMSM_ACT_NONE, row_scale, D, mask, f32, stream));
         else
@@ -500,8 +502,7 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
         FWD(res_linear(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], F));
     }
     FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
-    for (int b = 0; b < B; ++b)
-        FWD(rnamsm_pack_outputs(repr + b * Tm * D, row_attn + (int64_t)b * NL * H * C * C, emb + (int64_t)b * (C - 1) * D,
-                                atp + (int64_t)b * NL * H * (C - 1) * (C - 1), C, D, NL, H, stream));
+    // K10 of the whole batch in one launch (gridDim.y = alignment)
+    FWD(rnamsm::pack_outputs_batched(repr, row_attn, emb, atp, C, D, NL, H, B, Tm * D, (int64_t)NL * H * C * C, err_flag, hs));
     return RNAMSM_OK;
 }

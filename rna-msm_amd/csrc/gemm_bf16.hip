@@ -354,6 +354,12 @@ __global__ __launch_bounds__(HB_THREADS, SPLIT == 3 ? 1 : 2) void gemm_bf16_kern
                                                 Cout, ldc, M, scale, scale_cols, Ohi, Olo);
 }
 
+// Algorithmic HBM bytes of a plane-input 16-bit GEMM launch: both operands once as `npl` 16-bit planes, the output once
+// (planes, or the fp32 residual stream) and the residual read.
+static inline double gemm16_bytes(double M, double N, double K, int npl, bool has_res, bool out_planes) {
+    return 2.0 * npl * (M * K + N * K) + (out_planes ? 2.0 * npl : 4.0) * M * N + (has_res ? 4.0 * M * N : 0.0);
+}
+
 // ---- plane-input GEMM with LDS-DMA staging -------------------------------------------------------------------------
 // Both operands are 16-bit planes in HBM (A from rnamsm_layernorm_split / an O_PL epilogue, W from rnamsm_split_bf16), so
 // they go global -> LDS by global_load_lds_dwordx4 with no VGPR and no ds_write: the register-staged kernel above is
@@ -473,7 +479,7 @@ static int launch_hd(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
         configured.mark();
     }
     const unsigned grid = xcd_panel_grid((M + HB_BM - 1) / HB_BM, N / HB_BN);
-    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 2.0 * HdCfg<SPLIT>::NPL * ((double)M * K + (double)N * K) + 4.0 * (double)M * N * (HAS_RES ? 2 : 1), stream);
+    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, gemm16_bytes(M, N, K, HdCfg<SPLIT>::NPL, HAS_RES, O_PL), stream, PEAK_F16_MFMA_TFLOPS, SPLIT);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HB_THREADS), lds, stream, a_hi, a_lo, lda, Whi, Wlo, bias, residual, ldr, Cout,
                        ldc, M, N, K, scale, scale_cols, o_hi, o_lo);
     RNAMSM_CHECK_LAUNCH("gemm16_dma");
@@ -616,7 +622,7 @@ static int launch_hx(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
         configured.mark();
     }
     const unsigned grid = xcd_panel_grid((M + HX_BM - 1) / HX_BM, N / HX_BN);
-    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 2.0 * HxCfg<SPLIT>::NPL * ((double)M * K + (double)N * K) + 4.0 * (double)M * N * (HAS_RES ? 2 : 1), stream);
+    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, gemm16_bytes(M, N, K, HxCfg<SPLIT>::NPL, HAS_RES, O_PL), stream, PEAK_F16_MFMA_TFLOPS, SPLIT);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, a_lo, lda, Whi, Wlo, bias, residual, ldr, Cout,
                        ldc, M, N, K, scale, scale_cols, o_hi, o_lo);
     RNAMSM_CHECK_LAUNCH("gemm16_dma256");
@@ -815,7 +821,10 @@ static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
     // start offset step in cycles
     const unsigned pb = tuning().gemm16_persist > 0 ? (unsigned)tuning().gemm16_persist : 0u;
     const unsigned grid = pb && pb < total ? pb : total;
-    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 2.0 * HxCfg<SPLIT>::NPL * ((double)M * K + (double)N * K) + 4.0 * (double)M * N * (HAS_RES ? 2 : 1), stream);
+    // (a folded-LayerNorm producer also writes the new residual stream as planes: the next consumer's A operand)
+    KernelTimer timer(TC_GEMM, 2.0 * M * N * K,
+                      gemm16_bytes(M, N, K, HxCfg<SPLIT>::NPL, HAS_RES, O_PL) + (fa.xhi ? 2.0 * HxCfg<SPLIT>::NPL * (double)M * N : 0.0),
+                      stream, PEAK_F16_MFMA_TFLOPS, SPLIT);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, a_lo, lda, Whi, Wlo, bias, residual, ldr, Cout,
                        ldc, M, N, K, scale, scale_cols, o_hi, o_lo, group, total, pb ? tuning().gemm16_stagger : 0, fa);
     RNAMSM_CHECK_LAUNCH("gemm16_swp");
@@ -1108,7 +1117,7 @@ static int launch_hq(const uint16_t* Whi, const float* bias, const float* residu
     const unsigned total = xcd_panel_grid_grouped((M + HX_BM - 1) / HX_BM, N / HX_BN, (unsigned)group);
     const unsigned pb = tuning().gemm16_persist > 0 ? (unsigned)tuning().gemm16_persist : 0u;
     const unsigned grid = pb && pb < total ? pb : total;
-    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * N * (HAS_RES ? 2 : 1), stream);
+    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, gemm16_bytes(M, N, K, 1, HAS_RES, O_PL), stream, PEAK_F16_MFMA_TFLOPS, 1.0);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, lda, Whi, bias, residual, ldr, Cout, ldc, M, N, K,
                        scale, scale_cols, o_hi, group, total, fa);
     RNAMSM_CHECK_LAUNCH("gemm16_q16");
@@ -1197,7 +1206,9 @@ static int launch_hb(const float* A, int64_t lda, const uint16_t* Whi, const uin
         configured.mark();
     }
     const unsigned grid = xcd_panel_grid((M + HB_BM - 1) / HB_BM, N / HB_BN);
-    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + 0.5 * HbCfg<SPLIT>::NPL * (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
+    KernelTimer timer(TC_GEMM, 2.0 * M * N * K,
+                      (A_PL ? 2.0 * HbCfg<SPLIT>::NPL : 4.0) * (double)M * K + gemm16_bytes(M, N, 0, HbCfg<SPLIT>::NPL, HAS_RES, O_PL) +
+                          2.0 * HbCfg<SPLIT>::NPL * (double)N * K, stream, PEAK_F16_MFMA_TFLOPS, SPLIT);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HB_THREADS), lds, stream, A, lda, Whi, Wlo, bias, residual, ldr, Cout, ldc, M,
                        N, K, scale, scale_cols, pl.a_hi, pl.a_lo, pl.o_hi, pl.o_lo);
     RNAMSM_CHECK_LAUNCH("gemm_bf16");
@@ -1373,7 +1384,7 @@ extern "C" int rnamsm_layernorm_split(const float* x, const float* gamma, const 
                      (!lo || (reinterpret_cast<uintptr_t>(lo) & 7u) == 0), "layernorm_split: alignment");
     const int64_t blocks = (T + 3) / 4;
     const dim3 grid((unsigned)(blocks < 4096 ? blocks : 4096));
-    KernelTimer timer(TC_LAYERNORM, 0.0, (4.0 + (lo ? 4.0 : 2.0)) * T * D, static_cast<hipStream_t>(stream));
+    KernelTimer timer(TC_LAYERNORM, 0.0, (4.0 + (lo ? 4.0 : 2.0)) * T * D, static_cast<hipStream_t>(stream), PEAK_F16_MFMA_TFLOPS);
     if (fmt == 1)
         hipLaunchKernelGGL(layernorm_split_kernel<1>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, gamma, beta, hi, lo, T, D, eps);
     else

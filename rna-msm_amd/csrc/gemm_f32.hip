@@ -49,11 +49,14 @@ __device__ __forceinline__ float sum8_dpp(float v) {
     return v;
 }
 
-template <int ACT, bool HAS_RES, bool ZROWS, int NT, int FOLD = 0, bool STATS = false>
+// ZROWS: 0 = none; 1 = zero_rows is a uint8 mask, the scaled (q) columns of flagged rows are zeroed (f2: q *= 1 - padding_mask);
+// 2 = zero_rows is a float per-row factor multiplying the scaled columns after `scale` (ragged batches: 0 at <pad>,
+// 1/sqrt(true depth) elsewhere -- the general form of 1).
+template <int ACT, bool HAS_RES, int ZROWS, int NT, int FOLD = 0, bool STATS = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc,
-    int M, int N, int K, float scale, int scale_cols, const uint8_t* __restrict__ zero_rows, int group,
+    int M, int N, int K, float scale, int scale_cols, const void* __restrict__ zero_rows, int group,
     const float* __restrict__ fold_c, float ln_eps, float* row_partials, int64_t pld, int* fold_flag) {
     using Cfg = GemmCfg<NT>;
     constexpr int BN_ = Cfg::BN_, TILE_W = Cfg::TILE_W;
@@ -214,7 +217,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
         ov[i] = *reinterpret_cast<const f32x4*>(&stage[r * LDE + ec]);
         if (HAS_RES) ov[i] += res[i];
         // f2: q *= 1 - padding_mask (modules.py:767-772): padded tokens get q = 0 (the scaled columns are q)
-        if (ZROWS && gn < scale_cols && zero_rows[min(gm0 + r, M - 1)]) ov[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ZROWS == 1 && gn < scale_cols && static_cast<const uint8_t*>(zero_rows)[min(gm0 + r, M - 1)]) ov[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ZROWS == 2 && gn < scale_cols) ov[i] *= static_cast<const float*>(zero_rows)[min(gm0 + r, M - 1)];
     }
     if (STATS) {
         // What this lane stores of row r: 4 of the 32 columns its group of 8 lanes covers.  A second pass over the finished
@@ -253,10 +257,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
     }
 }
 
-template <int ACT, bool HAS_RES, bool ZROWS, int NT, int FOLD = 0, bool STATS = false>
+template <int ACT, bool HAS_RES, int ZROWS, int NT, int FOLD = 0, bool STATS = false>
 static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                           int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
-                          const uint8_t* zero_rows, hipStream_t stream, const float* fold_c = nullptr,
+                          const void* zero_rows, hipStream_t stream, const float* fold_c = nullptr,
                           float ln_eps = 0.f, float* row_partials = nullptr, int64_t pld = 0, int* fold_flag = nullptr,
                           int ksplit = 0) {
     using Cfg = GemmCfg<NT>;
@@ -302,13 +306,16 @@ static inline bool half_width_tiles_win(int M, int N) {
     return 0.5175 * cu_time(mp * (N / 64)) < 0.97 * cu_time(mp * (N / 128));
 }
 
-template <int ACT, bool HAS_RES, bool ZROWS = false>
+template <int ACT, bool HAS_RES, int ZROWS = 0>
 static int launch_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                        int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
-                       const uint8_t* zero_rows, hipStream_t stream) {
+                       const void* zero_rows, hipStream_t stream) {
+    if (ZROWS == 2 && half_width_tiles_win(M, N))       // ragged batches are small problems: keep the tile choice
+        return launch_gemm_nt<ACT, HAS_RES, 2, 1>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, scale, scale_cols,
+                                                  zero_rows, stream);
     if (!ZROWS && half_width_tiles_win(M, N))
-        return launch_gemm_nt<ACT, HAS_RES, false, 1>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, scale, scale_cols,
-                                                      zero_rows, stream);
+        return launch_gemm_nt<ACT, HAS_RES, 0, 1>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, scale, scale_cols,
+                                                  zero_rows, stream);
     return launch_gemm_nt<ACT, HAS_RES, ZROWS, 2>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, scale, scale_cols,
                                                   zero_rows, stream);
 }
@@ -319,9 +326,9 @@ static int launch_gemm_fold(const float* X, int64_t ldx, const float* Wg, const 
                             int M, int N, int K, float scale, int scale_cols, hipStream_t stream) {
     float* rp = const_cast<float*>(row_partials);                  // read-only in the FOLD kernels
     if (half_width_tiles_win(M, N))
-        return launch_gemm_nt<ACT, false, false, 1, FOLD>(X, ldx, Wg, dvec, nullptr, 0, Cout, ldc, M, N, K, scale, scale_cols,
+        return launch_gemm_nt<ACT, false, 0, 1, FOLD>(X, ldx, Wg, dvec, nullptr, 0, Cout, ldc, M, N, K, scale, scale_cols,
                                                           nullptr, stream, cvec, ln_eps, rp, pld, fold_flag);
-    return launch_gemm_nt<ACT, false, false, 2, FOLD>(X, ldx, Wg, dvec, nullptr, 0, Cout, ldc, M, N, K, scale, scale_cols,
+    return launch_gemm_nt<ACT, false, 0, 2, FOLD>(X, ldx, Wg, dvec, nullptr, 0, Cout, ldc, M, N, K, scale, scale_cols,
                                                       nullptr, stream, cvec, ln_eps, rp, pld, fold_flag);
 }
 
@@ -330,9 +337,9 @@ static int launch_gemm_res_stats(const float* A, int64_t lda, const float* W, co
                                  int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float* row_partials,
                                  int64_t pld, hipStream_t stream) {
     if (half_width_tiles_win(M, N))
-        return launch_gemm_nt<RNAMSM_ACT_NONE, true, false, 1, 0, true>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, 1.f, 0,
+        return launch_gemm_nt<RNAMSM_ACT_NONE, true, 0, 1, 0, true>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, 1.f, 0,
                                                                         nullptr, stream, nullptr, 0.f, row_partials, pld);
-    return launch_gemm_nt<RNAMSM_ACT_NONE, true, false, 2, 0, true>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, 1.f, 0,
+    return launch_gemm_nt<RNAMSM_ACT_NONE, true, 0, 2, 0, true>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, 1.f, 0,
                                                                     nullptr, stream, nullptr, 0.f, row_partials, pld);
 }
 
@@ -447,10 +454,28 @@ extern "C" int rnamsm_gemm_bias_act_res(const float* A, int64_t lda, const float
     launch_gemm<ACT_, RES_>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, zero_rows, s)
     if (zero_rows) {   // f2: only the QKV projection of row attention uses it (no activation, no residual)
         RNAMSM_CHECK_ARG(act == RNAMSM_ACT_NONE && !residual, "gemm: zero_rows is supported without activation / residual");
-        return launch_gemm<RNAMSM_ACT_NONE, false, true>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale,
-                                                         scale_cols, zero_rows, s);
+        return launch_gemm<RNAMSM_ACT_NONE, false, 1>(A, lda, W, bias, residual, ldr, Cout, ldc, m, N, K, scale,
+                                                      scale_cols, zero_rows, s);
     }
     if (act == RNAMSM_ACT_GELU_ERF) return residual ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, true) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_GELU_ERF, false);
     return residual ? RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_NONE, true) : RNAMSM_GEMM_DISPATCH(RNAMSM_ACT_NONE, false);
 #undef RNAMSM_GEMM_DISPATCH
+}
+
+// K2 with a per-row factor on the scaled columns: Cout[m, n] = ((A W^T + bias)[m, n] * scale) * row_factor[m] for n < scale_cols,
+// (A W^T + bias)[m, n] elsewhere -- the QKV projection of a RAGGED batch (rnamsm_forward_batch with true_rows), where a token's q
+// is scaled by dh^-1/2 / sqrt(the TRUE depth of its own MSA) and zeroed at <pad> (align_scaling and q *= 1 - padding_mask,
+// modules.py:713-715, 767-772): the general form of zero_rows.
+extern "C" int rnamsm_gemm_row_scaled(const float* A, int64_t lda, const float* W, const float* bias, float* Cout, int64_t ldc,
+                                      int64_t M, int N, int K, float scale, int scale_cols, const float* row_factor, int dtype,
+                                      void* stream) {
+    if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "gemm_row_scaled: only RNAMSM_F32 is implemented");
+    RNAMSM_CHECK_ARG(A && W && Cout && row_factor, "gemm_row_scaled: null pointer");
+    RNAMSM_CHECK_ARG(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "gemm_row_scaled: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    RNAMSM_CHECK_ARG(N % BN == 0 && K % BK == 0, "gemm_row_scaled: need N %% 128 == 0 and K %% 32 == 0 (N=%d K=%d)", N, K);
+    RNAMSM_CHECK_ARG(lda >= K && lda % 4 == 0 && ldc >= N && ldc % 4 == 0, "gemm_row_scaled: bad leading dimension");
+    RNAMSM_CHECK_ARG(scale_cols >= 0 && scale_cols <= N && scale_cols % 4 == 0, "gemm_row_scaled: scale_cols must be a multiple of 4 in [0, N]");
+    RNAMSM_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(Cout), "gemm_row_scaled: A, W and Cout must be 16-byte aligned");
+    return launch_gemm<RNAMSM_ACT_NONE, false, 2>(A, lda, W, bias, nullptr, 0, Cout, ldc, (int)M, N, K, scale, scale_cols,
+                                                  row_factor, static_cast<hipStream_t>(stream));
 }

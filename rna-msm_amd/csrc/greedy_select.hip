@@ -310,7 +310,9 @@ using namespace rnamsm;
 
 extern "C" int rnamsm_msa_weights(const uint8_t* msa, int N, int L, double seqid_cutoff, double* weights, void* stream) {
     RNAMSM_CHECK_ARG(msa && weights, "msa_weights: null pointer");
-    RNAMSM_CHECK_ARG(N > 0 && L > 0 && L <= 65536, "msa_weights: bad shape N=%d L=%d", N, L);
+    // the row under comparison is held in L bytes of dynamic LDS next to a static counter: the default 64 KB limit is never
+    // raised, so L is capped where that fits with room to spare (alignments are cropped to 1024 columns upstream)
+    RNAMSM_CHECK_ARG(N > 0 && L > 0 && L <= 32768, "msa_weights: bad shape N=%d L=%d (L <= 32768)", N, L);
     int G = 1;
     while (G < L && G < 64) G <<= 1;
     hipLaunchKernelGGL(msa_weights_kernel, dim3((unsigned)N), dim3(256), (size_t)L, static_cast<hipStream_t>(stream), msa, N,

@@ -604,7 +604,8 @@ extern "C" int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, c
     const unsigned tiles_c = big ? (C + 255) / 256 : (C + 127) / 128;
     const unsigned grid = xcd_panel_grid((unsigned)(H * sp.nsplit), tiles_c * tiles_c);
     KernelTimer timer(TC_ROW_LOGITS, 2.0 * H * C * C * R * 64,
-                      (q_lo ? 4.0 : 2.0) * 2.0 * R * C * H * 64 + 4.0 * (double)sp.nsplit * H * C * C, s);
+                      (q_lo ? 4.0 : 2.0) * 2.0 * R * C * H * 64 + 4.0 * (double)sp.nsplit * H * C * C, s, PEAK_F16_MFMA_TFLOPS,
+                      q_lo ? 3.0 : 1.0);
 #define RL_GO(SP_, FMT_)                                                                                            \
     do {                                                                                                            \
         if (big) {                                                                                                  \
@@ -654,7 +655,8 @@ extern "C" int rnamsm_row_apply16(const uint16_t* p_hi, const uint16_t* p_lo, in
     const unsigned tiles_i = big ? (C + 255) / 256 : (C + 127) / 128, tiles_n = big ? (R + 3) / 4 : (R + 1) / 2;
     const unsigned grid = xcd_panel_grid((unsigned)H * tiles_n, tiles_i);
     KernelTimer timer(TC_ROW_APPLY, 2.0 * H * C * C * R * 64,
-                      (p_lo ? 4.0 : 2.0) * ((double)R * C * H * 64 + (double)H * C * ldp) + 4.0 * R * C * H * 64, s);
+                      (p_lo ? 4.0 : 2.0) * ((double)R * C * H * 64 + (double)H * C * ldp) + (ctx_hi ? (p_lo ? 4.0 : 2.0) : 4.0) * R * C * H * 64,
+                      s, PEAK_F16_MFMA_TFLOPS, p_lo ? 3.0 : 1.0);
 #define RA_GO(SP_, FMT_, OUT_)                                                                                      \
     do {                                                                                                            \
         if (big) {                                                                                                  \

@@ -41,6 +41,8 @@ _SIGNATURES = {
     "rnamsm_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "rnamsm_gemm_bias_act_res": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                          c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),
+    "rnamsm_gemm_row_scaled": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_float,
+                                       c_int, c_void_p, c_int, c_void_p]),
     "rnamsm_split_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rnamsm_gemm_bf16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                  c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -108,6 +110,7 @@ _SIGNATURES = {
     "rnamsm_timing_collect": (c_int, []),
     "rnamsm_timing_get": (c_int, [c_int, POINTER(c_char_p), POINTER(ctypes.c_longlong), POINTER(ctypes.c_double),
                                   POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
+    "rnamsm_timing_get_bound": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "rnamsm_timing_reset": (None, []),
     "rnamsm_set_param": (c_int, [c_char_p, c_int]),
     "rnamsm_get_param": (c_int, [c_char_p]),
@@ -146,7 +149,8 @@ def check(rc: int) -> None:
 
 
 def kernel_timings() -> dict:
-    """Fold completed HIP-event pairs and return {kernel: {launches, ms, flops, bytes}} (rnamsm_timing_*)."""
+    """Fold completed HIP-event pairs and return {kernel: {launches, ms, flops, bytes, bound_ms, mfma_bound_ms, hbm_bound_ms}}
+    (rnamsm_timing_*; the bounds are per-launch max(matrix, HBM) roofline times summed over the launches)."""
     lib = load()
     n = lib.rnamsm_timing_collect()
     out = {}
@@ -155,5 +159,8 @@ def kernel_timings() -> dict:
         ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         check(lib.rnamsm_timing_get(c, ctypes.byref(name), ctypes.byref(cnt), ctypes.byref(ms), ctypes.byref(fl),
                                     ctypes.byref(by)))
-        out[name.value.decode()] = {"launches": cnt.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+        bd, mf, hb = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        check(lib.rnamsm_timing_get_bound(c, ctypes.byref(bd), ctypes.byref(mf), ctypes.byref(hb)))
+        out[name.value.decode()] = {"launches": cnt.value, "ms": ms.value, "flops": fl.value, "bytes": by.value,
+                                    "bound_ms": bd.value, "mfma_bound_ms": mf.value, "hbm_bound_ms": hb.value}
     return out

@@ -89,7 +89,7 @@ class MSATransformer(nn.Module):
         # at most batch_token_budget tokens -- pays below ~8 k tokens per MSA, where a lone forward leaves the chip idle
         self.batch_small_msas = True
         self.batch_token_budget = 32768
-        self.check_finite = True          # 16-bit modes: verify the outputs are finite, fall back to f32 per MSA otherwise
+        self.check_finite = True          # 16-bit modes, checked_forward_one: non-finite outputs (err bit 2) -> that MSA again on f32
         self._planes = None
         self._folded = None
         self._folded16 = None
@@ -358,23 +358,39 @@ class MSATransformer(nn.Module):
                         "row_attn": out["row_attn"][b, :, :, :cb, :cb], "err": out["err"]})
         return res
 
-    ERR_INDEX, ERR_FOLD = 1, 2            # bits of forward_one's "err": token / position index out of range; a row whose
-                                          # |mean| is so far above its spread that the folded LayerNorm loses > 5 bits
+    # bits of forward_one's "err" (device int32, OR-ed by the kernels): token / position index out of range; a row whose |mean| is
+    # so far above its spread that the folded LayerNorm loses > 5 bits; an emb / atp value that is not finite (K10 looks at
+    # every value it packs: in the 16-bit modes an operand outside fp16 range surfaces there as inf / NaN)
+    ERR_INDEX, ERR_FOLD, ERR_NONFINITE = 1, 2, 4
 
     def checked_forward_one(self, tokens2d: torch.Tensor, has_padding: Optional[bool] = None, need_repr: bool = True,
                             what: str = "MSA") -> Dict[str, torch.Tensor]:
-        """forward_one + the error word read back (one device sync): raises IndexError for out-of-range tokens like the
-        reference's embedding lookup would; an MSA that trips the folded LayerNorm's precondition (rnamsm.h, K1 folded) is
-        computed again with separate LayerNorm launches -- the caller never sees the difference."""
+        """forward_one + the error word read back (ONE device sync, the only one): raises IndexError for out-of-range tokens
+        like the reference's embedding lookup would; an MSA whose 16-bit-mode outputs are not finite is recomputed on the exact
+        path; one that trips the folded LayerNorm's precondition (rnamsm.h, K1 folded) is computed again with separate
+        LayerNorm launches -- the caller never sees the difference."""
         out = self.forward_one(tokens2d, has_padding, need_repr)
         err = int(out["err"].item())
         if err & self.ERR_INDEX:
             raise IndexError(f"{what}: token or position index out of range")
+        import warnings
+        mode = None                                   # None = self.gemm_dtype
+        if (err & self.ERR_NONFINITE) and self.gemm_dtype != "f32" and self.check_finite:
+            # f16x3 / bf16 operands live in 16-bit planes: fp16 overflows above 65504.  The synthetic weights stay far inside;
+            # a real checkpoint is not known to, so the MSA is redone on the exact path rather than written out as NaN
+            warnings.warn(f"{what}: gemm_dtype={self.gemm_dtype!r} produced non-finite outputs (operand outside the 16-bit "
+                          "range); this MSA is recomputed on the exact fp32 path")
+            with torch.cuda.device(tokens2d.device):
+                out = self._forward_one_on_device(tokens2d, has_padding, need_repr, self.fold_layernorm, gemm_dtype="f32")
+            mode = "f32"
+            err = int(out["err"].item())                  # the retry's word: every bit is recomputed by it
+            if err & self.ERR_INDEX:
+                raise IndexError(f"{what}: token or position index out of range")
         if err & self.ERR_FOLD:
-            import warnings
             warnings.warn(f"{what}: a token row's mean exceeds 32x its spread; LayerNorm is applied in its own launches for "
                           "this MSA instead of inside the GEMMs")
-            out = self.forward_one(tokens2d, has_padding, need_repr, fold_layernorm=False)
+            with torch.cuda.device(tokens2d.device):
+                out = self._forward_one_on_device(tokens2d, has_padding, need_repr, False, gemm_dtype=mode)
             if int(out["err"].item()) & self.ERR_INDEX:
                 raise IndexError(f"{what}: token or position index out of range")
         return out
@@ -410,15 +426,6 @@ class MSATransformer(nn.Module):
                                       row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
                                       err.data_ptr(), int(has_padding), max_tokens, _lib.OUT_REPR if need_repr else 0, dtype, planes,
                                       folded, folded16, torch.cuda.current_stream().cuda_stream))
-        if dtype != _lib.F32 and self.check_finite:
-            # f16x3 / bf16 operands live in 16-bit planes: fp16 overflows above 65504 (-> inf/NaN downstream).  The
-            # synthetic weights stay far inside; a real checkpoint is not known to, so the outputs are checked (one
-            # reduction over emb, ~1 us) and the MSA is redone on the exact path rather than written out as NaN
-            if not bool(torch.isfinite(emb).all()):
-                import warnings
-                warnings.warn(f"gemm_dtype={gemm_dtype!r} produced non-finite outputs (operand outside the 16-bit "
-                              "range); this MSA is recomputed on the exact fp32 path")
-                return self._forward_one_on_device(tokens2d, has_padding, need_repr, fold, gemm_dtype="f32")
         pruned = not need_repr and dtype == _lib.F32 and not has_padding and R > 1       # rnamsm_forward's condition
         return {"row_attn": row_attn, "repr": rep[:1] if pruned else rep, "emb": emb, "atp": atp, "err": err}
 

@@ -115,6 +115,21 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 
 @_on_operand_device
+def linear_row_scaled(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], row_factor: torch.Tensor,
+                      scale: float = 1.0, scale_cols: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[m, n] = ((a @ w.T + bias)[m, n] * scale) * row_factor[m] for n < scale_cols, (a @ w.T + bias)[m, n] elsewhere
+    (rnamsm_gemm_row_scaled: the QKV projection of a ragged batch; the general form of linear(zero_rows=...))."""
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_gemm_row_scaled(
+        _dev(a, "a"), _rowmajor(a, "a"), _dev(w.contiguous(), "w"), None if bias is None else _dev(bias, "bias"),
+        _dev(out, "out"), _rowmajor(out, "out"), M, N, K, scale, scale_cols, _dev(row_factor, "row_factor"), F32, _stream()))
+    return out
+
+
+@_on_operand_device
 def ln_fold_weights(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
     """LayerNorm(gamma, beta) folded into the Linear (w [N,K], bias) that consumes it: (Wg [N,K], c [N], d [N]) with
     LN(x) w^T + bias = rstd * (x Wg^T - mean * c) + d  (include/rnamsm.h, K1 folded)."""
@@ -515,7 +530,10 @@ def greedy_select(msa_u8: torch.Tensor, num_seqs: int, mode: str = "max") -> tor
 
 @_on_operand_device
 def msa_weights(msa_u8: torch.Tensor, seqid_cutoff: float = 0.2) -> torch.Tensor:
-    """msa uint8 [N, L] on the device -> float64 [N] sequence weights (MSA.weights, utils/align.py:250-253)."""
+    """msa uint8 [N, L] on the device -> float64 [N] sequence weights (MSA.weights, utils/align.py:250-253); L <= 32768.
+    The reference's pdist runs over the raw character bytes (utils/align.py:121-126); callers here pass TOKEN ids.  The
+    two agree for the alphabet that survives from_fasta's regexes (A/C/G/U/X/-, one token per character); characters that
+    fall to <unk> would be merged by the token form -- the reader raises for those before this is reached."""
     N, L = msa_u8.shape
     out = torch.empty(N, dtype=torch.float64, device=msa_u8.device)
     _lib.check(_lib.load().rnamsm_msa_weights(_dev(msa_u8.contiguous(), "msa", torch.uint8), N, L, float(seqid_cutoff),

@@ -15,6 +15,7 @@ of round k+1.
 """
 from __future__ import annotations
 
+import time
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
@@ -72,6 +73,11 @@ class RoundGatherer:
         self._inflight = None            # (round, works, keepalive, [(index, tensors)])
         self._side = torch.cuda.Stream(self.wire) if (self.world > 1 and self.wire.type == "cuda") else None
         self.bytes_received = 0
+        # how much of the gather was NOT hidden behind compute (diagnostics for the first real multi-GPU run, bench.py):
+        # host seconds this rank spent blocked in _retire, and -- device wire -- event pairs around the compute stream's wait
+        # for the transfer stream (read by stats(), which synchronises)
+        self.host_wait_s = 0.0
+        self._wait_events = []
 
     # ------------------------------------------------------------------ helpers
     def _has_item(self, rnd: int, rank: int) -> bool:
@@ -94,10 +100,18 @@ class RoundGatherer:
             return
         _, works, keep, items = self._inflight
         self._inflight = None
+        t0 = time.perf_counter()
+        cur = torch.cuda.current_stream(self.wire) if self._side is not None else None
+        if cur is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
         for w in works:
             w.wait()
-        if self._side is not None:
-            torch.cuda.current_stream(self.wire).wait_stream(self._side)
+        if cur is not None:
+            cur.wait_stream(self._side)
+            e1.record(cur)
+            self._wait_events.append((e0, e1))
+        self.host_wait_s += time.perf_counter() - t0
         if self.rank == self.dst and self.on_item is not None:
             for index, tensors in sorted(items, key=lambda it: it[0]):
                 self.on_item(index, [t if t.device == self.device else t.to(self.device) for t in tensors])
@@ -109,19 +123,23 @@ class RoundGatherer:
         if self.world == 1:
             self._inflight = (rnd, works, keep, [(index, list(own))])
             return
-        ev = None
-        if self._side is not None and self.rank != self.dst and own is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.wire))      # the payload is complete once this event has fired
+        ev = payload = None
+        if self.rank != self.dst and own is not None:
+            # made contiguous / moved to the wire HERE, on the producer's stream (behind the kernels that wrote the tensors),
+            # never on the side stream ahead of the event: a strided payload would otherwise be copied while its forward may
+            # still be running
+            payload = [t.contiguous().to(self.wire) for t in own]
+            if self._side is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.wire))  # the payload is complete once this event has fired
 
         def comm():
             if self.rank != self.dst:
                 if own is None:
                     return
-                # the header (shapes: known now) travels at once; the payload sends are queued behind the event, i.e.
-                # behind this item's forward.  dst can therefore read the header, post its receives and go on launching
-                # its next forward without waiting for anybody's kernels.
-                payload = [t.contiguous().to(self.wire) for t in own]
+                # the header (shapes: known now; a small host-built tensor of its own) travels at once; the payload sends
+                # are queued behind the event, i.e. behind this item's forward.  dst can therefore read the header, post its
+                # receives and go on launching its next forward without waiting for anybody's kernels.
                 hdr = self._header(payload).to(self.wire)
                 keep.extend([hdr] + payload)
                 works.append(dist.isend(hdr, self.dst, group=self.group))
@@ -162,6 +180,17 @@ class RoundGatherer:
         else:
             comm()
         self._inflight = (rnd, works, keep, items)
+
+    def stats(self) -> Dict[str, float]:
+        """Gather diagnostics of this rank: bytes received, host seconds blocked waiting for transfers, and (device wire)
+        the milliseconds the compute stream stood waiting for the transfer stream -- the part of the gather that was not
+        overlapped with the next forward.  Synchronises the device."""
+        exposed_ms = 0.0
+        if self._wait_events:
+            torch.cuda.synchronize(self.wire)
+            exposed_ms = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        return {"bytes_received": float(self.bytes_received), "host_wait_s": self.host_wait_s,
+                "stream_wait_ms": exposed_ms, "rounds": float(self._round)}
 
     # ------------------------------------------------------------------ API
     def submit(self, index: int, tensors: Sequence[torch.Tensor]) -> None:

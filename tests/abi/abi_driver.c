@@ -136,6 +136,7 @@ int main(void) {
     REFUSED(rnamsm_greedy_select(bytes, 8, 70000, 4, 0, ints, buf, 1 << 16, NULL));
     REFUSED(rnamsm_msa_weights(NULL, 8, 8, 0.2, (double*)buf, NULL));
     REFUSED(rnamsm_msa_weights(bytes, 0, 8, 0.2, (double*)buf, NULL));
+    REFUSED(rnamsm_msa_weights(bytes, 8, 40000, 0.2, (double*)buf, NULL));
     REFUSED(rnamsm_forward(NULL, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 0, NULL, NULL, NULL, NULL));
     REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 9, NULL, NULL, NULL, NULL));
     REFUSED(rnamsm_forward(&dims, weights, toks, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, 0, 1, 3, NULL, NULL, NULL, NULL));

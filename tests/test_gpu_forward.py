@@ -799,3 +799,31 @@ def test_reference_side_callers_run_unchanged(model):
     assert layer(x).shape == x.shape                                      # need_head_weights=False: the tensor alone
     # inside MSATransformer the layers are built without them (the model discards them, model.py:390)
     assert m.layers[0].column_self_attention.layer.return_probs is False
+
+
+def test_16bit_overflow_sets_the_nonfinite_bit_and_is_redone_on_fp32():
+    """the finiteness guard of the 16-bit modes is a bit of the forward's error word (K10 looks at every emb / atp
+    value it packs) -- no reduction and no extra host sync per MSA.  An fc1 scaled so that the hidden activation leaves fp16
+    range: forward_one reports bit 2; checked_forward_one (what the CLI and forward() call) recomputes that MSA on the exact
+    path, warns, and returns what the f32 model returns."""
+    import warnings
+    from rnamsm.model import MSATransformer
+    state = dict(synthetic.make_state_dict(seed=0))
+    for k in ("layers.3.feed_forward_layer.layer.fc1.weight", "layers.3.feed_forward_layer.layer.fc1.bias"):
+        state[k] = state[k] * np.float32(2e5)
+    m = MSATransformer(num_layers=10)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    m = m.eval().to("cuda:0")
+    toks = torch.from_numpy(golden("forward_m8_c17.npz")["tokens"]).to("cuda:0")
+    exact = m.forward_one(toks)
+    assert int(exact["err"].item()) == 0 and bool(torch.isfinite(exact["emb"]).all())
+    m.gemm_dtype = "f16x3"
+    raw = m.forward_one(toks)
+    assert int(raw["err"].item()) & m.ERR_NONFINITE and not bool(torch.isfinite(raw["emb"]).all())
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = m.checked_forward_one(toks, what="overflowing")
+    assert any("recomputed on the exact fp32 path" in str(x.message) for x in w)
+    assert torch.equal(out["emb"], exact["emb"]) and torch.equal(out["atp"], exact["atp"])
+    m.check_finite = False                                         # opt-out: the raw 16-bit result, flagged
+    assert int(m.checked_forward_one(toks)["err"].item()) & m.ERR_NONFINITE

@@ -7,7 +7,7 @@ error the reference's OWN arithmetic makes against the same truth (the oracle in
     bf16 (configs[4])  :  drift(HIP bf16) <= 1.5 x drift(oracle .bfloat16())
 
 i.e. the kernels are held to the reference's own fp32 (bf16) noise at the size in question instead of to a free
-tolerance.  Every number is appended to gpurun_out/r02_fullsize_parity.json (copied to profiles/ when committed).
+tolerance.  Every number is appended to gpurun_out/r03_fullsize_parity.json (copied to profiles/ when committed).
 """
 import json
 import os
@@ -35,7 +35,7 @@ def model():
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     REPORT["_device"] = torch.cuda.get_device_name(0)
-    with open(os.path.join(out_dir, "r02_fullsize_parity.json"), "w") as f:
+    with open(os.path.join(out_dir, "r03_fullsize_parity.json"), "w") as f:
         json.dump(REPORT, f, indent=1)
 
 
@@ -85,6 +85,9 @@ CASES = [
 
 
 CPU_YARDSTICK = {"configs[0]", "configs[1]", "configs[2]", "configs[3]"}     # sizes the CPU oracle finishes in <= ~90 s
+# configs[4] (M = L = 1024): the CPU oracle needs 12.6 minutes of 32 host threads there, so its errors against the same fp64
+# truth were measured ONCE on the GPU box (tests/analysis/yardstick_m1024.py, same tokens, same weights) and committed
+COMMITTED_YARDSTICK = {"configs[4]": "yardstick_m1024_l1024.json"}
 
 
 @pytest.mark.parametrize("label,make", CASES, ids=[c[0].split()[0] for c in CASES])
@@ -92,8 +95,9 @@ def test_every_baseline_config_against_fp64_truth(model, label, make):
     """Yardsticks, all against the same fp64 truth: `oracle_cpu_f32` = the oracle in fp32 on the host's cores, i.e. the
     reference's own arithmetic (PyTorch CPU) at this size -- the bar the HIP exact path and f16x3 are held to (x2);
     `oracle_dev_f32` / `oracle_dev_bf16` = the same code through torch's device kernels (recorded; the bf16 one is the
-    reference's .bfloat16() behaviour and bounds the bf16 mode x1.5; the fp32 one is the only fp32 yardstick that exists
-    at M = L = 1024, where the CPU oracle would need ~15 minutes)."""
+    reference's .bfloat16() behaviour and bounds the bf16 mode x1.5; the fp32 one is 30-60x noisier than the CPU's and is
+    never the bar).  At M = L = 1024 the CPU yardstick is the committed measurement tests/golden/yardstick_m1024_l1024.json
+    (emb rel-L2 8.1e-4: the fixed-order row split of the exact path must stay at or below 2x that -- it measures 4.8e-4)."""
     cfg = label.split()[0]
     toks = make()
     t_emb, t_atp = truth.oracle_outputs(toks, torch.float64, DEV)
@@ -103,7 +107,12 @@ def test_every_baseline_config_against_fp64_truth(model, label, make):
     if cfg in CPU_YARDSTICK:
         torch.set_num_threads(min(32, torch.get_num_threads()))                  # bench.py's sweep: 32 is the fastest
         rep["oracle_cpu_f32"] = truth.errors(*truth.oracle_outputs(toks, torch.float32, "cpu"), t_emb, t_atp)
-    e_ref = rep.get("oracle_cpu_f32", rep["oracle_dev_f32"])
+    if cfg in COMMITTED_YARDSTICK:
+        y = json.load(open(os.path.join(GOLDEN, COMMITTED_YARDSTICK[cfg])))
+        assert y["shape"] == list(toks.shape) and y["token_seed"] == 0
+        rep["oracle_cpu_f32"] = y["oracle_cpu_f32"]
+        rep["oracle_cpu_f32_source"] = f"tests/golden/{COMMITTED_YARDSTICK[cfg]} ({y['cpu_seconds']:.0f} s of {y['threads']} threads, {y['cpu_model']})"
+    e_ref = rep["oracle_cpu_f32"]            # the reference's own fp32 arithmetic (PyTorch CPU): measured here or committed
     for mode in ("f32", "f16x3", "bf16x3", "bf16"):
         rep[f"hip_{mode}"] = truth.errors(*hip_outputs(model, toks, mode), t_emb, t_atp)
     REPORT[label] = rep

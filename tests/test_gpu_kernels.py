@@ -506,6 +506,29 @@ def test_msa_weights_on_device_equal_host_and_reference(dev, full_2drb1_a2m):
         assert np.array_equal(msa.msa_weights(t, cut, device=dev), msa.msa_weights(t, cut)), (N, L)
 
 
+@pytest.mark.parametrize("M,N,K,cols", [(117, 384, 128, 128), (1000, 2304, 768, 768), (300, 128, 64, 0)])
+def test_gemm_with_a_per_row_factor_on_the_scaled_columns(dev, M, N, K, cols):
+    """rnamsm_gemm_row_scaled (the general form of zero_rows): ((x W^T + b) * scale) * f[m] on the first
+    `cols` columns, untouched elsewhere; with f in {0, 1} it IS the zero_rows kernel bit for bit, and it equals the two
+    launches it replaces in the ragged batch driver (GEMM with the scale, then the row factor) bit for bit."""
+    from rnamsm import ops
+    x, w, b = _rand(f"rs.x{M}", (M, K)), _rand(f"rs.w{N}", (N, K), 0.1), _rand(f"rs.b{N}", (N,), 0.1)
+    f = torch.from_numpy(np.abs(synthetic.normal(f"rs.f{M}", 3, (M,))).astype(np.float32))
+    f[::5] = 0.0                                                   # <pad> tokens
+    g = ops.linear_row_scaled(x.to(dev), w.to(dev), b.to(dev), f.to(dev), scale=0.125, scale_cols=cols)
+    want = x.double() @ w.double().t() + b.double()
+    want[:, :cols] *= 0.125 * f.double()[:, None]
+    assert rel_l2(g.cpu(), want) < 3e-6
+    two = ops.linear(x.to(dev), w.to(dev), b.to(dev), scale=0.125, scale_cols=cols)
+    two[:, :cols] *= f.to(dev)[:, None]
+    assert torch.equal(g, two)
+    if cols:
+        ind = (f != 0).to(torch.float32)
+        a = ops.linear_row_scaled(x.to(dev), w.to(dev), b.to(dev), ind.to(dev), scale=0.125, scale_cols=cols)
+        z = ops.linear(x.to(dev), w.to(dev), b.to(dev), scale=0.125, scale_cols=cols, zero_rows=(f == 0).to(torch.uint8).to(dev))
+        assert torch.equal(a, z)
+
+
 def test_padding_mask_kernel_semantics(dev):
     """SURVEY §8 f2 at kernel level: zero_rows on the q columns of the QKV GEMM, -10000 key fill in the row softmax,
     -10000 fill of padded keys in fused column attention (including a fully padded column -> uniform weights)."""

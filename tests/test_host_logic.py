@@ -142,8 +142,8 @@ def test_config_defaults_and_overrides():
                          "model.num_layers=3", "data.max_seqs_per_msa=64", "model.embed_positions_msa=false"])
     assert c.data.root_path == "/x" and c.data.MSA_path == "r2" and c.model.num_layers == 3
     assert c.data.max_seqs_per_msa == 64 and c.model.embed_positions_msa is False
-    assert Config().data.batch_small_msas is False                    # the extra CLI switch is opt-in ...
-    assert parse_overrides(["data.batch_small_msas=true"]).data.batch_small_msas is True
+    assert Config().data.batch_small_msas is True                     # the extra CLI switch: on by default (round 3) ...
+    assert parse_overrides(["data.batch_small_msas=false"]).data.batch_small_msas is False
     with pytest.raises(ValueError):
         parse_overrides(["data.batch_small_msas=maybe"])
     for bad in (["data.nope=1"], ["nogroup.x=1"], ["data.max_seqlen"], ["data.max_seqlen=abc"]):

@@ -116,3 +116,32 @@ def test_single_process_gather_is_identity():
     local = {i: _item(i) for i in range(3)}
     out = sharding.gather_arrays(local, 3)
     assert sorted(out) == [0, 1, 2] and torch.equal(out[1][1], _item(1)[1])
+
+
+def _strided_worker(rank, world, port, q):
+    """payloads need not be contiguous (a transposed view, a column slice) -- the gatherer materialises them
+    before they travel -- and stats() reports what the gather cost this rank."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_items = 4
+        got = {}
+        g = sharding.RoundGatherer(n_items, on_item=lambda i, ts: got.__setitem__(i, [t.clone() for t in ts]), tensors_per_item=2)
+        for idx in sharding.shard_indices(n_items, rank, world):
+            a, b = _item(idx)
+            g.submit(idx, [a.t(), b[:, :, 1:]])                      # both non-contiguous views
+        g.finish()
+        st = g.stats()
+        ok = st["rounds"] == 2 and st["host_wait_s"] >= 0.0 and st["stream_wait_ms"] == 0.0
+        if rank == 0:
+            ok = ok and sorted(got) == list(range(n_items)) and st["bytes_received"] > 0
+            for i in range(n_items):
+                a, b = _item(i)
+                ok = ok and torch.equal(got[i][0], a.t()) and torch.equal(got[i][1], b[:, :, 1:])
+        q.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_of_non_contiguous_payloads_and_stats():
+    assert all(_run(_strided_worker, 2))
