@@ -165,6 +165,10 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm16_mfma16 = value < 0 ? 0 : (value > 2 ? 2 : value);
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "gemm16_pp")) {
+        rnamsm::tuning().gemm16_pp = value != 0;
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "gemm16_persist")) {
         if (value < 0 || value % 8 != 0) return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: gemm16_persist must be a non-negative multiple of 8");
         rnamsm::tuning().gemm16_persist = value;
@@ -193,6 +197,7 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "greedy_fused")) return rnamsm::tuning().greedy_fused;
     if (name && !strcmp(name, "col_dma")) return rnamsm::tuning().col_dma;
     if (name && !strcmp(name, "row16_max_rows")) return rnamsm::tuning().row16_max_rows;
+    if (name && !strcmp(name, "gemm16_pp")) return rnamsm::tuning().gemm16_pp;
     if (name && !strcmp(name, "gemm16_persist")) return rnamsm::tuning().gemm16_persist;
     if (name && !strcmp(name, "gemm16_mfma16")) return rnamsm::tuning().gemm16_mfma16;
     if (name && !strcmp(name, "gemm_splitk")) return rnamsm::tuning().gemm_splitk;

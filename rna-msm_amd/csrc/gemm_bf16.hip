@@ -1267,6 +1267,10 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
     launch_hd<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
 #define HB_ACT_RES(SP_, FMT_)                                                                                       \
     do {                                                                                                            \
+        /* the epilogue-hiding kernel (gemm16_pp.hip): plain bf16, plane input, planes or fp32 (+ residual) out */      \
+        if (SP_ == 1 && A_hi && tuning().gemm16_dma >= 3 && gemm16_pp_eligible(M, N, K, bias) &&                      \
+            (O_hi ? !residual : act == RNAMSM_ACT_NONE))                                                            \
+            return gemm16_pp(A_hi, lda, W_hi, bias, residual, ldr, Cout, ldc, m, N, K, act, scale, scale_cols, O_hi, s); \
         /* 16x16x32 MFMAs: measured +6.5 % on QKV, +1.4 % on fc1, -2.5 % on out_proj, 0 on fc2 (one process, cfg3 shapes): wide N only */ \
         if (SP_ == 1 && A_hi && (tuning().gemm16_mfma16 == 1 ? N / HX_BN > 4 : tuning().gemm16_mfma16 == 2) && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= 2048 && K % 64 == 0) { \
             if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HQ_GO(RNAMSM_ACT_GELU_ERF, false, true)                    \

@@ -43,6 +43,13 @@ def test_two_ranks_gather_the_same_outputs_as_one_rank():
     for r in (one, two):
         assert r["outputs_finite"] and r["value"] > 0 and r["roofline"]["achieved"] > 0
         assert r["metric"].startswith("MSA-residues/sec") and r["config"]["msas_per_step"] == 6
+    # what a first real multi-GPU run needs to be diagnosable: the compute-only curve next to the value,
+    # bytes into every rank and the gather's exposed (non-overlapped) time
+    assert one["compute_only_value"] is None and one["gather_stats"] is None
+    gs = two["gather_stats"]
+    assert two["compute_only_value"] > 0 and two["compute_only_ms_per_step"] > 0
+    assert len(gs["per_rank_bytes_received"]) == 2 and gs["per_rank_bytes_received"][0] > 0 and gs["per_rank_bytes_received"][1] == 0
+    assert len(gs["per_rank_host_wait_s"]) == 2 and len(gs["per_rank_stream_wait_ms"]) == 2
 
 
 def test_default_workload_runs_weak_scaling_through_the_same_gatherer():
@@ -76,3 +83,45 @@ def test_the_drivers_torchrun_launch_takes_the_same_path():
     one = _bench(["--gpus", "1"] + COMMON)
     assert two["n_gpus"] == 2 and two["config"]["world_size_initialised"] == 2
     assert two["output_digest"]["value"] == one["output_digest"]["value"]
+
+
+def test_round_gatherer_on_the_rccl_backend_with_one_rank(tmp_path):
+    """The `nccl` (RCCL) configuration of RoundGatherer on the one GPU there is: a world of ONE rank initialises the backend
+    the 8-GPU run uses, so default_wire_device() and the device placement of the nccl branch are executed (payloads stay on
+    the HIP device, nothing is staged through the host); with one rank no transfer is posted -- the point-to-point branch
+    itself still needs a second GPU (SCALE / MULTICHIP runs of the driver)."""
+    code = r'''
+import os, sys, json
+sys.path[:0] = [os.path.join(@ROOT@, "rna-msm_amd"), @ROOT@]
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=@PORT@, HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from rnamsm import sharding
+wire = sharding.default_wire_device()
+got = {}
+g = sharding.RoundGatherer(3, on_item=lambda i, ts: got.__setitem__(i, ts), tensors_per_item=2)
+items = [(torch.full((4, 8), float(i), device="cuda:0").t(), torch.arange(2 * i + 2, device="cuda:0", dtype=torch.float32)) for i in range(3)]
+for i, ts in enumerate(items):
+    g.submit(i, ts)
+g.finish()
+t = torch.ones(4, device="cuda:0")
+dist.all_reduce(t)                                   # the backend really is up: one RCCL collective on the device
+ok = (wire.type == "cuda" and g.wire.type == "cuda" and sorted(got) == [0, 1, 2]
+      and all(a.is_cuda and torch.equal(a, b) for i in range(3) for a, b in zip(got[i], items[i])) and float(t.sum()) == 4.0)
+st = g.stats()
+print(json.dumps({"ok": bool(ok), "backend": dist.get_backend(), "stats": st}))
+dist.destroy_process_group()
+'''
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = code.replace("@ROOT@", repr(ROOT)).replace("@PORT@", repr(str(port)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["ok"] and res["backend"] == "nccl" and res["stats"]["bytes_received"] == 0
