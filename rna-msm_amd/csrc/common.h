@@ -61,8 +61,8 @@ struct Tuning {
                                    // 3 = LDS-DMA 256x256 with software-pipelined fragments, BK = 64 for split 1 (default),
                                    // 4 = the same with BK = 32 for every split
     int gemm16_mfma16 = 1;         // plain-bf16 256x256 GEMM: 1 = v_mfma_f32_16x16x32_bf16 (gemm16_q16_kernel) for wide N, 2 = always, 0 = 32x32x16
-    int gemm16_pp = 1;             // plain-bf16 plane GEMMs: 1 = gemm16_pp_kernel (4 waves x 512 registers, two accumulator sets: the epilogue of
-                                   // tile t leaves under the K loop of tile t+1; gemm16_pp.hip), 0 = the 256x256 kernels below
+    int gemm16_pp = 0;             // plain-bf16 plane GEMMs: 1 = gemm16_pp_kernel (4 waves x 512 registers, two accumulator sets: the epilogue of
+                                   // tile t leaves under the K loop of tile t+1; gemm16_pp.hip -- bit-identical, measured 0.61-0.83x: off), 0 = the 256x256 kernels below
     int gemm16_persist = 256;      // 256x256 16-bit GEMM: > 0 = that many persistent blocks walk the tiles (256 = one per CU; +1-5%, tools/gemm16_persist_ab.py), 0 = one block per tile
     int gemm16_stagger = 0;        // ... and block b starts (b/8 % 4) x this many cycles late (spreads the store bursts)
     int gemm_group = 0;            // fp32 GEMM: row panels per XCD group of the block order (xcd_panel_map_grouped); 0 = by shape

@@ -29,6 +29,12 @@
 
 namespace rnamsm {
 
+// PP_SPREAD 0: the LDS-DMA requests of a K tile go out in one burst after the barrier; 1: between the MFMAs of that half
+// (measured no faster -- a request's issue time is matrix-pipe idle time wherever it sits, see the header -- and fc2 slower)
+#ifndef PP_SPREAD
+#define PP_SPREAD 0
+#endif
+
 namespace pp {
 constexpr int BM = 256, BN = 128, BK = 64, THREADS = 256;
 constexpr int ROWB = BK * 2;                    // 128-byte tile rows (whole cache lines)
@@ -79,6 +85,8 @@ __device__ __forceinline__ void wait_vm_lgkm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 }  // namespace pp
+
+__device__ f32x4 g_pp_sink[128];               // where the lanes of rows past M store (never read)
 
 template <int ACT, bool HAS_RES, bool O_PL>
 __global__ __launch_bounds__(pp::THREADS, 1) void gemm16_pp_kernel(
@@ -140,12 +148,12 @@ __global__ __launch_bounds__(pp::THREADS, 1) void gemm16_pp_kernel(
     // nk = 12, an iteration = 2 mod 3 of the steady loop for nk >= 18) -- the stream then moves to the next output tile, or,
     // past the block's last tile, keeps requesting that last K tile (never read) so that the literal wait counts stay exact.
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem_b;      // LDS byte address of the ring
-    auto issue_next = [&](int slot, auto SWITCH_) __attribute__((always_inline)) {
+    auto issue_piece = [&](int slot, int j) __attribute__((always_inline)) {     // piece j of NDMA: 8 of the A tile, then 4 of W
         const unsigned base = lds0 + slot * STAGE;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dma16_sv(a_stream, avoff[j], base + (8 * (wv + 4 * j)) * ROWB);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma16_sv(w_stream, wvoff[j], base + A_BYTES + (8 * (wv + 4 * j)) * ROWB);
+        if (j < 8) dma16_sv(a_stream, avoff[j], base + (8 * (wv + 4 * j)) * ROWB);
+        else dma16_sv(w_stream, wvoff[j - 8], base + A_BYTES + (8 * (wv + 4 * (j - 8))) * ROWB);
+    };
+    auto stream_advance = [&](auto SWITCH_) __attribute__((always_inline)) {
         if (decltype(SWITCH_)::value && ikt + 1 == nk) {
             if (have_next) {
                 ikt = 0;
@@ -156,6 +164,11 @@ __global__ __launch_bounds__(pp::THREADS, 1) void gemm16_pp_kernel(
             a_stream += ROWB;
             w_stream += ROWB;
         }
+    };
+    auto issue_next = [&](int slot, auto SWITCH_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) issue_piece(slot, j);
+        stream_advance(SWITCH_);
     };
 
     // ---- fragments: lane (row fr, k-group fq) of a 16-row tile reads logical chunk 4 ks + fq of its row
@@ -237,7 +250,10 @@ __global__ __launch_bounds__(pp::THREADS, 1) void gemm16_pp_kernel(
             }
             if (HAS_RES) v[t] += r4[t];
         }
-        if (row < M) {
+        // Rows past M (ragged last row panel) must STILL issue their store instructions: the barriers wait with literal
+        // vmcnt counts, and an exec-masked-out store that the compiler branches around would make a count too large (a wait too
+        // short: a race that showed as rare wrong tiles at M = 9000).  Such lanes write to a sink instead.
+        {
 #pragma unroll
             for (int hlf = 0; hlf < 2; ++hlf) {
                 const int64_t o = (int64_t)row * ldc + c.gnb + 32 * hlf + 8 * fq;
@@ -249,10 +265,12 @@ __global__ __launch_bounds__(pp::THREADS, 1) void gemm16_pp_kernel(
                         hi[e] = (__bf16)v[2 * hlf][e];
                         hi[4 + e] = (__bf16)v[2 * hlf + 1][e];
                     }
-                    epi_store(reinterpret_cast<H8*>(Ohi + o), hi);
+                    H8* dst = row < M ? reinterpret_cast<H8*>(Ohi + o) : reinterpret_cast<H8*>(g_pp_sink) + lane;
+                    epi_store(dst, hi);
                 } else {
-                    epi_store(reinterpret_cast<f32x4*>(Cout + o), (f32x4)v[2 * hlf]);
-                    epi_store(reinterpret_cast<f32x4*>(Cout + o + 4), (f32x4)v[2 * hlf + 1]);
+                    f32x4* dst = row < M ? reinterpret_cast<f32x4*>(Cout + o) : g_pp_sink + 2 * lane;
+                    epi_store(dst, (f32x4)v[2 * hlf]);
+                    epi_store(dst + 1, (f32x4)v[2 * hlf + 1]);
                 }
             }
         }
@@ -274,10 +292,26 @@ __global__ __launch_bounds__(pp::THREADS, 1) void gemm16_pp_kernel(
         // ago) has landed -- every wave's share
         wait_vm_lgkm_barrier<wait_count<HAS_RES, O_PL>(I < NSPECIAL ? I : NSPECIAL, DRAIN)>();
         if constexpr (DRAIN && I < UNITS) unit_request(pc, I, b4, r4[I % 3]);
-        issue_next(S, std::integral_constant<bool, I == 8 || I == 14>{});
-        __builtin_amdgcn_sched_barrier(0);
         load_frags(std::integral_constant<int, (S + 1) % NSLOT>{}, std::integral_constant<int, 0>{}, F0);
-        mma(F1, cur);
+        // The NDMA requests of the next-but-two K tile go out BETWEEN the MFMAs of this half (one per 2-3 MFMAs), not in a
+        // burst ahead of them: with one wave per SIMD a request's issue time is matrix-pipe idle time, and back-to-back
+        // requests queue behind each other in the memory pipeline (round 3, first version: 3500 cycles per iteration for 1024
+        // cycles of MFMA).
+        if constexpr (PP_SPREAD) {
+#pragma unroll
+            for (int j = 0; j < NDMA; ++j) {
+                issue_piece(S, j);
+#pragma unroll
+                for (int q = (32 * j) / NDMA; q < (32 * (j + 1)) / NDMA; ++q)
+                    cur[q >> 2][q & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F1.b[q & 3], F1.a[q >> 2], cur[q >> 2][q & 3], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            stream_advance(std::integral_constant<bool, I == 8 || I == 14>{});
+        } else {
+            issue_next(S, std::integral_constant<bool, I == 8 || I == 14>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mma(F1, cur);
+        }
         if constexpr (DRAIN && I >= 2 && I < UNITS + 2) {
             constexpr int U = I - 2;
             // the unit's inputs were requested two iterations ago, before that iteration's DMA: this iteration's barrier wait

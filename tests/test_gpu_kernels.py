@@ -785,10 +785,10 @@ def test_epilogue_hiding_bf16_gemm_equals_the_256x256_kernels(dev, M, N, K, kind
             else:
                 assert rel_l2(new.cpu(), old.cpu()) < 1e-6
         _lib.check(lib.rnamsm_set_param(b"gemm16_persist", 256))
-        for _ in range(10):
+        for _ in range(25):
             assert torch.equal(run(), first)
     finally:
-        _lib.check(lib.rnamsm_set_param(b"gemm16_pp", 1))
+        _lib.check(lib.rnamsm_set_param(b"gemm16_pp", 0))           # the default: the kernel measured 0.61-0.83x (EXPERIMENTS.md)
         _lib.check(lib.rnamsm_set_param(b"gemm16_mfma16", 1))
         _lib.check(lib.rnamsm_set_param(b"gemm16_persist", 256))
     rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)]).to(dev)

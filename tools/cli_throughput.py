@@ -34,3 +34,35 @@ for mode in (False, True, False, True):
     nbytes = sum(os.path.getsize(os.path.join(root, "results", f)) for f in os.listdir(os.path.join(root, "results")) if f.endswith(".npy"))
     print(f"async_io={mode}: {N} MSAs ({M} x {L}) in {dt:.2f} s = {N / dt:.2f} MSA/s, {N * M * L / dt:.0f} residues/s, {nbytes / 1e6:.0f} MB written", flush=True)
     shutil.rmtree(root)
+
+# ---- a list of SMALL alignments: the default CLI (data.batch_small_msas=true: consecutive small alignments
+# share one ragged launch set) against the strictly one-by-one loop of the reference (data.batch_small_msas=false)
+NS = int(os.environ.get("NSMALL", 64))
+if NS:
+    res = {}
+    for rnd in range(2):
+        for batching in (False, True):
+            rng = np.random.RandomState(1)
+            root = tempfile.mkdtemp(prefix="rnamsm_cli_small_", dir=os.environ.get("SCRATCH", "/tmp"))
+            os.makedirs(os.path.join(root, "results"))
+            ids = [f"small{i:03d}" for i in range(NS)]
+            tokens = 0
+            for i in ids:
+                depth, length = int(rng.randint(4, 25)), int(rng.randint(40, 121))
+                tokens += depth * (length + 1)
+                rows = letters[rng.randint(0, 5, size=(depth, length))]
+                with open(os.path.join(root, "results", f"{i}.a2m_msa2"), "w") as f:
+                    for r in range(depth):
+                        f.write(f">s{r}\n{''.join(rows[r])}\n")
+            open(os.path.join(root, "rna_id.txt"), "w").write("\n".join(ids) + "\n")
+            cfg = Config()
+            cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = root, "results", "rna_id.txt"
+            cfg.data.sample_method, cfg.data.max_seqs_per_msa, cfg.data.batch_small_msas = "first", 64, batching
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            extract_feat(cfg, model=model)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            res.setdefault(batching, []).append(dt)
+            shutil.rmtree(root)
+    one, bat = min(res[False]), min(res[True])
+    print(f"{NS} small alignments (4-24 rows x 40-120 columns, {tokens} tokens): one by one {one:.3f} s = {NS / one:.1f} MSA/s; "
+          f"default (batched) {bat:.3f} s = {NS / bat:.1f} MSA/s; x{one / bat:.2f}", flush=True)

@@ -71,4 +71,4 @@ for (M, L) in ((256, 512), (1024, 1024)):
                 res[(v, "emb")] = o["emb"].clone()
     d = float((res[(0, "emb")] - res[(1, "emb")]).abs().max())
     print(f"forward bf16 M={M} L={L}: old {statistics.median(res[0]):.2f} ms, pp {statistics.median(res[1]):.2f} ms, x{statistics.median(res[0]) / statistics.median(res[1]):.3f}, emb max diff {d:.3g}", flush=True)
-setpp(1)
+setpp(0)
