@@ -407,11 +407,16 @@ int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, c
  * (align_scaling, modules.py:713-715).  With true_rows[b] = the real depth of MSA b that factor is applied per MSA, and
  * emb[b, :C_b-1], atp[b, :, :C_b-1, :C_b-1] equal rnamsm_forward's outputs on the unpadded MSA b to fp32 rounding.  Every MSA's outputs equal rnamsm_forward's on that MSA alone up
  * to fp32 rounding (bit-identical when the two shape-dependent choices agree: fc2 split-K and the folded LayerNorm are
- * decided by the batch's token count).  B*R*C must fit 31 bits. */
+ * decided by the batch's token count).  B*R*C must fit 31 bits.
+ * dtype / weight_planes as in rnamsm_forward (round 3): the 16-bit modes run the same plane data flow -- LayerNorm-split, the
+ * plane GEMMs, K4'..K7' with the MSA on gridDim.y; in a ragged batch the tied logits are scaled per MSA on the fp32
+ * accumulators (q stays unscaled in the planes) -- and need the "attn16" knob on; which GEMM kernel runs depends on the
+ * batch's token count, so an element agrees with its lone forward to the mode's rounding, not bit for bit. */
 size_t rnamsm_forward_batch_workspace_bytes(const rnamsm_model_dims* dims, int B, int R, int C);
 int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens, int B, int R, int C,
                          void* workspace, size_t workspace_bytes, float* row_attn, float* repr, float* emb, float* atp,
-                         int* err_flag, int has_padding, const int* true_rows, const float* const* ln_folded, void* stream);
+                         int* err_flag, int has_padding, const int* true_rows, const float* const* ln_folded, int dtype,
+                         const uint16_t* const* weight_planes, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's
  * roofline block; adds two event records per launch while enabled, nothing when disabled).

@@ -31,8 +31,15 @@ __global__ __launch_bounds__(C16_THREADS, JC == 32 ? 3 : 2) void col_attn16_kern
     const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
     const uint16_t* __restrict__ klo, const uint16_t* __restrict__ vhi, const uint16_t* __restrict__ vlo, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo,
-    float scale, const uint8_t* __restrict__ pad_mask) {
+    float scale, const uint8_t* __restrict__ pad_mask, int64_t qkv_bstride, int64_t ctx_bstride, int64_t mask_bstride) {
     constexpr int NPL = SPLIT == 3 ? 2 : 1;
+    // batched launch (rnamsm_forward_batch, 16-bit modes): MSA blockIdx.y
+    qhi += blockIdx.y * qkv_bstride; khi += blockIdx.y * qkv_bstride; vhi += blockIdx.y * qkv_bstride;
+    if (qlo) { qlo += blockIdx.y * qkv_bstride; klo += blockIdx.y * qkv_bstride; vlo += blockIdx.y * qkv_bstride; }
+    if (ctx) ctx += blockIdx.y * ctx_bstride;
+    if (ctx_hi) ctx_hi += blockIdx.y * ctx_bstride;
+    if (ctx_lo) ctx_lo += blockIdx.y * ctx_bstride;
+    if (MASKED) pad_mask += blockIdx.y * mask_bstride;
     constexpr int C16_JC = JC;
     constexpr int C16_TILE = JC * T16_ROWB;            // bytes per plane tile
     constexpr int BUF = 2 * NPL * C16_TILE;            // K planes then V planes
@@ -223,10 +230,11 @@ using namespace rnamsm;
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-extern "C" int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
-                                 const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R,
-                                 int C, int H, int head_dim, float scale, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt,
-                                 void* stream) {
+static int col_attn16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
+                             const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
+                             int head_dim, float scale, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt,
+                             void* stream, int batch, int64_t qkv_bstride, int64_t ctx_bstride, int64_t mask_bstride) {
+    RNAMSM_CHECK_ARG(batch >= 1 && batch <= 65535 && qkv_bstride % 8 == 0 && ctx_bstride % 4 == 0, "col_attn16: bad batch / strides");
     RNAMSM_CHECK_ARG(q_hi && k_hi && v_hi && (ctx || ctx_hi), "col_attn16: null pointer");
     RNAMSM_CHECK_ARG((q_lo == nullptr) == (k_lo == nullptr) && (q_lo == nullptr) == (v_lo == nullptr),
                      "col_attn16: the lo planes must all be given (x3) or all be null");
@@ -244,7 +252,7 @@ extern "C" int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, con
     const int npl = q_lo ? 2 : 1;
     const int jc = q_lo ? 32 : 64;
     const int lds = 2 * 2 * npl * jc * T16_ROWB;
-    KernelTimer timer(TC_COL_ATTN, 4.0 * C * H * (double)R * R * 64, (2.0 * npl * 3.0 + (ctx_hi ? 2.0 * npl : 4.0)) * R * C * H * 64, s,
+    KernelTimer timer(TC_COL_ATTN, 4.0 * batch * C * H * (double)R * R * 64, batch * (2.0 * npl * 3.0 + (ctx_hi ? 2.0 * npl : 4.0)) * R * C * H * 64, s,
                       PEAK_F16_MFMA_TFLOPS, q_lo ? 3.0 : 1.0);
 #define CA_GO(SP_, FMT_, OUT_)                                                                                      \
     do {                                                                                                            \
@@ -259,8 +267,8 @@ extern "C" int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, con
             if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn16: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
             cfg_.mark();                                                                                            \
         }                                                                                                           \
-        hipLaunchKernelGGL((col_attn16_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64), MASK_>), dim3(grid), dim3(C16_THREADS), lds, s, q_hi, q_lo, k_hi, \
-                           k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, scale, pad_mask);               \
+        hipLaunchKernelGGL((col_attn16_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64), MASK_>), dim3(grid, batch), dim3(C16_THREADS), lds, s, q_hi, q_lo, k_hi, \
+                           k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, scale, pad_mask, qkv_bstride, ctx_bstride, mask_bstride); \
     } while (0)
     if (!q_lo) {
         if (ctx_hi) CA_GO(1, 0, 1); else CA_GO(1, 0, 0);
@@ -274,3 +282,20 @@ extern "C" int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, con
     RNAMSM_CHECK_LAUNCH("col_attn16");
     return RNAMSM_OK;
 }
+
+extern "C" int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
+                                 const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R,
+                                 int C, int H, int head_dim, float scale, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt,
+                                 void* stream) {
+    return col_attn16_launch(q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H, head_dim, scale, pad_mask, ctx_hi, ctx_lo, fmt, stream,
+                             1, 0, 0, 0);
+}
+namespace rnamsm {
+int col_attn16_batched(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo, const uint16_t* v_hi,
+                       const uint16_t* v_lo, int64_t ld, int64_t ldc, int R, int C, int H, float scale, const uint8_t* pad_mask,
+                       uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, int batch, int64_t qkv_bstride, int64_t ctx_bstride, int64_t mask_bstride,
+                       void* stream) {
+    return col_attn16_launch(q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, ld, nullptr, ldc, R, C, H, 64, scale, pad_mask, ctx_hi, ctx_lo, fmt, stream,
+                             batch, qkv_bstride, ctx_bstride, mask_bstride);
+}
+}  // namespace rnamsm

@@ -262,6 +262,22 @@ int row_apply_batched(const float* probs, const float* v, int64_t ld, float* ctx
 int col_attn_batched(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
                      int batch, int64_t qkv_bstride, int64_t ctx_bstride, const uint8_t* pad_mask, void* stream);
 
+// the same for the 16-bit modes (row_attn16.hip, row_attn.hip, col_attn16.hip): plane operands, MSA b's planes b * stride halves
+// further on; true_rows (device int32 [batch], may be null): every MSA's tied logits are scaled by its own depth
+int row_logits16_batched(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo, int64_t ld,
+                         float* partial, int R, int C, int H, float scale, int fmt, int batch, int64_t qk_bstride,
+                         int64_t part_bstride, const int* true_rows, void* stream);
+int softmax_rows_planes_batched(const float* partial, int nsplit, float* probs, uint16_t* p_hi, uint16_t* p_lo, int64_t ldp,
+                                float plane_scale, int H, int C, const uint8_t* key_mask, int fmt, int batch, int64_t part_bstride,
+                                int64_t probs_bstride, int64_t mask_bstride, int64_t plane_bstride, void* stream);
+int row_apply16_batched(const uint16_t* p_hi, const uint16_t* p_lo, int64_t ldp, const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld,
+                        int64_t ldc, int R, int C, int H, float out_scale, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, int batch,
+                        int64_t p_bstride, int64_t v_bstride, int64_t ctx_bstride, void* stream);
+int col_attn16_batched(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo, const uint16_t* v_hi,
+                       const uint16_t* v_lo, int64_t ld, int64_t ldc, int R, int C, int H, float scale, const uint8_t* pad_mask,
+                       uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, int batch, int64_t qkv_bstride, int64_t ctx_bstride, int64_t mask_bstride,
+                       void* stream);
+
 // ragged batches (elementwise.hip): per-token q factor (0 at <pad>, 1/sqrt(true depth of the token's MSA) elsewhere), applied
 // to the q columns in the QKV GEMM's epilogue (rnamsm_gemm_row_scaled)
 int ragged_row_scale(const int64_t* tokens, int pad_idx, const int* true_rows, float* out, int64_t n, int64_t tokens_per_msa,

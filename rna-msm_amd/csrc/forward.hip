@@ -361,7 +361,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
 // of fc2 and the folded LayerNorm are decided by the batch's token count).
 namespace {
 struct BatchLayout {
-    size_t x, xn, wide, part, rowsum, stats, splitk, mask, qscale, total;
+    size_t x, xn, wide, part, rowsum, stats, splitk, mask, qscale, pplanes, total;
 };
 BatchLayout make_batch_layout(const rnamsm_model_dims& d, int B, int R, int C) {
     const size_t T = (size_t)B * R * C, D = d.embed_dim;
@@ -370,13 +370,17 @@ BatchLayout make_batch_layout(const rnamsm_model_dims& d, int B, int R, int C) {
     l.x = off;      off += align256(T * D * 4);
     l.xn = off;     off += align256(T * D * 4);
     l.wide = off;   off += align256(T * (size_t)(4 * D > (size_t)d.ffn_dim ? 4 * D : d.ffn_dim) * 4);
-    l.part = off;   off += align256((size_t)B * rnamsm_row_logits_workspace_bytes(R, C, d.num_heads));   // every MSA's logit slabs
+    {   // every MSA's logit slabs, for either arithmetic
+        const size_t a = rnamsm_row_logits_workspace_bytes(R, C, d.num_heads), b16 = rnamsm_row_logits16_workspace_bytes(R, C, d.num_heads);
+        l.part = off;   off += align256((size_t)B * (a > b16 ? a : b16));
+    }
     l.rowsum = off; off += align256(T * (D / 32) * 2 * sizeof(float));
     l.stats = off;  off += align256(T * 2 * sizeof(float));
     const size_t kt = (size_t)rnamsm::gemm_f32_splitk_factor((int64_t)T, (int)D, d.ffn_dim, true);
     l.splitk = off; off += align256((kt > 1 ? kt * T : 0) * D * sizeof(float));
     l.mask = off;   off += align256(T);              // padding mask uint8 [B, R, C]
     l.qscale = off; off += align256(T * sizeof(float));   // ragged batches: per-token q scale
+    l.pplanes = off; off += align256((size_t)B * d.num_heads * C * (size_t)((C + 63) / 64 * 64) * 4);   // 16-bit modes: P hi + lo planes of every MSA
     l.total = off;
     return l;
 }
@@ -390,8 +394,11 @@ extern "C" size_t rnamsm_forward_batch_workspace_bytes(const rnamsm_model_dims* 
 extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens, int B,
                                     int R, int C, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
                                     float* emb, float* atp, int* err_flag, int has_padding, const int* true_rows,
-                                    const float* const* ln_folded, void* stream) {
+                                    const float* const* ln_folded, int dtype, const uint16_t* const* weight_planes, void* stream) {
     RNAMSM_CHECK_ARG(dims && weights && tokens && workspace && row_attn && repr && emb && atp, "forward_batch: null pointer");
+    RNAMSM_CHECK_ARG(dtype >= RNAMSM_F32 && dtype <= RNAMSM_F16X3, "forward_batch: unknown dtype %d", dtype);
+    RNAMSM_CHECK_ARG(dtype == RNAMSM_F32 || (weight_planes && tuning().attn16 != 0),
+                     "forward_batch: the 16-bit modes need weight_planes (and the attn16 knob on: planes end to end)");
     const rnamsm_model_dims& d = *dims;
     const int D = d.embed_dim, H = d.num_heads, F = d.ffn_dim, NL = d.num_layers;
     RNAMSM_CHECK_ARG(D > 0 && H > 0 && D == H * 64, "forward_batch: embed_dim must be num_heads * 64 (D=%d H=%d)", D, H);
@@ -440,6 +447,65 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
     const float row_scale = true_rows ? col_scale : col_scale / sqrtf((float)R);
     float* qscale = reinterpret_cast<float*>(ws + lay.qscale);
     if (true_rows) FWD(rnamsm::ragged_row_scale(tokens, d.pad_idx, true_rows, qscale, T, Tm, hs));
+
+    if (dtype != RNAMSM_F32) {
+        // ---- 16-bit modes: the plane data flow of rnamsm_forward (LayerNorm and the QKV / fc1 epilogues write 16-bit planes, every
+        // contraction on the 16-bit matrix cores, fp32 softmax / statistics / residual stream), batched the same way: token-parallel
+        // launches once over the B*R*C tokens, K4'..K7' with the MSA on gridDim.y.  q stays unscaled in the planes; the tied logits are
+        // scaled on the fp32 accumulators -- by every MSA's own depth in a ragged batch (true_rows).
+        const int split = dtype == RNAMSM_BF16 ? 1 : 3, fmt = dtype == RNAMSM_F16X3 ? 1 : 0;
+        uint16_t* xn_hi = reinterpret_cast<uint16_t*>(xn);
+        uint16_t* xn_lo = split == 3 ? xn_hi + T * D : nullptr;
+        uint16_t* qkv_hi = reinterpret_cast<uint16_t*>(qkv);
+        uint16_t* qkv_lo = split == 3 ? qkv_hi + T * ldq : nullptr;
+        auto lo_at = [&](int64_t off) -> uint16_t* { return qkv_lo ? qkv_lo + off : nullptr; };
+        uint16_t* ctx_hi = reinterpret_cast<uint16_t*>(ctx);
+        uint16_t* ctx_lo = split == 3 ? ctx_hi + T * D : nullptr;
+        uint16_t* hid_hi = reinterpret_cast<uint16_t*>(hidden);
+        uint16_t* hid_lo = split == 3 ? hid_hi + T * (int64_t)F : nullptr;
+        const int64_t ldp = (C + 63) / 64 * 64, plane_bs = (int64_t)H * C * ldp;
+        uint16_t* p_hi = reinterpret_cast<uint16_t*>(ws + lay.pplanes);
+        uint16_t* p_lo = split == 3 ? p_hi + (int64_t)B * plane_bs : nullptr;
+        const int nsplit16 = rnamsm_row_logits16_nsplit(R, C, H, split);
+        const int64_t part_bs = (int64_t)nsplit16 * H * C * C, probs_bs = (int64_t)NL * H * C * C;
+        auto linear_pl = [&](int layer, int slot, const uint16_t* ahi, const uint16_t* alo, int64_t lda, const float* bias, const float* res,
+                             float* out, uint16_t* ohi, uint16_t* olo, int64_t ldc, int N, int K, int act) -> int {
+            const uint16_t* const* P = weight_planes + (size_t)layer * RNAMSM_PLANES_PER_LAYER + 2 * slot;
+            return rnamsm_gemm_bf16(nullptr, lda, P[0], P[1], bias, res, D, out, ldc, T, N, K, act, 1.f, 0, split, fmt, ahi, alo, ohi, olo,
+                                    stream);
+        };
+        FWD(rnamsm::embed_ln_batched(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
+                                     G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, B, R, C, D, d.vocab, d.num_positions, d.pad_idx,
+                                     d.ln_eps, err_flag, hs));
+        for (int l = 0; l < NL; ++l) {
+            const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
+            float* probs = row_attn + (int64_t)l * H * C * C;
+            // ---- tied row attention
+            FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
+            FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D, RNAMSM_ACT_NONE));
+            if (mask) FWD(rnamsm_zero_plane_rows(qkv_hi, qkv_lo, mask, T, D, ldq, stream));             // q *= 1 - padding_mask
+            FWD(rnamsm::row_logits16_batched(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), ldq, part, R, C, H, row_scale, fmt, B, Tm * ldq, part_bs,
+                                             true_rows, stream));
+            FWD(rnamsm::softmax_rows_planes_batched(part, nsplit16, probs, p_hi, p_lo, ldp, 4096.f, H, C, mask, fmt, B, part_bs, probs_bs, Tm,
+                                                    plane_bs, stream));
+            FWD(rnamsm::row_apply16_batched(p_hi, p_lo, ldp, qkv_hi + 2 * D, lo_at(2 * D), ldq, D, R, C, H, 1.f / 4096.f, ctx_hi, ctx_lo, fmt, B,
+                                            plane_bs, Tm * ldq, Tm * D, stream));
+            FWD(linear_pl(l, 1, ctx_hi, ctx_lo, D, W[RNAMSM_WL_ROW_BO], x, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE));
+            // ---- column attention
+            FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
+            FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D, RNAMSM_ACT_NONE));
+            FWD(rnamsm::col_attn16_batched(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, D, R, C, H, col_scale,
+                                           R > 1 ? mask : nullptr, ctx_hi, ctx_lo, fmt, B, Tm * ldq, Tm * D, Tm, stream));
+            FWD(linear_pl(l, 3, ctx_hi, ctx_lo, D, W[RNAMSM_WL_COL_BO], x, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE));
+            // ---- feed-forward
+            FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
+            FWD(linear_pl(l, 4, xn_hi, xn_lo, D, W[RNAMSM_WL_FC1_B], nullptr, nullptr, hid_hi, hid_lo, F, F, D, RNAMSM_ACT_GELU_ERF));
+            FWD(linear_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE));
+        }
+        FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
+        FWD(rnamsm::pack_outputs_batched(repr, row_attn, emb, atp, C, D, NL, H, B, Tm * D, (int64_t)NL * H * C * C, err_flag, hs));
+        return RNAMSM_OK;
+    }
 
     auto norm = [&](const float* g, const float* b) -> int {
         return fold ? RNAMSM_OK : rnamsm_layernorm(x, g, b, xn, T, D, d.ln_eps, stream);

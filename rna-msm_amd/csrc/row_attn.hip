@@ -127,11 +127,16 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
                                                            const uint8_t* __restrict__ key_mask,
                                                            uint16_t* __restrict__ p_hi, uint16_t* __restrict__ p_lo,
                                                            int64_t ldp, float plane_scale, int64_t mask_slab_stride,
-                                                           int64_t part_bstride, int64_t probs_bstride, int64_t mask_bstride) {
+                                                           int64_t part_bstride, int64_t probs_bstride, int64_t mask_bstride,
+                                                           int64_t plane_bstride) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    partial += blockIdx.y * part_bstride;        // batched launch: MSA blockIdx.y (fp32 probabilities only)
+    partial += blockIdx.y * part_bstride;        // batched launch: MSA blockIdx.y
     probs += blockIdx.y * probs_bstride;
+    if (PL != 0) {
+        p_hi += blockIdx.y * plane_bstride;
+        if (p_lo) p_lo += blockIdx.y * plane_bstride;
+    }
     if (key_mask) key_mask += blockIdx.y * mask_bstride;
     const int lane = threadIdx.x & 63;
     const int64_t slab = rows * C;
@@ -402,7 +407,7 @@ static int row_logits_launch(const float* q, const float* k, int64_t ld, float* 
 static int softmax_rows_launch(const float* partial, int nsplit, float* probs, int H, int C, const uint8_t* key_mask,
                                uint16_t* p_hi, uint16_t* p_lo, int64_t ldp, float plane_scale, int fmt, void* stream,
                                int64_t mask_slab_stride = 0, int batch = 1, int64_t part_bstride = 0, int64_t probs_bstride = 0,
-                               int64_t mask_bstride = 0) {
+                               int64_t mask_bstride = 0, int64_t plane_bstride = 0) {
     RNAMSM_CHECK_ARG(partial && probs, "softmax_rows: null pointer");
     RNAMSM_CHECK_ARG(nsplit >= 1 && H > 0 && C > 0 && C <= 64 * SOFTMAX_MAX_PER_LANE,
                      "softmax_rows: bad shape nsplit=%d H=%d C=%d (C <= %d)", nsplit, H, C, 64 * SOFTMAX_MAX_PER_LANE);
@@ -411,13 +416,13 @@ static int softmax_rows_launch(const float* partial, int nsplit, float* probs, i
     const int64_t rows = (int64_t)H * C;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((rows + 3) / 4), batch);
-    KernelTimer timer(TC_SOFTMAX, 0.0, 4.0 * (double)(nsplit + 1) * H * C * C + (p_hi ? (p_lo ? 4.0 : 2.0) * rows * ldp : 0.0), s);
+    KernelTimer timer(TC_SOFTMAX, 0.0, batch * (4.0 * (double)(nsplit + 1) * H * C * C + (p_hi ? (p_lo ? 4.0 : 2.0) * rows * ldp : 0.0)), s);
     if (!p_hi)
-        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride);
+        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride);
     else if (fmt == 0)
-        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride);
+        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride);
     else
-        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride);
+        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride);
     RNAMSM_CHECK_LAUNCH("softmax_rows");
     return RNAMSM_OK;
 }
@@ -503,6 +508,13 @@ int softmax_rows_batched(const float* partial, int nsplit, float* probs, int H, 
                          int64_t probs_bstride, const uint8_t* key_mask, int64_t mask_bstride, void* stream) {
     return softmax_rows_launch(partial, nsplit, probs, H, C, key_mask, nullptr, nullptr, 0, 1.f, 0, stream, 0, batch, part_bstride,
                                probs_bstride, mask_bstride);
+}
+int softmax_rows_planes_batched(const float* partial, int nsplit, float* probs, uint16_t* p_hi, uint16_t* p_lo, int64_t ldp,
+                                float plane_scale, int H, int C, const uint8_t* key_mask, int fmt, int batch, int64_t part_bstride,
+                                int64_t probs_bstride, int64_t mask_bstride, int64_t plane_bstride, void* stream) {
+    RNAMSM_CHECK_ARG(p_hi && plane_scale > 0.f && plane_scale <= 32768.f, "softmax_rows_planes_batched: bad plane arguments");
+    return softmax_rows_launch(partial, nsplit, probs, H, C, key_mask, p_hi, p_lo, ldp, plane_scale, fmt, stream, 0, batch, part_bstride,
+                               probs_bstride, mask_bstride, plane_bstride);
 }
 int row_apply_batched(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H, int batch,
                       int64_t probs_bstride, int64_t v_bstride, int64_t ctx_bstride, void* stream) {

@@ -47,7 +47,14 @@ template <int SPLIT, int FMT>
 __global__ __launch_bounds__(R16_THREADS, SPLIT == 3 ? 1 : 2) void row_logits16_kernel(
     const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
     const uint16_t* __restrict__ klo, int64_t ld, float* __restrict__ partial, int R, int C, int H, int nsplit,
-    int rows_per_split, float scale) {
+    int rows_per_split, float scale, int64_t qk_bstride, int64_t part_bstride, const int* __restrict__ true_rows) {
+    // batched launch (rnamsm_forward_batch, 16-bit modes): MSA blockIdx.y; a ragged batch scales every MSA's logits by its own depth
+    qhi += blockIdx.y * qk_bstride;
+    khi += blockIdx.y * qk_bstride;
+    if (qlo) qlo += blockIdx.y * qk_bstride;
+    if (klo) klo += blockIdx.y * qk_bstride;
+    partial += blockIdx.y * part_bstride;
+    if (true_rows) scale = scale / sqrtf((float)max(true_rows[blockIdx.y], 1));
     using Cfg = R16Cfg<SPLIT>;
     constexpr int NPL = Cfg::NPL;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
@@ -145,7 +152,15 @@ template <int SPLIT, int FMT, int OUT>
 __global__ __launch_bounds__(R16_THREADS, SPLIT == 3 ? 1 : 2) void row_apply16_kernel(
     const uint16_t* __restrict__ phi, const uint16_t* __restrict__ plo, int64_t ldp, const uint16_t* __restrict__ vhi,
     const uint16_t* __restrict__ vlo, int64_t ld, float* __restrict__ ctx, int64_t ldc, int R, int C, int H,
-    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, float out_scale) {
+    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, float out_scale, int64_t p_bstride, int64_t v_bstride,
+    int64_t ctx_bstride) {
+    phi += blockIdx.y * p_bstride;                           // batched launch: MSA blockIdx.y
+    vhi += blockIdx.y * v_bstride;
+    if (plo) plo += blockIdx.y * p_bstride;
+    if (vlo) vlo += blockIdx.y * v_bstride;
+    if (ctx) ctx += blockIdx.y * ctx_bstride;
+    if (ctx_hi) ctx_hi += blockIdx.y * ctx_bstride;
+    if (ctx_lo) ctx_lo += blockIdx.y * ctx_bstride;
     using Cfg = R16Cfg<SPLIT>;
     constexpr int NPL = Cfg::NPL;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
@@ -263,7 +278,14 @@ template <int SPLIT, int FMT>
 __global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
     const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
     const uint16_t* __restrict__ klo, int64_t ld, float* __restrict__ partial, int R, int C, int H, int nsplit,
-    int rows_per_split, float scale) {
+    int rows_per_split, float scale, int64_t qk_bstride, int64_t part_bstride, const int* __restrict__ true_rows) {
+    // batched launch (rnamsm_forward_batch, 16-bit modes): MSA blockIdx.y; a ragged batch scales every MSA's logits by its own depth
+    qhi += blockIdx.y * qk_bstride;
+    khi += blockIdx.y * qk_bstride;
+    if (qlo) qlo += blockIdx.y * qk_bstride;
+    if (klo) klo += blockIdx.y * qk_bstride;
+    partial += blockIdx.y * part_bstride;
+    if (true_rows) scale = scale / sqrtf((float)max(true_rows[blockIdx.y], 1));
     using Cfg = R16LCfg<SPLIT>;
     constexpr int NPL = Cfg::NPL;
     constexpr int NMF = 8 * (SPLIT == 3 ? 3 : 1);
@@ -411,7 +433,15 @@ template <int SPLIT, int FMT, int OUT>
 __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
     const uint16_t* __restrict__ phi, const uint16_t* __restrict__ plo, int64_t ldp, const uint16_t* __restrict__ vhi,
     const uint16_t* __restrict__ vlo, int64_t ld, float* __restrict__ ctx, int64_t ldc, int R, int C, int H,
-    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, float out_scale) {
+    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, float out_scale, int64_t p_bstride, int64_t v_bstride,
+    int64_t ctx_bstride) {
+    phi += blockIdx.y * p_bstride;                           // batched launch: MSA blockIdx.y
+    vhi += blockIdx.y * v_bstride;
+    if (plo) plo += blockIdx.y * p_bstride;
+    if (vlo) vlo += blockIdx.y * v_bstride;
+    if (ctx) ctx += blockIdx.y * ctx_bstride;
+    if (ctx_hi) ctx_hi += blockIdx.y * ctx_bstride;
+    if (ctx_lo) ctx_lo += blockIdx.y * ctx_bstride;
     using Cfg = R16XCfg<SPLIT>;
     constexpr int NPL = Cfg::NPL;
     constexpr int NMF = 8 * (SPLIT == 3 ? 3 : 1);          // MFMAs per k step per wave
@@ -588,23 +618,23 @@ extern "C" size_t rnamsm_row_logits16_workspace_bytes(int R, int C, int H) {
     return (size_t)n * H * C * C * sizeof(float);
 }
 
-extern "C" int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
-                                   int64_t ld, float* partial, int R, int C, int H, int head_dim, float scale, int fmt,
-                                   void* stream) {
+static int row_logits16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo, int64_t ld,
+                               float* partial, int R, int C, int H, int head_dim, float scale, int fmt, void* stream, int batch,
+                               int64_t qk_bstride, int64_t part_bstride, const int* true_rows) {
     RNAMSM_CHECK_ARG(q_hi && k_hi && partial, "row_logits16: null pointer");
     RNAMSM_CHECK_ARG((q_lo == nullptr) == (k_lo == nullptr), "row_logits16: q_lo and k_lo must both be given (x3) or both be null");
     RNAMSM_CHECK_ARG(head_dim == 64, "row_logits16: head_dim must be 64 (got %d)", head_dim);
-    RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0, "row_logits16: bad shape R=%d C=%d H=%d", R, C, H);
+    RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0 && batch >= 1 && batch <= 65535, "row_logits16: bad shape R=%d C=%d H=%d batch=%d", R, C, H, batch);
     RNAMSM_CHECK_ARG(fmt == 0 || (fmt == 1 && q_lo), "row_logits16: fmt must be 0 (bf16) or 1 (fp16, hi/lo only)");
-    RNAMSM_CHECK_ARG(ld >= (int64_t)H * 64 && ld % 8 == 0 && al16(q_hi) && al16(k_hi) && al16(q_lo) && al16(k_lo),
+    RNAMSM_CHECK_ARG(ld >= (int64_t)H * 64 && ld % 8 == 0 && qk_bstride % 8 == 0 && al16(q_hi) && al16(k_hi) && al16(q_lo) && al16(k_lo),
                      "row_logits16: planes must be 16-byte aligned with ld %% 8 == 0");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool big = row_logits16_big(C, q_lo != nullptr);
     const RowSplit sp = row_split16(R, C, H, big, q_lo != nullptr);
     const unsigned tiles_c = big ? (C + 255) / 256 : (C + 127) / 128;
     const unsigned grid = xcd_panel_grid((unsigned)(H * sp.nsplit), tiles_c * tiles_c);
-    KernelTimer timer(TC_ROW_LOGITS, 2.0 * H * C * C * R * 64,
-                      (q_lo ? 4.0 : 2.0) * 2.0 * R * C * H * 64 + 4.0 * (double)sp.nsplit * H * C * C, s, PEAK_F16_MFMA_TFLOPS,
+    KernelTimer timer(TC_ROW_LOGITS, 2.0 * batch * H * C * C * R * 64,
+                      batch * ((q_lo ? 4.0 : 2.0) * 2.0 * R * C * H * 64 + 4.0 * (double)sp.nsplit * H * C * C), s, PEAK_F16_MFMA_TFLOPS,
                       q_lo ? 3.0 : 1.0);
 #define RL_GO(SP_, FMT_)                                                                                            \
     do {                                                                                                            \
@@ -615,8 +645,8 @@ extern "C" int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, c
                 if (rc) return rc;                                                                                  \
                 cfgx_.mark();                                                                                       \
             }                                                                                                       \
-            hipLaunchKernelGGL((row_logits16x_kernel<SP_, FMT_>), dim3(grid), dim3(512), R16LCfg<SP_>::LDS, s, q_hi, q_lo,  \
-                               k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale);              \
+            hipLaunchKernelGGL((row_logits16x_kernel<SP_, FMT_>), dim3(grid, batch), dim3(512), R16LCfg<SP_>::LDS, s, q_hi, q_lo,  \
+                               k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale, qk_bstride, part_bstride, true_rows); \
             break;                                                                                                  \
         }                                                                                                           \
         static DeviceOnce cfg_;                                                                                   \
@@ -625,8 +655,8 @@ extern "C" int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, c
             if (rc) return rc;                                                                                      \
             cfg_.mark();                                                                                            \
         }                                                                                                           \
-        hipLaunchKernelGGL((row_logits16_kernel<SP_, FMT_>), dim3(grid), dim3(R16_THREADS), R16Cfg<SP_>::LDS, s, q_hi, \
-                           q_lo, k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale);            \
+        hipLaunchKernelGGL((row_logits16_kernel<SP_, FMT_>), dim3(grid, batch), dim3(R16_THREADS), R16Cfg<SP_>::LDS, s, q_hi, \
+                           q_lo, k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale, qk_bstride, part_bstride, true_rows); \
     } while (0)
     if (!q_lo) RL_GO(1, 0);
     else if (fmt == 0) RL_GO(3, 0);
@@ -636,17 +666,33 @@ extern "C" int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, c
     return RNAMSM_OK;
 }
 
-extern "C" int rnamsm_row_apply16(const uint16_t* p_hi, const uint16_t* p_lo, int64_t ldp, const uint16_t* v_hi,
-                                  const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
-                                  int head_dim, float out_scale, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, void* stream) {
+extern "C" int rnamsm_row_logits16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
+                                   int64_t ld, float* partial, int R, int C, int H, int head_dim, float scale, int fmt,
+                                   void* stream) {
+    return row_logits16_launch(q_hi, q_lo, k_hi, k_lo, ld, partial, R, C, H, head_dim, scale, fmt, stream, 1, 0, 0, nullptr);
+}
+namespace rnamsm {
+int row_logits16_batched(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo, int64_t ld,
+                         float* partial, int R, int C, int H, float scale, int fmt, int batch, int64_t qk_bstride,
+                         int64_t part_bstride, const int* true_rows, void* stream) {
+    return row_logits16_launch(q_hi, q_lo, k_hi, k_lo, ld, partial, R, C, H, 64, scale, fmt, stream, batch, qk_bstride, part_bstride,
+                               true_rows);
+}
+}  // namespace rnamsm
+
+static int row_apply16_launch(const uint16_t* p_hi, const uint16_t* p_lo, int64_t ldp, const uint16_t* v_hi, const uint16_t* v_lo,
+                              int64_t ld, float* ctx, int64_t ldc, int R, int C, int H, int head_dim, float out_scale,
+                              uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, void* stream, int batch, int64_t p_bstride,
+                              int64_t v_bstride, int64_t ctx_bstride) {
     RNAMSM_CHECK_ARG(p_hi && v_hi && (ctx || ctx_hi), "row_apply16: null pointer");
     RNAMSM_CHECK_ARG((p_lo == nullptr) == (v_lo == nullptr), "row_apply16: p_lo and v_lo must both be given (x3) or both be null");
     RNAMSM_CHECK_ARG(!ctx_hi || (ctx_lo == nullptr) == (p_lo == nullptr), "row_apply16: ctx_lo must match the operand split");
     RNAMSM_CHECK_ARG(head_dim == 64, "row_apply16: head_dim must be 64 (got %d)", head_dim);
-    RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0, "row_apply16: bad shape R=%d C=%d H=%d", R, C, H);
+    RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0 && batch >= 1 && batch <= 65535, "row_apply16: bad shape R=%d C=%d H=%d batch=%d", R, C, H, batch);
     RNAMSM_CHECK_ARG(fmt == 0 || (fmt == 1 && p_lo), "row_apply16: fmt must be 0 (bf16) or 1 (fp16, hi/lo only)");
     RNAMSM_CHECK_ARG(ldp >= C && ldp % 64 == 0, "row_apply16: P plane stride must be C rounded up to a multiple of 64");
-    RNAMSM_CHECK_ARG(ld >= (int64_t)H * 64 && ld % 8 == 0 && al16(p_hi) && al16(p_lo) && al16(v_hi) && al16(v_lo),
+    RNAMSM_CHECK_ARG(ld >= (int64_t)H * 64 && ld % 8 == 0 && p_bstride % 8 == 0 && v_bstride % 8 == 0 && ctx_bstride % 4 == 0 &&
+                     al16(p_hi) && al16(p_lo) && al16(v_hi) && al16(v_lo),
                      "row_apply16: planes must be 16-byte aligned with ld %% 8 == 0");
     RNAMSM_CHECK_ARG(ldc >= (int64_t)H * 64 && ldc % 4 == 0 && (ctx_hi ? (reinterpret_cast<uintptr_t>(ctx_hi) & 7u) == 0 : al16(ctx)),
                      "row_apply16: output alignment");
@@ -654,8 +700,8 @@ extern "C" int rnamsm_row_apply16(const uint16_t* p_hi, const uint16_t* p_lo, in
     const bool big = C >= 256 && R >= 4 && tuning().attn16 != 2;      // 256x256 tiles ("attn16" = 2 forces 128x128: A/B)
     const unsigned tiles_i = big ? (C + 255) / 256 : (C + 127) / 128, tiles_n = big ? (R + 3) / 4 : (R + 1) / 2;
     const unsigned grid = xcd_panel_grid((unsigned)H * tiles_n, tiles_i);
-    KernelTimer timer(TC_ROW_APPLY, 2.0 * H * C * C * R * 64,
-                      (p_lo ? 4.0 : 2.0) * ((double)R * C * H * 64 + (double)H * C * ldp) + (ctx_hi ? (p_lo ? 4.0 : 2.0) : 4.0) * R * C * H * 64,
+    KernelTimer timer(TC_ROW_APPLY, 2.0 * batch * H * C * C * R * 64,
+                      batch * ((p_lo ? 4.0 : 2.0) * ((double)R * C * H * 64 + (double)H * C * ldp) + (ctx_hi ? (p_lo ? 4.0 : 2.0) : 4.0) * R * C * H * 64),
                       s, PEAK_F16_MFMA_TFLOPS, p_lo ? 3.0 : 1.0);
 #define RA_GO(SP_, FMT_, OUT_)                                                                                      \
     do {                                                                                                            \
@@ -666,8 +712,8 @@ extern "C" int rnamsm_row_apply16(const uint16_t* p_hi, const uint16_t* p_lo, in
                 if (rc) return rc;                                                                                  \
                 cfgx_.mark();                                                                                       \
             }                                                                                                       \
-            hipLaunchKernelGGL((row_apply16x_kernel<SP_, FMT_, OUT_>), dim3(grid), dim3(R16X_THREADS), R16XCfg<SP_>::LDS, \
-                               s, p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale);   \
+            hipLaunchKernelGGL((row_apply16x_kernel<SP_, FMT_, OUT_>), dim3(grid, batch), dim3(R16X_THREADS), R16XCfg<SP_>::LDS, \
+                               s, p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride); \
             break;                                                                                                  \
         }                                                                                                           \
         static DeviceOnce cfg_;                                                                                   \
@@ -676,8 +722,8 @@ extern "C" int rnamsm_row_apply16(const uint16_t* p_hi, const uint16_t* p_lo, in
             if (rc) return rc;                                                                                      \
             cfg_.mark();                                                                                            \
         }                                                                                                           \
-        hipLaunchKernelGGL((row_apply16_kernel<SP_, FMT_, OUT_>), dim3(grid), dim3(R16_THREADS), R16Cfg<SP_>::LDS, s, p_hi, \
-                           p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale);                \
+        hipLaunchKernelGGL((row_apply16_kernel<SP_, FMT_, OUT_>), dim3(grid, batch), dim3(R16_THREADS), R16Cfg<SP_>::LDS, s, p_hi, \
+                           p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride); \
     } while (0)
     if (!p_lo) {
         if (ctx_hi) RA_GO(1, 0, 1); else RA_GO(1, 0, 0);
@@ -690,3 +736,17 @@ extern "C" int rnamsm_row_apply16(const uint16_t* p_hi, const uint16_t* p_lo, in
     RNAMSM_CHECK_LAUNCH("row_apply16");
     return RNAMSM_OK;
 }
+
+extern "C" int rnamsm_row_apply16(const uint16_t* p_hi, const uint16_t* p_lo, int64_t ldp, const uint16_t* v_hi,
+                                  const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
+                                  int head_dim, float out_scale, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, void* stream) {
+    return row_apply16_launch(p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, head_dim, out_scale, ctx_hi, ctx_lo, fmt, stream, 1, 0, 0, 0);
+}
+namespace rnamsm {
+int row_apply16_batched(const uint16_t* p_hi, const uint16_t* p_lo, int64_t ldp, const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld,
+                        int64_t ldc, int R, int C, int H, float out_scale, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, int batch,
+                        int64_t p_bstride, int64_t v_bstride, int64_t ctx_bstride, void* stream) {
+    return row_apply16_launch(p_hi, p_lo, ldp, v_hi, v_lo, ld, nullptr, ldc, R, C, H, 64, out_scale, ctx_hi, ctx_lo, fmt, stream, batch,
+                              p_bstride, v_bstride, ctx_bstride);
+}
+}  // namespace rnamsm

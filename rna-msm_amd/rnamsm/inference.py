@@ -18,7 +18,7 @@ from typing import Dict, List, Optional
 import numpy as np
 import torch
 
-from . import sharding
+from . import ops, sharding
 from .alphabet import RNAAlphabet
 from .config import Config
 from .model import MSATransformer
@@ -207,7 +207,7 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
             # data.batch_small_msas: consecutive small alignments wait in `group` and go through ONE launch set
             # (forward_ragged: padded into one frame, every MSA scaled by its own depth); a lone forward of a few hundred
             # tokens costs 5.5 ms on a mostly idle chip.  Order of delivery = order of the id list either way.
-            batching = bool(getattr(cfg.data, "batch_small_msas", True)) and model.gemm_dtype == "f32"
+            batching = bool(getattr(cfg.data, "batch_small_msas", True)) and (model.gemm_dtype == "f32" or ops.get_param("attn16") != 0)
             group: List = []                                          # (idx, tokens on the device)
 
             def flush() -> None:

@@ -85,7 +85,7 @@ class MSATransformer(nn.Module):
         # Arithmetic of the contractions: "f32" (exact, default), "f16x3", "bf16x3" or "bf16" (include/rnamsm.h) -- for the
         # C++ driver and, through the property below, for every mirror module of the layer-wise path
         self.gemm_dtype = "f32"
-        # forward(tokens[B,R,C]) with B > 1, no <pad>, exact path: MSAs are run together (rnamsm_forward_batch) in groups of
+        # forward(tokens[B,R,C]) with B > 1 (any arithmetic mode): MSAs are run together (rnamsm_forward_batch) in groups of
         # at most batch_token_budget tokens -- pays below ~8 k tokens per MSA, where a lone forward leaves the chip idle
         self.batch_small_msas = True
         self.batch_token_budget = 32768
@@ -285,18 +285,21 @@ class MSATransformer(nn.Module):
                                                self.fold_layernorm if fold_layernorm is None else fold_layernorm)
 
     def forward_batch(self, tokens3d: torch.Tensor, has_padding: Optional[bool] = None,
-                      fold_layernorm: Optional[bool] = None, true_rows: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        """B same-shape MSAs (ragged ones padded with <pad>; direct-path mask semantics) through rnamsm_forward_batch (exact
-        path): tokens [B,R,C] -> row_attn [B,NL,H,C,C], repr [B,R,C,D], emb [B,C-1,D], atp [B,NL*H,C-1,C-1], err int32[1]
-        (bits as in forward_one).  has_padding: None = look at the tokens.  true_rows (int32 [B] on the device): the real
-        depth of every element of a RAGGED batch -- each MSA's tied logits are then scaled by its own depth and the element comes
-        out as its unpadded forward would (forward_ragged); None = the reference's batch semantics (padded depth)."""
+                      fold_layernorm: Optional[bool] = None, true_rows: Optional[torch.Tensor] = None,
+                      gemm_dtype: Optional[str] = None) -> Dict[str, torch.Tensor]:
+        """B same-shape MSAs (ragged ones padded with <pad>; direct-path mask semantics) through rnamsm_forward_batch, in the
+        model's arithmetic mode (`gemm_dtype`: None = self.gemm_dtype): tokens [B,R,C] -> row_attn [B,NL,H,C,C], repr [B,R,C,D],
+        emb [B,C-1,D], atp [B,NL*H,C-1,C-1], err int32[1] (bits as in forward_one).  has_padding: None = look at the tokens.
+        true_rows (int32 [B] on the device): the real depth of every element of a RAGGED batch -- each MSA's tied logits are
+        then scaled by its own depth and the element comes out as its unpadded forward would (forward_ragged); None = the
+        reference's batch semantics (padded depth)."""
         if self.training:
             raise NotImplementedError("inference only (model.eval())")
         if not tokens3d.is_cuda:
             raise _lib.RnamsmError("tokens must be on the HIP device (no CPU path exists)")
         assert tokens3d.ndim == 3
         fold = self.fold_layernorm if fold_layernorm is None else fold_layernorm
+        mode = gemm_dtype or self.gemm_dtype
         with torch.cuda.device(tokens3d.device):
             B, R, C = tokens3d.shape
             lib = _lib.load()
@@ -313,25 +316,37 @@ class MSATransformer(nn.Module):
             emb = torch.empty(B, C - 1, D, device=dev, dtype=torch.float32)
             atp = torch.empty(B, NL * H, C - 1, C - 1, device=dev, dtype=torch.float32)
             err = torch.zeros(1, device=dev, dtype=torch.int32)
-            folded = self._folded_weights() if (fold and not has_padding) else None
+            dtype = _lib.DTYPES[mode]
+            if dtype != _lib.F32 and mode != self.gemm_dtype:
+                raise ValueError("forward_batch: a 16-bit gemm_dtype must be the model's own (the weight planes are built per mode)")
+            planes = self._weight_planes() if dtype != _lib.F32 else None
+            folded = self._folded_weights() if (fold and not has_padding and dtype == _lib.F32) else None
             _lib.check(lib.rnamsm_forward_batch(ctypes.byref(dims), ptrs, toks.data_ptr(), B, R, C, ws.data_ptr(), ws.numel(),
                                                 row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
                                                 err.data_ptr(), int(has_padding),
                                                 None if true_rows is None else true_rows.to(dev, torch.int32).contiguous().data_ptr(),
-                                                folded, torch.cuda.current_stream().cuda_stream))
+                                                folded, dtype, planes, torch.cuda.current_stream().cuda_stream))
         return {"row_attn": row_attn, "repr": rep, "emb": emb, "atp": atp, "err": err}
 
     def checked_forward_batch(self, tokens3d: torch.Tensor, has_padding: Optional[bool] = None,
                               true_rows: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
-        """forward_batch + the error word (see checked_forward_one)."""
+        """forward_batch + the error word (see checked_forward_one): index errors raise, a 16-bit batch with a non-finite output
+        is redone on the exact path, a failed folded-LayerNorm precondition without the fold."""
         out = self.forward_batch(tokens3d, has_padding, true_rows=true_rows)
         err = int(out["err"].item())
         if err & self.ERR_INDEX:
             raise IndexError("batch: token or position index out of range")
+        import warnings
+        mode = None
+        if (err & self.ERR_NONFINITE) and self.gemm_dtype != "f32" and self.check_finite:
+            warnings.warn(f"batch: gemm_dtype={self.gemm_dtype!r} produced non-finite outputs (operand outside the 16-bit range); "
+                          "the batch is recomputed on the exact fp32 path")
+            mode = "f32"
+            out = self.forward_batch(tokens3d, has_padding, true_rows=true_rows, gemm_dtype=mode)
+            err = int(out["err"].item())
         if err & self.ERR_FOLD:
-            import warnings
             warnings.warn("batch: a token row's mean exceeds 32x its spread; LayerNorm is applied in its own launches for this batch")
-            out = self.forward_batch(tokens3d, has_padding, fold_layernorm=False, true_rows=true_rows)
+            out = self.forward_batch(tokens3d, has_padding, fold_layernorm=False, true_rows=true_rows, gemm_dtype=mode)
         return out
 
     def forward_ragged(self, msas: List[torch.Tensor]) -> List[Dict[str, torch.Tensor]]:
@@ -475,7 +490,8 @@ class MSATransformer(nn.Module):
         fast = repr_set <= {self.num_layers}
         done = 0
         chunked = has_padding and _lib.load().rnamsm_row_chunks(R, C, min(int(self.max_tokens_per_msa), 2 ** 31 - 1)) > 0
-        if fast and B > 1 and not chunked and self.gemm_dtype == "f32" and self.batch_small_msas and not self.training:
+        if fast and B > 1 and not chunked and self.batch_small_msas and not self.training and (
+                self.gemm_dtype == "f32" or ops.get_param("attn16") != 0):
             # MSAs of a few thousand tokens, same shape or padded to it: their token-parallel launches are shared
             # (rnamsm_forward_batch); a padded batch above the reference's token budget keeps its per-chunk mask semantics
             # (rnamsm_forward per MSA)

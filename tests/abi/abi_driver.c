@@ -149,14 +149,17 @@ int main(void) {
     /* the batched form: same validation, plus the batch count and the 31-bit token range */
     EXPECT(rnamsm_forward_batch_workspace_bytes(&dims, 8, 16, 64) > rnamsm_forward_batch_workspace_bytes(&dims, 1, 16, 64));
     EXPECT(rnamsm_forward_batch_workspace_bytes(NULL, 2, 4, 4) == 0 && rnamsm_forward_batch_workspace_bytes(&dims, 0, 4, 4) == 0);
-    REFUSED(rnamsm_forward_batch(NULL, weights, toks, 2, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, NULL));
-    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 0, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, NULL));
-    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 2, 1025, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, NULL));
-    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 2, 4, 1, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, NULL));
-    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 4096, 1024, 1024, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, NULL));
-    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 2, 4, 4, NULL, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, NULL));
-    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 2, 64, 128, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, NULL));
+    REFUSED(rnamsm_forward_batch(NULL, weights, toks, 2, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, 0, NULL, NULL));
+    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 0, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, 0, NULL, NULL));
+    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 2, 1025, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, 0, NULL, NULL));
+    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 2, 4, 1, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, 0, NULL, NULL));
+    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 4096, 1024, 1024, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, 0, NULL, NULL));
+    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 2, 4, 4, NULL, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, 0, NULL, NULL));
+    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 2, 64, 128, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, 0, NULL, NULL));
     EXPECT(strstr(rnamsm_last_error(), "forward_batch: workspace too small") != NULL);
+    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 2, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, 9, NULL, NULL));
+    REFUSED(rnamsm_forward_batch(&dims, weights, toks, 2, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, 1, NULL, NULL));
+    EXPECT(strstr(rnamsm_last_error(), "need weight_planes") != NULL);
     {
         rnamsm_model_dims bad = dims;
         bad.embed_dim = 700;

@@ -827,3 +827,51 @@ def test_16bit_overflow_sets_the_nonfinite_bit_and_is_redone_on_fp32():
     assert torch.equal(out["emb"], exact["emb"]) and torch.equal(out["atp"], exact["atp"])
     m.check_finite = False                                         # opt-out: the raw 16-bit result, flagged
     assert int(m.checked_forward_one(toks)["err"].item()) & m.ERR_NONFINITE
+
+
+@pytest.mark.parametrize("mode,emb_tol,atp_tol", [("f16x3", 1e-4, 1e-4), ("bf16x3", 1e-4, 1e-3), ("bf16", 5e-2, 3e-1)])
+def test_batched_and_ragged_forward_in_the_16bit_modes(model, mode, emb_tol, atp_tol):
+    """rnamsm_forward_batch runs the 16-bit modes too (plane data flow, K4'..K7' with the MSA on gridDim.y,
+    the ragged batch's per-MSA logit scale on the fp32 accumulators).  Which GEMM kernel runs depends on the batch's token
+    count, so an element agrees with its lone forward to the MODE's rounding (f16x3: fp32-grade), not bit for bit; against the
+    oracle every element meets the mode's bar of test_gemm_arithmetic_modes_of_the_forward; reruns are bit-identical; the
+    padded B = 2 reference fixture goes through the same route."""
+    m, state = model
+    params = O.to_torch_params(state)
+    try:
+        m.gemm_dtype = mode
+        # same-shape batch, no padding (T = 3 * 40 * 60 = 7200 tokens: the batch runs the 256x256 GEMM kernels, an element alone the 128x128 ones)
+        toks = torch.from_numpy(np.stack([synthetic.make_tokens(40, 60, 300 + b) for b in range(3)])).to("cuda:0")
+        bat = m.checked_forward_batch(toks)
+        again = m.checked_forward_batch(toks)
+        assert torch.equal(bat["emb"], again["emb"]) and torch.equal(bat["atp"], again["atp"])
+        for b in range(3):
+            one = m.checked_forward_one(toks[b])
+            emb, atp = O.pack_outputs(O.forward(toks[b].cpu(), params))
+            assert rel_l2(bat["emb"][b].cpu().numpy(), np.asarray(emb)) < emb_tol, (mode, b)
+            assert np.abs(bat["atp"][b].cpu().numpy() - np.asarray(atp)).max() < atp_tol, (mode, b)
+            if mode == "f16x3":
+                assert rel_l2(bat["emb"][b].cpu().numpy(), one["emb"].cpu().numpy()) < 2e-5
+                assert np.abs(bat["atp"][b].cpu().numpy() - one["atp"].cpu().numpy()).max() < 5e-5
+        res = m(toks, repr_layers=[10], need_head_weights=True, need_logits=False)         # forward() takes the batched route
+        assert torch.equal(res["row_attentions"], bat["row_attn"])
+        # ragged batch: every alignment as alone
+        shapes = [(8, 17), (3, 9), (12, 17), (1, 30), (7, 25), (12, 30)]
+        msas = [torch.from_numpy(synthetic.make_tokens(r, c, 70 + i)).to("cuda:0") for i, (r, c) in enumerate(shapes)]
+        for t, got in zip(msas, m.forward_ragged(msas)):
+            emb, atp = O.pack_outputs(O.forward(t.cpu(), params))
+            assert got["emb"].shape == tuple(emb.shape) and got["atp"].shape == tuple(atp.shape)
+            assert rel_l2(got["emb"].cpu().numpy(), np.asarray(emb)) < emb_tol, (mode, tuple(t.shape))
+            assert np.abs(got["atp"].cpu().numpy() - np.asarray(atp)).max() < atp_tol, (mode, tuple(t.shape))
+            if mode == "f16x3":
+                one = m.checked_forward_one(t, need_repr=False)
+                assert rel_l2(got["emb"].cpu().numpy(), one["emb"].cpu().numpy()) < 2e-5
+                assert np.abs(got["atp"].cpu().numpy() - one["atp"].cpu().numpy()).max() < 5e-5
+        if mode == "f16x3":          # the reference's padded batch (direct-path masks) through the batched 16-bit route
+            g = golden("forward_padded_b2.npz")
+            out = m.checked_forward_batch(torch.from_numpy(g["tokens"]).to("cuda:0"))
+            for b in range(2):
+                assert rel_l2(out["repr"][b].cpu().numpy(), g["rep10"][b]) < 1e-4
+                assert np.abs(out["row_attn"][b].cpu().numpy() - g["row_attentions"][b]).max() < 1e-4
+    finally:
+        m.gemm_dtype = "f32"
