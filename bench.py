@@ -570,11 +570,13 @@ def run_rank(args) -> int:
         attn_fl = mult * sum(timings[k]["flops"] for k in ("row_logits", "row_apply", "col_attn"))
         kern_ms = sum(v["ms"] for v in timings.values())
         traffic, traffic_src = None, None
-        if (M, L) == (256, 512):                   # the shape the committed PMC passes were collected on
+        if (M, L) == (256, 512):                   # the shapes the committed PMC passes were collected on
             traffic, traffic_src = {"f32": lambda: pmc_traffic_per_launch(),
                                     "bf16": lambda: pmc_traffic_per_launch("rnamsm::gemm16_", "bf16_"),
                                     "f16x3": lambda: pmc_traffic_per_launch("rnamsm::gemm16_", "f16x3_"),
                                     "bf16x3": lambda: (None, None)}[args.gemm_dtype]()
+        elif (M, L) == (1024, 1024) and args.gemm_dtype == "bf16":     # BASELINE configs[4]
+            traffic, traffic_src = pmc_traffic_per_launch("rnamsm::gemm16_", "cfg4_bf16_")
         if world == 1:
             gather_note = "none (single GPU)"
         elif not gather:
