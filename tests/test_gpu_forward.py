@@ -759,44 +759,46 @@ def test_ragged_batch_equals_every_alignment_alone(model):
 
 
 def test_reference_side_callers_run_unchanged(model):
-    """the two call patterns of the reference that used to see None.
+    """the two call patterns of the reference that used to see None, against outputs of the reference
+    itself (tests/golden/make_golden_r3.py).
     (a) utils/likelihood.py:60-82 -- `model(batch)["logits"]` on a batch of masked copies, positions picked by index;
-    (b) AxialTransformerLayer.forward(x, need_head_weights=True)[1] -- the column probabilities [H,C,B,R,R]
-        (modules.py:253-267, 917-945), here from a stand-alone layer against the reference's own output (fixture)."""
+    (b) AxialTransformerLayer.forward(x, need_head_weights=True) -- (x, column probabilities [H,C,B,R,R], row probabilities),
+        modules.py:253-267, 917-945, with and without a padding mask."""
     m, state = model
-    g = golden("forward_m8_c17.npz")
-    toks = torch.from_numpy(g["tokens"]).to("cuda:0")
-    R, C = toks.shape
-    # (a) the reference's loop, statement for statement (mask_positions branch), on the first 5 positions
-    indices = torch.arange(1, 6)
-    batch = toks[None].repeat(len(indices), 1, 1)
-    batch[torch.arange(len(indices)), 0, indices] = m.vocab.mask_idx
-    batch_indices = torch.arange(batch.size(0))
-    out = m(batch)["logits"]                                               # [b, R, C, V]
-    picked = out[batch_indices, 0, indices]
-    params = O.to_torch_params(state)
-    for b in range(len(indices)):
-        res = O.forward(batch[b].cpu(), params)
-        want = O.lm_head(res["representation"], params)[0, indices[b]]
-        assert rel_l2(picked[b].cpu().numpy(), want.numpy()) < 1e-4
-    # (b) a stand-alone layer returns the three-tuple of the reference
+    gl = golden("likelihood_m8_c17.npz")
+    batch = torch.from_numpy(gl["masked_tokens"]).to("cuda:0")
+    indices = torch.from_numpy(gl["indices"])
+    assert int(gl["mask_idx"]) == m.vocab.mask_idx
+    out = m(batch)["logits"]                                               # the reference's statement, no extra keyword
+    assert tuple(out.shape) == tuple(int(v) for v in gl["logits_shape"])
+    picked = out[torch.arange(batch.size(0)), 0, indices]
+    assert rel_l2(picked.cpu().numpy(), gl["picked_logits"]) < 1e-4
     from rnamsm import modules as M
-    name = "d768_r6_c19"
-    go = golden(f"op_{name}.npz")
-    D, H, R, C, _ = (int(v) for v in go["meta"])
-    st = synthetic.make_state_dict(seed=7, embed_dim=D, num_layers=1, num_heads=H)
-    layer = M.AxialTransformerLayer(D, 4 * D, H, max_tokens_per_msa=2 ** 30)
-    layer.load_state_dict({k[len("layers.0."):]: torch.from_numpy(v) for k, v in st.items() if k.startswith("layers.0.")}, strict=True)
-    layer = layer.eval().to("cuda:0")
-    x = torch.from_numpy(synthetic.normal(f"x:{name}", 7, (R, C, 1, D)).astype(np.float32)).to("cuda:0")
-    y, cp, rp = layer(x, need_head_weights=True)
-    assert cp.shape == (H, C, 1, R, R) and rp.shape == (H, 1, C, C)
-    assert rel_l2(y.cpu()[:, :, 0], go["layer_out"]) < 1e-4
-    assert np.abs(rp.cpu().numpy()[:, 0] - go["layer_row_probs"]).max() < 2e-5
-    # the fixture's col_probs are the stand-alone column module's (input x, not the row block's output): checked in
-    # test_gpu_kernels.py::test_modules_match_reference_fixtures; here: a distribution over keys, consistent with the output
-    assert float((cp.sum(-1) - 1).abs().max()) < 1e-5
-    assert layer(x).shape == x.shape                                      # need_head_weights=False: the tensor alone
+    for name in ("d128_r7_c33", "d768_r6_c19"):
+        go = golden(f"layer_probs_{name}.npz")
+        D, H, R, C = (int(v) for v in go["meta"])
+        st = synthetic.make_state_dict(seed=7, embed_dim=D, num_layers=1, num_heads=H)
+        layer = M.AxialTransformerLayer(D, 4 * D, H, max_tokens_per_msa=2 ** 30)
+        layer.load_state_dict({k[len("layers.0."):]: torch.from_numpy(v) for k, v in st.items() if k.startswith("layers.0.")}, strict=True)
+        layer = layer.eval().to("cuda:0")
+        x = torch.from_numpy(synthetic.normal(f"x:{name}", 7, (R, C, 1, D)).astype(np.float32)).to("cuda:0")
+        y, cp, rp = layer(x, need_head_weights=True)
+        assert cp.shape == (H, C, 1, R, R) and rp.shape == (H, 1, C, C)
+        assert rel_l2(y.cpu()[:, :, 0], go["out"]) < 1e-4
+        assert np.abs(cp.cpu().numpy()[:, :, 0] - go["col_probs"]).max() < 2e-5
+        assert np.abs(rp.cpu().numpy()[:, 0] - go["row_probs"]).max() < 2e-5
+        pad = torch.from_numpy(go["pad"]).to("cuda:0")
+        ym, cpm, rpm = layer(x, self_attn_padding_mask=pad, need_head_weights=True)
+        assert rel_l2(ym.cpu()[:, :, 0], go["out_masked"]) < 1e-4
+        assert np.abs(cpm.cpu().numpy()[:, :, 0] - go["col_probs_masked"]).max() < 2e-5
+        assert np.abs(rpm.cpu().numpy()[:, 0] - go["row_probs_masked"]).max() < 2e-5
+        assert layer(x).shape == x.shape                                  # need_head_weights=False: the tensor alone
+        for mode in ("f16x3",):                                           # the 16-bit route of the same three-tuple
+            layer.row_self_attention.layer.gemm_dtype = layer.column_self_attention.layer.gemm_dtype = mode
+            layer.feed_forward_layer.layer.gemm_dtype = mode
+            y16, cp16, _ = layer(x, self_attn_padding_mask=pad, need_head_weights=True)
+            assert rel_l2(y16.cpu()[:, :, 0], go["out_masked"]) < 1e-4
+            assert np.abs(cp16.cpu().numpy()[:, :, 0] - go["col_probs_masked"]).max() < 5e-5
     # inside MSATransformer the layers are built without them (the model discards them, model.py:390)
     assert m.layers[0].column_self_attention.layer.return_probs is False
 

@@ -245,3 +245,38 @@ def test_a_padded_frame_differs_from_the_alignment_alone_only_through_the_padded
     deep[:3] = toks
     rows = O.forward(deep, params)
     assert np.abs(rows["row_attentions"].numpy() - alone["row_attentions"].numpy()).max() > 1e-2   # sqrt(6) instead of sqrt(3)
+
+
+def test_oracle_lm_head_on_masked_copies_matches_the_reference_likelihood_pattern():
+    """tests/golden/likelihood_m8_c17.npz (make_golden_r3.py): the reference's `model(batch)["logits"]` on masked copies of an
+    alignment, picked at (copy i, row 0, position i) as utils/likelihood.py:60-82 does -- the oracle's forward + lm_head."""
+    g = golden("likelihood_m8_c17.npz")
+    state = synthetic.make_state_dict(seed=0)
+    params = O.to_torch_params(state)
+    batch, idx = torch.from_numpy(g["masked_tokens"]), g["indices"]
+    got = np.stack([O.lm_head(O.forward(batch[b], params)["representation"], params)[0, int(idx[b])].numpy() for b in range(len(idx))])
+    assert rel_l2(got, g["picked_logits"]) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["d128_r7_c33", "d768_r6_c19"])
+def test_oracle_layer_three_tuple_matches_reference(name):
+    """tests/golden/layer_probs_*.npz (make_golden_r3.py): AxialTransformerLayer.forward(need_head_weights=True) of the
+    reference -- output, column probabilities, row probabilities -- without and with a padding mask, against the oracle's
+    row_attention / col_attention(return_probs=True) / ffn chained as modules.py:242-267 chains them."""
+    g = golden(f"layer_probs_{name}.npz")
+    D, H, R, C = (int(v) for v in g["meta"])
+    params = O.to_torch_params(synthetic.make_state_dict(seed=7, embed_dim=D, num_layers=1, num_heads=H))
+    x0 = torch.from_numpy(synthetic.normal(f"x:{name}", 7, (R, C, 1, D)).astype(np.float32))[:, :, 0]
+    for pad, sfx in ((None, ""), (torch.from_numpy(g["pad"])[0], "_masked")):
+        ln = lambda x, pre: O.layer_norm(x, params[f"{pre}.layer_norm.weight"], params[f"{pre}.layer_norm.bias"])
+        pre = "layers.0.row_self_attention"
+        y, rp = O.row_attention(ln(x0, pre), params, f"{pre}.layer", H, None, pad)
+        x1 = x0 + y
+        pre = "layers.0.column_self_attention"
+        y, cp = O.col_attention(ln(x1, pre), params, f"{pre}.layer", H, return_probs=True, pad=pad)
+        x2 = x1 + y
+        pre = "layers.0.feed_forward_layer"
+        x3 = x2 + O.ffn(ln(x2, pre), params, f"{pre}.layer")
+        assert rel_l2(x3.numpy(), g["out" + sfx]) < 1e-5
+        assert np.abs(cp.numpy() - g["col_probs" + sfx]).max() < 2e-5
+        assert np.abs(rp.numpy() - g["row_probs" + sfx]).max() < 2e-5

@@ -38,7 +38,11 @@ for mode in (False, True, False, True):
 # ---- a list of SMALL alignments: the default CLI (data.batch_small_msas=true: consecutive small alignments
 # share one ragged launch set) against the strictly one-by-one loop of the reference (data.batch_small_msas=false)
 NS = int(os.environ.get("NSMALL", 64))
-if NS:
+# two populations: "tiny" (2-12 rows x 40-80 columns: every alignment joins a group) and "small" (4-24 rows x 40-120 columns: a third
+# exceed the 1536-token limit and run alone, flushing the waiting group)
+for label, (dlo, dhi), (llo, lhi) in (("tiny", (2, 13), (40, 81)), ("small", (4, 25), (40, 121))):
+    if not NS:
+        break
     res = {}
     for rnd in range(2):
         for batching in (False, True):
@@ -48,7 +52,7 @@ if NS:
             ids = [f"small{i:03d}" for i in range(NS)]
             tokens = 0
             for i in ids:
-                depth, length = int(rng.randint(4, 25)), int(rng.randint(40, 121))
+                depth, length = int(rng.randint(dlo, dhi)), int(rng.randint(llo, lhi))
                 tokens += depth * (length + 1)
                 rows = letters[rng.randint(0, 5, size=(depth, length))]
                 with open(os.path.join(root, "results", f"{i}.a2m_msa2"), "w") as f:
@@ -64,5 +68,5 @@ if NS:
             res.setdefault(batching, []).append(dt)
             shutil.rmtree(root)
     one, bat = min(res[False]), min(res[True])
-    print(f"{NS} small alignments (4-24 rows x 40-120 columns, {tokens} tokens): one by one {one:.3f} s = {NS / one:.1f} MSA/s; "
+    print(f"{NS} {label} alignments ({dlo}-{dhi - 1} rows x {llo}-{lhi - 1} columns, {tokens} tokens): one by one {one:.3f} s = {NS / one:.1f} MSA/s; "
           f"default (batched) {bat:.3f} s = {NS / bat:.1f} MSA/s; x{one / bat:.2f}", flush=True)
