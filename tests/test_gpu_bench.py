@@ -52,6 +52,21 @@ def test_two_ranks_gather_the_same_outputs_as_one_rank():
     assert len(gs["per_rank_host_wait_s"]) == 2 and len(gs["per_rank_stream_wait_ms"]) == 2
 
 
+def test_eight_ranks_on_one_device_gather_the_same_outputs_as_one_rank():
+    """The driver's largest launch, `--gpus 8`, with the test hooks (all ranks on device 0, gloo): 11 MSAs over 8 ranks -- two
+    rounds, the second with five item-less ranks -- gathered bit-identical to the N = 1 run; per-rank gather statistics present."""
+    common = ["--workload", "configs3", "--num-msas", "11", "--num-seqs", "8", "--seq-len", "24", "--steps", "1", "--warmup", "1",
+              "--digest", "--no-cpu-baseline", "--no-fast-mode"]
+    one = _bench(["--gpus", "1"] + common)
+    eight = _bench(["--gpus", "8", "--backend", "gloo", "--one-device"] + common)
+    assert eight["n_gpus"] == 8 and eight["config"]["world_size_initialised"] == 8
+    assert one["output_digest"]["items"] == eight["output_digest"]["items"] == 11
+    assert one["output_digest"]["value"] == eight["output_digest"]["value"]
+    gs = eight["gather_stats"]
+    assert len(gs["per_rank_bytes_received"]) == 8 and gs["per_rank_bytes_received"][0] > 0 and sum(gs["per_rank_bytes_received"][1:]) == 0
+    assert eight["compute_only_value"] > 0
+
+
 def test_default_workload_runs_weak_scaling_through_the_same_gatherer():
     two = _bench(["--gpus", "2", "--backend", "gloo", "--one-device", "--num-seqs", "16", "--seq-len", "40", "--steps",
                   "2", "--warmup", "1", "--no-cpu-baseline", "--no-fast-mode", "--digest"])
