@@ -451,6 +451,11 @@ void rnamsm_timing_reset(void);
  *                 measured: no effect).  Speed only, results bit-identical.
  *   "gemm16_mfma16"  plain-bf16 256x256 GEMM: 1 (default) = the 16x16x32-MFMA kernel for N > 1024, 2 = for every N,
  *                 0 = the 32x32x16 kernel.  Results agree to fp32 rounding (the k order inside a step differs).
+ *   "gemm16_pp"   plain-bf16 plane GEMMs: 1 = gemm16_pp_kernel (four waves x 512 registers with two accumulator sets: a tile's
+ *                 epilogue leaves under the next tile's K loop), 0 (default) = the 256x256 kernels.  Bit-identical to the
+ *                 16x16x32 256x256 kernel; measured 0.61-0.83x (EXPERIMENTS.md R3.1), kept as the record of that experiment.
+ *   "col_small"   fp32 rnamsm_col_attn_fused at R <= 16: 1 (default) = one wave per (column, head) on v_mfma_f32_16x16x4_f32,
+ *                 no LDS; 0 = the 128-query-block kernels.  Results agree to fp32 rounding.
  *   "row16_max_rows"  hi/lo modes of rnamsm_row_logits16: cap on the rows of one partial slab (default 32, 0 = none).
  *                 Shorter fp32 accumulation chains; changes results at the rounding level (and the slab count).
  *   "col_dma"     fp32 rnamsm_col_attn_fused: 1 = K/V chunks staged by LDS-DMA, 32-key chunks, three blocks per CU;

@@ -184,6 +184,10 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().row16_max_rows = value;
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "col_small")) {
+        rnamsm::tuning().col_small = value != 0;
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "col_dma")) {
         rnamsm::tuning().col_dma = value < 0 ? -1 : (value != 0);
         return RNAMSM_OK;
@@ -195,6 +199,7 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "attn16")) return rnamsm::tuning().attn16;
     if (name && !strcmp(name, "ln_fold")) return rnamsm::tuning().ln_fold;
     if (name && !strcmp(name, "greedy_fused")) return rnamsm::tuning().greedy_fused;
+    if (name && !strcmp(name, "col_small")) return rnamsm::tuning().col_small;
     if (name && !strcmp(name, "col_dma")) return rnamsm::tuning().col_dma;
     if (name && !strcmp(name, "row16_max_rows")) return rnamsm::tuning().row16_max_rows;
     if (name && !strcmp(name, "gemm16_pp")) return rnamsm::tuning().gemm16_pp;

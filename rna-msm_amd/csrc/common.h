@@ -69,6 +69,7 @@ struct Tuning {
     int gemm_tile = 0;             // fp32 GEMM block tile: 0 = by shape, 1 = always 128x128, 2 = always 128x64
     int gemm_splitk = 1;           // rnamsm_forward, fc2 below ~1.4 k tokens: 1 = four K ranges + an ordered reduction (gemm_f32_splitk_factor), 0 = never, 2 / 4 / 8 = forced (A/B)
     int row_vt = 1;                // fp32 row_apply: 1 = V tile transposed while staged (b128 fragments), 0 = [k][n] tile
+    int col_small = 1;             // fp32 col_attn at R <= 16: 1 = one wave per (column, head), no LDS (col_attn_small_kernel), 0 = the 128-query blocks
     int col_dma = -1;              // fp32 col_attn: 1 = LDS-DMA staging, 32-key chunks, 3 blocks/CU; 0 = register-staged kernel; -1 = by shape
     int row16_max_rows = 32;       // hi/lo modes: cap on the rows of one row_logits16 slab (0 = none): accuracy, DESIGN 3.2
     int ln_fold = 1;               // rnamsm_forward with ln_folded: 1 = LayerNorm applied inside the consuming GEMM (row sums from the producers'

@@ -290,6 +290,40 @@ def test_col_attention_kernel(dev, R, C, H):
         assert np.abs(got.numpy() - p.numpy()).max() < 5e-6
 
 
+@pytest.mark.parametrize("R,C,H", [(1, 7, 3), (2, 64, 12), (8, 64, 12), (15, 33, 2), (16, 130, 4), (13, 5, 1)])
+def test_col_attention_for_shallow_alignments_one_wave_per_problem(dev, R, C, H):
+    """col_attn_small_kernel (R <= 16: one wave per (column, head), v_mfma_f32_16x16x4_f32, no LDS) against fp64 and against the
+    128-query-block kernels it replaces (knob "col_small" = 0), without and with a padding mask (incl. a column whose keys are
+    all padded: uniform weights, as the -10000 fill gives), R = 1 (ctx = v)."""
+    from rnamsm import ops
+    qkv, D = _qkv(R, C, H, f"cs{R}_{C}")
+    g = qkv.to(dev)
+    g[:, :D] *= 0.125
+    q = (qkv[:, :D].double() * 0.125).view(R, C, H, 64)
+    k = qkv[:, D:2 * D].double().view(R, C, H, 64)
+    v = qkv[:, 2 * D:].double().view(R, C, H, 64)
+    pad = torch.from_numpy(synthetic.normal(f"cspad{R}_{C}", 3, (R, C)) > 0.6)
+    pad[:, C // 2] = True                                          # a fully padded column
+    for mask in (None, pad):
+        w = torch.einsum("ichd,jchd->hcij", q, k)
+        if mask is not None:
+            w = w.masked_fill(mask.t()[None, :, None, :], -10000)
+        want = torch.einsum("hcij,jchd->ichd", torch.softmax(w, -1), v).reshape(R * C, D)
+        gm = None if mask is None or R == 1 else mask.to(torch.uint8).view(-1).to(dev)
+        if mask is not None and R == 1:
+            continue
+        try:
+            ops.set_param("col_small", 1)
+            small = ops.col_attn(g[:, :D], g[:, D:2 * D], g[:, 2 * D:], R, C, H, pad_mask=gm).cpu()
+            ops.set_param("col_small", 0)
+            big = ops.col_attn(g[:, :D], g[:, D:2 * D], g[:, 2 * D:], R, C, H, pad_mask=gm).cpu()
+        finally:
+            ops.set_param("col_small", 1)
+        assert rel_l2(small, want) < 5e-6, (R, C, H, mask is not None)
+        assert np.abs(small.numpy() - want.numpy()).max() < 2e-5 * max(1.0, float(want.abs().max()))
+        assert rel_l2(small, big) < 2e-6
+
+
 def test_col_attention_online_softmax_rescale_is_exercised(dev):
     """Forces the running-max rescale branch: one late key dominates every query (spike placed in the last
     64-key chunk), and a second case puts the dominant key first so later tiles never rescale."""
