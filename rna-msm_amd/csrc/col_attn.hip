@@ -502,20 +502,27 @@ namespace rnamsm {
 // ---- K7 for shallow alignments (R <= 16): ONE WAVE per (column, head) problem, no LDS, no barrier.
 // The kernels above give a (column, head) a block of 128 query rows: at R = 8 such a block is 6 % full and the launch is
 // bound by block turnover (batches of small alignments spend 5 % of their time here: 24576 blocks of ~4 us at B = 32, R = 8,
-// C = 64).  With R <= 16 the whole problem is one 16x16 tile of the exact-fp32 v_mfma_f32_16x16x4_f32:
-//   S^T = K Q^T   A = K (key j on the lane's row), B = Q^T (query i on the lane's column), k-slot fq <-> d = 4 s + fq: 16 steps;
-//                 the accumulator holds S^T[key 4 fq + t][query fr], t = 0..3 -- the softmax over keys is 4 registers + two
-//                 lane exchanges (xor 16, xor 32);
-//   O^T = V^T P^T A = V^T (head dim on the lane's row), B = P^T: at step s the k-slot fq stands for key 4 fq + s, so the lane's
-//                 OWN probability register s is its B operand (no data movement, the trick of the big kernels); 4 d tiles x 4 steps.
-// Operands come straight from global memory (32 + 16 four-byte loads per lane, L1/L2-served), 32 MFMAs of 32 cycles, ~80
-// registers: 6 waves per SIMD hide the latency.  Same arithmetic as the big kernels up to the summation order.
+// C = 64).  With R <= 16 the whole problem is one 16x16 tile of the exact-fp32 v_mfma_f32_16x16x4_f32 (lane = (fr, fq),
+// fr = lane & 15 the tile row / column it feeds, fq = lane >> 4 its k-slot):
+//   S^T = K Q^T   A = K (key fr), B = Q^T (query fr).  The 64 head dims are contracted in the order the loads deliver them: lane
+//                 (fr, fq) fetches the four float4 at d = 16 g + 4 fq of its row, and step (g, e) pairs k-slot fq with
+//                 d = 16 g + 4 fq + e in BOTH operands (any order is a valid contraction order as long as A and B agree).
+//                 The accumulator holds S^T[key 4 fq + t][query fr], t = 0..3: the softmax over keys is 4 registers + two
+//                 lane exchanges (xor 16, xor 32).
+//   O^T = V^T P^T at step s the k-slot fq stands for key 4 fq + s, so the lane's OWN probability register s is its B operand
+//                 (no data movement, the trick of the big kernels).  A = V^T with the head dims dealt over four tiles as
+//                 d = 4 row + tile: lane (fr, fq) fetches ONE float4 V[key 4 fq + s][4 fr .. 4 fr + 3] per step and feeds
+//                 element tile to tile `tile`; register t of the four accumulators is then d = 16 fq + 4 t + tile, i.e. four
+//                 consecutive head dims of query fr: float4 stores.
+// 12 sixteen-byte loads per lane straight from global memory (L1/L2-served), 32 MFMAs of 32 cycles, ~45 registers: 8 waves
+// per SIMD hide the latency.  Same arithmetic as the big kernels up to the summation order.  q_rows < R: only those query
+// rows are stored (rnamsm_col_attn_fused_queries), bit-identical to the full launch's.
 template <bool MASKED>
 __global__ __launch_bounds__(256) void col_attn_small_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                              const float* __restrict__ v, int64_t ld, float* __restrict__ ctx,
                                                              int64_t ldc, int R, int C, int H,
-                                                             const uint8_t* __restrict__ pad_mask, int64_t qkv_bstride,
-                                                             int64_t ctx_bstride) {
+                                                             const uint8_t* __restrict__ pad_mask, int q_rows,
+                                                             int64_t qkv_bstride, int64_t ctx_bstride) {
     typedef float f32x4s __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int prob = blockIdx.x * 4 + wave;
@@ -528,27 +535,23 @@ __global__ __launch_bounds__(256) void col_attn_small_kernel(const float* __rest
     const int c = prob / H, h = prob % H;
     const int fr = lane & 15, fq = lane >> 4;
     const int rr = min(fr, R - 1);                               // rows past R are clamped: masked as keys, not stored as queries
-    const float* krow = k + ((int64_t)rr * C + c) * ld + h * CA_HD + fq;
-    const float* qrow = q + ((int64_t)rr * C + c) * ld + h * CA_HD + fq;
-    float kv[16], qv[16];
+    const int64_t ro = ((int64_t)rr * C + c) * ld + h * CA_HD + 4 * fq;
+    f32x4s k4[4], q4[4], v4[4];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        kv[s] = krow[4 * s];
-        qv[s] = qrow[4 * s];
+    for (int g = 0; g < 4; ++g) {
+        k4[g] = *reinterpret_cast<const f32x4s*>(k + ro + 16 * g);
+        q4[g] = *reinterpret_cast<const f32x4s*>(q + ro + 16 * g);
     }
-    // V^T fragments: step s of d tile dt reads V[key 4 fq + s][16 dt + fr]
-    float vv[4][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const float* vrow = v + ((int64_t)min(4 * fq + s, R - 1) * C + c) * ld + h * CA_HD + fr;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) vv[dt][s] = vrow[16 * dt];
-    }
+    for (int s = 0; s < 4; ++s)
+        v4[s] = *reinterpret_cast<const f32x4s*>(v + ((int64_t)min(4 * fq + s, R - 1) * C + c) * ld + h * CA_HD + 4 * fr);
     f32x4s s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};   // two chains: the 16x16x4 MFMA's dependent latency exceeds its issue time
 #pragma unroll
-    for (int s = 0; s < 16; s += 2) {
-        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[s], qv[s], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[s + 1], qv[s + 1], s1, 0, 0, 0);
+    for (int g = 0; g < 4; ++g) {
+        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[g][0], q4[g][0], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[g][1], q4[g][1], s1, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[g][2], q4[g][2], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(k4[g][3], q4[g][3], s1, 0, 0, 0);
     }
     float p[4];
     float mx = -INFINITY;
@@ -573,15 +576,16 @@ __global__ __launch_bounds__(256) void col_attn_small_kernel(const float* __rest
     const float inv = 1.f / l;
     f32x4s o[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        o[dt] = f32x4s{0.f, 0.f, 0.f, 0.f};
+    for (int tile = 0; tile < 4; ++tile) {
+        o[tile] = f32x4s{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[dt][s], p[s], o[dt], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) o[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(v4[s][tile], p[s], o[tile], 0, 0, 0);
     }
-    if (fr < R) {                                                // lane (query fr, fq) holds head dims 16 dt + 4 fq + 0..3
-        float* orow = ctx + ((int64_t)fr * C + c) * ldc + h * CA_HD + 4 * fq;
+    if (fr < q_rows) {                                           // register t of the four tiles = head dims 16 fq + 4 t + 0..3 of query fr
+        float* orow = ctx + ((int64_t)fr * C + c) * ldc + h * CA_HD + 16 * fq;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4s*>(orow + 16 * dt) = o[dt] * inv;
+        for (int t = 0; t < 4; ++t)
+            *reinterpret_cast<f32x4s*>(orow + 4 * t) = f32x4s{o[0][t], o[1][t], o[2][t], o[3][t]} * inv;
     }
 }
 }  // namespace rnamsm
@@ -605,12 +609,12 @@ static int col_attn_launch(const float* q, const float* k, const float* v, int64
     const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
     KernelTimer timer(TC_COL_ATTN, 4.0 * batch * C * H * (double)q_rows * R * CA_HD, 4.0 * batch * (2.0 * R + 2.0 * q_rows) * C * H * CA_HD, s);
     // shallow alignments: one wave per (column, head), no LDS ("col_small" = 0 keeps the 128-query blocks: A/B)
-    if (R <= 16 && q_rows == R && !ctx_hi && tuning().col_small != 0) {
+    if (R <= 16 && !ctx_hi && tuning().col_small != 0) {
         const dim3 sgrid(((unsigned)C * H + 3) / 4, batch);
         if (pad_mask)
-            hipLaunchKernelGGL(col_attn_small_kernel<true>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, qkv_bstride, ctx_bstride);
+            hipLaunchKernelGGL(col_attn_small_kernel<true>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, q_rows, qkv_bstride, ctx_bstride);
         else
-            hipLaunchKernelGGL(col_attn_small_kernel<false>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, qkv_bstride, ctx_bstride);
+            hipLaunchKernelGGL(col_attn_small_kernel<false>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, q_rows, qkv_bstride, ctx_bstride);
         RNAMSM_CHECK_LAUNCH("col_attn_small");
         return RNAMSM_OK;
     }
