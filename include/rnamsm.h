@@ -454,6 +454,9 @@ void rnamsm_timing_reset(void);
  *   "gemm16_pp"   plain-bf16 plane GEMMs: 1 = gemm16_pp_kernel (four waves x 512 registers with two accumulator sets: a tile's
  *                 epilogue leaves under the next tile's K loop), 0 (default) = the 256x256 kernels.  Bit-identical to the
  *                 16x16x32 256x256 kernel; measured 0.61-0.83x (EXPERIMENTS.md R3.1), kept as the record of that experiment.
+ *   "row16_bk64"  plain bf16, C >= 256: 1 (default) = rnamsm_row_apply16 stages 64 keys per tile (whole cache lines per P row, half
+ *                 the barriers), 2 = rnamsm_row_logits16 too runs the 256x256-tile kernel with 64-deep tiles (measured equal to
+ *                 its 128x128 kernel), 0 = neither.  Results agree to fp32 rounding.
  *   "col_small"   fp32 rnamsm_col_attn_fused at R <= 16: 1 (default) = one wave per (column, head) on v_mfma_f32_16x16x4_f32,
  *                 no LDS; 0 = the 128-query-block kernels.  Results agree to fp32 rounding.
  *   "row16_max_rows"  hi/lo modes of rnamsm_row_logits16: cap on the rows of one partial slab (default 32, 0 = none).

@@ -71,6 +71,7 @@ struct Tuning {
     int row_vt = 1;                // fp32 row_apply: 1 = V tile transposed while staged (b128 fragments), 0 = [k][n] tile
     int col_small = 1;             // fp32 col_attn at R <= 16: 1 = one wave per (column, head), no LDS (col_attn_small_kernel), 0 = the 128-query blocks
     int col_dma = -1;              // fp32 col_attn: 1 = LDS-DMA staging, 32-key chunks, 3 blocks/CU; 0 = register-staged kernel; -1 = by shape
+    int row16_bk64 = 1;            // plain bf16 at C >= 256: 1 = row_apply16x on 64-key tiles, 2 = row_logits16 on the 256x256 kernel with 64-deep tiles too, 0 = neither
     int row16_max_rows = 32;       // hi/lo modes: cap on the rows of one row_logits16 slab (0 = none): accuracy, DESIGN 3.2
     int ln_fold = 1;               // rnamsm_forward with ln_folded: 1 = LayerNorm applied inside the consuming GEMM (row sums from the producers'
                                    // epilogues) when R*C >= 18432, 3 = for every shape, 2 = every GEMM sums its rows itself (A/B), 0 = separate launches

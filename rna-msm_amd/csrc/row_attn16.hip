@@ -260,21 +260,27 @@ __global__ __launch_bounds__(R16_THREADS, SPLIT == 3 ? 1 : 2) void row_apply16_k
 
 // ---------------------------------------------------------------------------------------------- K4' (large C)
 // 256x256 tile version of row_logits16 for C >= 256 (half the operand bytes per flop, see K6' (large C) below): both
-// operands are "k" tiles with 64-B rows, K tile = half of one alignment row's head dims (32 of 64), i.e. exactly the
-// loop of gemm16_swp_kernel with q / k planes for A / W.  One block per CU, so the row split is chosen for 256 slots.
-constexpr int R16L_PLANE = 256 * 64;               // [256 rows][32 halves] = 16 KB
-template <int SPLIT>
+// operands are "k" tiles, i.e. exactly the loop of gemm16_swp_kernel with q / k planes for A / W.  One block per CU, so the
+// row split is chosen for 256 slots.  K tile: BK = 32 -- half of one alignment row's head dims, 64-B tile rows (the hi/lo
+// modes: four planes per stage) -- or BK = 64 -- one whole alignment row, 128-B tile rows = whole cache lines per DMA row,
+// half the barriers (plain bf16 only: two 64 KB stages; round 3).
+template <int SPLIT, int BK>
 struct R16LCfg {
     static constexpr int NPL = SPLIT == 3 ? 2 : 1;
-    static constexpr int BUF = 2 * NPL * R16L_PLANE;
+    static constexpr int ROWB = BK * 2;
+    static constexpr int PLANE = 256 * ROWB;            // [256 rows][BK halves]
+    static constexpr int BUF = 2 * NPL * PLANE;
     static constexpr int LDS = 2 * BUF;
+    static constexpr int RPI = 1024 / ROWB;              // tile rows per wave DMA instruction
+    static constexpr int IPW = 256 / RPI / 8;            // DMA instructions per wave per plane tile
+    static constexpr int KS = BK / 16;                   // MFMA k steps per tile
 };
 template <int SPLIT, int FMT>
 struct R16LFrag {
     typename Half16<FMT>::V8 a[SPLIT == 3 ? 2 : 1][4], b[SPLIT == 3 ? 2 : 1][2];
 };
 
-template <int SPLIT, int FMT>
+template <int SPLIT, int FMT, int BK>
 __global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
     const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
     const uint16_t* __restrict__ klo, int64_t ld, float* __restrict__ partial, int R, int C, int H, int nsplit,
@@ -286,10 +292,11 @@ __global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
     if (klo) klo += blockIdx.y * qk_bstride;
     partial += blockIdx.y * part_bstride;
     if (true_rows) scale = scale / sqrtf((float)max(true_rows[blockIdx.y], 1));
-    using Cfg = R16LCfg<SPLIT>;
-    constexpr int NPL = Cfg::NPL;
+    using Cfg = R16LCfg<SPLIT, BK>;
+    constexpr int NPL = Cfg::NPL, ROWB = Cfg::ROWB, PLANE = Cfg::PLANE, KS = Cfg::KS;
     constexpr int NMF = 8 * (SPLIT == 3 ? 3 : 1);
     constexpr int NDS = 6 * NPL;
+    static_assert(BK == 32 || (BK == 64 && SPLIT == 1), "64-deep K tiles: two 64 KB stages fit for one plane per operand only");
     typedef typename Half16<FMT>::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
 
@@ -304,36 +311,41 @@ __global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wv >> 2, wn = wv & 3, li = lane & 31, lh = lane >> 5;
 
-    const int dchunk = (lane & 3) ^ ((lane >> 4) & 3);
-    int64_t qoff[2], koff[2];
+    // DMA map: a wave instruction covers RPI tile rows (16 of 64 B, or 8 of 128 B); lane -> (row RPI g + lane / chunks-per-row,
+    // physical chunk lane % chunks-per-row) fetching the logical chunk the read-side swizzle expects there; g = wv + 8 j
+    constexpr int CPR = ROWB / 16;
+    const int dchunk = BK == 32 ? ((lane & 3) ^ ((lane >> 4) & 3))                      // (row >> 2) & 3
+                                : ((lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7));    // (row >> 1) & 7, row = 8 g + lane / 8
+    int64_t qoff[Cfg::IPW], koff[Cfg::IPW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 16 * (wv + 8 * j) + (lane >> 2);
+    for (int j = 0; j < Cfg::IPW; ++j) {
+        const int row = Cfg::RPI * (wv + 8 * j) + lane / CPR;
         qoff[j] = (int64_t)min(i0 + row, C - 1) * ld + h * 64 + dchunk * 8;     // clamped columns feed discarded outputs
         koff[j] = (int64_t)min(j0 + row, C - 1) * ld + h * 64 + dchunk * 8;
     }
-    auto issue = [&](int kt, int buf) {                      // K tile kt = (alignment row r_begin + kt/2, d half kt&1)
+    // K tile kt: BK = 32 -> (alignment row r_begin + kt/2, d half kt&1); BK = 64 -> alignment row r_begin + kt
+    auto issue = [&](int kt, int buf) {
         char* base = smem_b + buf * Cfg::BUF;
-        const int64_t rb = (int64_t)(r_begin + (kt >> 1)) * C * ld + (kt & 1) * 32;
+        const int64_t rb = BK == 32 ? (int64_t)(r_begin + (kt >> 1)) * C * ld + (kt & 1) * 32 : (int64_t)(r_begin + kt) * C * ld;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int loff = (16 * (wv + 8 * j)) * 64;
+        for (int j = 0; j < Cfg::IPW; ++j) {
+            const int loff = (Cfg::RPI * (wv + 8 * j)) * ROWB;
             dma16(qhi + rb + qoff[j], base + loff);
-            if (SPLIT == 3) dma16(qlo + rb + qoff[j], base + R16L_PLANE + loff);
-            dma16(khi + rb + koff[j], base + NPL * R16L_PLANE + loff);
-            if (SPLIT == 3) dma16(klo + rb + koff[j], base + (NPL + 1) * R16L_PLANE + loff);
+            if (SPLIT == 3) dma16(qlo + rb + qoff[j], base + PLANE + loff);
+            dma16(khi + rb + koff[j], base + NPL * PLANE + loff);
+            if (SPLIT == 3) dma16(klo + rb + koff[j], base + (NPL + 1) * PLANE + loff);
         }
     };
     auto frag_load = [&](const char* buf, int kk, R16LFrag<SPLIT, FMT>& f) {
-        const int chunk = ((2 * kk + lh) ^ ((li >> 2) & 3)) * 16;
+        const int chunk = (BK == 32 ? ((2 * kk + lh) ^ ((li >> 2) & 3)) : ((2 * kk + lh) ^ ((li >> 1) & 7))) * 16;
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                f.a[p][t] = *reinterpret_cast<const V8*>(buf + p * R16L_PLANE + (wm * 128 + t * 32 + li) * 64 + chunk);
+                f.a[p][t] = *reinterpret_cast<const V8*>(buf + p * PLANE + (wm * 128 + t * 32 + li) * ROWB + chunk);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                f.b[p][t] = *reinterpret_cast<const V8*>(buf + (NPL + p) * R16L_PLANE + (wn * 64 + t * 32 + li) * 64 + chunk);
+                f.b[p][t] = *reinterpret_cast<const V8*>(buf + (NPL + p) * PLANE + (wn * 64 + t * 32 + li) * ROWB + chunk);
         }
     };
     auto frag_mma = [&](const R16LFrag<SPLIT, FMT>& f, f32x16 (&acc)[4][2]) {
@@ -366,31 +378,38 @@ __global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
 
-    const int nk = 2 * (r_end - r_begin);
+    const int nk = (BK == 32 ? 2 : 1) * (r_end - r_begin);
     issue(0, 0);
     wait_dma_then_barrier<0>();
-    issue(1, 1);                                             // nk >= 2 always
-    R16LFrag<SPLIT, FMT> f0, f1;
-    frag_load(smem_b, 0, f0);
+    issue(nk > 1 ? 1 : 0, 1);                                // (a redundant reload when nk == 1: never read)
+    R16LFrag<SPLIT, FMT> f[2];                               // step kk lives in f[kk & 1]; KS is even
+    frag_load(smem_b, 0, f[0]);
     for (int kt = 0; kt + 1 < nk; ++kt) {
         const char* cur = smem_b + (kt & 1) * Cfg::BUF;
         const char* nxt = smem_b + ((kt & 1) ^ 1) * Cfg::BUF;
-        frag_load(cur, 1, f1);
-        frag_mma(f0, acc);
-        interleave();
+#pragma unroll
+        for (int kk = 0; kk + 1 < KS; ++kk) {
+            frag_load(cur, kk + 1, f[(kk + 1) & 1]);
+            frag_mma(f[kk & 1], acc);
+            interleave();
+        }
+        // every wave is done reading `cur` once its last fragments have arrived; tile kt+1 (issued one tile ago) must have landed
         wait_dma_then_barrier<0>();
         issue(kt + 2 < nk ? kt + 2 : nk - 1, kt & 1);        // clamped: the last reload is never read
         __builtin_amdgcn_sched_barrier(0);
-        frag_load(nxt, 0, f0);
-        frag_mma(f1, acc);
+        frag_load(nxt, 0, f[0]);
+        frag_mma(f[(KS - 1) & 1], acc);
         interleave();
     }
     {
         const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
-        frag_load(cur, 1, f1);
-        frag_mma(f0, acc);
-        interleave();
-        frag_mma(f1, acc);
+#pragma unroll
+        for (int kk = 0; kk + 1 < KS; ++kk) {
+            frag_load(cur, kk + 1, f[(kk + 1) & 1]);
+            frag_mma(f[kk & 1], acc);
+            interleave();
+        }
+        frag_mma(f[(KS - 1) & 1], acc);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the clamped reload has landed before the block exits
 
@@ -415,21 +434,28 @@ __global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
 // 8 waves as 2 (M) x 4 (N): wave tile 128 x 64 = one alignment row; the loop is gemm16_swp_kernel's (two fragment sets,
 // one LDS read per MFMA, barrier in the middle of a tile), with the B fragments coming from "t" tiles by transposed read.
 constexpr int R16X_THREADS = 512;
-constexpr int R16X_PA = 256 * 64;                  // A plane tile: [256 rows i][32 keys] = 16 KB
-constexpr int R16X_PB = 4 * 32 * T16_ROWB;         // B plane tile: [4 rows r][32 keys][64 d] = 16 KB
-template <int SPLIT>
+// KT = keys per K tile: 32 (64-B P rows; the hi/lo modes: four planes per stage) or 64 (128-B P rows = whole cache lines per
+// DMA row, half the barriers; plain bf16 only, knob "row16_bk64": two 64 KB stages)
+template <int SPLIT, int KT>
 struct R16XCfg {
     static constexpr int NPL = SPLIT == 3 ? 2 : 1;
-    static constexpr int BUF = NPL * (R16X_PA + R16X_PB);
+    static constexpr int AROWB = KT * 2;
+    static constexpr int PA = 256 * AROWB;                 // A plane tile: [256 rows i][KT keys]
+    static constexpr int PB = 4 * KT * T16_ROWB;           // B plane tile: [4 rows r][KT keys][64 d]
+    static constexpr int BUF = NPL * (PA + PB);
     static constexpr int EPI = 8 * 64 * 68 * 4;
     static constexpr int LDS = 2 * BUF > EPI ? 2 * BUF : EPI;
+    static constexpr int RPI = 1024 / AROWB;               // A tile rows per wave DMA instruction
+    static constexpr int IPA = 256 / RPI / 8;              // DMA instructions per wave per A plane tile
+    static constexpr int IPB = 4 * KT / 8 / 8;             // ... per B plane tile (8 rows of 128 B each)
+    static constexpr int KS = KT / 16;
 };
 template <int SPLIT, int FMT>
 struct R16XFrag {
     typename Half16<FMT>::V8 a[SPLIT == 3 ? 2 : 1][4], b[SPLIT == 3 ? 2 : 1][2];
 };
 
-template <int SPLIT, int FMT, int OUT>
+template <int SPLIT, int FMT, int OUT, int KT>
 __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
     const uint16_t* __restrict__ phi, const uint16_t* __restrict__ plo, int64_t ldp, const uint16_t* __restrict__ vhi,
     const uint16_t* __restrict__ vlo, int64_t ld, float* __restrict__ ctx, int64_t ldc, int R, int C, int H,
@@ -442,10 +468,11 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
     if (ctx) ctx += blockIdx.y * ctx_bstride;
     if (ctx_hi) ctx_hi += blockIdx.y * ctx_bstride;
     if (ctx_lo) ctx_lo += blockIdx.y * ctx_bstride;
-    using Cfg = R16XCfg<SPLIT>;
-    constexpr int NPL = Cfg::NPL;
+    using Cfg = R16XCfg<SPLIT, KT>;
+    constexpr int NPL = Cfg::NPL, AROWB = Cfg::AROWB, PA = Cfg::PA, PB = Cfg::PB, KS = Cfg::KS;
     constexpr int NMF = 8 * (SPLIT == 3 ? 3 : 1);          // MFMAs per k step per wave
     constexpr int NDS = 8 * NPL;                           // LDS reads per k step per wave (4 b128 + 4 tr per plane)
+    static_assert(KT == 32 || (KT == 64 && SPLIT == 1), "64-key tiles: two 64 KB stages fit for one plane per operand only");
     typedef typename Half16<FMT>::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
 
@@ -458,44 +485,54 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wv >> 2, wn = wv & 3, li = lane & 31, lh = lane >> 5;
 
-    // DMA maps.  A (64-B rows): wave w moves row groups w and w+8 (16 rows each), lane -> (row 16g + lane/4, physical
-    // chunk lane%4) fetching logical chunk (lane%4) ^ ((row>>2)&3).  B (128-B rows, rows = r_local*32 + key): row groups
-    // w and w+8 (8 rows each), lane -> (row 8g + lane/8, physical chunk lane%8) fetching (lane%8) ^ swz_t(row).
-    const int ca = (lane & 3) ^ ((lane >> 4) & 3), ct = dma_chunk_t(lane);
-    int64_t poff[2], voff[2];
-    int vkey[2];
+    // DMA maps.  A (64- or 128-B rows): wave w moves row groups w + 8 j (RPI rows each), lane -> (row RPI g + lane / CPR,
+    // physical chunk lane % CPR) fetching the logical chunk the read-side swizzle expects there.  B (128-B rows, rows =
+    // r_local * KT + key): row groups w + 8 j (8 rows each), lane -> (row 8g + lane/8, physical chunk lane%8) fetching
+    // (lane%8) ^ swz_t(row).
+    constexpr int CPR = AROWB / 16;
+    const int ca = KT == 32 ? ((lane & 3) ^ ((lane >> 4) & 3)) : ((lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7));
+    const int ct = dma_chunk_t(lane);
+    int64_t poff[Cfg::IPA], voff[Cfg::IPB];
+    int vkey[Cfg::IPB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int rowa = 16 * (wv + 8 * j) + (lane >> 2);
+    for (int j = 0; j < Cfg::IPA; ++j) {
+        const int rowa = Cfg::RPI * (wv + 8 * j) + lane / CPR;
         poff[j] = ((int64_t)h * C + min(i0 + rowa, C - 1)) * ldp + ca * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::IPB; ++j) {
         const int rowb = 8 * (wv + 8 * j) + (lane >> 3);
-        const int r = min(rr0 + (rowb >> 5), R - 1);                   // rows past R are discarded at the store
+        const int r = min(rr0 + rowb / KT, R - 1);                     // rows past R are discarded at the store
         voff[j] = (int64_t)r * C * ld + h * 64 + ct * 8;
-        vkey[j] = rowb & 31;
+        vkey[j] = rowb % KT;
     }
     auto issue = [&](int kt, int buf) {
         char* base = smem_b + buf * Cfg::BUF;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int la = (16 * (wv + 8 * j)) * 64, lb = (8 * (wv + 8 * j)) * T16_ROWB;
+        for (int j = 0; j < Cfg::IPA; ++j) {
+            const int la = (Cfg::RPI * (wv + 8 * j)) * AROWB;
+            dma16(phi + poff[j] + kt * KT, base + la);
+            if (SPLIT == 3) dma16(plo + poff[j] + kt * KT, base + PA + la);
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::IPB; ++j) {
+            const int lb = (8 * (wv + 8 * j)) * T16_ROWB;
             // keys past C: P is zero-padded there, V is clamped (finite) -> contributes exactly 0
-            const int64_t vo = voff[j] + (int64_t)min(kt * 32 + vkey[j], C - 1) * ld;
-            dma16(phi + poff[j] + kt * 32, base + la);
-            if (SPLIT == 3) dma16(plo + poff[j] + kt * 32, base + R16X_PA + la);
-            dma16(vhi + vo, base + NPL * R16X_PA + lb);
-            if (SPLIT == 3) dma16(vlo + vo, base + NPL * R16X_PA + R16X_PB + lb);
+            const int64_t vo = voff[j] + (int64_t)min(kt * KT + vkey[j], C - 1) * ld;
+            dma16(vhi + vo, base + NPL * PA + lb);
+            if (SPLIT == 3) dma16(vlo + vo, base + NPL * PA + PB + lb);
         }
     };
     const int tq = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);    // transposed-read geometry
     auto frag_load = [&](const char* buf, int kk, R16XFrag<SPLIT, FMT>& f) {
-        const int chunk = ((2 * kk + lh) ^ ((li >> 2) & 3)) * 16;
+        const int chunk = (KT == 32 ? ((2 * kk + lh) ^ ((li >> 2) & 3)) : ((2 * kk + lh) ^ ((li >> 1) & 7))) * 16;
         const int ka = 16 * kk + 8 * lh + tq;
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                f.a[p][t] = *reinterpret_cast<const V8*>(buf + p * R16X_PA + (wm * 128 + t * 32 + li) * 64 + chunk);
-            const char* bt = buf + NPL * R16X_PA + p * R16X_PB + wn * 32 * T16_ROWB;    // this wave's alignment row
+                f.a[p][t] = *reinterpret_cast<const V8*>(buf + p * PA + (wm * 128 + t * 32 + li) * AROWB + chunk);
+            const char* bt = buf + NPL * PA + p * PB + wn * KT * T16_ROWB;    // this wave's alignment row
 #pragma unroll
             for (int t = 0; t < 2; ++t) f.b[p][t] = frag_t<FMT>(bt, ka, ka + 4, t * 32 + tcol);
         }
@@ -530,32 +567,38 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
 
-    const int nk = (C + 31) / 32;
+    const int nk = (C + KT - 1) / KT;
     issue(0, 0);
     wait_dma_then_barrier<0>();
     issue(nk > 1 ? 1 : 0, 1);
-    R16XFrag<SPLIT, FMT> f0, f1;
-    frag_load(smem_b, 0, f0);
+    R16XFrag<SPLIT, FMT> f[2];                                 // step kk lives in f[kk & 1]; KS is even
+    frag_load(smem_b, 0, f[0]);
     for (int kt = 0; kt + 1 < nk; ++kt) {
         const char* cur = smem_b + (kt & 1) * Cfg::BUF;
         const char* nxt = smem_b + ((kt & 1) ^ 1) * Cfg::BUF;
-        frag_load(cur, 1, f1);
-        frag_mma(f0, acc);
-        interleave();
-        // every wave is done reading `cur` once its f1 has arrived; tile kt+1 (issued one tile ago) must have landed
+#pragma unroll
+        for (int kk = 0; kk + 1 < KS; ++kk) {
+            frag_load(cur, kk + 1, f[(kk + 1) & 1]);
+            frag_mma(f[kk & 1], acc);
+            interleave();
+        }
+        // every wave is done reading `cur` once its last fragments have arrived; tile kt+1 (issued one tile ago) must have landed
         wait_dma_then_barrier<0>();
         issue(kt + 2 < nk ? kt + 2 : nk - 1, kt & 1);              // clamped: the last reload is never read
         __builtin_amdgcn_sched_barrier(0);
-        frag_load(nxt, 0, f0);
-        frag_mma(f1, acc);
+        frag_load(nxt, 0, f[0]);
+        frag_mma(f[(KS - 1) & 1], acc);
         interleave();
     }
     {
         const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
-        frag_load(cur, 1, f1);
-        frag_mma(f0, acc);
-        interleave();
-        frag_mma(f1, acc);
+#pragma unroll
+        for (int kk = 0; kk + 1 < KS; ++kk) {
+            frag_load(cur, kk + 1, f[(kk + 1) & 1]);
+            frag_mma(f[kk & 1], acc);
+            interleave();
+        }
+        frag_mma(f[(KS - 1) & 1], acc);
     }
     wait_dma_then_barrier<0>();   // LDS is free for the epilogue staging
 
@@ -594,7 +637,12 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 // The 256x256 kernel (and the 256-slot row split that goes with it) is used for C >= 256 in the hi/lo modes: measured at
 // cfg3 in one process, split 3 0.40 -> 0.34 ms, but plain bf16 0.166 -> 0.185 ms (its 128x128 kernel already runs
 // 64-deep tiles of whole cache lines with two blocks per CU), so split 1 stays on 128x128.  "attn16" = 2 forces 128x128.
-static inline bool row_logits16_big(int C, bool split3) { return split3 && C >= 256 && tuning().attn16 != 2; }
+// Round 3: the 256x256 kernel with 64-deep K tiles (whole cache lines per DMA row) for plain bf16, knob "row16_bk64" = 2:
+// 0.165-0.170 ms against 0.167-0.170 ms on the 128x128 kernel (cfg3, one process) -- no gain, stays off.  The same tile
+// depth in row_apply16x (64 keys per tile, "row16_bk64" >= 1) is the default: 0.215 -> 0.192 ms.
+static inline bool row_logits16_big(int C, bool split3) {
+    return (split3 || tuning().row16_bk64 >= 2) && C >= 256 && tuning().attn16 != 2;
+}
 // row split of the 16-bit logits kernels; the hi/lo modes cap a slab's rows ("row16_max_rows", see row_split.h and DESIGN 3.2)
 static inline RowSplit row_split16(int R, int C, int H, bool big, bool split3) {
     const int cap = split3 ? tuning().row16_max_rows : 0;
@@ -639,13 +687,14 @@ static int row_logits16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const
 #define RL_GO(SP_, FMT_)                                                                                            \
     do {                                                                                                            \
         if (big) {                                                                                                  \
+            constexpr int BKX_ = SP_ == 1 ? 64 : 32;                                                                \
             static DeviceOnce cfgx_;                                                                              \
             if (cfgx_.pending()) {                                                                                           \
-                int rc = set_lds16(row_logits16x_kernel<SP_, FMT_>, R16LCfg<SP_>::LDS, "row_logits16x");           \
+                int rc = set_lds16(row_logits16x_kernel<SP_, FMT_, BKX_>, R16LCfg<SP_, BKX_>::LDS, "row_logits16x");  \
                 if (rc) return rc;                                                                                  \
                 cfgx_.mark();                                                                                       \
             }                                                                                                       \
-            hipLaunchKernelGGL((row_logits16x_kernel<SP_, FMT_>), dim3(grid, batch), dim3(512), R16LCfg<SP_>::LDS, s, q_hi, q_lo,  \
+            hipLaunchKernelGGL((row_logits16x_kernel<SP_, FMT_, BKX_>), dim3(grid, batch), dim3(512), (R16LCfg<SP_, BKX_>::LDS), s, q_hi, q_lo,  \
                                k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale, qk_bstride, part_bstride, true_rows); \
             break;                                                                                                  \
         }                                                                                                           \
@@ -680,6 +729,24 @@ int row_logits16_batched(const uint16_t* q_hi, const uint16_t* q_lo, const uint1
 }
 }  // namespace rnamsm
 
+template <int SP, int FMT, int OUT, int KT>
+static int launch_apply16x(unsigned grid, int batch, hipStream_t s, const uint16_t* p_hi, const uint16_t* p_lo, int64_t ldp,
+                           const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
+                           uint16_t* ctx_hi, uint16_t* ctx_lo, float out_scale, int64_t p_bstride, int64_t v_bstride,
+                           int64_t ctx_bstride) {
+    static DeviceOnce cfg;
+    auto kern = row_apply16x_kernel<SP, FMT, OUT, KT>;
+    constexpr int lds = R16XCfg<SP, KT>::LDS;
+    if (cfg.pending()) {
+        int rc = set_lds16(kern, lds, "row_apply16x");
+        if (rc) return rc;
+        cfg.mark();
+    }
+    hipLaunchKernelGGL(kern, dim3(grid, batch), dim3(R16X_THREADS), lds, s, p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H,
+                       ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride);
+    return RNAMSM_OK;
+}
+
 static int row_apply16_launch(const uint16_t* p_hi, const uint16_t* p_lo, int64_t ldp, const uint16_t* v_hi, const uint16_t* v_lo,
                               int64_t ld, float* ctx, int64_t ldc, int R, int C, int H, int head_dim, float out_scale,
                               uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, void* stream, int batch, int64_t p_bstride,
@@ -706,14 +773,10 @@ static int row_apply16_launch(const uint16_t* p_hi, const uint16_t* p_lo, int64_
 #define RA_GO(SP_, FMT_, OUT_)                                                                                      \
     do {                                                                                                            \
         if (big) {                                                                                                  \
-            static DeviceOnce cfgx_;                                                                              \
-            if (cfgx_.pending()) {                                                                                           \
-                int rc = set_lds16(row_apply16x_kernel<SP_, FMT_, OUT_>, R16XCfg<SP_>::LDS, "row_apply16x");       \
-                if (rc) return rc;                                                                                  \
-                cfgx_.mark();                                                                                       \
-            }                                                                                                       \
-            hipLaunchKernelGGL((row_apply16x_kernel<SP_, FMT_, OUT_>), dim3(grid, batch), dim3(R16X_THREADS), R16XCfg<SP_>::LDS, \
-                               s, p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride); \
+            int rc = SP_ == 1 && tuning().row16_bk64                                                                \
+                         ? launch_apply16x<SP_, FMT_, OUT_, (SP_ == 1 ? 64 : 32)>(grid, batch, s, p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride) \
+                         : launch_apply16x<SP_, FMT_, OUT_, 32>(grid, batch, s, p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride); \
+            if (rc) return rc;                                                                                      \
             break;                                                                                                  \
         }                                                                                                           \
         static DeviceOnce cfg_;                                                                                   \

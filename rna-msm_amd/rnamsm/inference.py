@@ -123,6 +123,30 @@ def joins_group(group_shapes: List[tuple], shape: tuple) -> bool:
     return frame <= FRAME_TOKENS and frame <= 2 * sum(s[0] * s[1] for s in trial)
 
 
+# Without a gather the order in which alignments are computed is free (every alignment has its own files), so the small ones
+# of the list wait in a POOL (at most POOL_MSAS of them) and are grouped by shape instead of by list position: sorted by
+# (rows, columns) a frame's members are alike, groups fill up to GROUP_MEMBERS / FRAME_TOKENS instead of stopping at the first
+# alignment that would pad too much, and a large alignment in between no longer flushes anything.  64 alignments of 2-12 rows
+# x 40-80 columns: 12 groups in list order, 4 sorted (tools/cli_throughput.py).
+POOL_MSAS = 256
+
+
+def plan_groups(shapes: List[tuple]) -> List[List[int]]:
+    """Partition pooled small alignments (`shapes` = (rows, columns) each) into ragged-batch groups; returns lists of
+    positions into `shapes`, every position exactly once, members of a group in ascending position."""
+    order = sorted(range(len(shapes)), key=lambda j: (shapes[j][0], shapes[j][1], j))
+    groups: List[List[int]] = []
+    cur: List[int] = []
+    for j in order:
+        if cur and not joins_group([shapes[i] for i in cur], shapes[j]):
+            groups.append(sorted(cur))
+            cur = []
+        cur.append(j)
+    if cur:
+        groups.append(sorted(cur))
+    return groups
+
+
 def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_rank0: bool = False,
                  async_io: bool = True) -> List[str]:
     """async_io: read/tokenise the next alignment on a helper thread while the GPU runs the current one, and move the
@@ -204,11 +228,20 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                 else:
                     emit(ids[idx], emb, atp)
 
-            # data.batch_small_msas: consecutive small alignments wait in `group` and go through ONE launch set
-            # (forward_ragged: padded into one frame, every MSA scaled by its own depth); a lone forward of a few hundred
-            # tokens costs 5.5 ms on a mostly idle chip.  Order of delivery = order of the id list either way.
+            # data.batch_small_msas: small alignments go through ONE launch set per group (forward_ragged: padded into one
+            # frame, every MSA scaled by its own depth); a lone forward of a few hundred tokens costs 5.5 ms on a mostly
+            # idle chip.  Groups: by shape from the pool (plan_groups); under gather_to_rank0 the RoundGatherer needs this
+            # rank's items in list order, so there only CONSECUTIVE small alignments share a group.
             batching = bool(getattr(cfg.data, "batch_small_msas", True)) and (model.gemm_dtype == "f32" or ops.get_param("attn16") != 0)
+            pooled = batching and gatherer is None
             group: List = []                                          # (idx, tokens on the device)
+            pool: List = []                                           # (idx, tokens on the host)
+
+            def run_pool() -> None:
+                for members in plan_groups([tuple(t.shape) for _, t in pool]):
+                    group.extend((pool[j][0], torch.from_numpy(pool[j][1]).to(device)) for j in members)
+                    flush()
+                pool.clear()
 
             def flush() -> None:
                 if len(group) == 1:
@@ -230,6 +263,11 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                 if reader and n + 1 < len(mine):
                     pending = reader.submit(read, mine[n + 1])       # parsed while the GPU runs this MSA
                 if batching and tokens.size <= SMALL_MSA_TOKENS and not (tokens == alphabet.padding_idx).any():
+                    if pooled:
+                        pool.append((idx, tokens))
+                        if len(pool) >= POOL_MSAS:
+                            run_pool()
+                        continue
                     if not joins_group([tuple(t.shape) for _, t in group], tuple(tokens.shape)):
                         flush()                                       # this one would waste too much padding: start a new frame
                     group.append((idx, torch.from_numpy(tokens).to(device)))
@@ -238,6 +276,7 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                 out = model.checked_forward_one(torch.from_numpy(tokens).to(device), need_repr=False, what=rna_id)   # emb + atp are all that is written
                 deliver(idx, out["emb"], out["atp"])
             flush()
+            run_pool()
             if gatherer is not None:
                 gatherer.finish()
     finally:
@@ -247,4 +286,5 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
             writer.close()
     if rank == 0:
         print(f"Done! Generated files are saved at {save_dir}")
-    return written
+    position = {rna_id: n for n, rna_id in enumerate(ids)}
+    return sorted(written, key=position.__getitem__)                  # in list order, whatever order the groups ran in

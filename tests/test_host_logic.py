@@ -372,3 +372,27 @@ def test_cli_grouping_rule_for_small_alignments():
     assert not joins_group([(2, 10), (2, 10)], (30, 50))              # 3 x 30 x 50 = 4500 > 2 x 1540: too much padding
     assert joins_group([(30, 50)] * 9, (30, 50)) and not joins_group([(30, 50)] * 10, (30, 50))    # 11 x 1500 > 16384
     assert joins_group([(2, 8)] * 31, (2, 8)) and not joins_group([(2, 8)] * 32, (2, 8))
+
+
+def test_pooled_small_alignments_are_grouped_by_shape():
+    """plan_groups: every pooled alignment lands in exactly one group, groups obey joins_group's limits, and sorting by shape
+    needs far fewer groups than taking the list in order (the population of tools/cli_throughput.py's "tiny" case)."""
+    from rnamsm.inference import FRAME_TOKENS, GROUP_MEMBERS, joins_group, plan_groups
+    rng = np.random.RandomState(1)
+    shapes = [(int(rng.randint(2, 13)), int(rng.randint(40, 81)) + 1) for _ in range(64)]
+    groups = plan_groups(shapes)
+    assert sorted(j for g in groups for j in g) == list(range(64))
+    for g in groups:
+        assert g == sorted(g) and 1 <= len(g) <= GROUP_MEMBERS
+        frame = len(g) * max(shapes[j][0] for j in g) * max(shapes[j][1] for j in g)
+        assert frame <= FRAME_TOKENS and (len(g) == 1 or frame <= 2 * sum(shapes[j][0] * shapes[j][1] for j in g))
+    in_order, cur = 0, []
+    for sh in shapes:                                       # the consecutive rule (still used under gather_to_rank0)
+        if cur and not joins_group(cur, sh):
+            in_order, cur = in_order + 1, []
+        cur.append(sh)
+    in_order += 1
+    assert len(groups) <= 6 < in_order
+    assert plan_groups([]) == [] and plan_groups([(3, 20)]) == [[0]]
+    assert plan_groups([(40, 35), (2, 12), (2, 12), (2, 12), (40, 35)]) == [[1, 2, 3], [0, 4]]          # alike ones meet although the list separates them
+

@@ -7,7 +7,10 @@ sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd"))
 import numpy as np, torch
 from rnamsm import synthetic
 from rnamsm.config import Config
+from rnamsm import inference
 from rnamsm.inference import extract_feat
+if os.environ.get("SMALL_TOKENS"):                       # A/B of the "small alignment" limit
+    inference.SMALL_MSA_TOKENS = int(os.environ["SMALL_TOKENS"])
 from rnamsm.model import MSATransformer
 N, M, L = int(os.environ.get("N", 12)), int(os.environ.get("M", 256)), int(os.environ.get("L", 300))
 state = synthetic.make_state_dict(seed=0)

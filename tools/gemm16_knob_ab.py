@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Plain-bf16 plane GEMMs under knob settings, interleaved rounds in one process (the pool's devices differ and the chip
-is power-managed: only same-process numbers compare).  CONFIGS="base;gemm16_hoist2=0;gemm16_mfma16=2,gemm16_hoist2=1"
+is power-managed: only same-process numbers compare).  CONFIGS="base;gemm16_mfma16=2;gemm16_mfma16=0,gemm16_persist=0"
 (first = the reference for the diff and the ratio), T=..., ROUNDS=..., FORWARD=1 adds the whole bf16 forward at M=256 L=512."""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +18,7 @@ def parse(c):
     return {} if c.strip() in ("", "base") else {k: int(v) for k, v in (kv.split("=") for kv in c.split(","))}
 
 
-CONFIGS = [(c, parse(c)) for c in os.environ.get("CONFIGS", "base;gemm16_hoist2=0").split(";")]
+CONFIGS = [(c, parse(c)) for c in os.environ.get("CONFIGS", "base;gemm16_mfma16=2").split(";")]
 KNOBS = sorted({k for _, d in CONFIGS for k in d})
 DEFAULTS = {k: lib.rnamsm_get_param(k.encode()) for k in KNOBS}
 
