@@ -237,6 +237,16 @@ __device__ __forceinline__ bool xcd_panel_map_grouped(unsigned bid, unsigned num
     panel = (group * G + rem % G) * 8u + xcd;
     return panel < num_panels;
 }
+// Group size for PERSISTENT walks (block b takes virtual ids b, b + gridDim, ...): padding ids of a group that is not full
+// recur with the period of the walk, so whole blocks would own nothing but padding (16 row panels in groups of 8: a quarter of
+// the blocks did all the work -- 432 instead of 1136 TFLOP/s on a 4096^3 bf16 GEMM, tools/gemm16_square_knobs.py).  The
+// largest G <= want that divides the panels per XCD leaves no padding inside the groups.
+static inline unsigned xcd_group_for_persistent(unsigned num_panels, unsigned want) {
+    const unsigned local = (num_panels + 7u) / 8u;
+    unsigned g = want < 1u ? 1u : want;
+    while (g > 1u && local % g) --g;
+    return g;
+}
 static inline unsigned xcd_panel_grid_grouped(unsigned num_panels, unsigned inner, unsigned G) {
     const unsigned local = (num_panels + 7u) / 8u;                 // panels per XCD
     return ((local + G - 1u) / G) * G * 8u * inner;

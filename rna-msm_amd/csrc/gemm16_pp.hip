@@ -405,7 +405,7 @@ static int launch_pp(const uint16_t* Whi, const float* bias, const float* residu
         configured.mark();
     }
     const int nb = N / pp::BN;
-    const int group = tuning().gemm_group > 0 ? tuning().gemm_group : (nb > 8 ? 8 : 1);
+    const int group = tuning().gemm_group > 0 ? tuning().gemm_group : (nb > 8 ? (int)xcd_group_for_persistent((M + pp::BM - 1) / pp::BM, 8) : 1);
     const unsigned total = xcd_panel_grid_grouped((M + pp::BM - 1) / pp::BM, nb, (unsigned)group);
     const unsigned pb = tuning().gemm16_persist > 0 ? (unsigned)tuning().gemm16_persist : 256u;
     const unsigned grid = pb < total ? pb : total;

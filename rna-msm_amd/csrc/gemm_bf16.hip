@@ -815,7 +815,8 @@ static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
     // block order as in gemm_f32.hip: 32 blocks are resident per XCD; for the wide GEMMs (QKV 9, fc1 12 column blocks)
     // groups of 8 row panels keep a W slab shared by 8 panels instead of ~3: +5..6% (split 3), +7..10% (split 1),
     // measured in one process; the 3-column-block GEMMs (out_proj, fc2) are neutral to slightly worse and stay ungrouped
-    const int group = tuning().gemm_group > 0 ? tuning().gemm_group : (N / HX_BN > 4 ? 8 : 1);
+    const int group = tuning().gemm_group > 0 ? tuning().gemm_group
+                                              : (N / HX_BN > 4 ? (int)xcd_group_for_persistent((M + HX_BM - 1) / HX_BM, 8) : 1);
     const unsigned total = xcd_panel_grid_grouped((M + HX_BM - 1) / HX_BM, N / HX_BN, (unsigned)group);
     // "gemm16_persist" = number of persistent blocks (0 = one block per tile, hardware dispatch); "gemm16_stagger" =
     // start offset step in cycles
@@ -1113,7 +1114,8 @@ static int launch_hq(const uint16_t* Whi, const float* bias, const float* residu
         if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_q16: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured.mark();
     }
-    const int group = tuning().gemm_group > 0 ? tuning().gemm_group : (N / HX_BN > 4 ? 8 : 1);
+    const int group = tuning().gemm_group > 0 ? tuning().gemm_group
+                                              : (N / HX_BN > 4 ? (int)xcd_group_for_persistent((M + HX_BM - 1) / HX_BM, 8) : 1);
     const unsigned total = xcd_panel_grid_grouped((M + HX_BM - 1) / HX_BM, N / HX_BN, (unsigned)group);
     const unsigned pb = tuning().gemm16_persist > 0 ? (unsigned)tuning().gemm16_persist : 0u;
     const unsigned grid = pb && pb < total ? pb : total;

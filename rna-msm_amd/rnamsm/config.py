@@ -25,8 +25,8 @@ class DataConfig:                       # RNA_MSM_Inference.py:20-32
     max_tokens: int = 16384
     max_seqs_per_msa: int = 512
     sample_method: str = "hhfilter"
-    # extra (not in the reference): consecutive small alignments (<= 1536 tokens each) of the id list are padded into one frame
-    # and run as a ragged batch (MSATransformer.forward_ragged); outputs equal the one-by-one run to fp32 rounding (~1e-6;
+    # extra (not in the reference): small alignments (<= 3072 tokens each) of the id list are grouped by shape, padded into one
+    # frame per group and run as a ragged batch (MSATransformer.forward_ragged); outputs equal the one-by-one run to fp32 rounding (~1e-6;
     # tests/test_gpu_forward.py::test_ragged_batch_equals_every_alignment_alone, tests/test_gpu_cli.py).  On by default since
     # round 3: a lone forward of a few hundred tokens costs 5.5 ms on a mostly idle chip; data.batch_small_msas=false
     # restores the strictly one-by-one loop of the reference (RNA_MSM_Inference.py:141-148)

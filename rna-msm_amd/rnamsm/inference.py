@@ -108,10 +108,12 @@ class _AsyncNpyWriter:
 
 
 # data.batch_small_msas: which alignments wait for company, and when a group is full.  An alignment of up to SMALL_MSA_TOKENS
-# tokens is "small" (from ~2 k tokens on the padding of a ragged frame costs more than the shared launches return,
-# tools/ragged_batch_timing.py); a group's frame -- members x max rows x max columns -- stays within FRAME_TOKENS and within
-# twice the real tokens, and holds at most GROUP_MEMBERS alignments.
-SMALL_MSA_TOKENS, FRAME_TOKENS, GROUP_MEMBERS = 1536, 16384, 32
+# tokens is "small"; a group's frame -- members x max rows x max columns -- stays within FRAME_TOKENS and within twice the real
+# tokens, and holds at most GROUP_MEMBERS alignments.  (The limit was 1536 tokens while groups were formed in list order: from
+# ~2 k tokens on the padding of an ill-matched frame cost more than the shared launches returned, tools/ragged_batch_timing.py.
+# With groups formed by shape -- plan_groups -- frames are tight and 3072 measured x1.82 against x1.54 on a list of 4-24 rows x
+# 40-120 columns, tools/cli_throughput.py.)
+SMALL_MSA_TOKENS, FRAME_TOKENS, GROUP_MEMBERS = 3072, 16384, 32
 
 
 def joins_group(group_shapes: List[tuple], shape: tuple) -> bool:

@@ -140,9 +140,10 @@ def test_cli_gather_to_rank0_streams_rounds_and_writes_the_same_files(tmp_path):
 
 
 def test_cli_batches_small_alignments_by_default(tmp_path):
-    """data.batch_small_msas (default true; false = the reference's one-by-one loop): consecutive small alignments of the id list (different depths and lengths here) are padded
-    into one frame and run as a ragged batch; a large one in between flushes the group and runs alone.  Same files, same order,
-    values equal to the one-by-one run to fp32 rounding; an alignment with a bad character is still reported by name."""
+    """data.batch_small_msas (default true; false = the reference's one-by-one loop): the small alignments of the id list
+    (different depths and lengths here) are pooled, grouped by shape, padded into one frame per group and run as ragged batches; a
+    large one in between runs alone, at once.  Same files, the returned ids in list order, values equal to the one-by-one run
+    to fp32 rounding."""
     from rnamsm.config import Config
     from rnamsm.inference import extract_feat
     from rnamsm.model import MSATransformer
@@ -152,15 +153,15 @@ def test_cli_batches_small_alignments_by_default(tmp_path):
     records = open(os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2")).read().splitlines()
     names, seqs = records[0::2], records[1::2]
     ids = [f"rna{c}" for c in "ABCDEFGH"]
-    shapes = {"rnaA": (3, 20), "rnaB": (9, 35), "rnaC": (5, 28), "rnaD": (64, 35), "rnaE": (12, 30), "rnaF": (2, 12),
-              "rnaG": (7, 33), "rnaH": (1, 35)}                      # rnaD = 2240 tokens: not small, runs alone in between
+    shapes = {"rnaA": (3, 20), "rnaB": (9, 35), "rnaC": (5, 28), "rnaD": (64, 70), "rnaE": (12, 30), "rnaF": (2, 12),
+              "rnaG": (7, 33), "rnaH": (1, 35)}                      # rnaD = 4544 tokens: not small, runs alone in between
     outs = {}
     for mode in (False, True):
         root = tmp_path / ("batched" if mode else "plain")
         (root / "results").mkdir(parents=True)
         for i in ids:
             depth, length = shapes[i]
-            text = "".join(f"{names[r]}\n{seqs[r][:length]}\n" for r in range(depth))
+            text = "".join(f"{names[r]}\n{(seqs[r] * 2)[:length]}\n" for r in range(depth))
             (root / "results" / f"{i}.a2m_msa2").write_text(text)
         (root / "rna_id.txt").write_text("\n".join(ids) + "\n")
         cfg = Config()

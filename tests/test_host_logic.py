@@ -367,7 +367,7 @@ def test_reader_agrees_with_the_oracle_on_random_alignments():
 def test_cli_grouping_rule_for_small_alignments():
     """data.batch_small_msas: a group's frame stays within 16 k tokens and twice its real tokens, at most 32 members."""
     from rnamsm.inference import FRAME_TOKENS, GROUP_MEMBERS, SMALL_MSA_TOKENS, joins_group
-    assert (SMALL_MSA_TOKENS, FRAME_TOKENS, GROUP_MEMBERS) == (1536, 16384, 32)
+    assert (SMALL_MSA_TOKENS, FRAME_TOKENS, GROUP_MEMBERS) == (3072, 16384, 32)
     assert joins_group([], (3, 20)) and joins_group([(3, 20)], (4, 22))
     assert not joins_group([(2, 10), (2, 10)], (30, 50))              # 3 x 30 x 50 = 4500 > 2 x 1540: too much padding
     assert joins_group([(30, 50)] * 9, (30, 50)) and not joins_group([(30, 50)] * 10, (30, 50))    # 11 x 1500 > 16384

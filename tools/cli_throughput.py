@@ -41,8 +41,7 @@ for mode in (False, True, False, True):
 # ---- a list of SMALL alignments: the default CLI (data.batch_small_msas=true: consecutive small alignments
 # share one ragged launch set) against the strictly one-by-one loop of the reference (data.batch_small_msas=false)
 NS = int(os.environ.get("NSMALL", 64))
-# two populations: "tiny" (2-12 rows x 40-80 columns: every alignment joins a group) and "small" (4-24 rows x 40-120 columns: a third
-# exceed the 1536-token limit and run alone, flushing the waiting group)
+# two populations: "tiny" (2-12 rows x 40-80 columns) and "small" (4-24 rows x 40-120 columns: up to 2.9 k tokens each)
 for label, (dlo, dhi), (llo, lhi) in (("tiny", (2, 13), (40, 81)), ("small", (4, 25), (40, 121))):
     if not NS:
         break
