@@ -449,11 +449,15 @@ void rnamsm_timing_reset(void);
  *   "gemm16_persist" / "gemm16_stagger"  256x256 16-bit GEMM: number of persistent blocks that walk the output tiles
  *                 (default 256 = one per CU; 0 = one block per tile) and a per-block start offset in cycles (default 0;
  *                 measured: no effect).  Speed only, results bit-identical.
- *   "gemm16_mfma16"  plain-bf16 256x256 GEMM: 1 (default) = the 16x16x32-MFMA kernel for N > 1024, 2 = for every N,
+ *   "gemm16_mfma16"  plain-bf16 256x256 GEMM: 1 (default) = the 16x16x32-MFMA kernel for N > 1024 or K >= 2048, 2 = for every shape,
  *                 0 = the 32x32x16 kernel.  Results agree to fp32 rounding (the k order inside a step differs).
  *   "gemm16_pp"   plain-bf16 plane GEMMs: 1 = gemm16_pp_kernel (four waves x 512 registers with two accumulator sets: a tile's
  *                 epilogue leaves under the next tile's K loop), 0 (default) = the 256x256 kernels.  Bit-identical to the
  *                 16x16x32 256x256 kernel; measured 0.61-0.83x (EXPERIMENTS.md R3.1), kept as the record of that experiment.
+ *   "gemm16_dephase"  256x256 16-bit GEMMs: when the waves issue their LDS-DMA requests (a wave is stuck ~100 cycles per request, and
+ *                 while both waves of a SIMD issue at once nobody feeds the matrix pipe): 0 = all right after the tile barrier,
+ *                 1 = the upper wave group one (micro-)step later, 2 (default) = 1, and the 16x16x32 kernel stages by operand (W by
+ *                 the lower group, A by the upper one, half a tile apart: QKV +18 %, fc1 +14 %).  Speed only, results bit-identical.
  *   "row16_bk64"  plain bf16, C >= 256: 1 (default) = rnamsm_row_apply16 stages 64 keys per tile (whole cache lines per P row, half
  *                 the barriers), 2 = rnamsm_row_logits16 too runs the 256x256-tile kernel with 64-deep tiles (measured equal to
  *                 its 128x128 kernel), 0 = neither.  Results agree to fp32 rounding.

@@ -665,7 +665,8 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo, int64_t lda, const uint16_t* __restrict__ Whi,
     const uint16_t* __restrict__ Wlo, const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout,
     int64_t ldc, int M, int N, int K, float scale, int scale_cols, uint16_t* __restrict__ Ohi, uint16_t* __restrict__ Olo,
-    int group, unsigned total_tiles, int stagger_cycles, Fold16 fa) {
+    int group, unsigned total_tiles, int stagger_cycles, int dephase_arg, Fold16 fa) {
+    const bool dephase = dephase_arg != 0;                    // uniform
     using Cfg = HsCfg<SPLIT, BK>;
     constexpr int NPL = Cfg::NPL, ROWB = Cfg::ROWB, PLANE = Cfg::PLANE, KS = Cfg::KS;
     constexpr int NMF = 8 * (SPLIT == 3 ? 3 : 1);          // MFMAs per k step per wave
@@ -773,12 +774,17 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
         // have landed
         wait_dma_then_barrier<0>();
         const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;         // clamped: the last reload is never read
-        issue(k2, kt & 1);
+        // "gemm16_dephase": see gemm16_q16_kernel.  (Staging by operand as in gemm16_q16s_kernel -- row-half-major micro-steps,
+        // W requested half a tile before A -- was built for this kernel too and measured no better than this delay: f16x3 six
+        // GEMMs x1.026 against x1.035, plain bf16 QKV x1.01 and fc1 x0.93; EXPERIMENTS.md R3.3.)
+        if (!dephase || wm == 0) issue(k2, kt & 1);
         __builtin_amdgcn_sched_barrier(0);
         // last step of tile kt, step 0 of tile kt+1 arriving
         frag_load(nxt, 0, f[0]);
         hx_frag_mma<SPLIT, FMT>(f[(KS - 1) & 1], acc);
         interleave();
+        if (dephase && wm == 1) issue(k2, kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     {   // last tile
         const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
@@ -827,7 +833,7 @@ static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
                       gemm16_bytes(M, N, K, HxCfg<SPLIT>::NPL, HAS_RES, O_PL) + (fa.xhi ? 2.0 * HxCfg<SPLIT>::NPL * (double)M * N : 0.0),
                       stream, PEAK_F16_MFMA_TFLOPS, SPLIT);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, a_lo, lda, Whi, Wlo, bias, residual, ldr, Cout,
-                       ldc, M, N, K, scale, scale_cols, o_hi, o_lo, group, total, pb ? tuning().gemm16_stagger : 0, fa);
+                       ldc, M, N, K, scale, scale_cols, o_hi, o_lo, group, total, pb ? tuning().gemm16_stagger : 0, tuning().gemm16_dephase, fa);
     RNAMSM_CHECK_LAUNCH("gemm16_swp");
     return RNAMSM_OK;
 }
@@ -921,7 +927,8 @@ template <int ACT, bool HAS_RES, bool O_PL>
 __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16_kernel(
     const uint16_t* __restrict__ Ahi, int64_t lda, const uint16_t* __restrict__ Whi, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
-    uint16_t* __restrict__ Ohi, int group, unsigned total_tiles, Fold16 fa) {
+    uint16_t* __restrict__ Ohi, int group, unsigned total_tiles, int dephase_arg, Fold16 fa) {
+    const bool dephase = dephase_arg != 0;                    // uniform
     using Cfg = HsCfg<1, 64>;
     constexpr int BK = 64, ROWB = Cfg::ROWB, PLANE = Cfg::PLANE, KS = 2;     // two 32-deep k-steps per tile
     typedef typename Half16<0>::V8 V8;
@@ -1044,12 +1051,17 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16_kernel(
         HQ_PIN(4);
         wait_dma_then_barrier<0>();                           // all waves done reading `cur`; tile kt+1 has landed
         const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;         // clamped: the last reload is never read
-        issue(k2, kt & 1);
+        // "gemm16_dephase": a wave is stuck for ~100 cycles per LDS-DMA request it issues (8 per tile); when the two waves of a
+        // SIMD issue theirs at the same moment -- right after this barrier -- nobody feeds the matrix pipe meanwhile.  The
+        // upper wave group therefore issues one micro-step later, while the lower one is back at its MFMAs.
+        if (!dephase || wm == 0) issue(k2, kt & 1);
         __builtin_amdgcn_sched_barrier(0);
         load_a(nxt, 0, 0, ah[0]);                             // u3 computes, the next tile's u0 operands arriving
         load_b(nxt, 0, bq[0]);
         mma(1, ah[1], bq[1]);
         HQ_PIN(8);
+        if (dephase && wm == 1) issue(k2, kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     {
         const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
@@ -1103,15 +1115,208 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16_kernel(
 }
 
 template <int ACT, bool HAS_RES, bool O_PL>
+__global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16s_kernel(
+    const uint16_t* __restrict__ Ahi, int64_t lda, const uint16_t* __restrict__ Whi, const float* __restrict__ bias,
+    const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
+    uint16_t* __restrict__ Ohi, int group, unsigned total_tiles, int dephase_arg, Fold16 fa) {
+    (void)dephase_arg;
+    using Cfg = HsCfg<1, 64>;
+    constexpr int BK = 64, ROWB = Cfg::ROWB, PLANE = Cfg::PLANE;
+    typedef typename Half16<0>::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+
+    const unsigned nb = N / HX_BN, mp = (M + HX_BM - 1) / HX_BM;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv >> 2, wn = wv & 3, fr = lane & 15, fq = lane >> 4;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    constexpr int HQ_STORES = O_PL ? 16 : 32;                 // store instructions of one epilogue, per lane
+    // STAGING BY OPERAND.  A wave is stuck for ~100 cycles per LDS-DMA request it issues, and while both waves of a SIMD issue
+    // theirs at the same moment nobody feeds the matrix pipe.  Here the lower wave group (wm = 0) moves the whole W tile and
+    // the upper one the whole A tile -- 8 requests per wave and K tile either way -- and the micro-steps run in the order
+    // (ks 0, h 0), (ks 1, h 0), (ks 0, h 1), (ks 1, h 1): the W tile has been read completely after the FIRST micro-step's
+    // fragment reads, the A tile after the third's.  So W of tile kt+2 is requested behind a barrier at the start of
+    // micro-step 1 and A of tile kt+2 behind the barrier at the start of micro-step 3: the two bursts lie half a tile apart,
+    // each overlapped by the other group's MFMAs, and both have at least a whole tile of flight time.
+    const int w4 = wv & 3;
+    const int drow = lane >> 3;
+    const int dchunk = (lane & 7) ^ ((4 * (w4 & 1) + (lane >> 4)) & 7);      // (row >> 1) & 7, row = 8 (w4 + 4 j) + lane / 8
+    const int r0 = 8 * w4 + drow;                             // the wave's rows: r0 + 32 j, j = 0..7
+    const uint16_t* __restrict__ src = wm ? Ahi : Whi;        // uniform
+    int64_t off[8];
+    auto find_tile = [&](unsigned& vid, int& m0, int& n0) -> bool {
+        for (; vid < total_tiles; vid += gridDim.x) {
+            unsigned mpanel, nblk;
+            if (xcd_panel_map_grouped(vid, mp, nb, (unsigned)group, mpanel, nblk)) {
+                m0 = mpanel * HX_BM;
+                n0 = nblk * HX_BN;
+                return true;
+            }
+        }
+        return false;
+    };
+    auto set_offsets = [&](int m0, int n0) {
+        // W rows are PERMUTED on their way into LDS as in gemm16_q16_kernel: LDS row 64 g + 16 t + 4 a + b  <-  weight row
+        // 64 g + 32 (t >> 1) + 8 a + 4 (t & 1) + b; for LDS row r0 + 32 j (r0 < 32) that is weight row wrow(r0) + 32 j
+        const int tt = (r0 >> 4) & 1, aa = (r0 >> 2) & 3;
+        const int wrow0 = 8 * aa + 4 * tt + (r0 & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int m = m0 + r0 + 32 * j;
+            m = m < M ? m : M - 1;
+            off[j] = wm ? (int64_t)m * lda + dchunk * 8 : (int64_t)(n0 + wrow0 + 32 * j) * K + dchunk * 8;
+        }
+    };
+    auto issue_mine = [&](int kt, int buf) {                 // this wave group's operand of K tile kt
+        char* base = smem_b + buf * Cfg::BUF + (wm ? 0 : PLANE) + 1024 * w4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + off[j] + kt * BK), (lptr_t)(base + 4096 * j), 16, 0, 0);
+    };
+    unsigned vid = blockIdx.x;
+    int m0, n0;
+    if (!find_tile(vid, m0, n0)) return;
+    set_offsets(m0, n0);
+    issue_mine(0, 0);
+    bool stores_in_flight = false;                            // uniform
+    for (;;) {
+    // lane (row fr, k-group fq) of a 16-row tile reads logical chunk 4*ks + fq of its row; (row >> 1) & 7 = (fr >> 1) & 7.
+    // A tile is consumed in four micro-steps u = (k-step ks = u >> 1, row half h = u & 1) of 16 MFMAs: the A fragments of
+    // one half (4 x V8) ping-pong by micro-step, the B fragments of a k-step (4 x V8) by k-step -- 64 fragment registers
+    // instead of the 96 of two whole k-step sets, which with 128 accumulators would not fit 256.
+    V8 ah[2][4], bq[2][4];
+    auto load_a = [&](const char* buf, int ks, int h, V8 (&a)[4]) {
+        const int chunk = ((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const V8*>(buf + (wm * 128 + (4 * h + t) * 16 + fr) * ROWB + chunk);
+    };
+    auto load_b = [&](const char* buf, int ks, V8 (&b)[4]) {
+        const int chunk = ((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const V8*>(buf + PLANE + (wn * 64 + t * 16 + fr) * ROWB + chunk);
+    };
+    f32x4a acc[8][4];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4a{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](int h, const V8 (&a)[4], const V8 (&b)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                // operands swapped: the tile comes out TRANSPOSED in the registers -- lane (fr, fq) holds row fr, columns
+                // 4 fq .. 4 fq + 3 of the 16x16 tile -- so the epilogue stores row pieces straight from the accumulators
+                acc[4 * h + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt], a[mt], acc[4 * h + mt][nt], 0, 0, 0);
+    };
+
+    const int nk = K / BK;
+    // tile 0 was requested before the previous tile's stores (or at kernel start): it has landed once at most those
+    // stores are still outstanding
+    if (stores_in_flight) wait_dma_then_barrier<HQ_STORES>();
+    else wait_dma_then_barrier<0>();
+    issue_mine(nk > 1 ? 1 : 0, 1);
+    load_a(smem_b, 0, 0, ah[0]);
+    load_b(smem_b, 0, bq[0]);
+#define HQ_PIN(NDS_)                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < NDS_; ++i_) {                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+    }                                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 16 - NDS_, 0);                        \
+    __builtin_amdgcn_sched_barrier(0)
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const char* cur = smem_b + (kt & 1) * Cfg::BUF;
+        const char* nxt = smem_b + ((kt & 1) ^ 1) * Cfg::BUF;
+        const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;         // clamped: the last reload is never read (keeps the counts below fixed)
+        load_a(cur, 1, 0, ah[1]);                             // u0 = (ks 0, h 0) computes; u1 = (ks 1, h 0) arriving: the last reads of W
+        load_b(cur, 1, bq[1]);
+        mma(0, ah[0], bq[0]);
+        HQ_PIN(8);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave has read the W tile of `cur`
+        if (wm == 0) issue_mine(k2, kt & 1);                  // W of tile kt+2 -> the W plane of `cur`
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(cur, 0, 1, ah[0]);                             // u1 computes; u2 = (ks 0, h 1) arriving
+        mma(0, ah[1], bq[1]);
+        HQ_PIN(4);
+        load_a(cur, 1, 1, ah[1]);                             // u2 computes; u3 = (ks 1, h 1) arriving: the last reads of A
+        mma(1, ah[0], bq[0]);
+        HQ_PIN(4);
+        // every wave has read the A tile of `cur`, and tile kt+1 has landed: the A group waits for all of its requests, the W
+        // group leaves its newest 8 (W of tile kt+2, requested half a tile ago) in flight
+        if (wm == 0) wait_dma_then_barrier<8>();
+        else wait_dma_then_barrier<0>();
+        if (wm == 1) issue_mine(k2, kt & 1);                  // A of tile kt+2 -> the A plane of `cur`
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(nxt, 0, 0, ah[0]);                             // u3 computes; the next tile's u0 operands arriving
+        load_b(nxt, 0, bq[0]);
+        mma(1, ah[1], bq[1]);
+        HQ_PIN(8);
+    }
+    {
+        const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
+        load_a(cur, 1, 0, ah[1]);
+        load_b(cur, 1, bq[1]);
+        mma(0, ah[0], bq[0]);
+        HQ_PIN(8);
+        load_a(cur, 0, 1, ah[0]);
+        mma(0, ah[1], bq[1]);
+        HQ_PIN(4);
+        load_a(cur, 1, 1, ah[1]);
+        mma(1, ah[0], bq[0]);
+        HQ_PIN(4);
+        mma(1, ah[1], bq[1]);
+    }
+#undef HQ_PIN
+    wait_dma_then_barrier<0>();                               // every wave is done with LDS; the clamped reload has landed
+    // what the epilogue reads (bias / fold vectors, row statistics) first, then the next tile's tile 0, then the stores
+    HqEpiRegs er;
+    hq_epilogue_loads<HAS_RES>(er, m0 + wm * 128, n0 + wn * 64, lane, bias, M, fa);
+    // ... and waited for HERE (a use, as far as hipcc can tell): with an LDS-DMA in flight it would otherwise wait vmcnt(0) at
+    // their first real use and drain the next tile's operands inside the epilogue
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        asm volatile("" : "+v"(er.b4[t]));
+        asm volatile("" : "+v"(er.c4[t]));
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) asm volatile("" : "+v"(er.st[mt].x), "+v"(er.st[mt].y));
+    asm volatile("" ::: "memory");                            // ... and the requests below stay below
+    __builtin_amdgcn_sched_barrier(0);
+    const int em0 = m0 + wm * 128, en0 = n0 + wn * 64;
+    unsigned nvid = vid + gridDim.x;
+    int m1 = 0, n1 = 0;
+    const bool more = find_tile(nvid, m1, n1);
+    if (more) {
+        set_offsets(m1, n1);
+        issue_mine(0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    hq_epilogue<ACT, HAS_RES, O_PL>(acc, er, em0, en0, lane, residual, ldr, Cout, ldc, M, scale, scale_cols, Ohi);
+    if (!more) break;
+    vid = nvid;
+    m0 = m1;
+    n0 = n1;
+    // the hoisted request pays only if exactly HQ_STORES vector memory instructions follow it: a residual adds loads, a
+    // ragged last row panel drops stores -- those tiles drain (vmcnt(0)) as before
+    stores_in_flight = !HAS_RES && em0 + 128 <= M;
+    if (!stores_in_flight) __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0), keep expcnt / lgkmcnt
+    }   // persistent tile loop
+}
+
+template <int ACT, bool HAS_RES, bool O_PL>
 static int launch_hq(const uint16_t* Whi, const float* bias, const float* residual, int64_t ldr, float* Cout, int64_t ldc,
                      int64_t lda, int M, int N, int K, float scale, int scale_cols, const uint16_t* a_hi, uint16_t* o_hi,
                      hipStream_t stream, const Fold16& fa = Fold16{}) {
     static DeviceOnce configured;
-    auto kern = gemm16_q16_kernel<ACT, HAS_RES, O_PL>;
+    const bool by_operand = tuning().gemm16_dephase == 2;     // staging split by operand between the wave groups (gemm16_q16s_kernel)
+    auto kern = by_operand ? gemm16_q16s_kernel<ACT, HAS_RES, O_PL> : gemm16_q16_kernel<ACT, HAS_RES, O_PL>;
     constexpr int lds = HsCfg<1, 64>::LDS;
     if (configured.pending()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_q16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        for (auto kf : {gemm16_q16_kernel<ACT, HAS_RES, O_PL>, gemm16_q16s_kernel<ACT, HAS_RES, O_PL>}) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_q16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        }
         configured.mark();
     }
     const int group = tuning().gemm_group > 0 ? tuning().gemm_group
@@ -1121,7 +1326,7 @@ static int launch_hq(const uint16_t* Whi, const float* bias, const float* residu
     const unsigned grid = pb && pb < total ? pb : total;
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, gemm16_bytes(M, N, K, 1, HAS_RES, O_PL), stream, PEAK_F16_MFMA_TFLOPS, 1.0);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, lda, Whi, bias, residual, ldr, Cout, ldc, M, N, K,
-                       scale, scale_cols, o_hi, group, total, fa);
+                       scale, scale_cols, o_hi, group, total, tuning().gemm16_dephase, fa);
     RNAMSM_CHECK_LAUNCH("gemm16_q16");
     return RNAMSM_OK;
 }
@@ -1273,8 +1478,9 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
         if (SP_ == 1 && A_hi && tuning().gemm16_dma >= 3 && gemm16_pp_eligible(M, N, K, bias) &&                      \
             (O_hi ? !residual : act == RNAMSM_ACT_NONE))                                                            \
             return gemm16_pp(A_hi, lda, W_hi, bias, residual, ldr, Cout, ldc, m, N, K, act, scale, scale_cols, O_hi, s); \
-        /* 16x16x32 MFMAs: measured +6.5 % on QKV, +1.4 % on fc1, -2.5 % on out_proj, 0 on fc2 (one process, cfg3 shapes): wide N only */ \
-        if (SP_ == 1 && A_hi && (tuning().gemm16_mfma16 == 1 ? N / HX_BN > 4 : tuning().gemm16_mfma16 == 2) && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= 2048 && K % 64 == 0) { \
+        /* 16x16x32 MFMAs: round 2 +6.5 % on QKV, +1.4 % on fc1, -2.5 % on out_proj, 0 on fc2 (one process, cfg3 shapes): wide N only;   \
+           round 3, staged by operand (gemm16_q16s_kernel): QKV +18 %, fc1 +14 %, fc2 +6.6 % (long K), out_proj -14 %           */ \
+        if (SP_ == 1 && A_hi && (tuning().gemm16_mfma16 == 1 ? (N / HX_BN > 4 || (K >= 2048 && tuning().gemm16_dephase == 2)) : tuning().gemm16_mfma16 == 2) && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= 2048 && K % 64 == 0) { \
             if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HQ_GO(RNAMSM_ACT_GELU_ERF, false, true)                    \
                                                         : HQ_GO(RNAMSM_ACT_NONE, false, true);                       \
             return residual ? HQ_GO(RNAMSM_ACT_NONE, true, false) : HQ_GO(RNAMSM_ACT_NONE, false, false);            \

@@ -284,7 +284,8 @@ template <int SPLIT, int FMT, int BK>
 __global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
     const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
     const uint16_t* __restrict__ klo, int64_t ld, float* __restrict__ partial, int R, int C, int H, int nsplit,
-    int rows_per_split, float scale, int64_t qk_bstride, int64_t part_bstride, const int* __restrict__ true_rows) {
+    int rows_per_split, float scale, int64_t qk_bstride, int64_t part_bstride, const int* __restrict__ true_rows, int dephase_arg) {
+    const bool dephase = dephase_arg != 0;                   // uniform
     // batched launch (rnamsm_forward_batch, 16-bit modes): MSA blockIdx.y; a ragged batch scales every MSA's logits by its own depth
     qhi += blockIdx.y * qk_bstride;
     khi += blockIdx.y * qk_bstride;
@@ -395,11 +396,14 @@ __global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
         }
         // every wave is done reading `cur` once its last fragments have arrived; tile kt+1 (issued one tile ago) must have landed
         wait_dma_then_barrier<0>();
-        issue(kt + 2 < nk ? kt + 2 : nk - 1, kt & 1);        // clamped: the last reload is never read
+        const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;        // clamped: the last reload is never read
+        if (!dephase || wm == 0) issue(k2, kt & 1);          // "gemm16_dephase": the upper wave group issues one step later (gemm_bf16.hip)
         __builtin_amdgcn_sched_barrier(0);
         frag_load(nxt, 0, f[0]);
         frag_mma(f[(KS - 1) & 1], acc);
         interleave();
+        if (dephase && wm == 1) issue(k2, kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     {
         const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
@@ -460,7 +464,8 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
     const uint16_t* __restrict__ phi, const uint16_t* __restrict__ plo, int64_t ldp, const uint16_t* __restrict__ vhi,
     const uint16_t* __restrict__ vlo, int64_t ld, float* __restrict__ ctx, int64_t ldc, int R, int C, int H,
     uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, float out_scale, int64_t p_bstride, int64_t v_bstride,
-    int64_t ctx_bstride) {
+    int64_t ctx_bstride, int dephase_arg) {
+    const bool dephase = dephase_arg != 0;                   // uniform
     phi += blockIdx.y * p_bstride;                           // batched launch: MSA blockIdx.y
     vhi += blockIdx.y * v_bstride;
     if (plo) plo += blockIdx.y * p_bstride;
@@ -584,11 +589,14 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
         }
         // every wave is done reading `cur` once its last fragments have arrived; tile kt+1 (issued one tile ago) must have landed
         wait_dma_then_barrier<0>();
-        issue(kt + 2 < nk ? kt + 2 : nk - 1, kt & 1);              // clamped: the last reload is never read
+        const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;              // clamped: the last reload is never read
+        if (!dephase || wm == 0) issue(k2, kt & 1);                // "gemm16_dephase": the upper wave group issues one step later
         __builtin_amdgcn_sched_barrier(0);
         frag_load(nxt, 0, f[0]);
         frag_mma(f[(KS - 1) & 1], acc);
         interleave();
+        if (dephase && wm == 1) issue(k2, kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     {
         const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
@@ -695,7 +703,7 @@ static int row_logits16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const
                 cfgx_.mark();                                                                                       \
             }                                                                                                       \
             hipLaunchKernelGGL((row_logits16x_kernel<SP_, FMT_, BKX_>), dim3(grid, batch), dim3(512), (R16LCfg<SP_, BKX_>::LDS), s, q_hi, q_lo,  \
-                               k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale, qk_bstride, part_bstride, true_rows); \
+                               k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale, qk_bstride, part_bstride, true_rows, tuning().gemm16_dephase); \
             break;                                                                                                  \
         }                                                                                                           \
         static DeviceOnce cfg_;                                                                                   \
@@ -743,7 +751,7 @@ static int launch_apply16x(unsigned grid, int batch, hipStream_t s, const uint16
         cfg.mark();
     }
     hipLaunchKernelGGL(kern, dim3(grid, batch), dim3(R16X_THREADS), lds, s, p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H,
-                       ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride);
+                       ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride, tuning().gemm16_dephase);
     return RNAMSM_OK;
 }
 

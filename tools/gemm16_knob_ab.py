@@ -9,6 +9,8 @@ import torch
 from rnamsm import _lib, ops, synthetic
 from rnamsm._lib import ACT_GELU_ERF, ACT_NONE
 ROUNDS = int(os.environ.get("ROUNDS", 3))
+MODE = os.environ.get("MODE", "bf16")                     # bf16 (one plane per operand) | f16x3 (fp16 hi/lo planes, 3 products)
+LO, FMT = MODE == "f16x3", 1 if MODE == "f16x3" else 0
 dev = torch.device("cuda:0")
 lib = _lib.load()
 torch.manual_seed(0)
@@ -40,14 +42,14 @@ for T in [int(x) for x in os.environ.get("T", "131072").split(",")]:
     tot = [0.0] * len(CONFIGS)
     for tag, N, K, act, res, opl, per_layer in [("qkv", 2304, 768, ACT_NONE, False, True, 2), ("out", 768, 768, ACT_NONE, True, False, 2),
                                                 ("fc1", 3072, 768, ACT_GELU_ERF, False, True, 1), ("fc2", 768, 3072, ACT_NONE, True, False, 1)]:
-        a = torch.randn(T, K, device=dev); w = torch.randn(N, K, device=dev) * 0.04; b = torch.randn(N, device=dev) * 0.05
+        a = torch.randn(T, K, device=dev) * (0.5 if LO else 1.0); w = torch.randn(N, K, device=dev) * 0.04; b = torch.randn(N, device=dev) * 0.05
         r = torch.randn(T, N, device=dev) if res else None
         fl = 2.0 * T * N * K
-        ap = ops.split_bf16(a, want_lo=False); wp = ops.split_bf16(w, want_lo=False)
+        ap = ops.split_bf16(a, want_lo=LO, fmt=FMT); wp = ops.split_bf16(w, want_lo=LO, fmt=FMT)
         del a
         times, outs = [[] for _ in CONFIGS], [None] * len(CONFIGS)
         out = None if opl else torch.empty(T, N, device=dev)
-        fn = lambda: ops.linear_planes(ap, wp, b, act=act, residual=r, out=out, out_planes=opl)
+        fn = lambda: ops.linear_planes(ap, wp, b, act=act, residual=r, out=out, out_planes=opl, fmt=FMT)
         for rnd in range(ROUNDS):
             for i, (_, d) in enumerate(CONFIGS):
                 apply(d)
@@ -57,7 +59,7 @@ for T in [int(x) for x in os.environ.get("T", "131072").split(",")]:
         med = [statistics.median(t) for t in times]
         for i in range(len(CONFIGS)):
             tot[i] += per_layer * med[i]
-        line = f"T={T} {tag:4s}"
+        line = f"{MODE} T={T} {tag:4s}"
         for i, (name, _) in enumerate(CONFIGS):
             diff = float((outs[0].float() - outs[i].float()).abs().max())
             line += f" | {name}: {med[i]:.3f} ms {fl / med[i] / 1e9:5.0f} TF x{med[0] / med[i]:.3f} diff {diff:.2g}"
@@ -71,7 +73,7 @@ if os.environ.get("FORWARD", "1") != "0":
     state = synthetic.make_state_dict(seed=0)
     m = MSATransformer(num_layers=10)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
-    m = m.eval().to(dev); m.gemm_dtype = "bf16"; m.check_finite = False
+    m = m.eval().to(dev); m.gemm_dtype = MODE; m.check_finite = False
     toks = torch.from_numpy(synthetic.make_tokens(256, 512, 0)).to(dev)
     res, embs = [[] for _ in CONFIGS], [None] * len(CONFIGS)
     for rnd in range(3):
@@ -81,6 +83,6 @@ if os.environ.get("FORWARD", "1") != "0":
             embs[i] = o["emb"].clone()
             res[i].append(timeit(lambda: m.forward_one(toks), n=5))
     med = [statistics.median(t) for t in res]
-    print("forward bf16 M=256 L=512: " + " | ".join(
+    print(f"forward {MODE} M=256 L=512: " + " | ".join(
         f"{n}: {t:.2f} ms x{med[0] / t:.3f} emb diff {float((embs[0] - embs[i]).abs().max()):.2g}" for i, ((n, _), t) in enumerate(zip(CONFIGS, med))), flush=True)
 apply({})
