@@ -7,7 +7,7 @@ strided operand / output views (leading dimensions larger than the row), every e
   * rnamsm_row_logits + softmax_rows + row_apply,  rnamsm_col_attn_fused        q / k / v as column slices of one wide
                                   activation (ld = 3 H 64 + padding), R 1..300, C 1..300, H 1..12, padded keys
   * rnamsm_gemm_bf16 (plane operands)  M 1..6000 (both sides of the 2048-row kernel switch), N in 128 k up to 1536, K in 64 k,
-                                  bf16 / bf16x3 / f16x3, every staging variant ("gemm16_dma" 0..4, "gemm16_mfma16", "gemm_group"),
+                                  bf16 / bf16x3 / f16x3, every staging variant ("gemm16_dma" 0..4, "gemm16_mfma16", "gemm_group", "gemm16_dephase"),
                                   fp32 output (+ residual) or plane output (+ GELU / column scale), against the fp64
                                   product of the PLANE VALUES
   * rnamsm_greedy_select / rnamsm_msa_weights   random alignments built from a few mutated founders (ties everywhere), both
@@ -164,7 +164,8 @@ def fuzz_planes_gemm(rng, gen):
     K = 64 * int(rng.integers(1, 9))
     split, fmt = [(1, 0), (3, 0), (3, 1)][int(rng.integers(0, 3))]
     ht = torch.float16 if fmt == 1 else torch.bfloat16
-    knobs = {"gemm16_dma": int(rng.integers(0, 5)), "gemm16_mfma16": int(rng.integers(0, 3)), "gemm_group": int(rng.choice([0, 1, 3, 8]))}
+    knobs = {"gemm16_dma": int(rng.integers(0, 5)), "gemm16_mfma16": int(rng.integers(0, 3)), "gemm_group": int(rng.choice([0, 1, 3, 8])),
+             "gemm16_dephase": int(rng.integers(0, 3))}
     for k_, v_ in knobs.items():
         ops.set_param(k_, v_)
     a = ops.split_bf16(torch.randn(M, K, device=DEV, generator=gen), want_lo=split == 3, fmt=fmt)
@@ -221,7 +222,7 @@ def run(cases=40, seed=0, log=print):
     gen = torch.Generator(device=DEV)
     gen.manual_seed(seed)
     bad = 0
-    DEFAULT_PLANE_KNOBS = {k_: ops.get_param(k_) for k_ in ("gemm16_dma", "gemm16_mfma16", "gemm_group")}
+    DEFAULT_PLANE_KNOBS = {k_: ops.get_param(k_) for k_ in ("gemm16_dma", "gemm16_mfma16", "gemm_group", "gemm16_dephase")}
     try:
         for case in range(cases):
             for fn in (fuzz_gemm, fuzz_lnfold, fuzz_row_attention, fuzz_col_attention, fuzz_planes_gemm, fuzz_subsampling):
