@@ -260,7 +260,7 @@ def mode_roofline(timings, mode, mult, steps):
     tot_bound = sum(v["bound_ms"] for v in timings.values())
     raw = mult * g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
     lim = mult * g["flops"] / (g["bound_ms"] * 1e-3) / 1e12 if g["bound_ms"] > 0 else 0.0
-    return {"bound": "per launch max(mfma, hbm)", "kernel": "16-bit Linear GEMMs (gemm16_q16_kernel / gemm16_swp_kernel; nn.Linear, K2)",
+    return {"bound": "per launch max(mfma, hbm)", "kernel": "16-bit Linear GEMMs (gemm16_q16s_kernel / gemm16_swp_kernel; nn.Linear, K2)",
             "achieved": raw, "peak": lim,
             "unit": "TFLOP/s executed by the GEMM launches; peak = the same flops at every launch's own bound, "
                     "max(flops / 2.5 PFLOP/s, algorithmic bytes / 6.3 TB/s)" + (" (executed = 3 x algorithmic)" if mult == 3.0 else ""),
@@ -561,7 +561,7 @@ def run_rank(args) -> int:
         mult = {"f32": 1.0, "bf16": 1.0, "bf16x3": 3.0, "f16x3": 3.0}[args.gemm_dtype]
         peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_dtype == "f32" else F16_MFMA_PEAK_TFLOPS
         gemm_kernel = {"f32": "gemm_f32_kernel (nn.Linear, K2)",
-                       "bf16": "gemm16_q16_kernel (QKV, fc1) + gemm16_swp_kernel<split 1, bf16> (out_proj, fc2) (nn.Linear, K2)",
+                       "bf16": "gemm16_q16s_kernel (QKV, fc1, fc2) + gemm16_swp_kernel<split 1, bf16> (out_proj) (nn.Linear, K2)",
                        "bf16x3": "gemm16_swp_kernel<split 3, bf16> (nn.Linear, K2)",
                        "f16x3": "gemm16_swp_kernel<split 3, fp16> (nn.Linear, K2)"}[args.gemm_dtype]
         flop_unit = "TFLOP/s" if mult == 1.0 else "TFLOP/s (executed MFMA flops = 3 x algorithmic)"

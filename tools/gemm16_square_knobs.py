@@ -1,5 +1,11 @@
+#!/usr/bin/env python3
+"""The plain-bf16 plane GEMM (plane in, plane out) at square and tall shapes under the block-order / persistence knobs, one process:
+how far the persistent walk is from an even distribution of tiles when there are few row panels (gemm_group = 8 on 16 panels: a
+quarter of the blocks owned every tile, 432 TF at 4096^3; xcd_group_for_persistent: 1156 TF), and where the K loop stands at long K
+(1270-1290 TF) against the 1320-1340 TF cdna_hip_programming.md quotes for its 8-phase template at 4096^3."""
 import os, sys, statistics
-sys.path.insert(0, "rna-msm_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd"))
 import torch
 from rnamsm import _lib, ops
 from rnamsm._lib import ACT_NONE
