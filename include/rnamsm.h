@@ -458,6 +458,10 @@ void rnamsm_timing_reset(void);
  *                 while both waves of a SIMD issue at once nobody feeds the matrix pipe): 0 = all right after the tile barrier,
  *                 1 = the upper wave group one (micro-)step later, 2 (default) = 1, and the 16x16x32 kernel stages by operand (W by
  *                 the lower group, A by the upper one, half a tile apart: QKV +18 %, fc1 +14 %).  Speed only, results bit-identical.
+ *   "gemm16_x3q"  hi/lo modes, plane-output GEMMs (QKV, fc1) of >= 2048 rows: 1 = gemm16_x3q_kernel (16x16x32 MFMA, staged by
+ *                 operand; +1.8 % on the six GEMMs of a layer), 0 (default) = the 32x32x16 kernel.  Results agree to fp32 rounding
+ *                 (the k order inside a K tile differs) -- which at BASELINE configs[1] moved f16x3 from 6.5e-6 to 7.1e-6 of the
+ *                 truth, across the 2 x CPU-fp32 bar of tests/test_gpu_fullsize.py (6.6e-6): hence not the default.
  *   "row16_bk64"  plain bf16, C >= 256: 1 (default) = rnamsm_row_apply16 stages 64 keys per tile (whole cache lines per P row, half
  *                 the barriers), 2 = rnamsm_row_logits16 too runs the 256x256-tile kernel with 64-deep tiles (measured equal to
  *                 its 128x128 kernel), 0 = neither.  Results agree to fp32 rounding.

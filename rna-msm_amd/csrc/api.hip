@@ -183,6 +183,10 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm16_dephase = value < 0 ? 0 : (value > 2 ? 2 : value);
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "gemm16_x3q")) {
+        rnamsm::tuning().gemm16_x3q = value != 0;
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "row16_bk64")) {
         rnamsm::tuning().row16_bk64 = value < 0 ? 0 : (value > 2 ? 2 : value);
         return RNAMSM_OK;
@@ -210,6 +214,7 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "col_small")) return rnamsm::tuning().col_small;
     if (name && !strcmp(name, "col_dma")) return rnamsm::tuning().col_dma;
     if (name && !strcmp(name, "gemm16_dephase")) return rnamsm::tuning().gemm16_dephase;
+    if (name && !strcmp(name, "gemm16_x3q")) return rnamsm::tuning().gemm16_x3q;
     if (name && !strcmp(name, "row16_bk64")) return rnamsm::tuning().row16_bk64;
     if (name && !strcmp(name, "row16_max_rows")) return rnamsm::tuning().row16_max_rows;
     if (name && !strcmp(name, "gemm16_pp")) return rnamsm::tuning().gemm16_pp;

@@ -68,6 +68,7 @@ struct Tuning {
     int gemm16_dephase = 2;        // 256x256 16-bit GEMMs, who issues the LDS-DMA requests when: 0 = every wave right after the tile barrier;
                                    // 1 = the upper wave group one (micro-)step later; 2 = 1, and the 16x16x32 kernel stages by operand
                                    // (gemm16_q16s_kernel: W by the lower group, A by the upper one, half a tile apart)
+    int gemm16_x3q = 0;            // hi/lo modes, plane-output GEMMs (QKV, fc1): 1 = gemm16_x3q_kernel (16x16x32 MFMA, staged by operand), 0 = gemm16_swp_kernel
     int gemm_group = 0;            // fp32 GEMM: row panels per XCD group of the block order (xcd_panel_map_grouped); 0 = by shape
     int gemm_tile = 0;             // fp32 GEMM block tile: 0 = by shape, 1 = always 128x128, 2 = always 128x64
     int gemm_splitk = 1;           // rnamsm_forward, fc2 below ~1.4 k tokens: 1 = four K ranges + an ordered reduction (gemm_f32_splitk_factor), 0 = never, 2 / 4 / 8 = forced (A/B)

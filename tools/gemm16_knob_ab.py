@@ -9,6 +9,7 @@ import torch
 from rnamsm import _lib, ops, synthetic
 from rnamsm._lib import ACT_GELU_ERF, ACT_NONE
 ROUNDS = int(os.environ.get("ROUNDS", 3))
+OPERAND_SCALE = float(os.environ.get("OPERAND_SCALE", 1.0))      # 0 = zero-filled A and W (the clock the chip holds depends on the data: power)
 MODE = os.environ.get("MODE", "bf16")                     # bf16 (one plane per operand) | f16x3 (fp16 hi/lo planes, 3 products)
 LO, FMT = MODE == "f16x3", 1 if MODE == "f16x3" else 0
 dev = torch.device("cuda:0")
@@ -42,7 +43,7 @@ for T in [int(x) for x in os.environ.get("T", "131072").split(",")]:
     tot = [0.0] * len(CONFIGS)
     for tag, N, K, act, res, opl, per_layer in [("qkv", 2304, 768, ACT_NONE, False, True, 2), ("out", 768, 768, ACT_NONE, True, False, 2),
                                                 ("fc1", 3072, 768, ACT_GELU_ERF, False, True, 1), ("fc2", 768, 3072, ACT_NONE, True, False, 1)]:
-        a = torch.randn(T, K, device=dev) * (0.5 if LO else 1.0); w = torch.randn(N, K, device=dev) * 0.04; b = torch.randn(N, device=dev) * 0.05
+        a = torch.randn(T, K, device=dev) * (0.5 if LO else 1.0) * OPERAND_SCALE; w = torch.randn(N, K, device=dev) * 0.04 * OPERAND_SCALE; b = torch.randn(N, device=dev) * 0.05
         r = torch.randn(T, N, device=dev) if res else None
         fl = 2.0 * T * N * K
         ap = ops.split_bf16(a, want_lo=LO, fmt=FMT); wp = ops.split_bf16(w, want_lo=LO, fmt=FMT)
@@ -54,14 +55,18 @@ for T in [int(x) for x in os.environ.get("T", "131072").split(",")]:
             for i, (_, d) in enumerate(CONFIGS):
                 apply(d)
                 res_t = fn(); torch.cuda.synchronize()
-                outs[i] = (res_t[0] if opl else res_t).clone()
+                if opl:                                   # the value the planes hold (hi, or hi + lo)
+                    ht = torch.float16 if FMT == 1 else torch.bfloat16
+                    outs[i] = res_t[0].view(ht).float() + (res_t[1].view(ht).float() if res_t[1] is not None else 0.0)
+                else:
+                    outs[i] = res_t.clone()
                 times[i].append(timeit(fn))
         med = [statistics.median(t) for t in times]
         for i in range(len(CONFIGS)):
             tot[i] += per_layer * med[i]
         line = f"{MODE} T={T} {tag:4s}"
         for i, (name, _) in enumerate(CONFIGS):
-            diff = float((outs[0].float() - outs[i].float()).abs().max())
+            diff = float((outs[0].float() - outs[i].float()).norm() / outs[0].float().norm())       # relative L2
             line += f" | {name}: {med[i]:.3f} ms {fl / med[i] / 1e9:5.0f} TF x{med[0] / med[i]:.3f} diff {diff:.2g}"
         print(line, flush=True)
         del ap, wp, r, out, outs
