@@ -775,6 +775,53 @@ def test_16x16x32_gemm_with_the_next_tile_requested_before_the_stores(dev, M, N,
     assert rel_l2(first.view(ht)[rows].double().cpu(), want.cpu()) < 6e-3
 
 
+@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 1)])
+@pytest.mark.parametrize("M,N,K,kind", [(16384, 2304, 768, "planes"), (9000, 3072, 768, "gelu"), (8200, 768, 3072, "residual"),
+                                        (4100, 768, 768, "residual"), (2048, 1280, 128, "planes")])
+def test_dma_issue_schedules_of_the_256x256_gemms_are_bit_identical(dev, M, N, K, kind, split, fmt):
+    """Knob "gemm16_dephase": 0 = every wave issues its LDS-DMA requests right after the tile barrier, 1 = the upper wave group one
+    (micro-)step later, 2 (default) = 1, and the plain-bf16 16x16x32 kernel stages by operand behind two barriers per tile with a
+    counted vmcnt (gemm16_q16s_kernel; also taken by fc2, K >= 2048).  Pure scheduling: outputs must be bit-identical across the
+    three settings and across reruns (a wave that reads LDS ahead of a DMA shows as a rare mismatch: many tiles per block, ragged
+    last row panels, 2 .. 48 K tiles)."""
+    from rnamsm import ops, _lib
+    from rnamsm._lib import ACT_GELU_ERF
+    lib = _lib.load()
+    lo = split == 3
+    a = ops.split_bf16(_rand("dp.a", (M, K)).to(dev), want_lo=lo, fmt=fmt)
+    w = ops.split_bf16(_rand("dp.w", (N, K), 0.05).to(dev), want_lo=lo, fmt=fmt)
+    b = _rand("dp.b", (N,), 0.1).to(dev)
+    r = _rand("dp.r", (M, N)).to(dev) if kind == "residual" else None
+
+    def run():
+        if kind == "residual":
+            return [ops.linear_planes(a, w, b, residual=r, fmt=fmt)]
+        out = ops.linear_planes(a, w, b, act=ACT_GELU_ERF if kind == "gelu" else 0, out_planes=True, fmt=fmt)
+        return [t for t in out if t is not None]
+
+    assert lib.rnamsm_get_param(b"gemm16_dephase") == 2
+    try:
+        want = None
+        for dp in (2, 0, 1, 2):
+            _lib.check(lib.rnamsm_set_param(b"gemm16_dephase", dp))
+            for _ in range(6):
+                got = [t.clone() for t in run()]
+                if want is None:
+                    want = got
+                # (plain bf16 at K >= 2048 switches MFMA shape with the knob: fc2 is compared per setting below)
+                same_kernel = not (split == 1 and K >= 2048 and N <= 1024)
+                if same_kernel:
+                    assert all(torch.equal(g, w_) for g, w_ in zip(got, want)), (dp, kind)
+            if split == 1 and K >= 2048 and N <= 1024:
+                again = [t.clone() for t in run()]
+                assert all(torch.equal(g, w_) for g, w_ in zip(again, got)), (dp, kind)          # reruns identical per setting
+                ht = torch.bfloat16
+                base = a[0].view(ht).double() @ w[0].view(ht).double().t() + b.double() + r.double()
+                assert rel_l2(got[0].double().cpu(), base.cpu()) < 2e-6
+    finally:
+        _lib.check(lib.rnamsm_set_param(b"gemm16_dephase", 2))
+
+
 @pytest.mark.parametrize("fmt", [0, 1])
 @pytest.mark.parametrize("M,N,K,act", [(16384, 2304, 768, 0), (9000, 3072, 768, 1), (2048, 1280, 64, 0), (2100, 256, 128, 1)])
 def test_hi_lo_gemm_on_16x16x32_staged_by_operand(dev, M, N, K, act, fmt):
