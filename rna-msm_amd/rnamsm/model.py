@@ -12,6 +12,7 @@ never read "logits" (the CLI, bench.py -- the reference's CLI discards them too,
 from __future__ import annotations
 
 import ctypes
+import warnings
 from typing import Dict, Iterable, List, Optional
 
 import torch
@@ -377,6 +378,7 @@ class MSATransformer(nn.Module):
     # so far above its spread that the folded LayerNorm loses > 5 bits; an emb / atp value that is not finite (K10 looks at
     # every value it packs: in the 16-bit modes an operand outside fp16 range surfaces there as inf / NaN)
     ERR_INDEX, ERR_FOLD, ERR_NONFINITE = 1, 2, 4
+    _warned_chunked16 = False
 
     def checked_forward_one(self, tokens2d: torch.Tensor, has_padding: Optional[bool] = None, need_repr: bool = True,
                             what: str = "MSA") -> Dict[str, torch.Tensor]:
@@ -432,6 +434,11 @@ class MSATransformer(nn.Module):
         atp = torch.empty(NL * H, C - 1, C - 1, device=dev, dtype=torch.float32)
         err = torch.zeros(1, device=dev, dtype=torch.int32)
         dtype = _lib.DTYPES[gemm_dtype]
+        if dtype != _lib.F32 and max_tokens and lib.rnamsm_row_chunks(R, C, max_tokens) > 0 and not MSATransformer._warned_chunked16:
+            # rnamsm_forward runs such an MSA on the exact path as a whole (csrc/forward.hip): say so once instead of silently
+            MSATransformer._warned_chunked16 = True
+            warnings.warn(f"gemm_dtype={gemm_dtype!r}: a padded MSA above max_tokens_per_msa ({R} x {C} > {max_tokens}) follows the "
+                          "reference's chunked mask semantics, which exist in the exact-fp32 kernels only -- it runs in fp32")
         planes = self._weight_planes() if dtype != _lib.F32 else None
         folded = self._folded_weights() if (dtype == _lib.F32 and not has_padding and fold) else None
         # the 16-bit modes fold only on request (knob ln_fold = 3: measured neutral there): no tables otherwise
