@@ -60,15 +60,18 @@ def crop_tokens(tokens: np.ndarray, max_seqlen: int, rng: np.random.RandomState)
 class _AsyncNpyWriter:
     """Device tensors -> `.npy` files off the critical path: the D2H copy runs on a side stream into pinned buffers and a
     worker thread waits for it and calls np.save, so the GPU starts the next MSA while this one's 126 MB (L = 512) of maps
-    are still on their way to disk.  At most `depth` MSAs are in flight (bounds the pinned memory).  Files are written
-    in submission order; `close()` drains the queue and re-raises a worker exception."""
+    are still on their way to disk.  At most `depth` MSAs wait in the queue and `workers` are being written (bounds the pinned memory).  `workers` threads share
+    the queue (np.save releases the GIL while it writes: a list of small alignments is bound by the writer, 442 MB for 64 of
+    them); an alignment's two files are written by one worker, alignments may finish out of order.  `close()` drains the
+    queue and re-raises a worker exception."""
 
-    def __init__(self, device: torch.device, depth: int = 2):
+    def __init__(self, device: torch.device, depth: int = 2, workers: int = 2):
         self._stream = torch.cuda.Stream(device)
         self._q: "queue.Queue" = queue.Queue(maxsize=depth)
         self._err: Optional[BaseException] = None
-        self._thread = threading.Thread(target=self._run, name="rnamsm-npy-writer", daemon=True)
-        self._thread.start()
+        self._threads = [threading.Thread(target=self._run, name=f"rnamsm-npy-writer-{i}", daemon=True) for i in range(workers)]
+        for t in self._threads:
+            t.start()
 
     def _run(self) -> None:
         while True:
@@ -101,8 +104,10 @@ class _AsyncNpyWriter:
         self._q.put((event, staged, done))              # blocks when `depth` MSAs are already in flight
 
     def close(self) -> None:
-        self._q.put(None)
-        self._thread.join()
+        for _ in self._threads:
+            self._q.put(None)
+        for t in self._threads:
+            t.join()
         if self._err is not None:
             raise self._err
 
