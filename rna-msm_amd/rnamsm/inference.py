@@ -138,10 +138,10 @@ def joins_group(group_shapes: List[tuple], shape: tuple) -> bool:
 POOL_MSAS = 256
 
 
-def plan_groups(shapes: List[tuple]) -> List[List[int]]:
-    """Partition pooled small alignments (`shapes` = (rows, columns) each) into ragged-batch groups; returns lists of
-    positions into `shapes`, every position exactly once, members of a group in ascending position."""
-    order = sorted(range(len(shapes)), key=lambda j: (shapes[j][0], shapes[j][1], j))
+GROUP_OVERHEAD_TOKENS = 3300       # what one more launch set costs, in tokens of frame (~5.5 ms at ~600 k tokens/s)
+
+
+def _greedy_groups(shapes: List[tuple], order: List[int]) -> List[List[int]]:
     groups: List[List[int]] = []
     cur: List[int] = []
     for j in order:
@@ -152,6 +152,50 @@ def plan_groups(shapes: List[tuple]) -> List[List[int]]:
     if cur:
         groups.append(sorted(cur))
     return groups
+
+
+def _clustered_groups(shapes: List[tuple]) -> List[List[int]]:
+    """Seed a group with the largest alignment left, then keep adding the one that pads the frame least (joins_group's rule,
+    evaluated for all candidates at once)."""
+    rc = np.asarray(shapes, dtype=np.int64).reshape(-1, 2)
+    tok = rc[:, 0] * rc[:, 1]
+    left = np.ones(len(shapes), dtype=bool)
+    groups: List[List[int]] = []
+    while left.any():
+        seed = int(np.flatnonzero(left)[np.argmax(tok[left])])         # (the first of equals)
+        left[seed] = False
+        g, rows, cols, real = [seed], int(rc[seed, 0]), int(rc[seed, 1]), int(tok[seed])
+        while len(g) < GROUP_MEMBERS and left.any():
+            frame = (len(g) + 1) * np.maximum(rows, rc[:, 0]) * np.maximum(cols, rc[:, 1])
+            ok = left & (frame <= FRAME_TOKENS) & (frame <= 2 * (real + tok))
+            if not ok.any():
+                break
+            cost = np.where(ok, frame - real - tok, np.iinfo(np.int64).max)
+            best = int(np.argmin(cost))
+            left[best] = False
+            g.append(best)
+            rows, cols, real = max(rows, int(rc[best, 0])), max(cols, int(rc[best, 1])), real + int(tok[best])
+        groups.append(sorted(g))
+    return groups
+
+
+def frame_tokens(shapes: List[tuple], groups: List[List[int]]) -> int:
+    return sum(len(g) * max(shapes[j][0] for j in g) * max(shapes[j][1] for j in g) for g in groups)
+
+
+def plan_groups(shapes: List[tuple]) -> List[List[int]]:
+    """Partition pooled small alignments (`shapes` = (rows, columns) each) into ragged-batch groups; returns lists of
+    positions into `shapes`, every position exactly once, members of a group in ascending position.  Two plans are made -- fill
+    greedily in (rows, columns) order; cluster around the largest alignment left -- and the one with the smaller cost (tokens
+    of frame, padding included, plus GROUP_OVERHEAD_TOKENS per group) is taken, the first on a tie: 64 alignments of 2-12 rows x
+    40-80 columns -> 4 groups, frames 1.50 x the real tokens (sorted plan); 64 of 4-24 x 40-120 -> 9 groups at 1.40 x (clustered;
+    sorted: 1.51 x)."""
+    if not shapes:
+        return []
+    plans = [_greedy_groups(shapes, sorted(range(len(shapes)), key=lambda j: (shapes[j][0], shapes[j][1], j))),
+             _clustered_groups(shapes)]
+    cost = [frame_tokens(shapes, p) + GROUP_OVERHEAD_TOKENS * len(p) for p in plans]
+    return plans[0] if cost[0] <= cost[1] else plans[1]
 
 
 def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_rank0: bool = False,

@@ -393,6 +393,16 @@ def test_pooled_small_alignments_are_grouped_by_shape():
         cur.append(sh)
     in_order += 1
     assert len(groups) <= 6 < in_order
+    # a wider population (4-24 rows x 40-120 columns): the cheaper of the two plans keeps the frames within ~1.5 x the real tokens
+    from rnamsm.inference import frame_tokens
+    rng = np.random.RandomState(1)
+    wide = [(int(rng.randint(4, 25)), int(rng.randint(40, 121)) + 1) for _ in range(64)]
+    gw = plan_groups(wide)
+    assert sorted(j for g in gw for j in g) == list(range(64))
+    for g in gw:
+        frame = len(g) * max(wide[j][0] for j in g) * max(wide[j][1] for j in g)
+        assert len(g) <= GROUP_MEMBERS and frame <= FRAME_TOKENS and (len(g) == 1 or frame <= 2 * sum(wide[j][0] * wide[j][1] for j in g))
+    assert frame_tokens(wide, gw) <= 1.55 * sum(r * c for r, c in wide)
     assert plan_groups([]) == [] and plan_groups([(3, 20)]) == [[0]]
     assert plan_groups([(40, 35), (2, 12), (2, 12), (2, 12), (40, 35)]) == [[1, 2, 3], [0, 4]]          # alike ones meet although the list separates them
 
