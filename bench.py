@@ -526,7 +526,7 @@ def run_rank(args) -> int:
         import numpy as _np
         small_batches = {"what": "B same-shape MSAs one by one (rnamsm_forward each) vs one rnamsm_forward_batch call: ms per MSA "
                                  "and MSA-residues/s, exact path; outputs agree to fp32 rounding (tests/test_gpu_forward.py)", "cases": []}
-        for sm, sl, sb in ((8, 64, 32), (16, 128, 16), (32, 128, 8)):
+        for sm, sl, sb in ((8, 64, 64), (16, 128, 16), (32, 128, 8)):
             st = torch.from_numpy(_np.stack([synthetic.make_tokens(sm, sl, 900 + b) for b in range(sb)])).to(dev)
             for _ in range(2):
                 model.forward_batch(st, has_padding=False)

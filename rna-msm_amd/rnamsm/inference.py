@@ -118,7 +118,9 @@ class _AsyncNpyWriter:
 # ~2 k tokens on the padding of an ill-matched frame cost more than the shared launches returned, tools/ragged_batch_timing.py.
 # With groups formed by shape -- plan_groups -- frames are tight and 3072 measured x1.82 against x1.54 on a list of 4-24 rows x
 # 40-120 columns, tools/cli_throughput.py.)
-SMALL_MSA_TOKENS, FRAME_TOKENS, GROUP_MEMBERS = 3072, 16384, 32
+# (Frames: 16 k tokens / 32 members until the pool existed; a batch of 64 alignments of 8 x 64 runs at 676 k residues/s against
+# 649 k for 32 -- GEMM tile quantisation shrinks with the token count, tools/small_batch_knobs.py -- hence 32 k / 64.)
+SMALL_MSA_TOKENS, FRAME_TOKENS, GROUP_MEMBERS = 3072, 32768, 64
 
 
 def joins_group(group_shapes: List[tuple], shape: tuple) -> bool:
@@ -138,17 +140,26 @@ def joins_group(group_shapes: List[tuple], shape: tuple) -> bool:
 POOL_MSAS = 256
 
 
-GROUP_OVERHEAD_TOKENS = 3300       # what one more launch set costs, in tokens of frame (~5.5 ms at ~600 k tokens/s)
+# what one more launch set costs, in tokens of frame (~5.5 ms at ~600 k tokens/s): the padding one more member may add to a frame.
+# (Half and a quarter of it -- tighter frames, more groups -- measured the same within 5 % on lists of 64 and 256 alignments.)
+GROUP_OVERHEAD_TOKENS = 3300
 
 
 def _greedy_groups(shapes: List[tuple], order: List[int]) -> List[List[int]]:
+    """Fill groups in the given order; an alignment joins the waiting group while joins_group allows it AND the padding it adds
+    to the frame costs less than a launch set of its own (GROUP_OVERHEAD_TOKENS)."""
     groups: List[List[int]] = []
     cur: List[int] = []
+    rows = cols = 0
     for j in order:
-        if cur and not joins_group([shapes[i] for i in cur], shapes[j]):
-            groups.append(sorted(cur))
-            cur = []
+        r, c = shapes[j]
+        if cur:
+            grown = (len(cur) + 1) * max(rows, r) * max(cols, c) - len(cur) * rows * cols       # what the frame grows by
+            if not joins_group([shapes[i] for i in cur], shapes[j]) or grown - r * c > GROUP_OVERHEAD_TOKENS:
+                groups.append(sorted(cur))
+                cur, rows, cols = [], 0, 0
         cur.append(j)
+        rows, cols = max(rows, r), max(cols, c)
     if cur:
         groups.append(sorted(cur))
     return groups
@@ -156,7 +167,7 @@ def _greedy_groups(shapes: List[tuple], order: List[int]) -> List[List[int]]:
 
 def _clustered_groups(shapes: List[tuple]) -> List[List[int]]:
     """Seed a group with the largest alignment left, then keep adding the one that pads the frame least (joins_group's rule,
-    evaluated for all candidates at once)."""
+    evaluated for all candidates at once) while that padding costs less than a launch set of its own."""
     rc = np.asarray(shapes, dtype=np.int64).reshape(-1, 2)
     tok = rc[:, 0] * rc[:, 1]
     left = np.ones(len(shapes), dtype=bool)
@@ -168,10 +179,11 @@ def _clustered_groups(shapes: List[tuple]) -> List[List[int]]:
         while len(g) < GROUP_MEMBERS and left.any():
             frame = (len(g) + 1) * np.maximum(rows, rc[:, 0]) * np.maximum(cols, rc[:, 1])
             ok = left & (frame <= FRAME_TOKENS) & (frame <= 2 * (real + tok))
+            added_padding = frame - len(g) * rows * cols - tok
+            ok &= added_padding <= GROUP_OVERHEAD_TOKENS
             if not ok.any():
                 break
-            cost = np.where(ok, frame - real - tok, np.iinfo(np.int64).max)
-            best = int(np.argmin(cost))
+            best = int(np.argmin(np.where(ok, added_padding, np.iinfo(np.int64).max)))
             left[best] = False
             g.append(best)
             rows, cols, real = max(rows, int(rc[best, 0])), max(cols, int(rc[best, 1])), real + int(tok[best])
@@ -187,9 +199,9 @@ def plan_groups(shapes: List[tuple]) -> List[List[int]]:
     """Partition pooled small alignments (`shapes` = (rows, columns) each) into ragged-batch groups; returns lists of
     positions into `shapes`, every position exactly once, members of a group in ascending position.  Two plans are made -- fill
     greedily in (rows, columns) order; cluster around the largest alignment left -- and the one with the smaller cost (tokens
-    of frame, padding included, plus GROUP_OVERHEAD_TOKENS per group) is taken, the first on a tie: 64 alignments of 2-12 rows x
-    40-80 columns -> 4 groups, frames 1.50 x the real tokens (sorted plan); 64 of 4-24 x 40-120 -> 9 groups at 1.40 x (clustered;
-    sorted: 1.51 x)."""
+    of frame, padding included, plus GROUP_OVERHEAD_TOKENS per group) is taken, the first on a tie.  Lists of 64 / 256
+    alignments of 2-12 rows x 40-80 columns: 3 / 7 groups, x3.6 / x4.6 against one by one; of 4-24 x 40-120: 6 / 15 groups, x1.9 /
+    x2.3 (tools/cli_throughput.py)."""
     if not shapes:
         return []
     plans = [_greedy_groups(shapes, sorted(range(len(shapes)), key=lambda j: (shapes[j][0], shapes[j][1], j))),

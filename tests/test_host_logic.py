@@ -365,13 +365,13 @@ def test_reader_agrees_with_the_oracle_on_random_alignments():
 
 
 def test_cli_grouping_rule_for_small_alignments():
-    """data.batch_small_msas: a group's frame stays within 16 k tokens and twice its real tokens, at most 32 members."""
+    """data.batch_small_msas: a group's frame stays within 32 k tokens and twice its real tokens, at most 64 members."""
     from rnamsm.inference import FRAME_TOKENS, GROUP_MEMBERS, SMALL_MSA_TOKENS, joins_group
-    assert (SMALL_MSA_TOKENS, FRAME_TOKENS, GROUP_MEMBERS) == (3072, 16384, 32)
+    assert (SMALL_MSA_TOKENS, FRAME_TOKENS, GROUP_MEMBERS) == (3072, 32768, 64)
     assert joins_group([], (3, 20)) and joins_group([(3, 20)], (4, 22))
     assert not joins_group([(2, 10), (2, 10)], (30, 50))              # 3 x 30 x 50 = 4500 > 2 x 1540: too much padding
-    assert joins_group([(30, 50)] * 9, (30, 50)) and not joins_group([(30, 50)] * 10, (30, 50))    # 11 x 1500 > 16384
-    assert joins_group([(2, 8)] * 31, (2, 8)) and not joins_group([(2, 8)] * 32, (2, 8))
+    assert joins_group([(30, 50)] * 20, (30, 50)) and not joins_group([(30, 50)] * 21, (30, 50))    # 22 x 1500 > 32768
+    assert joins_group([(2, 8)] * 63, (2, 8)) and not joins_group([(2, 8)] * 64, (2, 8))
 
 
 def test_pooled_small_alignments_are_grouped_by_shape():
@@ -392,8 +392,8 @@ def test_pooled_small_alignments_are_grouped_by_shape():
             in_order, cur = in_order + 1, []
         cur.append(sh)
     in_order += 1
-    assert len(groups) <= 6 < in_order
-    # a wider population (4-24 rows x 40-120 columns): the cheaper of the two plans keeps the frames within ~1.5 x the real tokens
+    assert len(groups) <= 4 < in_order                       # (list order: 6 groups at the 32 k / 64 limits, 12 at 16 k / 32)
+    # a wider population (4-24 rows x 40-120 columns): the cheaper of the two plans; frames stay well inside the 2 x rule
     from rnamsm.inference import frame_tokens
     rng = np.random.RandomState(1)
     wide = [(int(rng.randint(4, 25)), int(rng.randint(40, 121)) + 1) for _ in range(64)]
@@ -402,7 +402,7 @@ def test_pooled_small_alignments_are_grouped_by_shape():
     for g in gw:
         frame = len(g) * max(wide[j][0] for j in g) * max(wide[j][1] for j in g)
         assert len(g) <= GROUP_MEMBERS and frame <= FRAME_TOKENS and (len(g) == 1 or frame <= 2 * sum(wide[j][0] * wide[j][1] for j in g))
-    assert frame_tokens(wide, gw) <= 1.55 * sum(r * c for r, c in wide)
+    assert frame_tokens(wide, gw) <= 1.8 * sum(r * c for r, c in wide)
     assert plan_groups([]) == [] and plan_groups([(3, 20)]) == [[0]]
     assert plan_groups([(40, 35), (2, 12), (2, 12), (2, 12), (40, 35)]) == [[1, 2, 3], [0, 4]]          # alike ones meet although the list separates them
 
