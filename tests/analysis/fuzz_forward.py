@@ -123,7 +123,9 @@ def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mod
                 # (a batch selects other GEMM tiles / split-K ranges than the MSA alone: rounding-level differences, which on tall,
                 # narrow alignments are as ill-conditioned as everything else there -- seed 41, R=300 C=3: 1.1e-4 in one map entry
                 # where the reference's own fp32 run is 3.2e-3 from the truth -- hence the yardstick term)
-                mod_ok = mod_ok and d_e < max(2e-5, 0.1 * ref["emb_rel_l2"]) and d_a < max(1e-4, 0.1 * ref["atp_max_abs"])
+                # (seed 46, R=255 C=17: alone 1.2e-4 and in the batch 7.1e-5 from the truth, 2.3e-4 from each other, the reference's own
+                # fp32 run 1.7e-4 from the truth: two results that each sit at the yardstick may differ by twice it)
+                mod_ok = mod_ok and d_e < max(2e-5, 2.0 * ref["emb_rel_l2"]) and d_a < max(1e-4, 2.0 * ref["atp_max_abs"])
                 mod_note += f" batch of 3: emb {bt['emb_rel_l2']:.2e} atp {bt['atp_max_abs']:.2e}, MSA 2 vs alone {d_e:.1e} / {d_a:.1e}"
             # padded exact-path cases also as the first of a padded batch of two (rnamsm_forward_batch, has_padding)
             if padded and mode == "f32" and R * C <= 16384:
