@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""rnamsm_forward_batch on B alignments of 8 x 64 (exact path) for several B and GEMM knobs, one process: how the residues/s of a
+batch of small alignments depends on its token count (GEMM tile quantisation: 576 k at B = 28, 649 k at 32, 603 k at 36, 660 k at 48,
+676 k at 64) and that none of gemm_tile / ln_fold / gemm_splitk moves it."""
 import os, sys, statistics, time
-sys.path.insert(0, "rna-msm_amd")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd"))
 import numpy as np, torch
 from rnamsm import _lib, synthetic, ops
 from rnamsm.model import MSATransformer
