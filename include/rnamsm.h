@@ -458,6 +458,11 @@ void rnamsm_timing_reset(void);
  *                 while both waves of a SIMD issue at once nobody feeds the matrix pipe): 0 = all right after the tile barrier,
  *                 1 = the upper wave group one (micro-)step later, 2 (default) = 1, and the 16x16x32 kernel stages by operand (W by
  *                 the lower group, A by the upper one, half a tile apart: QKV +18 %, fc1 +14 %).  Speed only, results bit-identical.
+ *   "gemm16_big_rows" / "gemm16_big_rows_fwd"  plane-operand 16-bit GEMMs: rows from which the 256x256-tile kernels replace the
+ *                 128x128 one -- in rnamsm_gemm_bf16 called directly (default 0 = 2048) and inside rnamsm_forward /
+ *                 rnamsm_forward_batch (default 0 = 10752 for plain bf16, 8960 for the hi/lo modes: below ~9-10 k tokens the
+ *                 256x256 kernels leave most CUs without a tile; 2048 tokens x1.33 / x1.59, 8192 x1.11 / x1.10).  The hi/lo modes'
+ *                 kernels sum every element in the same order (bit-identical); plain bf16 changes MFMA shape (fp32 rounding).
  *   "gemm16_x3q"  hi/lo modes, plane-output GEMMs (QKV, fc1) of >= 2048 rows: 1 = gemm16_x3q_kernel (16x16x32 MFMA, staged by
  *                 operand; +1.8 % on the six GEMMs of a layer), 0 (default) = the 32x32x16 kernel.  Results agree to fp32 rounding
  *                 (the k order inside a K tile differs) -- which at BASELINE configs[1] moved f16x3 from 6.5e-6 to 7.1e-6 of the

@@ -187,6 +187,14 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm16_x3q = value != 0;
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "gemm16_big_rows")) {
+        rnamsm::tuning().gemm16_big_rows = value < 0 ? 0 : value;
+        return RNAMSM_OK;
+    }
+    if (name && !strcmp(name, "gemm16_big_rows_fwd")) {
+        rnamsm::tuning().gemm16_big_rows_fwd = value < 0 ? 0 : value;
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "row16_bk64")) {
         rnamsm::tuning().row16_bk64 = value < 0 ? 0 : (value > 2 ? 2 : value);
         return RNAMSM_OK;
@@ -215,6 +223,8 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "col_dma")) return rnamsm::tuning().col_dma;
     if (name && !strcmp(name, "gemm16_dephase")) return rnamsm::tuning().gemm16_dephase;
     if (name && !strcmp(name, "gemm16_x3q")) return rnamsm::tuning().gemm16_x3q;
+    if (name && !strcmp(name, "gemm16_big_rows")) return rnamsm::tuning().gemm16_big_rows;
+    if (name && !strcmp(name, "gemm16_big_rows_fwd")) return rnamsm::tuning().gemm16_big_rows_fwd;
     if (name && !strcmp(name, "row16_bk64")) return rnamsm::tuning().row16_bk64;
     if (name && !strcmp(name, "row16_max_rows")) return rnamsm::tuning().row16_max_rows;
     if (name && !strcmp(name, "gemm16_pp")) return rnamsm::tuning().gemm16_pp;

@@ -69,6 +69,8 @@ struct Tuning {
                                    // 1 = the upper wave group one (micro-)step later; 2 = 1, and the 16x16x32 kernel stages by operand
                                    // (gemm16_q16s_kernel: W by the lower group, A by the upper one, half a tile apart)
     int gemm16_x3q = 0;            // hi/lo modes, plane-output GEMMs (QKV, fc1): 1 = gemm16_x3q_kernel (16x16x32 MFMA, staged by operand), 0 = gemm16_swp_kernel
+    int gemm16_big_rows = 0;       // rnamsm_gemm_bf16, plane operands: rows from which the 256x256-tile kernels are used (0 = 2048)
+    int gemm16_big_rows_fwd = 0;   // ... inside rnamsm_forward / rnamsm_forward_batch: 0 = by mode (10752 plain bf16, 8960 hi/lo), > 0 = that many
     int gemm_group = 0;            // fp32 GEMM: row panels per XCD group of the block order (xcd_panel_map_grouped); 0 = by shape
     int gemm_tile = 0;             // fp32 GEMM block tile: 0 = by shape, 1 = always 128x128, 2 = always 128x64
     int gemm_splitk = 1;           // rnamsm_forward, fc2 below ~1.4 k tokens: 1 = four K ranges + an ordered reduction (gemm_f32_splitk_factor), 0 = never, 2 / 4 / 8 = forced (A/B)
@@ -83,6 +85,19 @@ struct Tuning {
     int attn16 = 1;                // 16-bit modes of rnamsm_forward: 1 = attention contractions on the 16-bit matrix cores too, 0 = fp32 attention
 };
 Tuning& tuning();
+// rnamsm_forward's choice of the 16-bit GEMM tile by the MSA's token count: below ~9-10 k tokens the 256x256 kernels leave most
+// CUs without a tile (out_proj at 8192 tokens: 96 tiles for 256 CUs) and the 128x128 kernel is faster -- whole forward, one
+// process (tools/mid_size_tile_ab.py): 2048 tokens x1.33 (bf16) / x1.59 (f16x3), 4096 x1.14 / x1.32, 8192 x1.11 / x1.10, level at
+// 10 k (bf16) / 9 k (f16x3), 256x256 ahead from there (x0.92 at 12 k, x0.81-0.88 at 60 k).  The hi/lo modes' two kernels sum
+// every output element in the same order: bit-identical either way.
+struct BigRowsScope {
+    int saved;
+    explicit BigRowsScope(bool plain_bf16) : saved(tuning().gemm16_big_rows) {
+        const int fwd = tuning().gemm16_big_rows_fwd;
+        if (saved == 0) tuning().gemm16_big_rows = fwd > 0 ? fwd : (plain_bf16 ? 10752 : 8960);
+    }
+    ~BigRowsScope() { tuning().gemm16_big_rows = saved; }
+};
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the (function, DEVICE) pair, so "already configured" is
 // remembered per device of the calling thread, not per process (a process may drive several GPUs: data.device=cuda:1,

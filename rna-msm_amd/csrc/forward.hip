@@ -122,6 +122,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     // (a padded batch with the "attn16" knob off keeps the fp32 attention kernels and the masked fp32 QKV GEMM)
     // (per-chunk mask fills exist in the fp32 row kernels only: such an MSA takes the exact path as a whole)
     if (nchunks) dtype = RNAMSM_F32;
+    BigRowsScope big_rows_scope(dtype == RNAMSM_BF16);       // the 16-bit GEMMs' tile by this MSA's token count (common.h)
     const bool planes = dtype != RNAMSM_F32 && (!has_padding || tuning().attn16 != 0);
     const int split = dtype == RNAMSM_BF16 ? 1 : 3, fmt = dtype == RNAMSM_F16X3 ? 1 : 0;
     uint16_t* xn_hi = reinterpret_cast<uint16_t*>(xn);
@@ -429,6 +430,7 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
     const float* const* G = weights;
     const int f32 = RNAMSM_F32;
     const int nsplit = rnamsm_row_logits_nsplit(R, C, H);
+    BigRowsScope big_rows_scope(dtype == RNAMSM_BF16);       // (common.h)
     const int fold_mode = tuning().ln_fold;
     // statistics from the producers only; a ragged batch (true_rows) keeps the LayerNorm launches: its QKV GEMM carries the
     // per-token q factor in the epilogue slot the fold would need

@@ -1740,6 +1740,8 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
          : launch_hs<ACT_, RES_, SP_, FMT_, OPL_, 32>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s))
 #define HQ_GO(ACT_, RES_, OPL_) \
     launch_hq<ACT_, RES_, OPL_>(W_hi, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, O_hi, s)
+    // rows from which the 256x256-tile kernels take over from the 128x128 one ("gemm16_big_rows"; rnamsm_forward raises it, see there)
+    const int64_t big_rows = tuning().gemm16_big_rows > 0 ? tuning().gemm16_big_rows : 2048;
 #define HD_GO(ACT_, RES_, SP_, FMT_, OPL_) \
     launch_hd<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
 #define HB_ACT_RES(SP_, FMT_)                                                                                       \
@@ -1750,22 +1752,22 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
             return gemm16_pp(A_hi, lda, W_hi, bias, residual, ldr, Cout, ldc, m, N, K, act, scale, scale_cols, O_hi, s); \
         /* 16x16x32 MFMAs: round 2 +6.5 % on QKV, +1.4 % on fc1, -2.5 % on out_proj, 0 on fc2 (one process, cfg3 shapes): wide N only;   \
            round 3, staged by operand (gemm16_q16s_kernel): QKV +18 %, fc1 +14 %, fc2 +6.6 % (long K), out_proj -14 %           */ \
-        if (SP_ == 1 && A_hi && (tuning().gemm16_mfma16 == 1 ? (N / HX_BN > 4 || (K >= 2048 && tuning().gemm16_dephase == 2)) : tuning().gemm16_mfma16 == 2) && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= 2048 && K % 64 == 0) { \
+        if (SP_ == 1 && A_hi && (tuning().gemm16_mfma16 == 1 ? (N / HX_BN > 4 || (K >= 2048 && tuning().gemm16_dephase == 2)) : tuning().gemm16_mfma16 == 2) && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= big_rows && K % 64 == 0) { \
             if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HQ_GO(RNAMSM_ACT_GELU_ERF, false, true)                    \
                                                         : HQ_GO(RNAMSM_ACT_NONE, false, true);                       \
             return residual ? HQ_GO(RNAMSM_ACT_NONE, true, false) : HQ_GO(RNAMSM_ACT_NONE, false, false);            \
         }                                                                                                           \
         /* hi/lo modes, plane output: the 16x16x32 kernel staged by operand ("gemm16_x3q") */                         \
-        if (SP_ == 3 && A_hi && O_hi && tuning().gemm16_x3q && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= 2048 && K % 32 == 0) \
+        if (SP_ == 3 && A_hi && O_hi && tuning().gemm16_x3q && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= big_rows && K % 32 == 0) \
             return act == RNAMSM_ACT_GELU_ERF                                                                        \
                        ? launch_x3q<RNAMSM_ACT_GELU_ERF, FMT_>(W_hi, W_lo, bias, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s) \
                        : launch_x3q<RNAMSM_ACT_NONE, FMT_>(W_hi, W_lo, bias, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s);    \
-        if (A_hi && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= 2048) {   /* software-pipelined fragments */    \
+        if (A_hi && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= big_rows) {   /* software-pipelined fragments */    \
             if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HS_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true)        \
                                                         : HS_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, true);           \
             return residual ? HS_GO(RNAMSM_ACT_NONE, true, SP_, FMT_, false) : HS_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, false); \
         }                                                                                                           \
-        if (A_hi && tuning().gemm16_dma >= 2 && N % HX_BN == 0 && m >= 2048) {   /* 256x256 tile for large problems */ \
+        if (A_hi && tuning().gemm16_dma >= 2 && N % HX_BN == 0 && m >= big_rows) {   /* 256x256 tile for large problems */ \
             if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HX_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true)        \
                                                         : HX_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, true);           \
             return residual ? HX_GO(RNAMSM_ACT_NONE, true, SP_, FMT_, false) : HX_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, false); \
