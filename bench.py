@@ -55,6 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "f16x3", "bf16x3", "bf16"],
                     help="arithmetic of the contractions for the headline value (default: exact fp32)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16x3 / bf16 / outputs-only measurements")
+    ap.add_argument("--no-per-config", action="store_true", help="skip the one-forward-per-BASELINE-config block")
     ap.add_argument("--outputs-only", action="store_true",
                     help="headline on the outputs-only forward (rnamsm_forward without RNAMSM_OUT_REPR: what the CLI runs; the "
                          "last layer skips the rows emb/atp do not depend on).  Default: the complete forward.")
@@ -195,9 +196,10 @@ def host_cpu_info():
 def cpu_baseline(M, L, state):
     """The oracle (port of the reference) on the host's cores, measured at the BENCHMARKED shape.
     torch's intra-op pool is swept over {os.cpu_count(), physical cores, 1/2, 1/4, 1/8 of them} on ONE layer of the
-    M x L MSA of this bench (embedding and final LayerNorm included); at the fastest setting: one warm-up, then three
-    samples of that layer, `median_s` of them x 10 (the ten layers are identical in cost) = `value`.  Beside it the
-    complete 10-layer forward of BASELINE configs[1] (M=64 x L=128), which fits the time budget whole."""
+    M x L MSA of this bench (embedding and final LayerNorm included); at the fastest setting three more samples of that
+    layer (their median is the cross-check `per_layer_median_s`), then ONE COMPLETE 10-layer forward, timed whole:
+    `value` = M L / `full_forward_s`, no extrapolation (the sweep has paged the weights in and spun the pool up: it is the
+    warm-up).  RNAMSM_BENCH_CPU_FULL=0 falls back to the per-layer figure x 10 and says so."""
     import statistics
     import torch
     from oracle import msm_oracle as O
@@ -223,52 +225,65 @@ def cpu_baseline(M, L, state):
             sweep[n] = one_layer()
         best = min(sweep, key=sweep.get)
         torch.set_num_threads(best)
-        one_layer()                                                   # warm-up at the chosen setting
         samples = [one_layer() for _ in range(3)]
         med = statistics.median(samples)
-        small = torch.from_numpy(synthetic.make_tokens(64, 128, 0))
-        O.forward(small, params)
-        t0 = time.perf_counter()
-        O.forward(small, params)
-        t_cfg1 = time.perf_counter() - t0
-    return {"value": M * L / (10.0 * med), "unit": "MSA-residues/s", "cores": best, "kind": "port",
+        full_s = None
+        if os.environ.get("RNAMSM_BENCH_CPU_FULL", "1") != "0":
+            t0 = time.perf_counter()
+            O.forward(toks, params, ffn_token_chunk=chunk)            # all ten layers, embedding, final LayerNorm, maps
+            full_s = time.perf_counter() - t0
+    value = M * L / full_s if full_s else M * L / (10.0 * med)
+    return {"value": value, "unit": "MSA-residues/s", "cores": best, "kind": "port",
             "cpu_model": model, "physical_cores": physical, "logical_cpus": logical,
+            "full_forward_s": None if full_s is None else round(full_s, 3),
+            "extrapolation": None if full_s else "one of ten identical layers timed, x 10 (RNAMSM_BENCH_CPU_FULL=0)",
             "thread_sweep_at_bench_shape": {"shape": [M, L], "seconds_per_layer": {str(k): round(v, 4) for k, v in sweep.items()}},
-            "samples": [round(v, 4) for v in samples], "median_s": round(med, 4),
-            "extrapolation": "one of ten identical layers (embedding + final LayerNorm included) timed, x 10",
-            "configs1_full_forward": {"M": 64, "L": 128, "seconds": round(t_cfg1, 3), "residues_per_s": 64 * 128 / t_cfg1,
-                                      "what": "complete 10-layer forward, no extrapolation"},
+            "per_layer_samples_s": [round(v, 4) for v in samples], "per_layer_median_s": round(med, 4),
+            "per_layer_x10_cross_check_residues_per_s": M * L / (10.0 * med),
             "sample": f"oracle/msm_oracle.py on {model} ({physical} cores / {logical} threads), torch {torch.__version__} "
-                      f"CPU fp32 with {best} intra-op threads (fastest of a sweep on this shape): 1 of 10 layers of one M={M} "
-                      f"L={L} MSA, warm-up 1, median of 3 = {med:.2f} s, x10 extrapolated; the complete 10-layer M=64 L=128 "
-                      f"forward took {t_cfg1:.2f} s"}
+                      f"CPU fp32 with {best} intra-op threads (fastest of a one-layer sweep on this shape): "
+                      + (f"ONE complete 10-layer forward of one M={M} L={L} MSA = {full_s:.1f} s"
+                         if full_s else f"1 of 10 layers, median of 3 = {med:.2f} s, x 10")
+                      + f"; cross-check: one layer (embedding + final LayerNorm included) median of 3 = {med:.2f} s"}
 
 
-def mode_roofline(timings, mode, mult, steps):
-    """Roofline of a 16-bit mode, every launch priced against its OWN limit: bound = max(executed matrix flops / 2.5 PFLOP/s,
-    algorithmic bytes / 6.3 TB/s) per launch (csrc/common.h KernelTimer; in these modes out_proj, the LayerNorms and the
-    attention kernels are HBM-bound, QKV / fc1 matrix-bound), summed per kernel family; frac = bound time / measured
-    time.  The dominant family (the Linear GEMMs) is the block's headline; `all_kernels` is the whole step."""
-    g = timings["gemm_f32"]
+def per_kernel_bounds(timings, steps):
+    """{kernel family: ms, its roofline time, the fraction reached and WHICH limit binds it}: every launch is priced at
+    max(executed matrix flops / MFMA peak, algorithmic bytes / 6.3 TB/s, vector-ALU issue time) (csrc/common.h KernelTimer)."""
     per = {}
     for k, v in timings.items():
         if v["launches"]:
+            terms = {"mfma": v["mfma_bound_ms"], "hbm": v["hbm_bound_ms"], "valu": v.get("valu_bound_ms", 0.0)}
             per[k] = {"ms_per_step": v["ms"] / steps, "bound_ms_per_step": v["bound_ms"] / steps,
                       "frac": v["bound_ms"] / v["ms"] if v["ms"] > 0 else 0.0,
-                      "bound": "mfma" if v["mfma_bound_ms"] >= v["hbm_bound_ms"] else "hbm"}
+                      "bound": max(terms, key=terms.get),
+                      "bound_terms_ms_per_step": {a: b / steps for a, b in terms.items()}}
+    return per
+
+
+def mode_roofline(timings, mode, mult, steps):
+    """Roofline of a 16-bit mode.  `frac` / `peak` keep the meaning they have on the f32 line and had in earlier rounds: the GEMM
+    family's executed TFLOP/s against the 2.5 PFLOP/s dense MFMA peak.  Beside it every launch is priced against its OWN
+    limit -- max(executed matrix flops / 2.5 PFLOP/s, algorithmic bytes / 6.3 TB/s, vector-ALU issue time); out_proj, the
+    LayerNorms and the softmax are HBM-bound in these modes, QKV / fc1 matrix-bound -- and summed per kernel family:
+    `frac_of_own_bound` (GEMMs), `per_kernel`, `all_kernels` (the whole step)."""
+    g = timings["gemm_f32"]
+    per = per_kernel_bounds(timings, steps)
     tot_ms = sum(v["ms"] for v in timings.values())
     tot_bound = sum(v["bound_ms"] for v in timings.values())
     raw = mult * g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
     lim = mult * g["flops"] / (g["bound_ms"] * 1e-3) / 1e12 if g["bound_ms"] > 0 else 0.0
-    return {"bound": "per launch max(mfma, hbm)", "kernel": "16-bit Linear GEMMs (gemm16_q16s_kernel / gemm16_swp_kernel; nn.Linear, K2)",
-            "achieved": raw, "peak": lim,
-            "unit": "TFLOP/s executed by the GEMM launches; peak = the same flops at every launch's own bound, "
-                    "max(flops / 2.5 PFLOP/s, algorithmic bytes / 6.3 TB/s)" + (" (executed = 3 x algorithmic)" if mult == 3.0 else ""),
-            "frac": raw / lim if lim > 0 else 0.0,
+    return {"bound": "mfma", "kernel": "16-bit Linear GEMMs (gemm16_q16s_kernel / gemm16_swp_kernel; nn.Linear, K2)",
+            "achieved": raw, "peak": F16_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s executed by the GEMM launches" + (" (executed = 3 x algorithmic)" if mult == 3.0 else ""),
+            "frac": raw / F16_MFMA_PEAK_TFLOPS,
+            "frac_of_own_bound": raw / lim if lim > 0 else 0.0,
+            "own_bound_tflops": lim,
+            "own_bound_what": "the same flops with every launch at its own bound, max(flops / 2.5 PFLOP/s, algorithmic bytes / 6.3 TB/s)",
             "gemm_ms_per_step": g["ms"] / steps, "gemm_bound_ms_per_step": g["bound_ms"] / steps,
             "gemm_mfma_bound_ms": g["mfma_bound_ms"] / steps, "gemm_hbm_bound_ms": g["hbm_bound_ms"] / steps,
-            "gemm_frac_of_mfma_peak": raw / F16_MFMA_PEAK_TFLOPS, "gemm_algorithmic_tflops": raw / mult,
-            "peaks": {"mfma_tflops": F16_MFMA_PEAK_TFLOPS, "hbm_tbps": 6.3},
+            "gemm_algorithmic_tflops": raw / mult,
+            "peaks": {"mfma_tflops": F16_MFMA_PEAK_TFLOPS, "hbm_tbps": 6.3, "valu_lane_ops_per_s": 1024 * 32 * 2.4e9},
             "all_kernels": {"ms_per_step": tot_ms / steps, "bound_ms_per_step": tot_bound / steps,
                             "frac": tot_bound / tot_ms if tot_ms > 0 else 0.0},
             "per_kernel": per, "mode": mode}
@@ -552,6 +567,60 @@ def run_rank(args) -> int:
                                  ".bfloat16() arithmetic against an fp64 truth at every BASELINE size "
                                  "(profiles/r02_fullsize_parity.json)")
 
+    # ---- every BASELINE config on the driver-run line (N = 1): one MSA of each shape, 1 warm-up + 2 timed forwards with the
+    # hooks off, then one instrumented forward for the per-launch roofline sums
+    per_config = None
+    if args.gemm_dtype == "f32" and not args.no_per_config and world == 1 and not batch:
+        import numpy as _np
+        per_config = {"what": "one forward per BASELINE config (complete forward, emb + atp + representation), inputs resident in "
+                              "HBM: ms = mean of 2 timed forwards after 1 warm-up; model_tflops = SURVEY 8d flops / time; "
+                              "kernel_frac_of_bounds = sum of every launch's own roofline time / sum of launch times"}
+
+        def one_config(tokens, mode):
+            model.gemm_dtype = mode
+            cm, cl = int(tokens.shape[0]), int(tokens.shape[1])
+            model.forward_one(tokens, has_padding=False)
+            sync_all()
+            tc0 = time.perf_counter()
+            for _ in range(2):
+                out_c = model.forward_one(tokens, has_padding=False)
+            sync_all()
+            sec = (time.perf_counter() - tc0) / 2
+            ok = bool(torch.isfinite(out_c["emb"]).all()) and int(out_c["err"].item()) == 0
+            lib.rnamsm_timing_reset()
+            lib.rnamsm_timing_enable(1)
+            model.forward_one(tokens, has_padding=False)
+            sync_all()
+            lib.rnamsm_timing_enable(0)
+            tim = _lib.kernel_timings()
+            model.gemm_dtype = "f32"
+            del out_c
+            tot = sum(v["ms"] for v in tim.values())
+            return {"num_seqs": cm, "seq_len": cl, "dtype": mode, "ms_per_step": 1e3 * sec, "residues_per_s": cm * cl / sec,
+                    "model_tflops": flops_per_msa(cm, cl) / sec / 1e12, "outputs_finite_and_err_word_clear": ok,
+                    "kernel_ms": tot, "kernel_frac_of_bounds": sum(v["bound_ms"] for v in tim.values()) / tot if tot else 0.0,
+                    "per_kernel": {k: {"ms": round(v["ms_per_step"], 4), "frac": round(v["frac"], 4), "bound": v["bound"]}
+                                   for k, v in per_kernel_bounds(tim, 1).items()}}
+
+        gold = os.path.join(ROOT, "tests", "golden", "tokens_2DRB_1_full.npz")
+        try:
+            t0c = _np.load(gold)["diversity_max_512"].astype(_np.int64)
+            src0 = "the shipped 2DRB_1 alignment, 512 rows by diversity-max as the CLI selects them (tests/golden/tokens_2DRB_1_full.npz)"
+        except Exception:                                              # noqa: BLE001 -- the fixture is optional here
+            t0c = synthetic.make_tokens(512, 36, 0)
+            src0 = "synthetic 512 x 36 (fixture not found)"
+        cases = [("configs0_f32", torch.from_numpy(_np.ascontiguousarray(t0c)).to(dev), "f32", src0),
+                 ("configs1_f32", torch.from_numpy(synthetic.make_tokens(64, 128, 1)).to(dev), "f32", "synthetic"),
+                 ("configs3_f32", torch.from_numpy(synthetic.make_tokens(128, 256, 3)).to(dev), "f32", "synthetic, one MSA of the batch"),
+                 ("configs4_bf16", torch.from_numpy(synthetic.make_tokens(1024, 1024, 4)).to(dev), "bf16", "synthetic"),
+                 ("configs4_f16x3", None, "f16x3", "synthetic")]
+        for name, tk, mode, src in cases:
+            if tk is None:
+                tk = cases[3][1]
+            per_config[name] = dict(one_config(tk, mode), tokens=src)
+        del cases, tk
+        torch.cuda.empty_cache()
+
     probe_out = model.forward_one(first)
     finite = bool(torch.isfinite(probe_out["emb"]).all())
     err_word = int(probe_out["err"].item())       # 0: tokens in range (bit 0) and the folded LayerNorm's precondition held (bit 1)
@@ -639,6 +708,7 @@ def run_rank(args) -> int:
                                "peak": peak, "unit": flop_unit,
                                "frac": (attn_fl / (attn_ms * 1e-3) / 1e12 / peak) if attn_ms else 0.0},
             "kernel_ms_per_msa": {k: v["ms"] / roof_local for k, v in timings.items()},
+            "per_kernel": per_kernel_bounds(timings, roof_local),
             "kernel_time_share_of_roofline_pass": kern_ms / (1e3 * roof_elapsed),
         }
         if args.digest:
@@ -646,6 +716,8 @@ def run_rank(args) -> int:
                                        "what": "sum over gathered outputs of (global item index + 1) * sum(int32 bit patterns), mod 2^64"}
         if args.outputs_only:
             result["config"]["workload"] += " -- OUTPUTS-ONLY forward (--outputs-only): the last layer computes alignment row 0 only"
+        if per_config is not None:
+            result["per_config"] = per_config
         if fast is not None:
             result["outputs_only_mode"] = outputs_only
             result["small_msa_batches"] = small_batches

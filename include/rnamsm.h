@@ -432,13 +432,19 @@ int rnamsm_timing_get(int category, const char** name, long long* launches, doub
  * (peaks from MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 MFMA, 2.5 PFLOP/s bf16 / f16 MFMA, 6.3 TB/s HBM).  bound_ms / ms is
  * the fraction of its own roofline a kernel family reached (bench.py's `roofline` of the 16-bit modes). */
 int rnamsm_timing_get_bound(int category, double* bound_ms, double* mfma_ms, double* hbm_ms);
+/* Third roofline term, for the kernels whose softmax can out-weigh their contractions (the fused column attention at head_dim
+ * 64): the launches' vector-ALU issue time, (plain instructions + 4 x transcendentals) per score x scores / (1024 SIMDs x
+ * 32 lanes x 2.4 GHz).  bound_ms of rnamsm_timing_get_bound is the per-launch max over all three terms. */
+int rnamsm_timing_get_valu_bound(int category, double* valu_ms);
 void rnamsm_timing_reset(void);
 
 /* Knobs for in-process A/B measurements.  Known names:
- *   "gemm16_dma"  staging of the plane-input 16-bit GEMMs: 0 register-staged, 1 LDS-DMA 128x128 tile,
- *                 2 LDS-DMA 256x256 tile when the problem allows, 3 (default) = 2 with software-pipelined fragment
+ *   "gemm16_dma"  staging of the plane-input 16-bit GEMMs: 0 register-staged, 1 (or 2) LDS-DMA 128x128 tile,
+ *                 3 (default) = LDS-DMA 256x256 tile when the problem allows, software-pipelined fragment
  *                 reads and a mid-tile barrier (K tile 64 deep for plain bf16, 32 for the hi/lo modes), 4 = 3 with
- *                 32-deep K tiles for every mode.  Speed only.
+ *                 32-deep K tiles for every mode.  Speed only.  (The plain 256x256 kernel that was value 2, the non-staged
+ *                 16x16x32 kernel and the epilogue-hiding "gemm16_pp" kernel were removed from the library in round 4; their
+ *                 measurements are in EXPERIMENTS.md, the last one's source under tools/probes/.)
  *   "gemm_group"  GEMM block order (fp32 kernel and the 256x256 16-bit kernel): row panels per XCD group (0 = chosen
  *                 from the shape, default; 1 = whole panels).  Changes HBM-side traffic and speed, never results.
  *   "gemm_tile"   fp32 GEMM block tile: 0 (default) = 128x128, or 128x64 where that evens out the last round of blocks
@@ -451,13 +457,11 @@ void rnamsm_timing_reset(void);
  *                 measured: no effect).  Speed only, results bit-identical.
  *   "gemm16_mfma16"  plain-bf16 256x256 GEMM: 1 (default) = the 16x16x32-MFMA kernel for N > 1024 or K >= 2048, 2 = for every shape,
  *                 0 = the 32x32x16 kernel.  Results agree to fp32 rounding (the k order inside a step differs).
- *   "gemm16_pp"   plain-bf16 plane GEMMs: 1 = gemm16_pp_kernel (four waves x 512 registers with two accumulator sets: a tile's
- *                 epilogue leaves under the next tile's K loop), 0 (default) = the 256x256 kernels.  Bit-identical to the
- *                 16x16x32 256x256 kernel; measured 0.61-0.83x (EXPERIMENTS.md R3.1), kept as the record of that experiment.
- *   "gemm16_dephase"  256x256 16-bit GEMMs: when the waves issue their LDS-DMA requests (a wave is stuck ~100 cycles per request, and
- *                 while both waves of a SIMD issue at once nobody feeds the matrix pipe): 0 = all right after the tile barrier,
- *                 1 = the upper wave group one (micro-)step later, 2 (default) = 1, and the 16x16x32 kernel stages by operand (W by
- *                 the lower group, A by the upper one, half a tile apart: QKV +18 %, fc1 +14 %).  Speed only, results bit-identical.
+ *   "gemm16_dephase"  256x256 16-bit GEMMs on the 32x32x16 MFMA and the 256x256 row kernels: when the waves issue their LDS-DMA
+ *                 requests (a wave is stuck ~100 cycles per request, and while both waves of a SIMD issue at once nobody feeds the
+ *                 matrix pipe): 0 = all right after the tile barrier, 1 / 2 (default) = the upper wave group one (micro-)step
+ *                 later.  (The 16x16x32 kernels always stage by operand: W by the lower group, A by the upper one, half a tile
+ *                 apart: QKV +18 %, fc1 +14 %.)  Speed only, results bit-identical.
  *   "gemm16_big_rows" / "gemm16_big_rows_fwd"  plane-operand 16-bit GEMMs: rows from which the 256x256-tile kernels replace the
  *                 128x128 one -- in rnamsm_gemm_bf16 called directly (default 0 = 2048) and inside rnamsm_forward /
  *                 rnamsm_forward_batch (default 0 = 10752 for plain bf16, 8960 for the hi/lo modes: below ~9-10 k tokens the
@@ -467,6 +471,9 @@ void rnamsm_timing_reset(void);
  *                 operand; +1.8 % on the six GEMMs of a layer), 0 (default) = the 32x32x16 kernel.  Results agree to fp32 rounding
  *                 (the k order inside a K tile differs) -- which at BASELINE configs[1] moved f16x3 from 6.5e-6 to 7.1e-6 of the
  *                 truth, across the 2 x CPU-fp32 bar of tests/test_gpu_fullsize.py (6.6e-6): hence not the default.
+ *   "row16_q16"   plain bf16 rnamsm_row_logits16 at C >= 384 with C % 8 == 0: 1 (default) = row_logits16q_kernel (256x256 tiles on the
+ *                 16x16x32 MFMA, staged by operand, persistent blocks, register-direct epilogue), 0 = the 128x128 kernel.  Changes
+ *                 the row split (rnamsm_row_logits16_nsplit) and agrees to fp32 rounding.
  *   "row16_bk64"  plain bf16, C >= 256: 1 (default) = rnamsm_row_apply16 stages 64 keys per tile (whole cache lines per P row, half
  *                 the barriers), 2 = rnamsm_row_logits16 too runs the 256x256-tile kernel with 64-deep tiles (measured equal to
  *                 its 128x128 kernel), 0 = neither.  Results agree to fp32 rounding.
@@ -490,7 +497,9 @@ void rnamsm_timing_reset(void);
  *                 the fp32 rounding level), 0 = never, 2 / 4 / 8 = that many ranges whenever tiles x ranges <= 512 (A/B).
  *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit
  *                 matrix cores in the mode's operand format (K4'..K7'), 0 = they stay on the exact-fp32 kernels,
- *                 2 = as 1 but the row kernels keep 128x128 tiles for every C (A/B of the 256x256-tile kernels).
+ *                 2 = as 1 but the row kernels keep 128x128 tiles for every C (A/B of the 256x256-tile kernels);
+ *                 rnamsm_col_attn16 only: 4 = one 32-query block per wave for every R, 5 = the TRACKED (online-softmax) loop for
+ *                 every format (A/B, and the reference the FAST loop's fallback is tested against).
  *                 The RNAMSM_F32 path is not affected by either. */
 int rnamsm_set_param(const char* name, int value);
 int rnamsm_get_param(const char* name);

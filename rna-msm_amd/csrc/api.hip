@@ -25,13 +25,14 @@ int fail(int code, const char* fmt, ...) {
 namespace {
 struct Record {
     int category;
-    double flops, bytes, mfma_s, hbm_s;
+    double flops, bytes, mfma_s, hbm_s, valu_s;
     hipEvent_t start, stop;
 };
 struct Totals {
     long long launches = 0;
     double ms = 0, flops = 0, bytes = 0;
-    double bound_ms = 0, mfma_ms = 0, hbm_ms = 0;      // sums over launches of max(mfma, hbm), mfma, hbm time at the peaks
+    double bound_ms = 0, mfma_ms = 0, hbm_ms = 0;      // sums over launches of max(mfma, hbm, valu), mfma, hbm time at the peaks
+    double valu_ms = 0;                                // ... and of the vector-ALU issue time (softmax-bound attention kernels)
 };
 std::mutex g_tmu;
 bool g_ton = false;
@@ -53,9 +54,9 @@ hipEvent_t take_event() {
 }  // namespace
 
 bool timing_enabled() { return g_ton; }
-void timing_begin(int category, double flops, double bytes, double mfma_s, double hbm_s, hipStream_t stream) {
+void timing_begin(int category, double flops, double bytes, double mfma_s, double hbm_s, double valu_s, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_tmu);
-    Record r{category, flops, bytes, mfma_s, hbm_s, take_event(), take_event()};
+    Record r{category, flops, bytes, mfma_s, hbm_s, valu_s, take_event(), take_event()};
     (void)hipEventRecord(r.start, stream);
     g_pending.push_back(r);
 }
@@ -81,9 +82,11 @@ extern "C" int rnamsm_timing_collect(void) {
             t.ms += ms;
             t.flops += r.flops;
             t.bytes += r.bytes;
-            t.bound_ms += 1e3 * (r.mfma_s > r.hbm_s ? r.mfma_s : r.hbm_s);
+            const double two = r.mfma_s > r.hbm_s ? r.mfma_s : r.hbm_s;
+            t.bound_ms += 1e3 * (two > r.valu_s ? two : r.valu_s);
             t.mfma_ms += 1e3 * r.mfma_s;
             t.hbm_ms += 1e3 * r.hbm_s;
+            t.valu_ms += 1e3 * r.valu_s;
         }
         g_free.push_back(r.start);
         g_free.push_back(r.stop);
@@ -112,6 +115,13 @@ extern "C" int rnamsm_timing_get_bound(int category, double* bound_ms, double* m
     if (hbm_ms) *hbm_ms = g_tot[category].hbm_ms;
     return RNAMSM_OK;
 }
+extern "C" int rnamsm_timing_get_valu_bound(int category, double* valu_ms) {
+    using namespace rnamsm;
+    if (category < 0 || category >= TC_COUNT) return fail(RNAMSM_ERR_INVALID, "timing_get_valu_bound: bad category %d", category);
+    std::lock_guard<std::mutex> lk(g_tmu);
+    if (valu_ms) *valu_ms = g_tot[category].valu_ms;
+    return RNAMSM_OK;
+}
 extern "C" void rnamsm_timing_reset(void) {
     using namespace rnamsm;
     std::lock_guard<std::mutex> lk(g_tmu);
@@ -122,6 +132,10 @@ namespace rnamsm {
 Tuning& tuning() {
     static Tuning t;
     return t;
+}
+int& gemm16_big_rows_override() {
+    static thread_local int v = 0;
+    return v;
 }
 }  // namespace rnamsm
 extern "C" int rnamsm_set_param(const char* name, int value) {
@@ -165,10 +179,6 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm16_mfma16 = value < 0 ? 0 : (value > 2 ? 2 : value);
         return RNAMSM_OK;
     }
-    if (name && !strcmp(name, "gemm16_pp")) {
-        rnamsm::tuning().gemm16_pp = value != 0;
-        return RNAMSM_OK;
-    }
     if (name && !strcmp(name, "gemm16_persist")) {
         if (value < 0 || value % 8 != 0) return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: gemm16_persist must be a non-negative multiple of 8");
         rnamsm::tuning().gemm16_persist = value;
@@ -193,6 +203,10 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
     }
     if (name && !strcmp(name, "gemm16_big_rows_fwd")) {
         rnamsm::tuning().gemm16_big_rows_fwd = value < 0 ? 0 : value;
+        return RNAMSM_OK;
+    }
+    if (name && !strcmp(name, "row16_q16")) {
+        rnamsm::tuning().row16_q16 = value != 0;
         return RNAMSM_OK;
     }
     if (name && !strcmp(name, "row16_bk64")) {
@@ -225,9 +239,9 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "gemm16_x3q")) return rnamsm::tuning().gemm16_x3q;
     if (name && !strcmp(name, "gemm16_big_rows")) return rnamsm::tuning().gemm16_big_rows;
     if (name && !strcmp(name, "gemm16_big_rows_fwd")) return rnamsm::tuning().gemm16_big_rows_fwd;
+    if (name && !strcmp(name, "row16_q16")) return rnamsm::tuning().row16_q16;
     if (name && !strcmp(name, "row16_bk64")) return rnamsm::tuning().row16_bk64;
     if (name && !strcmp(name, "row16_max_rows")) return rnamsm::tuning().row16_max_rows;
-    if (name && !strcmp(name, "gemm16_pp")) return rnamsm::tuning().gemm16_pp;
     if (name && !strcmp(name, "gemm16_persist")) return rnamsm::tuning().gemm16_persist;
     if (name && !strcmp(name, "gemm16_mfma16")) return rnamsm::tuning().gemm16_mfma16;
     if (name && !strcmp(name, "gemm_splitk")) return rnamsm::tuning().gemm_splitk;

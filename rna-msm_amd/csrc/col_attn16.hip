@@ -1,24 +1,432 @@
 // K7': fused column attention on the 16-bit matrix cores (16-bit modes of ColumnSelfAttention, modules.py:875-924).
 //
-// Same algorithm as col_attn.hip (S^T = K Q^T with the query on the lane, online softmax in fp32 registers, exp(S^T)
-// used in place as the B operand of O^T += V^T P^T), with q/k/v arriving as 16-bit hi(+lo) planes [T, 3D] from the QKV
-// GEMM epilogue:
-//   K chunk [64 keys][64 d]  "k" tile of tile16.h, DMA-staged, read with ds_read_b128 (A operand of S^T, k = d);
-//   V chunk [64 keys][64 d]  "t" tile, staged exactly as it lies in memory and read with ds_read_b64_tr_b16 as the
+// Same algorithm as col_attn.hip (S^T = K Q^T with the query on the lane, softmax in fp32 registers, exp(S^T) used in place as
+// the B operand of O^T += V^T P^T), with q/k/v arriving as 16-bit hi(+lo) planes [T, 3D] from the QKV GEMM epilogue:
+//   K chunk [JC keys][64 d]  "k" tile of tile16.h, DMA-staged, read with ds_read_b128 (A operand of S^T, k = d);
+//   V chunk [JC keys][64 d]  "t" tile, staged exactly as it lies in memory and read with ds_read_b64_tr_b16 as the
 //                            A operand V^T[d][key] of O^T -- the hardware transposed read replaces a transposing copy;
 //   P                        the fp32 accumulator registers 8s..8s+7 of S^T, converted pairwise to halves, ARE the B
 //                            fragment of k-step s; its k order is key 16s + 8(e>>2) + 4*half + (e&3) for element e, so
 //                            the V fragment is built from the two 4-key blocks 16s + 4*half and 16s + 8 + 4*half.
 // scale (dh^-0.5) multiplies the fp32 scores, not q: an unscaled q keeps its fp16 lo plane clear of subnormals.
 // SPLIT 1: bf16 operands, one MFMA per product.  SPLIT 3: hi/lo pairs, 3 MFMAs (P = hi + lo with |lo| <= 2^-11 P).
-// Per 32-key tile and wave: (4 + 4) * SPLIT MFMAs of 32 cycles against ~150 VALU for the softmax -> VALU/exp-bound;
-// two blocks per CU interleave one block's softmax with the other's MFMAs.
+//
+// What bounds it (round 4).  Per 32-key tile and 32-query block a wave issues (4 + 4) * SPLIT MFMAs of 32 cycles -- 256 cycles
+// of matrix pipe in plain bf16 -- against the softmax of 16 scores per lane on the VALU, whose ISSUE cycles (4 per plain
+// instruction, 8 per v_exp_f32; MI355X_MICROARCH.md cycle constants) are the real limit at head_dim 64: the round-3 kernel
+// spent ~150 instructions (~690 issue cycles) per tile.  Two loops now:
+//   FAST (bf16 operands, no padding mask): NO running maximum.  The reference m of a query is fixed once, from its scores
+//     against the first 32 keys (a pre-pass of four MFMAs), and p = v_exp_f32(fma(s, scale*log2e, -m)) -- one fma and the raw
+//     transcendental per score, 8 v_cvt_pk for the operand, nothing else: no max chain, no exchange between the lane halves, no
+//     rescale of O, no branch.  A bf16 P (like the fp32 sums) keeps its relative precision at ANY magnitude, so an m that is
+//     stale by up to 2^96 costs no accuracy; the key that set m contributes P = 1, so the sum cannot underflow.  Only a score
+//     more than 96 log2-units (66 nats) above every score of the first tile overflows: then the row sum comes out >= 2^96 / non-
+//     finite, the block votes, and ALL its waves redo the column with the TRACKED loop.  tests/test_gpu_attn16.py forces that.
+//   TRACKED (fp16 operands -- P must stay below 2^16 --, padding masks, and the fallback): the classic online softmax in its
+//     cheapest form: v_maximum3_f32 chain on the raw scores (scale > 0), halves exchanged by v_permlane32_swap, log2 domain.
+//   Both: the row sums l of plain bf16 come from the MATRIX pipe, which has slack there -- one extra MFMA per k-step with an
+//     all-ones A operand (L^T += 1 P^T: every accumulator register of a lane is its query's sum, of exactly the rounded P that
+//     enters O; no exchange between the halves at the end) instead of 16 v_add_f32 per tile; QB = 2 (plain bf16, R > 128): a
+//     wave owns two 32-query blocks, so every K / V fragment read from LDS feeds two blocks (half the LDS reads, barriers and
+//     DMA requests per flop) and one block's softmax can issue under the other's MFMAs.
+// K / V chunks ride a three-deep LDS ring two chunks ahead of the compute (counted vmcnt).  The V^T reads are inline asm
+// (tile16.h: tr16_issue): behind the builtin hipcc drains every LDS-DMA in flight, which had made the round-3 ring synchronous.
+// The context leaves through LDS as whole 128-byte rows (16-byte stores, 8 lanes per row) instead of 8-byte pieces at a row stride.
+#include <type_traits>
+
 #include "tile16.h"
 
 namespace rnamsm {
 
 constexpr int C16_THREADS = 256;
-constexpr int C16_ROWS = 128;                  // query rows per block (4 waves x 32)
+constexpr int C16_NST = 3;                       // LDS ring depth (chunks)
+constexpr float C16_LOG2E = 1.4426950408889634f;
+constexpr float C16_OVERFLOW = 7.9228163e28f;    // 2^96: a FAST row sum at or above it (or not finite) sends the block to the TRACKED loop
+
+// maximum over the two lanes (l, l ^ 32) that share a query.  v_permlane32_swap as asm: this hipcc folds element 1 of
+// __builtin_amdgcn_permlane32_swap's result to element 0 (the IR keeps `extractvalue 0` only), which silently turned the
+// exchange into a copy; the s_nop covers the VALU-write -> permlane-read hazard hipcc does not pad inside an asm body.
+__device__ __forceinline__ float half_pair_max(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));      // a = {lo, lo}, b = {hi, hi}
+    return __builtin_elementwise_maximum(a, b);
+}
+// v_maximum3_f32 chain (NaN-propagating; no canonicalising v_max x, x in front of MFMA outputs as fmaxf gets)
+__device__ __forceinline__ float max16(const f32x16& s) {
+    float mx = s[0];
+#pragma unroll
+    for (int t = 1; t < 16; ++t) mx = __builtin_elementwise_maximum(mx, s[t]);
+    return mx;
+}
+
+template <int SPLIT, int QB>
+struct C16Cfg {
+    static constexpr int NPL = SPLIT == 3 ? 2 : 1;
+    static constexpr int JC = SPLIT == 3 ? 32 : 64;                 // keys per chunk
+    static constexpr int TILE = JC * T16_ROWB;                      // bytes per plane tile
+    static constexpr int BUF = 2 * NPL * TILE;                      // K planes then V planes
+    static constexpr int ROWS = 128 * QB;                           // query rows per block
+    static constexpr int EPI = 4 * 9216;                            // epilogue staging: 32 rows x 272 B (fp32) / 2 planes x 32 x 144 B per wave
+    static constexpr int RING = C16_NST * BUF > EPI ? C16_NST * BUF : EPI;
+    static constexpr int LDS = RING + 16;                           // + the four waves' overflow flags
+    static constexpr int NDMA = (JC / 32) * NPL * 2;                // LDS-DMA requests per wave per chunk
+};
+
+// MASKED: f2 padding mask (scores of padded keys of this column become -10000 after scaling, modules.py:911-915); the
+// un-masked instances carry no mask code.  FAST: see the header (requires bf16 operands and no mask).
+template <int SPLIT, int FMT, int OUT, int QB, bool MASKED, bool FAST>
+__global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
+    const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
+    const uint16_t* __restrict__ klo, const uint16_t* __restrict__ vhi, const uint16_t* __restrict__ vlo, int64_t ld,
+    float* __restrict__ ctx, int64_t ldc, int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo,
+    float scale, const uint8_t* __restrict__ pad_mask, int64_t qkv_bstride, int64_t ctx_bstride, int64_t mask_bstride,
+    int force_tracked) {
+    static_assert(!FAST || (FMT == 0 && !MASKED), "the FAST loop needs bf16's exponent range and no -10000 scores");
+    using Cfg = C16Cfg<SPLIT, QB>;
+    constexpr int NPL = Cfg::NPL, JC = Cfg::JC, TILE = Cfg::TILE, BUF = Cfg::BUF;
+    constexpr bool ONES = SPLIT == 1;             // row sums on the matrix pipe (plain bf16: it has slack; the hi/lo modes are MFMA-bound)
+    // TRACKED loop: P is kept as 2^12 exp(s - m) so that the fp16 lo plane of every P that matters stays normal
+    constexpr float SHIFT = FMT == 1 ? 12.f : 0.f;
+    // batched launch (rnamsm_forward_batch, 16-bit modes): MSA blockIdx.y
+    qhi += blockIdx.y * qkv_bstride; khi += blockIdx.y * qkv_bstride; vhi += blockIdx.y * qkv_bstride;
+    if (qlo) { qlo += blockIdx.y * qkv_bstride; klo += blockIdx.y * qkv_bstride; vlo += blockIdx.y * qkv_bstride; }
+    if (ctx) ctx += blockIdx.y * ctx_bstride;
+    if (ctx_hi) ctx_hi += blockIdx.y * ctx_bstride;
+    if (ctx_lo) ctx_lo += blockIdx.y * ctx_bstride;
+    if (MASKED) pad_mask += blockIdx.y * mask_bstride;
+    typedef typename Half16<FMT>::T Hh;
+    typedef typename Half16<FMT>::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+
+    const unsigned iblocks = (R + Cfg::ROWS - 1) / Cfg::ROWS;
+    unsigned prob, ib;
+    if (!xcd_panel_map(blockIdx.x, (unsigned)C * H, iblocks, prob, ib)) return;
+    const int c = prob / H, h = prob % H;
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int irow0 = ib * Cfg::ROWS + wave * 32 * QB;         // this wave's queries: irow0 + 32 qb + li
+    const bool active = irow0 < R;                             // wave-uniform
+    const int64_t col_off = (int64_t)c * ld + h * 64;          // + r*C*ld selects the alignment row
+
+    const uint16_t* qpl[2] = {qhi, qlo};
+    const uint16_t* kpl[2] = {khi, klo};
+    const uint16_t* vpl[2] = {vhi, vlo};
+
+    // Q fragments (B operand of S^T = K Q^T): lane (query i, half) holds q[i][16kk + 8*half + 0..7]; rows past R are clamped
+    // (computed, never stored)
+    V8 qf[QB][4][NPL];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = min(irow0 + 32 * qb + li, R - 1);
+        const int64_t qo = (int64_t)qi * C * ld + col_off + 8 * lh;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) qf[qb][kk][p] = *reinterpret_cast<const V8*>(qpl[p] + qo + 16 * kk);
+    }
+
+    // DMA map: a plane tile is JC / 8 groups of 8 key rows; wave w moves groups w and w+4.  Keys past R are clamped to the
+    // last key: their scores are masked to -inf and their V values only meet P = 0.
+    const int drow = lane >> 3;
+    const int ck = dma_chunk_k(lane, wave), ct = dma_chunk_t(lane);
+    auto issue = [&](int ch, int buf) {
+        char* base = smem_b + buf * BUF;
+#pragma unroll
+        for (int j = 0; j < JC / 32; ++j) {
+            const int row = 8 * (wave + 4 * j) + drow;
+            const int64_t ko = (int64_t)min(ch * JC + row, R - 1) * C * ld + col_off;
+            const int loff = (8 * (wave + 4 * j)) * T16_ROWB;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                dma16(kpl[p] + ko + ck * 8, base + p * TILE + loff);
+                dma16(vpl[p] + ko + ct * 8, base + (NPL + p) * TILE + loff);
+            }
+        }
+    };
+
+    f32x16 o0[QB], o1[QB], la[QB];       // O^T tiles: head dims [0,32) and [32,64) x 32 query rows; la: the row sums (ONES)
+    float m_run[QB], l_run[QB];          // log2 units (score * scale * log2e); FAST: m_run is the fixed reference
+    V8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (Hh)1.0f;
+
+    const float c2 = scale * C16_LOG2E;                      // raw score -> log2 units
+    const float zmask = -10000.f / scale;                    // a masked score in raw units (-10000 after scaling)
+    const int tq = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);    // transposed-read geometry
+
+    // one 32-key tile.  RAG (compile-time): the ragged last tile, whose keys >= R are masked out.  TRK: TRACKED arithmetic.
+    auto tile = [&](const char* Kc, const char* Vc, int jt, int jbase, auto rag_tag, auto trk_tag) {
+        constexpr bool RAG = decltype(rag_tag)::value, TRK = decltype(trk_tag)::value;
+        V8 kf[4][NPL];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) kf[kk][p] = frag_k<FMT>(Kc + p * TILE, jt * 32 + li, kk, lh);
+        // V^T fragments of this tile, requested now (asm: tile16.h) and waited for after the softmax
+        TrPieces vp[2][2][NPL];          // [d tile][k step][plane]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ra = jt * 32 + 16 * ks + 4 * lh + tq;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) vp[dt][ks][p] = tr16_issue(Vc + p * TILE, ra, ra + 8, dt * 32 + tcol);
+        }
+        // ---- S^T = K Q^T: 32 keys x 32 queries per block, k = 64 head dims
+        f32x16 s[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s[qb][t] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) s[qb] = mma16<SPLIT, FMT>(kf[kk], qf[qb][kk], s[qb]);
+        }
+        unsigned mbits = 0;              // MASKED: bit t = key of accumulator register t is padded in this column
+        if (MASKED) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int j = jbase + (t & 3) + 8 * (t >> 2) + 4 * lh;
+                if (j < R && pad_mask[(int64_t)j * C + c]) mbits |= 1u << t;
+            }
+        }
+        V8 pf[QB][2][NPL];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (RAG) {
+                const int limit = R - jbase;
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    if ((t & 3) + 8 * (t >> 2) + 4 * lh >= limit) s[qb][t] = -INFINITY;
+            }
+            if (MASKED) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    if ((mbits >> t) & 1u) s[qb][t] = zmask;
+            }
+            float nm;
+            if (TRK) {
+                // online softmax: tile maximum on the raw scores (scale > 0), both halves of the query; finite: key jbase is valid
+                const float m_new = __builtin_elementwise_maximum(m_run[qb], half_pair_max(max16(s[qb])) * c2);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);     // 0 on the first tile
+                m_run[qb] = m_new;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) { o0[qb][t] *= alpha; o1[qb][t] *= alpha; }
+                if (ONES) {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) la[qb][t] *= alpha;
+                } else {
+                    l_run[qb] *= alpha;
+                }
+                nm = SHIFT - m_new;
+            } else {
+                nm = -m_run[qb];
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                s[qb][t] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][t], c2, nm));
+                if (!ONES) psum += s[qb][t];
+            }
+            if (!ONES) l_run[qb] += psum;
+            // ---- P fragments: registers 8ks..8ks+7 -> halves (hi, and lo = P - hi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = s[qb][8 * ks + e];
+                    const Hh hi = (Hh)pv;
+                    pf[qb][ks][0][e] = hi;
+                    if (SPLIT == 3) pf[qb][ks][NPL - 1][e] = (Hh)(pv - (float)hi);
+                }
+        }
+        // ---- O^T += V^T P^T (and L^T += 1 P^T)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) tr16_wait4(vp[0][0][p], vp[0][1][p], vp[1][0][p], vp[1][1][p]);
+        V8 vf[2][2][NPL];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) vf[dt][ks][p] = tr16_frag<FMT>(vp[dt][ks][p]);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                o0[qb] = mma16<SPLIT, FMT>(vf[0][ks], pf[qb][ks], o0[qb]);
+                o1[qb] = mma16<SPLIT, FMT>(vf[1][ks], pf[qb][ks], o1[qb]);
+                if (ONES) la[qb] = Half16<FMT>::mfma(ones, pf[qb][ks][0], la[qb]);
+            }
+    };
+    typedef std::integral_constant<bool, false> no_t;
+    typedef std::integral_constant<bool, true> yes_t;
+
+    // FAST pre-pass: the reference of every query = its largest score against the first min(32, R) keys
+    auto reference_from_first_tile = [&](const char* Kc) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            f32x16 s;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s[t] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                V8 kf[NPL];
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) kf[p] = frag_k<FMT>(Kc + p * TILE, li, kk, lh);
+                s = mma16<SPLIT, FMT>(kf, qf[qb][kk], s);
+            }
+            if (R < 32) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    if ((t & 3) + 8 * (t >> 2) + 4 * lh >= R) s[t] = -INFINITY;
+            }
+            m_run[qb] = half_pair_max(max16(s)) * c2;
+        }
+    };
+
+    // The whole key loop: three-deep ring, two chunks ahead.  The request of a chunk past the end is clamped to the last chunk
+    // (a redundant reload into a free slot, never read) so that every wave has exactly NDMA requests per iteration in flight
+    // behind the awaited one.
+    auto run = [&](auto trk_tag) {
+        constexpr bool TRK = decltype(trk_tag)::value;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { o0[qb][t] = 0.f; o1[qb][t] = 0.f; la[qb][t] = 0.f; }
+            m_run[qb] = -INFINITY;
+            l_run[qb] = 0.f;
+        }
+        const int nch = (R + JC - 1) / JC, nfull = R / JC;
+        issue(0, 0);
+        issue(min(1, nch - 1), 1);
+        if (!TRK) {
+            wait_dma_then_barrier<Cfg::NDMA>();      // chunk 0 has landed
+            reference_from_first_tile(smem_b);
+        }
+        // Full chunks: a straight-line body.  (Any branch around the tiles -- an `if (active)`, a ragged variant -- makes hipcc
+        // merge the 512-bit accumulator tuples of its paths through copies: 48 v_mov per iteration.  A wave whose queries all
+        // lie past R therefore computes on clamped rows and stores nothing.)
+        int slot = 0;                        // ring slot of chunk ch
+        for (int ch = 0; ch < nfull; ++ch) {
+            wait_dma_then_barrier<Cfg::NDMA>();      // chunk ch has landed (every wave's share); everyone is done with chunk ch - 1
+            issue(min(ch + 2, nch - 1), slot == 0 ? 2 : slot - 1);
+            const char* Kc = smem_b + slot * BUF;
+            const char* Vc = Kc + NPL * TILE;
+            tile(Kc, Vc, 0, ch * JC, no_t(), trk_tag);
+            if (JC == 64) {
+                __builtin_amdgcn_sched_barrier(0);
+                tile(Kc, Vc, 1, ch * JC + 32, no_t(), trk_tag);
+            }
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+        if (nfull < nch) {                   // the partial last chunk: 1 .. JC - 1 keys
+            wait_dma_then_barrier<Cfg::NDMA>();
+            issue(nch - 1, slot == 0 ? 2 : slot - 1);
+            const char* Kc = smem_b + slot * BUF;
+            const char* Vc = Kc + NPL * TILE;
+            const int jbase = nfull * JC, rem = R - jbase;
+            if (JC == 64 && rem >= 32) {
+                tile(Kc, Vc, 0, jbase, no_t(), trk_tag);
+                if (rem > 32) tile(Kc, Vc, 1, jbase + 32, yes_t(), trk_tag);
+            } else {
+                tile(Kc, Vc, 0, jbase, yes_t(), trk_tag);
+            }
+        }
+        wait_dma_then_barrier<0>();          // the redundant reloads have landed, every wave is done with the ring
+    };
+    auto row_sum = [&](int qb) -> float {
+        if (ONES) return la[qb][0];
+        return l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    };
+
+    // (the context store is a lambda called on each path's own exit: merging the two loops' accumulators at a common epilogue
+    // would cost a second copy of all of them in registers)
+    auto store_context = [&]() {
+        if (!active) return;
+        // wave-private staging: [32 queries][64 d] as 16-bit rows of 144 B (hi, then lo) or fp32 rows of 272 B
+        char* stg = smem_b + wave * 9216;
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const float inv = 1.f / row_sum(qb);
+            if (qb) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the previous block's staging has been read
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {      // registers 4g..4g+3 are head dims 8g + 4*half + {0..3}
+                const f32x4 a = f32x4{o0[qb][4 * g] * inv, o0[qb][4 * g + 1] * inv, o0[qb][4 * g + 2] * inv, o0[qb][4 * g + 3] * inv};
+                const f32x4 b = f32x4{o1[qb][4 * g] * inv, o1[qb][4 * g + 1] * inv, o1[qb][4 * g + 2] * inv, o1[qb][4 * g + 3] * inv};
+                const int d = 8 * g + 4 * lh;
+                if (OUT == 0) {
+                    *reinterpret_cast<f32x4*>(stg + li * 272 + d * 4) = a;
+                    *reinterpret_cast<f32x4*>(stg + li * 272 + (32 + d) * 4) = b;
+                } else {
+                    typedef typename Half16<(OUT > 0 ? OUT - 1 : 0)>::T Ho;
+                    typedef Ho H4 __attribute__((ext_vector_type(4)));
+                    H4 ah, al, bh, bl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ah[e] = (Ho)a[e]; al[e] = (Ho)(a[e] - (float)ah[e]);
+                        bh[e] = (Ho)b[e]; bl[e] = (Ho)(b[e] - (float)bh[e]);
+                    }
+                    *reinterpret_cast<H4*>(stg + li * 144 + d * 2) = ah;
+                    *reinterpret_cast<H4*>(stg + li * 144 + (32 + d) * 2) = bh;
+                    if (SPLIT == 3) {
+                        *reinterpret_cast<H4*>(stg + 4608 + li * 144 + d * 2) = al;
+                        *reinterpret_cast<H4*>(stg + 4608 + li * 144 + (32 + d) * 2) = bl;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // wave-private: the wave's own writes are visible to its reads
+            const int i0 = irow0 + 32 * qb;
+            if (OUT == 0) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {       // 4 rows x 256 B per instruction
+                    const int row = 4 * it + (lane >> 4), chunk = lane & 15;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 272 + chunk * 16);
+                    if (i0 + row < R) *reinterpret_cast<f32x4*>(ctx + ((int64_t)(i0 + row) * C + c) * ldc + h * 64 + chunk * 4) = v;
+                }
+            } else {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {       // 8 rows x 128 B per instruction
+                    const int row = 8 * it + (lane >> 3), chunk = lane & 7;
+                    const int64_t ooff = ((int64_t)(i0 + row) * C + c) * ldc + h * 64 + chunk * 8;
+                    const u32x4 vh = *reinterpret_cast<const u32x4*>(stg + row * 144 + chunk * 16);
+                    if (i0 + row < R) *reinterpret_cast<u32x4*>(ctx_hi + ooff) = vh;
+                    if (SPLIT == 3) {
+                        const u32x4 vl = *reinterpret_cast<const u32x4*>(stg + 4608 + row * 144 + chunk * 16);
+                        if (i0 + row < R && ctx_lo) *reinterpret_cast<u32x4*>(ctx_lo + ooff) = vl;
+                    }
+                }
+            }
+        }
+    };
+
+    if (FAST && !force_tracked) {
+        run(no_t());
+        // a row sum that reached 2^96 (or is not finite): some score lay > 96 log2 units above the query's first-tile scores.
+        // The block's waves share the ring, so they vote and redo the column together.
+        bool bad = false;
+        if (active) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) bad = bad || !(row_sum(qb) < C16_OVERFLOW);
+        }
+        int* flags = reinterpret_cast<int*>(smem_b + Cfg::RING);
+        const int wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+        if (lane == 0) flags[wave] = wave_bad;
+        wait_dma_then_barrier<0>();
+        const int any_bad = flags[0] | flags[1] | flags[2] | flags[3];       // block-uniform
+        if (!any_bad) {
+            store_context();
+            return;
+        }
+        wait_dma_then_barrier<0>();          // every wave has read the flags before the ring is refilled
+    }
+    run(yes_t());
+    store_context();
+}
+
+// ---- the round-3 kernel, kept for A/B during round 4 (knob "attn16" = 3) -------------------------------------------------
+constexpr int C16R3_ROWS = 128;                  // query rows per block (4 waves x 32)
 // keys per chunk JC: 64 (two 32-key tiles per barrier) for plain bf16, 32 for the hi/lo modes -- their four planes per
 // chunk would otherwise cost 64 KB of LDS per block and cap the CU at two blocks; at 32 KB three fit (the registers'
 // limit), and this kernel lives on occupancy: one problem's loop is shorter than the fixed cost around it (strided q
@@ -27,7 +435,7 @@ constexpr int C16_ROWS = 128;                  // query rows per block (4 waves 
 // MASKED: f2 padding mask (scores of padded keys of this column become -10000 after scaling, modules.py:911-915); the
 // un-masked instances carry no mask code.
 template <int SPLIT, int FMT, int OUT, int JC, bool MASKED>
-__global__ __launch_bounds__(C16_THREADS, JC == 32 ? 3 : 2) void col_attn16_kernel(
+__global__ __launch_bounds__(C16_THREADS, JC == 32 ? 3 : 2) void col_attn16_r3_kernel(
     const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
     const uint16_t* __restrict__ klo, const uint16_t* __restrict__ vhi, const uint16_t* __restrict__ vlo, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo,
@@ -47,14 +455,14 @@ __global__ __launch_bounds__(C16_THREADS, JC == 32 ? 3 : 2) void col_attn16_kern
     typedef typename Half16<FMT>::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
 
-    const unsigned iblocks = (R + C16_ROWS - 1) / C16_ROWS;
+    const unsigned iblocks = (R + C16R3_ROWS - 1) / C16R3_ROWS;
     unsigned prob, ib;
     if (!xcd_panel_map(blockIdx.x, (unsigned)C * H, iblocks, prob, ib)) return;
     const int c = prob / H, h = prob % H;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int irow0 = ib * C16_ROWS + wave * 32;
+    const int irow0 = ib * C16R3_ROWS + wave * 32;
     const bool active = irow0 < R;                             // wave-uniform
     const int64_t col_off = (int64_t)c * ld + h * 64;          // + r*C*ld selects the alignment row
 
@@ -223,12 +631,29 @@ __global__ __launch_bounds__(C16_THREADS, JC == 32 ? 3 : 2) void col_attn16_kern
         }
     }
 }
-
 }  // namespace rnamsm
 
 using namespace rnamsm;
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int SP, int FMT, int OUT, int QB, bool MASK, bool FAST>
+static int col16_go(unsigned grid, int batch, hipStream_t s, const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi,
+                    const uint16_t* k_lo, const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C,
+                    int H, uint16_t* ctx_hi, uint16_t* ctx_lo, float scale, const uint8_t* pad_mask, int64_t qkv_bstride,
+                    int64_t ctx_bstride, int64_t mask_bstride, int force_tracked) {
+    static DeviceOnce cfg;
+    auto kern = col_attn16_kernel<SP, FMT, OUT, QB, MASK, FAST>;
+    constexpr int lds = C16Cfg<SP, QB>::LDS;
+    if (cfg.pending()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        cfg.mark();
+    }
+    hipLaunchKernelGGL(kern, dim3(grid, batch), dim3(C16_THREADS), lds, s, q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H,
+                       ctx_hi, ctx_lo, scale, pad_mask, qkv_bstride, ctx_bstride, mask_bstride, force_tracked);
+    return RNAMSM_OK;
+}
 
 static int col_attn16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
                              const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
@@ -241,44 +666,80 @@ static int col_attn16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const u
     RNAMSM_CHECK_ARG(!ctx_hi || (ctx_lo == nullptr) == (q_lo == nullptr), "col_attn16: ctx_lo must match the operand split");
     RNAMSM_CHECK_ARG(head_dim == 64, "col_attn16: head_dim must be 64 (got %d)", head_dim);
     RNAMSM_CHECK_ARG(R > 0 && R <= 1024 && C > 0 && H > 0, "col_attn16: bad shape R=%d C=%d H=%d", R, C, H);
+    RNAMSM_CHECK_ARG(scale > 0.f && scale < 1e30f, "col_attn16: scale must be positive and finite");
     RNAMSM_CHECK_ARG(fmt == 0 || (fmt == 1 && q_lo), "col_attn16: fmt must be 0 (bf16) or 1 (fp16, hi/lo only)");
     RNAMSM_CHECK_ARG(ld >= (int64_t)H * 64 && ld % 8 == 0 && al16(q_hi) && al16(k_hi) && al16(v_hi) && al16(q_lo) && al16(k_lo) && al16(v_lo),
                      "col_attn16: planes must be 16-byte aligned with ld %% 8 == 0");
-    RNAMSM_CHECK_ARG(ldc >= (int64_t)H * 64 && ldc % 4 == 0 && (ctx_hi ? (reinterpret_cast<uintptr_t>(ctx_hi) & 7u) == 0 : al16(ctx)),
-                     "col_attn16: output alignment");
+    RNAMSM_CHECK_ARG(ldc >= (int64_t)H * 64 && (ctx_hi ? ldc % 8 == 0 && ctx_bstride % 8 == 0 && al16(ctx_hi) && al16(ctx_lo) : ldc % 4 == 0 && al16(ctx)),
+                     "col_attn16: the context must be 16-byte aligned (ldc %% 8 == 0 for planes, %% 4 for fp32)");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const unsigned iblocks = (R + C16_ROWS - 1) / C16_ROWS;
-    const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
     const int npl = q_lo ? 2 : 1;
-    const int jc = q_lo ? 32 : 64;
-    const int lds = 2 * 2 * npl * jc * T16_ROWB;
+    const int var = tuning().attn16;
+    // vector-ALU instructions per score (a transcendental counts 4): FAST 1 fma + exp + 1/2 cvt_pk = 5.5; TRACKED adds the maximum
+    // (v_maximum3: 1/2) and the rescale of O and l (2-3); the hi/lo modes the lo half of P (sub + 1/2 cvt) and the row sum (1);
+    // the round-3 kernel ("attn16" = 3): mul, sub, mul + exp, add, max, 1/2 cvt, 2 rescale = 11.5
+    const bool fast_loop = fmt == 0 && !pad_mask && var != 5 && var != 3;
+    const double per_score = var == 3 ? 11.5 + (q_lo ? 1.5 : 0.0) : 5.5 + (fast_loop ? 0.0 : (q_lo ? 2.5 : 3.5)) + (q_lo ? 2.5 : 0.0);
+    // matrix flops executed: the row sums of plain bf16 ride the matrix pipe (one all-ones MFMA per k-step: + 1/8)
     KernelTimer timer(TC_COL_ATTN, 4.0 * batch * C * H * (double)R * R * 64, batch * (2.0 * npl * 3.0 + (ctx_hi ? 2.0 * npl : 4.0)) * R * C * H * 64, s,
-                      PEAK_F16_MFMA_TFLOPS, q_lo ? 3.0 : 1.0);
-#define CA_GO(SP_, FMT_, OUT_)                                                                                      \
+                      PEAK_F16_MFMA_TFLOPS, q_lo ? 3.0 : (var == 3 ? 1.0 : 1.125), per_score * batch * C * H * (double)R * R);
+    if (var == 3) {
+        const unsigned iblocks = (R + C16R3_ROWS - 1) / C16R3_ROWS;
+        const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
+        const int jc = q_lo ? 32 : 64;
+        const int lds = 2 * 2 * npl * jc * T16_ROWB;
+#define CA3_GO(SP_, FMT_, OUT_)                                                                                      \
     do {                                                                                                            \
-        if (pad_mask) CA_GO2(SP_, FMT_, OUT_, true); else CA_GO2(SP_, FMT_, OUT_, false);                           \
+        if (pad_mask) CA3_GO2(SP_, FMT_, OUT_, true); else CA3_GO2(SP_, FMT_, OUT_, false);                           \
     } while (0)
-#define CA_GO2(SP_, FMT_, OUT_, MASK_)                                                                              \
+#define CA3_GO2(SP_, FMT_, OUT_, MASK_)                                                                              \
     do {                                                                                                            \
         static DeviceOnce cfg_;                                                                                   \
         if (cfg_.pending()) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn16_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64), MASK_>),   \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn16_r3_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64), MASK_>),   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);                    \
             if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn16: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
             cfg_.mark();                                                                                            \
         }                                                                                                           \
-        hipLaunchKernelGGL((col_attn16_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64), MASK_>), dim3(grid, batch), dim3(C16_THREADS), lds, s, q_hi, q_lo, k_hi, \
+        hipLaunchKernelGGL((col_attn16_r3_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64), MASK_>), dim3(grid, batch), dim3(C16_THREADS), lds, s, q_hi, q_lo, k_hi, \
                            k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, scale, pad_mask, qkv_bstride, ctx_bstride, mask_bstride); \
     } while (0)
+        if (!q_lo) {
+            if (ctx_hi) CA3_GO(1, 0, 1); else CA3_GO(1, 0, 0);
+        } else if (fmt == 0) {
+            if (ctx_hi) CA3_GO(3, 0, 1); else CA3_GO(3, 0, 0);
+        } else {
+            if (ctx_hi) CA3_GO(3, 1, 2); else CA3_GO(3, 1, 0);
+        }
+#undef CA3_GO
+#undef CA3_GO2
+        RNAMSM_CHECK_LAUNCH("col_attn16");
+        return RNAMSM_OK;
+    }
+    // two query blocks per wave (256-query blocks) for plain bf16 without a mask when that adds no idle query rows; bf16
+    // operands without a mask take the FAST loop ("attn16" = 4: one query block per wave, 5: TRACKED loop only; A/B and tests)
+    const bool qb2 = !q_lo && !pad_mask && var != 4 && (R + 255) / 256 * 256 <= (R + 127) / 128 * 128;
+    const int force_tracked = var == 5;
+    const unsigned iblocks = qb2 ? (R + 255) / 256 : (R + 127) / 128;
+    const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
+    int rc;
+#define CA_ARGS grid, batch, s, q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, scale, pad_mask, qkv_bstride, ctx_bstride, mask_bstride, force_tracked
+#define CA_GO(SP_, FMT_, OUT_, QB_)                                                                                   \
+    do {                                                                                                              \
+        if (pad_mask) rc = col16_go<SP_, FMT_, OUT_, QB_, true, false>(CA_ARGS);                                      \
+        else rc = col16_go<SP_, FMT_, OUT_, QB_, false, FMT_ == 0>(CA_ARGS);                                          \
+    } while (0)
     if (!q_lo) {
-        if (ctx_hi) CA_GO(1, 0, 1); else CA_GO(1, 0, 0);
+        if (qb2) { if (ctx_hi) CA_GO(1, 0, 1, 2); else CA_GO(1, 0, 0, 2); }
+        else { if (ctx_hi) CA_GO(1, 0, 1, 1); else CA_GO(1, 0, 0, 1); }
     } else if (fmt == 0) {
-        if (ctx_hi) CA_GO(3, 0, 1); else CA_GO(3, 0, 0);
+        if (ctx_hi) CA_GO(3, 0, 1, 1); else CA_GO(3, 0, 0, 1);
     } else {
-        if (ctx_hi) CA_GO(3, 1, 2); else CA_GO(3, 1, 0);
+        if (ctx_hi) CA_GO(3, 1, 2, 1); else CA_GO(3, 1, 0, 1);
     }
 #undef CA_GO
-#undef CA_GO2
+#undef CA_ARGS
+    if (rc) return rc;
     RNAMSM_CHECK_LAUNCH("col_attn16");
     return RNAMSM_OK;
 }

@@ -37,18 +37,25 @@ enum TimingCategory {
 constexpr double PEAK_F32_MFMA_TFLOPS = 157.3;     // v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
 constexpr double PEAK_F16_MFMA_TFLOPS = 2500.0;    // dense bf16 / f16 MFMA
 constexpr double PEAK_HBM_TBPS = 6.3;              // measured float4 copy (8 TB/s spec)
+// Vector ALU: a wave64 instruction occupies its SIMD for 2 cycles (32 lanes per clock), a transcendental (v_exp_f32, v_rcp_f32)
+// for four times that; 1024 SIMDs x 32 lanes x 2.4 GHz lane-operations per second.  The softmax of the fused attention
+// kernels is priced with it: `valu_lane_ops` of a launch = scores x (plain instructions + 4 x transcendentals per score).
+constexpr double PEAK_VALU_LANE_OPS = 1024.0 * 32.0 * 2.4e9;
 bool timing_enabled();
-void timing_begin(int category, double flops, double bytes, double mfma_s, double hbm_s, hipStream_t stream);
+void timing_begin(int category, double flops, double bytes, double mfma_s, double hbm_s, double valu_s, hipStream_t stream);
 void timing_end(hipStream_t stream);
 struct KernelTimer {   // brackets one launch with two hipEventRecord calls when timing is on
     hipStream_t s;
     bool on;
     // flops / bytes: ALGORITHMIC work of the launch; peak_tflops: matrix peak of its MFMA family; flop_mult: executed MFMA
     // flops per algorithmic flop (3 in the hi/lo-split modes)
+    // valu_lane_ops: vector-ALU work of the launch in lane-operations (0 = not priced), see PEAK_VALU_LANE_OPS
     KernelTimer(int category, double flops, double bytes, hipStream_t stream, double peak_tflops = PEAK_F32_MFMA_TFLOPS,
-                double flop_mult = 1.0)
+                double flop_mult = 1.0, double valu_lane_ops = 0.0)
         : s(stream), on(timing_enabled()) {
-        if (on) timing_begin(category, flops, bytes, flop_mult * flops / (peak_tflops * 1e12), bytes / (PEAK_HBM_TBPS * 1e12), s);
+        if (on)
+            timing_begin(category, flops, bytes, flop_mult * flops / (peak_tflops * 1e12), bytes / (PEAK_HBM_TBPS * 1e12),
+                         valu_lane_ops / PEAK_VALU_LANE_OPS, s);
     }
     ~KernelTimer() {
         if (on) timing_end(s);
@@ -57,12 +64,10 @@ struct KernelTimer {   // brackets one launch with two hipEventRecord calls when
 
 // ---- tuning knobs (api.hip) -------------------------------------------------------------------------
 struct Tuning {
-    int gemm16_dma = 3;            // plane-input 16-bit GEMMs: 0 register staging, 1 LDS-DMA 128x128, 2 LDS-DMA 256x256,
+    int gemm16_dma = 3;            // plane-input 16-bit GEMMs: 0 register staging, 1 / 2 LDS-DMA 128x128,
                                    // 3 = LDS-DMA 256x256 with software-pipelined fragments, BK = 64 for split 1 (default),
                                    // 4 = the same with BK = 32 for every split
-    int gemm16_mfma16 = 1;         // plain-bf16 256x256 GEMM: 1 = v_mfma_f32_16x16x32_bf16 (gemm16_q16_kernel) for wide N, 2 = always, 0 = 32x32x16
-    int gemm16_pp = 0;             // plain-bf16 plane GEMMs: 1 = gemm16_pp_kernel (4 waves x 512 registers, two accumulator sets: the epilogue of
-                                   // tile t leaves under the K loop of tile t+1; gemm16_pp.hip -- bit-identical, measured 0.61-0.83x: off), 0 = the 256x256 kernels below
+    int gemm16_mfma16 = 1;         // plain-bf16 256x256 GEMM: 1 = v_mfma_f32_16x16x32_bf16 (gemm16_q16s_kernel) for wide N, 2 = always, 0 = 32x32x16
     int gemm16_persist = 256;      // 256x256 16-bit GEMM: > 0 = that many persistent blocks walk the tiles (256 = one per CU; +1-5%, tools/gemm16_persist_ab.py), 0 = one block per tile
     int gemm16_stagger = 0;        // ... and block b starts (b/8 % 4) x this many cycles late (spreads the store bursts)
     int gemm16_dephase = 2;        // 256x256 16-bit GEMMs, who issues the LDS-DMA requests when: 0 = every wave right after the tile barrier;
@@ -78,6 +83,7 @@ struct Tuning {
     int col_small = 1;             // fp32 col_attn at R <= 16: 1 = one wave per (column, head), no LDS (col_attn_small_kernel), 0 = the 128-query blocks
     int col_dma = -1;              // fp32 col_attn: 1 = LDS-DMA staging, 32-key chunks, 3 blocks/CU; 0 = register-staged kernel; -1 = by shape
     int row16_bk64 = 1;            // plain bf16 at C >= 256: 1 = row_apply16x on 64-key tiles, 2 = row_logits16 on the 256x256 kernel with 64-deep tiles too, 0 = neither
+    int row16_q16 = 1;             // plain bf16 at C >= 384, C % 8 == 0: 1 = row_logits16q_kernel (16x16x32 MFMA, staged by operand), 0 = the 128x128 kernel
     int row16_max_rows = 32;       // hi/lo modes: cap on the rows of one row_logits16 slab (0 = none): accuracy, DESIGN 3.2
     int ln_fold = 1;               // rnamsm_forward with ln_folded: 1 = LayerNorm applied inside the consuming GEMM (row sums from the producers'
                                    // epilogues) when R*C >= 18432, 3 = for every shape, 2 = every GEMM sums its rows itself (A/B), 0 = separate launches
@@ -90,14 +96,24 @@ Tuning& tuning();
 // process (tools/mid_size_tile_ab.py): 2048 tokens x1.33 (bf16) / x1.59 (f16x3), 4096 x1.14 / x1.32, 8192 x1.11 / x1.10, level at
 // 10 k (bf16) / 9 k (f16x3), 256x256 ahead from there (x0.92 at 12 k, x0.81-0.88 at 60 k).  The hi/lo modes' two kernels sum
 // every output element in the same order: bit-identical either way.
+// The choice is handed down as a THREAD-LOCAL override read by rnamsm_gemm_bf16 (gemm16_big_rows_now): the process-wide knob is
+// never written by a forward, so concurrent forwards from several threads / devices cannot leak their temporary threshold
+// into each other or into later direct rnamsm_gemm_bf16 calls.
+int& gemm16_big_rows_override();                 // api.hip: thread_local, 0 = none
 struct BigRowsScope {
     int saved;
-    explicit BigRowsScope(bool plain_bf16) : saved(tuning().gemm16_big_rows) {
+    explicit BigRowsScope(bool plain_bf16) : saved(gemm16_big_rows_override()) {
         const int fwd = tuning().gemm16_big_rows_fwd;
-        if (saved == 0) tuning().gemm16_big_rows = fwd > 0 ? fwd : (plain_bf16 ? 10752 : 8960);
+        if (tuning().gemm16_big_rows == 0) gemm16_big_rows_override() = fwd > 0 ? fwd : (plain_bf16 ? 10752 : 8960);
     }
-    ~BigRowsScope() { tuning().gemm16_big_rows = saved; }
+    ~BigRowsScope() { gemm16_big_rows_override() = saved; }
 };
+// rows from which rnamsm_gemm_bf16 uses the 256x256-tile kernels: the user's knob, else the calling forward's choice, else 2048
+inline int64_t gemm16_big_rows_now() {
+    if (tuning().gemm16_big_rows > 0) return tuning().gemm16_big_rows;
+    const int o = gemm16_big_rows_override();
+    return o > 0 ? o : 2048;
+}
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the (function, DEVICE) pair, so "already configured" is
 // remembered per device of the calling thread, not per process (a process may drive several GPUs: data.device=cuda:1,
@@ -276,11 +292,6 @@ static inline unsigned xcd_panel_grid_grouped(unsigned num_panels, unsigned inne
 int gemm_f32_splitk_factor(int64_t M, int N, int K, bool by_shape_only = false);
 int gemm_f32_splitk(const float* A, int64_t lda, const float* W, const float* bias, const float* residual, int64_t ldr,
                     float* Cout, int64_t ldc, int64_t M, int N, int K, int ks, float* partials, hipStream_t stream);
-
-// plain-bf16 plane GEMM with the epilogue hidden under the next tile's K loop (gemm16_pp.hip)
-bool gemm16_pp_eligible(int64_t M, int N, int K, const float* bias);
-int gemm16_pp(const uint16_t* a_hi, int64_t lda, const uint16_t* Whi, const float* bias, const float* residual, int64_t ldr,
-              float* Cout, int64_t ldc, int M, int N, int K, int act, float scale, int scale_cols, uint16_t* o_hi, hipStream_t stream);
 
 // the attention kernels of `batch` same-shape, unpadded MSAs in one launch each (gridDim.y = batch; MSA b's operands lie
 // b * stride elements further on): row_attn.hip, col_attn.hip; used by rnamsm_forward_batch

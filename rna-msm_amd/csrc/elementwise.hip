@@ -333,7 +333,9 @@ int embed_ln_batched(const int64_t* tokens, const float* embed_tokens, const flo
                      const float* gamma, const float* beta, float* out, int B, int R, int C, int D, int vocab, int num_positions,
                      int pad_idx, float eps, int* err_flag, hipStream_t stream) {
     const int64_t T = (int64_t)B * R * C;
-    KernelTimer timer(TC_EMBED, 0.0, 12.0 * T * D + 8.0 * T, stream);
+    // algorithmic HBM bytes: the output rows and the token ids; the two embedding tables (3.2 MB) are L2-resident, their rows are
+    // not HBM reads (counting them had given this launch a "fraction of roofline" above 1)
+    KernelTimer timer(TC_EMBED, 0.0, 4.0 * T * D + 8.0 * T, stream);
     hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid(T)), dim3(256), 0, stream, tokens, embed_tokens, embed_positions, row_pos,
                        gamma, beta, out, R, C, D, vocab, num_positions, pad_idx, eps, err_flag, B);
     RNAMSM_CHECK_LAUNCH("embed_ln");

@@ -508,21 +508,6 @@ struct HxFrag {
     typename Half16<FMT>::V8 a[HxCfg<SPLIT>::NPL][4], b[HxCfg<SPLIT>::NPL][2];
 };
 template <int SPLIT, int FMT>
-__device__ __forceinline__ void hx_frag_load(const char* buf, int kk, int wm, int wn, int li, int lh, HxFrag<SPLIT, FMT>& f) {
-    typedef typename Half16<FMT>::V8 V8;
-    constexpr int NPL = HxCfg<SPLIT>::NPL;
-    const int chunk = ((2 * kk + lh) ^ ((li >> 2) & 3)) * 16;      // rows are multiples of 32 + li
-#pragma unroll
-    for (int p = 0; p < NPL; ++p) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            f.a[p][t] = *reinterpret_cast<const V8*>(buf + p * HX_PLANE + (wm * 128 + t * 32 + li) * HX_ROWB + chunk);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-            f.b[p][t] = *reinterpret_cast<const V8*>(buf + (NPL + p) * HX_PLANE + (wn * 64 + t * 32 + li) * HX_ROWB + chunk);
-    }
-}
-template <int SPLIT, int FMT>
 __device__ __forceinline__ void hx_frag_mma(const HxFrag<SPLIT, FMT>& f, f32x16 (&acc)[4][2]) {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -536,101 +521,8 @@ __device__ __forceinline__ void hx_frag_mma(const HxFrag<SPLIT, FMT>& f, f32x16 
         }
 }
 
-template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
-__global__ __launch_bounds__(HX_THREADS, 2) void gemm16_dma256_kernel(
-    const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo, int64_t lda, const uint16_t* __restrict__ Whi,
-    const uint16_t* __restrict__ Wlo, const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout,
-    int64_t ldc, int M, int N, int K, float scale, int scale_cols, uint16_t* __restrict__ Ohi, uint16_t* __restrict__ Olo) {
-    using Cfg = HxCfg<SPLIT>;
-    constexpr int NPL = Cfg::NPL;
-    extern __shared__ __attribute__((aligned(16))) char smem_b[];
-
-    const unsigned nb = N / HX_BN, mp = (M + HX_BM - 1) / HX_BM;
-    unsigned mpanel, nblk;
-    if (!xcd_panel_map(blockIdx.x, mp, nb, mpanel, nblk)) return;
-    const int m0 = mpanel * HX_BM, n0 = nblk * HX_BN;
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wv >> 2, wn = wv & 3, li = lane & 31, lh = lane >> 5;
-
-    // DMA map: one wave instruction = 16 rows x 64 B; wave w moves row groups w and w + 8 of every plane.
-    // lane -> (row R0 + lane/4, physical chunk lane%4) holding logical chunk (lane%4) ^ ((row>>2)&3), (row>>2)&3 = (lane>>4)&3.
-    const int drow = lane >> 2;
-    const int dchunk = (lane & 3) ^ ((lane >> 4) & 3);
-    int64_t aoff[2], woff[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = 16 * (wv + 8 * j) + drow;
-        int m = m0 + row;
-        m = m < M ? m : M - 1;
-        aoff[j] = (int64_t)m * lda + dchunk * 8;
-        woff[j] = (int64_t)(n0 + row) * K + dchunk * 8;
-    }
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    auto issue = [&](int kt, int buf) {
-        char* base = smem_b + buf * Cfg::BUF;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int loff = (16 * (wv + 8 * j)) * HX_ROWB;
-            __builtin_amdgcn_global_load_lds((gptr_t)(Ahi + aoff[j] + kt * HX_BK), (lptr_t)(base + loff), 16, 0, 0);
-            if (SPLIT == 3)
-                __builtin_amdgcn_global_load_lds((gptr_t)(Alo + aoff[j] + kt * HX_BK), (lptr_t)(base + HX_PLANE + loff), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(Whi + woff[j] + kt * HX_BK), (lptr_t)(base + NPL * HX_PLANE + loff), 16, 0, 0);
-            if (SPLIT == 3)
-                __builtin_amdgcn_global_load_lds((gptr_t)(Wlo + woff[j] + kt * HX_BK), (lptr_t)(base + (NPL + 1) * HX_PLANE + loff), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
-
-    const int nk = K / HX_BK;
-    issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        wait_dma_then_barrier<0>();      // tile kt has landed (every wave's share), the other buffer is free again
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* cur = smem_b + (kt & 1) * Cfg::BUF;
-        HxFrag<SPLIT, FMT> f;
-        hx_frag_load<SPLIT, FMT>(cur, 0, wm, wn, li, lh, f);
-        hx_frag_mma<SPLIT, FMT>(f, acc);
-        hx_frag_load<SPLIT, FMT>(cur, 1, wm, wn, li, lh, f);
-        hx_frag_mma<SPLIT, FMT>(f, acc);
-    }
-    // epilogue in two 64-row passes of the 128-row wave tile (each pass = the shared 64x64-slab epilogue)
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-        hb_epilogue<ACT, HAS_RES, SPLIT, FMT, O_PL>(reinterpret_cast<f32x16(&)[2][2]>(acc[2 * p]), smem_b,
-                                                    m0 + wm * 128 + p * 64, n0 + wn * 64, wv, lane, li, lh, bias, residual,
-                                                    ldr, Cout, ldc, M, scale, scale_cols, Ohi, Olo);
-}
-
-template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL>
-static int launch_hx(const uint16_t* Whi, const uint16_t* Wlo, const float* bias, const float* residual, int64_t ldr,
-                     float* Cout, int64_t ldc, int64_t lda, int M, int N, int K, float scale, int scale_cols,
-                     const uint16_t* a_hi, const uint16_t* a_lo, uint16_t* o_hi, uint16_t* o_lo, hipStream_t stream) {
-    static DeviceOnce configured;
-    auto kern = gemm16_dma256_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL>;
-    constexpr int lds = HxCfg<SPLIT>::LDS;
-    if (configured.pending()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_dma256: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured.mark();
-    }
-    const unsigned grid = xcd_panel_grid((M + HX_BM - 1) / HX_BM, N / HX_BN);
-    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, gemm16_bytes(M, N, K, HxCfg<SPLIT>::NPL, HAS_RES, O_PL), stream, PEAK_F16_MFMA_TFLOPS, SPLIT);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, a_lo, lda, Whi, Wlo, bias, residual, ldr, Cout,
-                       ldc, M, N, K, scale, scale_cols, o_hi, o_lo);
-    RNAMSM_CHECK_LAUNCH("gemm16_dma256");
-    return RNAMSM_OK;
-}
-
 // ---- 256x256 tile, two buffers, software-pipelined fragments -------------------------------------------------------
-// gemm16_dma256_kernel reads a k-step's fragments and waits for them right before the MFMAs that use them; its two
+// A kernel that reads a k-step's fragments and waits for them right before the MFMAs that use them (round 1-3: gemm16_dma256_kernel, removed in round 4) has its two
 // waves per SIMD are barrier-synchronised, so they tend to sit in those waits together and the matrix pipe idles
 // (PMC, split 3 QKV: 56% MFMA busy at the actual clock, waves 32% of their time in s_waitcnt).  Here a k-step's
 // fragments are requested while the PREVIOUS step's MFMAs issue (two fragment sets, interleave pinned with
@@ -774,7 +666,9 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
         // have landed
         wait_dma_then_barrier<0>();
         const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;         // clamped: the last reload is never read
-        // "gemm16_dephase": see gemm16_q16_kernel.  (Staging by operand as in gemm16_q16s_kernel -- row-half-major micro-steps,
+        // "gemm16_dephase": a wave is stuck for ~100 cycles per LDS-DMA request it issues (8 per tile); when the two waves of a SIMD issue
+        // theirs at the same moment -- right after this barrier -- nobody feeds the matrix pipe meanwhile, so the upper wave group issues
+        // one step later.  (Staging by operand as in gemm16_q16s_kernel -- row-half-major micro-steps,
         // W requested half a tile before A -- was built for this kernel too and measured no better than this delay: f16x3 six
         // GEMMs x1.026 against x1.035, plain bf16 QKV x1.01 and fc1 x0.93; EXPERIMENTS.md R3.3.)
         if (!dephase || wm == 0) issue(k2, kt & 1);
@@ -924,197 +818,6 @@ __device__ __forceinline__ void hq_epilogue(f32x4a (&acc)[8][4], const HqEpiRegs
 }
 
 template <int ACT, bool HAS_RES, bool O_PL>
-__global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16_kernel(
-    const uint16_t* __restrict__ Ahi, int64_t lda, const uint16_t* __restrict__ Whi, const float* __restrict__ bias,
-    const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
-    uint16_t* __restrict__ Ohi, int group, unsigned total_tiles, int dephase_arg, Fold16 fa) {
-    const bool dephase = dephase_arg != 0;                    // uniform
-    using Cfg = HsCfg<1, 64>;
-    constexpr int BK = 64, ROWB = Cfg::ROWB, PLANE = Cfg::PLANE, KS = 2;     // two 32-deep k-steps per tile
-    typedef typename Half16<0>::V8 V8;
-    extern __shared__ __attribute__((aligned(16))) char smem_b[];
-
-    const unsigned nb = N / HX_BN, mp = (M + HX_BM - 1) / HX_BM;
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wv >> 2, wn = wv & 3, fr = lane & 15, fq = lane >> 4;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    // Persistent tile walk with the epilogue OFF the memory critical path.  The epilogue needs no LDS (hq_epilogue), so the
-    // next tile's first operand tile is requested BEFORE the current tile's stores: vector memory operations retire in
-    // order, and the first wait of the next tile then allows exactly the stores to stay in flight (vmcnt(HQ_STORES)) instead
-    // of draining them (a what-if: 27 % of the QKV launch, 34 % of fc1's, was the wait for the previous tile's stores).
-    constexpr int HQ_STORES = O_PL ? 16 : 32;                 // store instructions of one epilogue, per lane
-    const int drow = lane >> 3;
-    const int dchunk = (lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7);      // (row >> 1) & 7, row = 8g + lane/8
-    int64_t aoff[Cfg::IPW], woff[Cfg::IPW];
-    auto find_tile = [&](unsigned& vid, int& m0, int& n0) -> bool {
-        for (; vid < total_tiles; vid += gridDim.x) {
-            unsigned mpanel, nblk;
-            if (xcd_panel_map_grouped(vid, mp, nb, (unsigned)group, mpanel, nblk)) {
-                m0 = mpanel * HX_BM;
-                n0 = nblk * HX_BN;
-                return true;
-            }
-        }
-        return false;
-    };
-    // DMA map of gemm16_swp_kernel<BK 64>: a wave instruction covers 8 rows of 128 B
-    auto set_offsets = [&](int m0, int n0) {
-#pragma unroll
-        for (int j = 0; j < Cfg::IPW; ++j) {
-            const int row = Cfg::RPI * (wv + 8 * j) + drow;
-            int m = m0 + row;
-            m = m < M ? m : M - 1;
-            aoff[j] = (int64_t)m * lda + dchunk * 8;
-            // W rows are PERMUTED on their way into LDS so that the (transposed) accumulators of a lane are 8 + 8 consecutive
-            // output columns: LDS row 64 g + 16 t + 4 a + b  <-  weight row 64 g + 32 (t >> 1) + 8 a + 4 (t & 1) + b
-            // (g = the wave column's 64-row group, t = the MFMA tile, 4 a + b = the tile row).  See hq_epilogue.
-            const int tt = (row >> 4) & 3, aa = (row >> 2) & 3;
-            const int wrow = (row & ~63) + 32 * (tt >> 1) + 8 * aa + 4 * (tt & 1) + (row & 3);
-            woff[j] = (int64_t)(n0 + wrow) * K + dchunk * 8;
-        }
-    };
-    auto issue = [&](int kt, int buf) {
-        char* base = smem_b + buf * Cfg::BUF;
-#pragma unroll
-        for (int j = 0; j < Cfg::IPW; ++j) {
-            const int loff = (Cfg::RPI * (wv + 8 * j)) * ROWB;
-            __builtin_amdgcn_global_load_lds((gptr_t)(Ahi + aoff[j] + kt * BK), (lptr_t)(base + loff), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(Whi + woff[j] + kt * BK), (lptr_t)(base + PLANE + loff), 16, 0, 0);
-        }
-    };
-    unsigned vid = blockIdx.x;
-    int m0, n0;
-    if (!find_tile(vid, m0, n0)) return;
-    set_offsets(m0, n0);
-    issue(0, 0);
-    bool stores_in_flight = false;                            // uniform
-    for (;;) {
-    // lane (row fr, k-group fq) of a 16-row tile reads logical chunk 4*ks + fq of its row; (row >> 1) & 7 = (fr >> 1) & 7.
-    // A tile is consumed in four micro-steps u = (k-step ks = u >> 1, row half h = u & 1) of 16 MFMAs: the A fragments of
-    // one half (4 x V8) ping-pong by micro-step, the B fragments of a k-step (4 x V8) by k-step -- 64 fragment registers
-    // instead of the 96 of two whole k-step sets, which with 128 accumulators would not fit 256.
-    V8 ah[2][4], bq[2][4];
-    auto load_a = [&](const char* buf, int ks, int h, V8 (&a)[4]) {
-        const int chunk = ((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const V8*>(buf + (wm * 128 + (4 * h + t) * 16 + fr) * ROWB + chunk);
-    };
-    auto load_b = [&](const char* buf, int ks, V8 (&b)[4]) {
-        const int chunk = ((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const V8*>(buf + PLANE + (wn * 64 + t * 16 + fr) * ROWB + chunk);
-    };
-    f32x4a acc[8][4];
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4a{0.f, 0.f, 0.f, 0.f};
-    auto mma = [&](int h, const V8 (&a)[4], const V8 (&b)[4]) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                // operands swapped: the tile comes out TRANSPOSED in the registers -- lane (fr, fq) holds row fr, columns
-                // 4 fq .. 4 fq + 3 of the 16x16 tile -- so the epilogue stores row pieces straight from the accumulators
-                acc[4 * h + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt], a[mt], acc[4 * h + mt][nt], 0, 0, 0);
-    };
-    (void)KS;
-
-    const int nk = K / BK;
-    // tile 0 was requested before the previous tile's stores (or at kernel start): it has landed once at most those
-    // stores are still outstanding
-    if (stores_in_flight) wait_dma_then_barrier<HQ_STORES>();
-    else wait_dma_then_barrier<0>();
-    issue(nk > 1 ? 1 : 0, 1);
-    load_a(smem_b, 0, 0, ah[0]);
-    load_b(smem_b, 0, bq[0]);
-#define HQ_PIN(NDS_)                                                                  \
-    _Pragma("unroll") for (int i_ = 0; i_ < NDS_; ++i_) {                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
-    }                                                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x008, 16 - NDS_, 0);                        \
-    __builtin_amdgcn_sched_barrier(0)
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-        const char* cur = smem_b + (kt & 1) * Cfg::BUF;
-        const char* nxt = smem_b + ((kt & 1) ^ 1) * Cfg::BUF;
-        load_a(cur, 0, 1, ah[1]);                             // u0 computes, u1's A half arriving
-        mma(0, ah[0], bq[0]);
-        HQ_PIN(4);
-        load_a(cur, 1, 0, ah[0]);                             // u1 computes, u2's A half and k-step 1's B arriving
-        load_b(cur, 1, bq[1]);
-        mma(1, ah[1], bq[0]);
-        HQ_PIN(8);
-        load_a(cur, 1, 1, ah[1]);                             // u2 computes, u3's A half arriving: the last reads of `cur`
-        mma(0, ah[0], bq[1]);
-        HQ_PIN(4);
-        wait_dma_then_barrier<0>();                           // all waves done reading `cur`; tile kt+1 has landed
-        const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;         // clamped: the last reload is never read
-        // "gemm16_dephase": a wave is stuck for ~100 cycles per LDS-DMA request it issues (8 per tile); when the two waves of a
-        // SIMD issue theirs at the same moment -- right after this barrier -- nobody feeds the matrix pipe meanwhile.  The
-        // upper wave group therefore issues one micro-step later, while the lower one is back at its MFMAs.
-        if (!dephase || wm == 0) issue(k2, kt & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_a(nxt, 0, 0, ah[0]);                             // u3 computes, the next tile's u0 operands arriving
-        load_b(nxt, 0, bq[0]);
-        mma(1, ah[1], bq[1]);
-        HQ_PIN(8);
-        if (dephase && wm == 1) issue(k2, kt & 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    {
-        const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
-        load_a(cur, 0, 1, ah[1]);
-        mma(0, ah[0], bq[0]);
-        HQ_PIN(4);
-        load_a(cur, 1, 0, ah[0]);
-        load_b(cur, 1, bq[1]);
-        mma(1, ah[1], bq[0]);
-        HQ_PIN(8);
-        load_a(cur, 1, 1, ah[1]);
-        mma(0, ah[0], bq[1]);
-        HQ_PIN(4);
-        mma(1, ah[1], bq[1]);
-    }
-#undef HQ_PIN
-    wait_dma_then_barrier<0>();                               // every wave is done with LDS; the clamped reload has landed
-    // what the epilogue reads (bias / fold vectors, row statistics) first, then the next tile's tile 0, then the stores
-    HqEpiRegs er;
-    hq_epilogue_loads<HAS_RES>(er, m0 + wm * 128, n0 + wn * 64, lane, bias, M, fa);
-    // ... and waited for HERE (a use, as far as hipcc can tell): with an LDS-DMA in flight it would otherwise wait vmcnt(0) at
-    // their first real use and drain the next tile's operands inside the epilogue
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        asm volatile("" : "+v"(er.b4[t]));
-        asm volatile("" : "+v"(er.c4[t]));
-    }
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) asm volatile("" : "+v"(er.st[mt].x), "+v"(er.st[mt].y));
-    asm volatile("" ::: "memory");                            // ... and the requests below stay below
-    __builtin_amdgcn_sched_barrier(0);
-    const int em0 = m0 + wm * 128, en0 = n0 + wn * 64;
-    unsigned nvid = vid + gridDim.x;
-    int m1 = 0, n1 = 0;
-    const bool more = find_tile(nvid, m1, n1);
-    if (more) {
-        set_offsets(m1, n1);
-        issue(0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    hq_epilogue<ACT, HAS_RES, O_PL>(acc, er, em0, en0, lane, residual, ldr, Cout, ldc, M, scale, scale_cols, Ohi);
-    if (!more) break;
-    vid = nvid;
-    m0 = m1;
-    n0 = n1;
-    // the hoisted request pays only if exactly HQ_STORES vector memory instructions follow it: a residual adds loads, a
-    // ragged last row panel drops stores -- those tiles drain (vmcnt(0)) as before
-    stores_in_flight = !HAS_RES && em0 + 128 <= M;
-    if (!stores_in_flight) __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0), keep expcnt / lgkmcnt
-    }   // persistent tile loop
-}
-
-template <int ACT, bool HAS_RES, bool O_PL>
 __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16s_kernel(
     const uint16_t* __restrict__ Ahi, int64_t lda, const uint16_t* __restrict__ Whi, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
@@ -1130,6 +833,10 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16s_kernel(
     const int wm = wv >> 2, wn = wv & 3, fr = lane & 15, fq = lane >> 4;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
+    // Persistent tile walk with the epilogue OFF the memory critical path.  The epilogue needs no LDS (hq_epilogue), so the
+    // next tile's first operand tile is requested BEFORE the current tile's stores: vector memory operations retire in
+    // order, and the first wait of the next tile then allows exactly the stores to stay in flight (vmcnt(HQ_STORES)) instead
+    // of draining them (a what-if: 27 % of the QKV launch, 34 % of fc1's, was the wait for the previous tile's stores).
     constexpr int HQ_STORES = O_PL ? 16 : 32;                 // store instructions of one epilogue, per lane
     // STAGING BY OPERAND.  A wave is stuck for ~100 cycles per LDS-DMA request it issues, and while both waves of a SIMD issue
     // theirs at the same moment nobody feeds the matrix pipe.  Here the lower wave group (wm = 0) moves the whole W tile and
@@ -1156,7 +863,8 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16s_kernel(
         return false;
     };
     auto set_offsets = [&](int m0, int n0) {
-        // W rows are PERMUTED on their way into LDS as in gemm16_q16_kernel: LDS row 64 g + 16 t + 4 a + b  <-  weight row
+        // W rows are PERMUTED on their way into LDS so that the (transposed) accumulators of a lane are 8 + 8 consecutive output
+        // columns (hq_epilogue): LDS row 64 g + 16 t + 4 a + b  <-  weight row
         // 64 g + 32 (t >> 1) + 8 a + 4 (t & 1) + b; for LDS row r0 + 32 j (r0 < 32) that is weight row wrow(r0) + 32 j
         const int tt = (r0 >> 4) & 1, aa = (r0 >> 2) & 3;
         const int wrow0 = 8 * aa + 4 * tt + (r0 & 3);
@@ -1493,7 +1201,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_x3q_kernel(
     for (int t = 0; t < 4; ++t) {
         const int col = en0 + 32 * (t >> 1) + 8 * fq + 4 * (t & 1);
         b4[t] = bias ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-        asm volatile("" : "+v"(b4[t]));                       // waited for HERE, not inside the stores (see gemm16_q16_kernel)
+        asm volatile("" : "+v"(b4[t]));                       // waited for HERE, not inside the stores (see gemm16_q16s_kernel)
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -1579,14 +1287,11 @@ static int launch_hq(const uint16_t* Whi, const float* bias, const float* residu
                      int64_t lda, int M, int N, int K, float scale, int scale_cols, const uint16_t* a_hi, uint16_t* o_hi,
                      hipStream_t stream, const Fold16& fa = Fold16{}) {
     static DeviceOnce configured;
-    const bool by_operand = tuning().gemm16_dephase == 2;     // staging split by operand between the wave groups (gemm16_q16s_kernel)
-    auto kern = by_operand ? gemm16_q16s_kernel<ACT, HAS_RES, O_PL> : gemm16_q16_kernel<ACT, HAS_RES, O_PL>;
+    auto kern = gemm16_q16s_kernel<ACT, HAS_RES, O_PL>;        // staging split by operand between the wave groups
     constexpr int lds = HsCfg<1, 64>::LDS;
     if (configured.pending()) {
-        for (auto kf : {gemm16_q16_kernel<ACT, HAS_RES, O_PL>, gemm16_q16s_kernel<ACT, HAS_RES, O_PL>}) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_q16: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_q16s: hipFuncSetAttribute: %s", hipGetErrorString(e));
         configured.mark();
     }
     const int group = tuning().gemm_group > 0 ? tuning().gemm_group
@@ -1732,8 +1437,6 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
     const HbPlanes pl{A_hi, A_lo, O_hi, O_lo};
 #define HB_GO(ACT_, RES_, SP_, FMT_, APL_, OPL_) \
     launch_hb<ACT_, RES_, SP_, FMT_, APL_, OPL_>(A, lda, W_hi, W_lo, bias, residual, ldr, Cout, ldc, m, N, K, scale, scale_cols, pl, s)
-#define HX_GO(ACT_, RES_, SP_, FMT_, OPL_) \
-    launch_hx<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
 #define HS_GO(ACT_, RES_, SP_, FMT_, OPL_) \
     ((SP_ == 1 && tuning().gemm16_dma != 4 && K % 64 == 0)                                                             \
          ? launch_hs<ACT_, RES_, SP_, FMT_, OPL_, (SP_ == 1 ? 64 : 32)>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s) \
@@ -1741,18 +1444,14 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
 #define HQ_GO(ACT_, RES_, OPL_) \
     launch_hq<ACT_, RES_, OPL_>(W_hi, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, O_hi, s)
     // rows from which the 256x256-tile kernels take over from the 128x128 one ("gemm16_big_rows"; rnamsm_forward raises it, see there)
-    const int64_t big_rows = tuning().gemm16_big_rows > 0 ? tuning().gemm16_big_rows : 2048;
+    const int64_t big_rows = gemm16_big_rows_now();
 #define HD_GO(ACT_, RES_, SP_, FMT_, OPL_) \
     launch_hd<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)
 #define HB_ACT_RES(SP_, FMT_)                                                                                       \
     do {                                                                                                            \
-        /* the epilogue-hiding kernel (gemm16_pp.hip): plain bf16, plane input, planes or fp32 (+ residual) out */      \
-        if (SP_ == 1 && A_hi && tuning().gemm16_dma >= 3 && gemm16_pp_eligible(M, N, K, bias) &&                      \
-            (O_hi ? !residual : act == RNAMSM_ACT_NONE))                                                            \
-            return gemm16_pp(A_hi, lda, W_hi, bias, residual, ldr, Cout, ldc, m, N, K, act, scale, scale_cols, O_hi, s); \
         /* 16x16x32 MFMAs: round 2 +6.5 % on QKV, +1.4 % on fc1, -2.5 % on out_proj, 0 on fc2 (one process, cfg3 shapes): wide N only;   \
            round 3, staged by operand (gemm16_q16s_kernel): QKV +18 %, fc1 +14 %, fc2 +6.6 % (long K), out_proj -14 %           */ \
-        if (SP_ == 1 && A_hi && (tuning().gemm16_mfma16 == 1 ? (N / HX_BN > 4 || (K >= 2048 && tuning().gemm16_dephase == 2)) : tuning().gemm16_mfma16 == 2) && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= big_rows && K % 64 == 0) { \
+        if (SP_ == 1 && A_hi && (tuning().gemm16_mfma16 == 1 ? (N / HX_BN > 4 || K >= 2048) : tuning().gemm16_mfma16 == 2) && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= big_rows && K % 64 == 0) { \
             if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HQ_GO(RNAMSM_ACT_GELU_ERF, false, true)                    \
                                                         : HQ_GO(RNAMSM_ACT_NONE, false, true);                       \
             return residual ? HQ_GO(RNAMSM_ACT_NONE, true, false) : HQ_GO(RNAMSM_ACT_NONE, false, false);            \
@@ -1766,11 +1465,6 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
             if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HS_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true)        \
                                                         : HS_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, true);           \
             return residual ? HS_GO(RNAMSM_ACT_NONE, true, SP_, FMT_, false) : HS_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, false); \
-        }                                                                                                           \
-        if (A_hi && tuning().gemm16_dma >= 2 && N % HX_BN == 0 && m >= big_rows) {   /* 256x256 tile for large problems */ \
-            if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HX_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true)        \
-                                                        : HX_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, true);           \
-            return residual ? HX_GO(RNAMSM_ACT_NONE, true, SP_, FMT_, false) : HX_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, false); \
         }                                                                                                           \
         if (A_hi && tuning().gemm16_dma) {                                                                          \
             if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HD_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true)        \
@@ -1794,7 +1488,6 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
 #undef HD_GO
 #undef HQ_GO
 #undef HS_GO
-#undef HX_GO
 #undef HB_GO
 }
 

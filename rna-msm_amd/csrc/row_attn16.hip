@@ -14,6 +14,8 @@
 // fp16 lo plane into subnormals (absolute step 6e-8, only ~2^-18 of q), and probabilities are stored as P * 2^12 for the
 // same reason (exact power of two, undone by out_scale).
 // Roofline: MFMA-bound like the fp32 kernels (same flops, 16-bit rate x 1 or / 3).
+#include <type_traits>
+
 #include "row_split.h"
 #include "tile16.h"
 
@@ -201,17 +203,35 @@ __global__ __launch_bounds__(R16_THREADS, SPLIT == 3 ? 1 : 2) void row_apply16_k
     };
     // transposed-read geometry of this lane (tile16.h): addresses row q of the 4-row block, columns 4p..4p+3
     const int tq = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    auto frags = [&](const char* cur, int kk, R16Frag<SPLIT, FMT>& f) {
+    // B pieces are transposed reads issued as asm (tile16.h): usable after the counted wait in mma_t
+    struct FragT {
+        R16Frag<SPLIT, FMT> f;
+        TrPieces bp[2][NPL];
+    };
+    auto frags = [&](const char* cur, int kk, FragT& ft) {
 #pragma unroll
         for (int p = 0; p < NPL; ++p)
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                f.a[t][p] = frag_k<FMT>(cur + p * R16_PLANE, wm * 64 + t * 32 + li, kk, lh);
+                ft.f.a[t][p] = frag_k<FMT>(cur + p * R16_PLANE, wm * 64 + t * 32 + li, kk, lh);
                 // B[k = key][n = d]: lane (d = t*32 + li, lh) needs keys 16kk + 8lh + 0..7
                 const int ka = 16 * kk + 8 * lh + tq;
-                f.b[t][p] = frag_t<FMT>(cur + (NPL + p) * R16_PLANE + wn * 64 * T16_ROWB, ka, ka + 4, t * 32 + tcol);
+                ft.bp[t][p] = tr16_issue(cur + (NPL + p) * R16_PLANE + wn * 64 * T16_ROWB, ka, ka + 4, t * 32 + tcol);
             }
     };
+    // YOUNGER: transposed reads requested after this set's (4 per plane per set) -- LDS answers in order
+    auto mma_t = [&](FragT& ft, f32x16 (&acc)[2][2], auto younger_tag) {
+        constexpr int YOUNGER = decltype(younger_tag)::value;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+            tr16_wait2<YOUNGER>(ft.bp[0][p], ft.bp[1][p]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) ft.f.b[t][p] = tr16_frag<FMT>(ft.bp[t][p]);
+        }
+        r16_mma<SPLIT, FMT>(ft.f, acc);
+    };
+    typedef std::integral_constant<int, 4 * NPL> next_set_t;
+    typedef std::integral_constant<int, 0> none_t;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -227,18 +247,18 @@ __global__ __launch_bounds__(R16_THREADS, SPLIT == 3 ? 1 : 2) void row_apply16_k
         wait_dma_then_barrier<0>();
         if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
         const char* cur = smem_b + (kt & 1) * Cfg::BUF;
-        R16Frag<SPLIT, FMT> f0, f1;
+        FragT f0, f1;
         frags(cur, 0, f0);
         frags(cur, 1, f1);
-        r16_mma<SPLIT, FMT>(f0, acc);
+        mma_t(f0, acc, next_set_t());
         __builtin_amdgcn_sched_barrier(0);
         frags(cur, 2, f0);
-        r16_mma<SPLIT, FMT>(f1, acc);
+        mma_t(f1, acc, next_set_t());
         __builtin_amdgcn_sched_barrier(0);
         frags(cur, 3, f1);
-        r16_mma<SPLIT, FMT>(f0, acc);
+        mma_t(f0, acc, next_set_t());
         __builtin_amdgcn_sched_barrier(0);
-        r16_mma<SPLIT, FMT>(f1, acc);
+        mma_t(f1, acc, none_t());
     }
 
 #pragma unroll
@@ -431,6 +451,210 @@ __global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------- K4' (large C, plain bf16)
+// The K loop of gemm16_q16s_kernel (gemm_bf16.hip) on the tied-row logits: per head a [C x R*64] . [R*64 x C] product whose K
+// tile is one alignment row r (64 head dims = one 128-byte run per alignment column).  256x256 output tile, 8 waves (2 x 4),
+// wave tile 128 x 64 = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16, two 64 KB stages.  STAGING BY OPERAND: the lower wave group
+// moves the k tile (the "W" operand), the upper one the q tile, half a tile apart, each burst under the other group's MFMAs
+// and with a whole tile of flight time (see gemm16_q16s_kernel for the reasoning and the measurements); persistent blocks walk
+// (MSA, head, row slab, tile) and request the next tile's first stage before the current tile's stores.  The k rows are
+// permuted on their way into LDS so that a lane's (transposed) accumulators are 8 + 8 consecutive output columns: the
+// epilogue stores 16-byte pieces straight from the registers.  Needs C % 8 == 0 (16-byte stores into rows of C floats); other
+// alignments keep the 128x128 kernel above.  Round 4: the 128x128 kernel reached 790 TFLOP/s at M = L = 1024 (matrix pipe 47 %
+// busy, waves parked in the DMA wait / barrier 41 % of their time).
+constexpr int R16Q_ROWB = 128, R16Q_PLANE = 256 * R16Q_ROWB, R16Q_BUF = 2 * R16Q_PLANE, R16Q_LDS = 2 * R16Q_BUF;
+typedef float f32x4q __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512, 1) void row_logits16q_kernel(
+    const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ khi, int64_t ld, float* __restrict__ partial, int R, int C, int H,
+    int nsplit, int rows_per_split, float scale, int64_t qk_bstride, int64_t part_bstride, const int* __restrict__ true_rows,
+    unsigned num_panels, unsigned total_tiles) {
+    constexpr int ROWB = R16Q_ROWB, PLANE = R16Q_PLANE, BUF = R16Q_BUF;
+    typedef typename Half16<0>::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem_b[];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv >> 2, wn = wv & 3, fr = lane & 15, fq = lane >> 4;
+    const unsigned tiles_c = (C + 255) / 256;
+    const int64_t kstride = (int64_t)C * ld;                  // halves from alignment row r to r + 1
+    constexpr int NSTORES = 32;                               // store instructions of one epilogue, per lane
+
+    const int w4 = wv & 3;
+    const int drow = lane >> 3;
+    const int dchunk = (lane & 7) ^ ((4 * (w4 & 1) + (lane >> 4)) & 7);      // (row >> 1) & 7, row = 8 (w4 + 4 j) + lane / 8
+    const int r0 = 8 * w4 + drow;                             // the wave's LDS rows: r0 + 32 j, j = 0..7
+    const uint16_t* src = nullptr;                            // this wave group's operand of the current tile
+    int64_t off[8];
+    struct Tile { int b, h, split, i0, j0, r_begin, nk; };
+    auto find_tile = [&](unsigned& vid, Tile& t) -> bool {
+        for (; vid < total_tiles; vid += gridDim.x) {
+            unsigned panel, tl;
+            if (xcd_panel_map(vid, num_panels, tiles_c * tiles_c, panel, tl)) {
+                t.b = panel / (H * nsplit);
+                const int rest = panel % (H * nsplit);
+                t.h = rest / nsplit;
+                t.split = rest % nsplit;
+                t.i0 = (tl / tiles_c) * 256;
+                t.j0 = (tl % tiles_c) * 256;
+                t.r_begin = t.split * rows_per_split;
+                t.nk = min(R, t.r_begin + rows_per_split) - t.r_begin;
+                return true;
+            }
+        }
+        return false;
+    };
+    auto set_offsets = [&](const Tile& t) {
+        // k rows are PERMUTED on their way into LDS (gemm16_q16s_kernel): LDS row 64 g + 16 t + 4 a + b  <-  tile column
+        // 64 g + 32 (t >> 1) + 8 a + 4 (t & 1) + b; for LDS row r0 + 32 j (r0 < 32) that is column wrow(r0) + 32 j
+        const int tt = (r0 >> 4) & 1, aa = (r0 >> 2) & 3;
+        const int wrow0 = 8 * aa + 4 * tt + (r0 & 3);
+        src = (wm ? qhi : khi) + (int64_t)t.b * qk_bstride + (int64_t)t.r_begin * kstride + t.h * 64;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = wm ? t.i0 + r0 + 32 * j : t.j0 + wrow0 + 32 * j;     // clamped columns feed discarded outputs
+            off[j] = (int64_t)min(row, C - 1) * ld + dchunk * 8;
+        }
+    };
+    auto issue_mine = [&](int kt, int buf) {                 // this wave group's operand of K tile kt = alignment row r_begin + kt
+        char* base = smem_b + buf * BUF + (wm ? 0 : PLANE) + 1024 * w4;
+        const uint16_t* s = src + (int64_t)kt * kstride;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dma16(s + off[j], base + 4096 * j);
+    };
+    unsigned vid = blockIdx.x;
+    Tile t;
+    if (!find_tile(vid, t)) return;
+    set_offsets(t);
+    issue_mine(0, 0);
+    bool stores_in_flight = false;                            // uniform
+    for (;;) {
+    // lane (row fr, k-group fq) of a 16-row tile reads logical chunk 4*ks + fq of its row; (row >> 1) & 7 = (fr >> 1) & 7.
+    // A tile is consumed in four micro-steps (k-step, row half) of 16 MFMAs in the order (0,0) (1,0) (0,1) (1,1): the k tile has
+    // been read completely after the first micro-step's fragment reads, the q tile after the third's (gemm16_q16s_kernel).
+    V8 ah[2][4], bq[2][4];
+    auto load_a = [&](const char* buf, int ks, int hh, V8 (&a)[4]) {
+        const int chunk = ((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) a[tt] = *reinterpret_cast<const V8*>(buf + (wm * 128 + (4 * hh + tt) * 16 + fr) * ROWB + chunk);
+    };
+    auto load_b = [&](const char* buf, int ks, V8 (&b)[4]) {
+        const int chunk = ((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) b[tt] = *reinterpret_cast<const V8*>(buf + PLANE + (wn * 64 + tt * 16 + fr) * ROWB + chunk);
+    };
+    f32x4q acc[8][4];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4q{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](int hh, const V8 (&a)[4], const V8 (&b)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                // operands swapped: the tile comes out TRANSPOSED in the registers -- lane (fr, fq) holds row fr, columns
+                // 4 fq .. 4 fq + 3 of the 16x16 tile
+                acc[4 * hh + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt], a[mt], acc[4 * hh + mt][nt], 0, 0, 0);
+    };
+    const int nk = t.nk;
+    if (stores_in_flight) wait_dma_then_barrier<NSTORES>();
+    else wait_dma_then_barrier<0>();
+    issue_mine(nk > 1 ? 1 : 0, 1);
+    load_a(smem_b, 0, 0, ah[0]);
+    load_b(smem_b, 0, bq[0]);
+#define RQ_PIN(NDS_)                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < NDS_; ++i_) {                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
+    }                                                                                 \
+    __builtin_amdgcn_sched_group_barrier(0x008, 16 - NDS_, 0);                        \
+    __builtin_amdgcn_sched_barrier(0)
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const char* cur = smem_b + (kt & 1) * BUF;
+        const char* nxt = smem_b + ((kt & 1) ^ 1) * BUF;
+        const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;         // clamped: the last reload is never read (keeps the counts below fixed)
+        load_a(cur, 1, 0, ah[1]);                             // (ks 0, h 0) computes; (ks 1, h 0) arriving: the last reads of the k tile
+        load_b(cur, 1, bq[1]);
+        mma(0, ah[0], bq[0]);
+        RQ_PIN(8);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave has read the k tile of `cur`
+        if (wm == 0) issue_mine(k2, kt & 1);                  // k of tile kt+2 -> the k plane of `cur`
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(cur, 0, 1, ah[0]);
+        mma(0, ah[1], bq[1]);
+        RQ_PIN(4);
+        load_a(cur, 1, 1, ah[1]);                             // the last reads of the q tile
+        mma(1, ah[0], bq[0]);
+        RQ_PIN(4);
+        // every wave has read the q tile of `cur`, and tile kt+1 has landed: the q group waits for all of its requests, the k
+        // group leaves its newest 8 (k of tile kt+2, requested half a tile ago) in flight
+        if (wm == 0) wait_dma_then_barrier<8>();
+        else wait_dma_then_barrier<0>();
+        if (wm == 1) issue_mine(k2, kt & 1);                  // q of tile kt+2 -> the q plane of `cur`
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(nxt, 0, 0, ah[0]);
+        load_b(nxt, 0, bq[0]);
+        mma(1, ah[1], bq[1]);
+        RQ_PIN(8);
+    }
+    {
+        const char* cur = smem_b + ((nk - 1) & 1) * BUF;
+        load_a(cur, 1, 0, ah[1]);
+        load_b(cur, 1, bq[1]);
+        mma(0, ah[0], bq[0]);
+        RQ_PIN(8);
+        load_a(cur, 0, 1, ah[0]);
+        mma(0, ah[1], bq[1]);
+        RQ_PIN(4);
+        load_a(cur, 1, 1, ah[1]);
+        mma(1, ah[0], bq[0]);
+        RQ_PIN(4);
+        mma(1, ah[1], bq[1]);
+    }
+#undef RQ_PIN
+    wait_dma_then_barrier<0>();                               // every wave is done with LDS; the clamped reload has landed
+    // the epilogue's own data first (the scale of a ragged batch: every MSA's logits by ITS depth), then the next tile's first
+    // stage, then the stores
+    float sc = scale;
+    if (true_rows) sc = scale / sqrtf((float)max(true_rows[t.b], 1));
+    asm volatile("" : "+v"(sc));
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const Tile done = t;
+    unsigned nvid = vid + gridDim.x;
+    Tile nt;
+    const bool more = find_tile(nvid, nt);
+    if (more) {
+        set_offsets(nt);
+        issue_mine(0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        float* out = partial + (int64_t)done.b * part_bstride + ((int64_t)done.split * H + done.h) * C * C;
+        const int gm0 = done.i0 + wm * 128, gnb = done.j0 + wn * 64;
+        // lane (fr, fq): row 16 mt + fr, columns 8 fq .. + 7 (tiles 0, 1) and 32 + 8 fq .. + 7 (tiles 2, 3) of the wave's 128 x 64
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int i = gm0 + mt * 16 + fr;
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const int j = gnb + 32 * hlf + 8 * fq;
+                if (i < C && j < C) {                         // C % 8 == 0: a group of 8 columns is inside or outside as a whole
+                    float* o = out + (int64_t)i * C + j;
+                    epi_store(reinterpret_cast<f32x4*>(o), f32x4{acc[mt][2 * hlf][0] * sc, acc[mt][2 * hlf][1] * sc, acc[mt][2 * hlf][2] * sc, acc[mt][2 * hlf][3] * sc});
+                    epi_store(reinterpret_cast<f32x4*>(o + 4), f32x4{acc[mt][2 * hlf + 1][0] * sc, acc[mt][2 * hlf + 1][1] * sc, acc[mt][2 * hlf + 1][2] * sc, acc[mt][2 * hlf + 1][3] * sc});
+                }
+            }
+        }
+    }
+    if (!more) break;
+    vid = nvid;
+    t = nt;
+    // the hoisted request pays only if exactly NSTORES vector memory instructions follow it: a ragged tile drops stores and drains
+    stores_in_flight = done.i0 + 256 <= C && done.j0 + 256 <= C && !true_rows;
+    if (!stores_in_flight) __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0), keep expcnt / lgkmcnt
+    }   // persistent tile loop
+}
+
 // ---------------------------------------------------------------------------------------------- K6' (large C)
 // 256x256 tile version of row_apply16 for C >= 256: M = 256 alignment columns i, N = 4 alignment rows x 64 head dims,
 // K tile = 32 keys.  Per flop it moves half the operand bytes of the 128x128 kernel above -- the 16-bit kernels lose
@@ -456,7 +680,8 @@ struct R16XCfg {
 };
 template <int SPLIT, int FMT>
 struct R16XFrag {
-    typename Half16<FMT>::V8 a[SPLIT == 3 ? 2 : 1][4], b[SPLIT == 3 ? 2 : 1][2];
+    typename Half16<FMT>::V8 a[SPLIT == 3 ? 2 : 1][4];
+    TrPieces bp[SPLIT == 3 ? 2 : 1][2];                   // transposed-read pieces (asm requests, tile16.h), usable after tr16_wait2
 };
 
 template <int SPLIT, int FMT, int OUT, int KT>
@@ -476,7 +701,7 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
     using Cfg = R16XCfg<SPLIT, KT>;
     constexpr int NPL = Cfg::NPL, AROWB = Cfg::AROWB, PA = Cfg::PA, PB = Cfg::PB, KS = Cfg::KS;
     constexpr int NMF = 8 * (SPLIT == 3 ? 3 : 1);          // MFMAs per k step per wave
-    constexpr int NDS = 8 * NPL;                           // LDS reads per k step per wave (4 b128 + 4 tr per plane)
+    constexpr int NDS = 4 * NPL;                           // ds_read_b128 per k step per wave that the pinned interleave places (the 4 transposed reads per plane are asm)
     static_assert(KT == 32 || (KT == 64 && SPLIT == 1), "64-key tiles: two 64 KB stages fit for one plane per operand only");
     typedef typename Half16<FMT>::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
@@ -539,26 +764,37 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
                 f.a[p][t] = *reinterpret_cast<const V8*>(buf + p * PA + (wm * 128 + t * 32 + li) * AROWB + chunk);
             const char* bt = buf + NPL * PA + p * PB + wn * KT * T16_ROWB;    // this wave's alignment row
 #pragma unroll
-            for (int t = 0; t < 2; ++t) f.b[p][t] = frag_t<FMT>(bt, ka, ka + 4, t * 32 + tcol);
+            for (int t = 0; t < 2; ++t) f.bp[p][t] = tr16_issue(bt, ka, ka + 4, t * 32 + tcol);
         }
     };
-    auto frag_mma = [&](const R16XFrag<SPLIT, FMT>& f, f32x16 (&acc)[4][2]) {
+    // YOUNGER: transposed reads requested after this set's (the next set's, 4 per plane) -- LDS answers in order
+    auto frag_mma = [&](R16XFrag<SPLIT, FMT>& f, f32x16 (&acc)[4][2], auto younger_tag) {
+        constexpr int YOUNGER = decltype(younger_tag)::value;
+        V8 b[NPL][2];
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
+            tr16_wait2<YOUNGER>(f.bp[p][0], f.bp[p][1]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) b[p][t] = tr16_frag<FMT>(f.bp[p][t]);
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 if (SPLIT == 3) {
-                    acc[mt][nt] = Half16<FMT>::mfma(f.a[1][mt], f.b[0][nt], acc[mt][nt]);
-                    acc[mt][nt] = Half16<FMT>::mfma(f.a[0][mt], f.b[1][nt], acc[mt][nt]);
+                    acc[mt][nt] = Half16<FMT>::mfma(f.a[NPL - 1][mt], b[0][nt], acc[mt][nt]);
+                    acc[mt][nt] = Half16<FMT>::mfma(f.a[0][mt], b[NPL - 1][nt], acc[mt][nt]);
                 }
-                acc[mt][nt] = Half16<FMT>::mfma(f.a[0][mt], f.b[0][nt], acc[mt][nt]);
+                acc[mt][nt] = Half16<FMT>::mfma(f.a[0][mt], b[0][nt], acc[mt][nt]);
             }
     };
+    typedef std::integral_constant<int, 4 * NPL> next_set_t;
+    typedef std::integral_constant<int, 0> none_t;
     auto interleave = [&]() {
 #pragma unroll
         for (int i = 0; i < (NDS < NMF ? NDS : NMF); ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, NDS > NMF ? 2 : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         if (NMF > NDS) __builtin_amdgcn_sched_group_barrier(0x008, NMF - NDS, 0);
         __builtin_amdgcn_sched_barrier(0);
@@ -584,7 +820,7 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
 #pragma unroll
         for (int kk = 0; kk + 1 < KS; ++kk) {
             frag_load(cur, kk + 1, f[(kk + 1) & 1]);
-            frag_mma(f[kk & 1], acc);
+            frag_mma(f[kk & 1], acc, next_set_t());
             interleave();
         }
         // every wave is done reading `cur` once its last fragments have arrived; tile kt+1 (issued one tile ago) must have landed
@@ -593,7 +829,7 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
         if (!dephase || wm == 0) issue(k2, kt & 1);                // "gemm16_dephase": the upper wave group issues one step later
         __builtin_amdgcn_sched_barrier(0);
         frag_load(nxt, 0, f[0]);
-        frag_mma(f[(KS - 1) & 1], acc);
+        frag_mma(f[(KS - 1) & 1], acc, next_set_t());
         interleave();
         if (dephase && wm == 1) issue(k2, kt & 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -603,10 +839,10 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
 #pragma unroll
         for (int kk = 0; kk + 1 < KS; ++kk) {
             frag_load(cur, kk + 1, f[(kk + 1) & 1]);
-            frag_mma(f[kk & 1], acc);
+            frag_mma(f[kk & 1], acc, next_set_t());
             interleave();
         }
-        frag_mma(f[(KS - 1) & 1], acc);
+        frag_mma(f[(KS - 1) & 1], acc, none_t());
     }
     wait_dma_then_barrier<0>();   // LDS is free for the epilogue staging
 
@@ -648,12 +884,18 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 // Round 3: the 256x256 kernel with 64-deep K tiles (whole cache lines per DMA row) for plain bf16, knob "row16_bk64" = 2:
 // 0.165-0.170 ms against 0.167-0.170 ms on the 128x128 kernel (cfg3, one process) -- no gain, stays off.  The same tile
 // depth in row_apply16x (64 keys per tile, "row16_bk64" >= 1) is the default: 0.215 -> 0.192 ms.
+// Round 4: plain bf16 at C >= 384 (at C = 256 the 128x128 kernel's 2 blocks per CU win: 0.047 vs 0.054 ms at 128 x 256) with C % 8 == 0 takes row_logits16q_kernel (256x256 tiles on the 16x16x32 MFMA, staged by
+// operand; knob "row16_q16", default on): the same 256-slot row split as the other 256x256 kernel.
+static inline bool row_logits16_q16(int C, bool split3) {
+    return !split3 && tuning().row16_q16 != 0 && C >= 384 && C % 8 == 0 && tuning().attn16 != 2;
+}
 static inline bool row_logits16_big(int C, bool split3) {
-    return (split3 || tuning().row16_bk64 >= 2) && C >= 256 && tuning().attn16 != 2;
+    return ((split3 || tuning().row16_bk64 >= 2) && C >= 256 && tuning().attn16 != 2) || row_logits16_q16(C, split3);
 }
 // row split of the 16-bit logits kernels; the hi/lo modes cap a slab's rows ("row16_max_rows", see row_split.h and DESIGN 3.2)
 static inline RowSplit row_split16(int R, int C, int H, bool big, bool split3) {
     const int cap = split3 ? tuning().row16_max_rows : 0;
+    if (row_logits16_q16(C, split3)) return choose_row_split(R, C, H, 256, 256, 0, 0.01);
     return big ? choose_row_split(R, C, H, 256, 256, cap) : choose_row_split(R, C, H, 128, 512, cap);
 }
 
@@ -687,6 +929,24 @@ static int row_logits16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool big = row_logits16_big(C, q_lo != nullptr);
     const RowSplit sp = row_split16(R, C, H, big, q_lo != nullptr);
+    if (row_logits16_q16(C, q_lo != nullptr)) {
+        const unsigned tc = (C + 255) / 256;
+        const unsigned panels = (unsigned)batch * H * sp.nsplit;
+        const unsigned total = xcd_panel_grid(panels, tc * tc);
+        const unsigned pgrid = total < 256u ? total : 256u;               // persistent: one block per CU
+        static DeviceOnce cfgq;
+        if (cfgq.pending()) {
+            int rc = set_lds16(row_logits16q_kernel, R16Q_LDS, "row_logits16q");
+            if (rc) return rc;
+            cfgq.mark();
+        }
+        KernelTimer timer(TC_ROW_LOGITS, 2.0 * batch * H * C * C * R * 64,
+                          batch * (2.0 * 2.0 * R * C * H * 64 + 4.0 * (double)sp.nsplit * H * C * C), s, PEAK_F16_MFMA_TFLOPS, 1.0);
+        hipLaunchKernelGGL(row_logits16q_kernel, dim3(pgrid), dim3(512), R16Q_LDS, s, q_hi, k_hi, ld, partial, R, C, H, sp.nsplit,
+                           sp.rows_per_split, scale, qk_bstride, part_bstride, true_rows, panels, total);
+        RNAMSM_CHECK_LAUNCH("row_logits16q");
+        return RNAMSM_OK;
+    }
     const unsigned tiles_c = big ? (C + 255) / 256 : (C + 127) / 128;
     const unsigned grid = xcd_panel_grid((unsigned)(H * sp.nsplit), tiles_c * tiles_c);
     KernelTimer timer(TC_ROW_LOGITS, 2.0 * batch * H * C * C * R * 64,

@@ -18,7 +18,10 @@ struct RowSplit {
 // against an fp64 truth at M=256 x L=512 (tests/analysis/error_sources.py): chains of 4096 / 2048 / 1024 / 512 / 256 terms leave
 // the 10-layer embedding 1.26e-4 / 7.1e-5 / 4.1e-5 / 3.2e-5 / 3.1e-5 from the truth -- the reference's own CPU arithmetic
 // (blocked sgemm) sits at 3.2e-5.  The fp32 kernel therefore keeps every chain at 8 rows (512 terms).
-inline RowSplit choose_row_split(int R, int C, int H, int tile = 128, int slots = 512, int max_rows = 0) {
+// slab_penalty: what one more partial slab costs in units of fill efficiency (each slab is an H*C*C fp32 write here and a
+// read in K5, and one more epilogue per output tile): 0.002 breaks ties only; the persistent 256x256 bf16 kernel, whose launch
+// is short enough for that traffic to show, passes 0.01 (M=256 x L=512: 5 slabs of 51 rows instead of 16 of 16).
+inline RowSplit choose_row_split(int R, int C, int H, int tile = 128, int slots = 512, int max_rows = 0, double slab_penalty = 0.002) {
     const long tiles = (long)((C + tile - 1) / tile) * ((C + tile - 1) / tile) * H;
     const int min_ns = max_rows > 0 ? (R + max_rows - 1) / max_rows : 1;
     int best_ns = min_ns;
@@ -31,7 +34,7 @@ inline RowSplit choose_row_split(int R, int C, int H, int tile = 128, int slots 
         const long blocks = tiles * real_ns;
         const long rounds = (blocks + slots - 1) / slots;
         double score = (double)blocks / (double)(rounds * slots);   // fill efficiency of the last round
-        score -= 0.002 * real_ns;                                    // prefer fewer partial slabs on ties
+        score -= slab_penalty * real_ns;                             // prefer fewer partial slabs
         if (score > best_score + 1e-9) {
             best_score = score;
             best_ns = real_ns;

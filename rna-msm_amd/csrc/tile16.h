@@ -56,6 +56,40 @@ __device__ __forceinline__ typename Half16<FMT>::V8 frag_t(const char* tile, int
     return __builtin_bit_cast(typename Half16<FMT>::V8, r);
 }
 
+// The same transposed read as inline asm, in two steps.  hipcc treats the ds_read_tr16 builtin as a possible LDS STORE and puts
+// an s_waitcnt vmcnt(0) in front of it whenever an LDS-DMA may be in flight (found in round 4 in the ISA of every kernel that
+// mixes frag_t with a DMA ring: the prefetched tile was drained right after it had been requested, so no transfer ever
+// overlapped the MFMAs).  An asm statement is invisible to that bookkeeping: tr16_issue() requests the 4-row pieces, and
+// tr16_wait*() -- an s_waitcnt lgkmcnt(0) naming every piece as "+v", placed before the first consumer -- makes them usable
+// (cdna_hip_programming.md 5.7 item 1, form (ii)).  LDS returns data in order, so hipcc's own counted lgkmcnt waits can only
+// over-wait because of these requests, never under-wait.
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+struct TrPieces { s16x4 a, b; };
+__device__ __forceinline__ TrPieces tr16_issue(const char* tile, int row_a, int row_b, int col) {
+    const uint32_t pa = lds_addr_of(tile + row_a * T16_ROWB + (((col >> 3) ^ swz_t(row_a)) << 4) + (col & 7) * 2);
+    const uint32_t pb = lds_addr_of(tile + row_b * T16_ROWB + (((col >> 3) ^ swz_t(row_b)) << 4) + (col & 7) * 2);
+    TrPieces r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r.a) : "v"(pa));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r.b) : "v"(pb));
+    return r;
+}
+__device__ __forceinline__ void tr16_wait4(TrPieces& p0, TrPieces& p1, TrPieces& p2, TrPieces& p3) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(p0.a), "+v"(p0.b), "+v"(p1.a), "+v"(p1.b), "+v"(p2.a), "+v"(p2.b), "+v"(p3.a), "+v"(p3.b));
+}
+// counted form for software-pipelined fragment sets: N = transposed reads (asm) requested AFTER these pieces and before this wait
+template <int N>
+__device__ __forceinline__ void tr16_wait2(TrPieces& p0, TrPieces& p1) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(p0.a), "+v"(p0.b), "+v"(p1.a), "+v"(p1.b) : "n"(N));
+}
+template <int FMT>
+__device__ __forceinline__ typename Half16<FMT>::V8 tr16_frag(const TrPieces& p) {
+    const s16x8 r = __builtin_shufflevector(p.a, p.b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(typename Half16<FMT>::V8, r);
+}
+
 // acc += A.B with hi/lo operand pairs (SPLIT 3: small cross terms first, the leading term last) or hi only (SPLIT 1)
 template <int SPLIT, int FMT>
 __device__ __forceinline__ f32x16 mma16(const typename Half16<FMT>::V8 (&a)[SPLIT == 3 ? 2 : 1],

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "rnamsm_timing_get": (c_int, [c_int, POINTER(c_char_p), POINTER(ctypes.c_longlong), POINTER(ctypes.c_double),
                                   POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
     "rnamsm_timing_get_bound": (c_int, [c_int, POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_double)]),
+    "rnamsm_timing_get_valu_bound": (c_int, [c_int, POINTER(ctypes.c_double)]),
     "rnamsm_timing_reset": (None, []),
     "rnamsm_set_param": (c_int, [c_char_p, c_int]),
     "rnamsm_get_param": (c_int, [c_char_p]),
@@ -150,8 +151,8 @@ def check(rc: int) -> None:
 
 
 def kernel_timings() -> dict:
-    """Fold completed HIP-event pairs and return {kernel: {launches, ms, flops, bytes, bound_ms, mfma_bound_ms, hbm_bound_ms}}
-    (rnamsm_timing_*; the bounds are per-launch max(matrix, HBM) roofline times summed over the launches)."""
+    """Fold completed HIP-event pairs and return {kernel: {launches, ms, flops, bytes, bound_ms, mfma_bound_ms, hbm_bound_ms,
+    valu_bound_ms}} (rnamsm_timing_*; bound_ms = per-launch max(matrix, HBM, vector-ALU) roofline times summed over the launches)."""
     lib = load()
     n = lib.rnamsm_timing_collect()
     out = {}
@@ -162,6 +163,9 @@ def kernel_timings() -> dict:
                                     ctypes.byref(by)))
         bd, mf, hb = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         check(lib.rnamsm_timing_get_bound(c, ctypes.byref(bd), ctypes.byref(mf), ctypes.byref(hb)))
+        va = ctypes.c_double()
+        check(lib.rnamsm_timing_get_valu_bound(c, ctypes.byref(va)))
         out[name.value.decode()] = {"launches": cnt.value, "ms": ms.value, "flops": fl.value, "bytes": by.value,
-                                    "bound_ms": bd.value, "mfma_bound_ms": mf.value, "hbm_bound_ms": hb.value}
+                                    "bound_ms": bd.value, "mfma_bound_ms": mf.value, "hbm_bound_ms": hb.value,
+                                    "valu_bound_ms": va.value}
     return out

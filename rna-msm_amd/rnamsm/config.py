@@ -31,6 +31,10 @@ class DataConfig:                       # RNA_MSM_Inference.py:20-32
     # round 3: a lone forward of a few hundred tokens costs 5.5 ms on a mostly idle chip; data.batch_small_msas=false
     # restores the strictly one-by-one loop of the reference (RNA_MSM_Inference.py:141-148)
     batch_small_msas: bool = True
+    # ... and in the 16-bit arithmetic modes (model.gemm_dtype = bf16 | bf16x3 | f16x3) only on request: there a ragged batch picks
+    # its GEMM kernels by the BATCH's token count, so an alignment's files would depend (at the mode's rounding level, ~1e-2
+    # in bf16) on what else is in the id list; one by one every alignment's output is a function of that alignment alone
+    batch_small_msas_16bit: bool = False
 
 
 @dataclass

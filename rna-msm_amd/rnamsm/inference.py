@@ -121,6 +121,11 @@ class _AsyncNpyWriter:
 # (Frames: 16 k tokens / 32 members until the pool existed; a batch of 64 alignments of 8 x 64 runs at 676 k residues/s against
 # 649 k for 32 -- GEMM tile quantisation shrinks with the token count, tools/small_batch_knobs.py -- hence 32 k / 64.)
 SMALL_MSA_TOKENS, FRAME_TOKENS, GROUP_MEMBERS = 3072, 32768, 64
+# ... and within FRAME_MAP_ELEMS = members x (max columns)^2: the maps (row_attn and atp: layers x heads x C^2 floats per member,
+# 480 B per element at 10 x 12) scale with C^2, not with the tokens -- 32 shallow alignments of 1 x 1024 would be 16 GB of maps for
+# a frame of 32 k tokens, and batching gains nothing at that C.  2^20 elements = 0.5 GB of atp per group: 64 members up to C = 128,
+# 16 at C = 256, none above C = 1024 / alone.
+FRAME_MAP_ELEMS = 1 << 20
 
 
 def joins_group(group_shapes: List[tuple], shape: tuple) -> bool:
@@ -128,8 +133,9 @@ def joins_group(group_shapes: List[tuple], shape: tuple) -> bool:
     if len(group_shapes) >= GROUP_MEMBERS:
         return False
     trial = list(group_shapes) + [shape]
-    frame = len(trial) * max(s[0] for s in trial) * max(s[1] for s in trial)
-    return frame <= FRAME_TOKENS and frame <= 2 * sum(s[0] * s[1] for s in trial)
+    cols = max(s[1] for s in trial)
+    frame = len(trial) * max(s[0] for s in trial) * cols
+    return frame <= FRAME_TOKENS and frame <= 2 * sum(s[0] * s[1] for s in trial) and len(trial) * cols * cols <= FRAME_MAP_ELEMS
 
 
 # Without a gather the order in which alignments are computed is free (every alignment has its own files), so the small ones
@@ -179,6 +185,7 @@ def _clustered_groups(shapes: List[tuple]) -> List[List[int]]:
         while len(g) < GROUP_MEMBERS and left.any():
             frame = (len(g) + 1) * np.maximum(rows, rc[:, 0]) * np.maximum(cols, rc[:, 1])
             ok = left & (frame <= FRAME_TOKENS) & (frame <= 2 * (real + tok))
+            ok &= (len(g) + 1) * np.maximum(cols, rc[:, 1]) ** 2 <= FRAME_MAP_ELEMS
             added_padding = frame - len(g) * rows * cols - tok
             ok &= added_padding <= GROUP_OVERHEAD_TOKENS
             if not ok.any():
@@ -295,7 +302,10 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
             # frame, every MSA scaled by its own depth); a lone forward of a few hundred tokens costs 5.5 ms on a mostly
             # idle chip.  Groups: by shape from the pool (plan_groups); under gather_to_rank0 the RoundGatherer needs this
             # rank's items in list order, so there only CONSECUTIVE small alignments share a group.
-            batching = bool(getattr(cfg.data, "batch_small_msas", True)) and (model.gemm_dtype == "f32" or ops.get_param("attn16") != 0)
+            # (16-bit modes: only with data.batch_small_msas_16bit -- a batch's token count selects the GEMM kernels there, so
+            # an alignment's files would depend on its neighbours in the list at the mode's rounding level)
+            batching = bool(getattr(cfg.data, "batch_small_msas", True)) and (
+                model.gemm_dtype == "f32" or (bool(getattr(cfg.data, "batch_small_msas_16bit", False)) and ops.get_param("attn16") != 0))
             pooled = batching and gatherer is None
             group: List = []                                          # (idx, tokens on the device)
             pool: List = []                                           # (idx, tokens on the host)
@@ -320,24 +330,40 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                         deliver(i, out["emb"].contiguous(), out["atp"].contiguous())
                 group.clear()
 
-            for n, idx in enumerate(mine):
-                rna_id = ids[idx]
-                tokens = pending.result() if reader else read(idx)
-                if reader and n + 1 < len(mine):
-                    pending = reader.submit(read, mine[n + 1])       # parsed while the GPU runs this MSA
-                if batching and tokens.size <= SMALL_MSA_TOKENS and not (tokens == alphabet.padding_idx).any():
-                    if pooled:
-                        pool.append((idx, tokens))
-                        if len(pool) >= POOL_MSAS:
-                            run_pool()
+            def read_and_run() -> None:
+                nonlocal pending
+                for n, idx in enumerate(mine):
+                    rna_id = ids[idx]
+                    tokens = pending.result() if reader else read(idx)
+                    if reader and n + 1 < len(mine):
+                        pending = reader.submit(read, mine[n + 1])       # parsed while the GPU runs this MSA
+                    if (batching and tokens.size <= SMALL_MSA_TOKENS and 2 * tokens.shape[1] ** 2 <= FRAME_MAP_ELEMS
+                            and not (tokens == alphabet.padding_idx).any()):
+                        if pooled:
+                            pool.append((idx, tokens))
+                            if len(pool) >= POOL_MSAS:
+                                run_pool()
+                            continue
+                        if not joins_group([tuple(t.shape) for _, t in group], tuple(tokens.shape)):
+                            flush()                                       # this one would waste too much padding: start a new frame
+                        group.append((idx, torch.from_numpy(tokens).to(device)))
                         continue
-                    if not joins_group([tuple(t.shape) for _, t in group], tuple(tokens.shape)):
-                        flush()                                       # this one would waste too much padding: start a new frame
-                    group.append((idx, torch.from_numpy(tokens).to(device)))
-                    continue
-                flush()
-                out = model.checked_forward_one(torch.from_numpy(tokens).to(device), need_repr=False, what=rna_id)   # emb + atp are all that is written
-                deliver(idx, out["emb"], out["atp"])
+                    flush()
+                    out = model.checked_forward_one(torch.from_numpy(tokens).to(device), need_repr=False, what=rna_id)   # emb + atp are all that is written
+                    deliver(idx, out["emb"], out["atp"])
+
+            try:
+                read_and_run()
+            except BaseException:
+                # a bad alignment late in the list must not cost the results already computed or read: what waits in the
+                # group / pool is run and written (as the one-by-one loop would have done before reaching it), then the
+                # error goes up.  A second failure in here is dropped in favour of the first.
+                try:
+                    flush()
+                    run_pool()
+                except BaseException:                                 # noqa: BLE001
+                    pass
+                raise
             flush()
             run_pool()
             if gatherer is not None:

@@ -266,7 +266,12 @@ class MSATransformer(nn.Module):
         {"row_attn" [NL,H,C,C], "repr" [R,C,D], "emb" [C-1,D], "atp" [NL*H,C-1,C-1]}.
         need_repr=False: only what the CLI writes (emb, atp; bit-identical) -- the last layer then skips the rows the
         outputs do not depend on and "repr" holds alignment row 0 only ([1, C, D]).
-        fold_layernorm: None = self.fold_layernorm; False = separate LayerNorm launches for this call."""
+        fold_layernorm: None = self.fold_layernorm; False = separate LayerNorm launches for this call.
+        The result also carries "err" (int32[1] on the device): bit 0 ERR_INDEX a token / position id out of range, bit 1 ERR_FOLD
+        the folded LayerNorm's precondition failed, bit 2 ERR_NONFINITE an emb / atp value is inf or NaN.  This entry point does
+        NOT look at it (no host sync) and never falls back: in a 16-bit mode an overflow comes back as inf / NaN outputs with
+        bit 2 set, whatever `check_finite` says -- callers must test `out["err"] & ERR_NONFINITE` themselves, or use
+        checked_forward_one (one sync per MSA; redoes the MSA on the exact path when check_finite is set)."""
         if self.training:
             raise NotImplementedError("rnamsm implements the inference path only: call .eval()")
         if not tokens2d.is_cuda:
@@ -293,7 +298,8 @@ class MSATransformer(nn.Module):
         emb [B,C-1,D], atp [B,NL*H,C-1,C-1], err int32[1] (bits as in forward_one).  has_padding: None = look at the tokens.
         true_rows (int32 [B] on the device): the real depth of every element of a RAGGED batch -- each MSA's tied logits are
         then scaled by its own depth and the element comes out as its unpadded forward would (forward_ragged); None = the
-        reference's batch semantics (padded depth)."""
+        reference's batch semantics (padded depth).  Like forward_one this entry point never inspects "err" and never falls back:
+        test `err & ERR_NONFINITE` in a 16-bit mode, or call checked_forward_batch."""
         if self.training:
             raise NotImplementedError("inference only (model.eval())")
         if not tokens3d.is_cuda:

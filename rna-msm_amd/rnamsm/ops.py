@@ -432,18 +432,23 @@ def zero_plane_rows(pl, mask: torch.Tensor, ncols: int) -> None:
 
 @_on_operand_device
 def col_attn16(q, k, v, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0,
-               pad_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+               pad_mask: Optional[torch.Tensor] = None, out_planes: bool = False):
     """q, k, v: (hi, lo) plane views [R*C, *] with a common row stride; returns softmax(scale * q k^T) v, fp32
-    [R*C, H*64] (q UNSCALED)."""
-    ctx = torch.empty(R * C, H * HEAD_DIM, device=v[0].device, dtype=torch.float32)
+    [R*C, H*64] (q UNSCALED) -- or, with out_planes, the context as the 16-bit (hi, lo | None) int16 planes the forward's
+    out_proj GEMM reads (format = the operands': bf16, or fp16 for fmt 1)."""
+    D = H * HEAD_DIM
     ld = _rowmajor(q[0], "q_hi")
     assert _rowmajor(k[0], "k_hi") == ld and _rowmajor(v[0], "v_hi") == ld
+    ctx = None if out_planes else torch.empty(R * C, D, device=v[0].device, dtype=torch.float32)
+    c_hi = torch.empty(R * C, D, device=v[0].device, dtype=torch.int16) if out_planes else None
+    c_lo = torch.empty(R * C, D, device=v[0].device, dtype=torch.int16) if out_planes and q[1] is not None else None
     _lib.check(_lib.load().rnamsm_col_attn16(_pl(q[0], "q_hi"), _pl(q[1], "q_lo"), _pl(k[0], "k_hi"), _pl(k[1], "k_lo"),
-                                             _pl(v[0], "v_hi"), _pl(v[1], "v_lo"), ld, _dev(ctx, "ctx"), _rowmajor(ctx, "ctx"),
+                                             _pl(v[0], "v_hi"), _pl(v[1], "v_lo"), ld,
+                                             None if ctx is None else _dev(ctx, "ctx"), D,
                                              R, C, H, HEAD_DIM, scale,
                                              None if pad_mask is None else _dev(pad_mask, "pad_mask", torch.uint8),
-                                             None, None, fmt, _stream()))
-    return ctx
+                                             _pl(c_hi, "ctx_hi"), _pl(c_lo, "ctx_lo"), fmt, _stream()))
+    return (c_hi, c_lo) if out_planes else ctx
 
 
 @_on_operand_device

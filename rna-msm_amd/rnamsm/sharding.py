@@ -78,6 +78,7 @@ class RoundGatherer:
         # for the transfer stream (read by stats(), which synchronises)
         self.host_wait_s = 0.0
         self._wait_events = []
+        self._wait_ms_folded = 0.0         # elapsed time of event pairs already folded (the list stays short on long id lists)
 
     # ------------------------------------------------------------------ helpers
     def _has_item(self, rnd: int, rank: int) -> bool:
@@ -111,6 +112,8 @@ class RoundGatherer:
             cur.wait_stream(self._side)
             e1.record(cur)
             self._wait_events.append((e0, e1))
+            if len(self._wait_events) > 64:                           # fold the pairs that have completed; never grows past this
+                self._fold_wait_events(keep_pending=True)
         self.host_wait_s += time.perf_counter() - t0
         if self.rank == self.dst and self.on_item is not None:
             for index, tensors in sorted(items, key=lambda it: it[0]):
@@ -185,12 +188,27 @@ class RoundGatherer:
         """Gather diagnostics of this rank: bytes received, host seconds blocked waiting for transfers, and (device wire)
         the milliseconds the compute stream stood waiting for the transfer stream -- the part of the gather that was not
         overlapped with the next forward.  Synchronises the device."""
-        exposed_ms = 0.0
         if self._wait_events:
             torch.cuda.synchronize(self.wire)
-            exposed_ms = sum(a.elapsed_time(b) for a, b in self._wait_events)
+            self._fold_wait_events(keep_pending=False)
+        exposed_ms = self._wait_ms_folded
         return {"bytes_received": float(self.bytes_received), "host_wait_s": self.host_wait_s,
                 "stream_wait_ms": exposed_ms, "rounds": float(self._round)}
+
+    def _fold_wait_events(self, keep_pending: bool) -> None:
+        """Add the elapsed time of recorded (start, stop) pairs to the running total and drop them; with keep_pending only the
+        pairs whose stop event has completed (no synchronisation), else all (the caller has synchronised)."""
+        rest = []
+        for a, b in self._wait_events:
+            if keep_pending and not b.query():
+                rest.append((a, b))
+            else:
+                self._wait_ms_folded += a.elapsed_time(b)
+        if keep_pending and len(rest) > 64:                            # nothing completes (a stalled stream): wait for the oldest
+            a, b = rest.pop(0)
+            b.synchronize()
+            self._wait_ms_folded += a.elapsed_time(b)
+        self._wait_events = rest
 
     # ------------------------------------------------------------------ API
     def submit(self, index: int, tensors: Sequence[torch.Tensor]) -> None:

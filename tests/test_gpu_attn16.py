@@ -204,6 +204,68 @@ def test_col_attention_16bit_online_softmax_rescale(dev, split, fmt):
         assert rel_l2(ctx, want.reshape(R * C, 64)) < (3e-3 if split == 1 else 3e-6)
 
 
+@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 0)])
+@pytest.mark.parametrize("R", [40, 200, 300])
+def test_col_attention_16bit_fast_loop_falls_back_when_a_score_overflows_its_reference(dev, split, fmt, R):
+    """The bf16 column kernel fixes every query's softmax reference from its first 32 keys (no running maximum) and redoes a
+    column with the tracked loop when a row sum reaches 2^96.  Here one key far down the column scores ~390 log2 units above
+    everything in the first tile for the queries of ONE wave-sized group: the fallback must produce the exact softmax (the spike
+    key's value row), the untouched columns / heads must equal the tracked kernel's output, and forcing the tracked loop
+    ("attn16" = 5) must agree everywhere."""
+    from rnamsm import ops, _lib
+    lib = _lib.load()
+    C, H = 3, 2
+    D = 64 * H
+    qkv = _rand(f"ovf16.{R}", (R * C, 3 * D), 0.5)
+    spike = R - 3                                           # beyond the first tile for every R here
+    qv = qkv.view(R, C, 3 * D)
+    qv[:, 1, 0:64] = 0.0
+    qv[5:9, 1, 0] = 48.0                                    # queries 5..8 of column 1, head 0: q = 48 e_0
+    qv[:, 1, D:D + 64][:, 0] = 0.0                          # every key of that column / head: k_0 = 0 ...
+    qv[spike, 1, D] = 45.0                                  # ... but the spike key: score 2160 * 0.125 = 270 nats
+    pl, eff = _planes(qkv.to(dev), split, fmt)
+    args = (_views(pl, 0, D), _views(pl, D, 2 * D), _views(pl, 2 * D, 3 * D), R, C, H)
+    got = ops.col_attn16(*args, fmt=fmt, scale=0.125).cpu()
+    try:
+        _lib.check(lib.rnamsm_set_param(b"attn16", 5))
+        tracked = ops.col_attn16(*args, fmt=fmt, scale=0.125).cpu()
+    finally:
+        _lib.check(lib.rnamsm_set_param(b"attn16", 1))
+    e = eff.double()
+    want = _col_ref(0.125 * e[:, :D].view(R, C, H, 64), e[:, D:2 * D].view(R, C, H, 64), e[:, 2 * D:].view(R, C, H, 64))[0].reshape(R * C, D)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < (3e-3 if split == 1 else 4e-5)
+    assert rel_l2(tracked, want) < (3e-3 if split == 1 else 4e-5)
+    gv, wv = got.view(R, C, D), want.view(R, C, D)
+    v_spike = e[:, 2 * D:].view(R, C, D)[spike, 1, :64]
+    for i in range(5, 9):                                   # the spiked queries see the spike key only
+        assert np.abs(gv[i, 1, :64].numpy() - v_spike.numpy()).max() < 2e-2 * max(1.0, float(v_spike.abs().max()))
+        assert np.abs(gv[i, 1, :64].numpy() - wv[i, 1, :64].numpy()).max() < 1e-2
+
+
+@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 0), (3, 1)])
+@pytest.mark.parametrize("R,C,H", [(7, 33, 2), (130, 5, 2), (300, 4, 1), (256, 3, 2)])
+def test_col_attention_16bit_plane_outputs_equal_the_rounded_fp32_output(dev, split, fmt, R, C, H):
+    """The forward reads the context as 16-bit planes written through the kernel's LDS-transposed epilogue: hi must be the
+    fp32 output rounded to the format and hi + lo must reproduce it to the pair's precision."""
+    from rnamsm import ops
+    D = 64 * H
+    qkv = _rand(f"colpl.{R}.{C}", (R * C, 3 * D))
+    pl, _ = _planes(qkv.to(dev), split, fmt)
+    args = (_views(pl, 0, D), _views(pl, D, 2 * D), _views(pl, 2 * D, 3 * D), R, C, H)
+    f32 = ops.col_attn16(*args, fmt=fmt, scale=0.125)
+    hi, lo = ops.col_attn16(*args, fmt=fmt, scale=0.125, out_planes=True)
+    ht = torch.float16 if fmt == 1 else torch.bfloat16
+    assert torch.equal(hi.view(ht), f32.to(ht))
+    if split == 3:
+        assert lo is not None
+        back = hi.view(ht).double() + lo.view(ht).double()
+        err = float(((back - f32.double()).abs() / f32.double().abs().clamp_min(2.0 ** -6)).max())
+        assert err < (2.0 ** -16 if fmt == 0 else 2.0 ** -21), err       # relative per element (absolute below 2^-6: fp16 subnormal lo)
+    else:
+        assert lo is None
+
+
 def test_16bit_attention_rejects_inconsistent_planes(dev):
     from rnamsm import ops, _lib
     R, C, H = 4, 8, 1

@@ -872,68 +872,6 @@ def _x3q_checks(dev, ops, lib, _lib, M, N, K, act, fmt):
     assert torch.equal(eff(oi).cpu(), (ai @ wi.t()).double())        # |values| <= 36 K: exact in fp32 and in a hi/lo pair
 
 
-@pytest.mark.parametrize("M,N,K,kind", [(16384, 2304, 768, "qkv"), (9000, 3072, 768, "fc1"), (8200, 768, 768, "out"),
-                                        (4100, 768, 3072, "fc2"), (2048, 128, 768, "plain"), (70000, 768, 768, "out")])
-def test_epilogue_hiding_bf16_gemm_equals_the_256x256_kernels(dev, M, N, K, kind):
-    """gemm16_pp_kernel (round 3: 4 waves x 512 registers, two accumulator sets; tile t's bias / residual / conversion / stores
-    leave in eight units under tile t+1's K loop; three-slot LDS-DMA ring running across tile boundaries; every wait a
-    literal vmcnt over hand-counted loads, stores and DMA requests).  Same products in the same order per accumulator and the
-    same epilogue arithmetic as gemm16_q16_kernel -> BIT-identical to the kernels it replaces (knob "gemm16_pp" = 0), for
-    every epilogue form, with one / two / many tiles per persistent block (the first tile drains nothing, the last drains in a
-    tail), a ragged last row panel, K = 768 (all 12 K iterations special) and K = 3072 (steady loop; the stream's tile switch
-    sits in it); reruns bit-identical (a miscounted wait shows as rare wrong tiles); values against fp64 on the plane values."""
-    from rnamsm import ops, _lib
-    from rnamsm._lib import ACT_GELU_ERF, ACT_NONE
-    lib = _lib.load()
-    ht = torch.bfloat16
-    a = ops.split_bf16(_rand(f"pp.a{M}", (M, K)).to(dev), want_lo=False)
-    w = ops.split_bf16(_rand(f"pp.w{N}", (N, K), 0.05).to(dev), want_lo=False)
-    b = _rand(f"pp.b{N}", (N,), 0.1).to(dev)
-    r = _rand(f"pp.r{M}", (M, N)).to(dev) if kind in ("out", "fc2") else None
-    planes = kind in ("qkv", "fc1")
-    act = ACT_GELU_ERF if kind == "fc1" else ACT_NONE
-    sc = dict(scale=0.125, scale_cols=768) if kind == "qkv" else {}
-
-    def run():
-        res = ops.linear_planes(a, w, b, act=act, residual=r, out_planes=planes, **sc)
-        return (res[0] if planes else res).clone()
-
-    exact = N % 256 == 0        # the 16x16x32 256x256 kernel exists for N % 256 == 0; otherwise the 32x32x16 128x128 one (rounding differs)
-    try:
-        _lib.check(lib.rnamsm_set_param(b"gemm16_pp", 0))
-        _lib.check(lib.rnamsm_set_param(b"gemm16_mfma16", 2))       # gemm16_q16_kernel for every shape it covers
-        old = run()
-        _lib.check(lib.rnamsm_set_param(b"gemm16_pp", 1))
-        first = None
-        for persist in (256, 64, 8):                        # tiles per block: few ... hundreds
-            _lib.check(lib.rnamsm_set_param(b"gemm16_persist", persist))
-            new = run()
-            first = new if first is None else first
-            assert torch.equal(new, first), (kind, persist)
-            if exact:
-                assert torch.equal(new, old), (kind, persist, float((new.view(ht).float() - old.view(ht).float()).abs().max()) if planes
-                                               else float((new - old).abs().max()))
-            else:
-                assert rel_l2(new.cpu(), old.cpu()) < 1e-6
-        _lib.check(lib.rnamsm_set_param(b"gemm16_persist", 256))
-        for _ in range(25):
-            assert torch.equal(run(), first)
-    finally:
-        _lib.check(lib.rnamsm_set_param(b"gemm16_pp", 0))           # the default: the kernel measured 0.61-0.83x (EXPERIMENTS.md)
-        _lib.check(lib.rnamsm_set_param(b"gemm16_mfma16", 1))
-        _lib.check(lib.rnamsm_set_param(b"gemm16_persist", 256))
-    rows = torch.cat([torch.arange(0, 300), torch.arange(M - 300, M)]).to(dev)
-    want = a[0].view(ht)[rows].double() @ w[0].view(ht).double().t() + b.double()
-    if kind == "qkv":
-        want[:, :768] *= 0.125
-    if act:
-        want = O.gelu_erf(want)
-    if r is not None:
-        want = want + r[rows].double()
-    got = (old.view(ht) if planes else old)[rows].double()
-    assert rel_l2(got.cpu(), want.cpu()) < (6e-3 if planes else 2e-6)
-
-
 @pytest.mark.parametrize("M,N,K", [(300, 2304, 96), (4100, 1280, 64), (1025, 768, 768), (129, 3072, 32)])
 def test_gemm_block_order_never_changes_results(dev, M, N, K):
     """rnamsm_set_param("gemm_group"): the XCD-aware block order (whole panels, groups of G panels, by-shape default)

@@ -142,6 +142,8 @@ def test_config_defaults_and_overrides():
                          "model.num_layers=3", "data.max_seqs_per_msa=64", "model.embed_positions_msa=false"])
     assert c.data.root_path == "/x" and c.data.MSA_path == "r2" and c.model.num_layers == 3
     assert c.data.max_seqs_per_msa == 64 and c.model.embed_positions_msa is False
+    assert Config().data.batch_small_msas_16bit is False              # ... for the exact path; the 16-bit modes batch on request only
+    assert parse_overrides(["data.batch_small_msas_16bit=true"]).data.batch_small_msas_16bit is True
     assert Config().data.batch_small_msas is True                     # the extra CLI switch: on by default (round 3) ...
     assert parse_overrides(["data.batch_small_msas=false"]).data.batch_small_msas is False
     with pytest.raises(ValueError):
@@ -228,7 +230,8 @@ def test_library_validates_arguments_without_a_gpu(lib):
     need = lib.rnamsm_forward_workspace_bytes(ctypes.byref(dims), 256, 512, 0, 0)
     T = 256 * 512
     assert lib.rnamsm_row_logits16_nsplit(256, 512, 12, 3) == 16    # 256x256 tiles, one block per CU: 12 * 16 * 4 = 3 rounds
-    assert lib.rnamsm_row_logits16_nsplit(256, 512, 12, 1) == 8     # plain bf16 stays on the 128x128 kernel
+    assert lib.rnamsm_row_logits16_nsplit(256, 512, 12, 1) == 5     # plain bf16, C % 8 == 0: persistent 256x256 kernel, 240 tiles, few slabs
+    assert lib.rnamsm_row_logits16_nsplit(1024, 1024, 12, 1) == 4   # 12 heads x 16 tiles x 4 slabs = 3 rounds of 256 blocks
     assert lib.rnamsm_row_logits16_nsplit(256, 100, 12, 3) == 37     # small C: 128x128 tiles, split by block count only
     assert lib.rnamsm_row_logits16_workspace_bytes(256, 512, 12) == 16 * 12 * 512 * 512 * 4
     assert need >= T * 768 * 4 * 6 + 16 * 12 * 512 * 512 * 4 + T and need < T * 768 * 4 * 7.2
@@ -372,6 +375,11 @@ def test_cli_grouping_rule_for_small_alignments():
     assert not joins_group([(2, 10), (2, 10)], (30, 50))              # 3 x 30 x 50 = 4500 > 2 x 1540: too much padding
     assert joins_group([(30, 50)] * 20, (30, 50)) and not joins_group([(30, 50)] * 21, (30, 50))    # 22 x 1500 > 32768
     assert joins_group([(2, 8)] * 63, (2, 8)) and not joins_group([(2, 8)] * 64, (2, 8))
+    # the maps scale with members x columns^2, not with the tokens: shallow, long alignments stay (nearly) alone
+    from rnamsm.inference import FRAME_MAP_ELEMS
+    assert FRAME_MAP_ELEMS == 1 << 20
+    assert joins_group([(1, 1024)], (1, 1024)) is False               # 2 x 1024^2 maps: 1 GB of atp for 2 k tokens
+    assert joins_group([(3, 256)] * 15, (3, 256)) and not joins_group([(3, 256)] * 16, (3, 256))
 
 
 def test_pooled_small_alignments_are_grouped_by_shape():
@@ -386,6 +394,7 @@ def test_pooled_small_alignments_are_grouped_by_shape():
         assert g == sorted(g) and 1 <= len(g) <= GROUP_MEMBERS
         frame = len(g) * max(shapes[j][0] for j in g) * max(shapes[j][1] for j in g)
         assert frame <= FRAME_TOKENS and (len(g) == 1 or frame <= 2 * sum(shapes[j][0] * shapes[j][1] for j in g))
+        assert len(g) == 1 or len(g) * max(shapes[j][1] for j in g) ** 2 <= (1 << 20)
     in_order, cur = 0, []
     for sh in shapes:                                       # the consecutive rule (still used under gather_to_rank0)
         if cur and not joins_group(cur, sh):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timing of the 16-bit attention kernels at cfg3 (R=256, C=512, H=12) in the three operand modes.
-VARIANTS=1,2,.. sweeps rnamsm_set_param("attn16", v) when a build carries experimental kernel variants behind it."""
+VARIANTS=1,2,.. sweeps rnamsm_set_param("attn16", v): 1 default, 2 = 128x128 row kernels, 4 = column attention with one query
+block per wave, 5 = column attention on the TRACKED loop only.  The column kernel is timed with plane outputs, as the forward runs it."""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd"))
@@ -9,6 +10,7 @@ from rnamsm import _lib, ops
 R, C, H = int(os.environ.get("R", 256)), int(os.environ.get("C", 512)), 12
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "1").split(",")]
 BK64 = [int(v) for v in os.environ.get("BK64", "1").split(",")]
+Q16 = [int(v) for v in os.environ.get("Q16", "1").split(",")]               # rnamsm_set_param("row16_q16", v) (plain bf16 logits)
 DEPHASE = [int(v) for v in os.environ.get("DEPHASE", "2").split(",")]       # rnamsm_set_param("gemm16_dephase", v)           # rnamsm_set_param("row16_bk64", v) (plain bf16 only)
 D = 64 * H
 dev = torch.device("cuda:0")
@@ -21,7 +23,10 @@ def timeit(fn, n=7):
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return statistics.median(ts[2:])
 lib = _lib.load()
+MODES = os.environ.get("MODES", "bf16,bf16x3,f16x3").split(",")
 for name, split, fmt in (("bf16", 1, 0), ("bf16x3", 3, 0), ("f16x3", 3, 1)):
+    if name not in MODES:
+        continue
     hi, lo = ops.split_bf16(qkv, want_lo=split == 3, fmt=fmt)
     v = lambda a, b: (hi[:, a:b], None if lo is None else lo[:, a:b])
     q, k, vv = v(0, D), v(D, 2 * D), v(2 * D, 3 * D)
@@ -31,15 +36,17 @@ for name, split, fmt in (("bf16", 1, 0), ("bf16x3", 3, 0), ("f16x3", 3, 1)):
     for rnd in range(int(os.environ.get("ROUNDS", 1))):
         for var in VARIANTS:
             for bk in (BK64 if split == 1 else [0]):
-                for dp in DEPHASE:
+                for dp, q16 in [(d, q) for d in DEPHASE for q in (Q16 if split == 1 else [1])]:
+                    _lib.check(lib.rnamsm_set_param(b"row16_q16", q16))
                     _lib.check(lib.rnamsm_set_param(b"attn16", var))
                     _lib.check(lib.rnamsm_set_param(b"row16_bk64", bk))
                     _lib.check(lib.rnamsm_set_param(b"gemm16_dephase", dp))
                     t1 = timeit(lambda: ops.row_logits16(q, k, R, C, H, fmt=fmt, scale=ops.row_scaling(R)))
                     t2 = timeit(lambda: ops.row_apply16(pp, vv, R, C, H, fmt=fmt, out_scale=1 / 4096.0))
-                    t3 = timeit(lambda: ops.col_attn16(q, k, vv, R, C, H, fmt=fmt, scale=0.125))
-                    line.append(f"[v{var} bk64={bk} dephase={dp}] logits {t1:.3f} apply {t2:.3f} col {t3:.3f} ms")
+                    t3 = timeit(lambda: ops.col_attn16(q, k, vv, R, C, H, fmt=fmt, scale=0.125, out_planes=True))
+                    line.append(f"[v{var} bk64={bk} dephase={dp} q16={q16}] logits {t1:.3f} apply {t2:.3f} col {t3:.3f} ms")
     _lib.check(lib.rnamsm_set_param(b"attn16", 1))
+    _lib.check(lib.rnamsm_set_param(b"row16_q16", 1))
     _lib.check(lib.rnamsm_set_param(b"row16_bk64", 1))
     _lib.check(lib.rnamsm_set_param(b"gemm16_dephase", 2))
     print(" ".join(line), flush=True)
