@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RNAMSM_VERSION 300 /* major*10000 + minor*100 + patch */
+#define RNAMSM_VERSION 400 /* major*10000 + minor*100 + patch; 4.0: rnamsm_model_dims.row_pos_dim, rnamsm_embed_ln_rows */
 
 typedef enum {
     RNAMSM_OK = 0,
@@ -64,6 +64,12 @@ int rnamsm_embed_ln(const int64_t* tokens, const float* embed_tokens, const floa
                     const float* row_pos, const float* gamma, const float* beta, float* out,
                     int R, int C, int D, int vocab, int num_positions, int pad_idx, float eps,
                     int* err_flag, void* stream);
+/* The same with the per-channel alignment-row embedding of msm/model.py:289-292: row_pos_dim = D reads row_pos as
+ * [>=R, D] (x[r,c,:] += row_pos[r,:]); row_pos_dim = 0 or 1 is rnamsm_embed_ln. */
+int rnamsm_embed_ln_rows(const int64_t* tokens, const float* embed_tokens, const float* embed_positions,
+                         const float* row_pos, int row_pos_dim, const float* gamma, const float* beta, float* out,
+                         int R, int C, int D, int vocab, int num_positions, int pad_idx, float eps,
+                         int* err_flag, void* stream);
 
 /* K1 -- nn.LayerNorm over the last dim (modules.py:383,387; model.py:396): y = (x-mean)/sqrt(var+eps)*gamma+beta,
  * biased variance.  x, y [T, D] contiguous (y may alias x). */
@@ -281,6 +287,14 @@ int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t
                       const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C,
                       int H, int head_dim, float scale, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo,
                       int fmt, void* stream);
+/* The same for bf16 operand formats (plain bf16: lo planes NULL, or bf16 hi/lo pairs) without a padding mask, with q PRESCALED:
+ * the q planes hold q * scale * log2(e) (scale = dh^-0.5), multiplied in BEFORE the rounding to 16 bits -- rnamsm_gemm_bf16's
+ * epilogue does that for the q columns (scale, scale_cols) -- so the kernel's softmax is p = exp2(q'.k) with no multiply, no
+ * reference subtraction and no pre-pass; a row sum outside [2^-96, 2^96] sends the block to the online-softmax loop.  This is
+ * what rnamsm_forward runs in the bf16 modes. */
+int rnamsm_col_attn16_prescaled(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
+                                const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R,
+                                int C, int H, int head_dim, uint16_t* ctx_hi, uint16_t* ctx_lo, void* stream);
 /* f2 in the 16-bit modes: zero the first ncols halves of the plane rows flagged in mask (uint8 [T]) -- q *= 1 -
  * padding_mask (modules.py:767-772) applied to the q planes after the QKV GEMM. */
 int rnamsm_zero_plane_rows(uint16_t* hi, uint16_t* lo, const uint8_t* mask, int64_t T, int ncols, int64_t ld, void* stream);
@@ -331,6 +345,11 @@ int rnamsm_msa_weights(const uint8_t* msa, int N, int L, double seqid_cutoff, do
 typedef struct {
     int num_layers, embed_dim, num_heads, ffn_dim, vocab, num_positions, pad_idx;
     float ln_eps;
+    /* msa_position_embedding: 0 or 1 = one scalar per alignment row, weights[RNAMSM_W_ROW_POS] = [1024] (the RNA-MSM
+     * model, model.py:293-296: shape (1,1024,1,1)); embed_dim = one VECTOR per alignment row, [1024, embed_dim] (the msm/
+     * variant of the shell, msm/model.py:289-292: shape (1,1024,1,emb_dim)).  A trailing field: an initialiser written for
+     * ABI 3.x leaves it 0. */
+    int row_pos_dim;
 } rnamsm_model_dims;
 
 enum {

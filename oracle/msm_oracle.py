@@ -73,7 +73,9 @@ def embed(tokens: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor
             f"depth of 1024, but received {R} alignments.")          # model.py:355-359
     x = params["embed_tokens.weight"][tokens]
     x = x + params["embed_positions.weight"][positions_from_tokens(tokens)]
-    x = x + params["msa_position_embedding"][0, :R]                 # [R,1,1] broadcast
+    # (1,1024,1,1): one scalar per alignment row, [R,1,1] broadcast (model.py:293-296); the msm/ variant of the shell
+    # holds (1,1024,1,D), a vector per row, [R,1,D] (msm/model.py:289-292, :346) -- the same indexing serves both
+    x = x + params["msa_position_embedding"][0, :R]
     x = layer_norm(x, params["emb_layer_norm_before.weight"], params["emb_layer_norm_before.bias"])
     pad = tokens == PAD_IDX
     if bool(pad.any()):                                             # model.py:366-367
@@ -178,17 +180,22 @@ def ffn(x: torch.Tensor, params, prefix: str, token_chunk: Optional[int] = None)
 
 def axial_layer(x: torch.Tensor, params, layer: int, num_heads: int,
                 max_tokens: Optional[int] = None, pad: Optional[torch.Tensor] = None,
-                ffn_token_chunk: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                ffn_token_chunk: Optional[int] = None, col_probs_out: Optional[List[torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """AxialTransformerLayer.forward (modules.py:242-267) with each sub-block wrapped as
-    NormalizedResidualBlock (modules.py:385-401): x + f(LN(x)); dropout is the identity in eval."""
+    NormalizedResidualBlock (modules.py:385-401): x + f(LN(x)); dropout is the identity in eval.
+    col_probs_out: a list that receives the layer's column probabilities [H, C, R, R] (what msm/model.py:383 stacks)."""
     base = f"layers.{layer}"
     pre = f"{base}.row_self_attention"
     y, row_probs = row_attention(layer_norm(x, params[f"{pre}.layer_norm.weight"], params[f"{pre}.layer_norm.bias"]),
                                  params, f"{pre}.layer", num_heads, max_tokens, pad)
     x = x + y
     pre = f"{base}.column_self_attention"
-    x = x + col_attention(layer_norm(x, params[f"{pre}.layer_norm.weight"], params[f"{pre}.layer_norm.bias"]),
-                          params, f"{pre}.layer", num_heads, pad=pad)
+    cy = col_attention(layer_norm(x, params[f"{pre}.layer_norm.weight"], params[f"{pre}.layer_norm.bias"]),
+                       params, f"{pre}.layer", num_heads, return_probs=col_probs_out is not None, pad=pad)
+    if col_probs_out is not None:
+        cy, cp = cy
+        col_probs_out.append(cp)
+    x = x + cy
     pre = f"{base}.feed_forward_layer"
     x = x + ffn(layer_norm(x, params[f"{pre}.layer_norm.weight"], params[f"{pre}.layer_norm.bias"]),
                 params, f"{pre}.layer", ffn_token_chunk)
@@ -198,7 +205,7 @@ def axial_layer(x: torch.Tensor, params, layer: int, num_heads: int,
 def forward(tokens: torch.Tensor, params: Dict[str, torch.Tensor], num_layers: int = 10,
             num_heads: int = 12, max_tokens: Optional[int] = None,
             layers_to_run: Optional[int] = None, force_mask: bool = False,
-            ffn_token_chunk: Optional[int] = None) -> Dict[str, torch.Tensor]:
+            ffn_token_chunk: Optional[int] = None, return_col_attentions: bool = False) -> Dict[str, torch.Tensor]:
     """MSATransformer.forward (model.py:338-416) for one MSA, need_head_weights=True,
     repr_layers=[num_layers]; lm_head / contact head are not on this path.
     tokens int64 [R, C].  Returns representation [R, C, D] (after emb_layer_norm_after,
@@ -208,12 +215,16 @@ def forward(tokens: torch.Tensor, params: Dict[str, torch.Tensor], num_layers: i
     pad = pad if (bool(pad.any()) or force_mask) else None          # model.py:346-348
     x = embed(tokens, params)
     rows: List[torch.Tensor] = []
+    cols: Optional[List[torch.Tensor]] = [] if return_col_attentions else None
     n = num_layers if layers_to_run is None else layers_to_run
     for i in range(n):
-        x, pr = axial_layer(x, params, i, num_heads, max_tokens, pad, ffn_token_chunk)
+        x, pr = axial_layer(x, params, i, num_heads, max_tokens, pad, ffn_token_chunk, cols)
         rows.append(pr)
     x = layer_norm(x, params["emb_layer_norm_after.weight"], params["emb_layer_norm_after.bias"])
-    return {"representation": x, "row_attentions": torch.stack(rows, 0)}
+    out = {"representation": x, "row_attentions": torch.stack(rows, 0)}
+    if return_col_attentions:                                       # msm/model.py:404-410: [L, H, C, R, R] (B squeezed)
+        out["col_attentions"] = torch.stack(cols, 0)
+    return out
 
 
 def pack_outputs(result: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:

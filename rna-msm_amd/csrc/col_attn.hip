@@ -221,8 +221,9 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
                     H4 ah, al, bh, bl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        ah[e] = (Hh)a[e]; al[e] = (Hh)(a[e] - (float)ah[e]);
-                        bh[e] = (Hh)b[e]; bl[e] = (Hh)(b[e] - (float)bh[e]);
+                        const float av = pinned(a[e]), bv = pinned(b[e]);
+                        ah[e] = (Hh)av; al[e] = (Hh)(av - (float)ah[e]);
+                        bh[e] = (Hh)bv; bl[e] = (Hh)(bv - (float)bh[e]);
                     }
                     *reinterpret_cast<H4*>(ctx_hi + ooff + 8 * g) = ah;
                     *reinterpret_cast<H4*>(ctx_hi + ooff + 32 + 8 * g) = bh;
@@ -462,8 +463,9 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
                     H4 ah, al, bh, bl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        ah[e] = (Hh)a[e]; al[e] = (Hh)(a[e] - (float)ah[e]);
-                        bh[e] = (Hh)b[e]; bl[e] = (Hh)(b[e] - (float)bh[e]);
+                        const float av = pinned(a[e]), bv = pinned(b[e]);
+                        ah[e] = (Hh)av; al[e] = (Hh)(av - (float)ah[e]);
+                        bh[e] = (Hh)bv; bl[e] = (Hh)(bv - (float)bh[e]);
                     }
                     *reinterpret_cast<H4*>(ctx_hi + ooff + 8 * g) = ah;
                     *reinterpret_cast<H4*>(ctx_hi + ooff + 32 + 8 * g) = bh;

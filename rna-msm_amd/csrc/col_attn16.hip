@@ -24,11 +24,14 @@
 //     finite, the block votes, and ALL its waves redo the column with the TRACKED loop.  tests/test_gpu_attn16.py forces that.
 //   TRACKED (fp16 operands -- P must stay below 2^16 --, padding masks, and the fallback): the classic online softmax in its
 //     cheapest form: v_maximum3_f32 chain on the raw scores (scale > 0), halves exchanged by v_permlane32_swap, log2 domain.
-//   Both: the row sums l of plain bf16 come from the MATRIX pipe, which has slack there -- one extra MFMA per k-step with an
-//     all-ones A operand (L^T += 1 P^T: every accumulator register of a lane is its query's sum, of exactly the rounded P that
-//     enters O; no exchange between the halves at the end) instead of 16 v_add_f32 per tile; QB = 2 (plain bf16, R > 128): a
-//     wave owns two 32-query blocks, so every K / V fragment read from LDS feeds two blocks (half the LDS reads, barriers and
-//     DMA requests per flop) and one block's softmax can issue under the other's MFMAs.
+//   PRESCALED q (rnamsm_col_attn16_prescaled, what the forward runs in the bf16 modes): the QKV epilogue multiplies the q columns by
+//     scale * log2(e) before it rounds them, so the scores arrive in the log2 domain and p = v_exp_f32(s): no fma, no reference, no
+//     pre-pass -- 16 exp, 16 adds and 8 v_cvt_pk per 32-key tile and query block.
+//   QB = 2 (plain bf16, R >= 256): a wave owns two 32-query blocks, so every K / V fragment read from LDS feeds two blocks (half
+//     the LDS reads, barriers and DMA requests per flop) and one block's softmax can issue under the other's MFMAs.
+//   (Row sums on the matrix pipe -- L^T += 1 P^T, one all-ones MFMA per k-step instead of 16 v_add_f32 per tile -- were built and
+//     measured: +8 MFMAs on the pipe that is already the busier one (60 %) and 32 more registers; 4.25 against 3.83 ms at
+//     M = L = 1024 once the addressing was trimmed.  Dropped; EXPERIMENTS.md R4.1.)
 // K / V chunks ride a three-deep LDS ring two chunks ahead of the compute (counted vmcnt).  The V^T reads are inline asm
 // (tile16.h: tr16_issue): behind the builtin hipcc drains every LDS-DMA in flight, which had made the round-3 ring synchronous.
 // The context leaves through LDS as whole 128-byte rows (16-byte stores, 8 lanes per row) instead of 8-byte pieces at a row stride.
@@ -59,6 +62,22 @@ __device__ __forceinline__ float max16(const f32x16& s) {
     return mx;
 }
 
+// acc += the eight bf16 values of a P fragment, in fp32: four v_dot2c_f32_bf16 against (1, 1) in ONE asm statement (hipcc cannot
+// select the builtin on gfx950, and pads every asm boundary).  Plain bf16 sums the ROUNDED P with it -- the values that enter
+// O^T += V^T P^T -- so that O / l stays exact where one key takes all the weight (a P of 2^k (1 + eps) rounds by up to 2^-9; with
+// the running maximum gone P is no longer 1.0 there, and a sum of the unrounded values showed as 3e-4 relative in
+// test_col_attention_16bit_selects_the_right_value_rows) -- in half the instructions of sixteen v_add_f32.
+typedef unsigned u32x4c __attribute__((ext_vector_type(4)));
+template <class V8T>
+__device__ __forceinline__ float sum8_bf16(const V8T& p, float acc) {
+    const u32x4c u = __builtin_bit_cast(u32x4c, p);
+    const unsigned ones = 0x3f803f80u;
+    asm("v_dot2c_f32_bf16 %0, %1, %5\n\tv_dot2c_f32_bf16 %0, %2, %5\n\tv_dot2c_f32_bf16 %0, %3, %5\n\tv_dot2c_f32_bf16 %0, %4, %5"
+        : "+v"(acc)
+        : "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]), "v"(ones));
+    return acc;
+}
+
 template <int SPLIT, int QB>
 struct C16Cfg {
     static constexpr int NPL = SPLIT == 3 ? 2 : 1;
@@ -74,17 +93,20 @@ struct C16Cfg {
 
 // MASKED: f2 padding mask (scores of padded keys of this column become -10000 after scaling, modules.py:911-915); the
 // un-masked instances carry no mask code.  FAST: see the header (requires bf16 operands and no mask).
-template <int SPLIT, int FMT, int OUT, int QB, bool MASKED, bool FAST>
-__global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
+// PRE (FAST only): q arrives PRESCALED by scale * log2(e) (the QKV GEMM's epilogue multiplies the q columns before it rounds them:
+// no second rounding) -- the scores are log2-domain already and p = v_exp_f32(s): not even the fma, no reference, no pre-pass.  A
+// row sum outside [2^-96, 2^96] (or not finite) sends the block to the TRACKED loop as before.
+template <int SPLIT, int FMT, int OUT, int QB, bool MASKED, bool FAST, bool PRE>
+__global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kernel(
     const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
     const uint16_t* __restrict__ klo, const uint16_t* __restrict__ vhi, const uint16_t* __restrict__ vlo, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo,
     float scale, const uint8_t* __restrict__ pad_mask, int64_t qkv_bstride, int64_t ctx_bstride, int64_t mask_bstride,
     int force_tracked) {
     static_assert(!FAST || (FMT == 0 && !MASKED), "the FAST loop needs bf16's exponent range and no -10000 scores");
+    static_assert(!PRE || FAST, "prescaled q is the FAST loop's input");
     using Cfg = C16Cfg<SPLIT, QB>;
     constexpr int NPL = Cfg::NPL, JC = Cfg::JC, TILE = Cfg::TILE, BUF = Cfg::BUF;
-    constexpr bool ONES = SPLIT == 1;             // row sums on the matrix pipe (plain bf16: it has slack; the hi/lo modes are MFMA-bound)
     // TRACKED loop: P is kept as 2^12 exp(s - m) so that the fp16 lo plane of every P that matters stays normal
     constexpr float SHIFT = FMT == 1 ? 12.f : 0.f;
     // batched launch (rnamsm_forward_batch, 16-bit modes): MSA blockIdx.y
@@ -130,12 +152,19 @@ __global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
     // last key: their scores are masked to -inf and their V values only meet P = 0.
     const int drow = lane >> 3;
     const int ck = dma_chunk_k(lane, wave), ct = dma_chunk_t(lane);
+    // a lane's source offsets within chunk 0 (halves), a chunk on = JC alignment rows: one 64-bit add per request in the loop;
+    // only the last chunk of a ragged column clamps its rows (a multiply per request, once per block)
+    int64_t krow[JC / 32];
+#pragma unroll
+    for (int j = 0; j < JC / 32; ++j) krow[j] = (int64_t)(8 * (wave + 4 * j) + drow) * C * ld + col_off;
+    const int64_t chunk_stride = (int64_t)JC * C * ld;
     auto issue = [&](int ch, int buf) {
         char* base = smem_b + buf * BUF;
+        const bool ragged = (ch + 1) * JC > R;                 // block-uniform
 #pragma unroll
         for (int j = 0; j < JC / 32; ++j) {
             const int row = 8 * (wave + 4 * j) + drow;
-            const int64_t ko = (int64_t)min(ch * JC + row, R - 1) * C * ld + col_off;
+            const int64_t ko = ragged ? (int64_t)min(ch * JC + row, R - 1) * C * ld + col_off : krow[j] + ch * chunk_stride;
             const int loff = (8 * (wave + 4 * j)) * T16_ROWB;
 #pragma unroll
             for (int p = 0; p < NPL; ++p) {
@@ -145,15 +174,19 @@ __global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
         }
     };
 
-    f32x16 o0[QB], o1[QB], la[QB];       // O^T tiles: head dims [0,32) and [32,64) x 32 query rows; la: the row sums (ONES)
+    f32x16 o0[QB], o1[QB];               // O^T tiles: head dims [0,32) and [32,64) x 32 query rows
     float m_run[QB], l_run[QB];          // log2 units (score * scale * log2e); FAST: m_run is the fixed reference
-    V8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (Hh)1.0f;
-
-    const float c2 = scale * C16_LOG2E;                      // raw score -> log2 units
+    const float c2 = PRE ? 1.f : scale * C16_LOG2E;          // raw score -> log2 units (PRE: q carries the factor already)
     const float zmask = -10000.f / scale;                    // a masked score in raw units (-10000 after scaling)
     const int tq = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);    // transposed-read geometry
+    // byte offset of this lane's transposed-read address inside a V tile for rows 4 lh + tq (+ 16 ks, + 8, + 32 jt: multiples of 8
+    // rows leave the row swizzle alone) and d tile dt
+    uint32_t vbase[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const int row = 4 * lh + tq, col = dt * 32 + tcol;
+        vbase[dt] = row * T16_ROWB + (((col >> 3) ^ swz_t(row)) << 4) + (col & 7) * 2;
+    }
 
     // one 32-key tile.  RAG (compile-time): the ragged last tile, whose keys >= R are masked out.  TRK: TRACKED arithmetic.
     auto tile = [&](const char* Kc, const char* Vc, int jt, int jbase, auto rag_tag, auto trk_tag) {
@@ -163,15 +196,20 @@ __global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int p = 0; p < NPL; ++p) kf[kk][p] = frag_k<FMT>(Kc + p * TILE, jt * 32 + li, kk, lh);
-        // V^T fragments of this tile, requested now (asm: tile16.h) and waited for after the softmax
+        // V^T fragments of this tile, requested now (asm: tile16.h) and waited for after the softmax.  A lane's address =
+        // (its row / swizzled column within an 8-row group: vbase[d tile], fixed for the kernel) + slot + a compile-time offset
+        // (tile, k-step, second 4-key block, plane): one v_add per d tile and chunk instead of one per request
         TrPieces vp[2][2][NPL];          // [d tile][k step][plane]
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ra = jt * 32 + 16 * ks + 4 * lh + tq;
+        for (int dt = 0; dt < 2; ++dt) {
+            const uint32_t va = lds_addr_of(Vc) + vbase[dt];
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) vp[dt][ks][p] = tr16_issue(Vc + p * TILE, ra, ra + 8, dt * 32 + tcol);
+                for (int p = 0; p < NPL; ++p) {
+                    if (jt == 0) tr16_issue_at<0>(va, ks * 16 * T16_ROWB + p * TILE, vp[dt][ks][p]);
+                    else tr16_issue_at<32 * T16_ROWB>(va, ks * 16 * T16_ROWB + p * TILE, vp[dt][ks][p]);
+                }
         }
         // ---- S^T = K Q^T: 32 keys x 32 queries per block, k = 64 head dims
         f32x16 s[QB];
@@ -212,12 +250,7 @@ __global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
                 m_run[qb] = m_new;
 #pragma unroll
                 for (int t = 0; t < 16; ++t) { o0[qb][t] *= alpha; o1[qb][t] *= alpha; }
-                if (ONES) {
-#pragma unroll
-                    for (int t = 0; t < 16; ++t) la[qb][t] *= alpha;
-                } else {
-                    l_run[qb] *= alpha;
-                }
+                l_run[qb] *= alpha;
                 nm = SHIFT - m_new;
             } else {
                 nm = -m_run[qb];
@@ -225,22 +258,23 @@ __global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
             float psum = 0.f;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                s[qb][t] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][t], c2, nm));
-                if (!ONES) psum += s[qb][t];
+                s[qb][t] = (PRE && !TRK) ? __builtin_amdgcn_exp2f(s[qb][t]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][t], c2, nm));
+                if (SPLIT == 3) psum += s[qb][t];           // hi + lo carries P to 2^-17 / 2^-22: the fp32 values serve
             }
-            if (!ONES) l_run[qb] += psum;
+            if (SPLIT == 3) l_run[qb] += psum;
             // ---- P fragments: registers 8ks..8ks+7 -> halves (hi, and lo = P - hi)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float pv = s[qb][8 * ks + e];
+                    const float pv = SPLIT == 3 ? pinned(s[qb][8 * ks + e]) : s[qb][8 * ks + e];
                     const Hh hi = (Hh)pv;
                     pf[qb][ks][0][e] = hi;
                     if (SPLIT == 3) pf[qb][ks][NPL - 1][e] = (Hh)(pv - (float)hi);
                 }
+            if (SPLIT == 1) l_run[qb] = sum8_bf16(pf[qb][1][0], sum8_bf16(pf[qb][0][0], l_run[qb]));     // the rounded P (see sum8_bf16)
         }
-        // ---- O^T += V^T P^T (and L^T += 1 P^T)
+        // ---- O^T += V^T P^T
 #pragma unroll
         for (int p = 0; p < NPL; ++p) tr16_wait4(vp[0][0][p], vp[0][1][p], vp[1][0][p], vp[1][1][p]);
         V8 vf[2][2][NPL];
@@ -256,7 +290,6 @@ __global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
             for (int ks = 0; ks < 2; ++ks) {
                 o0[qb] = mma16<SPLIT, FMT>(vf[0][ks], pf[qb][ks], o0[qb]);
                 o1[qb] = mma16<SPLIT, FMT>(vf[1][ks], pf[qb][ks], o1[qb]);
-                if (ONES) la[qb] = Half16<FMT>::mfma(ones, pf[qb][ks][0], la[qb]);
             }
     };
     typedef std::integral_constant<bool, false> no_t;
@@ -293,14 +326,14 @@ __global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) { o0[qb][t] = 0.f; o1[qb][t] = 0.f; la[qb][t] = 0.f; }
+            for (int t = 0; t < 16; ++t) { o0[qb][t] = 0.f; o1[qb][t] = 0.f; }
             m_run[qb] = -INFINITY;
             l_run[qb] = 0.f;
         }
         const int nch = (R + JC - 1) / JC, nfull = R / JC;
         issue(0, 0);
         issue(min(1, nch - 1), 1);
-        if (!TRK) {
+        if (!TRK && !PRE) {
             wait_dma_then_barrier<Cfg::NDMA>();      // chunk 0 has landed
             reference_from_first_tile(smem_b);
         }
@@ -335,10 +368,7 @@ __global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
         }
         wait_dma_then_barrier<0>();          // the redundant reloads have landed, every wave is done with the ring
     };
-    auto row_sum = [&](int qb) -> float {
-        if (ONES) return la[qb][0];
-        return l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
-    };
+    auto row_sum = [&](int qb) -> float { return l_run[qb] + __shfl_xor(l_run[qb], 32, 64); };
 
     // (the context store is a lambda called on each path's own exit: merging the two loops' accumulators at a common epilogue
     // would cost a second copy of all of them in registers)
@@ -364,8 +394,9 @@ __global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
                     H4 ah, al, bh, bl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        ah[e] = (Ho)a[e]; al[e] = (Ho)(a[e] - (float)ah[e]);
-                        bh[e] = (Ho)b[e]; bl[e] = (Ho)(b[e] - (float)bh[e]);
+                        const float av = pinned(a[e]), bv = pinned(b[e]);
+                        ah[e] = (Ho)av; al[e] = (Ho)(av - (float)ah[e]);
+                        bh[e] = (Ho)bv; bl[e] = (Ho)(bv - (float)bh[e]);
                     }
                     *reinterpret_cast<H4*>(stg + li * 144 + d * 2) = ah;
                     *reinterpret_cast<H4*>(stg + li * 144 + (32 + d) * 2) = bh;
@@ -408,7 +439,7 @@ __global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
         bool bad = false;
         if (active) {
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) bad = bad || !(row_sum(qb) < C16_OVERFLOW);
+            for (int qb = 0; qb < QB; ++qb) bad = bad || !(row_sum(qb) < C16_OVERFLOW) || (PRE && !(row_sum(qb) > 1.f / C16_OVERFLOW));
         }
         int* flags = reinterpret_cast<int*>(smem_b + Cfg::RING);
         const int wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
@@ -425,225 +456,19 @@ __global__ __launch_bounds__(C16_THREADS, 2) void col_attn16_kernel(
     store_context();
 }
 
-// ---- the round-3 kernel, kept for A/B during round 4 (knob "attn16" = 3) -------------------------------------------------
-constexpr int C16R3_ROWS = 128;                  // query rows per block (4 waves x 32)
-// keys per chunk JC: 64 (two 32-key tiles per barrier) for plain bf16, 32 for the hi/lo modes -- their four planes per
-// chunk would otherwise cost 64 KB of LDS per block and cap the CU at two blocks; at 32 KB three fit (the registers'
-// limit), and this kernel lives on occupancy: one problem's loop is shorter than the fixed cost around it (strided q
-// rows, first chunk, output stores), which only other resident blocks can hide.
-
-// MASKED: f2 padding mask (scores of padded keys of this column become -10000 after scaling, modules.py:911-915); the
-// un-masked instances carry no mask code.
-template <int SPLIT, int FMT, int OUT, int JC, bool MASKED>
-__global__ __launch_bounds__(C16_THREADS, JC == 32 ? 3 : 2) void col_attn16_r3_kernel(
-    const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
-    const uint16_t* __restrict__ klo, const uint16_t* __restrict__ vhi, const uint16_t* __restrict__ vlo, int64_t ld,
-    float* __restrict__ ctx, int64_t ldc, int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo,
-    float scale, const uint8_t* __restrict__ pad_mask, int64_t qkv_bstride, int64_t ctx_bstride, int64_t mask_bstride) {
-    constexpr int NPL = SPLIT == 3 ? 2 : 1;
-    // batched launch (rnamsm_forward_batch, 16-bit modes): MSA blockIdx.y
-    qhi += blockIdx.y * qkv_bstride; khi += blockIdx.y * qkv_bstride; vhi += blockIdx.y * qkv_bstride;
-    if (qlo) { qlo += blockIdx.y * qkv_bstride; klo += blockIdx.y * qkv_bstride; vlo += blockIdx.y * qkv_bstride; }
-    if (ctx) ctx += blockIdx.y * ctx_bstride;
-    if (ctx_hi) ctx_hi += blockIdx.y * ctx_bstride;
-    if (ctx_lo) ctx_lo += blockIdx.y * ctx_bstride;
-    if (MASKED) pad_mask += blockIdx.y * mask_bstride;
-    constexpr int C16_JC = JC;
-    constexpr int C16_TILE = JC * T16_ROWB;            // bytes per plane tile
-    constexpr int BUF = 2 * NPL * C16_TILE;            // K planes then V planes
-    typedef typename Half16<FMT>::T Hh;
-    typedef typename Half16<FMT>::V8 V8;
-    extern __shared__ __attribute__((aligned(16))) char smem_b[];
-
-    const unsigned iblocks = (R + C16R3_ROWS - 1) / C16R3_ROWS;
-    unsigned prob, ib;
-    if (!xcd_panel_map(blockIdx.x, (unsigned)C * H, iblocks, prob, ib)) return;
-    const int c = prob / H, h = prob % H;
-
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int li = lane & 31, lh = lane >> 5;
-    const int irow0 = ib * C16R3_ROWS + wave * 32;
-    const bool active = irow0 < R;                             // wave-uniform
-    const int64_t col_off = (int64_t)c * ld + h * 64;          // + r*C*ld selects the alignment row
-
-    const uint16_t* qpl[2] = {qhi, qlo};
-    const uint16_t* kpl[2] = {khi, klo};
-    const uint16_t* vpl[2] = {vhi, vlo};
-
-    // Q fragment (B operand of S^T = K Q^T): lane (query i, half) holds q[i][16kk + 8*half + 0..7]
-    V8 qf[4][NPL];
-    {
-        const int qi = min(irow0 + li, R - 1);
-        const int64_t qo = (int64_t)qi * C * ld + col_off + 8 * lh;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) qf[kk][p] = *reinterpret_cast<const V8*>(qpl[p] + qo + 16 * kk);
-    }
-
-    // DMA map: a plane tile is 8 groups of 8 key rows; wave w moves groups w and w+4.  Keys past R are clamped to the
-    // last key: their scores are masked to -inf and their V values only meet P = 0.
-    const int drow = lane >> 3;
-    const int ck = dma_chunk_k(lane, wave), ct = dma_chunk_t(lane);
-    auto issue = [&](int ch, int buf) {
-        char* base = smem_b + buf * BUF;
-#pragma unroll
-        for (int j = 0; j < JC / 32; ++j) {
-            const int row = 8 * (wave + 4 * j) + drow;
-            const int64_t ko = (int64_t)min(ch * C16_JC + row, R - 1) * C * ld + col_off;
-            const int loff = (8 * (wave + 4 * j)) * T16_ROWB;
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) {
-                dma16(kpl[p] + ko + ck * 8, base + p * C16_TILE + loff);
-                dma16(vpl[p] + ko + ct * 8, base + (NPL + p) * C16_TILE + loff);
-            }
-        }
-    };
-
-    f32x16 o0, o1;                       // O^T tiles: head dims [0,32) and [32,64) x 32 query rows
-#pragma unroll
-    for (int t = 0; t < 16; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-
-    const int tq = (lane & 15) >> 2, tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);    // transposed-read geometry
-
-    auto tile = [&](const char* Kc, const char* Vc, int jt, int jbase) {
-        // ---- S^T = K Q^T: 32 keys x 32 queries, k = 64 head dims
-        f32x16 s;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) s[t] = 0.f;
-        V8 kf[4][NPL];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) kf[kk][p] = frag_k<FMT>(Kc + p * C16_TILE, jt * 32 + li, kk, lh);
-        // V^T fragments of this tile, requested before the MFMAs that hide them
-        V8 vf[2][2][NPL];                // [d tile][k step][plane]
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ra = jt * 32 + 16 * ks + 4 * lh + tq;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int p = 0; p < NPL; ++p)
-                    vf[dt][ks][p] = frag_t<FMT>(Vc + p * C16_TILE, ra, ra + 8, dt * 32 + tcol);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) s = mma16<SPLIT, FMT>(kf[kk], qf[kk], s);
-        // ---- online softmax (fp32): keys >= R masked branch-free; __expf = v_exp_f32(x * log2e)
-        const int limit = R - jbase;
-        if (limit < 32) {        // block-uniform: only a ragged last tile holds keys >= R
-#pragma unroll
-            for (int t = 0; t < 16; ++t)
-                s[t] = ((t & 3) + 8 * (t >> 2) + 4 * lh < limit) ? s[t] * scale : -INFINITY;
-        } else {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) s[t] *= scale;
-        }
-        if (MASKED) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int j = jbase + (t & 3) + 8 * (t >> 2) + 4 * lh;
-                if (j < R && pad_mask[(int64_t)j * C + c]) s[t] = -10000.f;
-            }
-        }
-        float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);                    // finite: key jbase is valid
-        const float alpha = __expf(m_run - m_new);               // 0 on the first tile
-        // P is kept as exp(s - m) * 2^12 (the max shifted by 12 ln 2): the running sum carries the same factor, so
-        // O / l is unchanged, and the fp16 lo plane of P stays out of subnormals for every P that matters.
-        const float m_shift = m_new - 8.317766167f;
-        float psum = 0.f;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            s[t] = __expf(s[t] - m_shift);
-            psum += s[t];
-        }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
-        // ---- P fragments: registers 8ks..8ks+7 -> halves (hi, and lo = P - hi)
-        V8 pf[2][NPL];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float pv = s[8 * ks + e];
-                const Hh hi = (Hh)pv;
-                pf[ks][0][e] = hi;
-                if (SPLIT == 3) pf[ks][NPL - 1][e] = (Hh)(pv - (float)hi);
-            }
-        // ---- O^T += V^T P^T
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            o0 = mma16<SPLIT, FMT>(vf[0][ks], pf[ks], o0);
-            o1 = mma16<SPLIT, FMT>(vf[1][ks], pf[ks], o1);
-        }
-    };
-
-    const int nch = (R + C16_JC - 1) / C16_JC;
-    issue(0, 0);
-    for (int ch = 0; ch < nch; ++ch) {
-        wait_dma_then_barrier<0>();      // chunk ch has landed (every wave's share), the other buffer is free again
-        if (ch + 1 < nch) issue(ch + 1, (ch + 1) & 1);
-        if (active) {
-            const char* Kc = smem_b + (ch & 1) * BUF;
-            const char* Vc = Kc + NPL * C16_TILE;
-            const int jbase = ch * C16_JC;
-            tile(Kc, Vc, 0, jbase);
-            if (JC == 64 && jbase + 32 < R) tile(Kc, Vc, 1, jbase + 32);     // block-uniform
-        }
-    }
-
-    if (active) {
-        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const float inv = 1.f / l_tot;
-        const int i = irow0 + li;
-        if (i < R) {
-            const int64_t ooff = ((int64_t)i * C + c) * ldc + h * 64 + 4 * lh;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {      // registers 4g..4g+3 are head dims 8g + 4*half + {0..3}
-                const f32x4 a = f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
-                const f32x4 b = f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
-                if (OUT == 0) {
-                    *reinterpret_cast<f32x4*>(ctx + ooff + 8 * g) = a;
-                    *reinterpret_cast<f32x4*>(ctx + ooff + 32 + 8 * g) = b;
-                } else {
-                    typedef typename Half16<(OUT > 0 ? OUT - 1 : 0)>::T Ho;
-                    typedef Ho H4 __attribute__((ext_vector_type(4)));
-                    H4 ah, al, bh, bl;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ah[e] = (Ho)a[e]; al[e] = (Ho)(a[e] - (float)ah[e]);
-                        bh[e] = (Ho)b[e]; bl[e] = (Ho)(b[e] - (float)bh[e]);
-                    }
-                    *reinterpret_cast<H4*>(ctx_hi + ooff + 8 * g) = ah;
-                    *reinterpret_cast<H4*>(ctx_hi + ooff + 32 + 8 * g) = bh;
-                    if (ctx_lo) {
-                        *reinterpret_cast<H4*>(ctx_lo + ooff + 8 * g) = al;
-                        *reinterpret_cast<H4*>(ctx_lo + ooff + 32 + 8 * g) = bl;
-                    }
-                }
-            }
-        }
-    }
-}
 }  // namespace rnamsm
 
 using namespace rnamsm;
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <int SP, int FMT, int OUT, int QB, bool MASK, bool FAST>
+template <int SP, int FMT, int OUT, int QB, bool MASK, bool FAST, bool PRE>
 static int col16_go(unsigned grid, int batch, hipStream_t s, const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi,
                     const uint16_t* k_lo, const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C,
                     int H, uint16_t* ctx_hi, uint16_t* ctx_lo, float scale, const uint8_t* pad_mask, int64_t qkv_bstride,
                     int64_t ctx_bstride, int64_t mask_bstride, int force_tracked) {
     static DeviceOnce cfg;
-    auto kern = col_attn16_kernel<SP, FMT, OUT, QB, MASK, FAST>;
+    auto kern = col_attn16_kernel<SP, FMT, OUT, QB, MASK, FAST, PRE>;
     constexpr int lds = C16Cfg<SP, QB>::LDS;
     if (cfg.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -658,8 +483,9 @@ static int col16_go(unsigned grid, int batch, hipStream_t s, const uint16_t* q_h
 static int col_attn16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
                              const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
                              int head_dim, float scale, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt,
-                             void* stream, int batch, int64_t qkv_bstride, int64_t ctx_bstride, int64_t mask_bstride) {
+                             void* stream, int batch, int64_t qkv_bstride, int64_t ctx_bstride, int64_t mask_bstride, bool prescaled = false) {
     RNAMSM_CHECK_ARG(batch >= 1 && batch <= 65535 && qkv_bstride % 8 == 0 && ctx_bstride % 4 == 0, "col_attn16: bad batch / strides");
+    RNAMSM_CHECK_ARG(!prescaled || (fmt == 0 && !pad_mask), "col_attn16_prescaled: bf16 operand formats without a padding mask only");
     RNAMSM_CHECK_ARG(q_hi && k_hi && v_hi && (ctx || ctx_hi), "col_attn16: null pointer");
     RNAMSM_CHECK_ARG((q_lo == nullptr) == (k_lo == nullptr) && (q_lo == nullptr) == (v_lo == nullptr),
                      "col_attn16: the lo planes must all be given (x3) or all be null");
@@ -675,47 +501,13 @@ static int col_attn16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const u
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int npl = q_lo ? 2 : 1;
     const int var = tuning().attn16;
-    // vector-ALU instructions per score (a transcendental counts 4): FAST 1 fma + exp + 1/2 cvt_pk = 5.5; TRACKED adds the maximum
-    // (v_maximum3: 1/2) and the rescale of O and l (2-3); the hi/lo modes the lo half of P (sub + 1/2 cvt) and the row sum (1);
-    // the round-3 kernel ("attn16" = 3): mul, sub, mul + exp, add, max, 1/2 cvt, 2 rescale = 11.5
-    const bool fast_loop = fmt == 0 && !pad_mask && var != 5 && var != 3;
-    const double per_score = var == 3 ? 11.5 + (q_lo ? 1.5 : 0.0) : 5.5 + (fast_loop ? 0.0 : (q_lo ? 2.5 : 3.5)) + (q_lo ? 2.5 : 0.0);
-    // matrix flops executed: the row sums of plain bf16 ride the matrix pipe (one all-ones MFMA per k-step: + 1/8)
+    // vector-ALU instructions per score (a transcendental counts 4): exp 4 + 1/2 v_cvt_pk + 1/2 v_dot2c (row sum) = 5, + 1 fma when q
+    // is not prescaled; TRACKED adds the maximum (v_maximum3: 1/2) and the rescale of O (2); the hi/lo modes the lo half of P
+    // (sub + 1/2 cvt) and an fp32 add instead of the dot2c (+ 1/2)
+    const bool fast_loop = fmt == 0 && !pad_mask && var != 5;
+    const double per_score = (prescaled ? 5.0 : 6.0) + (fast_loop ? 0.0 : 2.5) + (q_lo ? 2.0 : 0.0);
     KernelTimer timer(TC_COL_ATTN, 4.0 * batch * C * H * (double)R * R * 64, batch * (2.0 * npl * 3.0 + (ctx_hi ? 2.0 * npl : 4.0)) * R * C * H * 64, s,
-                      PEAK_F16_MFMA_TFLOPS, q_lo ? 3.0 : (var == 3 ? 1.0 : 1.125), per_score * batch * C * H * (double)R * R);
-    if (var == 3) {
-        const unsigned iblocks = (R + C16R3_ROWS - 1) / C16R3_ROWS;
-        const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
-        const int jc = q_lo ? 32 : 64;
-        const int lds = 2 * 2 * npl * jc * T16_ROWB;
-#define CA3_GO(SP_, FMT_, OUT_)                                                                                      \
-    do {                                                                                                            \
-        if (pad_mask) CA3_GO2(SP_, FMT_, OUT_, true); else CA3_GO2(SP_, FMT_, OUT_, false);                           \
-    } while (0)
-#define CA3_GO2(SP_, FMT_, OUT_, MASK_)                                                                              \
-    do {                                                                                                            \
-        static DeviceOnce cfg_;                                                                                   \
-        if (cfg_.pending()) {                                                                                                \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn16_r3_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64), MASK_>),   \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);                    \
-            if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn16: hipFuncSetAttribute: %s", hipGetErrorString(e)); \
-            cfg_.mark();                                                                                            \
-        }                                                                                                           \
-        hipLaunchKernelGGL((col_attn16_r3_kernel<SP_, FMT_, OUT_, (SP_ == 3 ? 32 : 64), MASK_>), dim3(grid, batch), dim3(C16_THREADS), lds, s, q_hi, q_lo, k_hi, \
-                           k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, scale, pad_mask, qkv_bstride, ctx_bstride, mask_bstride); \
-    } while (0)
-        if (!q_lo) {
-            if (ctx_hi) CA3_GO(1, 0, 1); else CA3_GO(1, 0, 0);
-        } else if (fmt == 0) {
-            if (ctx_hi) CA3_GO(3, 0, 1); else CA3_GO(3, 0, 0);
-        } else {
-            if (ctx_hi) CA3_GO(3, 1, 2); else CA3_GO(3, 1, 0);
-        }
-#undef CA3_GO
-#undef CA3_GO2
-        RNAMSM_CHECK_LAUNCH("col_attn16");
-        return RNAMSM_OK;
-    }
+                      PEAK_F16_MFMA_TFLOPS, q_lo ? 3.0 : 1.0, per_score * batch * C * H * (double)R * R);
     // two query blocks per wave (256-query blocks) for plain bf16 without a mask when that adds no idle query rows; bf16
     // operands without a mask take the FAST loop ("attn16" = 4: one query block per wave, 5: TRACKED loop only; A/B and tests)
     const bool qb2 = !q_lo && !pad_mask && var != 4 && (R + 255) / 256 * 256 <= (R + 127) / 128 * 128;
@@ -724,10 +516,13 @@ static int col_attn16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const u
     const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
     int rc;
 #define CA_ARGS grid, batch, s, q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, scale, pad_mask, qkv_bstride, ctx_bstride, mask_bstride, force_tracked
+    // (SP, FMT, OUT, QB) x mask x {plain, prescaled}
 #define CA_GO(SP_, FMT_, OUT_, QB_)                                                                                   \
     do {                                                                                                              \
-        if (pad_mask) rc = col16_go<SP_, FMT_, OUT_, QB_, true, false>(CA_ARGS);                                      \
-        else rc = col16_go<SP_, FMT_, OUT_, QB_, false, FMT_ == 0>(CA_ARGS);                                          \
+        constexpr bool F_ = FMT_ == 0;                                                                                \
+        if (pad_mask) rc = col16_go<SP_, FMT_, OUT_, QB_, true, false, false>(CA_ARGS);                               \
+        else rc = prescaled ? col16_go<SP_, FMT_, OUT_, QB_, false, F_, F_>(CA_ARGS)                                  \
+                            : col16_go<SP_, FMT_, OUT_, QB_, false, F_, false>(CA_ARGS);                              \
     } while (0)
     if (!q_lo) {
         if (qb2) { if (ctx_hi) CA_GO(1, 0, 1, 2); else CA_GO(1, 0, 0, 2); }
@@ -751,12 +546,18 @@ extern "C" int rnamsm_col_attn16(const uint16_t* q_hi, const uint16_t* q_lo, con
     return col_attn16_launch(q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H, head_dim, scale, pad_mask, ctx_hi, ctx_lo, fmt, stream,
                              1, 0, 0, 0);
 }
+extern "C" int rnamsm_col_attn16_prescaled(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo,
+                                           const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R,
+                                           int C, int H, int head_dim, uint16_t* ctx_hi, uint16_t* ctx_lo, void* stream) {
+    return col_attn16_launch(q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H, head_dim, 1.f, nullptr, ctx_hi, ctx_lo, 0, stream,
+                             1, 0, 0, 0, true);
+}
 namespace rnamsm {
 int col_attn16_batched(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo, const uint16_t* v_hi,
                        const uint16_t* v_lo, int64_t ld, int64_t ldc, int R, int C, int H, float scale, const uint8_t* pad_mask,
                        uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, int batch, int64_t qkv_bstride, int64_t ctx_bstride, int64_t mask_bstride,
-                       void* stream) {
+                       void* stream, bool prescaled) {
     return col_attn16_launch(q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, ld, nullptr, ldc, R, C, H, 64, scale, pad_mask, ctx_hi, ctx_lo, fmt, stream,
-                             batch, qkv_bstride, ctx_bstride, mask_bstride);
+                             batch, qkv_bstride, ctx_bstride, mask_bstride, prescaled);
 }
 }  // namespace rnamsm

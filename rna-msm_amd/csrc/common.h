@@ -318,7 +318,7 @@ int row_apply16_batched(const uint16_t* p_hi, const uint16_t* p_lo, int64_t ldp,
 int col_attn16_batched(const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi, const uint16_t* k_lo, const uint16_t* v_hi,
                        const uint16_t* v_lo, int64_t ld, int64_t ldc, int R, int C, int H, float scale, const uint8_t* pad_mask,
                        uint16_t* ctx_hi, uint16_t* ctx_lo, int fmt, int batch, int64_t qkv_bstride, int64_t ctx_bstride, int64_t mask_bstride,
-                       void* stream);
+                       void* stream, bool prescaled = false);
 
 // ragged batches (elementwise.hip): per-token q factor (0 at <pad>, 1/sqrt(true depth of the token's MSA) elsewhere), applied
 // to the q columns in the QKV GEMM's epilogue (rnamsm_gemm_row_scaled)
@@ -330,7 +330,7 @@ int ragged_row_scale(const int64_t* tokens, int pad_idx, const int* true_rows, f
 // probs_all + b * probs_bstride.  pack_outputs sets bit 2 of *err_flag (RNAMSM_ERR_NONFINITE) when an output is inf / NaN.
 int embed_ln_batched(const int64_t* tokens, const float* embed_tokens, const float* embed_positions, const float* row_pos,
                      const float* gamma, const float* beta, float* out, int B, int R, int C, int D, int vocab, int num_positions,
-                     int pad_idx, float eps, int* err_flag, hipStream_t stream);
+                     int pad_idx, float eps, int* err_flag, hipStream_t stream, int row_pos_dim = 0);
 int pack_outputs_batched(const float* x_final, const float* probs_all, float* emb, float* atp, int C, int D, int num_layers, int H,
                          int B, int64_t x_bstride, int64_t probs_bstride, int* err_flag, hipStream_t stream);
 

@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
                                                        const float* __restrict__ row_pos,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ out, int R, int C, int D, int vocab,
-                                                       int num_positions, int pad_idx, float eps, int* err_flag, int B) {
+                                                       int num_positions, int pad_idx, float eps, int* err_flag, int B,
+                                                       int row_pos_ld) {
     // tokens [B, R, C] -> out [B*R*C, D]: the row-position table restarts with every alignment (r = global row mod R)
     const int lane = threadIdx.x & 63;
     const int nvec = D / 4;
@@ -173,7 +174,10 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
             tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
             pos = pos >= num_positions ? num_positions - 1 : pos;
         }
-        const float rp = row_pos[r];
+        // msa_position_embedding: one scalar per alignment row (model.py:293-296), or -- row_pos_ld = D -- a vector per row
+        // (msm/model.py:289-292); the scalar keeps its broadcast in a register
+        const float rp = row_pos_ld ? 0.f : row_pos[r];
+        const float* rpv = row_pos + (int64_t)r * row_pos_ld;
         f32x4 v[LN_MAX_VEC];
 #pragma unroll
         for (int e = 0; e < LN_MAX_VEC; ++e) {
@@ -181,8 +185,9 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
             if (vi < nvec) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(embed_tokens + tok * D + 4 * vi);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(embed_positions + (int64_t)pos * D + 4 * vi);
+                const f32x4 rv = row_pos_ld ? *reinterpret_cast<const f32x4*>(rpv + 4 * vi) : f32x4{rp, rp, rp, rp};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[e][i] = (a[i] + b[i]) + rp;     // same association as model.py:349-360
+                for (int i = 0; i < 4; ++i) v[e][i] = (a[i] + b[i]) + rv[i];     // same association as model.py:349-360
             }
         }
         if (trow[c] == pad_idx) {      // x * (1 - padding_mask) after emb_layer_norm_before (model.py:366-367)
@@ -325,19 +330,38 @@ extern "C" int rnamsm_embed_ln(const int64_t* tokens, const float* embed_tokens,
     RNAMSM_CHECK_ARG(aligned16(embed_tokens) && aligned16(embed_positions) && aligned16(out) && aligned16(gamma) && aligned16(beta),
                      "embed_ln: 16-byte alignment");
     return embed_ln_batched(tokens, embed_tokens, embed_positions, row_pos, gamma, beta, out, 1, R, C, D, vocab, num_positions,
-                            pad_idx, eps, err_flag, static_cast<hipStream_t>(stream));
+                            pad_idx, eps, err_flag, static_cast<hipStream_t>(stream), 0);
+}
+
+extern "C" int rnamsm_embed_ln_rows(const int64_t* tokens, const float* embed_tokens, const float* embed_positions,
+                                    const float* row_pos, int row_pos_dim, const float* gamma, const float* beta, float* out,
+                                    int R, int C, int D, int vocab, int num_positions, int pad_idx, float eps, int* err_flag,
+                                    void* stream) {
+    RNAMSM_CHECK_ARG(row_pos_dim == 0 || row_pos_dim == 1 || row_pos_dim == D, "embed_ln_rows: row_pos_dim must be 0, 1 or D (got %d)", row_pos_dim);
+    if (row_pos_dim <= 1)
+        return rnamsm_embed_ln(tokens, embed_tokens, embed_positions, row_pos, gamma, beta, out, R, C, D, vocab, num_positions, pad_idx,
+                               eps, err_flag, stream);
+    RNAMSM_CHECK_ARG(tokens && embed_tokens && embed_positions && row_pos && gamma && beta && out, "embed_ln_rows: null pointer");
+    RNAMSM_CHECK_ARG(R > 0 && C > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_VEC, "embed_ln_rows: bad shape R=%d C=%d D=%d", R, C, D);
+    if (R > 1024)   // msm/model.py:341-345
+        return fail(RNAMSM_ERR_INVALID,
+                    "Using model with MSA position embedding trained on maximum MSA depth of 1024, but received %d alignments.", R);
+    RNAMSM_CHECK_ARG(aligned16(embed_tokens) && aligned16(embed_positions) && aligned16(out) && aligned16(gamma) && aligned16(beta) && aligned16(row_pos),
+                     "embed_ln_rows: 16-byte alignment");
+    return embed_ln_batched(tokens, embed_tokens, embed_positions, row_pos, gamma, beta, out, 1, R, C, D, vocab, num_positions,
+                            pad_idx, eps, err_flag, static_cast<hipStream_t>(stream), D);
 }
 
 namespace rnamsm {
 int embed_ln_batched(const int64_t* tokens, const float* embed_tokens, const float* embed_positions, const float* row_pos,
                      const float* gamma, const float* beta, float* out, int B, int R, int C, int D, int vocab, int num_positions,
-                     int pad_idx, float eps, int* err_flag, hipStream_t stream) {
+                     int pad_idx, float eps, int* err_flag, hipStream_t stream, int row_pos_dim) {
     const int64_t T = (int64_t)B * R * C;
     // algorithmic HBM bytes: the output rows and the token ids; the two embedding tables (3.2 MB) are L2-resident, their rows are
     // not HBM reads (counting them had given this launch a "fraction of roofline" above 1)
     KernelTimer timer(TC_EMBED, 0.0, 4.0 * T * D + 8.0 * T, stream);
     hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid(T)), dim3(256), 0, stream, tokens, embed_tokens, embed_positions, row_pos,
-                       gamma, beta, out, R, C, D, vocab, num_positions, pad_idx, eps, err_flag, B);
+                       gamma, beta, out, R, C, D, vocab, num_positions, pad_idx, eps, err_flag, B, row_pos_dim > 1 ? row_pos_dim : 0);
     RNAMSM_CHECK_LAUNCH("embed_ln");
     return RNAMSM_OK;
 }

@@ -78,6 +78,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     const int D = d.embed_dim, H = d.num_heads, F = d.ffn_dim, NL = d.num_layers;
     RNAMSM_CHECK_ARG(D > 0 && H > 0 && D == H * 64, "forward: embed_dim must be num_heads * 64 (D=%d H=%d)", D, H);
     RNAMSM_CHECK_ARG(D % 128 == 0 && F % 128 == 0 && NL > 0, "forward: embed_dim and ffn_dim must be multiples of 128");
+    RNAMSM_CHECK_ARG(d.row_pos_dim == 0 || d.row_pos_dim == 1 || d.row_pos_dim == D, "forward: row_pos_dim must be 0, 1 or embed_dim (got %d)", d.row_pos_dim);
     RNAMSM_CHECK_ARG(C >= 2 && R >= 1, "forward: need R >= 1 and C >= 2 (got R=%d C=%d)", R, C);
     if (R > 1024)   // model.py:355-359
         return fail(RNAMSM_ERR_INVALID,
@@ -219,9 +220,9 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         mask = reinterpret_cast<uint8_t*>(ws + lay.mask);
         FWD(rnamsm_pad_mask(tokens, mask, T, d.pad_idx, stream));
     }
-    FWD(rnamsm_embed_ln(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
-                        G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, R, C, D, d.vocab, d.num_positions,
-                        d.pad_idx, d.ln_eps, err_flag, stream));
+    FWD(rnamsm_embed_ln_rows(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS], d.row_pos_dim,
+                             G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, R, C, D, d.vocab, d.num_positions,
+                             d.pad_idx, d.ln_eps, err_flag, stream));
     if (fold16) {                                    // K0's output as planes, with its statistics
         FWD(rnamsm_split_bf16(x, xn_hi, xn_lo, T * D, fmt, stream));
         FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
@@ -296,13 +297,20 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         // ---- column attention block
         if (!fold && !fold16) FWD(ln_for_gemm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
         if (attn16) {
+            // bf16 operand formats, no padding: q leaves the QKV epilogue PRESCALED by dh^-0.5 log2(e) (multiplied in before the
+            // rounding to 16 bits) and the column kernel exponentiates the scores as they come (rnamsm_col_attn16_prescaled)
+            const bool pre = fmt == 0 && !mask && !fold16;
             if (fold16)
                 FWD(lin16_fold(l, 1, qkv_hi, qkv_lo, ldq, 3 * D, RNAMSM_ACT_NONE));
             else
                 FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
-                              RNAMSM_ACT_NONE, 1.f, 0));
-            FWD(rnamsm_col_attn16(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C,
-                                  H, 64, col_scale, mask, ctx_hi, ctx_lo, fmt, stream));
+                              RNAMSM_ACT_NONE, pre ? col_scale * 1.4426950408889634f : 1.f, pre ? D : 0));
+            if (pre)
+                FWD(rnamsm_col_attn16_prescaled(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C,
+                                                H, 64, ctx_hi, ctx_lo, stream));
+            else
+                FWD(rnamsm_col_attn16(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C,
+                                      H, 64, col_scale, mask, ctx_hi, ctx_lo, fmt, stream));
         } else {
             if (planes)
                 FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
@@ -404,6 +412,7 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
     const int D = d.embed_dim, H = d.num_heads, F = d.ffn_dim, NL = d.num_layers;
     RNAMSM_CHECK_ARG(D > 0 && H > 0 && D == H * 64, "forward_batch: embed_dim must be num_heads * 64 (D=%d H=%d)", D, H);
     RNAMSM_CHECK_ARG(D % 128 == 0 && F % 128 == 0 && NL > 0, "forward_batch: embed_dim and ffn_dim must be multiples of 128");
+    RNAMSM_CHECK_ARG(d.row_pos_dim == 0 || d.row_pos_dim == 1 || d.row_pos_dim == D, "forward_batch: row_pos_dim must be 0, 1 or embed_dim (got %d)", d.row_pos_dim);
     RNAMSM_CHECK_ARG(B >= 1 && C >= 2 && R >= 1, "forward_batch: need B >= 1, R >= 1 and C >= 2 (got B=%d R=%d C=%d)", B, R, C);
     if (R > 1024)   // model.py:355-359
         return fail(RNAMSM_ERR_INVALID,
@@ -471,14 +480,17 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
         const int nsplit16 = rnamsm_row_logits16_nsplit(R, C, H, split);
         const int64_t part_bs = (int64_t)nsplit16 * H * C * C, probs_bs = (int64_t)NL * H * C * C;
         auto linear_pl = [&](int layer, int slot, const uint16_t* ahi, const uint16_t* alo, int64_t lda, const float* bias, const float* res,
-                             float* out, uint16_t* ohi, uint16_t* olo, int64_t ldc, int N, int K, int act) -> int {
+                             float* out, uint16_t* ohi, uint16_t* olo, int64_t ldc, int N, int K, int act, float scale = 1.f,
+                             int scale_cols = 0) -> int {
             const uint16_t* const* P = weight_planes + (size_t)layer * RNAMSM_PLANES_PER_LAYER + 2 * slot;
-            return rnamsm_gemm_bf16(nullptr, lda, P[0], P[1], bias, res, D, out, ldc, T, N, K, act, 1.f, 0, split, fmt, ahi, alo, ohi, olo,
-                                    stream);
+            return rnamsm_gemm_bf16(nullptr, lda, P[0], P[1], bias, res, D, out, ldc, T, N, K, act, scale, scale_cols, split, fmt, ahi, alo,
+                                    ohi, olo, stream);
         };
+        // bf16 operand formats, no padding: the column kernel takes q prescaled by dh^-0.5 log2(e) (see rnamsm_forward)
+        const bool pre = fmt == 0 && !mask;
         FWD(rnamsm::embed_ln_batched(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
                                      G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, B, R, C, D, d.vocab, d.num_positions, d.pad_idx,
-                                     d.ln_eps, err_flag, hs));
+                                     d.ln_eps, err_flag, hs, d.row_pos_dim));
         for (int l = 0; l < NL; ++l) {
             const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
             float* probs = row_attn + (int64_t)l * H * C * C;
@@ -495,9 +507,10 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
             FWD(linear_pl(l, 1, ctx_hi, ctx_lo, D, W[RNAMSM_WL_ROW_BO], x, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE));
             // ---- column attention
             FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
-            FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D, RNAMSM_ACT_NONE));
+            FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D, RNAMSM_ACT_NONE,
+                          pre ? col_scale * 1.4426950408889634f : 1.f, pre ? D : 0));
             FWD(rnamsm::col_attn16_batched(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, D, R, C, H, col_scale,
-                                           R > 1 ? mask : nullptr, ctx_hi, ctx_lo, fmt, B, Tm * ldq, Tm * D, Tm, stream));
+                                           R > 1 ? mask : nullptr, ctx_hi, ctx_lo, fmt, B, Tm * ldq, Tm * D, Tm, stream, pre));
             FWD(linear_pl(l, 3, ctx_hi, ctx_lo, D, W[RNAMSM_WL_COL_BO], x, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE));
             // ---- feed-forward
             FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
@@ -534,7 +547,7 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
     // K0 of the whole batch in one launch (the row-position table restarts with every alignment: row index mod R)
     FWD(rnamsm::embed_ln_batched(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
                                  G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, B, R, C, D, d.vocab, d.num_positions, d.pad_idx,
-                                 d.ln_eps, err_flag, hs));
+                                 d.ln_eps, err_flag, hs, d.row_pos_dim));
     if (fold) {
         FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
         FWD(rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream));

@@ -71,14 +71,12 @@ __device__ __forceinline__ void split8(const f32x4& x, const f32x4& y, typename 
     typedef typename Half16<FMT>::T H;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        hi[i] = (H)x[i];
-        hi[4 + i] = (H)y[i];
-    }
-    if (want_lo) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            lo[i] = (H)(x[i] - (float)hi[i]);
-            lo[4 + i] = (H)(y[i] - (float)hi[4 + i]);
+        const float xv = pinned(x[i]), yv = pinned(y[i]);
+        hi[i] = (H)xv;
+        hi[4 + i] = (H)yv;
+        if (want_lo) {
+            lo[i] = (H)(xv - (float)hi[i]);
+            lo[4 + i] = (H)(yv - (float)hi[4 + i]);
         }
     }
 }
@@ -132,8 +130,9 @@ __device__ __forceinline__ void fold16_produce(const f32x4 (&ov)[16], const Fold
             H4 hi, lo;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                hi[e] = (H)ov[i][e];
-                lo[e] = (H)(ov[i][e] - (float)hi[e]);
+                const float x = pinned(ov[i][e]);
+                hi[e] = (H)x;
+                lo[e] = (H)(x - (float)hi[e]);
             }
             const int64_t o = (int64_t)(gm0 + er + 4 * i) * fa.ldx + gn;
             epi_store(reinterpret_cast<H4*>(fa.xhi + o), hi);
@@ -224,8 +223,9 @@ __device__ __forceinline__ void hb_epilogue(f32x16 (&acc)[2][2], char* smem_b, i
                 H4 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    hi[e] = (H)ov[i][e];
-                    lo[e] = (H)(ov[i][e] - (float)hi[e]);
+                    const float x = pinned(ov[i][e]);
+                    hi[e] = (H)x;
+                    lo[e] = (H)(x - (float)hi[e]);
                 }
                 const int64_t o = (int64_t)(gm0 + er + 4 * i) * ldc + gn;
                 epi_store(reinterpret_cast<H4*>(Ohi + o), hi);
@@ -1238,10 +1238,11 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_x3q_kernel(
                     H8 hi, lo;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        hi[e] = (H)v[2 * hlf][e];
-                        hi[4 + e] = (H)v[2 * hlf + 1][e];
-                        lo[e] = (H)(v[2 * hlf][e] - (float)hi[e]);
-                        lo[4 + e] = (H)(v[2 * hlf + 1][e] - (float)hi[4 + e]);
+                        const float x0 = pinned(v[2 * hlf][e]), x1 = pinned(v[2 * hlf + 1][e]);
+                        hi[e] = (H)x0;
+                        hi[4 + e] = (H)x1;
+                        lo[e] = (H)(x0 - (float)hi[e]);
+                        lo[4 + e] = (H)(x1 - (float)hi[4 + e]);
                     }
                     epi_store(reinterpret_cast<H8*>(Ohi + o), hi);
                     epi_store(reinterpret_cast<H8*>(Olo + o), lo);
@@ -1346,7 +1347,7 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
                 H4 h, l;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float y = (v[e][i] - mean) * rstd * g[i] + b[i];
+                    const float y = pinned((v[e][i] - mean) * rstd * g[i] + b[i]);
                     h[i] = (H)y;
                     l[i] = (H)(y - (float)h[i]);
                 }
@@ -1363,7 +1364,7 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     typedef typename Half16<FMT>::T H;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const float x = src[i];
+        const float x = pinned(src[i]);
         const H h = (H)x;
         hi[i] = __builtin_bit_cast(uint16_t, h);
         if (lo) lo[i] = __builtin_bit_cast(uint16_t, (H)(x - (float)h));

@@ -9,6 +9,18 @@ namespace rnamsm {
 // operands inside fp16 range -- true for this model's GEMM inputs (LayerNorm outputs, attention contexts, GELU
 // activations, 0.04-scale weights); values below 2^-24 * 2^11 of an element's magnitude fall into fp16 subnormals of
 // the lo plane, an ABSOLUTE error <= 3e-8 per element.
+// A value about to be split into hi = round16(x), lo = round16(x - hi) is made OPAQUE to the optimiser first.  Found in round 4
+// (tests/test_gpu_attn16.py, plane outputs): with the default -ffp-contract=fast hipcc contracts the multiplication that
+// produced x into the conversions -- the STORED hi comes from v_cvt_pk(fl32(a * b)), the hi inside the lo term from
+// v_fma_mixlo_f16(a, b, 0) on the exact product -- and at a near-tie of the 16-bit grid the two round to different neighbours:
+// hi + lo is then off by a whole 16-bit ulp (2^-11 relative in fp16; one element in ~30 000, ~3e-6 of relative L2 error, the
+// size of the f16x3 mode's whole error budget).  An empty asm with the value as a read-write operand costs nothing and
+// pins ONE fp32 value for both conversions.
+__device__ __forceinline__ float pinned(float x) {
+    asm("" : "+v"(x));
+    return x;
+}
+
 template <int FMT> struct Half16;
 template <> struct Half16<0> {
     typedef __bf16 T;
@@ -55,8 +67,9 @@ __device__ __forceinline__ void slab_store_64x64(const f32x16 (&acc)[2][2], floa
                 H4 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    hi[e] = (H)ov[i][e];
-                    lo[e] = (H)(ov[i][e] - (float)hi[e]);
+                    const float x = pinned(ov[i][e]);
+                    hi[e] = (H)x;
+                    lo[e] = (H)(x - (float)hi[e]);
                 }
                 *reinterpret_cast<H4*>(out_hi + off + ec) = hi;
                 if (out_lo) *reinterpret_cast<H4*>(out_lo + off + ec) = lo;

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
         if (j < C) probs[row * C + j] = v[e] * inv;
         if (PL != 0 && j < ldp) {
             typedef typename Half16<(PL > 0 ? PL - 1 : 0)>::T Hh;
-            const float p = j < C ? v[e] * inv * plane_scale : 0.f;
+            const float p = pinned(j < C ? v[e] * inv * plane_scale : 0.f);
             const Hh hi = (Hh)p;
             reinterpret_cast<Hh*>(p_hi)[row * ldp + j] = hi;
             if (p_lo) reinterpret_cast<Hh*>(p_lo)[row * ldp + j] = (Hh)(p - (float)hi);

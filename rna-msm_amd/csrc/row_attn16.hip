@@ -1032,6 +1032,11 @@ static int row_apply16_launch(const uint16_t* p_hi, const uint16_t* p_lo, int64_
     RNAMSM_CHECK_ARG(ldc >= (int64_t)H * 64 && ldc % 4 == 0 && (ctx_hi ? (reinterpret_cast<uintptr_t>(ctx_hi) & 7u) == 0 : al16(ctx)),
                      "row_apply16: output alignment");
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // (Round 4: the same contraction on the operand-staged 16x16x32 loop of row_logits16q_kernel -- 256x256 tiles, V fragments by
+    // asm transposed reads, register-direct epilogue through v_permlane16_swap -- was built, passed the tests and measured 2.09 ms
+    // against 2.00 ms at M = L = 1024 and 0.22 against 0.18 ms at 256 x 512: with only C / 64 = 16 K tiles per output tile the
+    // 128 KB store burst of the epilogue (10 k cycles with nothing resident to cover it, in-kernel stamps) is 15 % of a tile
+    // whatever the loop does.  Not kept; EXPERIMENTS.md R4.3.)
     const bool big = C >= 256 && R >= 4 && tuning().attn16 != 2;      // 256x256 tiles ("attn16" = 2 forces 128x128: A/B)
     const unsigned tiles_i = big ? (C + 255) / 256 : (C + 127) / 128, tiles_n = big ? (R + 3) / 4 : (R + 1) / 2;
     const unsigned grid = xcd_panel_grid((unsigned)H * tiles_n, tiles_i);

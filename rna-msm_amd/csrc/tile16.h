@@ -75,6 +75,14 @@ __device__ __forceinline__ TrPieces tr16_issue(const char* tile, int row_a, int 
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r.b) : "v"(pb));
     return r;
 }
+// the same from a per-lane LDS byte address `va` (row / swizzled column inside an 8-row group, computed once) plus offsets that are
+// multiples of 8 rows: CT compile-time, `off` a constant after unrolling; the second 4-row... block of the fragment lies 8 rows on
+template <int CT>
+__device__ __forceinline__ void tr16_issue_at(uint32_t va, int off, TrPieces& r) {
+    const uint32_t a = va + (uint32_t)(CT + off);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r.a) : "v"(a));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(r.b) : "v"(a));
+}
 __device__ __forceinline__ void tr16_wait4(TrPieces& p0, TrPieces& p1, TrPieces& p2, TrPieces& p3) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(p0.a), "+v"(p0.b), "+v"(p1.a), "+v"(p1.b), "+v"(p2.a), "+v"(p2.b), "+v"(p3.a), "+v"(p3.b));

@@ -29,7 +29,8 @@ W_LAYER = ("row_ln_g", "row_ln_b", "row_wqkv", "row_bqkv", "row_wo", "row_bo",
 
 class ModelDims(ctypes.Structure):
     _fields_ = [("num_layers", c_int), ("embed_dim", c_int), ("num_heads", c_int), ("ffn_dim", c_int),
-                ("vocab", c_int), ("num_positions", c_int), ("pad_idx", c_int), ("ln_eps", c_float)]
+                ("vocab", c_int), ("num_positions", c_int), ("pad_idx", c_int), ("ln_eps", c_float),
+                ("row_pos_dim", c_int)]          # 0 / 1: scalar per alignment row; embed_dim: the msm/ variant's per-channel rows
 
 
 _SIGNATURES = {
@@ -38,6 +39,8 @@ _SIGNATURES = {
     "rnamsm_device_count": (c_int, []),
     "rnamsm_embed_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "rnamsm_embed_ln_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "rnamsm_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "rnamsm_gemm_bias_act_res": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                          c_int64, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),
@@ -71,6 +74,8 @@ _SIGNATURES = {
                                    c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     "rnamsm_col_attn16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                   c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "rnamsm_col_attn16_prescaled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                            c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rnamsm_zero_plane_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
     "rnamsm_head_mean": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "rnamsm_pad_mask": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),

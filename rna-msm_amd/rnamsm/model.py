@@ -46,7 +46,15 @@ class MSATransformer(nn.Module):
     def __init__(self, vocab: Optional[RNAAlphabet] = None, optimizer_config=None, contact_train_data=None,
                  embed_dim: int = 768, num_attention_heads: int = 12, num_layers: int = 12,
                  embed_positions_msa: bool = True, dropout: float = 0.1, attention_dropout: float = 0.1,
-                 activation_dropout: float = 0.1, max_tokens_per_msa: int = 2 ** 14, max_seqlen: int = 1024):
+                 activation_dropout: float = 0.1, max_tokens_per_msa: int = 2 ** 14, max_seqlen: int = 1024,
+                 embed_positions_msa_dim: Optional[int] = None, return_col_attentions: bool = False):
+        """embed_positions_msa_dim / return_col_attentions: the msm/ variant of the shell (msm/model.py:206-423).  Its
+        msa_position_embedding is (1, 1024, 1, embed_positions_msa_dim) -- a per-CHANNEL vector per alignment row when the dim is
+        embed_dim (msm/model.py:289-292) instead of RNA-MSM's (1, 1024, 1, 1) scalar; None / 1 = the scalar.  A state_dict whose
+        tensor has the other shape is accepted as well (load_state_dict reshapes the parameter first).  return_col_attentions:
+        forward(..., need_head_weights=True) also returns result["col_attentions"] [B, L, H, C, R, R] (msm/model.py:404-410),
+        computed by rnamsm_col_attn_probs layer by layer; refused above COL_ATTENTIONS_MAX_BYTES (the fused column kernel never
+        forms these: 16 GB per MSA at M = 256, L = 512)."""
         super().__init__()
         self.vocab = vocab if vocab is not None else RNAAlphabet()
         self.embed_dim = embed_dim
@@ -63,7 +71,10 @@ class MSATransformer(nn.Module):
 
         n_vocab, pad = len(self.vocab), self.vocab.pad_idx
         self.embed_tokens = nn.Embedding(n_vocab, embed_dim, padding_idx=pad)
-        self.msa_position_embedding = nn.Parameter(0.01 * torch.randn(1, 1024, 1, 1), requires_grad=False)
+        if embed_positions_msa_dim not in (None, 1, embed_dim):
+            raise ValueError(f"embed_positions_msa_dim must be 1 or embed_dim ({embed_dim}), got {embed_positions_msa_dim}")
+        self.msa_position_embedding = nn.Parameter(0.01 * torch.randn(1, 1024, 1, embed_positions_msa_dim or 1), requires_grad=False)
+        self.return_col_attentions = bool(return_col_attentions)
         self.layers = nn.ModuleList([
             AxialTransformerLayer(embedding_dim=embed_dim, ffn_embedding_dim=4 * embed_dim,
                                   num_attention_heads=num_attention_heads, dropout=dropout,
@@ -112,6 +123,23 @@ class MSATransformer(nn.Module):
                 m.gemm_dtype = mode
 
     # ------------------------------------------------------------------ reference API
+    COL_ATTENTIONS_MAX_BYTES = 8 << 30
+
+    @property
+    def row_pos_dim(self) -> int:
+        """1 = one scalar per alignment row (RNA-MSM, model.py:293-296); embed_dim = a vector per row (msm/model.py:289-292)."""
+        return int(self.msa_position_embedding.shape[-1])
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # a checkpoint of the other shell variant: take its msa_position_embedding shape before the strict shape check
+        t = state_dict.get(prefix + "msa_position_embedding")
+        if t is not None and tuple(t.shape) != tuple(self.msa_position_embedding.shape) and tuple(t.shape) in (
+                (1, 1024, 1, 1), (1, 1024, 1, self.embed_dim)):
+            cur = self.msa_position_embedding
+            self.msa_position_embedding = nn.Parameter(torch.empty(t.shape, dtype=cur.dtype, device=cur.device), requires_grad=False)
+            self._pack_key = None
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def max_tokens_per_msa_(self, value: int) -> None:
         """model.py:418-428.  The reference uses it to bound memory by chunking; the HIP kernels tile internally, so
         without padding results are identical for every value.  With padding the reference's chunked row attention fills
@@ -144,7 +172,7 @@ class MSATransformer(nn.Module):
             return t
 
         table: List[torch.Tensor] = [
-            f(self.embed_tokens.weight), f(self.embed_positions.weight), f(self.msa_position_embedding.view(-1)),
+            f(self.embed_tokens.weight), f(self.embed_positions.weight), f(self.msa_position_embedding.reshape(-1)),
             f(self.emb_layer_norm_before.weight), f(self.emb_layer_norm_before.bias),
             f(self.emb_layer_norm_after.weight), f(self.emb_layer_norm_after.bias)]
         for layer in self.layers:
@@ -161,7 +189,7 @@ class MSATransformer(nn.Module):
         ptrs = (ctypes.c_void_p * len(table))(*[t.data_ptr() for t in table])
         dims = _lib.ModelDims(self.num_layers, self.embed_dim, self.num_attention_heads, 4 * self.embed_dim,
                               self.embed_tokens.num_embeddings, self.embed_positions.num_embeddings,
-                              self.vocab.pad_idx, float(self.emb_layer_norm_before.eps))
+                              self.vocab.pad_idx, float(self.emb_layer_norm_before.eps), self.row_pos_dim)
         self._pack = (dims, ptrs, keep)
         self._pack_key = key
         return self._pack
@@ -457,22 +485,33 @@ class MSATransformer(nn.Module):
         pruned = not need_repr and dtype == _lib.F32 and not has_padding and R > 1       # rnamsm_forward's condition
         return {"row_attn": row_attn, "repr": rep[:1] if pruned else rep, "emb": emb, "atp": atp, "err": err}
 
-    def _forward_layerwise(self, tokens2d: torch.Tensor, repr_layers: Iterable[int], has_padding: bool = False):
+    def _forward_layerwise(self, tokens2d: torch.Tensor, repr_layers: Iterable[int], has_padding: bool = False,
+                           col_attentions: Optional[List[torch.Tensor]] = None):
         """Module-by-module path (same HIP kernels, launched from Python) used when intermediate
-        representations are requested."""
+        representations -- or the column attention probabilities (col_attentions: a list that receives [1,NL,H,C,R,R]) -- are
+        requested."""
         R, C = tokens2d.shape
         D = self.embed_dim
         pmask = (tokens2d == self.vocab.pad_idx)[None] if has_padding else None      # [1, R, C]
         x = ops.embed_ln(tokens2d.to(torch.int64), self.embed_tokens.weight.detach(), self.embed_positions.weight.detach(),
-                         self.msa_position_embedding.detach().view(-1).contiguous(),
+                         self.msa_position_embedding.detach().reshape(-1).contiguous(),
                          self.emb_layer_norm_before.weight.detach(), self.emb_layer_norm_before.bias.detach(),
-                         self.vocab.pad_idx, self.emb_layer_norm_before.eps).view(R, C, 1, D)
+                         self.vocab.pad_idx, self.emb_layer_norm_before.eps, row_pos_dim=self.row_pos_dim).view(R, C, 1, D)
         reps = {}
         if 0 in repr_layers:
             reps[0] = x.permute(2, 0, 1, 3)
-        rows = []
+        rows, cols = [], []
         for i, layer in enumerate(self.layers):
-            x, _, row_attn = layer(x, self_attn_padding_mask=pmask, need_head_weights=True)
+            if col_attentions is not None:
+                attn = layer.column_self_attention.layer
+                keep, attn.return_probs = attn.return_probs, True
+                try:
+                    x, col_attn, row_attn = layer(x, self_attn_padding_mask=pmask, need_head_weights=True)
+                finally:
+                    attn.return_probs = keep
+                cols.append(col_attn.permute(2, 0, 1, 3, 4))                        # [H,C,1,R,R] -> [1,H,C,R,R] (msm/model.py:383)
+            else:
+                x, _, row_attn = layer(x, self_attn_padding_mask=pmask, need_head_weights=True)
             rows.append(row_attn.permute(1, 0, 2, 3))                               # [1,H,C,C]
             if (i + 1) in repr_layers and (i + 1) != self.num_layers:
                 reps[i + 1] = x.permute(2, 0, 1, 3)
@@ -480,6 +519,8 @@ class MSATransformer(nn.Module):
                            self.emb_layer_norm_after.eps)
         if self.num_layers in repr_layers:
             reps[self.num_layers] = xf.permute(2, 0, 1, 3)
+        if col_attentions is not None:
+            col_attentions.append(torch.stack(cols, 1))                             # [1,NL,H,C,R,R]
         return reps, torch.stack(rows, 1)                                           # [1,NL,H,C,C]
 
     def forward(self, tokens, repr_layers=[], need_head_weights=False, return_contacts=False, need_logits=None):
@@ -500,7 +541,15 @@ class MSATransformer(nn.Module):
             repr_set = repr_set | {self.num_layers}
         reps: Dict[int, List[torch.Tensor]] = {i: [] for i in repr_set}
         atts: List[torch.Tensor] = []
-        fast = repr_set <= {self.num_layers}
+        want_cols = need_head_weights and self.return_col_attentions               # msm/model.py:404-410
+        cols: Optional[List[torch.Tensor]] = [] if want_cols else None
+        if want_cols:
+            need = 4 * B * self.num_layers * self.num_attention_heads * C * R * R
+            if need > self.COL_ATTENTIONS_MAX_BYTES:
+                raise _lib.RnamsmError(f"col_attentions of this input would take {need / 2 ** 30:.1f} GiB "
+                                       f"(> {self.COL_ATTENTIONS_MAX_BYTES / 2 ** 30:.0f} GiB): build the model with "
+                                       f"return_col_attentions=False or pass fewer / shallower alignments")
+        fast = repr_set <= {self.num_layers} and not want_cols
         done = 0
         chunked = has_padding and _lib.load().rnamsm_row_chunks(R, C, min(int(self.max_tokens_per_msa), 2 ** 31 - 1)) > 0
         if fast and B > 1 and not chunked and self.batch_small_msas and not self.training and (
@@ -523,7 +572,7 @@ class MSATransformer(nn.Module):
                     reps[self.num_layers].append(out["repr"].unsqueeze(0))
                 atts.append(out["row_attn"].unsqueeze(0))
             else:
-                r, a = self._forward_layerwise(tokens[b], repr_set, has_padding)
+                r, a = self._forward_layerwise(tokens[b], repr_set, has_padding, col_attentions=cols)
                 for i in repr_set:
                     reps[i].append(r[i])
                 atts.append(a)
@@ -532,6 +581,8 @@ class MSATransformer(nn.Module):
         result = {"logits": logits, "representations": {i: v for i, v in full.items() if i in want}}
         if need_head_weights:
             result["row_attentions"] = torch.cat(atts, 0)                           # [B, NL, H, C, C]
+            if want_cols:
+                result["col_attentions"] = torch.cat(cols, 0)                       # [B, NL, H, C, R, R]
         if return_contacts:                                                         # model.py:412-414
             reg = self.contact_head.regression
             maps = torch.cat(atts, 0)

@@ -432,16 +432,24 @@ def zero_plane_rows(pl, mask: torch.Tensor, ncols: int) -> None:
 
 @_on_operand_device
 def col_attn16(q, k, v, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0,
-               pad_mask: Optional[torch.Tensor] = None, out_planes: bool = False):
+               pad_mask: Optional[torch.Tensor] = None, out_planes: bool = False, prescaled: bool = False):
     """q, k, v: (hi, lo) plane views [R*C, *] with a common row stride; returns softmax(scale * q k^T) v, fp32
     [R*C, H*64] (q UNSCALED) -- or, with out_planes, the context as the 16-bit (hi, lo | None) int16 planes the forward's
-    out_proj GEMM reads (format = the operands': bf16, or fp16 for fmt 1)."""
+    out_proj GEMM reads (format = the operands': bf16, or fp16 for fmt 1).  prescaled (bf16 formats, no mask): the q planes
+    hold q * scale * log2(e) already (rnamsm_col_attn16_prescaled: what the forward runs); `scale` is then ignored."""
     D = H * HEAD_DIM
     ld = _rowmajor(q[0], "q_hi")
     assert _rowmajor(k[0], "k_hi") == ld and _rowmajor(v[0], "v_hi") == ld
     ctx = None if out_planes else torch.empty(R * C, D, device=v[0].device, dtype=torch.float32)
     c_hi = torch.empty(R * C, D, device=v[0].device, dtype=torch.int16) if out_planes else None
     c_lo = torch.empty(R * C, D, device=v[0].device, dtype=torch.int16) if out_planes and q[1] is not None else None
+    if prescaled:
+        assert fmt == 0 and pad_mask is None
+        _lib.check(_lib.load().rnamsm_col_attn16_prescaled(_pl(q[0], "q_hi"), _pl(q[1], "q_lo"), _pl(k[0], "k_hi"), _pl(k[1], "k_lo"),
+                                                           _pl(v[0], "v_hi"), _pl(v[1], "v_lo"), ld,
+                                                           None if ctx is None else _dev(ctx, "ctx"), D, R, C, H, HEAD_DIM,
+                                                           _pl(c_hi, "ctx_hi"), _pl(c_lo, "ctx_lo"), _stream()))
+        return (c_hi, c_lo) if out_planes else ctx
     _lib.check(_lib.load().rnamsm_col_attn16(_pl(q[0], "q_hi"), _pl(q[1], "q_lo"), _pl(k[0], "k_hi"), _pl(k[1], "k_lo"),
                                              _pl(v[0], "v_hi"), _pl(v[1], "v_lo"), ld,
                                              None if ctx is None else _dev(ctx, "ctx"), D,
@@ -467,15 +475,16 @@ def col_attn_probs16(q, k, R: int, C: int, H: int, fmt: int = 0, scale: float = 
 
 @_on_operand_device
 def embed_ln(tokens: torch.Tensor, embed_tokens: torch.Tensor, embed_positions: torch.Tensor, row_pos: torch.Tensor,
-             gamma: torch.Tensor, beta: torch.Tensor, pad_idx: int, eps: float = 1e-5) -> torch.Tensor:
-    """tokens int64 [R,C] -> x [R*C, D]; raises on token / position ids outside the tables."""
+             gamma: torch.Tensor, beta: torch.Tensor, pad_idx: int, eps: float = 1e-5, row_pos_dim: int = 1) -> torch.Tensor:
+    """tokens int64 [R,C] -> x [R*C, D]; raises on token / position ids outside the tables.  row_pos: [>= R] scalars per
+    alignment row (row_pos_dim 1), or flattened [>= R, D] vectors (row_pos_dim = D: the msm/ variant, msm/model.py:289-292)."""
     R, C = tokens.shape
     D = embed_tokens.shape[1]
     out = torch.empty(R * C, D, device=tokens.device, dtype=torch.float32)
     err = torch.zeros(1, device=tokens.device, dtype=torch.int32)
-    _lib.check(_lib.load().rnamsm_embed_ln(
+    _lib.check(_lib.load().rnamsm_embed_ln_rows(
         _dev(tokens.contiguous(), "tokens", torch.int64), _dev(embed_tokens, "embed_tokens"),
-        _dev(embed_positions, "embed_positions"), _dev(row_pos, "row_pos"), _dev(gamma, "gamma"), _dev(beta, "beta"),
+        _dev(embed_positions, "embed_positions"), _dev(row_pos, "row_pos"), int(row_pos_dim), _dev(gamma, "gamma"), _dev(beta, "beta"),
         _dev(out, "out"), R, C, D, embed_tokens.shape[0], embed_positions.shape[0], pad_idx, eps,
         _dev(err, "err", torch.int32), _stream()))
     if int(err.item()) != 0:

@@ -18,6 +18,22 @@ for p in (os.path.join(ROOT, "rna-msm_amd"), ROOT):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    config.addinivalue_line("markers", "slow: a GPU test of more than ~20 s whose claim a faster test of the default run also "
+                                       "covers; deselected unless the -m expression names `slow` (-m \"gpu and slow\", or "
+                                       "-m \"gpu or slow\" for everything) or RNAMSM_RUN_SLOW=1")
+
+
+def pytest_collection_modifyitems(config, items):
+    """The driver's `-m gpu` run has a wall-clock cap: tests marked `slow` stay out of it unless asked for."""
+    expr = config.getoption("-m") or ""
+    if "slow" in expr or os.environ.get("RNAMSM_RUN_SLOW") == "1":
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("slow") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 def golden(name):

@@ -52,6 +52,7 @@ def test_two_ranks_gather_the_same_outputs_as_one_rank():
     assert len(gs["per_rank_host_wait_s"]) == 2 and len(gs["per_rank_stream_wait_ms"]) == 2
 
 
+@pytest.mark.slow        # 33 s; the two-rank test above and tests/test_sharding.py (gloo, world 3) cover the same protocol in the default run
 def test_eight_ranks_on_one_device_gather_the_same_outputs_as_one_rank():
     """The driver's largest launch, `--gpus 8`, with the test hooks (all ranks on device 0, gloo): 11 MSAs over 8 ranks -- two
     rounds, the second with five item-less ranks -- gathered bit-identical to the N = 1 run; per-rank gather statistics present."""
@@ -140,3 +141,75 @@ dist.destroy_process_group()
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
     res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["ok"] and res["backend"] == "nccl" and res["stats"]["bytes_received"] == 0
+
+
+def test_round_gatherer_on_the_rccl_backend_with_two_ranks_on_one_device_or_records_why_not(tmp_path):
+    """the point-to-point branch of RoundGatherer (header isend, event-gated batch_isend_irecv, blocking
+    recv of the headers on rank 0; sharding.py `_post_round` / `_retire`) has never executed with a peer on backend `nccl`,
+    because the boxes this suite sees have ONE GPU and RCCL refuses two ranks on one device.  This test TRIES exactly that --
+    two fresh child processes of a GPU-free parent (nothing re-execs after touching the GPU), both on device 0, a bounded wait
+    -- and either verifies the gathered tensors bit for bit (the first execution of that branch) or SKIPS with RCCL's own error
+    text, so the reason is on record in the run's log instead of in prose."""
+    code = r'''
+import os, sys, json, traceback
+rank = int(sys.argv[1])
+sys.path[:0] = [os.path.join(@ROOT@, "rna-msm_amd"), @ROOT@]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=@PORT@, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0")
+import datetime
+import torch, torch.distributed as dist
+try:
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=2, device_id=torch.device("cuda", 0), timeout=datetime.timedelta(seconds=60))
+    t = torch.full((4,), float(rank + 1), device="cuda:0")
+    dist.all_reduce(t)                                   # communicator creation happens here: two ranks, one device
+    torch.cuda.synchronize()
+    assert float(t[0]) == 3.0
+except Exception as e:                                    # noqa: BLE001
+    print(json.dumps({"refused": f"{type(e).__name__}: {str(e)[:600]}"}), flush=True)
+    sys.exit(77)
+from rnamsm import sharding
+got = {}
+n = 5                                                    # rounds 0, 1 full; round 2 with an item-less rank 1
+g = sharding.RoundGatherer(n, on_item=lambda i, ts: got.__setitem__(i, [x.clone() for x in ts]), tensors_per_item=2, dst=0,
+                           device=torch.device("cuda", 0))
+def item(i):
+    return (torch.full((3 + i, 8), float(i), device="cuda:0").t(), torch.arange(4 * i + 2, device="cuda:0", dtype=torch.float32) * (i + 1))
+for i in sharding.shard_indices(n, rank, 2):
+    g.submit(i, item(i))
+g.finish()
+torch.cuda.synchronize()
+ok = True
+if rank == 0:
+    ok = sorted(got) == list(range(n)) and all(torch.equal(a, b) for i in range(n) for a, b in zip(got[i], item(i)))
+print(json.dumps({"ok": bool(ok), "rank": rank, "stats": g.stats()}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = code.replace("@ROOT@", repr(ROOT)).replace("@PORT@", repr(str(port)))
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        e.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e, cwd=ROOT)
+             for r in range(2)]
+    outs = []
+    timed_out = False
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=180))
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            p.kill()                                       # the exact PIDs this test started
+            outs.append(p.communicate())
+    texts = [ln for o, _ in outs for ln in o.splitlines() if ln.startswith("{")]
+    refused = [json.loads(t)["refused"] for t in texts if "refused" in t]
+    if refused or timed_out or any(p.returncode == 77 for p in procs):
+        why = refused[0] if refused else ("no answer within 180 s (the ranks were ended)" if timed_out else (outs[0][1] or outs[1][1])[-600:])
+        pytest.skip(f"RCCL does not run two ranks on one device here, the nccl point-to-point branch stays unexecuted: {why}")
+    assert all(p.returncode == 0 for p in procs), [(p.returncode, o[-1500:], er[-3000:]) for p, (o, er) in zip(procs, outs)]
+    res = [json.loads(t) for t in texts]
+    assert all(r["ok"] for r in res) and any(r["rank"] == 0 and r["stats"]["bytes_received"] > 0 for r in res)

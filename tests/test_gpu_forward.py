@@ -498,9 +498,10 @@ def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model,
     assert rel_l2(fold["emb"].cpu().numpy(), plain["emb"].cpu().numpy()) < 2e-5
     # two samples of fp32 noise: each is ~6e-5 (max-abs) from the fp64 truth at the deepest of these shapes
     assert np.abs(fold["atp"].cpu().numpy() - plain["atp"].cpu().numpy()).max() < 2e-4
-    res = O.forward(torch.from_numpy(tokens), O.to_torch_params(state, torch.float64))
-    o_emb, o_atp = O.pack_outputs(res)
-    e_fold, e_plain = rel_l2(fold["emb"].cpu().numpy(), o_emb.numpy()), rel_l2(plain["emb"].cpu().numpy(), o_emb.numpy())
+    import truth                                                              # the oracle in fp64 on the device (same weights: seed 0)
+    o_emb, _ = truth.oracle_outputs(tokens, torch.float64, "cuda:0")          # (on the host this took up to 25 s per shape)
+    o_emb = o_emb.cpu().numpy()
+    e_fold, e_plain = rel_l2(fold["emb"].cpu().numpy(), o_emb), rel_l2(plain["emb"].cpu().numpy(), o_emb)
     assert e_fold < 1.5 * e_plain + 1e-7, (e_fold, e_plain)
     # padded MSAs keep the separate launches (and their exact reference mask semantics): the flag is simply not used
     ptoks = toks.clone()
@@ -877,3 +878,46 @@ def test_batched_and_ragged_forward_in_the_16bit_modes(model, mode, emb_tol, atp
                 assert np.abs(out["row_attn"][b].cpu().numpy() - g["row_attentions"][b]).max() < 1e-4
     finally:
         m.gemm_dtype = "f32"
+
+
+@pytest.mark.parametrize("name", ["d128_b2_r5_c9", "d768_b1_r4_c7"])
+def test_msm_variant_of_the_model_shell_matches_reference_fixture(name):
+    """msm.model.MSATransformer (msm/model.py:206-423): msa_position_embedding of shape (1,1024,1,D) -- a per-channel vector per
+    alignment row, msm/model.py:289-292 -- and result["col_attentions"] [B,L,H,C,R,R] (:404-410), against outputs of the
+    reference itself (tests/golden/make_golden_r4.py).  A state_dict of that variant loads strictly into a model built for
+    RNA-MSM's scalar rows (load_state_dict reshapes the parameter), the C++ driver (rnamsm_forward, row_pos_dim = D) and the
+    layer-wise path agree, and the scalar variant keeps working on the same object."""
+    from test_oracle_golden import msm_variant_state
+    from rnamsm import _lib
+    from rnamsm.model import MSATransformer
+    g = golden(f"msm_variant_{name}.npz")
+    state, (D, H, L, B, R, C) = msm_variant_state(g)
+    m = MSATransformer(embed_dim=D, num_attention_heads=H, num_layers=L, return_col_attentions=True)
+    assert m.row_pos_dim == 1
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    assert m.row_pos_dim == D and tuple(m.msa_position_embedding.shape) == (1, 1024, 1, D)
+    m = m.eval().to("cuda:0")
+    toks = torch.from_numpy(g["tokens"]).to("cuda:0")
+    res = m(toks, repr_layers=[L], need_head_weights=True)
+    assert set(res) >= {"logits", "representations", "row_attentions", "col_attentions"}
+    assert res["col_attentions"].shape == g["col_attentions"].shape == (B, L, H, C, R, R)
+    assert rel_l2(res["representations"][L].cpu().numpy(), g["repr_last"]) < 1e-5
+    assert np.abs(res["row_attentions"].cpu().numpy() - g["row_attentions"]).max() < 2e-5
+    assert np.abs(res["col_attentions"].cpu().numpy() - g["col_attentions"]).max() < 2e-5
+    assert rel_l2(res["logits"].cpu().numpy(), g["logits"]) < 1e-5
+    # the fused driver (one C call per MSA) with the per-channel rows: same representation as the layer-wise path
+    m.return_col_attentions = False
+    fused = m(toks, repr_layers=[L], need_head_weights=True)
+    assert "col_attentions" not in fused
+    assert rel_l2(fused["representations"][L].cpu().numpy(), g["repr_last"]) < 1e-5
+    assert np.abs(fused["row_attentions"].cpu().numpy() - g["row_attentions"]).max() < 2e-5
+    # too large a request is refused, not attempted
+    m.return_col_attentions = True
+    m.COL_ATTENTIONS_MAX_BYTES = 1024
+    with pytest.raises(_lib.RnamsmError, match="col_attentions"):
+        m(toks, need_head_weights=True)
+    # the standalone kernel entry: row_pos_dim must be 0, 1 or D
+    from rnamsm import ops
+    with pytest.raises(_lib.RnamsmError):
+        ops.embed_ln(toks[0], m.embed_tokens.weight, m.embed_positions.weight, m.msa_position_embedding.reshape(-1),
+                     m.emb_layer_norm_before.weight, m.emb_layer_norm_before.bias, 1, row_pos_dim=7)

@@ -7,7 +7,7 @@ error the reference's OWN arithmetic makes against the same truth (the oracle in
     bf16 (configs[4])  :  drift(HIP bf16) <= 1.5 x drift(oracle .bfloat16())
 
 i.e. the kernels are held to the reference's own fp32 (bf16) noise at the size in question instead of to a free
-tolerance.  Every number is appended to gpurun_out/r03_fullsize_parity.json (copied to profiles/ when committed).
+tolerance.  Every number is appended to gpurun_out/r04_fullsize_parity.json (copied to profiles/ when committed).
 """
 import json
 import os
@@ -35,7 +35,7 @@ def model():
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     REPORT["_device"] = torch.cuda.get_device_name(0)
-    with open(os.path.join(out_dir, "r03_fullsize_parity.json"), "w") as f:
+    with open(os.path.join(out_dir, "r04_fullsize_parity.json"), "w") as f:
         json.dump(REPORT, f, indent=1)
 
 
@@ -84,10 +84,30 @@ CASES = [
 ]
 
 
-CPU_YARDSTICK = {"configs[0]", "configs[1]", "configs[2]", "configs[3]"}     # sizes the CPU oracle finishes in <= ~90 s
+CPU_YARDSTICK = {"configs[0]", "configs[1]", "configs[3]"}     # sizes the CPU oracle finishes in <= ~20 s
 # configs[4] (M = L = 1024): the CPU oracle needs 12.6 minutes of 32 host threads there, so its errors against the same fp64
-# truth were measured ONCE on the GPU box (tests/analysis/yardstick_m1024.py, same tokens, same weights) and committed
-COMMITTED_YARDSTICK = {"configs[4]": "yardstick_m1024_l1024.json"}
+# truth were measured ONCE on the GPU box (tests/analysis/yardstick_m1024.py, same tokens, same weights) and committed.
+# configs[2] (M = 256, L = 512): 70 s of the same -- measured live in the suite until round 3; since round 4 (the suite's wall-
+# clock cap) the default run uses the committed measurement and the `slow` variant below re-measures it.
+COMMITTED_YARDSTICK = {"configs[4]": "yardstick_m1024_l1024.json", "configs[2]": "yardstick_m256_l512.json"}
+
+
+@pytest.mark.slow
+def test_configs2_against_a_live_cpu_yardstick(model):
+    """-m "gpu and slow": BASELINE configs[2] with the reference's own fp32 error measured live on this host (70 s of 32 threads)
+    instead of read from tests/golden/yardstick_m256_l512.json, and the committed figure checked against it."""
+    label, make = CASES[2]
+    toks = make()
+    t_emb, t_atp = truth.oracle_outputs(toks, torch.float64, DEV)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    live = truth.errors(*truth.oracle_outputs(toks, torch.float32, "cpu"), t_emb, t_atp)
+    y = json.load(open(os.path.join(GOLDEN, COMMITTED_YARDSTICK["configs[2]"])))["oracle_cpu_f32"]
+    for k in ("emb_rel_l2", "atp_rel_l2", "atp_mean_abs"):
+        assert 0.8 * y[k] <= live[k] <= 1.25 * y[k], (k, live, y)       # thread blocking moves fp32 sums a little, not the scale
+    for mode in ("f32", "f16x3"):
+        e = truth.errors(*hip_outputs(model, toks, mode), t_emb, t_atp)
+        for k in ("emb_rel_l2", "atp_rel_l2", "atp_mean_abs"):
+            assert e[k] <= 2.0 * live[k] + 1e-9, (mode, k, e, live)
 
 
 @pytest.mark.parametrize("label,make", CASES, ids=[c[0].split()[0] for c in CASES])

@@ -183,7 +183,7 @@ def test_library_exports_every_symbol_declared_in_the_header(lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rnamsm_version() == 300         # ABI 3.0 (round 3): + rnamsm_col_attn_probs[16]; see the header's change notes
+    assert lib.rnamsm_version() == 400         # ABI 4.0 (round 4): rnamsm_model_dims.row_pos_dim, + rnamsm_embed_ln_rows, rnamsm_timing_get_valu_bound
 
 
 def test_ctypes_signatures_match_the_header_prototypes():

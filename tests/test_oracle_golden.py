@@ -280,3 +280,32 @@ def test_oracle_layer_three_tuple_matches_reference(name):
         assert rel_l2(x3.numpy(), g["out" + sfx]) < 1e-5
         assert np.abs(cp.numpy() - g["col_probs" + sfx]).max() < 2e-5
         assert np.abs(rp.numpy() - g["row_probs" + sfx]).max() < 2e-5
+
+
+MSM_VARIANT_CASES = ["d128_b2_r5_c9", "d768_b1_r4_c7"]
+
+
+def msm_variant_state(g):
+    """The weights behind a msm_variant_*.npz fixture: synthetic.make_state_dict(seed, D, L, H) with the per-channel
+    msa_position_embedding of the msm/ shell variant (rows past the stored ones are never read: zeros)."""
+    D, H, L, B, R, C, seed = (int(v) for v in g["meta"])
+    state = synthetic.make_state_dict(seed=seed, embed_dim=D, num_layers=L, num_heads=H)
+    rows = np.zeros((1, 1024, 1, D), dtype=np.float32)
+    rows[:, :R] = g["msa_position_embedding_rows"]
+    state["msa_position_embedding"] = rows
+    return state, (D, H, L, B, R, C)
+
+
+@pytest.mark.parametrize("name", MSM_VARIANT_CASES)
+def test_oracle_matches_the_msm_variant_of_the_model_shell(name):
+    """msm/model.py:206-423 (per-channel msa_position_embedding, col_attentions next to row_attentions), VERDICT r03 item 6."""
+    g = golden(f"msm_variant_{name}.npz")
+    state, (D, H, L, B, R, C) = msm_variant_state(g)
+    params = O.to_torch_params(state)
+    for b in range(B):
+        out = O.forward(torch.from_numpy(g["tokens"][b]), params, num_layers=L, num_heads=H, return_col_attentions=True)
+        assert rel_l2(out["representation"].numpy(), g["repr_last"][b]) < 1e-5
+        assert np.abs(out["row_attentions"].numpy() - g["row_attentions"][b]).max() < 2e-5
+        assert out["col_attentions"].shape == g["col_attentions"][b].shape == (L, H, C, R, R)
+        assert np.abs(out["col_attentions"].numpy() - g["col_attentions"][b]).max() < 2e-5
+        assert rel_l2(O.lm_head(out["representation"], params).numpy(), g["logits"][b]) < 1e-5

@@ -44,7 +44,8 @@ for name, split, fmt in (("bf16", 1, 0), ("bf16x3", 3, 0), ("f16x3", 3, 1)):
                     t1 = timeit(lambda: ops.row_logits16(q, k, R, C, H, fmt=fmt, scale=ops.row_scaling(R)))
                     t2 = timeit(lambda: ops.row_apply16(pp, vv, R, C, H, fmt=fmt, out_scale=1 / 4096.0))
                     t3 = timeit(lambda: ops.col_attn16(q, k, vv, R, C, H, fmt=fmt, scale=0.125, out_planes=True))
-                    line.append(f"[v{var} bk64={bk} dephase={dp} q16={q16}] logits {t1:.3f} apply {t2:.3f} col {t3:.3f} ms")
+                    t4 = timeit(lambda: ops.col_attn16(q, k, vv, R, C, H, fmt=0, out_planes=True, prescaled=True)) if fmt == 0 else float("nan")
+                    line.append(f"[v{var} bk64={bk} dephase={dp} q16={q16}] logits {t1:.3f} apply {t2:.3f} col {t3:.3f} col(prescaled q) {t4:.3f} ms")
     _lib.check(lib.rnamsm_set_param(b"attn16", 1))
     _lib.check(lib.rnamsm_set_param(b"row16_q16", 1))
     _lib.check(lib.rnamsm_set_param(b"row16_bk64", 1))
