@@ -486,10 +486,6 @@ void rnamsm_timing_reset(void);
  *                 rnamsm_forward_batch (default 0 = 10752 for plain bf16, 8960 for the hi/lo modes: below ~9-10 k tokens the
  *                 256x256 kernels leave most CUs without a tile; 2048 tokens x1.33 / x1.59, 8192 x1.11 / x1.10).  The hi/lo modes'
  *                 kernels sum every element in the same order (bit-identical); plain bf16 changes MFMA shape (fp32 rounding).
- *   "gemm16_x3q"  hi/lo modes, plane-output GEMMs (QKV, fc1) of >= 2048 rows: 1 = gemm16_x3q_kernel (16x16x32 MFMA, staged by
- *                 operand; +1.8 % on the six GEMMs of a layer), 0 (default) = the 32x32x16 kernel.  Results agree to fp32 rounding
- *                 (the k order inside a K tile differs) -- which at BASELINE configs[1] moved f16x3 from 6.5e-6 to 7.1e-6 of the
- *                 truth, across the 2 x CPU-fp32 bar of tests/test_gpu_fullsize.py (6.6e-6): hence not the default.
  *   "row16_q16"   plain bf16 rnamsm_row_logits16 at C >= 384 with C % 8 == 0: 1 (default) = row_logits16q_kernel (256x256 tiles on the
  *                 16x16x32 MFMA, staged by operand, persistent blocks, register-direct epilogue), 0 = the 128x128 kernel.  Changes
  *                 the row split (rnamsm_row_logits16_nsplit) and agrees to fp32 rounding.

@@ -193,10 +193,6 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm16_dephase = value < 0 ? 0 : (value > 2 ? 2 : value);
         return RNAMSM_OK;
     }
-    if (name && !strcmp(name, "gemm16_x3q")) {
-        rnamsm::tuning().gemm16_x3q = value != 0;
-        return RNAMSM_OK;
-    }
     if (name && !strcmp(name, "gemm16_big_rows")) {
         rnamsm::tuning().gemm16_big_rows = value < 0 ? 0 : value;
         return RNAMSM_OK;
@@ -236,7 +232,6 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "col_small")) return rnamsm::tuning().col_small;
     if (name && !strcmp(name, "col_dma")) return rnamsm::tuning().col_dma;
     if (name && !strcmp(name, "gemm16_dephase")) return rnamsm::tuning().gemm16_dephase;
-    if (name && !strcmp(name, "gemm16_x3q")) return rnamsm::tuning().gemm16_x3q;
     if (name && !strcmp(name, "gemm16_big_rows")) return rnamsm::tuning().gemm16_big_rows;
     if (name && !strcmp(name, "gemm16_big_rows_fwd")) return rnamsm::tuning().gemm16_big_rows_fwd;
     if (name && !strcmp(name, "row16_q16")) return rnamsm::tuning().row16_q16;

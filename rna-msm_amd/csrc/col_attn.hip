@@ -642,7 +642,7 @@ static int col_attn_launch(const float* q, const float* k, const float* v, int64
         if (use_dma) CA_GO2(col_attn_dma_kernel, CD_LDS_BYTES, M_, OUT_);                                           \
         else CA_GO2(col_attn_kernel, CA_LDS_BYTES, M_, OUT_);                                                       \
     } while (0)
-    if (pad_mask) CA_GO(true, 0);
+    if (pad_mask) CA_GO2(col_attn_dma_kernel, CD_LDS_BYTES, true, 0);      // (the register-staged kernel has no masked instance: it spilled)
     else if (!ctx_hi) CA_GO(false, 0);
     else if (plane_fmt == 0) CA_GO(false, 1);
     else CA_GO(false, 2);

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
 #pragma unroll
     for (int j = 0; j < JC / 32; ++j) krow[j] = (int64_t)(8 * (wave + 4 * j) + drow) * C * ld + col_off;
     const int64_t chunk_stride = (int64_t)JC * C * ld;
-    auto issue = [&](int ch, int buf) {
+    auto issue = [&](int ch, int buf) __attribute__((always_inline)) {
         char* base = smem_b + buf * BUF;
         const bool ragged = (ch + 1) * JC > R;                 // block-uniform
 #pragma unroll
@@ -189,8 +189,13 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
     }
 
     // one 32-key tile.  RAG (compile-time): the ragged last tile, whose keys >= R are masked out.  TRK: TRACKED arithmetic.
-    auto tile = [&](const char* Kc, const char* Vc, int jt, int jbase, auto rag_tag, auto trk_tag) {
+    auto tile = [&](const char* Kc, const char* Vc, int jt, int jbase, auto rag_tag, auto trk_tag) __attribute__((always_inline)) {
         constexpr bool RAG = decltype(rag_tag)::value, TRK = decltype(trk_tag)::value;
+        // the masked three-product instances are one register over their budget: their per-lane K addresses are re-derived per
+        // tile (a few VALU ops) instead of being held from kernel entry
+        int lane_t = lane;
+        if (MASKED && SPLIT == 3) asm volatile("" : "+v"(lane_t));
+        const int li = lane_t & 31, lh = lane_t >> 5;
         V8 kf[4][NPL];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
@@ -226,6 +231,7 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
             for (int t = 0; t < 16; ++t) {
                 const int j = jbase + (t & 3) + 8 * (t >> 2) + 4 * lh;
                 if (j < R && pad_mask[(int64_t)j * C + c]) mbits |= 1u << t;
+                if ((t & 3) == 3) asm volatile("" : "+v"(mbits));      // four byte loads in flight, not sixteen (registers)
             }
         }
         V8 pf[QB][2][NPL];
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
     // The whole key loop: three-deep ring, two chunks ahead.  The request of a chunk past the end is clamped to the last chunk
     // (a redundant reload into a free slot, never read) so that every wave has exactly NDMA requests per iteration in flight
     // behind the awaited one.
-    auto run = [&](auto trk_tag) {
+    auto run = [&](auto trk_tag) __attribute__((always_inline)) {
         constexpr bool TRK = decltype(trk_tag)::value;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
@@ -372,8 +378,13 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
 
     // (the context store is a lambda called on each path's own exit: merging the two loops' accumulators at a common epilogue
     // would cost a second copy of all of them in registers)
-    auto store_context = [&]() {
+    auto store_context = [&]() __attribute__((always_inline)) {
         if (!active) return;
+        // lane geometry re-derived from an opaque copy: values computed at kernel entry and used only here would otherwise be
+        // held (or spilled) across the whole key loop
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int li_e = lane_e & 31, lh_e = lane_e >> 5;
         // wave-private staging: [32 queries][64 d] as 16-bit rows of 144 B (hi, then lo) or fp32 rows of 272 B
         char* stg = smem_b + wave * 9216;
 #pragma unroll
@@ -384,10 +395,10 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
             for (int g = 0; g < 4; ++g) {      // registers 4g..4g+3 are head dims 8g + 4*half + {0..3}
                 const f32x4 a = f32x4{o0[qb][4 * g] * inv, o0[qb][4 * g + 1] * inv, o0[qb][4 * g + 2] * inv, o0[qb][4 * g + 3] * inv};
                 const f32x4 b = f32x4{o1[qb][4 * g] * inv, o1[qb][4 * g + 1] * inv, o1[qb][4 * g + 2] * inv, o1[qb][4 * g + 3] * inv};
-                const int d = 8 * g + 4 * lh;
+                const int d = 8 * g + 4 * lh_e;
                 if (OUT == 0) {
-                    *reinterpret_cast<f32x4*>(stg + li * 272 + d * 4) = a;
-                    *reinterpret_cast<f32x4*>(stg + li * 272 + (32 + d) * 4) = b;
+                    *reinterpret_cast<f32x4*>(stg + li_e * 272 + d * 4) = a;
+                    *reinterpret_cast<f32x4*>(stg + li_e * 272 + (32 + d) * 4) = b;
                 } else {
                     typedef typename Half16<(OUT > 0 ? OUT - 1 : 0)>::T Ho;
                     typedef Ho H4 __attribute__((ext_vector_type(4)));
@@ -398,11 +409,11 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
                         ah[e] = (Ho)av; al[e] = (Ho)(av - (float)ah[e]);
                         bh[e] = (Ho)bv; bl[e] = (Ho)(bv - (float)bh[e]);
                     }
-                    *reinterpret_cast<H4*>(stg + li * 144 + d * 2) = ah;
-                    *reinterpret_cast<H4*>(stg + li * 144 + (32 + d) * 2) = bh;
+                    *reinterpret_cast<H4*>(stg + li_e * 144 + d * 2) = ah;
+                    *reinterpret_cast<H4*>(stg + li_e * 144 + (32 + d) * 2) = bh;
                     if (SPLIT == 3) {
-                        *reinterpret_cast<H4*>(stg + 4608 + li * 144 + d * 2) = al;
-                        *reinterpret_cast<H4*>(stg + 4608 + li * 144 + (32 + d) * 2) = bl;
+                        *reinterpret_cast<H4*>(stg + 4608 + li_e * 144 + d * 2) = al;
+                        *reinterpret_cast<H4*>(stg + 4608 + li_e * 144 + (32 + d) * 2) = bl;
                     }
                 }
             }
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
             if (OUT == 0) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {       // 4 rows x 256 B per instruction
-                    const int row = 4 * it + (lane >> 4), chunk = lane & 15;
+                    const int row = 4 * it + (lane_e >> 4), chunk = lane_e & 15;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * 272 + chunk * 16);
                     if (i0 + row < R) *reinterpret_cast<f32x4*>(ctx + ((int64_t)(i0 + row) * C + c) * ldc + h * 64 + chunk * 4) = v;
                 }
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {       // 8 rows x 128 B per instruction
-                    const int row = 8 * it + (lane >> 3), chunk = lane & 7;
+                    const int row = 8 * it + (lane_e >> 3), chunk = lane_e & 7;
                     const int64_t ooff = ((int64_t)(i0 + row) * C + c) * ldc + h * 64 + chunk * 8;
                     const u32x4 vh = *reinterpret_cast<const u32x4*>(stg + row * 144 + chunk * 16);
                     if (i0 + row < R) *reinterpret_cast<u32x4*>(ctx_hi + ooff) = vh;

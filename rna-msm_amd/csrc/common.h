@@ -73,7 +73,6 @@ struct Tuning {
     int gemm16_dephase = 2;        // 256x256 16-bit GEMMs, who issues the LDS-DMA requests when: 0 = every wave right after the tile barrier;
                                    // 1 = the upper wave group one (micro-)step later; 2 = 1, and the 16x16x32 kernel stages by operand
                                    // (gemm16_q16s_kernel: W by the lower group, A by the upper one, half a tile apart)
-    int gemm16_x3q = 0;            // hi/lo modes, plane-output GEMMs (QKV, fc1): 1 = gemm16_x3q_kernel (16x16x32 MFMA, staged by operand), 0 = gemm16_swp_kernel
     int gemm16_big_rows = 0;       // rnamsm_gemm_bf16, plane operands: rows from which the 256x256-tile kernels are used (0 = 2048)
     int gemm16_big_rows_fwd = 0;   // ... inside rnamsm_forward / rnamsm_forward_batch: 0 = by mode (10752 plain bf16, 8960 hi/lo), > 0 = that many
     int gemm_group = 0;            // fp32 GEMM: row panels per XCD group of the block order (xcd_panel_map_grouped); 0 = by shape

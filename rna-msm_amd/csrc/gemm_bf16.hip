@@ -568,8 +568,8 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
 
     const unsigned nb = N / HX_BN, mp = (M + HX_BM - 1) / HX_BM;
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wv >> 2, wn = wv & 3, li = lane & 31, lh = lane >> 5;
+    const int lane_k = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wv >> 2, wn = wv & 3;
     // Persistent form: gridDim.x blocks (one per CU) walk the output tiles in launch order, block b taking virtual ids
     // b, b + gridDim.x, ... (gridDim.x % 8 == 0 keeps the XCD affinity of xcd_panel_map_grouped).  A tile's stores then
     // drain while the block already accumulates its next tile, and a start offset per block (stagger_cycles x (b/8 % 4))
@@ -585,21 +585,28 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     const int m0 = mpanel * HX_BM, n0 = nblk * HX_BN;
     __syncthreads();                 // every wave has finished reading the previous tile's epilogue staging
 
+    // Per-tile lane geometry from an OPAQUE copy of the lane id (see the epilogue below): nothing lane-derived is loop-invariant,
+    // so nothing is hoisted to kernel entry and carried -- spilled -- across the tiles.
+    int lane = lane_k, li = lane_k & 31, lh = lane_k >> 5;
+    asm volatile("" : "+v"(lane));
+    li = lane & 31;
+    lh = lane >> 5;
     // DMA map: a wave instruction covers RPI rows; lane -> (row RPI*g + lane / chunks-per-row, physical chunk lane %
     // chunks-per-row), fetching the logical chunk the read-side swizzle expects there.  g = wv + 8j.
     constexpr int CPR = ROWB / 16;
     const int drow = lane / CPR;
     const int dchunk = BK == 32 ? ((lane & 3) ^ ((lane >> 4) & 3))                      // (row >> 2) & 3
                                 : ((lane & 7) ^ ((4 * (wv & 1) + (lane >> 4)) & 7));    // (row >> 1) & 7, row = 8g + lane/8
-    int64_t aoff[Cfg::IPW], woff[Cfg::IPW];
+    // source offsets: one 64-bit base per operand and lane; a lane's further rows lie 8 RPI rows apart -- a uniform stride for W
+    // (N % 256 == 0), a 32-bit delta per row for A (rows past M are clamped to the last one: <= 255 rows, fits an int).  Eight 64-bit
+    // offsets per lane used to live here: with 128 accumulators and two fragment sets that spilled 1-7 registers.
+    const int row0 = Cfg::RPI * wv + drow;
+    const int ma0 = min(m0 + row0, M - 1);
+    const int64_t aoff0 = (int64_t)ma0 * lda + dchunk * 8, woff0 = (int64_t)(n0 + row0) * K + dchunk * 8;
+    const int64_t wstride = (int64_t)(8 * Cfg::RPI) * K;
+    int adelta[Cfg::IPW];
 #pragma unroll
-    for (int j = 0; j < Cfg::IPW; ++j) {
-        const int row = Cfg::RPI * (wv + 8 * j) + drow;
-        int m = m0 + row;
-        m = m < M ? m : M - 1;
-        aoff[j] = (int64_t)m * lda + dchunk * 8;
-        woff[j] = (int64_t)(n0 + row) * K + dchunk * 8;
-    }
+    for (int j = 0; j < Cfg::IPW; ++j) adelta[j] = (min(m0 + row0 + 8 * Cfg::RPI * j, M - 1) - ma0) * (int)lda;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     auto issue = [&](int kt, int buf) {
@@ -607,12 +614,13 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
 #pragma unroll
         for (int j = 0; j < Cfg::IPW; ++j) {
             const int loff = (Cfg::RPI * (wv + 8 * j)) * ROWB;
-            __builtin_amdgcn_global_load_lds((gptr_t)(Ahi + aoff[j] + kt * BK), (lptr_t)(base + loff), 16, 0, 0);
+            const int64_t ao = aoff0 + adelta[j] + kt * BK, wo = woff0 + j * wstride + kt * BK;
+            __builtin_amdgcn_global_load_lds((gptr_t)(Ahi + ao), (lptr_t)(base + loff), 16, 0, 0);
             if (SPLIT == 3)
-                __builtin_amdgcn_global_load_lds((gptr_t)(Alo + aoff[j] + kt * BK), (lptr_t)(base + PLANE + loff), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(Whi + woff[j] + kt * BK), (lptr_t)(base + NPL * PLANE + loff), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(Alo + ao), (lptr_t)(base + PLANE + loff), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(Whi + wo), (lptr_t)(base + NPL * PLANE + loff), 16, 0, 0);
             if (SPLIT == 3)
-                __builtin_amdgcn_global_load_lds((gptr_t)(Wlo + woff[j] + kt * BK), (lptr_t)(base + (NPL + 1) * PLANE + loff), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(Wlo + wo), (lptr_t)(base + (NPL + 1) * PLANE + loff), 16, 0, 0);
         }
     };
     auto frag_load = [&](const char* buf, int kk, HxFrag<SPLIT, FMT>& f) {
@@ -691,10 +699,15 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
         hx_frag_mma<SPLIT, FMT>(f[(KS - 1) & 1], acc);
     }
     wait_dma_then_barrier<0>();                               // the clamped reload has landed: LDS is free for the epilogue
+    // The epilogue's lane geometry is re-derived from an OPAQUE copy of the lane id inside the tile loop: values computed from
+    // the loop-invariant `lane` are hoisted to kernel entry, live across the whole K loop next to 128 accumulators and two
+    // fragment sets, and were spilled (7 registers in the plain-bf16 residual instance, reloaded once per tile).
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
 #pragma unroll
     for (int p = 0; p < 2; ++p)
         hb_epilogue<ACT, HAS_RES, SPLIT, FMT, O_PL>(reinterpret_cast<f32x16(&)[2][2]>(acc[2 * p]), smem_b,
-                                                    m0 + wm * 128 + p * 64, n0 + wn * 64, wv, lane, li, lh, bias, residual,
+                                                    m0 + wm * 128 + p * 64, n0 + wn * 64, wv, lane_e, lane_e & 31, lane_e >> 5, bias, residual,
                                                     ldr, Cout, ldc, M, scale, scale_cols, Ohi, Olo, fa);
     }   // persistent tile loop
 }
@@ -1012,276 +1025,8 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16s_kernel(
     }   // persistent tile loop
 }
 
-// ---- hi/lo modes on v_mfma_f32_16x16x32_{bf16,f16}, staged by operand (plane outputs: QKV, fc1) ---------------------------
-// The structure of gemm16_q16s_kernel for operands that are hi + lo planes (three products per tile pair): 256x256 tile, 8
-// waves (2 x 4), wave tile 128 x 64 = 8 x 4 MFMA tiles, BK = 32 = ONE k-step of the 16x16x32 MFMA, four 16 KB planes per stage
-// (A hi, A lo, W hi, W lo; 64-byte tile rows), two stages.  A tile is consumed in four micro-steps (row quarters q = 0..3 of the
-// wave's 128 rows; 24 MFMAs each).  Fragments: the A fragments of a quarter ping-pong (2 x 16 registers), the B fragments of
-// the tile (32 registers) serve all four micro-steps and are REPLACED column tile by column tile during the last one, each
-// right after its last use (the MFMAs run column-tile-major), so the next tile's B needs no registers of its own: 64 fragment
-// registers next to 128 accumulators (a half-tile ping-pong, 96, spilled).  Consequence for the staging: the W planes of a
-// stage have been read completely when its tile STARTS (B was fetched during the previous tile's last quarter) and the A planes
-// when its last quarter starts -- so the lower wave group requests W of tile t+2 behind the barrier at the start of quarter 0
-// and the upper one A of tile t+2 behind the barrier at the start of quarter 3: each burst under the other group's MFMAs (see
-// gemm16_q16s_kernel), flight time 1.75 / 1 tiles.
-// 64-byte rows need their own swizzle for the 16-row fragment reads: a ds_read_b128 is served in groups of 16 lanes that here
-// hold four row quads q = (row >> 2) & 3 at two k-chunks; physical chunk = logical chunk ^ s(q), s = {0, 2, 3, 1}, gives the
-// 16 lanes 16 distinct 16-byte slots of the 256-byte bank row.
-// The epilogue is register-direct (hq_epilogue's map: W rows permuted by the DMA so a lane holds 8 + 8 consecutive columns)
-// and writes hi and lo planes; the next output tile's first stage is requested before the stores.
-__device__ __forceinline__ int x3q_swz(int q) { return (0x78 >> (2 * q)) & 3; }     // {0, 2, 3, 1}
-
-template <int ACT, int FMT>
-__global__ __launch_bounds__(HX_THREADS, 1) void gemm16_x3q_kernel(
-    const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo, int64_t lda, const uint16_t* __restrict__ Whi,
-    const uint16_t* __restrict__ Wlo, const float* __restrict__ bias, int64_t ldc, int M, int N, int K, float scale,
-    int scale_cols, uint16_t* __restrict__ Ohi, uint16_t* __restrict__ Olo, int group, unsigned total_tiles) {
-    constexpr int BK = 32, ROWB = 64, PLANE = 256 * ROWB, BUF = 4 * PLANE;
-    typedef typename Half16<FMT>::V8 V8;
-    typedef typename Half16<FMT>::T H;
-    extern __shared__ __attribute__((aligned(16))) char smem_b[];
-
-    const unsigned nb = N / HX_BN, mp = (M + HX_BM - 1) / HX_BM;
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wv >> 2, wn = wv & 3, fr = lane & 15, fq = lane >> 4, w4 = wv & 3;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    constexpr int X3_STORES = 32;                             // store instructions of one epilogue, per lane
-    // staging: a wave instruction covers 16 tile rows of 64 B; this wave's row groups are g = w4 + 4 j (j < 4) of its group's
-    // operand; lane -> (row 16 g + lane / 4, physical chunk lane % 4) fetching the logical chunk the read-side swizzle expects
-    const int dchunk = (lane & 3) ^ x3q_swz((lane >> 4) & 3);                 // (row >> 2) & 3 = (lane >> 4) & 3
-    const uint16_t* __restrict__ src_hi = wm ? Ahi : Whi;    // uniform
-    const uint16_t* __restrict__ src_lo = wm ? Alo : Wlo;
-    int64_t off[4];
-    auto find_tile = [&](unsigned& vid, int& m0, int& n0) -> bool {
-        for (; vid < total_tiles; vid += gridDim.x) {
-            unsigned mpanel, nblk;
-            if (xcd_panel_map_grouped(vid, mp, nb, (unsigned)group, mpanel, nblk)) {
-                m0 = mpanel * HX_BM;
-                n0 = nblk * HX_BN;
-                return true;
-            }
-        }
-        return false;
-    };
-    auto set_offsets = [&](int m0, int n0) {
-        // W rows are permuted on their way into LDS (hq_epilogue): LDS row 64 G + 16 t + 4 a + b  <-  weight row
-        // 64 G + 32 (t >> 1) + 8 a + 4 (t & 1) + b; for LDS row 16 (w4 + 4 j) + lane / 4: G = j, t = w4, 4 a + b = lane / 4
-        const int wrow0 = 32 * (w4 >> 1) + 8 * ((lane >> 4) & 3) + 4 * (w4 & 1) + ((lane >> 2) & 3);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int m = m0 + 16 * (w4 + 4 * j) + (lane >> 2);
-            m = m < M ? m : M - 1;
-            off[j] = wm ? (int64_t)m * lda + dchunk * 8 : (int64_t)(n0 + wrow0 + 64 * j) * K + dchunk * 8;
-        }
-    };
-    auto issue_mine = [&](int kt, int buf) {                 // this wave group's operand (hi and lo planes) of K tile kt
-        char* base = smem_b + buf * BUF + (wm ? 0 : 2 * PLANE) + 1024 * w4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(src_hi + off[j] + kt * BK), (lptr_t)(base + 4096 * j), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(src_lo + off[j] + kt * BK), (lptr_t)(base + PLANE + 4096 * j), 16, 0, 0);
-        }
-    };
-    unsigned vid = blockIdx.x;
-    int m0, n0;
-    if (!find_tile(vid, m0, n0)) return;
-    set_offsets(m0, n0);
-    issue_mine(0, 0);
-    bool stores_in_flight = false;                            // uniform
-    const int chunk = (fq ^ x3q_swz((fr >> 2) & 3)) * 16;     // lane (row fr, k-group fq) of a 16-row tile reads logical chunk fq
-    for (;;) {
-    V8 ah[2][2][2], bq[2][4];                                 // [set][plane][row tile of the quarter], [plane][column tile]
-    auto load_a1 = [&](const char* buf, int q, int set, int p) {      // one plane of row quarter q (row tiles 2 q, 2 q + 1)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-            ah[set][p][t] = *reinterpret_cast<const V8*>(buf + p * PLANE + (wm * 128 + (2 * q + t) * 16 + fr) * ROWB + chunk);
-    };
-    auto load_b1 = [&](const char* buf, int nt) {             // both planes of one column tile
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-            bq[p][nt] = *reinterpret_cast<const V8*>(buf + (2 + p) * PLANE + (wn * 64 + nt * 16 + fr) * ROWB + chunk);
-    };
-    f32x4a acc[8][4];
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4a{0.f, 0.f, 0.f, 0.f};
-    // one column tile of a micro-step: 2 row tiles x 3 products (small cross terms first, the leading term last); operands
-    // swapped so the tile comes out transposed in the registers (hq_epilogue)
-    auto mma_nt = [&](int q, int set, int nt) {
-        f32x4a c0 = acc[2 * q][nt], c1 = acc[2 * q + 1][nt];  // the two row tiles alternate: no MFMA waits for its predecessor's result
-        if (FMT == 1) {
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[0][nt], ah[set][1][0], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[0][nt], ah[set][1][1], c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[1][nt], ah[set][0][0], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[1][nt], ah[set][0][1], c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[0][nt], ah[set][0][0], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bq[0][nt], ah[set][0][1], c1, 0, 0, 0);
-        } else {
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[0][nt], ah[set][1][0], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[0][nt], ah[set][1][1], c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[1][nt], ah[set][0][0], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[1][nt], ah[set][0][1], c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[0][nt], ah[set][0][0], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[0][nt], ah[set][0][1], c1, 0, 0, 0);
-        }
-        acc[2 * q][nt] = c0;
-        acc[2 * q + 1][nt] = c1;
-    };
-    // pin "6 MFMAs with NDS_ fragment reads between the first of them"
-#define X3_PIN(NDS_)                                                                  \
-    _Pragma("unroll") for (int i_ = 0; i_ < NDS_; ++i_) {                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
-    }                                                                                 \
-    __builtin_amdgcn_sched_group_barrier(0x008, 6 - NDS_, 0);                         \
-    __builtin_amdgcn_sched_barrier(0)
-    // a quarter whose successor's A fragments come from `abuf` (quarter qn into set sn): one read per column tile
-#define X3_QUARTER(Q_, SET_, ABUF_, QN_, SN_)                                         \
-    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                \
-        if ((nt & 1) == 0) load_a1(ABUF_, QN_, SN_, nt >> 1);                         \
-        mma_nt(Q_, SET_, nt);                                                         \
-        if ((nt & 1) == 0) { X3_PIN(2); } else { X3_PIN(0); }                         \
-    }
-
-    const int nk = K / BK;
-    // tile 0 was requested before the previous output tile's stores (or at kernel start)
-    if (stores_in_flight) wait_dma_then_barrier<X3_STORES>();
-    else wait_dma_then_barrier<0>();
-    issue_mine(nk > 1 ? 1 : 0, 1);
-    load_a1(smem_b, 0, 0, 0);
-    load_a1(smem_b, 0, 0, 1);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) load_b1(smem_b, t);
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* cur = smem_b + (kt & 1) * BUF;
-        const char* nxt = smem_b + ((kt & 1) ^ 1) * BUF;
-        const bool more = kt + 1 < nk;                        // uniform
-        const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;         // clamped: the last reload is never read (keeps the counted wait fixed)
-        if (more) {
-            // every wave holds its B fragments of tile kt (fetched during the previous tile's last quarter): the W planes of
-            // `cur` are free
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (wm == 0) issue_mine(k2, kt & 1);              // W of tile kt+2
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        X3_QUARTER(0, 0, cur, 1, 1)
-        X3_QUARTER(1, 1, cur, 2, 0)
-        X3_QUARTER(2, 0, cur, 3, 1)                           // (the last reads of the A planes of `cur`)
-        if (more) {
-            // every wave has read the A planes of `cur`, and tile kt+1 has landed: the A group waits for all of its requests,
-            // the W group leaves its newest 8 (W of tile kt+2, requested 3/4 of a tile ago) in flight
-            if (wm == 0) wait_dma_then_barrier<8>();
-            else wait_dma_then_barrier<0>();
-            if (wm == 1) issue_mine(k2, kt & 1);              // A of tile kt+2
-            __builtin_amdgcn_sched_barrier(0);
-            // the last quarter computes; the next tile's first quarter and, column tile by column tile behind its last use,
-            // the next tile's B fragments arriving
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                if (nt > 0) load_b1(nxt, nt - 1);
-                if ((nt & 1) == 0) load_a1(nxt, 0, 0, nt >> 1);
-                mma_nt(3, 1, nt);
-                if (nt == 0) { X3_PIN(2); } else if (nt == 2) { X3_PIN(4); } else { X3_PIN(2); }
-            }
-            load_b1(nxt, 3);
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) mma_nt(3, 1, nt);
-        }
-    }
-#undef X3_QUARTER
-#undef X3_PIN
-    wait_dma_then_barrier<0>();                               // every wave is done with LDS; the clamped reloads have landed
-    // ---- epilogue: bias first, then the next output tile's first stage, then the stores
-    const int em0 = m0 + wm * 128, en0 = n0 + wn * 64;
-    f32x4 b4[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int col = en0 + 32 * (t >> 1) + 8 * fq + 4 * (t & 1);
-        b4[t] = bias ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-        asm volatile("" : "+v"(b4[t]));                       // waited for HERE, not inside the stores (see gemm16_q16s_kernel)
-    }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    unsigned nvid = vid + gridDim.x;
-    int m1 = 0, n1 = 0;
-    const bool more_tiles = find_tile(nvid, m1, n1);
-    if (more_tiles) {
-        set_offsets(m1, n1);
-        issue_mine(0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        float fs[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) fs[t] = en0 + 32 * (t >> 1) + 8 * fq + 4 * (t & 1) < scale_cols ? scale : 1.f;   // scale_cols % 4 == 0
-        typedef H H8 __attribute__((ext_vector_type(8)));
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int row = em0 + mt * 16 + fr;
-            f32x4 v[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[t][e] = (acc[mt][t][e] + b4[t][e]) * fs[t];
-                if (ACT == RNAMSM_ACT_GELU_ERF) {
-                    const f32x2 g0 = gelu_erf2(f32x2{v[t][0], v[t][1]}), g1 = gelu_erf2(f32x2{v[t][2], v[t][3]});
-                    v[t] = f32x4{g0[0], g0[1], g1[0], g1[1]};
-                }
-            }
-#pragma unroll
-            for (int hlf = 0; hlf < 2; ++hlf) {               // columns 8 fq .. + 7 of the tile's first / second 32
-                if (row < M) {
-                    const int64_t o = (int64_t)row * ldc + en0 + 32 * hlf + 8 * fq;
-                    H8 hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x0 = pinned(v[2 * hlf][e]), x1 = pinned(v[2 * hlf + 1][e]);
-                        hi[e] = (H)x0;
-                        hi[4 + e] = (H)x1;
-                        lo[e] = (H)(x0 - (float)hi[e]);
-                        lo[4 + e] = (H)(x1 - (float)hi[4 + e]);
-                    }
-                    epi_store(reinterpret_cast<H8*>(Ohi + o), hi);
-                    epi_store(reinterpret_cast<H8*>(Olo + o), lo);
-                }
-            }
-        }
-    }
-    if (!more_tiles) break;
-    vid = nvid;
-    m0 = m1;
-    n0 = n1;
-    stores_in_flight = em0 + 128 <= M;                        // a ragged last row panel drops stores: those tiles drain
-    if (!stores_in_flight) __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0), keep expcnt / lgkmcnt
-    }   // persistent tile loop
-}
-
-template <int ACT, int FMT>
-static int launch_x3q(const uint16_t* Whi, const uint16_t* Wlo, const float* bias, int64_t ldc, int64_t lda, int M, int N, int K,
-                      float scale, int scale_cols, const uint16_t* a_hi, const uint16_t* a_lo, uint16_t* o_hi, uint16_t* o_lo,
-                      hipStream_t stream) {
-    static DeviceOnce configured;
-    auto kern = gemm16_x3q_kernel<ACT, FMT>;
-    constexpr int lds = 2 * 4 * 256 * 64;
-    if (configured.pending()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_x3q: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured.mark();
-    }
-    const int group = tuning().gemm_group > 0 ? tuning().gemm_group
-                                              : (N / HX_BN > 4 ? (int)xcd_group_for_persistent((M + HX_BM - 1) / HX_BM, 8) : 1);
-    const unsigned total = xcd_panel_grid_grouped((M + HX_BM - 1) / HX_BM, N / HX_BN, (unsigned)group);
-    const unsigned pb = tuning().gemm16_persist > 0 ? (unsigned)tuning().gemm16_persist : 0u;
-    const unsigned grid = pb && pb < total ? pb : total;
-    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, gemm16_bytes(M, N, K, 2, false, true), stream, PEAK_F16_MFMA_TFLOPS, 3.0);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, a_lo, lda, Whi, Wlo, bias, ldc, M, N, K, scale,
-                       scale_cols, o_hi, o_lo, group, total);
-    RNAMSM_CHECK_LAUNCH("gemm16_x3q");
-    return RNAMSM_OK;
-}
+// (a three-product 16x16x32 kernel staged by operand, "gemm16_x3q", was measured at +1.8 % and removed in round 4: its k order
+// moved the f16x3 embedding error -- EXPERIMENTS.md R3.3b, git history)
 
 template <int ACT, bool HAS_RES, bool O_PL>
 static int launch_hq(const uint16_t* Whi, const float* bias, const float* residual, int64_t ldr, float* Cout, int64_t ldc,
@@ -1457,11 +1202,6 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
                                                         : HQ_GO(RNAMSM_ACT_NONE, false, true);                       \
             return residual ? HQ_GO(RNAMSM_ACT_NONE, true, false) : HQ_GO(RNAMSM_ACT_NONE, false, false);            \
         }                                                                                                           \
-        /* hi/lo modes, plane output: the 16x16x32 kernel staged by operand ("gemm16_x3q") */                         \
-        if (SP_ == 3 && A_hi && O_hi && tuning().gemm16_x3q && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= big_rows && K % 32 == 0) \
-            return act == RNAMSM_ACT_GELU_ERF                                                                        \
-                       ? launch_x3q<RNAMSM_ACT_GELU_ERF, FMT_>(W_hi, W_lo, bias, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s) \
-                       : launch_x3q<RNAMSM_ACT_NONE, FMT_>(W_hi, W_lo, bias, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s);    \
         if (A_hi && tuning().gemm16_dma >= 3 && N % HX_BN == 0 && m >= big_rows) {   /* software-pipelined fragments */    \
             if (O_hi) return act == RNAMSM_ACT_GELU_ERF ? HS_GO(RNAMSM_ACT_GELU_ERF, false, SP_, FMT_, true)        \
                                                         : HS_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, true);           \

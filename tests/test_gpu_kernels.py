@@ -822,56 +822,6 @@ def test_dma_issue_schedules_of_the_256x256_gemms_are_bit_identical(dev, M, N, K
         _lib.check(lib.rnamsm_set_param(b"gemm16_dephase", 2))
 
 
-@pytest.mark.parametrize("fmt", [0, 1])
-@pytest.mark.parametrize("M,N,K,act", [(16384, 2304, 768, 0), (9000, 3072, 768, 1), (2048, 1280, 64, 0), (2100, 256, 128, 1)])
-def test_hi_lo_gemm_on_16x16x32_staged_by_operand(dev, M, N, K, act, fmt):
-    """Knob "gemm16_x3q": the hi/lo modes' plane-output GEMMs (QKV, fc1) on gemm16_x3q_kernel: v_mfma_f32_16x16x32, four 16 KB planes per stage in
-    64-byte rows with their own swizzle, W staged by the lower wave group and A by the upper one behind two barriers per tile with a
-    counted vmcnt, B fragments replaced in place during the last quarter, the next output tile requested before the 32 stores.
-    Many tiles per block, a ragged last row panel (its tile drains), two and four K tiles: reruns bit-identical (a miscounted wait
-    would read LDS ahead of a DMA now and then), values against fp64 on what the planes hold, the 32x32x16 kernel next to it
-    (knob "gemm16_x3q" = 0; the k order inside a tile differs: fp32 rounding), exact on integers."""
-    from rnamsm import ops, _lib
-    lib = _lib.load()
-    _lib.check(lib.rnamsm_set_param(b"gemm16_x3q", 1))       # (not the default: see include/rnamsm.h)
-    try:
-        _x3q_checks(dev, ops, lib, _lib, M, N, K, act, fmt)
-    finally:
-        _lib.check(lib.rnamsm_set_param(b"gemm16_x3q", 0))
-
-
-def _x3q_checks(dev, ops, lib, _lib, M, N, K, act, fmt):
-    ht = torch.float16 if fmt == 1 else torch.bfloat16
-    eff = lambda pl: sum(p.view(ht).double() for p in pl if p is not None)
-    a = ops.split_bf16(_rand("x3.a", (M, K)).to(dev), want_lo=True, fmt=fmt)
-    w = ops.split_bf16(_rand("x3.w", (N, K), 0.05).to(dev), want_lo=True, fmt=fmt)
-    b = _rand("x3.b", (N,), 0.1).to(dev)
-    run = lambda: ops.linear_planes(a, w, b, act=act, scale=0.125, scale_cols=768 if (not act and N >= 768) else 0, out_planes=True, fmt=fmt)
-    first = [t.clone() for t in run()]
-    for _ in range(15):
-        again = run()
-        assert torch.equal(again[0], first[0]) and torch.equal(again[1], first[1])
-    rows = torch.cat([torch.arange(0, min(512, M)), torch.arange(M - 300, M)]).to(dev)      # first tiles and the ragged tail
-    want = eff(a)[rows] @ eff(w).t() + b.double()
-    if act:
-        want = O.gelu_erf(want)
-    elif N >= 768:
-        want[:, :768] *= 0.125
-    tol = 4e-5 if fmt == 0 else 3e-6
-    got = eff(first)[rows]
-    assert rel_l2(got.cpu(), want.cpu()) < tol
-    _lib.check(lib.rnamsm_set_param(b"gemm16_x3q", 0))
-    try:
-        other = eff(run())[rows]
-    finally:
-        _lib.check(lib.rnamsm_set_param(b"gemm16_x3q", 1))
-    assert rel_l2(got.cpu(), other.cpu()) < tol
-    ai = torch.from_numpy(((np.arange(M * K).reshape(M, K) * 7 + 3) % 13 - 6).astype(np.float32))
-    wi = torch.from_numpy(((np.arange(N * K).reshape(N, K) * 5 + 1) % 11 - 5).astype(np.float32))
-    oi = ops.linear_planes(ops.split_bf16(ai.to(dev), want_lo=True, fmt=fmt), ops.split_bf16(wi.to(dev), want_lo=True, fmt=fmt), out_planes=True, fmt=fmt)
-    assert torch.equal(eff(oi).cpu(), (ai @ wi.t()).double())        # |values| <= 36 K: exact in fp32 and in a hi/lo pair
-
-
 @pytest.mark.parametrize("M,N,K", [(300, 2304, 96), (4100, 1280, 64), (1025, 768, 768), (129, 3072, 32)])
 def test_gemm_block_order_never_changes_results(dev, M, N, K):
     """rnamsm_set_param("gemm_group"): the XCD-aware block order (whole panels, groups of G panels, by-shape default)

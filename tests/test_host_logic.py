@@ -186,6 +186,21 @@ def test_library_exports_every_symbol_declared_in_the_header(lib):
     assert lib.rnamsm_version() == 400         # ABI 4.0 (round 4): rnamsm_model_dims.row_pos_dim, + rnamsm_embed_ln_rows, rnamsm_timing_get_valu_bound
 
 
+def test_no_kernel_of_the_shipped_library_spills(lib):
+    """Every gfx950 kernel in librnamsm_hip.so, from the code objects' own metadata (tools/code_objects.py): no VGPR spill and
+    no scratch at all -- a default-path kernel that spills re-reads its own registers from memory inside the loop the roofline
+    fraction is quoted on.  (SGPR spills go to VGPR lanes, not memory, and are only reported by the tool.)"""
+    import importlib.util
+    from rnamsm import _lib
+    spec = importlib.util.spec_from_file_location("code_objects", os.path.join(ROOT, "tools", "code_objects.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ks = mod.kernels_of(_lib.LIB_PATH)
+    assert len(ks) > 100, len(ks)
+    bad = [(k["name"], k["vgpr_spills"], k["scratch_bytes"]) for k in ks if k["vgpr_spills"] or k["scratch_bytes"]]
+    assert not bad, bad
+
+
 def test_ctypes_signatures_match_the_header_prototypes():
     """Every prototype of include/rnamsm.h against the ctypes table of rnamsm/_lib.py: same number of parameters, and per
     parameter the same class (pointer / 64-bit integer / int / float / size_t) -- a drifted binding would otherwise pass
