@@ -437,6 +437,28 @@ int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* const* weig
                          int* err_flag, int has_padding, const int* true_rows, const float* const* ln_folded, int dtype,
                          const uint16_t* const* weight_planes, void* stream);
 
+/* B alignments of DIFFERENT shapes as one TOKEN-PACKED batch (round 4): no frame, no padding, exact fp32 path.  The reference
+ * feeds short RNAs of unlike length and depth one by one (RNA_MSM_Inference.py:141-148, model.py:338-416 per MSA); a padded
+ * frame of such alignments (rnamsm_forward_batch with true_rows) holds 1.4-1.5x their real tokens.  Here the alignments lie
+ * back to back on the token axis and every output is the concatenation of what rnamsm_forward returns per alignment:
+ *   tokens   int64 [T], T = sum R_b*C_b: alignment 0's [R_0, C_0] row-major, then alignment 1's, ... (device)
+ *   shapes   int32 [B][2] = {R_b, C_b} on the HOST (read during the call; 1 <= R_b <= 1024, 2 <= C_b)
+ *   row_attn [sum L*H*C_b*C_b]   repr [T, D]   emb [sum (C_b-1)*D]   atp [sum L*H*(C_b-1)^2]   (device, fp32)
+ * The per-token launches (LayerNorm, the six GEMMs of a layer) run once over the T real tokens; K0, K4-K7 and K10 take the
+ * alignment from gridDim.y and its shape / offsets from a descriptor table the call writes into the workspace.  Every
+ * alignment keeps the tied-logit slab split of its own forward; q carries dh^-1/2 and the alignment's 1/sqrt(R_b)
+ * (align_scaling, modules.py:713-715) multiplies its summed logits -- one rounding apart from rnamsm_forward, which folds both
+ * into q -- and fc2's split-K / the folded LayerNorm are decided by T: outputs equal rnamsm_forward's per alignment to fp32
+ * rounding (tests: 2e-6), not bit for bit.  A packed batch builds no masks: <pad> inside it sets bit 3 (value 8) of *err_flag
+ * and the caller reruns that batch framed.  dtype must be RNAMSM_F32 (RNAMSM_ERR_UNSUPPORTED otherwise: 16-bit batches go
+ * through rnamsm_forward_batch); ln_folded as in rnamsm_forward or NULL.  rnamsm_forward_packed_workspace_bytes returns 0 for
+ * a shape outside the limits. */
+#define RNAMSM_ERR_PAD_IN_PACKED 8
+size_t rnamsm_forward_packed_workspace_bytes(const rnamsm_model_dims* dims, int B, const int* shapes);
+int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens, int B,
+                          const int* shapes, void* workspace, size_t workspace_bytes, float* row_attn, float* repr, float* emb,
+                          float* atp, int* err_flag, const float* const* ln_folded, int dtype, void* stream);
+
 /* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's
  * roofline block; adds two event records per launch while enabled, nothing when disabled).
  *   rnamsm_timing_enable(1) ... enqueue work ... (caller synchronises the stream) ... rnamsm_timing_collect()

@@ -36,7 +36,8 @@ template <bool MASKED, int OUT>
 __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask,
-    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows, int64_t qkv_bstride, int64_t ctx_bstride) {
+    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows, int64_t qkv_bstride, int64_t ctx_bstride,
+    const PackedMsa* /* packed batches run on col_attn_dma_kernel */, int) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     q += blockIdx.y * qkv_bstride;        // batched launch (rnamsm_forward_batch): MSA blockIdx.y, fp32 context
     k += blockIdx.y * qkv_bstride;
@@ -265,13 +266,26 @@ template <bool MASKED, int OUT>
 __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask,
-    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows, int64_t qkv_bstride, int64_t ctx_bstride) {
+    uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows, int64_t qkv_bstride, int64_t ctx_bstride,
+    const PackedMsa* __restrict__ pk, int pk_skip_shallow) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
-    q += blockIdx.y * qkv_bstride;        // batched launch (rnamsm_forward_batch): MSA blockIdx.y, fp32 context
-    k += blockIdx.y * qkv_bstride;
-    v += blockIdx.y * qkv_bstride;
-    if (OUT == 0) ctx += blockIdx.y * ctx_bstride;
-    if (MASKED) pad_mask += blockIdx.y * ((int64_t)R * C);         // its own [R, C] mask
+    if (pk) {
+        // token-packed batch (rnamsm_forward_packed; unmasked, fp32 context): alignment blockIdx.y's own shape and token offset;
+        // the shallow ones (R <= 16) belong to col_attn_small_kernel's launch when pk_skip_shallow is set
+        const PackedMsa& m = pk[blockIdx.y];
+        if (pk_skip_shallow && m.R <= 16) return;
+        R = m.R; C = m.C; q_rows = m.R;
+        q += m.tok0 * ld;
+        k += m.tok0 * ld;
+        v += m.tok0 * ld;
+        if (OUT == 0) ctx += m.tok0 * ldc;
+    } else {
+        q += blockIdx.y * qkv_bstride;        // batched launch (rnamsm_forward_batch): MSA blockIdx.y, fp32 context
+        k += blockIdx.y * qkv_bstride;
+        v += blockIdx.y * qkv_bstride;
+        if (OUT == 0) ctx += blockIdx.y * ctx_bstride;
+        if (MASKED) pad_mask += blockIdx.y * ((int64_t)R * C);         // its own [R, C] mask
+    }
 
     const unsigned iblocks = (q_rows + CA_ROWS - 1) / CA_ROWS;       // query rows [0, q_rows) only (q_rows == R: all)
     unsigned prob, ib;
@@ -524,16 +538,27 @@ __global__ __launch_bounds__(256) void col_attn_small_kernel(const float* __rest
                                                              const float* __restrict__ v, int64_t ld, float* __restrict__ ctx,
                                                              int64_t ldc, int R, int C, int H,
                                                              const uint8_t* __restrict__ pad_mask, int q_rows,
-                                                             int64_t qkv_bstride, int64_t ctx_bstride) {
+                                                             int64_t qkv_bstride, int64_t ctx_bstride,
+                                                             const PackedMsa* __restrict__ pk) {
     typedef float f32x4s __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int prob = blockIdx.x * 4 + wave;
+    if (pk) {                                                    // token-packed batch: the shallow alignments only
+        const PackedMsa& m = pk[blockIdx.y];
+        if (m.R > 16) return;
+        R = m.R; C = m.C; q_rows = m.R;
+        q += m.tok0 * ld;
+        k += m.tok0 * ld;
+        v += m.tok0 * ld;
+        ctx += m.tok0 * ldc;
+    } else {
+        q += blockIdx.y * qkv_bstride;
+        k += blockIdx.y * qkv_bstride;
+        v += blockIdx.y * qkv_bstride;
+        ctx += blockIdx.y * ctx_bstride;
+        if (MASKED) pad_mask += blockIdx.y * ((int64_t)R * C);
+    }
     if (prob >= C * H) return;                                   // wave-uniform
-    q += blockIdx.y * qkv_bstride;
-    k += blockIdx.y * qkv_bstride;
-    v += blockIdx.y * qkv_bstride;
-    ctx += blockIdx.y * ctx_bstride;
-    if (MASKED) pad_mask += blockIdx.y * ((int64_t)R * C);
     const int c = prob / H, h = prob % H;
     const int fr = lane & 15, fq = lane >> 4;
     const int rr = min(fr, R - 1);                               // rows past R are clamped: masked as keys, not stored as queries
@@ -614,9 +639,9 @@ static int col_attn_launch(const float* q, const float* k, const float* v, int64
     if (R <= 16 && !ctx_hi && tuning().col_small != 0) {
         const dim3 sgrid(((unsigned)C * H + 3) / 4, batch);
         if (pad_mask)
-            hipLaunchKernelGGL(col_attn_small_kernel<true>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, q_rows, qkv_bstride, ctx_bstride);
+            hipLaunchKernelGGL(col_attn_small_kernel<true>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, q_rows, qkv_bstride, ctx_bstride, (const PackedMsa*)nullptr);
         else
-            hipLaunchKernelGGL(col_attn_small_kernel<false>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, q_rows, qkv_bstride, ctx_bstride);
+            hipLaunchKernelGGL(col_attn_small_kernel<false>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, q_rows, qkv_bstride, ctx_bstride, (const PackedMsa*)nullptr);
         RNAMSM_CHECK_LAUNCH("col_attn_small");
         return RNAMSM_OK;
     }
@@ -630,7 +655,7 @@ static int col_attn_launch(const float* q, const float* k, const float* v, int64
             cfg_.mark();                                                                                            \
         }                                                                                                           \
         hipLaunchKernelGGL((KERN_<M_, OUT_>), dim3(grid, batch), dim3(CA_THREADS), LDS_, s, q, k, v, ld, ctx, ldc, R, C, H, \
-                           pad_mask, ctx_hi, ctx_lo, q_rows, qkv_bstride, ctx_bstride);                             \
+                           pad_mask, ctx_hi, ctx_lo, q_rows, qkv_bstride, ctx_bstride, (const PackedMsa*)nullptr, 0); \
     } while (0)
     // "col_dma": 1 = the LDS-DMA, three-blocks-per-CU variant, 0 = the register-staged kernel, -1 (default) = the former.
     // Measured in one process (tools/col_attn_ab.py, after the key-range masking was confined to the ragged last tile):
@@ -659,5 +684,47 @@ int col_attn_batched(const float* q, const float* k, const float* v, int64_t ld,
                      int batch, int64_t qkv_bstride, int64_t ctx_bstride, const uint8_t* pad_mask, void* stream) {
     return col_attn_launch(q, k, v, ld, ctx, ldc, R, C, H, CA_HD, pad_mask, nullptr, nullptr, 0, RNAMSM_F32, stream, R, batch,
                            qkv_bstride, ctx_bstride);
+}
+
+// K7 of a token-packed batch (rnamsm_forward_packed): the LDS-DMA kernel with gridDim.y = alignment, gridDim.x sized for the
+// largest alignment; with "col_small" on, the alignments of R <= 16 go to a second launch of the one-wave-per-problem kernel
+int col_attn_packed(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int H, const PackedMsa* pk,
+                    const PackedMsa* host, int B, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool split_shallow = tuning().col_small != 0;
+    unsigned grid = 0, sgrid = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const PackedMsa& m = host[b];
+        if (split_shallow && m.R <= 16) {
+            const unsigned g = ((unsigned)m.C * H + 3) / 4;
+            sgrid = g > sgrid ? g : sgrid;
+        } else {
+            const unsigned g = xcd_panel_grid((unsigned)m.C * H, (m.R + CA_ROWS - 1) / CA_ROWS);
+            grid = g > grid ? g : grid;
+        }
+        flops += 4.0 * m.C * H * (double)m.R * m.R * CA_HD;
+        bytes += 4.0 * 4.0 * m.R * m.C * H * CA_HD;
+    }
+    KernelTimer timer(TC_COL_ATTN, flops, bytes, s);
+    if (grid) {
+        static DeviceOnce cfg;
+        if (cfg.pending()) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn_dma_kernel<false, 0>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS_BYTES);
+            if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn (packed): hipFuncSetAttribute: %s", hipGetErrorString(e));
+            cfg.mark();
+        }
+        hipLaunchKernelGGL((col_attn_dma_kernel<false, 0>), dim3(grid, B), dim3(CA_THREADS), CD_LDS_BYTES, s, q, k, v, ld, ctx, ldc, 0, 0, H,
+                           (const uint8_t*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr, 0, (int64_t)0, (int64_t)0, pk,
+                           split_shallow ? 1 : 0);
+        RNAMSM_CHECK_LAUNCH("col_attn (packed)");
+    }
+    if (sgrid) {
+        hipLaunchKernelGGL(col_attn_small_kernel<false>, dim3(sgrid, B), dim3(256), 0, s, q, k, v, ld, ctx, ldc, 0, 0, H,
+                           (const uint8_t*)nullptr, 0, (int64_t)0, (int64_t)0, pk);
+        RNAMSM_CHECK_LAUNCH("col_attn_small (packed)");
+    }
+    return RNAMSM_OK;
 }
 }  // namespace rnamsm

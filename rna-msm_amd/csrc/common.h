@@ -333,4 +333,37 @@ int embed_ln_batched(const int64_t* tokens, const float* embed_tokens, const flo
 int pack_outputs_batched(const float* x_final, const float* probs_all, float* emb, float* atp, int C, int D, int num_layers, int H,
                          int B, int64_t x_bstride, int64_t probs_bstride, int* err_flag, hipStream_t stream);
 
+
+// ---- token-packed batches (rnamsm_forward_packed): alignments of DIFFERENT shapes concatenated along the token axis, no padding.
+// The token-parallel launches (GEMMs, LayerNorm) see one [T, D] matrix; K0, K4-K7 and K10 take the alignment from blockIdx.y and
+// its shape / offsets from this descriptor (device array of B entries, written by packed_descriptors_upload), gridDim.x sized
+// for the largest alignment of the batch (blocks past an alignment's own need return at once).
+struct PackedMsa {           // 64 bytes
+    int32_t R, C;            // the alignment's own shape
+    int32_t nsplit, rows_per_split;      // its tied-logits slabs (choose_row_split of ITS shape: the summation order of its own forward)
+    int64_t tok0;            // tokens of the alignments before it
+    int64_t part_off;        // floats: its slabs [nsplit, H, C, C] inside the slab workspace
+    int64_t probs_off;       // floats: its maps [NL, H, C, C] inside row_attn
+    int64_t emb_off;         // floats: its [C-1, D] inside emb
+    int64_t atp_off;         // floats: its [NL*H, C-1, C-1] inside atp
+    float logit_scale;       // 1 / sqrt(R): align_scaling's depth factor, applied to the summed tied logits (modules.py:713-715)
+    int32_t pad_;
+};
+static_assert(sizeof(PackedMsa) == 64, "PackedMsa layout");
+int packed_descriptors_upload(const PackedMsa* host, int B, PackedMsa* dev, hipStream_t stream);
+int embed_ln_packed(const int64_t* tokens, const float* embed_tokens, const float* embed_positions, const float* row_pos,
+                    const float* gamma, const float* beta, float* out, const PackedMsa* pk, int B, int64_t T, int D, int vocab,
+                    int num_positions, int pad_idx, float eps, int* err_flag, hipStream_t stream, int row_pos_dim);
+int pack_outputs_packed(const float* x_final, const float* row_attn, float* emb, float* atp, const PackedMsa* pk, int B, int max_C, int D,
+                        int num_layers, int H, double total_out_floats, int* err_flag, hipStream_t stream);
+// K4-K7, fp32: `host` = the same descriptors on the host (grid sizing, timer bytes); `layer` selects the maps inside an alignment's probs block
+int row_logits_packed(const float* q, const float* k, int64_t ld, float* partial, int H, const PackedMsa* pk, const PackedMsa* host,
+                      int B, void* stream);
+int softmax_rows_packed(const float* partial, float* row_attn, int layer, int H, const PackedMsa* pk, const PackedMsa* host, int B,
+                        void* stream);
+int row_apply_packed(const float* row_attn, int layer, const float* v, int64_t ld, float* ctx, int64_t ldc, int H, const PackedMsa* pk,
+                     const PackedMsa* host, int B, void* stream);
+int col_attn_packed(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int H, const PackedMsa* pk,
+                    const PackedMsa* host, int B, void* stream);
+
 }  // namespace rnamsm

@@ -150,16 +150,32 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        float* __restrict__ out, int R, int C, int D, int vocab,
                                                        int num_positions, int pad_idx, float eps, int* err_flag, int B,
-                                                       int row_pos_ld) {
+                                                       int row_pos_ld, const PackedMsa* __restrict__ pk, int64_t packed_T) {
     // tokens [B, R, C] -> out [B*R*C, D]: the row-position table restarts with every alignment (r = global row mod R)
     const int lane = threadIdx.x & 63;
     const int nvec = D / 4;
-    const int64_t T = (int64_t)B * R * C;
+    const int64_t T = pk ? packed_T : (int64_t)B * R * C;
     const int64_t stride = (int64_t)gridDim.x * 4;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += stride) {
-        const int64_t rg = row / C;
-        const int r = (int)(rg % R), c = (int)(row % C);
-        const int64_t* trow = tokens + rg * C;
+        int r, c;
+        const int64_t* trow;
+        if (pk) {
+            // token-packed batch: alignments of different shapes back to back; the token's alignment = the last descriptor
+            // whose first token is <= row (wave-uniform binary search over B entries)
+            int lo = 0, hi = B - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (pk[mid].tok0 <= row) lo = mid; else hi = mid - 1;
+            }
+            const PackedMsa& m = pk[lo];
+            const int64_t local = row - m.tok0;
+            r = (int)(local / m.C); c = (int)(local % m.C);
+            trow = tokens + m.tok0 + (int64_t)r * m.C;
+        } else {
+            const int64_t rg = row / C;
+            r = (int)(rg % R); c = (int)(row % C);
+            trow = tokens + rg * C;
+        }
         // pos = cumsum(tok != pad)[c] * (tok[c] != pad) + pad   (modules.py:288-290)
         int count = 0;
         for (int base = 0; base <= c; base += 64) {
@@ -190,6 +206,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
                 for (int i = 0; i < 4; ++i) v[e][i] = (a[i] + b[i]) + rv[i];     // same association as model.py:349-360
             }
         }
+        // a packed batch carries no masks: <pad> inside one is reported (bit 3 of the error word), the caller reruns it framed
+        if (pk && trow[c] == pad_idx && lane == 0 && err_flag) atomicOr(err_flag, 8);
         if (trow[c] == pad_idx) {      // x * (1 - padding_mask) after emb_layer_norm_before (model.py:366-367)
 #pragma unroll
             for (int e = 0; e < LN_MAX_VEC; ++e)
@@ -239,12 +257,24 @@ __global__ __launch_bounds__(256) void pack_outputs_kernel(const float* __restri
                                                            const float* __restrict__ probs_all,
                                                            float* __restrict__ emb, float* __restrict__ atp, int C,
                                                            int D, int64_t n_emb, int64_t n_atp, int64_t x_bstride,
-                                                           int64_t probs_bstride, int* err_flag) {
+                                                           int64_t probs_bstride, int* err_flag, const PackedMsa* __restrict__ pk,
+                                                           int channels) {
+    if (pk) {       // token-packed batch: alignment blockIdx.y's own width and offsets; channels = num_layers * H
+        const PackedMsa& m = pk[blockIdx.y];
+        C = m.C;
+        n_emb = (int64_t)(C - 1) * D;
+        n_atp = (int64_t)channels * (C - 1) * (C - 1);
+        x_final += m.tok0 * D;
+        probs_all += m.probs_off;
+        emb += m.emb_off;
+        atp += m.atp_off;
+    } else {
+        x_final += blockIdx.y * x_bstride;
+        probs_all += blockIdx.y * probs_bstride;
+        emb += blockIdx.y * n_emb;
+        atp += blockIdx.y * n_atp;
+    }
     const int L = C - 1;
-    x_final += blockIdx.y * x_bstride;
-    probs_all += blockIdx.y * probs_bstride;
-    emb += blockIdx.y * n_emb;
-    atp += blockIdx.y * n_atp;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     bool bad = false;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_emb + n_atp; idx += stride) {
@@ -361,8 +391,44 @@ int embed_ln_batched(const int64_t* tokens, const float* embed_tokens, const flo
     // not HBM reads (counting them had given this launch a "fraction of roofline" above 1)
     KernelTimer timer(TC_EMBED, 0.0, 4.0 * T * D + 8.0 * T, stream);
     hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid(T)), dim3(256), 0, stream, tokens, embed_tokens, embed_positions, row_pos,
-                       gamma, beta, out, R, C, D, vocab, num_positions, pad_idx, eps, err_flag, B, row_pos_dim > 1 ? row_pos_dim : 0);
+                       gamma, beta, out, R, C, D, vocab, num_positions, pad_idx, eps, err_flag, B, row_pos_dim > 1 ? row_pos_dim : 0,
+                       (const PackedMsa*)nullptr, (int64_t)0);
     RNAMSM_CHECK_LAUNCH("embed_ln");
+    return RNAMSM_OK;
+}
+int embed_ln_packed(const int64_t* tokens, const float* embed_tokens, const float* embed_positions, const float* row_pos,
+                    const float* gamma, const float* beta, float* out, const PackedMsa* pk, int B, int64_t T, int D, int vocab,
+                    int num_positions, int pad_idx, float eps, int* err_flag, hipStream_t stream, int row_pos_dim) {
+    KernelTimer timer(TC_EMBED, 0.0, 4.0 * T * D + 8.0 * T, stream);
+    hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid(T)), dim3(256), 0, stream, tokens, embed_tokens, embed_positions, row_pos,
+                       gamma, beta, out, 0, 0, D, vocab, num_positions, pad_idx, eps, err_flag, B, row_pos_dim > 1 ? row_pos_dim : 0, pk, T);
+    RNAMSM_CHECK_LAUNCH("embed_ln (packed)");
+    return RNAMSM_OK;
+}
+// PackedMsa descriptors host -> device WITHOUT a host buffer that has to outlive the call: they travel as kernel arguments,
+// 32 (2 KB) per launch
+struct PackedChunk { PackedMsa m[32]; };
+__global__ void packed_descriptors_kernel(PackedChunk chunk, int n, PackedMsa* __restrict__ dev) {
+    if ((int)threadIdx.x < n) dev[threadIdx.x] = chunk.m[threadIdx.x];
+}
+int packed_descriptors_upload(const PackedMsa* host, int B, PackedMsa* dev, hipStream_t stream) {
+    for (int b0 = 0; b0 < B; b0 += 32) {
+        PackedChunk chunk;
+        const int n = B - b0 < 32 ? B - b0 : 32;
+        for (int i = 0; i < 32; ++i) chunk.m[i] = host[b0 + (i < n ? i : 0)];
+        hipLaunchKernelGGL(packed_descriptors_kernel, dim3(1), dim3(32), 0, stream, chunk, n, dev + b0);
+        RNAMSM_CHECK_LAUNCH("packed_descriptors");
+    }
+    return RNAMSM_OK;
+}
+int pack_outputs_packed(const float* x_final, const float* row_attn, float* emb, float* atp, const PackedMsa* pk, int B, int max_C, int D,
+                        int num_layers, int H, double total_out_floats, int* err_flag, hipStream_t stream) {
+    const int64_t L = max_C - 1;
+    const int64_t blocks = (L * D + (int64_t)num_layers * H * L * L + 255) / 256;
+    KernelTimer timer(TC_PACK, 0.0, 8.0 * total_out_floats, stream);
+    hipLaunchKernelGGL(pack_outputs_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048), (unsigned)B), dim3(256), 0, stream, x_final,
+                       row_attn, emb, atp, 0, D, (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0, err_flag, pk, num_layers * H);
+    RNAMSM_CHECK_LAUNCH("pack_outputs (packed)");
     return RNAMSM_OK;
 }
 int pack_outputs_batched(const float* x_final, const float* probs_all, float* emb, float* atp, int C, int D, int num_layers, int H,
@@ -373,7 +439,7 @@ int pack_outputs_batched(const float* x_final, const float* probs_all, float* em
     const int64_t cap = B > 1 ? 2048 : 8192;
     KernelTimer timer(TC_PACK, 0.0, 8.0 * B * (n_emb + n_atp), stream);
     hipLaunchKernelGGL(pack_outputs_kernel, dim3((unsigned)(blocks < cap ? blocks : cap), (unsigned)B), dim3(256), 0, stream, x_final,
-                       probs_all, emb, atp, C, D, n_emb, n_atp, x_bstride, probs_bstride, err_flag);
+                       probs_all, emb, atp, C, D, n_emb, n_atp, x_bstride, probs_bstride, err_flag, (const PackedMsa*)nullptr, 0);
     RNAMSM_CHECK_LAUNCH("pack_outputs");
     return RNAMSM_OK;
 }

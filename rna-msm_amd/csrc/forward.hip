@@ -587,3 +587,165 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
     FWD(rnamsm::pack_outputs_batched(repr, row_attn, emb, atp, C, D, NL, H, B, Tm * D, (int64_t)NL * H * C * C, err_flag, hs));
     return RNAMSM_OK;
 }
+
+// ---- B alignments of DIFFERENT shapes, token-packed (no padding, exact path) -----------------------------------------------
+// The reference's real workload is many short RNAs of unlike length and depth (RNA_MSM_Inference.py:141-148 feeds them one by
+// one); rnamsm_forward_batch needs one common [R, C] frame, and frames of unlike alignments hold 1.4-1.5x their true tokens.
+// Here the alignments lie back to back on the token axis: tokens [T] = MSA 0's [R0, C0] row-major, then MSA 1's, ...  The
+// token-parallel launches (K0's LayerNorm, the six GEMMs of a layer, the LayerNorms) run once over the T real tokens; K0, K4-K7
+// and K10 take the alignment from gridDim.y and its shape / offsets from a PackedMsa descriptor (common.h).  Every alignment
+// keeps the slab split of its own forward; q is scaled by dh^-1/2 in the QKV epilogue and the alignment's 1/sqrt(R) meets the
+// summed tied logits in K5 (one rounding apart from rnamsm_forward, which folds both into q).  No <pad> inside a packed batch
+// (no masks are built; K0 reports it: bit 3 of *err_flag); outputs are the concatenation of what rnamsm_forward returns per
+// alignment: row_attn [NL,H,C_b,C_b], repr [R_b*C_b, D], emb [C_b-1, D], atp [NL*H, C_b-1, C_b-1].
+#include <vector>
+#include "row_split.h"
+namespace {
+struct PackedLayout {
+    size_t x, xn, wide, part, rowsum, stats, splitk, desc, total;
+};
+// fills `host` (B descriptors) from shapes; returns false on a bad shape
+bool make_packed(const rnamsm_model_dims& d, int B, const int* shapes, std::vector<PackedMsa>& host, PackedLayout& l, int64_t& T_out) {
+    host.resize(B);
+    int64_t tok = 0, part = 0, probs = 0, emb = 0, atp = 0;
+    const int H = d.num_heads, NL = d.num_layers, D = d.embed_dim;
+    for (int b = 0; b < B; ++b) {
+        const int R = shapes[2 * b], C = shapes[2 * b + 1];
+        if (R < 1 || R > 1024 || C < 2 || C > d.num_positions - d.pad_idx - 1) return false;
+        const RowSplit sp = choose_row_split(R, C, H, 128, 512, ROW_LOGITS_F32_MAX_ROWS);
+        PackedMsa& m = host[b];
+        m.R = R; m.C = C; m.nsplit = sp.nsplit; m.rows_per_split = sp.rows_per_split;
+        m.tok0 = tok; m.part_off = part; m.probs_off = probs; m.emb_off = emb; m.atp_off = atp;
+        m.logit_scale = 1.0f / sqrtf((float)R);
+        m.pad_ = 0;
+        tok += (int64_t)R * C;
+        part += (int64_t)sp.nsplit * H * C * C;
+        probs += (int64_t)NL * H * C * C;
+        emb += (int64_t)(C - 1) * D;
+        atp += (int64_t)NL * H * (C - 1) * (C - 1);
+    }
+    T_out = tok;
+    const size_t T = (size_t)tok;
+    size_t off = 0;
+    l.x = off;      off += align256(T * D * 4);
+    l.xn = off;     off += align256(T * D * 4);
+    l.wide = off;   off += align256(T * (size_t)(4 * D > d.ffn_dim ? 4 * D : d.ffn_dim) * 4);
+    l.part = off;   off += align256((size_t)part * 4);
+    l.rowsum = off; off += align256(T * (D / 32) * 2 * sizeof(float));
+    l.stats = off;  off += align256(T * 2 * sizeof(float));
+    const size_t kt = (size_t)rnamsm::gemm_f32_splitk_factor((int64_t)T, D, d.ffn_dim, true);
+    l.splitk = off; off += align256((kt > 1 ? kt * T : 0) * D * sizeof(float));
+    l.desc = off;   off += align256((size_t)B * sizeof(PackedMsa));
+    l.total = off;
+    return true;
+}
+}  // namespace
+
+extern "C" size_t rnamsm_forward_packed_workspace_bytes(const rnamsm_model_dims* dims, int B, const int* shapes) {
+    if (!dims || B <= 0 || !shapes) return 0;
+    std::vector<PackedMsa> host;
+    PackedLayout lay;
+    int64_t T;
+    return make_packed(*dims, B, shapes, host, lay, T) ? lay.total : 0;
+}
+
+extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens, int B,
+                                     const int* shapes, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
+                                     float* emb, float* atp, int* err_flag, const float* const* ln_folded, int dtype, void* stream) {
+    RNAMSM_CHECK_ARG(dims && weights && tokens && shapes && workspace && row_attn && repr && emb && atp, "forward_packed: null pointer");
+    if (dtype != RNAMSM_F32)
+        return fail(RNAMSM_ERR_UNSUPPORTED, "forward_packed: the exact fp32 path only (16-bit batches: rnamsm_forward_batch)");
+    const rnamsm_model_dims& d = *dims;
+    const int D = d.embed_dim, H = d.num_heads, F = d.ffn_dim, NL = d.num_layers;
+    RNAMSM_CHECK_ARG(D > 0 && H > 0 && D == H * 64, "forward_packed: embed_dim must be num_heads * 64 (D=%d H=%d)", D, H);
+    RNAMSM_CHECK_ARG(D % 128 == 0 && F % 128 == 0 && NL > 0, "forward_packed: embed_dim and ffn_dim must be multiples of 128");
+    RNAMSM_CHECK_ARG(d.row_pos_dim == 0 || d.row_pos_dim == 1 || d.row_pos_dim == D, "forward_packed: row_pos_dim must be 0, 1 or embed_dim (got %d)", d.row_pos_dim);
+    RNAMSM_CHECK_ARG(B >= 1 && B <= 65535, "forward_packed: need 1 <= B <= 65535 alignments (got %d)", B);
+    std::vector<PackedMsa> host;
+    PackedLayout lay;
+    int64_t T = 0;
+    if (!make_packed(d, B, shapes, host, lay, T))
+        return fail(RNAMSM_ERR_INVALID, "forward_packed: every alignment needs 1 <= R <= 1024 and 2 <= C <= %d", d.num_positions - d.pad_idx - 1);
+    RNAMSM_CHECK_ARG(T <= INT32_MAX, "forward_packed: %lld tokens exceed the GEMM row range", (long long)T);
+    RNAMSM_CHECK_ARG(workspace_bytes >= lay.total, "forward_packed: workspace too small (%zu < %zu)", workspace_bytes, lay.total);
+    RNAMSM_CHECK_ARG(aligned16(workspace), "forward_packed: workspace must be 16-byte aligned");
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    char* ws = static_cast<char*>(workspace);
+    float* x = reinterpret_cast<float*>(ws + lay.x);
+    float* xn = reinterpret_cast<float*>(ws + lay.xn);
+    float* wide = reinterpret_cast<float*>(ws + lay.wide);
+    float* part = reinterpret_cast<float*>(ws + lay.part);
+    float* rowsum = reinterpret_cast<float*>(ws + lay.rowsum);
+    float* stats = reinterpret_cast<float*>(ws + lay.stats);
+    float* splitk = reinterpret_cast<float*>(ws + lay.splitk);
+    PackedMsa* desc = reinterpret_cast<PackedMsa*>(ws + lay.desc);
+    const int64_t ldq = 3 * (int64_t)D;
+    float* qkv = wide;                 // [T, 3D]
+    float* ctx = wide + T * ldq;       // [T, D]
+    float* hidden = wide;              // [T, F]
+    const float* const* G = weights;
+    const int f32 = RNAMSM_F32;
+    const int fold_mode = tuning().ln_fold;
+    const bool fold = ln_folded && (fold_mode == 3 || (fold_mode == 1 && T >= 18432));
+    const float qk_scale = 1.0f / sqrtf(64.0f);
+    const PackedMsa* hp = host.data();
+
+    auto norm = [&](const float* g, const float* b) -> int {
+        return fold ? RNAMSM_OK : rnamsm_layernorm(x, g, b, xn, T, D, d.ln_eps, stream);
+    };
+    auto lin_normed = [&](int layer, int fslot, const float* Wf, const float* bias, float* out, int64_t ldc, int N, int act,
+                          float scale, int scale_cols) -> int {
+        if (fold) {
+            const float* const* Fp = ln_folded + (size_t)layer * RNAMSM_FOLDED_PER_LAYER + 3 * fslot;
+            return rnamsm_gemm_lnfold(x, D, Fp[0], Fp[1], Fp[2], d.ln_eps, stats, err_flag, out, ldc, T, N, D, act, scale,
+                                      scale_cols, f32, stream);
+        }
+        return rnamsm_gemm_bias_act_res(xn, D, Wf, bias, nullptr, 0, out, ldc, T, N, D, act, scale, scale_cols, nullptr, f32, stream);
+    };
+    auto res_linear = [&](const float* A, int64_t lda, const float* Wf, const float* bias, int K) -> int {
+        if (fold) {
+            FWD(rnamsm_gemm_residual_stats(A, lda, Wf, bias, x, D, x, D, T, D, K, rowsum, T, f32, stream));
+            return rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream);
+        }
+        const int ks = rnamsm::gemm_f32_splitk_factor(T, D, K);
+        if (ks > 1) return rnamsm::gemm_f32_splitk(A, lda, Wf, bias, x, D, x, D, T, D, K, ks, splitk, hs);
+        return rnamsm_gemm_bias_act_res(A, lda, Wf, bias, x, D, x, D, T, D, K, RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream);
+    };
+
+    FWD(rnamsm::packed_descriptors_upload(hp, B, desc, hs));
+    FWD(rnamsm::embed_ln_packed(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS], G[RNAMSM_W_LN_BEFORE_G],
+                                G[RNAMSM_W_LN_BEFORE_B], x, desc, B, T, D, d.vocab, d.num_positions, d.pad_idx, d.ln_eps, err_flag, hs,
+                                d.row_pos_dim));
+    if (fold) {
+        FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
+        FWD(rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream));
+    }
+    for (int l = 0; l < NL; ++l) {
+        const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
+        // ---- tied row attention (q carries dh^-1/2; each alignment's 1/sqrt(R) is applied to its summed logits in K5)
+        FWD(norm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
+        FWD(lin_normed(l, 0, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, qk_scale, D));
+        FWD(rnamsm::row_logits_packed(qkv, qkv + D, ldq, part, H, desc, hp, B, stream));
+        FWD(rnamsm::softmax_rows_packed(part, row_attn, l, H, desc, hp, B, stream));
+        FWD(rnamsm::row_apply_packed(row_attn, l, qkv + 2 * D, ldq, ctx, D, H, desc, hp, B, stream));
+        FWD(res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], D));
+        // ---- column attention
+        FWD(norm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
+        FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, qk_scale, D));
+        FWD(rnamsm::col_attn_packed(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, H, desc, hp, B, stream));
+        FWD(res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], D));
+        // ---- feed-forward
+        FWD(norm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
+        FWD(lin_normed(l, 2, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], hidden, F, F, RNAMSM_ACT_GELU_ERF, 1.f, 0));
+        FWD(res_linear(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], F));
+    }
+    FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
+    int max_C = 0;
+    double out_floats = 0.0;
+    for (int b = 0; b < B; ++b) {
+        max_C = host[b].C > max_C ? host[b].C : max_C;
+        out_floats += (double)(host[b].C - 1) * D + (double)NL * H * (host[b].C - 1) * (host[b].C - 1);
+    }
+    FWD(rnamsm::pack_outputs_packed(repr, row_attn, emb, atp, desc, B, max_C, D, NL, H, out_floats, err_flag, hs));
+    return RNAMSM_OK;
+}

@@ -34,14 +34,24 @@ constexpr int ROWAPPLY_VT_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;
 // slab reads in K5, and four times the K loop per block prologue / epilogue.
 __global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int64_t ld, float* __restrict__ partial,
-    int R, int C, int H, int nsplit, int rows_per_split, int chain_tiles, int64_t qk_bstride, int64_t part_bstride) {
+    int R, int C, int H, int nsplit, int rows_per_split, int chain_tiles, int64_t qk_bstride, int64_t part_bstride,
+    const PackedMsa* __restrict__ pk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;
     float* Ks = smem + 2 * TILE_KC;
-    // batched launch (gridDim.y MSAs of the same shape, rnamsm_forward_batch): MSA blockIdx.y's operands and slabs
-    q += blockIdx.y * qk_bstride;
-    k += blockIdx.y * qk_bstride;
-    partial += blockIdx.y * part_bstride;
+    if (pk) {
+        // token-packed batch (rnamsm_forward_packed): alignment blockIdx.y has its own shape, slabs and token offset
+        const PackedMsa& m = pk[blockIdx.y];
+        R = m.R; C = m.C; nsplit = m.nsplit; rows_per_split = m.rows_per_split;
+        q += m.tok0 * ld;
+        k += m.tok0 * ld;
+        partial += m.part_off;
+    } else {
+        // batched launch (gridDim.y MSAs of the same shape, rnamsm_forward_batch): MSA blockIdx.y's operands and slabs
+        q += blockIdx.y * qk_bstride;
+        k += blockIdx.y * qk_bstride;
+        partial += blockIdx.y * part_bstride;
+    }
 
     const unsigned tiles_c = (C + BM - 1) / BM;
     unsigned panel, tile;
@@ -128,11 +138,20 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
                                                            uint16_t* __restrict__ p_hi, uint16_t* __restrict__ p_lo,
                                                            int64_t ldp, float plane_scale, int64_t mask_slab_stride,
                                                            int64_t part_bstride, int64_t probs_bstride, int64_t mask_bstride,
-                                                           int64_t plane_bstride) {
+                                                           int64_t plane_bstride, const PackedMsa* __restrict__ pk, int layer, int H) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float packed_scale = 1.f;
+    if (pk) {       // token-packed batch: alignment blockIdx.y's own width, slabs, maps and depth factor (fp32 maps only)
+        const PackedMsa& m = pk[blockIdx.y];
+        C = m.C; rows = (int64_t)H * C; nsplit = m.nsplit;
+        partial += m.part_off;
+        probs += m.probs_off + (int64_t)layer * H * C * C;
+        packed_scale = m.logit_scale;
+    } else {
+        partial += blockIdx.y * part_bstride;        // batched launch: MSA blockIdx.y
+        probs += blockIdx.y * probs_bstride;
+    }
     if (row >= rows) return;
-    partial += blockIdx.y * part_bstride;        // batched launch: MSA blockIdx.y
-    probs += blockIdx.y * probs_bstride;
     if (PL != 0) {
         p_hi += blockIdx.y * plane_bstride;
         if (p_lo) p_lo += blockIdx.y * plane_bstride;
@@ -161,6 +180,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
                 const int j = lane + 64 * e;
                 if (j < C) v[e] += ps[j];
             }
+        }
+        // packed batch: q carries dh^-1/2 only, the alignment's 1/sqrt(R) meets the summed logits here
+        if (pk) {
+#pragma unroll
+            for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) v[e] *= packed_scale;
         }
         // f2: masked_fill(padding_mask[:, 0], -10000) on the key axis (modules.py:781-785)
         if (key_mask) {
@@ -231,12 +255,20 @@ template <bool ALIGNED, int OUT, bool VT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
     const float* __restrict__ probs, const float* __restrict__ v, int64_t ld, float* __restrict__ ctx, int64_t ldc,
     int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int64_t probs_bstride, int64_t v_bstride,
-    int64_t ctx_bstride) {
+    int64_t ctx_bstride, const PackedMsa* __restrict__ pk, int layer) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ps = smem;                    // [2][BM][LDK]
-    probs += blockIdx.y * probs_bstride;         // batched launch: MSA blockIdx.y (fp32 context only)
-    v += blockIdx.y * v_bstride;
-    if (OUT == 0) ctx += blockIdx.y * ctx_bstride;
+    if (pk) {                            // token-packed batch (fp32 context only): alignment blockIdx.y's own shape and offsets
+        const PackedMsa& m = pk[blockIdx.y];
+        R = m.R; C = m.C;
+        probs += m.probs_off + (int64_t)layer * H * C * C;
+        v += m.tok0 * ld;
+        if (OUT == 0) ctx += m.tok0 * ldc;
+    } else {
+        probs += blockIdx.y * probs_bstride;         // batched launch: MSA blockIdx.y (fp32 context only)
+        v += blockIdx.y * v_bstride;
+        if (OUT == 0) ctx += blockIdx.y * ctx_bstride;
+    }
     float* Vs = smem + 2 * TILE_KC;      // [2][BK][LDN], or [2][BN][LDK] when VT
     constexpr int TILE_V = VT ? TILE_KC : TILE_NC;
 
@@ -399,7 +431,7 @@ static int row_logits_launch(const float* q, const float* k, int64_t ld, float* 
                       4.0 * batch * (2.0 * R * C * H * HEAD_DIM + (double)sp.nsplit * H * C * C), static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(row_logits_kernel, dim3(grid, batch), dim3(GEMM_THREADS), ROWLOGITS_LDS_BYTES,
                        static_cast<hipStream_t>(stream), q, k, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split,
-                       ROW_LOGITS_F32_CHAIN_ROWS * (HEAD_DIM / BK), qk_bstride, part_bstride);
+                       ROW_LOGITS_F32_CHAIN_ROWS * (HEAD_DIM / BK), qk_bstride, part_bstride, (const PackedMsa*)nullptr);
     RNAMSM_CHECK_LAUNCH("row_logits");
     return RNAMSM_OK;
 }
@@ -418,11 +450,11 @@ static int softmax_rows_launch(const float* partial, int nsplit, float* probs, i
     const dim3 grid((unsigned)((rows + 3) / 4), batch);
     KernelTimer timer(TC_SOFTMAX, 0.0, batch * (4.0 * (double)(nsplit + 1) * H * C * C + (p_hi ? (p_lo ? 4.0 : 2.0) * rows * ldp : 0.0)), s);
     if (!p_hi)
-        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride);
+        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H);
     else if (fmt == 0)
-        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride);
+        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H);
     else
-        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride);
+        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H);
     RNAMSM_CHECK_LAUNCH("softmax_rows");
     return RNAMSM_OK;
 }
@@ -475,7 +507,7 @@ static int row_apply_launch(const float* probs, const float* v, int64_t ld, floa
             cfg_.mark();                                                                                          \
         }                                                                                                         \
         hipLaunchKernelGGL((row_apply_kernel<AL_, OUT_, VT_>), dim3(grid, batch), dim3(GEMM_THREADS), lds_, s, probs, \
-                           v, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, probs_bstride, v_bstride, ctx_bstride);          \
+                           v, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, probs_bstride, v_bstride, ctx_bstride, (const PackedMsa*)nullptr, 0); \
     } while (0)
 #define RA_GO(AL_, OUT_)                                                                                          \
     do {                                                                                                          \
@@ -520,5 +552,80 @@ int row_apply_batched(const float* probs, const float* v, int64_t ld, float* ctx
                       int64_t probs_bstride, int64_t v_bstride, int64_t ctx_bstride, void* stream) {
     return row_apply_launch(probs, v, ld, ctx, ldc, R, C, H, HEAD_DIM, nullptr, nullptr, 0, RNAMSM_F32, stream, batch, probs_bstride,
                             v_bstride, ctx_bstride);
+}
+
+// ---- K4-K6 of a token-packed batch (rnamsm_forward_packed): one launch each, gridDim.y = alignment, gridDim.x sized for the
+// alignment that needs most blocks; every alignment keeps the slab split of its own forward (PackedMsa::nsplit)
+int row_logits_packed(const float* q, const float* k, int64_t ld, float* partial, int H, const PackedMsa* pk, const PackedMsa* host,
+                      int B, void* stream) {
+    static DeviceOnce configured;
+    if (configured.pending()) {
+        int rc = set_lds(row_logits_kernel, ROWLOGITS_LDS_BYTES, "row_logits");
+        if (rc) return rc;
+        configured.mark();
+    }
+    unsigned grid = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const PackedMsa& m = host[b];
+        const unsigned tiles_c = (m.C + BM - 1) / BM;
+        const unsigned g = xcd_panel_grid((unsigned)(H * m.nsplit), tiles_c * tiles_c);
+        grid = g > grid ? g : grid;
+        flops += 2.0 * H * m.C * m.C * (double)m.R * HEAD_DIM;
+        bytes += 4.0 * (2.0 * m.R * m.C * H * HEAD_DIM + (double)m.nsplit * H * m.C * m.C);
+    }
+    KernelTimer timer(TC_ROW_LOGITS, flops, bytes, static_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(row_logits_kernel, dim3(grid, B), dim3(GEMM_THREADS), ROWLOGITS_LDS_BYTES, static_cast<hipStream_t>(stream), q, k,
+                       ld, partial, 0, 0, H, 0, 0, ROW_LOGITS_F32_CHAIN_ROWS * (HEAD_DIM / BK), (int64_t)0, (int64_t)0, pk);
+    RNAMSM_CHECK_LAUNCH("row_logits (packed)");
+    return RNAMSM_OK;
+}
+int softmax_rows_packed(const float* partial, float* row_attn, int layer, int H, const PackedMsa* pk, const PackedMsa* host, int B,
+                        void* stream) {
+    int max_C = 0;
+    double bytes = 0.0;
+    for (int b = 0; b < B; ++b) {
+        max_C = host[b].C > max_C ? host[b].C : max_C;
+        bytes += 4.0 * (double)(host[b].nsplit + 1) * H * host[b].C * host[b].C;
+    }
+    RNAMSM_CHECK_ARG(max_C <= 64 * SOFTMAX_MAX_PER_LANE, "softmax_rows (packed): C <= %d", 64 * SOFTMAX_MAX_PER_LANE);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    KernelTimer timer(TC_SOFTMAX, 0.0, bytes, s);
+    hipLaunchKernelGGL(softmax_rows_kernel<0>, dim3((unsigned)(((int64_t)H * max_C + 3) / 4), B), dim3(256), 0, s, partial, 0, row_attn,
+                       (int64_t)0, 0, (const uint8_t*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr, (int64_t)0, 1.f, (int64_t)0,
+                       (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0, pk, layer, H);
+    RNAMSM_CHECK_LAUNCH("softmax_rows (packed)");
+    return RNAMSM_OK;
+}
+int row_apply_packed(const float* row_attn, int layer, const float* v, int64_t ld, float* ctx, int64_t ldc, int H, const PackedMsa* pk,
+                     const PackedMsa* host, int B, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    unsigned grid = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const PackedMsa& m = host[b];
+        const unsigned g = xcd_panel_grid((unsigned)H * ((m.R + 1) / 2), (m.C + BM - 1) / BM);
+        grid = g > grid ? g : grid;
+        flops += 2.0 * H * m.C * m.C * (double)m.R * HEAD_DIM;
+        bytes += 4.0 * (2.0 * m.R * m.C * H * HEAD_DIM + (double)H * m.C * m.C);
+    }
+    KernelTimer timer(TC_ROW_APPLY, flops, bytes, s);
+    // (maps of odd widths are not 16-byte aligned: the scalar-load instance for every alignment of the batch)
+#define RA_PK(VT_)                                                                                                \
+    do {                                                                                                          \
+        static DeviceOnce cfg_;                                                                                   \
+        constexpr int lds_ = VT_ ? ROWAPPLY_VT_LDS_BYTES : ROWAPPLY_LDS_BYTES;                                     \
+        if (cfg_.pending()) {                                                                                     \
+            int rc = set_lds(row_apply_kernel<false, 0, VT_>, lds_, "row_apply");                                 \
+            if (rc) return rc;                                                                                    \
+            cfg_.mark();                                                                                          \
+        }                                                                                                         \
+        hipLaunchKernelGGL((row_apply_kernel<false, 0, VT_>), dim3(grid, B), dim3(GEMM_THREADS), lds_, s, row_attn, v, ld, ctx, ldc, 0, 0, \
+                           H, (uint16_t*)nullptr, (uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, pk, layer);  \
+    } while (0)
+    if (tuning().row_vt) RA_PK(true); else RA_PK(false);
+#undef RA_PK
+    RNAMSM_CHECK_LAUNCH("row_apply (packed)");
+    return RNAMSM_OK;
 }
 }  // namespace rnamsm

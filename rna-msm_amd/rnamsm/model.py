@@ -384,12 +384,84 @@ class MSATransformer(nn.Module):
             out = self.forward_batch(tokens3d, has_padding, fold_layernorm=False, true_rows=true_rows, gemm_dtype=mode)
         return out
 
-    def forward_ragged(self, msas: List[torch.Tensor]) -> List[Dict[str, torch.Tensor]]:
-        """Alignments of DIFFERENT shapes ([R_b, C_b] int64 tokens, column 0 = <cls>) in one launch set: padded into
-        one [max R, max C] frame and run as a ragged batch (rnamsm_forward_batch with true_rows).  Returns per MSA what
-        forward_one(need_repr=False) returns -- emb [C_b-1, D], atp [NL*H, C_b-1, C_b-1], row_attn [NL, H, C_b, C_b] -- equal to
-        the MSA's own forward to fp32 rounding.  Pays for alignments of a few thousand tokens and similar shapes (padding is
-        computed too)."""
+    def forward_packed(self, msas: List[torch.Tensor], fold_layernorm: Optional[bool] = None,
+                       need_repr: bool = False) -> List[Dict[str, torch.Tensor]]:
+        """Alignments of DIFFERENT shapes ([R_b, C_b] int64 tokens, column 0 = <cls>, no <pad>) as ONE token-packed batch
+        (rnamsm_forward_packed, exact fp32 path): the alignments lie back to back on the token axis, nothing is padded.
+        Returns per MSA what forward_one(need_repr=False) returns -- emb [C_b-1, D], atp [NL*H, C_b-1, C_b-1], row_attn
+        [NL, H, C_b, C_b] (views of the packed outputs; with need_repr also repr [R_b, C_b, D]) and the batch's "err" word --
+        equal to the MSA's own forward to fp32 rounding.  Never inspects "err" (bit 3 = ERR_PAD_IN_PACKED: a <pad> inside the
+        batch, whose masks this path does not build -- forward_ragged reruns such a batch framed)."""
+        if self.training:
+            raise NotImplementedError("inference only (model.eval())")
+        if not msas or not all(t.is_cuda and t.ndim == 2 for t in msas):
+            raise _lib.RnamsmError("forward_packed: a non-empty list of [R, C] token tensors on the HIP device")
+        dev = msas[0].device
+        fold = self.fold_layernorm if fold_layernorm is None else fold_layernorm
+        with torch.cuda.device(dev):
+            lib = _lib.load()
+            dims, ptrs, _ = self._packed_weights()
+            NL, H, D = self.num_layers, self.num_attention_heads, self.embed_dim
+            B = len(msas)
+            shapes = (ctypes.c_int * (2 * B))(*[int(v) for t in msas for v in t.shape])
+            toks = torch.cat([t.to(torch.int64).reshape(-1) for t in msas])
+            T = toks.numel()
+            ws_bytes = lib.rnamsm_forward_packed_workspace_bytes(ctypes.byref(dims), B, shapes)
+            if ws_bytes == 0:
+                bad = [tuple(t.shape) for t in msas if not (1 <= t.shape[0] <= 1024 and t.shape[1] >= 2)]
+                if any(s_[0] > 1024 for s_ in bad):
+                    raise RuntimeError("Using model with MSA position embedding trained on maximum MSA "
+                                       f"depth of 1024, but received {max(s_[0] for s_ in bad)} alignments.")      # model.py:355-359
+                raise _lib.RnamsmError(f"forward_packed: shapes outside the limits: {bad or [tuple(t.shape) for t in msas]}")
+            ws = self._get_workspace(ws_bytes, dev)
+            cs = [int(t.shape[1]) for t in msas]
+            n_map = [NL * H * c * c for c in cs]
+            n_emb = [(c - 1) * D for c in cs]
+            n_atp = [NL * H * (c - 1) * (c - 1) for c in cs]
+            row_attn = torch.empty(sum(n_map), device=dev, dtype=torch.float32)
+            rep = torch.empty(T, D, device=dev, dtype=torch.float32)
+            emb = torch.empty(sum(n_emb), device=dev, dtype=torch.float32)
+            atp = torch.empty(sum(n_atp), device=dev, dtype=torch.float32)
+            err = torch.zeros(1, device=dev, dtype=torch.int32)
+            folded = self._folded_weights() if fold else None
+            _lib.check(lib.rnamsm_forward_packed(ctypes.byref(dims), ptrs, toks.data_ptr(), B, shapes, ws.data_ptr(), ws.numel(),
+                                                 row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(), err.data_ptr(),
+                                                 folded, _lib.F32, torch.cuda.current_stream().cuda_stream))
+        res, om, oe, oa, ot = [], 0, 0, 0, 0
+        for b, t in enumerate(msas):
+            r, c = int(t.shape[0]), cs[b]
+            item = {"emb": emb[oe:oe + n_emb[b]].view(c - 1, D), "atp": atp[oa:oa + n_atp[b]].view(NL * H, c - 1, c - 1),
+                    "row_attn": row_attn[om:om + n_map[b]].view(NL, H, c, c), "err": err}
+            if need_repr:
+                item["repr"] = rep[ot:ot + r * c].view(r, c, D)
+            res.append(item)
+            om, oe, oa, ot = om + n_map[b], oe + n_emb[b], oa + n_atp[b], ot + r * c
+        return res
+
+    ERR_PAD_IN_PACKED = 8
+
+    def forward_ragged(self, msas: List[torch.Tensor], packed: Optional[bool] = None) -> List[Dict[str, torch.Tensor]]:
+        """Alignments of DIFFERENT shapes ([R_b, C_b] int64 tokens, column 0 = <cls>) in one launch set.  Exact mode (and
+        packed is not False): the token-packed batch of forward_packed -- no padding; its error word is read (one sync): index
+        errors raise, a failed folded-LayerNorm precondition reruns without the fold, a <pad> inside the batch reruns it framed.
+        Otherwise (16-bit modes, packed=False, <pad> present): padded into one [max R, max C] frame and run as a ragged batch
+        (rnamsm_forward_batch with true_rows; padding is computed too).  Returns per MSA what forward_one(need_repr=False)
+        returns -- emb [C_b-1, D], atp [NL*H, C_b-1, C_b-1], row_attn [NL, H, C_b, C_b] -- equal to the MSA's own forward to
+        fp32 rounding."""
+        if packed is None:
+            packed = self.gemm_dtype == "f32"
+        if packed and self.gemm_dtype == "f32":
+            import warnings
+            res = self.forward_packed(msas)
+            err = int(res[0]["err"].item())
+            if err & self.ERR_INDEX:
+                raise IndexError("batch: token or position index out of range")
+            if (err & self.ERR_FOLD) and not (err & self.ERR_PAD_IN_PACKED):
+                warnings.warn("batch: a token row's mean exceeds 32x its spread; LayerNorm is applied in its own launches for this batch")
+                res = self.forward_packed(msas, fold_layernorm=False)
+                err = int(res[0]["err"].item())
+            if not (err & self.ERR_PAD_IN_PACKED):
+                return res
         B = len(msas)
         R = max(int(t.shape[0]) for t in msas)
         C = max(int(t.shape[1]) for t in msas)

@@ -727,14 +727,16 @@ def test_padded_ragged_batch_through_the_batched_driver(model):
     assert not torch.equal(chunked["row_attentions"], out["row_attn"])
 
 
-def test_ragged_batch_equals_every_alignment_alone(model):
-    """forward_ragged: alignments of different shapes share one launch set (padded into one frame, rnamsm_forward_batch with
-    true_rows): every MSA must come out as from its own unpadded forward -- the padded depth must not leak into the tied-row
-    scaling as it does in the reference's batch semantics -- to fp32 rounding, and meet the bar against the oracle."""
+@pytest.mark.parametrize("packed", [False, True])
+def test_ragged_batch_equals_every_alignment_alone(model, packed):
+    """forward_ragged: alignments of different shapes share one launch set -- padded into one frame (rnamsm_forward_batch with
+    true_rows) or, packed, back to back on the token axis (rnamsm_forward_packed): every MSA must come out as from its own
+    unpadded forward -- the padded depth must not leak into the tied-row scaling as it does in the reference's batch
+    semantics -- to fp32 rounding, and meet the bar against the oracle."""
     m, state = model
     shapes = [(8, 17), (3, 9), (12, 17), (1, 30), (7, 25), (12, 30)]
     msas = [torch.from_numpy(synthetic.make_tokens(r, c, 70 + i)).to("cuda:0") for i, (r, c) in enumerate(shapes)]
-    outs = m.forward_ragged(msas)
+    outs = m.forward_ragged(msas, packed=packed)
     params = O.to_torch_params(state)
     for t, got in zip(msas, outs):
         one = m.checked_forward_one(t, need_repr=False)
@@ -754,9 +756,72 @@ def test_ragged_batch_equals_every_alignment_alone(model):
     assert np.abs(ref_sem["atp"][0].cpu().numpy() - alone["atp"].cpu().numpy()).max() > 1e-3
     # same shapes, no padding at all: forward_ragged is the plain batched forward
     same = [torch.from_numpy(synthetic.make_tokens(5, 11, 90 + i)).to("cuda:0") for i in range(3)]
-    for t, got in zip(same, m.forward_ragged(same)):
+    for t, got in zip(same, m.forward_ragged(same, packed=packed)):
         one = m.checked_forward_one(t, need_repr=False)
         assert rel_l2(got["emb"].cpu().numpy(), one["emb"].cpu().numpy()) < 1e-5
+
+
+def test_token_packed_batch_equals_every_alignment_alone(model):
+    """rnamsm_forward_packed (round 4): alignments of unlike shapes back to back on the token axis, nothing padded.  Shapes
+    chosen to reach every per-alignment branch of the packed kernels in ONE batch: depth 1; R <= 16 (the one-wave column kernel's
+    launch) next to R > 16 (the LDS-DMA one, a ragged last 32-key chunk and more than one 128-query block); widths below / above
+    one 128-wide tile and not multiples of 4 (the scalar-load row_apply instance, maps that are not 16-byte aligned); an alignment
+    whose tied logits split into several slabs.  Bars: an alignment's packed outputs against its own forward differ by fp32
+    summation ORDER only (fc2's split-K is decided by the token count of the launch; 1/sqrt(R) meets the summed logits instead
+    of q) -- measured 1.4e-6..4.5e-6 rel on emb / repr, up to 5e-5 abs on the maps of the deep (140, 35) alignment, the same as
+    the framed ragged batch shows -- so "equal to alone" is held as: 1e-5 rel / 1e-4 abs against alone, AND against the fp64
+    truth the packed error is no larger than 1.5x the lone forward's own error (+1e-6).  Reruns bit-identical; the oracle's
+    bar; the error word: a <pad> inside the batch is reported (bit 3) and forward_ragged reruns that batch framed."""
+    m, state = model
+    shapes = [(1, 21), (5, 133), (16, 40), (17, 33), (40, 150), (3, 9), (140, 35), (33, 64), (2, 257)]
+    msas = [torch.from_numpy(synthetic.make_tokens(r, c, 500 + i)).to("cuda:0") for i, (r, c) in enumerate(shapes)]
+    import truth                                                              # the oracle in fp64 on the device (same weights: seed 0)
+    outs = m.forward_packed(msas, need_repr=True)
+    assert int(outs[0]["err"].item()) == 0
+    again = m.forward_packed(msas, need_repr=True)
+    params = O.to_torch_params(state)
+    for i, (t, got, got2) in enumerate(zip(msas, outs, again)):
+        for key in ("emb", "atp", "row_attn", "repr"):
+            assert torch.equal(got[key], got2[key]), (shapes[i], key)
+        one = m.checked_forward_one(t, need_repr=True)
+        assert got["emb"].shape == one["emb"].shape and got["atp"].shape == one["atp"].shape and got["repr"].shape == one["repr"].shape
+        assert rel_l2(got["emb"].cpu().numpy(), one["emb"].cpu().numpy()) < 1e-5, shapes[i]
+        assert rel_l2(got["repr"].cpu().numpy(), one["repr"].cpu().numpy()) < 1e-5, shapes[i]
+        assert np.abs(got["atp"].cpu().numpy() - one["atp"].cpu().numpy()).max() < 1e-4, shapes[i]
+        assert np.abs(got["row_attn"].cpu().numpy() - one["row_attn"].cpu().numpy()).max() < 1e-4, shapes[i]
+        t_emb, t_atp = truth.oracle_outputs(t.cpu().numpy(), torch.float64, "cuda:0")
+        e_pk, e_one = rel_l2(got["emb"].double().cpu(), t_emb.cpu()), rel_l2(one["emb"].double().cpu(), t_emb.cpu())
+        a_pk, a_one = float((got["atp"].double() - t_atp).abs().max()), float((one["atp"].double() - t_atp).abs().max())
+        assert e_pk < 1.5 * e_one + 1e-6 and e_pk < 1e-4, (shapes[i], e_pk, e_one)
+        assert a_pk < 1.5 * a_one + 1e-6 and a_pk < 1e-4, (shapes[i], a_pk, a_one)
+        if t.numel() <= 2500:
+            emb, atp = O.pack_outputs(O.forward(t.cpu(), params))
+            assert rel_l2(got["emb"].cpu().numpy(), np.asarray(emb)) < 1e-4
+            assert np.abs(got["atp"].cpu().numpy() - np.asarray(atp)).max() < 1e-4
+    # without the folded LayerNorm (separate launches): same bar
+    for t, got in zip(msas, m.forward_packed(msas, fold_layernorm=False)):
+        one = m.checked_forward_one(t, need_repr=False)
+        assert rel_l2(got["emb"].cpu().numpy(), one["emb"].cpu().numpy()) < 1e-5
+    # a single alignment is a valid packed batch
+    solo = m.forward_packed(msas[4:5])[0]
+    assert rel_l2(solo["emb"].cpu().numpy(), m.checked_forward_one(msas[4], need_repr=False)["emb"].cpu().numpy()) < 1e-5
+    # <pad> inside a packed batch: reported, and forward_ragged falls back to the framed ragged batch (masks)
+    padded = [t.clone() for t in msas[:4]]
+    padded[1][3:, 100:] = m.vocab.pad_idx
+    bad = m.forward_packed(padded)
+    assert int(bad[0]["err"].item()) & m.ERR_PAD_IN_PACKED
+    framed = m.forward_ragged(padded)
+    want = m.checked_forward_one(padded[1], need_repr=False)
+    assert rel_l2(framed[1]["emb"].cpu().numpy(), want["emb"].cpu().numpy()) < 1e-5
+    # limits are the reference's: depth above 1024 raises its message (model.py:355-359)
+    with pytest.raises(RuntimeError, match="maximum MSA depth of 1024"):
+        m.forward_packed([torch.zeros(1025, 4, dtype=torch.int64, device="cuda:0") + 5])
+    # an out-of-range token is reported like everywhere else (bit 0)
+    broken = [t.clone() for t in msas[:3]]
+    broken[2][1, 2] = 999
+    assert int(m.forward_packed(broken)[0]["err"].item()) & m.ERR_INDEX
+    with pytest.raises(IndexError):
+        m.forward_ragged(broken)
 
 
 def test_reference_side_callers_run_unchanged(model):
