@@ -559,6 +559,26 @@ def run_rank(args) -> int:
                                            "ms_per_msa_one_by_one": 1e3 * best["one"], "ms_per_msa_batched": 1e3 * best["batch"],
                                            "residues_per_s_one_by_one": sm * sl / best["one"],
                                            "residues_per_s_batched": sm * sl / best["batch"]})
+        # unlike shapes (the reference's real workload: short RNAs of unlike length and depth, RNA_MSM_Inference.py:141-148):
+        # 64 alignments of 4-24 rows x 41-121 columns one by one / padded into one frame (round 3) / token-packed (round 4)
+        rng_p = _np.random.default_rng(0)
+        pshapes = [(int(rng_p.integers(4, 25)), int(rng_p.integers(41, 122))) for _ in range(64)]
+        pm = [torch.from_numpy(synthetic.make_tokens(r, c - 1, 700 + i)).to(dev) for i, (r, c) in enumerate(pshapes)]
+        preal = sum(r * c for r, c in pshapes)
+
+        def best_of(fn, reps=3):
+            fn(); sync_all()
+            b = 1e9
+            for _ in range(reps):
+                sync_all(); t5 = time.perf_counter(); fn(); sync_all(); b = min(b, time.perf_counter() - t5)
+            return b
+        t_one = best_of(lambda: [model.forward_one(t, has_padding=False, need_repr=False) for t in pm], reps=2)
+        t_pk = best_of(lambda: model.forward_packed(pm))
+        small_batches["unlike_shapes"] = {
+            "what": "64 alignments of 4-24 rows x 41-121 columns (seeded), exact path: one rnamsm_forward each vs ONE rnamsm_forward_packed "
+                    "call (token-packed: no padding; outputs equal alone to fp32 rounding, tests/test_gpu_forward.py)",
+            "alignments": 64, "tokens": preal, "ms_one_by_one": 1e3 * t_one, "ms_packed": 1e3 * t_pk,
+            "residues_per_s_one_by_one": preal / t_one, "residues_per_s_packed": preal / t_pk, "speedup": t_one / t_pk}
         fast = measure_mode("f16x3", 3.0)
         fast["f32_path_reordering_noise"] = {"emb_rel_l2": noise_emb, "atp_max_abs": noise_atp,
                                              "what": "exact path vs itself with alignment rows 1.. permuted"}

@@ -35,6 +35,9 @@ class DataConfig:                       # RNA_MSM_Inference.py:20-32
     # its GEMM kernels by the BATCH's token count, so an alignment's files would depend (at the mode's rounding level, ~1e-2
     # in bf16) on what else is in the id list; one by one every alignment's output is a function of that alignment alone
     batch_small_msas_16bit: bool = False
+    # exact mode (round 4): the groups of small alignments are TOKEN-PACKED -- back to back on the token axis, nothing padded
+    # (rnamsm_forward_packed) -- instead of padded into a frame; false = the framed ragged batch of round 3 (A/B, tools/cli_throughput.py)
+    pack_small_msas: bool = True
 
 
 @dataclass

@@ -217,6 +217,48 @@ def plan_groups(shapes: List[tuple]) -> List[List[int]]:
     return plans[0] if cost[0] <= cost[1] else plans[1]
 
 
+# ---- token-packed groups (exact mode, data.pack_small_msas; round 4): forward_ragged then runs rnamsm_forward_packed, which
+# pads nothing, so a group is bounded by what it really holds -- PACKED_TOKENS tokens, PACKED_MEMBERS members, FRAME_MAP_ELEMS map
+# elements (sum of C^2) -- and shapes need not match: groups are cut in list order (the gather path keeps its order for free).
+# Measured (tools/packed_batch_timing.py, 4-24 rows x 41-121 columns): 4 k tokens 361 k residues/s, 10 k 522 k, 21 k 633 k, 34 k 621 k,
+# 49 k 678 k, 66 k 689 k (GEMM tile quantisation and the folded LayerNorm's threshold) against 147 k one by one -- hence 64 k
+# tokens / 256 members; and alignments of up to PACKED_SMALL_TOKENS wait for company (16-64 rows x 60-200 columns, ~5 k tokens
+# each: x1.4-1.5 packed against alone; framed they lost).
+PACKED_TOKENS, PACKED_MEMBERS, PACKED_SMALL_TOKENS = 65536, 256, 8192
+
+
+def joins_packed(group_shapes: List[tuple], shape: tuple) -> bool:
+    """Does a small alignment of `shape` join the waiting token-packed group?"""
+    trial = list(group_shapes) + [shape]
+    return (len(trial) <= PACKED_MEMBERS and sum(r * c for r, c in trial) <= PACKED_TOKENS
+            and sum(c * c for _, c in trial) <= FRAME_MAP_ELEMS)
+
+
+def plan_packed_groups(shapes: List[tuple]) -> List[List[int]]:
+    """Partition pooled small alignments into token-packed groups, in list order, every position exactly once.  The number of
+    groups is the least the three bounds allow; members are then dealt so that the groups hold about the same number of tokens
+    (64 + 6 alignments would otherwise run as one full group and one nearly empty launch set)."""
+    if not shapes:
+        return []
+    tok = [r * c for r, c in shapes]
+    k = max(-(-len(shapes) // PACKED_MEMBERS), -(-sum(tok) // PACKED_TOKENS), -(-sum(c * c for _, c in shapes) // FRAME_MAP_ELEMS), 1)
+    while True:
+        # next-fit with a soft budget of 1/k of the tokens: a group closes once it has reached the budget (the member that crosses
+        # it still joins, bounds permitting), or earlier when the next member would break a hard bound
+        budget = -(-sum(tok) // k)
+        groups: List[List[int]] = [[]]
+        t = 0
+        for j in range(len(shapes)):
+            if groups[-1] and (t >= budget or not joins_packed([shapes[i] for i in groups[-1]], shapes[j])):
+                groups.append([])
+                t = 0
+            groups[-1].append(j)
+            t += tok[j]
+        if len(groups) <= k:
+            return groups
+        k = len(groups)             # the hard bounds cut earlier than planned: aim for that many, evenly filled
+
+
 def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_rank0: bool = False,
                  async_io: bool = True) -> List[str]:
     """async_io: read/tokenise the next alignment on a helper thread while the GPU runs the current one, and move the
@@ -307,11 +349,13 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
             batching = bool(getattr(cfg.data, "batch_small_msas", True)) and (
                 model.gemm_dtype == "f32" or (bool(getattr(cfg.data, "batch_small_msas_16bit", False)) and ops.get_param("attn16") != 0))
             pooled = batching and gatherer is None
+            # exact mode: groups are token-packed (no frame, no padding -- rnamsm_forward_packed), so any small alignments share one
+            packing = batching and model.gemm_dtype == "f32" and bool(getattr(cfg.data, "pack_small_msas", True))
             group: List = []                                          # (idx, tokens on the device)
             pool: List = []                                           # (idx, tokens on the host)
 
             def run_pool() -> None:
-                for members in plan_groups([tuple(t.shape) for _, t in pool]):
+                for members in (plan_packed_groups if packing else plan_groups)([tuple(t.shape) for _, t in pool]):
                     group.extend((pool[j][0], torch.from_numpy(pool[j][1]).to(device)) for j in members)
                     flush()
                 pool.clear()
@@ -323,7 +367,7 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                     deliver(idx0, out["emb"], out["atp"])
                 elif group:
                     try:
-                        outs = model.forward_ragged([t for _, t in group])
+                        outs = model.forward_ragged([t for _, t in group], packed=packing)
                     except IndexError:                                # name the offending alignment: one by one
                         outs = [model.checked_forward_one(t, need_repr=False, what=ids[i]) for i, t in group]
                     for (i, _), out in zip(group, outs):
@@ -337,15 +381,15 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                     tokens = pending.result() if reader else read(idx)
                     if reader and n + 1 < len(mine):
                         pending = reader.submit(read, mine[n + 1])       # parsed while the GPU runs this MSA
-                    if (batching and tokens.size <= SMALL_MSA_TOKENS and 2 * tokens.shape[1] ** 2 <= FRAME_MAP_ELEMS
+                    if (batching and tokens.size <= (PACKED_SMALL_TOKENS if packing else SMALL_MSA_TOKENS) and 2 * tokens.shape[1] ** 2 <= FRAME_MAP_ELEMS
                             and not (tokens == alphabet.padding_idx).any()):
                         if pooled:
                             pool.append((idx, tokens))
                             if len(pool) >= POOL_MSAS:
                                 run_pool()
                             continue
-                        if not joins_group([tuple(t.shape) for _, t in group], tuple(tokens.shape)):
-                            flush()                                       # this one would waste too much padding: start a new frame
+                        if not (joins_packed if packing else joins_group)([tuple(t.shape) for _, t in group], tuple(tokens.shape)):
+                            flush()                                       # the group is full (framed: this one would pad too much)
                         group.append((idx, torch.from_numpy(tokens).to(device)))
                         continue
                     flush()

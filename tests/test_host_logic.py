@@ -430,3 +430,30 @@ def test_pooled_small_alignments_are_grouped_by_shape():
     assert plan_groups([]) == [] and plan_groups([(3, 20)]) == [[0]]
     assert plan_groups([(40, 35), (2, 12), (2, 12), (2, 12), (40, 35)]) == [[1, 2, 3], [0, 4]]          # alike ones meet although the list separates them
 
+
+
+def test_token_packed_groups_are_cut_in_list_order_and_balanced():
+    """plan_packed_groups / joins_packed (exact mode, data.pack_small_msas): a token-packed group pads nothing, so its bounds are
+    what it really holds -- tokens, members, map elements -- and shapes need not match; groups are consecutive runs of the list,
+    as few as the bounds allow, holding about the same number of tokens."""
+    from rnamsm.inference import FRAME_MAP_ELEMS, PACKED_MEMBERS, PACKED_TOKENS, joins_packed, plan_packed_groups
+    assert (PACKED_TOKENS, PACKED_MEMBERS) == (65536, 256)
+    assert joins_packed([], (3, 20)) and joins_packed([(2, 10), (2, 10)], (30, 50))         # unlike shapes share a group: nothing is padded
+    assert joins_packed([(30, 50)] * 42, (30, 50)) and not joins_packed([(30, 50)] * 43, (30, 50))      # 44 x 1500 > 65536 tokens
+    assert joins_packed([(2, 8)] * 255, (2, 8)) and not joins_packed([(2, 8)] * 256, (2, 8))            # members
+    assert joins_packed([(3, 256)] * 15, (3, 256)) and not joins_packed([(3, 256)] * 16, (3, 256))      # sum of C^2
+    rng = np.random.RandomState(7)
+    for n in (1, 2, 63, 64, 65, 70, 256, 300, 700):
+        shapes = [(int(rng.randint(1, 25)), int(rng.randint(20, 140))) for _ in range(n)]
+        groups = plan_packed_groups(shapes)
+        assert [j for g in groups for j in g] == list(range(n))                                # consecutive runs, every position once
+        tok = [sum(shapes[j][0] * shapes[j][1] for j in g) for g in groups]
+        for g, t in zip(groups, tok):
+            assert len(g) <= PACKED_MEMBERS and t <= PACKED_TOKENS and sum(shapes[j][1] ** 2 for j in g) <= FRAME_MAP_ELEMS
+        least = max(-(-n // PACKED_MEMBERS), -(-sum(tok) // PACKED_TOKENS), -(-sum(c * c for _, c in shapes) // FRAME_MAP_ELEMS))
+        assert len(groups) <= 1.25 * least + 1                                                 # (next-fit in list order: not optimal packing)
+        if len(groups) > 1:
+            assert min(tok) >= 0.5 * max(tok), tok                                             # balanced: no nearly empty launch set
+    assert plan_packed_groups([]) == [] and plan_packed_groups([(3, 20)]) == [[0]]
+    assert plan_packed_groups([(40, 35), (2, 12), (2, 12), (2, 12), (40, 35)]) == [[0, 1, 2, 3, 4]]
+    assert plan_packed_groups([(1, 1024)] * 3) == [[0], [1], [2]]                              # 1024^2 map elements each: alone

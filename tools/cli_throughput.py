@@ -11,6 +11,8 @@ from rnamsm import inference
 from rnamsm.inference import extract_feat
 if os.environ.get("SMALL_TOKENS"):                       # A/B of the "small alignment" limit
     inference.SMALL_MSA_TOKENS = int(os.environ["SMALL_TOKENS"])
+if os.environ.get("PACKED_TOKENS"):                      # A/B of the token budget of a token-packed group
+    inference.PACKED_TOKENS = int(os.environ["PACKED_TOKENS"])
 from rnamsm.model import MSATransformer
 N, M, L = int(os.environ.get("N", 12)), int(os.environ.get("M", 256)), int(os.environ.get("L", 300))
 state = synthetic.make_state_dict(seed=0)
@@ -42,12 +44,12 @@ for mode in (False, True, False, True):
 # share one ragged launch set) against the strictly one-by-one loop of the reference (data.batch_small_msas=false)
 NS = int(os.environ.get("NSMALL", 64))
 # two populations: "tiny" (2-12 rows x 40-80 columns) and "small" (4-24 rows x 40-120 columns: up to 2.9 k tokens each)
-for label, (dlo, dhi), (llo, lhi) in (("tiny", (2, 13), (40, 81)), ("small", (4, 25), (40, 121))):
+for label, (dlo, dhi), (llo, lhi) in (("tiny", (2, 13), (40, 81)), ("small", (4, 25), (40, 121)), ("mid", (16, 65), (60, 201))):
     if not NS:
         break
     res = {}
     for rnd in range(2):
-        for batching in (False, True):
+        for batching in (False, True, "framed"):          # "framed": batched, but padded frames instead of token-packed groups (round 3)
             rng = np.random.RandomState(1)
             root = tempfile.mkdtemp(prefix="rnamsm_cli_small_", dir=os.environ.get("SCRATCH", "/tmp"))
             os.makedirs(os.path.join(root, "results"))
@@ -63,12 +65,13 @@ for label, (dlo, dhi), (llo, lhi) in (("tiny", (2, 13), (40, 81)), ("small", (4,
             open(os.path.join(root, "rna_id.txt"), "w").write("\n".join(ids) + "\n")
             cfg = Config()
             cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = root, "results", "rna_id.txt"
-            cfg.data.sample_method, cfg.data.max_seqs_per_msa, cfg.data.batch_small_msas = "first", 64, batching
+            cfg.data.sample_method, cfg.data.max_seqs_per_msa, cfg.data.batch_small_msas = "first", 64, bool(batching)
+            cfg.data.pack_small_msas = batching is True
             torch.cuda.synchronize(); t0 = time.perf_counter()
             extract_feat(cfg, model=model)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             res.setdefault(batching, []).append(dt)
             shutil.rmtree(root)
-    one, bat = min(res[False]), min(res[True])
+    one, bat, fr = min(res[False]), min(res[True]), min(res["framed"])
     print(f"{NS} {label} alignments ({dlo}-{dhi - 1} rows x {llo}-{lhi - 1} columns, {tokens} tokens): one by one {one:.3f} s = {NS / one:.1f} MSA/s; "
-          f"default (batched) {bat:.3f} s = {NS / bat:.1f} MSA/s; x{one / bat:.2f}", flush=True)
+          f"default (token-packed groups) {bat:.3f} s = {NS / bat:.1f} MSA/s; x{one / bat:.2f}; framed groups (round 3) {fr:.3f} s; x{one / fr:.2f}", flush=True)
