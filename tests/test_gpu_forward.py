@@ -789,11 +789,12 @@ def test_token_packed_batch_equals_every_alignment_alone(model):
         assert rel_l2(got["repr"].cpu().numpy(), one["repr"].cpu().numpy()) < 1e-5, shapes[i]
         assert np.abs(got["atp"].cpu().numpy() - one["atp"].cpu().numpy()).max() < 1e-4, shapes[i]
         assert np.abs(got["row_attn"].cpu().numpy() - one["row_attn"].cpu().numpy()).max() < 1e-4, shapes[i]
-        t_emb, t_atp = truth.oracle_outputs(t.cpu().numpy(), torch.float64, "cuda:0")
-        e_pk, e_one = rel_l2(got["emb"].double().cpu(), t_emb.cpu()), rel_l2(one["emb"].double().cpu(), t_emb.cpu())
-        a_pk, a_one = float((got["atp"].double() - t_atp).abs().max()), float((one["atp"].double() - t_atp).abs().max())
-        assert e_pk < 1.5 * e_one + 1e-6 and e_pk < 1e-4, (shapes[i], e_pk, e_one)
-        assert a_pk < 1.5 * a_one + 1e-6 and a_pk < 1e-4, (shapes[i], a_pk, a_one)
+        if shapes[i] in ((5, 133), (17, 33), (140, 35), (2, 257)):      # (the fp64 evaluation costs seconds per shape: four of the nine)
+            t_emb, t_atp = truth.oracle_outputs(t.cpu().numpy(), torch.float64, "cuda:0")
+            e_pk, e_one = rel_l2(got["emb"].double().cpu(), t_emb.cpu()), rel_l2(one["emb"].double().cpu(), t_emb.cpu())
+            a_pk, a_one = float((got["atp"].double() - t_atp).abs().max()), float((one["atp"].double() - t_atp).abs().max())
+            assert e_pk < 1.5 * e_one + 1e-6 and e_pk < 1e-4, (shapes[i], e_pk, e_one)
+            assert a_pk < 1.5 * a_one + 1e-6 and a_pk < 1e-4, (shapes[i], a_pk, a_one)
         if t.numel() <= 2500:
             emb, atp = O.pack_outputs(O.forward(t.cpu(), params))
             assert rel_l2(got["emb"].cpu().numpy(), np.asarray(emb)) < 1e-4

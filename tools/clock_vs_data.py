@@ -12,6 +12,7 @@ import torch
 from rnamsm import ops
 
 dev = torch.device("cuda:0")
+BURST = int(os.environ.get("BURST", 400))
 T, N, K = int(os.environ.get("T", 131072)), 2304, 768
 
 
@@ -63,11 +64,20 @@ print("rocm-smi --showclocks (raw, idle):\n" + _run(["rocm-smi", "--showclocks"]
 w = ops.split_bf16(torch.randn(N, K, device=dev) * 0.04, want_lo=False, fmt=0)
 b = torch.zeros(N, device=dev)
 flops = 2.0 * T * N * K
+F32 = os.environ.get("MODE", "bf16") == "f32"       # MODE=f32: the exact path's fp32 GEMM (the headline kernel) instead of the bf16 one
+if F32:
+    wf = torch.randn(N, K, device=dev) * 0.04
+    outf = torch.empty(T, N, device=dev)
+print("kernel:", "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)" if F32 else "plain-bf16 plane GEMM (16x16x32 bf16 MFMA)", f"T={T} N={N} K={K}", flush=True)
 for tag, make in (("zeros", lambda: torch.zeros(T, K, device=dev)), ("ones", lambda: torch.ones(T, K, device=dev)),
                   ("N(0,1)", lambda: torch.randn(T, K, device=dev)), ("zeros again", lambda: torch.zeros(T, K, device=dev))):
     a = ops.split_bf16(make(), want_lo=False, fmt=0)
     ww = w if tag != "zeros" and tag != "zeros again" else ops.split_bf16(torch.zeros(N, K, device=dev), want_lo=False, fmt=0)
     fn = lambda: ops.linear_planes(a, ww, b, out_planes=True, fmt=0)
+    if F32:
+        af = make()
+        wz = wf if "zeros" not in tag else torch.zeros_like(wf)
+        fn = lambda: ops.linear(af, wz, b, out=outf)
     for _ in range(50):
         fn()
     torch.cuda.synchronize()
@@ -76,7 +86,7 @@ for tag, make in (("zeros", lambda: torch.zeros(T, K, device=dev)), ("ones", lam
     for burst in range(25):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(400):
+        for _ in range(BURST):
             fn()
         e1.record()
         time.sleep(0.02)                 # the burst is executing now (launches are asynchronous)
@@ -87,7 +97,7 @@ for tag, make in (("zeros", lambda: torch.zeros(T, K, device=dev)), ("ones", lam
                     samples[n].append(v)
         still_running = not e1.query()
         torch.cuda.synchronize()
-        per_launch.append((e0.elapsed_time(e1) / 400, still_running))
+        per_launch.append((e0.elapsed_time(e1) / BURST, still_running))
     ms = statistics.median(t for t, _ in per_launch)
     busy = sum(1 for _, r in per_launch if r)
     print(f"operands {tag:12s}: {ms:.4f} ms / launch = {flops / ms / 1e9:7.0f} TFLOP/s; bursts still executing after the readback: {busy}/25; "

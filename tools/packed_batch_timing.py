@@ -17,6 +17,9 @@ model = model.eval().to(dev)
 POPS = {"tiny": ((2, 12), (41, 81)), "small": ((4, 24), (41, 121)), "mid": ((16, 64), (60, 200))}
 (rlo, rhi), (clo, chi) = POPS[os.environ.get("POP", "small")]
 lib = _lib.load()
+for kv in os.environ.get("KNOBS", "").split(","):          # KNOBS=ln_fold=3,gemm_tile=2: rnamsm_set_param before the runs
+    if kv:
+        _lib.check(lib.rnamsm_set_param(kv.split("=")[0].encode(), int(kv.split("=")[1])))
 for target in [int(v) for v in os.environ.get("TOKENS", "4096,8192,12288,16384,20480,24576,32768,49152,65536").split(",")]:
     rng = np.random.default_rng(0)
     shapes, real = [], 0
