@@ -222,6 +222,10 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().col_dma = value < 0 ? -1 : (value != 0);
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "col_fast")) {
+        rnamsm::tuning().col_fast = value != 0;
+        return RNAMSM_OK;
+    }
     return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: unknown parameter %s", name ? name : "(null)");
 }
 extern "C" int rnamsm_get_param(const char* name) {
@@ -231,6 +235,7 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "greedy_fused")) return rnamsm::tuning().greedy_fused;
     if (name && !strcmp(name, "col_small")) return rnamsm::tuning().col_small;
     if (name && !strcmp(name, "col_dma")) return rnamsm::tuning().col_dma;
+    if (name && !strcmp(name, "col_fast")) return rnamsm::tuning().col_fast;
     if (name && !strcmp(name, "gemm16_dephase")) return rnamsm::tuning().gemm16_dephase;
     if (name && !strcmp(name, "gemm16_big_rows")) return rnamsm::tuning().gemm16_big_rows;
     if (name && !strcmp(name, "gemm16_big_rows_fwd")) return rnamsm::tuning().gemm16_big_rows_fwd;

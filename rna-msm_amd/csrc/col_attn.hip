@@ -37,7 +37,7 @@ __global__ __launch_bounds__(CA_THREADS, 2) void col_attn_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask,
     uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows, int64_t qkv_bstride, int64_t ctx_bstride,
-    const PackedMsa* /* packed batches run on col_attn_dma_kernel */, int) {
+    const PackedMsa* /* packed batches run on col_attn_dma_kernel */, int, int) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     q += blockIdx.y * qkv_bstride;        // batched launch (rnamsm_forward_batch): MSA blockIdx.y, fp32 context
     k += blockIdx.y * qkv_bstride;
@@ -262,12 +262,17 @@ __host__ __device__ constexpr int cd_vidx(int t, int dt) {
 }
 __host__ __device__ constexpr int cd_vrow(int t) { return (t & 3) + 8 * (t >> 2); }
 
-template <bool MASKED, int OUT>
+// PRE (round 4): q arrives PRESCALED by dh^-1/2 * log2(e) (the QKV GEMM's epilogue), scores are in log2 units and the kernel
+// first runs a FAST loop with NO running maximum -- p = v_exp_f32(s) on the raw score, no max chain, no half exchange, no
+// rescale of the accumulators (softmax is invariant to the reference point; fp32 p and sums keep their relative precision
+// whatever the scale) -- and looks at the row sums afterwards: outside [2^-100, 2^100] or not finite, some score left the
+// exponent range; the block votes and redoes its column on the TRACKED loop (the online softmax below, in log2 units).
+template <bool MASKED, int OUT, bool PRE = false>
 __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, const uint8_t* __restrict__ pad_mask,
     uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int q_rows, int64_t qkv_bstride, int64_t ctx_bstride,
-    const PackedMsa* __restrict__ pk, int pk_skip_shallow) {
+    const PackedMsa* __restrict__ pk, int pk_skip_shallow, int pre_tracked_only) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     if (pk) {
         // token-packed batch (rnamsm_forward_packed; unmasked, fp32 context): alignment blockIdx.y's own shape and token offset;
@@ -366,8 +371,9 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
 
     // One 32-key tile, order pinned.  V values travel in quarters of 8 (steps 4q..4q+3, both head-dim tiles) that ping-pong:
     // quarter 0 under the QK^T MFMAs, quarter q+1 under the PV MFMAs of quarter q -- 16 live V registers instead of 32.
-    auto tile = [&](auto bufc, int jbase) {
+    auto tile = [&](auto bufc, int jbase, auto trk_tag) __attribute__((always_inline)) {
         constexpr int BUF = decltype(bufc)::value;
+        constexpr bool TRK = decltype(trk_tag)::value;
         f32x4 kf[8];
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) kf[kk] = *reinterpret_cast<const f32x4*>(kb[kk] + BUF * CD_BUF);
@@ -403,21 +409,31 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
                 if (j < R && pad_mask[(int64_t)j * C + c]) s[t] = -10000.f;
             }
         }
-        float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
-        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
-        float psum = 0.f;
+        if (TRK) {
+            float mx = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+            mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[8], s[9]), fmaxf(s[10], s[11])), fmaxf(fmaxf(s[12], s[13]), fmaxf(s[14], s[15]))));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = PRE ? __builtin_amdgcn_exp2f(m_run - m_new) : __expf(m_run - m_new);
+            float psum = 0.f;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            s[t] = __expf(s[t] - m_new);
-            psum += s[t];
+            for (int t = 0; t < 16; ++t) {
+                s[t] = PRE ? __builtin_amdgcn_exp2f(s[t] - m_new) : __expf(s[t] - m_new);
+                psum += s[t];
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
+        } else {
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                s[t] = __builtin_amdgcn_exp2f(s[t]);          // keys past R hold -inf: 0
+                psum += s[t];
+            }
+            l_run += psum;
         }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) { o0[t] *= alpha; o1[t] *= alpha; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
@@ -445,16 +461,38 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
     };
 
     const int nch = (R + CD_JC - 1) / CD_JC;
-    issue(0, 0);
-    for (int ch = 0; ch < nch; ch += 2) {                     // unrolled by two: the buffer index is a compile-time constant
-        wait_dma_then_barrier<0>();      // chunk ch has landed (every wave's share) and the other buffer is free again
-        if (ch + 1 < nch) issue(ch + 1, 1);
-        if (active) tile(std::integral_constant<int, 0>{}, ch * CD_JC);
-        if (ch + 1 < nch) {
-            wait_dma_then_barrier<0>();
-            if (ch + 2 < nch) issue(ch + 2, 0);
-            if (active) tile(std::integral_constant<int, 1>{}, (ch + 1) * CD_JC);
+    auto run = [&](auto trk_tag) __attribute__((always_inline)) {
+        issue(0, 0);
+        for (int ch = 0; ch < nch; ch += 2) {                     // unrolled by two: the buffer index is a compile-time constant
+            wait_dma_then_barrier<0>();      // chunk ch has landed (every wave's share) and the other buffer is free again
+            if (ch + 1 < nch) issue(ch + 1, 1);
+            if (active) tile(std::integral_constant<int, 0>{}, ch * CD_JC, trk_tag);
+            if (ch + 1 < nch) {
+                wait_dma_then_barrier<0>();
+                if (ch + 2 < nch) issue(ch + 2, 0);
+                if (active) tile(std::integral_constant<int, 1>{}, (ch + 1) * CD_JC, trk_tag);
+            }
         }
+    };
+    if (PRE && !pre_tracked_only) {
+        run(std::integral_constant<bool, false>{});
+        // the block shares the ring: its waves vote and redo the column together
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const bool bad = active && !(l_tot < 0x1p100f && l_tot > 0x1p-100f);
+        __shared__ int flags[4];
+        const int wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+        if (lane == 0) flags[wave] = wave_bad;
+        wait_dma_then_barrier<0>();
+        const int any_bad = flags[0] | flags[1] | flags[2] | flags[3];       // block-uniform
+        if (any_bad) {
+            wait_dma_then_barrier<0>();      // every wave has read the flags and is done with the ring
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
+            m_run = -INFINITY; l_run = 0.f;
+            run(std::integral_constant<bool, true>{});
+        }
+    } else {
+        run(std::integral_constant<bool, true>{});
     }
 #undef CD_VREAD
 
@@ -499,7 +537,8 @@ using namespace rnamsm;
 
 static int col_attn_launch(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,
                            int H, int head_dim, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt,
-                           int dtype, void* stream, int q_rows, int batch = 1, int64_t qkv_bstride = 0, int64_t ctx_bstride = 0);
+                           int dtype, void* stream, int q_rows, int batch = 1, int64_t qkv_bstride = 0, int64_t ctx_bstride = 0,
+                           bool prescaled = false);
 
 extern "C" int rnamsm_col_attn_fused(const float* q, const float* k, const float* v, int64_t ld, float* ctx,
                                      int64_t ldc, int R, int C, int H, int head_dim, const uint8_t* pad_mask,
@@ -512,6 +551,12 @@ extern "C" int rnamsm_col_attn_fused_queries(const float* q, const float* k, con
                                              const uint8_t* pad_mask, int dtype, void* stream) {
     RNAMSM_CHECK_ARG(q_rows >= 1 && q_rows <= R, "col_attn_queries: q_rows must be in [1, R] (got %d, R=%d)", q_rows, R);
     return col_attn_launch(q, k, v, ld, ctx, ldc, R, C, H, head_dim, pad_mask, nullptr, nullptr, 0, dtype, stream, q_rows);
+}
+
+extern "C" int rnamsm_col_attn_fused_prescaled(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc,
+                                               int R, int C, int H, int head_dim, int q_rows, void* stream) {
+    RNAMSM_CHECK_ARG(q_rows >= 1 && q_rows <= R, "col_attn_prescaled: q_rows must be in [1, R] (got %d, R=%d)", q_rows, R);
+    return col_attn_launch(q, k, v, ld, ctx, ldc, R, C, H, head_dim, nullptr, nullptr, nullptr, 0, RNAMSM_F32, stream, q_rows, 1, 0, 0, true);
 }
 
 namespace rnamsm {
@@ -539,7 +584,7 @@ __global__ __launch_bounds__(256) void col_attn_small_kernel(const float* __rest
                                                              int64_t ldc, int R, int C, int H,
                                                              const uint8_t* __restrict__ pad_mask, int q_rows,
                                                              int64_t qkv_bstride, int64_t ctx_bstride,
-                                                             const PackedMsa* __restrict__ pk) {
+                                                             const PackedMsa* __restrict__ pk, int log2_domain) {
     typedef float f32x4s __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int prob = blockIdx.x * 4 + wave;
@@ -595,7 +640,7 @@ __global__ __launch_bounds__(256) void col_attn_small_kernel(const float* __rest
     float l = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        p[t] = __expf(p[t] - mx);                                // keys past R: exp(-inf) = 0
+        p[t] = log2_domain ? __builtin_amdgcn_exp2f(p[t] - mx) : __expf(p[t] - mx);      // keys past R: exp(-inf) = 0; log2_domain: q carries log2(e)
         l += p[t];
     }
     l += __shfl_xor(l, 16, 64);
@@ -619,8 +664,9 @@ __global__ __launch_bounds__(256) void col_attn_small_kernel(const float* __rest
 
 static int col_attn_launch(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,
                            int H, int head_dim, const uint8_t* pad_mask, uint16_t* ctx_hi, uint16_t* ctx_lo, int plane_fmt,
-                           int dtype, void* stream, int q_rows, int batch, int64_t qkv_bstride, int64_t ctx_bstride) {
+                           int dtype, void* stream, int q_rows, int batch, int64_t qkv_bstride, int64_t ctx_bstride, bool prescaled) {
     if (dtype != RNAMSM_F32) return fail(RNAMSM_ERR_UNSUPPORTED, "col_attn: only RNAMSM_F32 is implemented");
+    RNAMSM_CHECK_ARG(!prescaled || (!pad_mask && !ctx_hi), "col_attn: prescaled q has no masked / plane-output variant");
     RNAMSM_CHECK_ARG(batch == 1 || (!ctx_hi && qkv_bstride % 4 == 0 && ctx_bstride % 4 == 0),
                      "col_attn: a batched launch writes fp32 context");
     RNAMSM_CHECK_ARG(q && k && v && (ctx || ctx_hi), "col_attn: null pointer");
@@ -639,9 +685,9 @@ static int col_attn_launch(const float* q, const float* k, const float* v, int64
     if (R <= 16 && !ctx_hi && tuning().col_small != 0) {
         const dim3 sgrid(((unsigned)C * H + 3) / 4, batch);
         if (pad_mask)
-            hipLaunchKernelGGL(col_attn_small_kernel<true>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, q_rows, qkv_bstride, ctx_bstride, (const PackedMsa*)nullptr);
+            hipLaunchKernelGGL(col_attn_small_kernel<true>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, q_rows, qkv_bstride, ctx_bstride, (const PackedMsa*)nullptr, prescaled ? 1 : 0);
         else
-            hipLaunchKernelGGL(col_attn_small_kernel<false>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, q_rows, qkv_bstride, ctx_bstride, (const PackedMsa*)nullptr);
+            hipLaunchKernelGGL(col_attn_small_kernel<false>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, q_rows, qkv_bstride, ctx_bstride, (const PackedMsa*)nullptr, prescaled ? 1 : 0);
         RNAMSM_CHECK_LAUNCH("col_attn_small");
         return RNAMSM_OK;
     }
@@ -655,7 +701,7 @@ static int col_attn_launch(const float* q, const float* k, const float* v, int64
             cfg_.mark();                                                                                            \
         }                                                                                                           \
         hipLaunchKernelGGL((KERN_<M_, OUT_>), dim3(grid, batch), dim3(CA_THREADS), LDS_, s, q, k, v, ld, ctx, ldc, R, C, H, \
-                           pad_mask, ctx_hi, ctx_lo, q_rows, qkv_bstride, ctx_bstride, (const PackedMsa*)nullptr, 0); \
+                           pad_mask, ctx_hi, ctx_lo, q_rows, qkv_bstride, ctx_bstride, (const PackedMsa*)nullptr, 0, 0); \
     } while (0)
     // "col_dma": 1 = the LDS-DMA, three-blocks-per-CU variant, 0 = the register-staged kernel, -1 (default) = the former.
     // Measured in one process (tools/col_attn_ab.py, after the key-range masking was confined to the ragged last tile):
@@ -667,6 +713,20 @@ static int col_attn_launch(const float* q, const float* k, const float* v, int64
         if (use_dma) CA_GO2(col_attn_dma_kernel, CD_LDS_BYTES, M_, OUT_);                                           \
         else CA_GO2(col_attn_kernel, CA_LDS_BYTES, M_, OUT_);                                                       \
     } while (0)
+    if (prescaled) {        // log2-domain scores: FAST loop first ("col_fast" = 0: the TRACKED loop only, A/B)
+        static DeviceOnce cfgp;
+        if (cfgp.pending()) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn_dma_kernel<false, 0, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS_BYTES);
+            if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            cfgp.mark();
+        }
+        hipLaunchKernelGGL((col_attn_dma_kernel<false, 0, true>), dim3(grid, batch), dim3(CA_THREADS), CD_LDS_BYTES, s, q, k, v, ld, ctx, ldc,
+                           R, C, H, pad_mask, ctx_hi, ctx_lo, q_rows, qkv_bstride, ctx_bstride, (const PackedMsa*)nullptr, 0,
+                           tuning().col_fast ? 0 : 1);
+        RNAMSM_CHECK_LAUNCH("col_attn (prescaled)");
+        return RNAMSM_OK;
+    }
     if (pad_mask) CA_GO2(col_attn_dma_kernel, CD_LDS_BYTES, true, 0);      // (the register-staged kernel has no masked instance: it spilled)
     else if (!ctx_hi) CA_GO(false, 0);
     else if (plane_fmt == 0) CA_GO(false, 1);
@@ -681,15 +741,15 @@ namespace rnamsm {
 // K7 for `batch` same-shape MSAs in one launch (rnamsm_forward_batch): MSA b's q / k / v lie b * qkv_bstride elements on,
 // its padding mask (if any) b * R * C bytes on
 int col_attn_batched(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
-                     int batch, int64_t qkv_bstride, int64_t ctx_bstride, const uint8_t* pad_mask, void* stream) {
+                     int batch, int64_t qkv_bstride, int64_t ctx_bstride, const uint8_t* pad_mask, void* stream, bool prescaled) {
     return col_attn_launch(q, k, v, ld, ctx, ldc, R, C, H, CA_HD, pad_mask, nullptr, nullptr, 0, RNAMSM_F32, stream, R, batch,
-                           qkv_bstride, ctx_bstride);
+                           qkv_bstride, ctx_bstride, prescaled);
 }
 
 // K7 of a token-packed batch (rnamsm_forward_packed): the LDS-DMA kernel with gridDim.y = alignment, gridDim.x sized for the
 // largest alignment; with "col_small" on, the alignments of R <= 16 go to a second launch of the one-wave-per-problem kernel
 int col_attn_packed(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int H, const PackedMsa* pk,
-                    const PackedMsa* host, int B, void* stream) {
+                    const PackedMsa* host, int B, void* stream, bool prescaled) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool split_shallow = tuning().col_small != 0;
     unsigned grid = 0, sgrid = 0;
@@ -715,14 +775,26 @@ int col_attn_packed(const float* q, const float* k, const float* v, int64_t ld, 
             if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn (packed): hipFuncSetAttribute: %s", hipGetErrorString(e));
             cfg.mark();
         }
+        if (prescaled) {
+            static DeviceOnce cfgp;
+            if (cfgp.pending()) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(col_attn_dma_kernel<false, 0, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS_BYTES);
+                if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn (packed): hipFuncSetAttribute: %s", hipGetErrorString(e));
+                cfgp.mark();
+            }
+            hipLaunchKernelGGL((col_attn_dma_kernel<false, 0, true>), dim3(grid, B), dim3(CA_THREADS), CD_LDS_BYTES, s, q, k, v, ld, ctx, ldc, 0,
+                               0, H, (const uint8_t*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr, 0, (int64_t)0, (int64_t)0, pk,
+                               split_shallow ? 1 : 0, tuning().col_fast ? 0 : 1);
+        } else
         hipLaunchKernelGGL((col_attn_dma_kernel<false, 0>), dim3(grid, B), dim3(CA_THREADS), CD_LDS_BYTES, s, q, k, v, ld, ctx, ldc, 0, 0, H,
                            (const uint8_t*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr, 0, (int64_t)0, (int64_t)0, pk,
-                           split_shallow ? 1 : 0);
+                           split_shallow ? 1 : 0, 0);
         RNAMSM_CHECK_LAUNCH("col_attn (packed)");
     }
     if (sgrid) {
         hipLaunchKernelGGL(col_attn_small_kernel<false>, dim3(sgrid, B), dim3(256), 0, s, q, k, v, ld, ctx, ldc, 0, 0, H,
-                           (const uint8_t*)nullptr, 0, (int64_t)0, (int64_t)0, pk);
+                           (const uint8_t*)nullptr, 0, (int64_t)0, (int64_t)0, pk, prescaled ? 1 : 0);
         RNAMSM_CHECK_LAUNCH("col_attn_small (packed)");
     }
     return RNAMSM_OK;

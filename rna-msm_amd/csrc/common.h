@@ -80,6 +80,7 @@ struct Tuning {
     int gemm_splitk = 1;           // rnamsm_forward, fc2 below ~1.4 k tokens: 1 = four K ranges + an ordered reduction (gemm_f32_splitk_factor), 0 = never, 2 / 4 / 8 = forced (A/B)
     int row_vt = 1;                // fp32 row_apply: 1 = V tile transposed while staged (b128 fragments), 0 = [k][n] tile
     int col_small = 1;             // fp32 col_attn at R <= 16: 1 = one wave per (column, head), no LDS (col_attn_small_kernel), 0 = the 128-query blocks
+    int col_fast = 1;              // fp32 col_attn on prescaled q (rnamsm_col_attn_fused_prescaled): 1 = FAST loop (no running maximum) with the TRACKED loop as fallback, 0 = TRACKED only (A/B)
     int col_dma = -1;              // fp32 col_attn: 1 = LDS-DMA staging, 32-key chunks, 3 blocks/CU; 0 = register-staged kernel; -1 = by shape
     int row16_bk64 = 1;            // plain bf16 at C >= 256: 1 = row_apply16x on 64-key tiles, 2 = row_logits16 on the 256x256 kernel with 64-deep tiles too, 0 = neither
     int row16_q16 = 1;             // plain bf16 at C >= 384, C % 8 == 0: 1 = row_logits16q_kernel (16x16x32 MFMA, staged by operand), 0 = the 128x128 kernel
@@ -301,7 +302,7 @@ int softmax_rows_batched(const float* partial, int nsplit, float* probs, int H, 
 int row_apply_batched(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H, int batch,
                       int64_t probs_bstride, int64_t v_bstride, int64_t ctx_bstride, void* stream);
 int col_attn_batched(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,
-                     int batch, int64_t qkv_bstride, int64_t ctx_bstride, const uint8_t* pad_mask, void* stream);
+                     int batch, int64_t qkv_bstride, int64_t ctx_bstride, const uint8_t* pad_mask, void* stream, bool prescaled = false);
 
 // the same for the 16-bit modes (row_attn16.hip, row_attn.hip, col_attn16.hip): plane operands, MSA b's planes b * stride halves
 // further on; true_rows (device int32 [batch], may be null): every MSA's tied logits are scaled by its own depth
@@ -364,6 +365,6 @@ int softmax_rows_packed(const float* partial, float* row_attn, int layer, int H,
 int row_apply_packed(const float* row_attn, int layer, const float* v, int64_t ld, float* ctx, int64_t ldc, int H, const PackedMsa* pk,
                      const PackedMsa* host, int B, void* stream);
 int col_attn_packed(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int H, const PackedMsa* pk,
-                    const PackedMsa* host, int B, void* stream);
+                    const PackedMsa* host, int B, void* stream, bool prescaled = false);
 
 }  // namespace rnamsm

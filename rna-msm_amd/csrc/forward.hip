@@ -23,6 +23,7 @@
 using namespace rnamsm;
 
 namespace {
+constexpr float LOG2E = 1.4426950408889634f;
 struct Layout {
     size_t x, xn, wide, part, mask, pplanes, rowsum, stats, splitk, total;
 };
@@ -284,8 +285,8 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             const int64_t Tq = C;
             FWD(norm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B], T));
             FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], D, qkv + D, ldq, T, 2 * D, RNAMSM_ACT_NONE, 1.f, 0));   // k | v
-            FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], 0, qkv, ldq, Tq, D, RNAMSM_ACT_NONE, col_scale, D));  // q, row 0
-            FWD(rnamsm_col_attn_fused_queries(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, 1, nullptr, f32, stream));
+            FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], 0, qkv, ldq, Tq, D, RNAMSM_ACT_NONE, col_scale * LOG2E, D));  // q, row 0 (log2 units, as below)
+            FWD(rnamsm_col_attn_fused_prescaled(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, 1, stream));
             FWD(res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], Tq, D));
             FWD(norm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B], Tq));
             FWD(lin_normed(l, 2, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], 0, hidden, F, Tq, F, RNAMSM_ACT_GELU_ERF, 1.f, 0));
@@ -312,15 +313,22 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
                 FWD(rnamsm_col_attn16(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C,
                                       H, 64, col_scale, mask, ctx_hi, ctx_lo, fmt, stream));
         } else {
+            // exact path without padding: q leaves the QKV epilogue in log2 units (dh^-1/2 * log2(e)) and the column kernel's first
+            // pass runs without a running maximum (rnamsm_col_attn_fused_prescaled)
+            const bool pre32 = dtype == RNAMSM_F32 && !mask;
+            const float cs = pre32 ? col_scale * LOG2E : col_scale;
             if (planes)
                 FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
                               RNAMSM_ACT_NONE, col_scale, D));
             else if (fold)
-                FWD(lin_normed(l, 1, nullptr, nullptr, 0, qkv, ldq, T, 3 * D, RNAMSM_ACT_NONE, col_scale, D));
+                FWD(lin_normed(l, 1, nullptr, nullptr, 0, qkv, ldq, T, 3 * D, RNAMSM_ACT_NONE, cs, D));
             else
                 FWD(linear(l, 2, xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
-                           RNAMSM_ACT_NONE, col_scale, D, nullptr));
-            FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, mask, ctx_hi, ctx_lo, fmt, f32, stream));
+                           RNAMSM_ACT_NONE, cs, D, nullptr));
+            if (pre32)
+                FWD(rnamsm_col_attn_fused_prescaled(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, R, stream));
+            else
+                FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, mask, ctx_hi, ctx_lo, fmt, f32, stream));
         }
         if (fold16)
             FWD(res16_fold(l, 3, ctx_hi, ctx_lo, D, W[RNAMSM_WL_COL_BO], D));
@@ -574,8 +582,8 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
         FWD(res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], D));
         // ---- column attention
         FWD(norm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
-        FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, col_scale, D));
-        FWD(rnamsm::col_attn_batched(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, B, Tm * ldq, Tm * D, mask, stream));
+        FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, mask ? col_scale : col_scale * LOG2E, D));
+        FWD(rnamsm::col_attn_batched(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, B, Tm * ldq, Tm * D, mask, stream, !mask));
         FWD(res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], D));
         // ---- feed-forward
         FWD(norm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
@@ -731,8 +739,8 @@ extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float*
         FWD(res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], D));
         // ---- column attention
         FWD(norm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
-        FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, qk_scale, D));
-        FWD(rnamsm::col_attn_packed(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, H, desc, hp, B, stream));
+        FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, qk_scale * LOG2E, D));
+        FWD(rnamsm::col_attn_packed(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, H, desc, hp, B, stream, true));
         FWD(res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], D));
         // ---- feed-forward
         FWD(norm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));

@@ -109,6 +109,8 @@ _SIGNATURES = {
     "rnamsm_row_stats_from_partials": (c_int, [c_void_p, c_int64, c_int64, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "rnamsm_gemm_lnfold": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p,
                                    c_int64, c_int64, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "rnamsm_col_attn_fused_prescaled": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
+                                                c_int, c_int, c_void_p]),
     "rnamsm_col_attn_fused_queries": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                               c_int, c_int, c_void_p, c_int, c_void_p]),
     "rnamsm_col_attn_probs": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_float,

@@ -214,6 +214,14 @@ class ColumnSelfAttention(_AxialAttentionBase):
             probs = ops.col_attn_probs16(q, k, R, C, H, fmt=fmt, scale=self.scaling,
                                          pad_mask=mask if R > 1 else None).view(H, C, 1, R, R) if want else None
             return self._project_out(ctx, res2).view(R, C, 1, D), probs
+        if mask is None:
+            # no padding: q in log2 units (dh^-1/2 * log2 e from the QKV epilogue) and the kernel whose first pass needs no running
+            # maximum -- what rnamsm_forward runs (rnamsm_col_attn_fused_prescaled); the probabilities undo the factor (ln 2)
+            qkv = self._qkv(x2, self.scaling * 1.4426950408889634)
+            ctx = ops.col_attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], R, C, H, prescaled=True)
+            probs = ops.col_attn_probs(qkv[:, :D], qkv[:, D:2 * D], R, C, H,
+                                       scale=0.6931471805599453).view(H, C, 1, R, R) if want else None
+            return self._project_out(ctx, res2).view(R, C, 1, D), probs
         qkv = self._qkv(x2, self.scaling)
         # R == 1 reduces to ctx = v; padded keys get score -10000 (modules.py:911-915)
         ctx = ops.col_attn(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], R, C, H, pad_mask=mask if R > 1 else None)

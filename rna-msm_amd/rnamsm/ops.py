@@ -291,10 +291,18 @@ def row_apply(probs: torch.Tensor, v: torch.Tensor, R: int, C: int, H: int,
 
 @_on_operand_device
 def col_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, R: int, C: int, H: int,
-             out: Optional[torch.Tensor] = None, pad_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+             out: Optional[torch.Tensor] = None, pad_mask: Optional[torch.Tensor] = None, prescaled: bool = False,
+             q_rows: Optional[int] = None) -> torch.Tensor:
+    """prescaled: q carries dh^-1/2 * log2(e) (rnamsm_col_attn_fused_prescaled: no running maximum in the first pass)."""
     ctx = torch.empty(R * C, H * HEAD_DIM, device=v.device, dtype=torch.float32) if out is None else out
     ld = _rowmajor(q, "q")
     assert _rowmajor(k, "k") == ld and _rowmajor(v, "v") == ld
+    if prescaled:
+        assert pad_mask is None
+        _lib.check(_lib.load().rnamsm_col_attn_fused_prescaled(_dev(q, "q"), _dev(k, "k"), _dev(v, "v"), ld, _dev(ctx, "ctx"),
+                                                               _rowmajor(ctx, "ctx"), R, C, H, HEAD_DIM, R if q_rows is None else q_rows,
+                                                               _stream()))
+        return ctx
     _lib.check(_lib.load().rnamsm_col_attn_fused(_dev(q, "q"), _dev(k, "k"), _dev(v, "v"), ld, _dev(ctx, "ctx"),
                                                  _rowmajor(ctx, "ctx"), R, C, H, HEAD_DIM,
                                                  None if pad_mask is None else _dev(pad_mask, "pad_mask", torch.uint8),

@@ -324,6 +324,59 @@ def test_col_attention_for_shallow_alignments_one_wave_per_problem(dev, R, C, H)
         assert rel_l2(small, big) < 2e-6
 
 
+@pytest.mark.parametrize("R,C,H", [(1, 7, 3), (8, 64, 12), (16, 130, 4), (17, 33, 2), (100, 30, 3), (129, 5, 1), (300, 4, 2)])
+def test_col_attention_on_prescaled_q_without_a_running_maximum(dev, R, C, H):
+    """rnamsm_col_attn_fused_prescaled (round 4; what the exact-path forward calls without padding): q carries dh^-1/2 * log2(e), the
+    first pass exponentiates the raw scores (no running maximum, no rescale) and a block whose row sums leave [2^-100, 2^100]
+    redoes its column with the online softmax.  Against fp64 on the prescaled operands at the bar of the natural-domain kernel,
+    against that kernel on q / log2(e) (rounding apart), with the TRACKED loop forced (knob "col_fast" = 0), restricted to the
+    first query rows (bit-identical to the full launch), and with scores far outside exp2's range in both directions: a query
+    whose best key sits ~200 log2 units up (overflow without a reference) and one whose every score is below -130 (all
+    exponentials underflow: a zero row sum) -- finite and right through the fallback."""
+    from rnamsm import ops
+    LOG2E = 1.4426950408889634
+    qkv, D = _qkv(R, C, H, f"cp{R}_{C}")
+    g = qkv.to(dev)
+    g[:, :D] *= 0.125 * LOG2E
+
+    def truth(t):
+        q = t[:, :D].double().view(R, C, H, 64) / LOG2E
+        k = t[:, D:2 * D].double().view(R, C, H, 64)
+        v = t[:, 2 * D:].double().view(R, C, H, 64)
+        return torch.einsum("hcij,jchd->ichd", torch.softmax(torch.einsum("ichd,jchd->hcij", q, k), -1), v).reshape(R * C, D)
+    want = truth(g.cpu())
+    fast = ops.col_attn(g[:, :D], g[:, D:2 * D], g[:, 2 * D:], R, C, H, prescaled=True)
+    assert rel_l2(fast.cpu(), want) < 5e-6
+    assert np.abs(fast.cpu().numpy() - want.numpy()).max() < 2e-5 * max(1.0, float(want.abs().max()))
+    assert torch.equal(fast, ops.col_attn(g[:, :D], g[:, D:2 * D], g[:, 2 * D:], R, C, H, prescaled=True))
+    try:
+        ops.set_param("col_fast", 0)
+        tracked = ops.col_attn(g[:, :D], g[:, D:2 * D], g[:, 2 * D:], R, C, H, prescaled=True)
+    finally:
+        ops.set_param("col_fast", 1)
+    assert rel_l2(tracked.cpu(), want) < 5e-6 and rel_l2(fast.cpu(), tracked.cpu()) < 2e-6
+    nat = g.clone()
+    nat[:, :D] /= LOG2E
+    assert rel_l2(fast.cpu(), ops.col_attn(nat[:, :D], nat[:, D:2 * D], nat[:, 2 * D:], R, C, H).cpu()) < 2e-6
+    qr = max(1, R // 3)
+    part = torch.full((R * C, D), float("nan"), device=dev)
+    ops.col_attn(g[:, :D], g[:, D:2 * D], g[:, 2 * D:], R, C, H, out=part, prescaled=True, q_rows=qr)
+    assert torch.equal(part[:qr * C], fast[:qr * C]) and bool(torch.isnan(part[qr * C:]).all())
+    if R >= 8:
+        wild = g.clone()
+        qv, kv = wild[:, :D].view(R, C, H, 64), wild[:, D:2 * D].view(R, C, H, 64)
+        qv[5, C // 2, H - 1] = 26.0 * kv[7, C // 2, H - 1] / kv[7, C // 2, H - 1].norm()       # q . k_7 = 26 |k_7| ~ 208 log2 units
+        u = torch.zeros(64, device=dev)
+        u[0] = 1.0
+        kv[:, 0, 0] += 8.0 * u                                                                     # the keys of (column 0, head 0) share a component ...
+        qv[3, 0, 0] = -30.0 * u                                                                    # ... against which this query scores ~ -240 on every key
+        sc = torch.einsum("ichd,jchd->hcij", qv.double(), kv.double())
+        assert float(sc.max()) > 128 and float(sc[0, 0, 3].max()) < -130                  # beyond exp2 in fp32 on both sides
+        got = ops.col_attn(wild[:, :D], wild[:, D:2 * D], wild[:, 2 * D:], R, C, H, prescaled=True)
+        assert bool(torch.isfinite(got).all())
+        assert rel_l2(got.cpu(), truth(wild.cpu())) < 5e-6
+
+
 def test_col_attention_online_softmax_rescale_is_exercised(dev):
     """Forces the running-max rescale branch: one late key dominates every query (spike placed in the last
     64-key chunk), and a second case puts the dominant key first so later tiles never rescale."""
