@@ -518,6 +518,8 @@ void rnamsm_timing_reset(void);
  *                 rnamsm_forward_batch (default 0 = 10752 for plain bf16, 8960 for the hi/lo modes: below ~9-10 k tokens the
  *                 256x256 kernels leave most CUs without a tile; 2048 tokens x1.33 / x1.59, 8192 x1.11 / x1.10).  The hi/lo modes'
  *                 kernels sum every element in the same order (bit-identical); plain bf16 changes MFMA shape (fp32 rounding).
+ *   "col_fast"    rnamsm_col_attn_fused_prescaled: 1 (default) = first pass without a running maximum, the online softmax as the
+ *                 fallback of a block whose row sums leave [2^-100, 2^100]; 0 = the online softmax only (A/B; results agree to rounding).
  *   "row16_q16"   plain bf16 rnamsm_row_logits16 at C >= 384 with C % 8 == 0: 1 (default) = row_logits16q_kernel (256x256 tiles on the
  *                 16x16x32 MFMA, staged by operand, persistent blocks, register-direct epilogue), 0 = the 128x128 kernel.  Changes
  *                 the row split (rnamsm_row_logits16_nsplit) and agrees to fp32 rounding.
