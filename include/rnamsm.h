@@ -326,6 +326,11 @@ size_t rnamsm_contact_head_workspace_bytes(int C, int nch);
 int rnamsm_contact_head(const float* row_attn, const float* weight, const float* bias, float* contacts,
                         void* workspace, size_t workspace_bytes, int C, int nch, void* stream);
 
+/* a7 -- the residual add of NormalizedResidualBlock around a layer that is NOT one of this library's (modules.py:396,
+ * `x = residual + x`; around the library's own layers the add is fused into the layer's last GEMM): out[i] = a[i] + b[i], fp32,
+ * out may alias a or b. */
+int rnamsm_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+
 /* a10 -- head-averaged attention weights of the generic MultiheadAttention (msm/multihead_attention.py:389-397,
  * need_weights=True without need_head_weights): out[i] = mean_h probs[h, i], probs [H, n] fp32, out [n]. */
 int rnamsm_head_mean(const float* probs, float* out, int H, int64_t n, void* stream);

@@ -474,6 +474,21 @@ extern "C" int rnamsm_pad_mask(const int64_t* tokens, uint8_t* mask, int64_t n, 
     return RNAMSM_OK;
 }
 
+namespace rnamsm {
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                  int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+}  // namespace rnamsm
+
+extern "C" int rnamsm_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    RNAMSM_CHECK_ARG(a && b && out && n > 0, "add: bad arguments");
+    hipLaunchKernelGGL(rnamsm::add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out, n);
+    RNAMSM_CHECK_LAUNCH("add");
+    return RNAMSM_OK;
+}
+
 extern "C" int rnamsm_head_mean(const float* probs, float* out, int H, int64_t n, void* stream) {
     RNAMSM_CHECK_ARG(probs && out && H > 0 && n > 0, "head_mean: bad arguments");
     hipLaunchKernelGGL(head_mean_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),

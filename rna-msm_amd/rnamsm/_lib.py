@@ -77,6 +77,7 @@ _SIGNATURES = {
     "rnamsm_col_attn16_prescaled": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                             c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rnamsm_zero_plane_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "rnamsm_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rnamsm_head_mean": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "rnamsm_pad_mask": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rnamsm_pack_outputs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -264,13 +264,13 @@ class FeedForwardNetwork(nn.Module):
 
 
 class NormalizedResidualBlock(nn.Module):
-    """x + layer(LayerNorm(x)); mirrors modules.py:369-401.  The residual add is fused into the wrapped
-    layer's last GEMM epilogue, so `layer` must be one of the modules above."""
+    """x + layer(LayerNorm(x)); mirrors modules.py:369-401.  Around this package's RowSelfAttention / ColumnSelfAttention /
+    FeedForwardNetwork the residual add is fused into the layer's last GEMM epilogue; ANY other nn.Module is wrapped as the
+    reference wraps it (modules.py:385-401): LayerNorm (rnamsm_layernorm), the layer called on the normalised tensor with the
+    caller's arguments, a tuple result split into (x, *rest), the residual added by rnamsm_add."""
 
     def __init__(self, layer: nn.Module, embedding_dim: int, dropout: float = 0.1):
         super().__init__()
-        if not isinstance(layer, (RowSelfAttention, ColumnSelfAttention, FeedForwardNetwork)):
-            raise TypeError("NormalizedResidualBlock wraps rnamsm RowSelfAttention / ColumnSelfAttention / FeedForwardNetwork")
         self.embedding_dim = embedding_dim
         self.layer = layer
         self.dropout = dropout
@@ -279,8 +279,15 @@ class NormalizedResidualBlock(nn.Module):
     def forward(self, x, *args, **kwargs):
         _check_inference(self, self.dropout)
         xn = ops.layernorm(x, self.layer_norm.weight.detach(), self.layer_norm.bias.detach(), self.layer_norm.eps)
-        outputs = self.layer(xn, *args, _residual=x, **kwargs)
-        return outputs
+        if isinstance(self.layer, (RowSelfAttention, ColumnSelfAttention, FeedForwardNetwork)):
+            return self.layer(xn, *args, _residual=x, **kwargs)
+        outputs = self.layer(xn.view(x.shape), *args, **kwargs)                    # a foreign layer: modules.py:388-401 as written
+        if isinstance(outputs, tuple):
+            y, *out = outputs
+        else:
+            y, out = outputs, None
+        y = ops.add(x, y.to(torch.float32))
+        return (y,) + tuple(out) if out is not None else y
 
 
 class AxialTransformerLayer(nn.Module):
@@ -333,8 +340,8 @@ class MultiheadAttention(_AxialAttentionBase):
       * need_weights=False: the fused column-attention kernel with R := T and C := B (every batch element attends along
         T; the probabilities never exist), weights = None;
       * key_padding_mask [B,T] (:360-369): masked keys get probability 0.  The reference fills -inf, the kernels -10000
-        (exp underflows to 0 in fp32 either way); a query whose keys are ALL masked is NaN in the reference and a
-        uniform distribution here.
+        (exp underflows to 0 in fp32 either way); a batch element whose keys are ALL masked is NaN in the reference
+        (softmax over -inf only) -- outputs and weights of such an element are set to NaN here too (_reference_nan).
     Raises for what is outside eval-mode self-attention: attn_mask, incremental state, static_kv, before_softmax,
     bias_kv / zero_attn, cross-attention, dropout in training."""
 
@@ -348,8 +355,28 @@ class MultiheadAttention(_AxialAttentionBase):
         self.embed_dim = embed_dim
         self.self_attention = True
 
+    @staticmethod
+    def _reference_nan(out, weights, kpm, need_head_weights):
+        """msm/multihead_attention.py:360-371: masked_fill(-inf) then softmax -- a batch element with EVERY key masked comes out
+        NaN (attention output and weights).  The kernels give such an element uniform weights; one select per tensor restores
+        the reference's values (only when a mask was passed; no host sync)."""
+        dead = kpm.bool().all(dim=1)                                                # [B]
+        nan = torch.full((), float("nan"), device=out.device, dtype=out.dtype)
+        out = torch.where(dead[None, :, None], nan, out)
+        if weights is not None:
+            weights = torch.where(dead[None, :, None, None] if need_head_weights else dead[:, None, None], nan, weights)
+        return out, weights
+
     def forward(self, query, key=None, value=None, key_padding_mask=None, incremental_state=None, need_weights=True,
                 static_kv=False, attn_mask=None, before_softmax=False, need_head_weights=False):
+        out, weights = self._forward(query, key, value, key_padding_mask, incremental_state, need_weights, static_kv, attn_mask,
+                                     before_softmax, need_head_weights)
+        if key_padding_mask is not None:
+            out, weights = self._reference_nan(out, weights, key_padding_mask.to(out.device), need_head_weights and weights is not None)
+        return out, weights
+
+    def _forward(self, query, key=None, value=None, key_padding_mask=None, incremental_state=None, need_weights=True,
+                 static_kv=False, attn_mask=None, before_softmax=False, need_head_weights=False):
         if attn_mask is not None or incremental_state is not None or static_kv:
             raise NotImplementedError("attn_mask / incremental decoding are not implemented")
         if before_softmax:

@@ -512,6 +512,16 @@ def pack_outputs(x_final: torch.Tensor, probs_all: torch.Tensor, C: int) -> Tupl
 
 
 @_on_operand_device
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a + b, fp32, same shape (the residual add of NormalizedResidualBlock around a foreign layer, modules.py:396)."""
+    assert a.shape == b.shape
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a, dtype=torch.float32)
+    _lib.check(_lib.load().rnamsm_add(_dev(a, "a"), _dev(b, "b"), _dev(out, "out"), out.numel(), _stream()))
+    return out
+
+
+@_on_operand_device
 def head_mean(probs: torch.Tensor) -> torch.Tensor:
     """probs [H, ...] fp32 -> mean over the head axis [...] (msm/multihead_attention.py:394-397)."""
     probs = probs.contiguous()
