@@ -803,6 +803,15 @@ def test_token_packed_batch_equals_every_alignment_alone(model):
     for t, got in zip(msas, m.forward_packed(msas, fold_layernorm=False)):
         one = m.checked_forward_one(t, need_repr=False)
         assert rel_l2(got["emb"].cpu().numpy(), one["emb"].cpu().numpy()) < 1e-5
+    # more members than one descriptor launch carries (32 per launch: 32 + 32 + 6), every fourth checked against its lone forward
+    many_shapes = [(1 + (i * 7) % 19, 5 + (i * 11) % 40) for i in range(70)]
+    many = [torch.from_numpy(synthetic.make_tokens(r, c, 900 + i)).to("cuda:0") for i, (r, c) in enumerate(many_shapes)]
+    outs_many = m.forward_packed(many)
+    assert int(outs_many[0]["err"].item()) == 0
+    for i in range(0, 70, 4):
+        one = m.checked_forward_one(many[i], need_repr=False)
+        assert rel_l2(outs_many[i]["emb"].cpu().numpy(), one["emb"].cpu().numpy()) < 1e-5, many_shapes[i]
+        assert np.abs(outs_many[i]["atp"].cpu().numpy() - one["atp"].cpu().numpy()).max() < 1e-4, many_shapes[i]
     # a single alignment is a valid packed batch
     solo = m.forward_packed(msas[4:5])[0]
     assert rel_l2(solo["emb"].cpu().numpy(), m.checked_forward_one(msas[4], need_repr=False)["emb"].cpu().numpy()) < 1e-5
