@@ -986,6 +986,14 @@ def test_msm_variant_of_the_model_shell_matches_reference_fixture(name):
     assert "col_attentions" not in fused
     assert rel_l2(fused["representations"][L].cpu().numpy(), g["repr_last"]) < 1e-5
     assert np.abs(fused["row_attentions"].cpu().numpy() - g["row_attentions"]).max() < 2e-5
+    # the token-packed batch reads the per-channel rows too (K0 with the descriptor table): the fixture's alignments plus a
+    # shallower, narrower one, each against the reference's representation / its own lone forward
+    extra = toks[0, : max(1, R - 2), : C - 2].contiguous()
+    packed = m.forward_packed([toks[b] for b in range(B)] + [extra], need_repr=True)
+    for b in range(B):
+        assert rel_l2(packed[b]["repr"].cpu().numpy(), g["repr_last"][b]) < 1e-5
+        assert np.abs(packed[b]["row_attn"].cpu().numpy() - g["row_attentions"][b]).max() < 2e-5
+    assert rel_l2(packed[B]["repr"].cpu().numpy(), m.forward_one(extra)["repr"].cpu().numpy()) < 1e-5
     # too large a request is refused, not attempted
     m.return_col_attentions = True
     m.COL_ATTENTIONS_MAX_BYTES = 1024
