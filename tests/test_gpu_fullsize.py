@@ -166,3 +166,34 @@ def test_configs0_through_the_reader_and_device_subsampling(model, full_2drb1_a2
     b = hip_outputs(model, want, "f32")
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert a[0].shape == (35, 768) and a[1].shape == (120, 35, 35)                  # shapes of the shipped 2DRB_1_*.npy
+
+
+@pytest.mark.parametrize("layers,R,L", [(1, 128, 255), (2, 128, 255), (2, 40, 99), (3, 256, 511)])
+def test_bf16_mode_at_shallow_depth_against_the_references_bf16_drift(layers, R, L):
+    """at ten layers with these weights the bf16 yardstick itself is emb rel-L2 0.25-0.46 and atp max-abs ~ 1 -- a
+    bar that catches a broken kernel, not a degraded one.  At one to three layers the reference's own `.bfloat16()` drift is
+    1e-2-scale (asserted: the yardstick is far from saturation), and the HIP bf16 mode -- the whole plane data flow, the
+    16x16x32 GEMM kernels from 10 k tokens, the rebuilt attention kernels incl. the prescaled-q column kernel -- is held to
+    1.5x of it on every measure.  Truth: the oracle in fp64 on the device, same weights."""
+    from oracle import msm_oracle as O
+    from rnamsm.model import MSATransformer
+    state = synthetic.make_state_dict(seed=0, num_layers=layers)
+    m = MSATransformer(num_layers=layers)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    m = m.eval().to(DEV)
+    toks = synthetic.make_tokens(R, L, 5)
+
+    def oracle(dtype):
+        with torch.no_grad():
+            res = O.forward(torch.from_numpy(toks).to(DEV), O.to_torch_params(state, dtype, DEV), num_layers=layers, ffn_token_chunk=32768)
+            emb, atp = O.pack_outputs(res)
+        return emb.double(), atp.double()
+    t_emb, t_atp = oracle(torch.float64)
+    e_ref = truth.errors(*oracle(torch.bfloat16), t_emb, t_atp)
+    e_hip = truth.errors(*hip_outputs(m, toks, "bf16"), t_emb, t_atp)
+    print(json.dumps({"layers": layers, "shape": [R, L + 1], "oracle_bf16": e_ref, "hip_bf16": e_hip}))
+    assert 1e-4 < e_ref["emb_rel_l2"] < 0.1 and e_ref["atp_rel_l2"] < 0.2, e_ref              # a yardstick with room above AND below
+    for k in ("emb_rel_l2", "atp_rel_l2", "atp_mean_abs", "atp_max_abs"):
+        assert e_hip[k] <= 1.5 * e_ref[k], (k, e_hip, e_ref)
+    e_f16 = truth.errors(*hip_outputs(m, toks, "f16x3"), t_emb, t_atp)                       # and the fp32-grade mode at fp32 scale
+    assert e_f16["emb_rel_l2"] < 2e-5 and e_f16["atp_max_abs"] < 2e-4, e_f16
