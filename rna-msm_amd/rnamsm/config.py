@@ -35,8 +35,12 @@ class DataConfig:                       # RNA_MSM_Inference.py:20-32
     # its GEMM kernels by the BATCH's token count, so an alignment's files would depend (at the mode's rounding level, ~1e-2
     # in bf16) on what else is in the id list; one by one every alignment's output is a function of that alignment alone
     batch_small_msas_16bit: bool = False
-    # exact mode (round 4): the groups of small alignments are TOKEN-PACKED -- back to back on the token axis, nothing padded
-    # (rnamsm_forward_packed) -- instead of padded into a frame; false = the framed ragged batch of round 3 (A/B, tools/cli_throughput.py)
+    # round 4: the groups of small alignments are TOKEN-PACKED -- back to back on the token axis, nothing padded
+    # (rnamsm_forward_packed, exact fp32 arithmetic) -- instead of padded into a frame; false = the framed ragged batch of round 3
+    # (A/B, tools/cli_throughput.py).  In a 16-bit mode (model.gemm_dtype != f32) the alignments of <= 1024 (bf16) / 2048 (hi/lo modes) tokens take this EXACT
+    # packed path as well: alone, such an alignment costs 2.6-3.4 ms of launches in any arithmetic, so the exact batch is faster and
+    # its files are the exact path's (every alignment's output then depends on the rest of the list at fp32 rounding only, ~1e-6);
+    # pack_small_msas=false or batch_small_msas=false keeps every alignment in the model's own arithmetic, one by one
     pack_small_msas: bool = True
 
 

@@ -225,6 +225,11 @@ def plan_groups(shapes: List[tuple]) -> List[List[int]]:
 # tokens / 256 members; and alignments of up to PACKED_SMALL_TOKENS wait for company (16-64 rows x 60-200 columns, ~5 k tokens
 # each: x1.4-1.5 packed against alone; framed they lost).
 PACKED_TOKENS, PACKED_MEMBERS, PACKED_SMALL_TOKENS = 65536, 256, 8192
+# ... and in a 16-bit arithmetic mode, where a lone forward of a mid-size alignment is cheaper than its share of an exact batch
+# (packed exact ~650 k residues/s; a lone forward costs 2.6 ms of launches in bf16, 3.4 ms in the hi/lo modes, up to a few thousand
+# tokens).  Measured (MODE=bf16 | f16x3 tools/cli_throughput.py, 64 alignments): bf16 tiny x2.1, small x1.0-1.2, mid x0.86-0.91 at a
+# limit of 2048-4096 -- hence 1024 there; f16x3 tiny x2.8, small x1.55, mid x1.00 at 2048.
+PACKED_SMALL_TOKENS_16BIT = {"bf16": 1024, "bf16x3": 2048, "f16x3": 2048}
 
 
 def joins_packed(group_shapes: List[tuple], shape: tuple) -> bool:
@@ -346,11 +351,17 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
             # rank's items in list order, so there only CONSECUTIVE small alignments share a group.
             # (16-bit modes: only with data.batch_small_msas_16bit -- a batch's token count selects the GEMM kernels there, so
             # an alignment's files would depend on its neighbours in the list at the mode's rounding level)
-            batching = bool(getattr(cfg.data, "batch_small_msas", True)) and (
-                model.gemm_dtype == "f32" or (bool(getattr(cfg.data, "batch_small_msas_16bit", False)) and ops.get_param("attn16") != 0))
+            exact = model.gemm_dtype == "f32"
+            framed16 = bool(getattr(cfg.data, "batch_small_msas_16bit", False)) and ops.get_param("attn16") != 0
+            # groups are token-packed (no frame, no padding -- rnamsm_forward_packed, EXACT fp32 arithmetic), so any small alignments
+            # share one.  In a 16-bit mode the small alignments (<= PACKED_SMALL_TOKENS_16BIT[mode] tokens) take that exact path too: a lone
+            # 16-bit forward of so few tokens costs its 2.6-3.4 ms of launches whatever the arithmetic, the packed exact batch is
+            # faster AND closer to the reference -- unless 16-bit framed batches were asked for (data.batch_small_msas_16bit)
+            packing = (bool(getattr(cfg.data, "batch_small_msas", True)) and bool(getattr(cfg.data, "pack_small_msas", True))
+                       and (exact or not framed16))
+            batching = bool(getattr(cfg.data, "batch_small_msas", True)) and (exact or framed16 or packing)
             pooled = batching and gatherer is None
-            # exact mode: groups are token-packed (no frame, no padding -- rnamsm_forward_packed), so any small alignments share one
-            packing = batching and model.gemm_dtype == "f32" and bool(getattr(cfg.data, "pack_small_msas", True))
+            small_limit = (PACKED_SMALL_TOKENS if exact else PACKED_SMALL_TOKENS_16BIT.get(model.gemm_dtype, 1024)) if packing else SMALL_MSA_TOKENS
             group: List = []                                          # (idx, tokens on the device)
             pool: List = []                                           # (idx, tokens on the host)
 
@@ -381,7 +392,7 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                     tokens = pending.result() if reader else read(idx)
                     if reader and n + 1 < len(mine):
                         pending = reader.submit(read, mine[n + 1])       # parsed while the GPU runs this MSA
-                    if (batching and tokens.size <= (PACKED_SMALL_TOKENS if packing else SMALL_MSA_TOKENS) and 2 * tokens.shape[1] ** 2 <= FRAME_MAP_ELEMS
+                    if (batching and tokens.size <= small_limit and 2 * tokens.shape[1] ** 2 <= FRAME_MAP_ELEMS
                             and not (tokens == alphabet.padding_idx).any()):
                         if pooled:
                             pool.append((idx, tokens))

@@ -385,7 +385,7 @@ class MSATransformer(nn.Module):
         return out
 
     def forward_packed(self, msas: List[torch.Tensor], fold_layernorm: Optional[bool] = None,
-                       need_repr: bool = False) -> List[Dict[str, torch.Tensor]]:
+                       need_repr: bool = False, _warn_16bit: bool = True) -> List[Dict[str, torch.Tensor]]:
         """Alignments of DIFFERENT shapes ([R_b, C_b] int64 tokens, column 0 = <cls>, no <pad>) as ONE token-packed batch
         (rnamsm_forward_packed, exact fp32 path): the alignments lie back to back on the token axis, nothing is padded.
         Returns per MSA what forward_one(need_repr=False) returns -- emb [C_b-1, D], atp [NL*H, C_b-1, C_b-1], row_attn
@@ -396,6 +396,11 @@ class MSATransformer(nn.Module):
             raise NotImplementedError("inference only (model.eval())")
         if not msas or not all(t.is_cuda and t.ndim == 2 for t in msas):
             raise _lib.RnamsmError("forward_packed: a non-empty list of [R, C] token tensors on the HIP device")
+        if self.gemm_dtype != "f32" and _warn_16bit and not MSATransformer._warned_packed_exact:
+            import warnings
+            MSATransformer._warned_packed_exact = True
+            warnings.warn(f"forward_packed runs the exact fp32 path whatever gemm_dtype says (the model is in {self.gemm_dtype!r}); "
+                          "batches in a 16-bit mode go through forward_ragged(packed=False) / forward_batch")
         dev = msas[0].device
         fold = self.fold_layernorm if fold_layernorm is None else fold_layernorm
         with torch.cuda.device(dev):
@@ -439,26 +444,28 @@ class MSATransformer(nn.Module):
         return res
 
     ERR_PAD_IN_PACKED = 8
+    _warned_packed_exact = False
 
     def forward_ragged(self, msas: List[torch.Tensor], packed: Optional[bool] = None) -> List[Dict[str, torch.Tensor]]:
-        """Alignments of DIFFERENT shapes ([R_b, C_b] int64 tokens, column 0 = <cls>) in one launch set.  Exact mode (and
-        packed is not False): the token-packed batch of forward_packed -- no padding; its error word is read (one sync): index
-        errors raise, a failed folded-LayerNorm precondition reruns without the fold, a <pad> inside the batch reruns it framed.
-        Otherwise (16-bit modes, packed=False, <pad> present): padded into one [max R, max C] frame and run as a ragged batch
+        """Alignments of DIFFERENT shapes ([R_b, C_b] int64 tokens, column 0 = <cls>) in one launch set.  packed (None = in
+        exact mode): the token-packed batch of forward_packed -- no padding, EXACT fp32 arithmetic whatever the model's mode; its
+        error word is read (one sync): index errors raise, a failed folded-LayerNorm precondition reruns without the fold, a
+        <pad> inside the batch reruns it framed.
+        Otherwise (16-bit modes by default, packed=False, <pad> present): padded into one [max R, max C] frame and run as a ragged batch
         (rnamsm_forward_batch with true_rows; padding is computed too).  Returns per MSA what forward_one(need_repr=False)
         returns -- emb [C_b-1, D], atp [NL*H, C_b-1, C_b-1], row_attn [NL, H, C_b, C_b] -- equal to the MSA's own forward to
         fp32 rounding."""
         if packed is None:
             packed = self.gemm_dtype == "f32"
-        if packed and self.gemm_dtype == "f32":
+        if packed:          # (asked for explicitly in a 16-bit mode: the EXACT packed path -- what the CLI does with small alignments)
             import warnings
-            res = self.forward_packed(msas)
+            res = self.forward_packed(msas, _warn_16bit=False)
             err = int(res[0]["err"].item())
             if err & self.ERR_INDEX:
                 raise IndexError("batch: token or position index out of range")
             if (err & self.ERR_FOLD) and not (err & self.ERR_PAD_IN_PACKED):
                 warnings.warn("batch: a token row's mean exceeds 32x its spread; LayerNorm is applied in its own launches for this batch")
-                res = self.forward_packed(msas, fold_layernorm=False)
+                res = self.forward_packed(msas, fold_layernorm=False, _warn_16bit=False)
                 err = int(res[0]["err"].item())
             if not (err & self.ERR_PAD_IN_PACKED):
                 return res

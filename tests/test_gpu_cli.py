@@ -139,11 +139,14 @@ def test_cli_gather_to_rank0_streams_rounds_and_writes_the_same_files(tmp_path):
         assert a[name] == b[name], name
 
 
-def test_cli_batches_small_alignments_by_default(tmp_path):
+@pytest.mark.parametrize("packing", [True, False])
+def test_cli_batches_small_alignments_by_default(tmp_path, packing):
     """data.batch_small_msas (default true; false = the reference's one-by-one loop): the small alignments of the id list
-    (different depths and lengths here) are pooled, grouped by shape, padded into one frame per group and run as ragged batches; a
-    large one in between runs alone, at once.  Same files, the returned ids in list order, values equal to the one-by-one run
-    to fp32 rounding."""
+    (different depths and lengths here) share launch sets -- packing (data.pack_small_msas, the default): one token-packed group,
+    nothing padded, the 4544-token alignment included; packing off: pooled, grouped by shape, padded into one frame per group, the
+    4544-token one alone in between.  Same files, the returned ids in list order, values equal to the one-by-one run to fp32
+    rounding.  (rnaD comes out bit-identical either way: alone when framed; packed, its depth factor 1/sqrt(64) is a power of
+    two and its GEMM tiles are chosen as for the lone forward.)"""
     from rnamsm.config import Config
     from rnamsm.inference import extract_feat
     from rnamsm.model import MSATransformer
@@ -167,6 +170,7 @@ def test_cli_batches_small_alignments_by_default(tmp_path):
         cfg = Config()
         cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = str(root), "results", "rna_id.txt"
         cfg.data.sample_method, cfg.data.max_seqs_per_msa, cfg.data.batch_small_msas = "first", 64, mode
+        cfg.data.pack_small_msas = packing
         assert extract_feat(cfg, model=model) == ids
         outs[mode] = {f.name: np.load(f) for f in sorted((root / "results").glob("*.npy"))}
     assert outs[True].keys() == outs[False].keys() and len(outs[True]) == 2 * len(ids)
@@ -178,3 +182,51 @@ def test_cli_batches_small_alignments_by_default(tmp_path):
         else:
             assert np.abs(got - want).max() < 2e-5, name
     assert np.array_equal(outs[True]["rnaD_emb.npy"], outs[False]["rnaD_emb.npy"])       # the large one ran alone: same bits
+
+
+def test_cli_in_a_16bit_mode_runs_its_small_alignments_on_the_exact_packed_path(tmp_path):
+    """model.gemm_dtype=bf16 through the CLI: alignments of <= 1024 tokens leave as ONE token-packed batch in EXACT fp32 arithmetic
+    (alone they would cost 2.6 ms of launches each in any arithmetic) -- their files equal the exact path's one-by-one files to
+    fp32 rounding, not bf16's; the larger ones run alone in bf16 (bit-identical to forward_one in that mode).
+    data.pack_small_msas=false keeps every alignment in the model's own arithmetic."""
+    from rnamsm.config import Config
+    from rnamsm.inference import extract_feat
+    from rnamsm.model import MSATransformer
+    state = synthetic.make_state_dict(seed=0)
+    model = MSATransformer(num_layers=10)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    records = open(os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2")).read().splitlines()
+    names, seqs = records[0::2], records[1::2]
+    shapes = {"rnaA": (3, 20), "rnaB": (9, 35), "rnaC": (40, 70), "rnaD": (5, 28), "rnaE": (12, 30)}     # rnaC: 2840 tokens > 1024
+    ids = sorted(shapes)
+
+    def run(tag, dtype, **flags):
+        root = tmp_path / tag
+        (root / "results").mkdir(parents=True)
+        for i in ids:
+            depth, length = shapes[i]
+            (root / "results" / f"{i}.a2m_msa2").write_text("".join(f"{names[r]}\n{(seqs[r] * 2)[:length]}\n" for r in range(depth)))
+        (root / "rna_id.txt").write_text("\n".join(ids) + "\n")
+        cfg = Config()
+        cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = str(root), "results", "rna_id.txt"
+        cfg.data.sample_method, cfg.data.max_seqs_per_msa = "first", 64
+        for k, v in flags.items():
+            setattr(cfg.data, k, v)
+        cfg.model.gemm_dtype = dtype                     # (the CLI's override: model.gemm_dtype=bf16)
+        try:
+            assert extract_feat(cfg, model=model) == ids
+        finally:
+            model.gemm_dtype = "f32"
+        return {f.name: np.load(f) for f in sorted((root / "results").glob("*.npy"))}
+    exact = run("exact_one_by_one", "f32", batch_small_msas=False)
+    bf16_alone = run("bf16_one_by_one", "bf16", batch_small_msas=False)
+    default = run("bf16_default", "bf16")
+    own = run("bf16_own_arithmetic", "bf16", pack_small_msas=False)
+    for i in ids:
+        e = f"{i}_emb.npy"
+        if i == "rnaC":
+            assert np.array_equal(default[e], bf16_alone[e])                       # above the limit: alone, in the model's mode
+        else:
+            assert rel_l2(default[e], exact[e]) < 1e-5, i                          # the exact path's values ...
+            assert rel_l2(bf16_alone[e], exact[e]) > 1e-3, i                       # ... which bf16 alone is far from
+        assert np.array_equal(own[e], bf16_alone[e]), i

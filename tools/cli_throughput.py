@@ -18,6 +18,9 @@ N, M, L = int(os.environ.get("N", 12)), int(os.environ.get("M", 256)), int(os.en
 state = synthetic.make_state_dict(seed=0)
 model = MSATransformer(num_layers=10)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+MODE = os.environ.get("MODE", "f32")                      # MODE=bf16 | f16x3: the CLI in a 16-bit arithmetic mode (model.gemm_dtype=...)
+if os.environ.get("PACKED_SMALL_16"):
+    inference.PACKED_SMALL_TOKENS_16BIT = {k: int(os.environ["PACKED_SMALL_16"]) for k in inference.PACKED_SMALL_TOKENS_16BIT}
 rng = np.random.RandomState(0)
 letters = np.array(list("ACGU-"))
 for mode in (False, True, False, True):
@@ -31,6 +34,7 @@ for mode in (False, True, False, True):
                 f.write(f">s{r}\n{''.join(rows[r])}\n")
     open(os.path.join(root, "rna_id.txt"), "w").write("\n".join(ids) + "\n")
     cfg = Config()
+    cfg.model.gemm_dtype = MODE
     cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = root, "results", "rna_id.txt"
     cfg.data.sample_method, cfg.data.max_seqs_per_msa = "first", M
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -64,6 +68,7 @@ for label, (dlo, dhi), (llo, lhi) in (("tiny", (2, 13), (40, 81)), ("small", (4,
                         f.write(f">s{r}\n{''.join(rows[r])}\n")
             open(os.path.join(root, "rna_id.txt"), "w").write("\n".join(ids) + "\n")
             cfg = Config()
+            cfg.model.gemm_dtype = MODE
             cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = root, "results", "rna_id.txt"
             cfg.data.sample_method, cfg.data.max_seqs_per_msa, cfg.data.batch_small_msas = "first", 64, bool(batching)
             cfg.data.pack_small_msas = batching is True
