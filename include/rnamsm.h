@@ -502,7 +502,9 @@ void rnamsm_timing_reset(void);
  *                 16x16x32 kernel and the epilogue-hiding "gemm16_pp" kernel were removed from the library in round 4; their
  *                 measurements are in EXPERIMENTS.md, the last one's source under tools/probes/.)
  *   "gemm_group"  GEMM block order (fp32 kernel and the 256x256 16-bit kernel): row panels per XCD group (0 = chosen
- *                 from the shape, default; 1 = whole panels).  Changes HBM-side traffic and speed, never results.
+ *                 from the shape, default: 8 for N > 1024, else 1 -- and the fp32 kernel deals a GEMM of <= 512 tiles flat,
+ *                 tile = block id; 1 = whole panels).  An XCD's panels beyond its full groups form one smaller group: no padding
+ *                 groups (round 4).  Changes HBM-side traffic and speed, never results.
  *   "gemm_tile"   fp32 GEMM block tile: 0 (default) = 128x128, or 128x64 where that evens out the last round of blocks
  *                 on a small problem; 1 = always 128x128; 2 = always 128x64.  Results are bit-identical under either
  *                 tile: each output element sums its K products in the same order.
@@ -523,6 +525,8 @@ void rnamsm_timing_reset(void);
  *                 rnamsm_forward_batch (default 0 = 10752 for plain bf16, 8960 for the hi/lo modes: below ~9-10 k tokens the
  *                 256x256 kernels leave most CUs without a tile; 2048 tokens x1.33 / x1.59, 8192 x1.11 / x1.10).  The hi/lo modes'
  *                 kernels sum every element in the same order (bit-identical); plain bf16 changes MFMA shape (fp32 rounding).
+ *   "gemm_splitk_short"  rnamsm_forward*, the K = 768 GEMMs of a lone small alignment (<= 192 tiles): 0 (default) = off, 2 / 4 = that
+ *                 many K ranges with the epilogue applied by the reduction pass (A/B: no gain once the block order was fixed).
  *   "col_fast"    rnamsm_col_attn_fused_prescaled: 1 (default) = first pass without a running maximum, the online softmax as the
  *                 fallback of a block whose row sums leave [2^-100, 2^100]; 0 = the online softmax only (A/B; results agree to rounding).
  *   "row16_q16"   plain bf16 rnamsm_row_logits16 at C >= 384 with C % 8 == 0: 1 (default) = row_logits16q_kernel (256x256 tiles on the

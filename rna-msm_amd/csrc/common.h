@@ -77,6 +77,7 @@ struct Tuning {
     int gemm16_big_rows_fwd = 0;   // ... inside rnamsm_forward / rnamsm_forward_batch: 0 = by mode (10752 plain bf16, 8960 hi/lo), > 0 = that many
     int gemm_group = 0;            // fp32 GEMM: row panels per XCD group of the block order (xcd_panel_map_grouped); 0 = by shape
     int gemm_tile = 0;             // fp32 GEMM block tile: 0 = by shape, 1 = always 128x128, 2 = always 128x64
+    int gemm_splitk_short = 0;     // rnamsm_forward*, the K = 768 GEMMs of a lone small alignment (<= 192 tiles): K ranges (0 = off: the default -- measured no gain once the block order was fixed; 2, 4), gemm_f32_splitk_factor
     int gemm_splitk = 1;           // rnamsm_forward, fc2 below ~1.4 k tokens: 1 = four K ranges + an ordered reduction (gemm_f32_splitk_factor), 0 = never, 2 / 4 / 8 = forced (A/B)
     int row_vt = 1;                // fp32 row_apply: 1 = V tile transposed while staged (b128 fragments), 0 = [k][n] tile
     int col_small = 1;             // fp32 col_attn at R <= 16: 1 = one wave per (column, head), no LDS (col_attn_small_kernel), 0 = the 128-query blocks
@@ -272,6 +273,35 @@ __device__ __forceinline__ bool xcd_panel_map_grouped(unsigned bid, unsigned num
     panel = (group * G + rem % G) * 8u + xcd;
     return panel < num_panels;
 }
+// The same order WITHOUT padding groups (gemm_f32_kernel, round 4): the panels an XCD has left after its full groups of G form one
+// last, smaller group.  Why it matters: hardware hands an XCD's consecutive workgroups to its CUs in turn, and a padded group
+// holds its real blocks at a stride of G -- 1 real panel in a group of 8 put all its column blocks on 4 of the XCD's 32 CUs (a
+// 82-token QKV GEMM: 18 tiles, 117 us instead of 26; the same at the ragged end of every mid-size GEMM: tools/gemm_f32_small_m.py).
+__device__ __forceinline__ bool xcd_panel_map_ragged(unsigned bid, unsigned num_panels, unsigned inner, unsigned G,
+                                                     unsigned& panel, unsigned& in_panel) {
+    if (G == 0u) {          // FLAT: fewer tiles than block slots -- tile = block id, so the tiles spread over all XCDs and CUs
+        panel = bid / inner;
+        in_panel = bid % inner;
+        return panel < num_panels;
+    }
+    const unsigned xcd = bid & 7u, idx = bid >> 3;
+    const unsigned local = (num_panels + 7u) / 8u, full = local / G, per_group = G * inner;
+    unsigned local_panel;
+    if (idx < full * per_group) {
+        const unsigned group = idx / per_group, rem = idx % per_group;
+        in_panel = rem / G;
+        local_panel = group * G + rem % G;
+    } else {
+        const unsigned tail = local - full * G, r = idx - full * per_group;      // tail >= 1: the grid ends at local * inner
+        in_panel = r / tail;
+        local_panel = full * G + r % tail;
+    }
+    panel = local_panel * 8u + xcd;
+    return panel < num_panels;
+}
+static inline unsigned xcd_panel_grid_ragged(unsigned num_panels, unsigned inner, unsigned G) {
+    return G == 0u ? num_panels * inner : ((num_panels + 7u) / 8u) * 8u * inner;
+}
 // Group size for PERSISTENT walks (block b takes virtual ids b, b + gridDim, ...): padding ids of a group that is not full
 // recur with the period of the walk, so whole blocks would own nothing but padding (16 row panels in groups of 8: a quarter of
 // the blocks did all the work -- 432 instead of 1136 TFLOP/s on a 4096^3 bf16 GEMM, tools/gemm16_square_knobs.py).  The
@@ -291,7 +321,19 @@ static inline unsigned xcd_panel_grid_grouped(unsigned num_panels, unsigned inne
 // partial tiles in `partials` ([ks][M][N] floats), then out = sum of the slabs in order + bias + residual.
 int gemm_f32_splitk_factor(int64_t M, int N, int K, bool by_shape_only = false);
 int gemm_f32_splitk(const float* A, int64_t lda, const float* W, const float* bias, const float* residual, int64_t ldr,
-                    float* Cout, int64_t ldc, int64_t M, int N, int K, int ks, float* partials, hipStream_t stream);
+                    float* Cout, int64_t ldc, int64_t M, int N, int K, int ks, float* partials, hipStream_t stream,
+                    int act = RNAMSM_ACT_NONE, float scale = 1.f, int scale_cols = 0, const uint8_t* zero_rows = nullptr);
+// floats the split-K partial slabs of a forward over T tokens may need (sized by shape alone, for every knob value)
+static inline size_t splitk_workspace_floats(int64_t T, int D, int F) {
+    const size_t long_k = (size_t)gemm_f32_splitk_factor(T, D, F, true);              // fc2: [ks][T][D]
+    size_t n = long_k > 1 ? long_k * (size_t)T * D : 0;
+    const int widest = 3 * D > F ? 3 * D : F;                                          // QKV / fc1: [ks][T][3D | F]
+    const size_t short_k = (size_t)gemm_f32_splitk_factor(T, widest, D, true);
+    if (short_k > 1 && short_k * (size_t)T * widest > n) n = short_k * (size_t)T * widest;
+    const size_t short_d = (size_t)gemm_f32_splitk_factor(T, D, D, true);              // out_proj: [ks][T][D]
+    if (short_d > 1 && short_d * (size_t)T * D > n) n = short_d * (size_t)T * D;
+    return n;
+}
 
 // the attention kernels of `batch` same-shape, unpadded MSAs in one launch each (gridDim.y = batch; MSA b's operands lie
 // b * stride elements further on): row_attn.hip, col_attn.hip; used by rnamsm_forward_batch

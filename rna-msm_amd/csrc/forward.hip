@@ -47,8 +47,7 @@ Layout make_layout(const rnamsm_model_dims& d, int R, int C, int nchunks) {
     l.stats = off; off += align256(T * 2 * sizeof(float));            // (mean, rstd) per token, combined from rowsum
     {   // split-K partial tiles of fc2 at small token counts (gemm_f32_splitk): [ks][T][D] -- sized by shape alone, for the most
         // ranges any knob value can ask for, so that a knob changed between the two calls cannot outgrow it
-        const size_t kt = (size_t)rnamsm::gemm_f32_splitk_factor((int64_t)T, (int)D, d.ffn_dim, true);
-        l.splitk = off; off += align256((kt > 1 ? kt * T : 0) * D * sizeof(float));
+        l.splitk = off; off += align256(rnamsm::splitk_workspace_floats((int64_t)T, (int)D, d.ffn_dim) * sizeof(float));
     }
     l.total = off;
     return l;
@@ -110,9 +109,15 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     auto linear = [&](int layer, int slot, const float* A, int64_t lda, const float* Wf, const float* bias,
                       const float* res, int64_t ldr, float* out, int64_t ldc, int N, int K, int act, float scale,
                       int scale_cols, const uint8_t* zero_rows) -> int {
-        if (dtype == RNAMSM_F32 || zero_rows)
+        if (dtype == RNAMSM_F32 || zero_rows) {
+            // a lone small alignment: split over idle CUs (gemm_f32_splitk_factor; the reduction pass carries the epilogue)
+            const int ks = rnamsm::gemm_f32_splitk_factor(T, N, K);
+            if (ks > 1)
+                return rnamsm::gemm_f32_splitk(A, lda, Wf, bias, res, ldr, out, ldc, T, N, K, ks, reinterpret_cast<float*>(ws + lay.splitk),
+                                               static_cast<hipStream_t>(stream), act, scale, scale_cols, zero_rows);
             return rnamsm_gemm_bias_act_res(A, lda, Wf, bias, res, ldr, out, ldc, T, N, K, act, scale, scale_cols,
                                             zero_rows, f32, stream);
+        }
         const uint16_t* const* P = weight_planes + (size_t)layer * RNAMSM_PLANES_PER_LAYER + 2 * slot;
         return rnamsm_gemm_bf16(A, lda, P[0], P[1], bias, res, ldr, out, ldc, T, N, K, act, scale, scale_cols,
                                 dtype == RNAMSM_BF16 ? 1 : 3, dtype == RNAMSM_F16X3 ? 1 : 0, nullptr, nullptr, nullptr,
@@ -210,6 +215,12 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             return rnamsm_gemm_lnfold(x, D, Fp[0] + (size_t)n_ofs * D, Fp[1] + n_ofs, Fp[2] + n_ofs, d.ln_eps, fold_sums ? stats : nullptr, err_flag, out, ldc, rows, N, D,
                                       act, scale, scale_cols, f32, stream);
         }
+        // a lone small alignment: the K = 768 GEMM split over idle CUs too (decided by the whole alignment's token count and the
+        // FULL width of the Linear, so that a part of it -- the outputs-only forward -- sums in the same order)
+        const int ks = rnamsm::gemm_f32_splitk_factor(T, fslot == 2 ? F : 3 * D, D);
+        if (ks > 1 && N % 128 == 0)
+            return rnamsm::gemm_f32_splitk(xn, D, Wf + (size_t)n_ofs * D, bias + n_ofs, nullptr, 0, out, ldc, rows, N, D, ks, splitk,
+                                           static_cast<hipStream_t>(stream), act, scale, scale_cols);
         return rnamsm_gemm_bias_act_res(xn, D, Wf + (size_t)n_ofs * D, bias + n_ofs, nullptr, 0, out, ldc, rows, N, D, act, scale,
                                         scale_cols, nullptr, f32, stream);
     };
@@ -393,8 +404,7 @@ BatchLayout make_batch_layout(const rnamsm_model_dims& d, int B, int R, int C) {
     }
     l.rowsum = off; off += align256(T * (D / 32) * 2 * sizeof(float));
     l.stats = off;  off += align256(T * 2 * sizeof(float));
-    const size_t kt = (size_t)rnamsm::gemm_f32_splitk_factor((int64_t)T, (int)D, d.ffn_dim, true);
-    l.splitk = off; off += align256((kt > 1 ? kt * T : 0) * D * sizeof(float));
+    l.splitk = off; off += align256(rnamsm::splitk_workspace_floats((int64_t)T, (int)D, d.ffn_dim) * sizeof(float));
     l.mask = off;   off += align256(T);              // padding mask uint8 [B, R, C]
     l.qscale = off; off += align256(T * sizeof(float));   // ragged batches: per-token q scale
     l.pplanes = off; off += align256((size_t)B * d.num_heads * C * (size_t)((C + 63) / 64 * 64) * 4);   // 16-bit modes: P hi + lo planes of every MSA
@@ -540,6 +550,8 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
             return rnamsm_gemm_lnfold(x, D, Fp[0], Fp[1], Fp[2], d.ln_eps, stats, err_flag, out, ldc, T, N, D, act, scale,
                                       scale_cols, f32, stream);
         }
+        const int ks = rnamsm::gemm_f32_splitk_factor(T, N, D);          // (few tokens: the K = 768 GEMM split over idle CUs)
+        if (ks > 1) return rnamsm::gemm_f32_splitk(xn, D, Wf, bias, nullptr, 0, out, ldc, T, N, D, ks, splitk, hs, act, scale, scale_cols);
         return rnamsm_gemm_bias_act_res(xn, D, Wf, bias, nullptr, 0, out, ldc, T, N, D, act, scale, scale_cols, nullptr, f32, stream);
     };
     auto res_linear = [&](const float* A, int64_t lda, const float* Wf, const float* bias, int K) -> int {
@@ -641,8 +653,7 @@ bool make_packed(const rnamsm_model_dims& d, int B, const int* shapes, std::vect
     l.part = off;   off += align256((size_t)part * 4);
     l.rowsum = off; off += align256(T * (D / 32) * 2 * sizeof(float));
     l.stats = off;  off += align256(T * 2 * sizeof(float));
-    const size_t kt = (size_t)rnamsm::gemm_f32_splitk_factor((int64_t)T, D, d.ffn_dim, true);
-    l.splitk = off; off += align256((kt > 1 ? kt * T : 0) * D * sizeof(float));
+    l.splitk = off; off += align256(rnamsm::splitk_workspace_floats((int64_t)T, D, d.ffn_dim) * sizeof(float));
     l.desc = off;   off += align256((size_t)B * sizeof(PackedMsa));
     l.total = off;
     return true;
@@ -708,6 +719,8 @@ extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float*
             return rnamsm_gemm_lnfold(x, D, Fp[0], Fp[1], Fp[2], d.ln_eps, stats, err_flag, out, ldc, T, N, D, act, scale,
                                       scale_cols, f32, stream);
         }
+        const int ks = rnamsm::gemm_f32_splitk_factor(T, N, D);          // (few tokens: the K = 768 GEMM split over idle CUs)
+        if (ks > 1) return rnamsm::gemm_f32_splitk(xn, D, Wf, bias, nullptr, 0, out, ldc, T, N, D, ks, splitk, hs, act, scale, scale_cols);
         return rnamsm_gemm_bias_act_res(xn, D, Wf, bias, nullptr, 0, out, ldc, T, N, D, act, scale, scale_cols, nullptr, f32, stream);
     };
     auto res_linear = [&](const float* A, int64_t lda, const float* Wf, const float* bias, int K) -> int {

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
         Cout += (int64_t)s_ * M * ldc;
     }
     unsigned mpanel, nblk;
-    if (!xcd_panel_map_grouped(bid, mp, nb, (unsigned)(group & 0xffff), mpanel, nblk)) return;
+    if (!xcd_panel_map_ragged(bid, mp, nb, (unsigned)(group & 0xffff), mpanel, nblk)) return;
     const int m0 = mpanel * BM, n0 = nblk * BN_;
 
     const WaveCoord w = wave_coord();
@@ -277,8 +277,13 @@ static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const flo
     // groups of 8 panels x 8 column blocks halve the fabric reads (PMC, cfg3: QKV 4.9 -> 2.9 GB, fc1 8.0 -> 3.6 GB per
     // launch; same speed, the kernel is MFMA-bound).  N = 768 (6 column blocks) is already balanced and stays ungrouped.
     const int nb = N / Cfg::BN_;
-    const int group = tuning().gemm_group > 0 ? tuning().gemm_group : (nb > 8 * (3 - NT) ? 8 : 1);
-    const unsigned grid = xcd_panel_grid_grouped((M + BM - 1) / BM, nb, (unsigned)group) * (ksplit > 1 ? ksplit : 1);
+    // (round 4) no padding groups: an XCD's last panels form a smaller group (xcd_panel_map_ragged); and a GEMM with fewer tiles
+    // than the chip has block slots is dealt FLAT (group 0: tile = block id), so that a lone small alignment's 18-24 column
+    // tiles run on as many CUs of all XCDs instead of on one XCD's
+    const int mp_ = (M + BM - 1) / BM;
+    const int group = tuning().gemm_group > 0 ? tuning().gemm_group
+                                              : ((int64_t)mp_ * nb * (ksplit > 1 ? ksplit : 1) <= 512 ? 0 : (nb > 8 * (3 - NT) ? 8 : 1));
+    const unsigned grid = xcd_panel_grid_ragged(mp_, nb, (unsigned)group) * (ksplit > 1 ? ksplit : 1);
     // algorithmic work: 2MNK flops; bytes = A + W + C once (+ residual read)
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), FOLD ? Cfg::LDS_FOLD : Cfg::LDS_BYTES, stream, A, lda, W, bias,
@@ -350,9 +355,24 @@ static int launch_gemm_res_stats(const float* A, int64_t lda, const float* W, co
 // CUs / 4 the copies share CUs and the gain is gone (2048 tokens -1 %, 4096 -1 %), and two ranges never paid -- so: four
 // ranges while tiles * 4 <= 256, else none.  Knob "gemm_splitk": 0 = never, 1 = that rule, 2 / 4 / 8 = that many ranges
 // whenever tiles * ks <= 512 (A/B).
+//
+// Round 4: the K = 768 GEMMs (QKV, out_proj, fc1) of a LONE small alignment.  At 520 tokens a forward is 61 GEMM launches of ~80 us
+// each -- one tile's serial K loop on 90 of 256 CUs (tools/lone_small_profile.py: 5.0 of 5.5 ms) -- so the same split applies:
+// knob "gemm_splitk_short" K ranges (0 = off) while tiles * ranges <= 512 and the GEMM has at most SPLITK_SHORT_MAX_TILES tiles; the
+// reduction pass then also applies the column scale, the activation and the q = 0 rows of the GEMM it completes.
+constexpr int64_t SPLITK_SHORT_MAX_TILES = 192;
 int gemm_f32_splitk_factor(int64_t M, int N, int K, bool by_shape_only) {
     const int knob = by_shape_only ? 8 : tuning().gemm_splitk;      // by_shape_only: the most the workspace may be asked for
-    if (knob == 0 || K < 2048 || N % BN) return 1;
+    if (N % BN) return 1;
+    if (K < 2048) {
+        const int ks = by_shape_only ? 4 : tuning().gemm_splitk_short;
+        const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);
+        if (ks < 2 || tiles > SPLITK_SHORT_MAX_TILES) return 1;
+        for (int k2 = ks; k2 >= 2; k2 >>= 1)
+            if (tiles * k2 <= 512 && K % (k2 * BK) == 0) return k2;
+        return 1;
+    }
+    if (knob == 0) return 1;
     const int64_t tiles = ((M + BM - 1) / BM) * (N / BN);
     if (knob == 1) return (tiles * 4 <= 256 && K % (4 * BK) == 0) ? 4 : 1;
     for (int ks = knob; ks >= 2; ks >>= 1)
@@ -360,9 +380,12 @@ int gemm_f32_splitk_factor(int64_t M, int N, int K, bool by_shape_only) {
     return 1;
 }
 
+// the epilogue of gemm_f32_kernel (same order: + bias, column scale / zeroed rows on the scaled columns, activation, + residual)
+// on the ordered sum of the partial slabs
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partials, int ks, int64_t slab,
                                                             const float* __restrict__ bias, const float* residual, int64_t ldr,
-                                                            float* out, int64_t ldc, int64_t M, int N) {
+                                                            float* out, int64_t ldc, int64_t M, int N, int act, float scale,
+                                                            int scale_cols, const uint8_t* __restrict__ zero_rows) {
     const int n4 = N / 4;
     const int64_t total = M * n4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -371,13 +394,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         f32x4 v = *reinterpret_cast<const f32x4*>(partials + m * N + n);
         for (int s = 1; s < ks; ++s) v += *reinterpret_cast<const f32x4*>(partials + s * slab + m * N + n);
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (n < scale_cols) v *= scale;            // scale_cols % 4 == 0: the four columns lie on one side
+        if (act == RNAMSM_ACT_GELU_ERF) {
+            const f32x2 a = gelu_erf2(f32x2{v[0], v[1]}), b = gelu_erf2(f32x2{v[2], v[3]});
+            v = f32x4{a[0], a[1], b[0], b[1]};
+        }
         if (residual) v += *reinterpret_cast<const f32x4*>(residual + m * ldr + n);
+        if (zero_rows && n < scale_cols && zero_rows[m]) v = f32x4{0.f, 0.f, 0.f, 0.f};      // q *= 1 - padding_mask (modules.py:767-772)
         *reinterpret_cast<f32x4*>(out + m * ldc + n) = v;
     }
 }
 
 int gemm_f32_splitk(const float* A, int64_t lda, const float* W, const float* bias, const float* residual, int64_t ldr,
-                    float* Cout, int64_t ldc, int64_t M, int N, int K, int ks, float* partials, hipStream_t stream) {
+                    float* Cout, int64_t ldc, int64_t M, int N, int K, int ks, float* partials, hipStream_t stream, int act,
+                    float scale, int scale_cols, const uint8_t* zero_rows) {
+    RNAMSM_CHECK_ARG(scale_cols % 4 == 0, "gemm_splitk: scale_cols must be a multiple of 4 (got %d)", scale_cols);
     RNAMSM_CHECK_ARG(ks >= 2 && K % (ks * BK) == 0 && N % BN == 0 && partials, "gemm_splitk: bad split %d for K=%d N=%d", ks, K, N);
     const int rc = launch_gemm_nt<RNAMSM_ACT_NONE, false, false, 2>(A, lda, W, nullptr, nullptr, 0, partials, N, (int)M, N, K, 1.f, 0,
                                                                     nullptr, stream, nullptr, 0.f, nullptr, 0, nullptr, ks);
@@ -385,7 +416,7 @@ int gemm_f32_splitk(const float* A, int64_t lda, const float* W, const float* bi
     const int64_t total = M * (N / 4);
     const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, partials, ks, M * (int64_t)N, bias, residual, ldr,
-                       Cout, ldc, M, N);
+                       Cout, ldc, M, N, act, scale, scale_cols, zero_rows);
     RNAMSM_CHECK_LAUNCH("splitk_reduce");
     return RNAMSM_OK;
 }

@@ -1004,3 +1004,28 @@ def test_msm_variant_of_the_model_shell_matches_reference_fixture(name):
     with pytest.raises(_lib.RnamsmError):
         ops.embed_ln(toks[0], m.embed_tokens.weight, m.embed_positions.weight, m.msa_position_embedding.reshape(-1),
                      m.emb_layer_norm_before.weight, m.emb_layer_norm_before.bias, 1, row_pos_dim=7)
+
+
+def test_short_k_split_of_a_lone_small_alignment_agrees_to_rounding(model):
+    """Knob "gemm_splitk_short" (default 0): the K = 768 GEMMs of a lone small alignment split over K ranges, the reduction pass
+    carrying the GEMM's epilogue (column scale, erf-GELU, residual, q = 0 at padded tokens).  Not the default -- once the block
+    order stopped stacking a small GEMM's tiles on four CUs the split measured no gain (EXPERIMENTS R4.8) -- but it must stay
+    right: unpadded and padded alignments against the unsplit forward at fp32 rounding, reruns bit-identical."""
+    from rnamsm import ops
+    m, _ = model
+    plain = torch.from_numpy(synthetic.make_tokens(6, 40, 321)).to("cuda:0")
+    padded = plain.clone()
+    padded[4:, 25:] = m.vocab.pad_idx
+    for toks in (plain, padded):
+        base = m.forward_one(toks)
+        try:
+            ops.set_param("gemm_splitk_short", 4)
+            split = m.forward_one(toks)
+            again = m.forward_one(toks)
+        finally:
+            ops.set_param("gemm_splitk_short", 0)
+        assert int(split["err"].item()) == 0
+        assert torch.equal(split["emb"], again["emb"]) and torch.equal(split["atp"], again["atp"])
+        assert not torch.equal(split["repr"], base["repr"])                      # the split form is what ran
+        assert rel_l2(split["repr"].cpu().numpy(), base["repr"].cpu().numpy()) < 5e-6
+        assert np.abs(split["atp"].cpu().numpy() - base["atp"].cpu().numpy()).max() < 2e-5

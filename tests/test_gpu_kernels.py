@@ -937,11 +937,14 @@ def test_dma_issue_schedules_of_the_256x256_gemms_are_bit_identical(dev, M, N, K
         _lib.check(lib.rnamsm_set_param(b"gemm16_dephase", 2))
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 2304, 96), (4100, 1280, 64), (1025, 768, 768), (129, 3072, 32)])
+@pytest.mark.parametrize("M,N,K", [(300, 2304, 96), (4100, 1280, 64), (1025, 768, 768), (129, 3072, 32), (9000, 2304, 64),
+                                   (2100, 3072, 32), (82, 2304, 768)])
 def test_gemm_block_order_never_changes_results(dev, M, N, K):
     """rnamsm_set_param("gemm_group"): the XCD-aware block order (whole panels, groups of G panels, by-shape default)
     only permutes which block computes which tile -- every setting must give bit-identical output, including ragged M
-    (padding blocks of the grouped grid must exit without touching memory)."""
+    (padding blocks of the grid must exit without touching memory).  Round 4: no padding GROUPS any more -- an XCD's last
+    panels form a smaller group (9000 rows: 71 panels = 8 + 1 per XCD) -- and by default a GEMM of at most 512 tiles is dealt
+    flat, tile = block id (82 x 2304: a lone small alignment's QKV, 18 tiles: 117 -> 28 us)."""
     from rnamsm import ops, _lib
     lib = _lib.load()
     a, w, b = _rand("go.a", (M, K)), _rand("go.w", (N, K), 0.05), _rand("go.b", (N,), 0.1)
