@@ -285,19 +285,22 @@ __device__ __forceinline__ bool xcd_panel_map_ragged(unsigned bid, unsigned num_
         return panel < num_panels;
     }
     const unsigned xcd = bid & 7u, idx = bid >> 3;
-    const unsigned local = (num_panels + 7u) / 8u, full = local / G, per_group = G * inner;
+    // THIS XCD's panels (xcd, xcd + 8, ...): where the panel count is no multiple of 8 the higher XCDs own one fewer, and their
+    // spare block ids lie at the END of their sequence, not strided through a group
+    const unsigned local = (num_panels + 7u - xcd) / 8u, full = local / G, per_group = G * inner;
+    if (idx >= local * inner) return false;
     unsigned local_panel;
     if (idx < full * per_group) {
         const unsigned group = idx / per_group, rem = idx % per_group;
         in_panel = rem / G;
         local_panel = group * G + rem % G;
     } else {
-        const unsigned tail = local - full * G, r = idx - full * per_group;      // tail >= 1: the grid ends at local * inner
+        const unsigned tail = local - full * G, r = idx - full * per_group;      // tail >= 1 here
         in_panel = r / tail;
         local_panel = full * G + r % tail;
     }
     panel = local_panel * 8u + xcd;
-    return panel < num_panels;
+    return true;
 }
 static inline unsigned xcd_panel_grid_ragged(unsigned num_panels, unsigned inner, unsigned G) {
     return G == 0u ? num_panels * inner : ((num_panels + 7u) / 8u) * 8u * inner;
