@@ -84,24 +84,27 @@ CASES = [
 ]
 
 
-CPU_YARDSTICK = {"configs[0]", "configs[1]", "configs[3]"}     # sizes the CPU oracle finishes in <= ~20 s
+CPU_YARDSTICK = {"configs[1]"}     # the size the CPU oracle finishes in 2-3 s; configs[0] / [3] (8-20 s of 32 threads, twice that on a box
+# with slow host cores) use committed measurements since the end of round 4, like configs[2] / [4]; the `slow` test re-measures them
 # configs[4] (M = L = 1024): the CPU oracle needs 12.6 minutes of 32 host threads there, so its errors against the same fp64
 # truth were measured ONCE on the GPU box (tests/analysis/yardstick_m1024.py, same tokens, same weights) and committed.
 # configs[2] (M = 256, L = 512): 70 s of the same -- measured live in the suite until round 3; since round 4 (the suite's wall-
 # clock cap) the default run uses the committed measurement and the `slow` variant below re-measures it.
-COMMITTED_YARDSTICK = {"configs[4]": "yardstick_m1024_l1024.json", "configs[2]": "yardstick_m256_l512.json"}
+COMMITTED_YARDSTICK = {"configs[4]": "yardstick_m1024_l1024.json", "configs[2]": "yardstick_m256_l512.json",
+                       "configs[0]": "yardstick_2drb1_512x36.json", "configs[3]": "yardstick_m128_l256.json"}
 
 
 @pytest.mark.slow
-def test_configs2_against_a_live_cpu_yardstick(model):
-    """-m "gpu and slow": BASELINE configs[2] with the reference's own fp32 error measured live on this host (70 s of 32 threads)
-    instead of read from tests/golden/yardstick_m256_l512.json, and the committed figure checked against it."""
-    label, make = CASES[2]
+@pytest.mark.parametrize("case", [0, 2, 3])
+def test_configs2_against_a_live_cpu_yardstick(model, case):
+    """-m "gpu and slow": BASELINE configs[0] / [2] / [3] with the reference's own fp32 error measured live on this host (8-70 s of
+    32 threads) instead of read from tests/golden/yardstick_*.json, and the committed figure checked against it."""
+    label, make = CASES[case]
     toks = make()
     t_emb, t_atp = truth.oracle_outputs(toks, torch.float64, DEV)
     torch.set_num_threads(min(32, torch.get_num_threads()))
     live = truth.errors(*truth.oracle_outputs(toks, torch.float32, "cpu"), t_emb, t_atp)
-    y = json.load(open(os.path.join(GOLDEN, COMMITTED_YARDSTICK["configs[2]"])))["oracle_cpu_f32"]
+    y = json.load(open(os.path.join(GOLDEN, COMMITTED_YARDSTICK[label.split()[0]])))["oracle_cpu_f32"]
     for k in ("emb_rel_l2", "atp_rel_l2", "atp_mean_abs"):
         assert 0.8 * y[k] <= live[k] <= 1.25 * y[k], (k, live, y)       # thread blocking moves fp32 sums a little, not the scale
     for mode in ("f32", "f16x3"):
@@ -129,7 +132,7 @@ def test_every_baseline_config_against_fp64_truth(model, label, make):
         rep["oracle_cpu_f32"] = truth.errors(*truth.oracle_outputs(toks, torch.float32, "cpu"), t_emb, t_atp)
     if cfg in COMMITTED_YARDSTICK:
         y = json.load(open(os.path.join(GOLDEN, COMMITTED_YARDSTICK[cfg])))
-        assert y["shape"] == list(toks.shape) and y["token_seed"] == 0
+        assert y["shape"] == list(toks.shape) and y["token_seed"] == (3 if cfg == "configs[3]" else 0)
         rep["oracle_cpu_f32"] = y["oracle_cpu_f32"]
         rep["oracle_cpu_f32_source"] = f"tests/golden/{COMMITTED_YARDSTICK[cfg]} ({y['cpu_seconds']:.0f} s of {y['threads']} threads, {y['cpu_model']})"
     e_ref = rep["oracle_cpu_f32"]            # the reference's own fp32 arithmetic (PyTorch CPU): measured here or committed
