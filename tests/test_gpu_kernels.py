@@ -1068,3 +1068,28 @@ def test_generic_mha_edge_shapes_against_oracle(dev):
             assert w3.shape == (H, B, T, T) and np.abs(w3.cpu().numpy() - wts.numpy()).max() < 5 * tol, (T, mode)
             if T == 1:
                 assert float((w3 - 1).abs().max()) == 0.0
+
+
+def test_small_m_gemm_tiles_run_side_by_side(dev):
+    """Performance guard for EXPERIMENTS R4.8: a GEMM with one row panel and 18 column tiles (a lone small alignment's QKV) must
+    take about as long as one with 6 (its tiles are independent and 238 CUs are idle) -- with padded XCD groups the hardware's
+    in-turn CU assignment had stacked the 18 tiles on four CUs: 117 us against 26 us, a ratio of 4.5.  Bound 2.0 (measured
+    1.1), on the per-launch time inside a queue of 200 launches; timing ratios of one process on one device are stable."""
+    import time
+    from rnamsm import ops
+    M, K = 82, 768
+    a = torch.randn(M, K, device=dev)
+
+    def per_launch(N):
+        w, b, out = torch.randn(N, K, device=dev) * 0.04, torch.zeros(N, device=dev), torch.empty(M, N, device=dev)
+        for _ in range(20):
+            ops.linear(a, w, b, out=out)
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(200):
+                ops.linear(a, w, b, out=out)
+            torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 200)
+        return best
+    narrow, wide, widest = per_launch(768), per_launch(2304), per_launch(3072)
+    assert wide < 2.0 * narrow and widest < 2.0 * narrow, (narrow * 1e6, wide * 1e6, widest * 1e6)
