@@ -525,6 +525,8 @@ void rnamsm_timing_reset(void);
  *                 rnamsm_forward_batch (default 0 = 10752 for plain bf16, 8960 for the hi/lo modes: below ~9-10 k tokens the
  *                 256x256 kernels leave most CUs without a tile; 2048 tokens x1.33 / x1.59, 8192 x1.11 / x1.10).  The hi/lo modes'
  *                 kernels sum every element in the same order (bit-identical); plain bf16 changes MFMA shape (fp32 rounding).
+ *   "gemm_flat_tiles"  fp32 GEMM: at most this many tiles (default 512 = the chip's block slots) are dealt flat, tile = block id, instead
+ *                 of XCD-aware (A/B: larger values win a stand-alone GEMM and lose inside the forward).  Never changes results.
  *   "gemm_splitk_short"  rnamsm_forward*, the K = 768 GEMMs of a lone small alignment (<= 192 tiles): 0 (default) = off, 2 / 4 = that
  *                 many K ranges with the epilogue applied by the reduction pass (A/B: no gain once the block order was fixed).
  *   "col_fast"    rnamsm_col_attn_fused_prescaled: 1 (default) = first pass without a running maximum, the online softmax as the

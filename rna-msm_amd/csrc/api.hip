@@ -226,6 +226,10 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().col_fast = value != 0;
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "gemm_flat_tiles")) {
+        rnamsm::tuning().gemm_flat_tiles = value < 0 ? 0 : value;
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "gemm_splitk_short")) {
         rnamsm::tuning().gemm_splitk_short = value <= 0 ? 0 : (value >= 4 ? 4 : 2);
         return RNAMSM_OK;
@@ -240,6 +244,7 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "col_small")) return rnamsm::tuning().col_small;
     if (name && !strcmp(name, "col_dma")) return rnamsm::tuning().col_dma;
     if (name && !strcmp(name, "col_fast")) return rnamsm::tuning().col_fast;
+    if (name && !strcmp(name, "gemm_flat_tiles")) return rnamsm::tuning().gemm_flat_tiles;
     if (name && !strcmp(name, "gemm_splitk_short")) return rnamsm::tuning().gemm_splitk_short;
     if (name && !strcmp(name, "gemm16_dephase")) return rnamsm::tuning().gemm16_dephase;
     if (name && !strcmp(name, "gemm16_big_rows")) return rnamsm::tuning().gemm16_big_rows;

@@ -277,12 +277,12 @@ static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const flo
     // groups of 8 panels x 8 column blocks halve the fabric reads (PMC, cfg3: QKV 4.9 -> 2.9 GB, fc1 8.0 -> 3.6 GB per
     // launch; same speed, the kernel is MFMA-bound).  N = 768 (6 column blocks) is already balanced and stays ungrouped.
     const int nb = N / Cfg::BN_;
-    // (round 4) no padding groups: an XCD's last panels form a smaller group (xcd_panel_map_ragged); and a GEMM with fewer tiles
-    // than the chip has block slots is dealt FLAT (group 0: tile = block id), so that a lone small alignment's 18-24 column
-    // tiles run on as many CUs of all XCDs instead of on one XCD's
+    // (round 4) no padding groups: an XCD's last panels form a smaller group (xcd_panel_map_ragged); and a GEMM with no more tiles
+    // than the chip has block slots ("gemm_flat_tiles", 512) is dealt FLAT (group 0: tile = block id), so that a lone small
+    // alignment's 18-24 column tiles run on as many CUs of all XCDs instead of on one XCD's
     const int mp_ = (M + BM - 1) / BM;
     const int group = tuning().gemm_group > 0 ? tuning().gemm_group
-                                              : ((int64_t)mp_ * nb * (ksplit > 1 ? ksplit : 1) <= 512 ? 0 : (nb > 8 * (3 - NT) ? 8 : 1));
+                                              : ((int64_t)mp_ * nb * (ksplit > 1 ? ksplit : 1) <= tuning().gemm_flat_tiles ? 0 : (nb > 8 * (3 - NT) ? 8 : 1));
     const unsigned grid = xcd_panel_grid_ragged(mp_, nb, (unsigned)group) * (ksplit > 1 ? ksplit : 1);
     // algorithmic work: 2MNK flops; bytes = A + W + C once (+ residual read)
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
