@@ -16,6 +16,17 @@ for p in (os.path.join(ROOT, "rna-msm_amd"), ROOT):
         sys.path.insert(0, p)
 
 
+def pytest_sessionstart(session):
+    """The CPU oracle (torch on the host) is the checker in many GPU tests.  On the GPU box's 256-thread host torch's default intra-op
+    pool is 4-5x SLOWER than 32 threads on these sizes (bench.py's sweep: one layer 39 s at 256 threads, 8 s at 32) and its speed
+    varies from box to box -- two of the round's suite runs took 575 / 689 s instead of 370.  32 threads for the whole session."""
+    try:
+        import torch
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+    except Exception:               # noqa: BLE001 -- a CPU-only collection without torch still has to work
+        pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
     config.addinivalue_line("markers", "slow: a GPU test of more than ~20 s whose claim a faster test of the default run also "
