@@ -331,11 +331,14 @@ int gemm_f32_splitk(const float* A, int64_t lda, const float* W, const float* bi
 static inline size_t splitk_workspace_floats(int64_t T, int D, int F) {
     const size_t long_k = (size_t)gemm_f32_splitk_factor(T, D, F, true);              // fc2: [ks][T][D]
     size_t n = long_k > 1 ? long_k * (size_t)T * D : 0;
-    const int widest = 3 * D > F ? 3 * D : F;                                          // QKV / fc1: [ks][T][3D | F]
-    const size_t short_k = (size_t)gemm_f32_splitk_factor(T, widest, D, true);
-    if (short_k > 1 && short_k * (size_t)T * widest > n) n = short_k * (size_t)T * widest;
-    const size_t short_d = (size_t)gemm_f32_splitk_factor(T, D, D, true);              // out_proj: [ks][T][D]
-    if (short_d > 1 && short_d * (size_t)T * D > n) n = short_d * (size_t)T * D;
+    // QKV / fc1 / out_proj / a part of them (K = D): the factor depends on the tile count of the GEMM at hand, so every width the
+    // forward uses is asked (a narrower GEMM has fewer tiles and may take MORE ranges than the widest one: sizing by the widest
+    // alone overran the region -- found by the forward fuzz with the knob on, seed 73)
+    const int widths[5] = {D, 2 * D, 3 * D, F, 4 * D};
+    for (int N : widths) {
+        const size_t ks = (size_t)gemm_f32_splitk_factor(T, N, D, true);
+        if (ks > 1 && ks * (size_t)T * N > n) n = ks * (size_t)T * N;
+    }
     return n;
 }
 

@@ -39,7 +39,8 @@ EDGES = [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 1
 # reference's own 4.0e-5 (emb 8.2e-6); its multiple is 4
 TOL = {"f32": (1e-4, 1e-4, 3.0), "f16x3": (1e-4, 1e-4, 4.0), "bf16x3": (2e-4, 3e-3, 5.0),
        "bf16": (2e-2, 2e-2, 2.0)}         # plain bf16: yardstick = the oracle run in bfloat16 (what the reference's .bfloat16() does)
-KNOB_DEFAULTS = {"ln_fold": 1, "gemm_tile": 0, "col_dma": -1, "row_vt": 1, "attn16": 1, "gemm_splitk": 1}
+KNOB_DEFAULTS = {"ln_fold": 1, "gemm_tile": 0, "col_dma": -1, "row_vt": 1, "attn16": 1, "gemm_splitk": 1,
+                 "col_fast": 1, "gemm_flat_tiles": 512, "gemm_splitk_short": 0, "col_small": 1}     # (the last four: round 4)
 
 
 def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mode=None, model=None, log=print):
@@ -66,7 +67,9 @@ def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mod
             mode = str(rng.choice(["f32", "f32", "f16x3", "bf16x3", "bf16"]))
             knobs = {"ln_fold": int(rng.choice([0, 1, 2, 3])), "gemm_tile": int(rng.choice([0, 1, 2])),
                      "col_dma": int(rng.choice([-1, 0, 1])), "row_vt": int(rng.choice([0, 1])), "attn16": int(rng.choice([0, 1, 1])),
-                     "gemm_splitk": int(rng.choice([0, 1, 1, 2, 4, 8]))}
+                     "gemm_splitk": int(rng.choice([0, 1, 1, 2, 4, 8])), "col_fast": int(rng.choice([0, 1, 1])),
+                     "gemm_flat_tiles": int(rng.choice([0, 512, 512, 100000])), "gemm_splitk_short": int(rng.choice([0, 0, 2, 4])),
+                     "col_small": int(rng.choice([0, 1, 1]))}
             padded = rng.random() < 0.3 and R > 1 and C > 3
             if fixed:
                 (R, C), padded = fixed[case], False
@@ -127,6 +130,22 @@ def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mod
                 # fp32 run 1.7e-4 from the truth: two results that each sit at the yardstick may differ by twice it)
                 mod_ok = mod_ok and d_e < max(2e-5, 2.0 * ref["emb_rel_l2"]) and d_a < max(1e-4, 2.0 * ref["atp_max_abs"])
                 mod_note += f" batch of 3: emb {bt['emb_rel_l2']:.2e} atp {bt['atp_max_abs']:.2e}, MSA 2 vs alone {d_e:.1e} / {d_a:.1e}"
+            # every fourth unpadded exact-path case also as one member of a TOKEN-PACKED batch of unlike alignments
+            # (rnamsm_forward_packed, round 4): against the truth at the case's own bar, against its lone forward at the batch bar
+            if case % 4 == 2 and not padded and mode == "f32":
+                others = []
+                for j in range(int(rng.integers(1, 5))):
+                    ro, co = int(rng.choice(EDGES[:14])) if rng.random() < 0.5 else int(rng.integers(1, 60)), int(rng.integers(2, 90))
+                    others.append(torch.from_numpy(synthetic.make_tokens(ro, co, 9000 + 11 * case + j)).to("cuda:0"))
+                where = int(rng.integers(0, len(others) + 1))
+                members = others[:where] + [t] + others[where:]
+                pk = model.forward_ragged(members, packed=True)
+                pe = truth.errors(pk[where]["emb"], pk[where]["atp"], t_emb, t_atp)
+                d_e = float((pk[where]["emb"] - out["emb"]).norm() / out["emb"].norm())
+                d_a = float((pk[where]["atp"] - out["atp"]).abs().max())
+                mod_ok = (mod_ok and pe["emb_rel_l2"] < emb_bar and pe["atp_max_abs"] < atp_bar
+                          and d_e < max(2e-5, 2.0 * ref["emb_rel_l2"]) and d_a < max(1e-4, 2.0 * ref["atp_max_abs"]))
+                mod_note += f" packed with {len(others)} others: emb {pe['emb_rel_l2']:.2e} atp {pe['atp_max_abs']:.2e}, vs alone {d_e:.1e} / {d_a:.1e}"
             # padded exact-path cases also as the first of a padded batch of two (rnamsm_forward_batch, has_padding)
             if padded and mode == "f32" and R * C <= 16384:
                 other = synthetic.make_tokens(R, C, 7000 + case).copy()
