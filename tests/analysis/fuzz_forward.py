@@ -132,7 +132,7 @@ def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mod
                 mod_note += f" batch of 3: emb {bt['emb_rel_l2']:.2e} atp {bt['atp_max_abs']:.2e}, MSA 2 vs alone {d_e:.1e} / {d_a:.1e}"
             # every fourth unpadded exact-path case also as one member of a TOKEN-PACKED batch of unlike alignments
             # (rnamsm_forward_packed, round 4): against the truth at the case's own bar, against its lone forward at the batch bar
-            if case % 4 == 2 and not padded and mode == "f32":
+            if case % int(os.environ.get("FUZZ_PACKED_EVERY", 4)) == int(os.environ.get("FUZZ_PACKED_EVERY", 4)) // 2 and not padded and mode == "f32":
                 others = []
                 for j in range(int(rng.integers(1, 5))):
                     ro, co = int(rng.choice(EDGES[:14])) if rng.random() < 0.5 else int(rng.integers(1, 60)), int(rng.integers(2, 90))
