@@ -27,5 +27,29 @@ for (R, C), iters in (((256, 512), ITER), ((37, 300), 2 * ITER), ((64, 128), 2 *
                 mism += 1
         bad += mism
         print(f"{R}x{C} {mode}: {iters} reruns, {mism} mismatches", flush=True)
+# round 4: the configs[4] shape in the 16-bit modes (two query blocks per wave, the operand-staged tied-row kernel) and a token-packed batch
+if os.environ.get("BIG", "1") != "0":
+    import numpy as np
+    toks = torch.from_numpy(synthetic.make_tokens(1024, 1023, 5)).cuda()
+    for mode in ("bf16", "f16x3"):
+        m.gemm_dtype = mode
+        ref = m.forward_one(toks, need_repr=False)
+        e, a = ref["emb"].clone(), ref["atp"].clone()
+        mism = 0
+        for _ in range(max(4, ITER // 12)):
+            o = m.forward_one(toks, need_repr=False)
+            mism += 0 if (torch.equal(o["emb"], e) and torch.equal(o["atp"], a)) else 1
+        bad += mism
+        print(f"1024x1024 {mode}: {max(4, ITER // 12)} reruns, {mism} mismatches", flush=True)
+    m.gemm_dtype = "f32"
+    rng = np.random.default_rng(3)
+    msas = [torch.from_numpy(synthetic.make_tokens(int(rng.integers(1, 40)), int(rng.integers(5, 150)), 100 + i)).cuda() for i in range(40)]
+    ref = m.forward_packed(msas)
+    mism = 0
+    for _ in range(ITER):
+        out = m.forward_packed(msas)
+        mism += 0 if all(torch.equal(x["emb"], y["emb"]) and torch.equal(x["atp"], y["atp"]) for x, y in zip(out, ref)) else 1
+    bad += mism
+    print(f"packed batch of 40 unlike alignments: {ITER} reruns, {mism} mismatches", flush=True)
 print("SOAK", "FAILED" if bad else "OK")
 sys.exit(1 if bad else 0)
