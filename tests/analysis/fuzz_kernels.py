@@ -143,7 +143,23 @@ def fuzz_col_attention(rng, gen):
         mask.view(R, C)[0] = False                      # a column never loses all its keys in the reference's use
         mask = mask.to(torch.uint8)
     ops.set_param("col_dma", int(rng.integers(-1, 2)))
-    ctx = ops.col_attn(q, k, v, R, C, H, pad_mask=mask)
+    ops.set_param("col_small", int(rng.integers(0, 2)))
+    # (round 4) unmasked cases half the time through the log2-domain entry (rnamsm_col_attn_fused_prescaled: first pass without a
+    # running maximum, "col_fast" = 0 keeps the online softmax), now and then with a query whose scores leave exp2's range
+    pre = mask is None and rng.random() < 0.5
+    if pre:
+        ops.set_param("col_fast", int(rng.integers(0, 2)))
+        if rng.random() < 0.3 and R >= 4:
+            i, c = int(rng.integers(0, R)), int(rng.integers(0, C))
+            kk = k.view(R, C, H, 64)[int(rng.integers(0, R)), c, 0]
+            q.view(R, C, H, 64)[i, c, 0] = (100.0 if rng.random() < 0.5 else -100.0) * kk / kk.norm()
+        qs = buf.clone()
+        qs[:, :64 * H] *= 1.4426950408889634
+        ctx = ops.col_attn(qs[:, :64 * H], qs[:, 64 * H:128 * H], qs[:, 128 * H:192 * H], R, C, H, prescaled=True)
+        ops.set_param("col_fast", 1)
+    else:
+        ctx = ops.col_attn(q, k, v, R, C, H, pad_mask=mask)
+    ops.set_param("col_small", 1)
     q4 = q.double().reshape(R, C, H, 64)
     k4 = k.double().reshape(R, C, H, 64)
     v4 = v.double().reshape(R, C, H, 64)
@@ -155,7 +171,7 @@ def fuzz_col_attention(rng, gen):
     else:
         want = torch.einsum("hcij,jchd->ichd", s.softmax(-1), v4).reshape(R * C, H * 64)
     err = rel(ctx, want)
-    return err < 2e-5, f"col attention R={R} C={C} H={H} ld={ld} masked={mask is not None}: {err:.2e}"
+    return err < 2e-5 and bool(torch.isfinite(ctx).all()), f"col attention R={R} C={C} H={H} ld={ld} masked={mask is not None} prescaled={pre}: {err:.2e}"
 
 
 def fuzz_planes_gemm(rng, gen):
