@@ -52,7 +52,7 @@ def parse_args(argv=None):
     ap.add_argument("--num-msas", type=int, default=512, help="configs3: MSAs in the batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the output gather to rank 0 (N > 1)")
-    ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "f16x3", "bf16x3", "bf16"],
+    ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "f16x3", "bf16"],
                     help="arithmetic of the contractions for the headline value (default: exact fp32)")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra f16x3 / bf16 / outputs-only measurements")
     ap.add_argument("--no-per-config", action="store_true", help="skip the one-forward-per-BASELINE-config block")
@@ -585,7 +585,7 @@ def run_rank(args) -> int:
         bf16_mode = measure_mode("bf16", 1.0)
         bf16_mode["accuracy"] = ("tests/test_gpu_fullsize.py holds this mode to 1.5x the drift of the reference's own "
                                  ".bfloat16() arithmetic against an fp64 truth at every BASELINE size "
-                                 "(profiles/r02_fullsize_parity.json)")
+                                 "(profiles/r04_fullsize_parity.json)")
 
     # ---- every BASELINE config on the driver-run line (N = 1): one MSA of each shape, 1 warm-up + 2 timed forwards with the
     # hooks off, then one instrumented forward for the per-launch roofline sums
@@ -647,11 +647,10 @@ def run_rank(args) -> int:
     if rank == 0:
         residues = msas_timed * M * L
         g = timings["gemm_f32"]
-        mult = {"f32": 1.0, "bf16": 1.0, "bf16x3": 3.0, "f16x3": 3.0}[args.gemm_dtype]
+        mult = {"f32": 1.0, "bf16": 1.0, "f16x3": 3.0}[args.gemm_dtype]
         peak = FP32_MFMA_PEAK_TFLOPS if args.gemm_dtype == "f32" else F16_MFMA_PEAK_TFLOPS
         gemm_kernel = {"f32": "gemm_f32_kernel (nn.Linear, K2)",
                        "bf16": "gemm16_q16s_kernel (QKV, fc1, fc2) + gemm16_swp_kernel<split 1, bf16> (out_proj) (nn.Linear, K2)",
-                       "bf16x3": "gemm16_swp_kernel<split 3, bf16> (nn.Linear, K2)",
                        "f16x3": "gemm16_swp_kernel<split 3, fp16> (nn.Linear, K2)"}[args.gemm_dtype]
         flop_unit = "TFLOP/s" if mult == 1.0 else "TFLOP/s (executed MFMA flops = 3 x algorithmic)"
         gemm_tflops = mult * g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
@@ -662,8 +661,7 @@ def run_rank(args) -> int:
         if (M, L) == (256, 512):                   # the shapes the committed PMC passes were collected on
             traffic, traffic_src = {"f32": lambda: pmc_traffic_per_launch(),
                                     "bf16": lambda: pmc_traffic_per_launch("rnamsm::gemm16_", "bf16_"),
-                                    "f16x3": lambda: pmc_traffic_per_launch("rnamsm::gemm16_", "f16x3_"),
-                                    "bf16x3": lambda: (None, None)}[args.gemm_dtype]()
+                                    "f16x3": lambda: pmc_traffic_per_launch("rnamsm::gemm16_", "f16x3_")}[args.gemm_dtype]()
         elif (M, L) == (1024, 1024) and args.gemm_dtype == "bf16":     # BASELINE configs[4]
             traffic, traffic_src = pmc_traffic_per_launch("rnamsm::gemm16_", "cfg4_bf16_")
         if world == 1:
@@ -688,7 +686,7 @@ def run_rank(args) -> int:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong" if batch else "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "f16x3": "f16x3 (fp16 hi/lo split, f32 accumulate)", "bf16x3": "bf16x3", "bf16": "bf16"}[args.gemm_dtype],
+            "dtype": {"f32": "f32", "f16x3": "f16x3 (fp16 hi/lo split, f32 accumulate)", "bf16": "bf16"}[args.gemm_dtype],
             "data": "synthetic",
             "config": {"workload": (f"BASELINE {base_cfg}: " + (f"batch of {per_step} synthetic MSAs" if batch else "synthetic MSA")
                                     + f" M={M} x L={L} (col 0 = <cls>), D=768 H=12 10 layers, "

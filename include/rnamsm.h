@@ -42,10 +42,11 @@ typedef enum {
  * LayerNorm, residual stream, outputs -- is fp32 in every mode):
  *   RNAMSM_F32     exact-fp32 MFMA (default; the parity path)
  *   RNAMSM_BF16    bf16 MFMA on bf16-rounded operands, fp32 accumulate (mixed precision; BASELINE config 4)
- *   RNAMSM_BF16X3  bf16 MFMA on hi/lo-split operands, 3 products, fp32 accumulate (~2^-17 operand error)
+ *   (value 2, RNAMSM_BF16X3_REMOVED: hi/lo bf16 pairs, 3 products -- removed in round 5: the same three MFMAs per product as
+ *                  F16X3 with 17 instead of 22 operand bits; every entry point answers RNAMSM_ERR_UNSUPPORTED for it)
  *   RNAMSM_F16X3   fp16 MFMA on hi/lo-split operands, 3 products, fp32 accumulate (~2^-22 operand error: fp32-grade
  *                  for the fp16-range operands this model feeds its Linear layers) */
-typedef enum { RNAMSM_F32 = 0, RNAMSM_BF16 = 1, RNAMSM_BF16X3 = 2, RNAMSM_F16X3 = 3 } rnamsm_dtype;
+typedef enum { RNAMSM_F32 = 0, RNAMSM_BF16 = 1, RNAMSM_BF16X3_REMOVED = 2, RNAMSM_F16X3 = 3 } rnamsm_dtype;
 typedef enum { RNAMSM_ACT_NONE = 0, RNAMSM_ACT_GELU_ERF = 1 } rnamsm_act;
 
 int rnamsm_version(void);
@@ -140,10 +141,11 @@ int rnamsm_gemm_row_scaled(const float* A, int64_t lda, const float* W, const fl
 
 /* Linear on the bf16 matrix cores (fp32 accumulate, fp32 activations in HBM), same epilogue as above.
  *   split = 1: operands rounded to bf16 (mixed-precision mode, BASELINE config 4);
- *   split = 3: "bf16x3" -- both operands as hi + lo bf16 pairs, product = hi*hi + hi*lo + lo*hi (~2^-17 relative
- *              operand error, fp32 accumulation); opt-in fast mode, the exact-fp32 kernel stays the default.
- *   fmt   = 0: bf16 halves;  fmt = 1 (split 3 only): fp16 halves, "f16x3": a hi/lo fp16 pair carries ~22 mantissa
- *              bits (fp32: 24) for operands inside fp16 range (|x| < 65504).
+ *   split = 3: both operands as hi + lo pairs, product = hi*hi + hi*lo + lo*hi, fp32 accumulation; opt-in fast mode, the
+ *              exact-fp32 kernel stays the default.
+ *   fmt   = 0: bf16 halves (split 1 only: split 3 with fmt 0, "bf16x3", was removed -> RNAMSM_ERR_UNSUPPORTED);
+ *   fmt   = 1 (split 3 only): fp16 halves, "f16x3": a hi/lo fp16 pair carries ~22 mantissa bits (fp32: 24) for operands
+ *              inside fp16 range (|x| < 65504).
  * W_hi / W_lo [N, K] are bf16 planes produced once by rnamsm_split_bf16 (lo = bf16(w - hi); may be NULL there
  * and here when split = 1); A is split while it is staged.  Requires N % 128 == 0, K % 64 == 0. */
 int rnamsm_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, int64_t n, int fmt, void* stream);
@@ -243,7 +245,7 @@ int rnamsm_col_attn_fused_queries(const float* q, const float* k, const float* v
 /* K7 on PRESCALED q (round 4): q already carries dh^-1/2 * log2(e) (the scale / scale_cols of the QKV GEMM's epilogue), so the
  * scores are in log2 units and the kernel's first pass needs no running maximum -- p = exp2(s) on the raw score, no max chain, no
  * rescale of the accumulators (softmax does not depend on the reference point and fp32 keeps its relative precision at any
- * scale); a block whose row sums leave [2^-100, 2^100] (a score outside fp32's exponent range) redoes its column with the online
+ * scale); a block whose row sums leave [2^-64, 2^100] (a score outside fp32's exponent range) redoes its column with the online
  * softmax in log2 units.  No mask, fp32 context; q_rows as in rnamsm_col_attn_fused_queries (q_rows == R: all rows).  Results
  * equal rnamsm_col_attn_fused on q / log2(e) to fp32 rounding.  What rnamsm_forward / _batch / _packed call on the exact path
  * when the MSA has no padding.  Knob "col_fast" = 0 keeps the online softmax only (A/B). */
@@ -269,7 +271,7 @@ int rnamsm_col_attn_probs16(const uint16_t* q_hi, const uint16_t* q_lo, const ui
  * are 16-bit planes in HBM, addressed like their fp32 counterparts (element (r,c,h,d) = plane[(r*C+c)*ld + h*64 + d],
  * ld in halves): q/k/v as written by rnamsm_gemm_bf16's plane epilogue (O_hi/O_lo over the fused [T,3D] QKV output),
  * P as written by rnamsm_softmax_rows_planes.  All *_lo NULL = bf16 operands, one MFMA per product (fmt must be 0);
- * all *_lo given = hi/lo pairs, three MFMAs per product (fmt 0 = bf16x3, 1 = f16x3; f16x3 is fp32-grade).
+ * all *_lo given = hi/lo pairs, three MFMAs per product (fmt must be 1 = f16x3, fp32-grade; fmt 0 with lo planes -- bf16x3 -- was removed).
  * Accumulation, softmax and the partial-slab sum stay fp32.  Padding masks (f2): rnamsm_zero_plane_rows on the q
  * planes, key_mask in rnamsm_softmax_rows_planes, pad_mask in rnamsm_col_attn16. */
 /* Scaling is applied to fp32 accumulators, never to 16-bit operands (a q scaled by ~1e-2 or a probability ~1e-3 would
@@ -530,7 +532,7 @@ void rnamsm_timing_reset(void);
  *   "gemm_splitk_short"  rnamsm_forward*, the K = 768 GEMMs of a lone small alignment (<= 192 tiles): 0 (default) = off, 2 / 4 = that
  *                 many K ranges with the epilogue applied by the reduction pass (A/B: no gain once the block order was fixed).
  *   "col_fast"    rnamsm_col_attn_fused_prescaled: 1 (default) = first pass without a running maximum, the online softmax as the
- *                 fallback of a block whose row sums leave [2^-100, 2^100]; 0 = the online softmax only (A/B; results agree to rounding).
+ *                 fallback of a block whose row sums leave [2^-64, 2^100]; 0 = the online softmax only (A/B; results agree to rounding).
  *   "row16_q16"   plain bf16 rnamsm_row_logits16 at C >= 384 with C % 8 == 0: 1 (default) = row_logits16q_kernel (256x256 tiles on the
  *                 16x16x32 MFMA, staged by operand, persistent blocks, register-direct epilogue), 0 = the 128x128 kernel.  Changes
  *                 the row split (rnamsm_row_logits16_nsplit) and agrees to fp32 rounding.
@@ -560,7 +562,10 @@ void rnamsm_timing_reset(void);
  *                 2 = as 1 but the row kernels keep 128x128 tiles for every C (A/B of the 256x256-tile kernels);
  *                 rnamsm_col_attn16 only: 4 = one 32-query block per wave for every R, 5 = the TRACKED (online-softmax) loop for
  *                 every format (A/B, and the reference the FAST loop's fallback is tested against).
- *                 The RNAMSM_F32 path is not affected by either. */
+ *                 The RNAMSM_F32 path is not affected by either.
+ * Threading: the knobs are process-global and are read on the host while a call enqueues its launches.  Change them only between
+ * calls; while any thread is inside rnamsm_forward / _forward_batch / _forward_packed, rnamsm_set_param changes nothing and returns
+ * RNAMSM_ERR_INVALID (the one per-forward choice that used to be a knob write, the 16-bit GEMM tile threshold, is thread-local). */
 int rnamsm_set_param(const char* name, int value);
 int rnamsm_get_param(const char* name);
 

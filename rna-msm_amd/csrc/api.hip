@@ -133,12 +133,19 @@ Tuning& tuning() {
     static Tuning t;
     return t;
 }
+std::atomic<int>& forwards_enqueuing() {
+    static std::atomic<int> n{0};
+    return n;
+}
 int& gemm16_big_rows_override() {
     static thread_local int v = 0;
     return v;
 }
 }  // namespace rnamsm
 extern "C" int rnamsm_set_param(const char* name, int value) {
+    if (rnamsm::forwards_enqueuing().load(std::memory_order_acquire) != 0)
+        return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: a forward driver is enqueuing on another thread; knobs are process-global "
+                                                "and may only change between forwards");
     if (name && !strcmp(name, "gemm16_dma")) {
         rnamsm::tuning().gemm16_dma = value;
         return RNAMSM_OK;

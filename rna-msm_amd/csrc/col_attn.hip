@@ -265,7 +265,7 @@ __host__ __device__ constexpr int cd_vrow(int t) { return (t & 3) + 8 * (t >> 2)
 // PRE (round 4): q arrives PRESCALED by dh^-1/2 * log2(e) (the QKV GEMM's epilogue), scores are in log2 units and the kernel
 // first runs a FAST loop with NO running maximum -- p = v_exp_f32(s) on the raw score, no max chain, no half exchange, no
 // rescale of the accumulators (softmax is invariant to the reference point; fp32 p and sums keep their relative precision
-// whatever the scale) -- and looks at the row sums afterwards: outside [2^-100, 2^100] or not finite, some score left the
+// whatever the scale) -- and looks at the row sums afterwards: outside [2^-64, 2^100] or not finite, some score left the
 // exponent range; the block votes and redoes its column on the TRACKED loop (the online softmax below, in log2 units).
 template <bool MASKED, int OUT, bool PRE = false>
 __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kernel(
@@ -478,7 +478,9 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
         run(std::integral_constant<bool, false>{});
         // the block shares the ring: its waves vote and redo the column together
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-        const bool bad = active && !(l_tot < 0x1p100f && l_tot > 0x1p-100f);
+        // lower bound 2^-64 (not 2^-100): v_exp_f32 flushes below 2^-126, so a row whose LARGEST weight is 2^-w silently drops keys
+        // 2^-(126-w) below it; at 2^-64 (less log2 R <= 10 of spread) every dropped key is < 2^-52 of the sum, under fp32 rounding
+        const bool bad = active && !(l_tot < 0x1p100f && l_tot > 0x1p-64f);
         __shared__ int flags[4];
         const int wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
         if (lane == 0) flags[wave] = wave_bad;

@@ -509,6 +509,7 @@ static int col_attn16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const u
                      "col_attn16: planes must be 16-byte aligned with ld %% 8 == 0");
     RNAMSM_CHECK_ARG(ldc >= (int64_t)H * 64 && (ctx_hi ? ldc % 8 == 0 && ctx_bstride % 8 == 0 && al16(ctx_hi) && al16(ctx_lo) : ldc % 4 == 0 && al16(ctx)),
                      "col_attn16: the context must be 16-byte aligned (ldc %% 8 == 0 for planes, %% 4 for fp32)");
+    RNAMSM_NO_BF16X3(q_lo && fmt == 0, "col_attn16");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int npl = q_lo ? 2 : 1;
     const int var = tuning().attn16;
@@ -538,8 +539,6 @@ static int col_attn16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const u
     if (!q_lo) {
         if (qb2) { if (ctx_hi) CA_GO(1, 0, 1, 2); else CA_GO(1, 0, 0, 2); }
         else { if (ctx_hi) CA_GO(1, 0, 1, 1); else CA_GO(1, 0, 0, 1); }
-    } else if (fmt == 0) {
-        if (ctx_hi) CA_GO(3, 0, 1, 1); else CA_GO(3, 0, 0, 1);
     } else {
         if (ctx_hi) CA_GO(3, 1, 2, 1); else CA_GO(3, 1, 0, 1);
     }

@@ -19,6 +19,15 @@ int fail(int code, const char* fmt, ...);
         if (!(cond)) return ::rnamsm::fail(RNAMSM_ERR_INVALID, __VA_ARGS__); \
     } while (0)
 
+// The hi/lo-bf16 three-product mode ("bf16x3") was removed in round 5: it costs the same three MFMAs per product as f16x3 with
+// 17 instead of 22 operand bits (tests/analysis/README.md held a recorded exceedance of it).  Entry points that take (split, fmt)
+// or lo planes with fmt 0 answer RNAMSM_ERR_UNSUPPORTED.
+#define RNAMSM_NO_BF16X3(cond, name)                                                                                     \
+    do {                                                                                                                 \
+        if (cond)                                                                                                        \
+            return ::rnamsm::fail(RNAMSM_ERR_UNSUPPORTED, name ": hi/lo bf16 pairs (bf16x3) were removed; use fmt 1 (f16x3)"); \
+    } while (0)
+
 #define RNAMSM_CHECK_LAUNCH(name)                                                         \
     do {                                                                                  \
         hipError_t e_ = hipGetLastError();                                                \
@@ -93,6 +102,16 @@ struct Tuning {
     int attn16 = 1;                // 16-bit modes of rnamsm_forward: 1 = attention contractions on the 16-bit matrix cores too, 0 = fp32 attention
 };
 Tuning& tuning();
+// The knobs are process-global A/B instruments, read on the HOST while a driver enqueues its launches.  Writing one while another
+// thread is inside a forward driver would let that forward mix two settings (and, for the arithmetic knobs, two roundings): the
+// drivers count themselves in and rnamsm_set_param refuses (RNAMSM_ERR_INVALID) while the count is non-zero.
+std::atomic<int>& forwards_enqueuing();
+struct ForwardScope {
+    ForwardScope() { forwards_enqueuing().fetch_add(1, std::memory_order_acq_rel); }
+    ~ForwardScope() { forwards_enqueuing().fetch_sub(1, std::memory_order_acq_rel); }
+    ForwardScope(const ForwardScope&) = delete;
+    ForwardScope& operator=(const ForwardScope&) = delete;
+};
 // rnamsm_forward's choice of the 16-bit GEMM tile by the MSA's token count: below ~9-10 k tokens the 256x256 kernels leave most
 // CUs without a tile (out_proj at 8192 tokens: 96 tiles for 256 CUs) and the 128x128 kernel is faster -- whole forward, one
 // process (tools/mid_size_tile_ab.py): 2048 tokens x1.33 (bf16) / x1.59 (f16x3), 4096 x1.14 / x1.32, 8192 x1.11 / x1.10, level at

@@ -475,16 +475,18 @@ extern "C" int rnamsm_pad_mask(const int64_t* tokens, uint8_t* mask, int64_t n, 
 }
 
 namespace rnamsm {
-__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                                                  int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = a[i] + b[i];
+// (no __restrict__: include/rnamsm.h lets `out` alias `a` or `b`; grid-stride: the grid is capped, any n is covered)
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, float* out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = a[i] + b[i];
 }
 }  // namespace rnamsm
 
 extern "C" int rnamsm_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
     RNAMSM_CHECK_ARG(a && b && out && n > 0, "add: bad arguments");
-    hipLaunchKernelGGL(rnamsm::add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a, b, out, n);
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(rnamsm::add_kernel, dim3((unsigned)(blocks < (1 << 20) ? blocks : (1 << 20))), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), a, b, out, n);
     RNAMSM_CHECK_LAUNCH("add");
     return RNAMSM_OK;
 }

@@ -72,6 +72,8 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
                               int dtype, const uint16_t* const* weight_planes, const float* const* ln_folded,
                               const void* const* ln_folded16, void* stream) {
     RNAMSM_CHECK_ARG(dtype >= RNAMSM_F32 && dtype <= RNAMSM_F16X3, "forward: unknown dtype %d", dtype);
+    RNAMSM_NO_BF16X3(dtype == RNAMSM_BF16X3_REMOVED, "forward");
+    ForwardScope in_flight;                                  // rnamsm_set_param refuses until the launches are enqueued (common.h)
     RNAMSM_CHECK_ARG(dtype == RNAMSM_F32 || weight_planes, "forward: bf16 modes need weight_planes");
     RNAMSM_CHECK_ARG(dims && weights && tokens && workspace && row_attn && repr && emb && atp, "forward: null pointer");
     const rnamsm_model_dims& d = *dims;
@@ -424,6 +426,8 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
                                     const float* const* ln_folded, int dtype, const uint16_t* const* weight_planes, void* stream) {
     RNAMSM_CHECK_ARG(dims && weights && tokens && workspace && row_attn && repr && emb && atp, "forward_batch: null pointer");
     RNAMSM_CHECK_ARG(dtype >= RNAMSM_F32 && dtype <= RNAMSM_F16X3, "forward_batch: unknown dtype %d", dtype);
+    RNAMSM_NO_BF16X3(dtype == RNAMSM_BF16X3_REMOVED, "forward_batch");
+    ForwardScope in_flight;
     RNAMSM_CHECK_ARG(dtype == RNAMSM_F32 || (weight_planes && tuning().attn16 != 0),
                      "forward_batch: the 16-bit modes need weight_planes (and the attn16 knob on: planes end to end)");
     const rnamsm_model_dims& d = *dims;
@@ -674,6 +678,7 @@ extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float*
     RNAMSM_CHECK_ARG(dims && weights && tokens && shapes && workspace && row_attn && repr && emb && atp, "forward_packed: null pointer");
     if (dtype != RNAMSM_F32)
         return fail(RNAMSM_ERR_UNSUPPORTED, "forward_packed: the exact fp32 path only (16-bit batches: rnamsm_forward_batch)");
+    ForwardScope in_flight;
     const rnamsm_model_dims& d = *dims;
     const int D = d.embed_dim, H = d.num_heads, F = d.ffn_dim, NL = d.num_layers;
     RNAMSM_CHECK_ARG(D > 0 && H > 0 && D == H * 64, "forward_packed: embed_dim must be num_heads * 64 (D=%d H=%d)", D, H);

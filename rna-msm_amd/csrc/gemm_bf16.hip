@@ -1170,6 +1170,7 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
     RNAMSM_CHECK_ARG(!A_hi || O_hi || act == RNAMSM_ACT_NONE, "gemm_bf16: plane input with fp32 output supports act none only");
     RNAMSM_CHECK_ARG(split == 1 || (split == 3 && W_lo), "gemm_bf16: split must be 1, or 3 with a lo plane");
     RNAMSM_CHECK_ARG((fmt == 0) || (fmt == 1 && split == 3), "gemm_bf16: fmt 0 (bf16) or 1 (fp16, split 3 only)");
+    RNAMSM_NO_BF16X3(split == 3 && fmt == 0, "gemm_bf16");
     RNAMSM_CHECK_ARG(M > 0 && M <= INT32_MAX && N > 0 && K > 0, "gemm_bf16: bad shape");
     RNAMSM_CHECK_ARG(N % HB_BN == 0 && K % HB_BK == 0, "gemm_bf16: need N %% 128 == 0 and K %% 64 == 0 (N=%d K=%d)", N, K);
     RNAMSM_CHECK_ARG(lda >= K && lda % 8 == 0 && ldc >= N && ldc % 4 == 0, "gemm_bf16: bad leading dimension");
@@ -1223,7 +1224,6 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
                         : HB_GO(RNAMSM_ACT_NONE, false, SP_, FMT_, false, false);                                   \
     } while (0)
     if (fmt == 1) HB_ACT_RES(3, 1);
-    if (split == 3) HB_ACT_RES(3, 0);
     HB_ACT_RES(1, 0);
 #undef HB_ACT_RES
 #undef HD_GO
@@ -1263,8 +1263,8 @@ extern "C" int rnamsm_gemm16_lnfold(const uint16_t* X_hi, const uint16_t* X_lo, 
             return gelu ? LF_HQ(RNAMSM_ACT_GELU_ERF) : LF_HQ(RNAMSM_ACT_NONE);
         return gelu ? LF_HS(RNAMSM_ACT_GELU_ERF, 1, 0, 64) : LF_HS(RNAMSM_ACT_NONE, 1, 0, 64);
     }
-    if (fmt == 1) return gelu ? LF_HS(RNAMSM_ACT_GELU_ERF, 3, 1, 32) : LF_HS(RNAMSM_ACT_NONE, 3, 1, 32);
-    return gelu ? LF_HS(RNAMSM_ACT_GELU_ERF, 3, 0, 32) : LF_HS(RNAMSM_ACT_NONE, 3, 0, 32);
+    RNAMSM_NO_BF16X3(fmt == 0, "gemm16_lnfold");
+    return gelu ? LF_HS(RNAMSM_ACT_GELU_ERF, 3, 1, 32) : LF_HS(RNAMSM_ACT_NONE, 3, 1, 32);
 #undef LF_HQ
 #undef LF_HS
 }
@@ -1294,8 +1294,8 @@ extern "C" int rnamsm_gemm16_residual_stats(const uint16_t* A_hi, const uint16_t
 #define RS_HS(SP_, FMT_, BK_) \
     launch_hs<RNAMSM_ACT_NONE, true, SP_, FMT_, false, BK_>(W_hi, W_lo, bias, x, ldx, x, ldx, lda, m, N, K, 1.f, 0, A_hi, A_lo, nullptr, nullptr, s, fa)
     if (split == 1) return RS_HS(1, 0, 64);
-    if (fmt == 1) return RS_HS(3, 1, 32);
-    return RS_HS(3, 0, 32);
+    RNAMSM_NO_BF16X3(fmt == 0, "gemm16_residual_stats");
+    return RS_HS(3, 1, 32);
 #undef RS_HS
 }
 

@@ -975,8 +975,8 @@ static int row_logits16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const
         hipLaunchKernelGGL((row_logits16_kernel<SP_, FMT_>), dim3(grid, batch), dim3(R16_THREADS), R16Cfg<SP_>::LDS, s, q_hi, \
                            q_lo, k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale, qk_bstride, part_bstride, true_rows); \
     } while (0)
+    RNAMSM_NO_BF16X3(q_lo && fmt == 0, "row_logits16");
     if (!q_lo) RL_GO(1, 0);
-    else if (fmt == 0) RL_GO(3, 0);
     else RL_GO(3, 1);
 #undef RL_GO
     RNAMSM_CHECK_LAUNCH("row_logits16");
@@ -1061,10 +1061,9 @@ static int row_apply16_launch(const uint16_t* p_hi, const uint16_t* p_lo, int64_
         hipLaunchKernelGGL((row_apply16_kernel<SP_, FMT_, OUT_>), dim3(grid, batch), dim3(R16_THREADS), R16Cfg<SP_>::LDS, s, p_hi, \
                            p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride); \
     } while (0)
+    RNAMSM_NO_BF16X3(p_lo && fmt == 0, "row_apply16");
     if (!p_lo) {
         if (ctx_hi) RA_GO(1, 0, 1); else RA_GO(1, 0, 0);
-    } else if (fmt == 0) {
-        if (ctx_hi) RA_GO(3, 0, 1); else RA_GO(3, 0, 0);
     } else {
         if (ctx_hi) RA_GO(3, 1, 2); else RA_GO(3, 1, 0);
     }

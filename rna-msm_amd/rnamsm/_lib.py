@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RNAMSM_LIB_PATH") or os.path.join(_HERE, "librnamsm_hip.so")    # override: A/B builds only
 
 RNAMSM_OK = 0
-F32, BF16, BF16X3, F16X3 = 0, 1, 2, 3
-DTYPES = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3, "f16x3": F16X3}
+F32, BF16, F16X3 = 0, 1, 3        # (2 was "bf16x3", removed in round 5: include/rnamsm.h)
+DTYPES = {"f32": F32, "bf16": BF16, "f16x3": F16X3}
 ACT_NONE, ACT_GELU_ERF = 0, 1
 OUT_REPR = 1
 

@@ -31,7 +31,7 @@ class DataConfig:                       # RNA_MSM_Inference.py:20-32
     # round 3: a lone forward of a few hundred tokens costs 5.5 ms on a mostly idle chip; data.batch_small_msas=false
     # restores the strictly one-by-one loop of the reference (RNA_MSM_Inference.py:141-148)
     batch_small_msas: bool = True
-    # ... and in the 16-bit arithmetic modes (model.gemm_dtype = bf16 | bf16x3 | f16x3) only on request: there a ragged batch picks
+    # ... and in the 16-bit arithmetic modes (model.gemm_dtype = bf16 | f16x3) only on request: there a ragged batch picks
     # its GEMM kernels by the BATCH's token count, so an alignment's files would depend (at the mode's rounding level, ~1e-2
     # in bf16) on what else is in the id list; one by one every alignment's output is a function of that alignment alone
     batch_small_msas_16bit: bool = False
@@ -53,7 +53,7 @@ class MSATransformerModelConfig:        # RNA_MSM_Inference.py:35-43
     dropout: float = 0.1
     attention_dropout: float = 0.1
     activation_dropout: float = 0.1
-    # extra (not in the reference): arithmetic of the Linear GEMMs -- f32 (exact, default) | f16x3 | bf16x3 | bf16
+    # extra (not in the reference): arithmetic of the Linear GEMMs -- f32 (exact, default) | f16x3 | bf16
     gemm_dtype: str = "f32"
 
 

@@ -229,7 +229,7 @@ PACKED_TOKENS, PACKED_MEMBERS, PACKED_SMALL_TOKENS = 65536, 256, 8192
 # (packed exact ~650 k residues/s; a lone forward costs 2.6 ms of launches in bf16, 3.4 ms in the hi/lo modes, up to a few thousand
 # tokens).  Measured (MODE=bf16 | f16x3 tools/cli_throughput.py, 64 alignments): bf16 tiny x2.1, small x1.0-1.2, mid x0.86-0.91 at a
 # limit of 2048-4096 -- hence 1024 there; f16x3 tiny x2.8, small x1.55, mid x1.00 at 2048.
-PACKED_SMALL_TOKENS_16BIT = {"bf16": 1024, "bf16x3": 2048, "f16x3": 2048}
+PACKED_SMALL_TOKENS_16BIT = {"bf16": 1024, "f16x3": 2048}
 
 
 def joins_packed(group_shapes: List[tuple], shape: tuple) -> bool:
@@ -371,16 +371,27 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                     flush()
                 pool.clear()
 
+            def alone(i: int, t: torch.Tensor) -> dict:
+                """One member of a group by itself, in the arithmetic the GROUP runs in: the model's mode -- except that in a
+                16-bit mode the small alignments are the EXACT packed path's (a group of one must not come out in bf16 because it
+                had no company: ADVICE r04), so there a lone one is a packed batch of one."""
+                if packing and not exact:
+                    try:
+                        return model.forward_ragged([t], packed=True)[0]
+                    except IndexError:
+                        raise IndexError(f"{ids[i]}: token or position index out of range") from None
+                return model.checked_forward_one(t, need_repr=False, what=ids[i])
+
             def flush() -> None:
                 if len(group) == 1:
                     idx0, t0 = group[0]
-                    out = model.checked_forward_one(t0, need_repr=False, what=ids[idx0])
-                    deliver(idx0, out["emb"], out["atp"])
+                    out = alone(idx0, t0)
+                    deliver(idx0, out["emb"].contiguous(), out["atp"].contiguous())
                 elif group:
                     try:
                         outs = model.forward_ragged([t for _, t in group], packed=packing)
                     except IndexError:                                # name the offending alignment: one by one
-                        outs = [model.checked_forward_one(t, need_repr=False, what=ids[i]) for i, t in group]
+                        outs = [alone(i, t) for i, t in group]
                     for (i, _), out in zip(group, outs):
                         deliver(i, out["emb"].contiguous(), out["atp"].contiguous())
                 group.clear()
@@ -409,15 +420,19 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
 
             try:
                 read_and_run()
-            except BaseException:
+            except Exception:
                 # a bad alignment late in the list must not cost the results already computed or read: what waits in the
                 # group / pool is run and written (as the one-by-one loop would have done before reaching it), then the
-                # error goes up.  A second failure in here is dropped in favour of the first.
-                try:
-                    flush()
-                    run_pool()
-                except BaseException:                                 # noqa: BLE001
-                    pass
+                # error goes up.  KeyboardInterrupt / SystemExit are not caught: they propagate at once.  Under a gatherer the
+                # peers are not known to be in the same state (a deliver() could block on them): no salvage there.  A second
+                # failure in here is reported and dropped in favour of the first.
+                if gatherer is None:
+                    try:
+                        flush()
+                        run_pool()
+                    except Exception as second:                       # noqa: BLE001
+                        import warnings
+                        warnings.warn(f"while writing the results computed before the error: {type(second).__name__}: {second}")
                 raise
             flush()
             run_pool()

@@ -94,7 +94,7 @@ class MSATransformer(nn.Module):
         self._workspace = None
         self._lm_pad = None
         self.compute_logits = True        # model.py:402; forward(need_logits=False) skips the LM head
-        # Arithmetic of the contractions: "f32" (exact, default), "f16x3", "bf16x3" or "bf16" (include/rnamsm.h) -- for the
+        # Arithmetic of the contractions: "f32" (exact, default), "f16x3" or "bf16" (include/rnamsm.h) -- for the
         # C++ driver and, through the property below, for every mirror module of the layer-wise path
         self.gemm_dtype = "f32"
         # forward(tokens[B,R,C]) with B > 1 (any arithmetic mode): MSAs are run together (rnamsm_forward_batch) in groups of

@@ -52,7 +52,7 @@ class _PackedQKV:
         return self._w, self._b
 
 
-GEMM_DTYPES = ("f32", "f16x3", "bf16x3", "bf16")
+GEMM_DTYPES = ("f32", "f16x3", "bf16")
 
 
 def _mode_of(module: nn.Module):

@@ -222,7 +222,7 @@ def split_bf16(w: torch.Tensor, want_lo: bool = True, fmt: int = 0):
 def linear_bf16(a: torch.Tensor, w_hi: torch.Tensor, w_lo: Optional[torch.Tensor], bias: Optional[torch.Tensor] = None,
                 act: int = ACT_NONE, residual: Optional[torch.Tensor] = None, scale: float = 1.0, scale_cols: int = 0,
                 out: Optional[torch.Tensor] = None, split: int = 3, fmt: int = 0) -> torch.Tensor:
-    """`linear` on the 16-bit matrix cores: split = 1 (bf16 operands) or 3 (hi/lo split; fmt 0 = bf16x3, 1 = f16x3)."""
+    """`linear` on the 16-bit matrix cores: split = 1 (bf16 operands) or 3 (hi/lo fp16 split: fmt must be 1 = f16x3)."""
     M, K = a.shape
     N = w_hi.shape[0]
     if out is None:

@@ -17,7 +17,7 @@ m.load_state_dict({k: torch.from_numpy(v) for k, v in truth.state().items()}, st
 m = m.eval().to(dev)
 t_emb, t_atp = truth.oracle_outputs(toks, torch.float64, dev)
 t = torch.from_numpy(toks).to(dev)
-for mode in ("f16x3", "bf16x3"):
+for mode in ("f16x3",):
     m.gemm_dtype = mode
     for cap in (0, 128, 64, 32, 16, 8):
         _lib.check(lib.rnamsm_set_param(b"row16_max_rows", cap))

@@ -64,7 +64,7 @@ def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mod
                 C = int(rng.choice(EDGES[1:])) if rng.random() < 0.6 else int(rng.integers(2, 301))
                 if R * C <= max_tokens:
                     break
-            mode = str(rng.choice(["f32", "f32", "f16x3", "bf16x3", "bf16"]))
+            mode = str(rng.choice(["f32", "f32", "f16x3", "f16x3", "bf16"]))      # (same stream as before; the bf16x3 draws now run f16x3: the mode was removed in round 5)
             knobs = {"ln_fold": int(rng.choice([0, 1, 2, 3])), "gemm_tile": int(rng.choice([0, 1, 2])),
                      "col_dma": int(rng.choice([-1, 0, 1])), "row_vt": int(rng.choice([0, 1])), "attn16": int(rng.choice([0, 1, 1])),
                      "gemm_splitk": int(rng.choice([0, 1, 1, 2, 4, 8])), "col_fast": int(rng.choice([0, 1, 1])),

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""End-to-end error and speed of the GEMM arithmetic modes (f32 / bf16x3 / bf16) of rnamsm_forward:
+"""End-to-end error and speed of the GEMM arithmetic modes (f32 / f16x3 / bf16) of rnamsm_forward:
 error vs the reference fixtures (fp32 and fp64 runs of the reference) and vs the CPU oracle at M=64, L=128."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
@@ -16,7 +16,7 @@ toks64 = synthetic.make_tokens(64, 128, 0)
 res = O.forward(torch.from_numpy(toks64), O.to_torch_params(state, torch.float64))
 o_emb, o_atp = (t.numpy() for t in O.pack_outputs(res))
 from rnamsm import _lib
-for mode, attn16 in (("f32", 1), ("f16x3", 0), ("f16x3", 1), ("bf16x3", 0), ("bf16x3", 1), ("bf16", 0), ("bf16", 1)):
+for mode, attn16 in (("f32", 1), ("f16x3", 0), ("f16x3", 1), ("bf16", 0), ("bf16", 1)):
     m.gemm_dtype = mode
     _lib.check(_lib.load().rnamsm_set_param(b"attn16", attn16))
     line = [f"{mode} attn16={attn16}"]

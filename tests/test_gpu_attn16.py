@@ -4,7 +4,7 @@ Two references per case, both fp64 on the host:
   * "eff": the contraction evaluated on the values the planes actually hold (hi, or hi + lo).  What the kernel adds to
     that is fp32 accumulation and, for the x3 modes, the dropped lo*lo term (2^-16 relative for bf16 pairs, 2^-22 for
     fp16 pairs): a TIGHT bound that catches any wrong lane / swizzle / transposed-read mapping in every mode;
-  * the contraction on the original fp32 operands, at the mode's stated accuracy (bf16 2^-9 operands, bf16x3 ~2^-17,
+  * the contraction on the original fp32 operands, at the mode's stated accuracy (bf16 2^-9 operands,
     f16x3 ~2^-22 = fp32-grade).
 Integer operands are exactly representable in both 16-bit formats, so row_logits16 / row_apply16 must be bit-exact.
 """
@@ -22,7 +22,7 @@ ATT_SHAPES = [(1, 5, 2), (7, 33, 2), (34, 66, 2), (6, 19, 12), (3, 130, 2), (65,
               (8, 300, 2), (5, 520, 1), (9, 257, 2), (4, 256, 1), (3, 300, 1),
               (64, 128, 12), (96, 70, 12)]       # thousands of blocks, several resident per CU: staging races show up here
 # (split, fmt, tolerance vs eff operands, tolerance vs fp32 operands)
-MODES = [(1, 0, 2e-6, 8e-3), (3, 0, 4e-5, 4e-5), (3, 1, 3e-6, 3e-6)]
+MODES = [(1, 0, 2e-6, 8e-3), (3, 1, 3e-6, 3e-6)]
 
 
 @pytest.fixture(scope="module")
@@ -94,7 +94,7 @@ def test_row_attention_16bit(dev, R, C, H, split, fmt, tol_eff, tol_f32):
 
 
 @pytest.mark.parametrize("R,C", [(5, 150), (6, 300)])
-@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 0), (3, 1)])
+@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 1)])
 def test_row_kernels_16bit_are_exact_on_integers(dev, split, fmt, R, C):
     """Small integers are exact in bf16 and fp16 (lo planes = 0) and every partial sum is exact in fp32: the result must
     equal the integer contraction bit for bit.  The data are asymmetric in every index, so a transposed tile, a swapped
@@ -204,7 +204,7 @@ def test_col_attention_16bit_online_softmax_rescale(dev, split, fmt):
         assert rel_l2(ctx, want.reshape(R * C, 64)) < (3e-3 if split == 1 else 3e-6)
 
 
-@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 0)])
+@pytest.mark.parametrize("split,fmt", [(1, 0)])
 @pytest.mark.parametrize("R", [40, 200, 300])
 def test_col_attention_16bit_fast_loop_falls_back_when_a_score_overflows_its_reference(dev, split, fmt, R):
     """The bf16 column kernel fixes every query's softmax reference from its first 32 keys (no running maximum) and redoes a
@@ -243,7 +243,7 @@ def test_col_attention_16bit_fast_loop_falls_back_when_a_score_overflows_its_ref
         assert np.abs(gv[i, 1, :64].numpy() - wv[i, 1, :64].numpy()).max() < 1e-2
 
 
-@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 0), (3, 1)])
+@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 1)])
 @pytest.mark.parametrize("R,C,H", [(7, 33, 2), (130, 5, 2), (300, 4, 1), (256, 3, 2)])
 def test_col_attention_16bit_plane_outputs_equal_the_rounded_fp32_output(dev, split, fmt, R, C, H):
     """The forward reads the context as 16-bit planes written through the kernel's LDS-transposed epilogue: hi must be the
@@ -274,7 +274,7 @@ def test_col_attention_16bit_plane_outputs_equal_the_rounded_fp32_output(dev, sp
         assert lo is None
 
 
-@pytest.mark.parametrize("split", [1, 3])
+@pytest.mark.parametrize("split", [1])
 @pytest.mark.parametrize("R,C,H", [(7, 33, 2), (40, 9, 2), (130, 5, 2), (300, 4, 1), (256, 3, 2), (64, 128, 12)])
 def test_col_attention_16bit_with_prescaled_q(dev, split, R, C, H):
     """rnamsm_col_attn16_prescaled (what rnamsm_forward runs in the bf16 modes): the q planes hold q * dh^-0.5 * log2(e), rounded

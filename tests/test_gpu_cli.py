@@ -230,3 +230,44 @@ def test_cli_in_a_16bit_mode_runs_its_small_alignments_on_the_exact_packed_path(
             assert rel_l2(default[e], exact[e]) < 1e-5, i                          # the exact path's values ...
             assert rel_l2(bf16_alone[e], exact[e]) > 1e-3, i                       # ... which bf16 alone is far from
         assert np.array_equal(own[e], bf16_alone[e]), i
+
+
+def test_cli_in_a_16bit_mode_a_lone_small_alignment_still_takes_the_exact_path(tmp_path):
+    """whether a small alignment's files carry fp32 or bf16 rounding must not depend on whether it had company.  A bf16
+    list with exactly ONE small alignment (and one large one, which runs alone in bf16): the small one's files must be the exact
+    path's (a packed batch of one), to fp32 rounding -- and identical to what it gets inside a group of small ones."""
+    from rnamsm.config import Config
+    from rnamsm.inference import extract_feat
+    from rnamsm.model import MSATransformer
+    state = synthetic.make_state_dict(seed=0)
+    model = MSATransformer(num_layers=10)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    records = open(os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2")).read().splitlines()
+    names, seqs = records[0::2], records[1::2]
+    shapes = {"rnaA": (9, 35), "rnaB": (40, 70), "rnaC": (3, 20), "rnaD": (5, 28)}      # rnaB: 2840 tokens > 1024
+
+    def run(tag, dtype, ids, **flags):
+        root = tmp_path / tag
+        (root / "results").mkdir(parents=True)
+        for i in ids:
+            depth, length = shapes[i]
+            (root / "results" / f"{i}.a2m_msa2").write_text("".join(f"{names[r]}\n{(seqs[r] * 2)[:length]}\n" for r in range(depth)))
+        (root / "rna_id.txt").write_text("\n".join(ids) + "\n")
+        cfg = Config()
+        cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = str(root), "results", "rna_id.txt"
+        cfg.data.sample_method, cfg.data.max_seqs_per_msa = "first", 64
+        for k, v in flags.items():
+            setattr(cfg.data, k, v)
+        cfg.model.gemm_dtype = dtype
+        try:
+            assert extract_feat(cfg, model=model) == sorted(ids)
+        finally:
+            model.gemm_dtype = "f32"
+        return {f.name: np.load(f) for f in sorted((root / "results").glob("*.npy"))}
+    exact = run("exact", "f32", ["rnaA"], batch_small_msas=False)
+    lone = run("bf16_lone_small", "bf16", ["rnaA", "rnaB"])
+    grouped = run("bf16_group_of_small", "bf16", ["rnaA", "rnaB", "rnaC", "rnaD"])
+    for name in ("rnaA_emb.npy", "rnaA_atp.npy"):
+        assert rel_l2(lone[name], exact[name]) < 1e-5, name                       # fp32 rounding, not bf16's ~1e-2
+        assert np.array_equal(lone[name], grouped[name]), name                    # ... and the same bits with or without company
+    assert np.array_equal(lone["rnaB_emb.npy"], grouped["rnaB_emb.npy"])          # the large one: alone in bf16 either way

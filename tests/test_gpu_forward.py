@@ -78,10 +78,10 @@ def test_contact_head_kernel_on_random_maps_with_large_weights(model):
         assert got.shape == (C - 1, C - 1) and np.abs(got - want).max() < 2e-5, C
 
 
-@pytest.mark.parametrize("mode,emb_tol,atp_tol", [("f16x3", 1e-4, 1e-4), ("bf16x3", 1e-4, 1e-3), ("bf16", 5e-2, 3e-1)])
+@pytest.mark.parametrize("mode,emb_tol,atp_tol", [("f16x3", 1e-4, 1e-4), ("bf16", 5e-2, 3e-1)])
 def test_gemm_arithmetic_modes_of_the_forward(model, mode, emb_tol, atp_tol):
     """Linear GEMMs on the 16-bit matrix cores (model.gemm_dtype): f16x3 must meet the SAME 1e-4 bar as the exact
-    path (observed ~2e-6, the fp32 noise floor); bf16x3 meets it for emb and 1e-3 for the maps; bf16 is the
+    path (observed ~2e-6, the fp32 noise floor); bf16 is the
     mixed-precision mode of BASELINE config 4, gated at the reference's own bf16 drift (emb rel 2.2e-2, atp 9e-2,
     SURVEY §6) with margin."""
     m, state = model
@@ -309,13 +309,13 @@ def test_forward_shape_sweep_against_oracle_all_fp32_grade_modes(model, R, C):
     """Shapes chosen to cross every kernel-selection threshold with ragged edges: C = 2 (the minimum), C >= 256 (256x256
     row kernels of the 16-bit modes), tiny and odd R (a lone alignment row in a 2- or 4-row block), T = R*C small enough
     for the half-width GEMM tile and the 128x128 16-bit GEMM.  Exact fp32 and f16x3 must both hold the 1e-4 bar against
-    the oracle; bf16x3 its own (1e-3 on the maps)."""
+    the oracle."""
     m, state = model
     toks = synthetic.make_tokens(R, C, 100 + R)
     emb, atp = O.pack_outputs(O.forward(torch.from_numpy(toks), O.to_torch_params(state)))
     t = torch.from_numpy(toks).to("cuda:0")
     try:
-        for mode, emb_tol, atp_tol in (("f32", 1e-4, 1e-4), ("f16x3", 1e-4, 1e-4), ("bf16x3", 2e-4, 1e-3)):
+        for mode, emb_tol, atp_tol in (("f32", 1e-4, 1e-4), ("f16x3", 1e-4, 1e-4)):
             m.gemm_dtype = mode
             out = m.forward_one(t)
             assert out["emb"].shape == (C - 1, 768) and out["atp"].shape == (120, C - 1, C - 1)
@@ -405,7 +405,7 @@ def test_padded_batch_on_the_chunked_path_matches_reference_fixture(model, mode)
         m.max_tokens_per_msa_(2 ** 14)
 
 
-@pytest.mark.parametrize("mode", ["f16x3", "bf16x3", "bf16"])
+@pytest.mark.parametrize("mode", ["f16x3", "bf16"])
 def test_module_path_runs_the_16bit_modes_like_the_driver(model, mode):
     """VERDICT r01 missing #5: `model.gemm_dtype` reaches the mirror modules (RowSelfAttention, ColumnSelfAttention,
     FeedForwardNetwork via NormalizedResidualBlock / AxialTransformerLayer), so the layer-wise path -- taken whenever an
@@ -425,7 +425,7 @@ def test_module_path_runs_the_16bit_modes_like_the_driver(model, mode):
         tol, atol = (2e-5, 1e-4) if mode != "bf16" else (2e-2, 2e-1)
         assert rel_l2(res["representations"][10][0].cpu().numpy(), fast["repr"].cpu().numpy()) < tol
         assert np.abs(res["row_attentions"][0].cpu().numpy() - fast["row_attn"].cpu().numpy()).max() < atol
-        emb_tol, atp_tol = {"f16x3": (1e-4, 1e-4), "bf16x3": (1e-4, 1e-3), "bf16": (5e-2, 3e-1)}[mode]
+        emb_tol, atp_tol = {"f16x3": (1e-4, 1e-4), "bf16": (5e-2, 3e-1)}[mode]
         assert rel_l2(res["representations"][10][0, 0, 1:].cpu().numpy(), g["emb"]) < emb_tol
         atp = res["row_attentions"][0][..., 1:, 1:].reshape(-1, 32, 32).cpu().numpy()
         assert np.abs(atp - g["atp"]).max() < atp_tol
@@ -566,7 +566,7 @@ def test_forward_falls_back_when_the_folded_layernorm_precondition_fails(model):
     assert torch.equal(got["emb"], want["emb"]) and torch.equal(got["atp"], want["atp"])
 
 
-@pytest.mark.parametrize("mode,emb_tol", [("f16x3", 2e-5), ("bf16x3", 2e-4), ("bf16", 0.08)])
+@pytest.mark.parametrize("mode,emb_tol", [("f16x3", 2e-5), ("bf16", 0.08)])
 def test_folded_layernorm_in_the_16bit_modes(model, mode, emb_tol):
     """Knob ln_fold = 3 also folds LayerNorm in the 16-bit modes (rnamsm_gemm16_lnfold / rnamsm_gemm16_residual_stats: the
     residual GEMMs write the new x as planes + slab sums, the QKV / fc1 GEMMs read the raw planes).  Measured neutral in
@@ -907,7 +907,7 @@ def test_16bit_overflow_sets_the_nonfinite_bit_and_is_redone_on_fp32():
     assert int(m.checked_forward_one(toks)["err"].item()) & m.ERR_NONFINITE
 
 
-@pytest.mark.parametrize("mode,emb_tol,atp_tol", [("f16x3", 1e-4, 1e-4), ("bf16x3", 1e-4, 1e-3), ("bf16", 5e-2, 3e-1)])
+@pytest.mark.parametrize("mode,emb_tol,atp_tol", [("f16x3", 1e-4, 1e-4), ("bf16", 5e-2, 3e-1)])
 def test_batched_and_ragged_forward_in_the_16bit_modes(model, mode, emb_tol, atp_tol):
     """rnamsm_forward_batch runs the 16-bit modes too (plane data flow, K4'..K7' with the MSA on gridDim.y,
     the ragged batch's per-MSA logit scale on the fp32 accumulators).  Which GEMM kernel runs depends on the batch's token

@@ -136,7 +136,7 @@ def test_every_baseline_config_against_fp64_truth(model, label, make):
         rep["oracle_cpu_f32"] = y["oracle_cpu_f32"]
         rep["oracle_cpu_f32_source"] = f"tests/golden/{COMMITTED_YARDSTICK[cfg]} ({y['cpu_seconds']:.0f} s of {y['threads']} threads, {y['cpu_model']})"
     e_ref = rep["oracle_cpu_f32"]            # the reference's own fp32 arithmetic (PyTorch CPU): measured here or committed
-    for mode in ("f32", "f16x3", "bf16x3", "bf16"):
+    for mode in ("f32", "f16x3", "bf16"):
         rep[f"hip_{mode}"] = truth.errors(*hip_outputs(model, toks, mode), t_emb, t_atp)
     REPORT[label] = rep
     print(json.dumps({label: rep}))

@@ -327,7 +327,7 @@ def test_col_attention_for_shallow_alignments_one_wave_per_problem(dev, R, C, H)
 @pytest.mark.parametrize("R,C,H", [(1, 7, 3), (8, 64, 12), (16, 130, 4), (17, 33, 2), (100, 30, 3), (129, 5, 1), (300, 4, 2)])
 def test_col_attention_on_prescaled_q_without_a_running_maximum(dev, R, C, H):
     """rnamsm_col_attn_fused_prescaled (round 4; what the exact-path forward calls without padding): q carries dh^-1/2 * log2(e), the
-    first pass exponentiates the raw scores (no running maximum, no rescale) and a block whose row sums leave [2^-100, 2^100]
+    first pass exponentiates the raw scores (no running maximum, no rescale) and a block whose row sums leave [2^-64, 2^100]
     redoes its column with the online softmax.  Against fp64 on the prescaled operands at the bar of the natural-domain kernel,
     against that kernel on q / log2(e) (rounding apart), with the TRACKED loop forced (knob "col_fast" = 0), restricted to the
     first query rows (bit-identical to the full launch), and with scores far outside exp2's range in both directions: a query
@@ -748,13 +748,13 @@ def test_chunked_path_padding_mask_kernels(dev, R, C, max_tokens):
 @pytest.mark.parametrize("M,N,K", [(1, 128, 64), (300, 384, 128), (1025, 768, 768), (513, 768, 3072)])
 def test_gemm_16bit_matrix_core_modes(dev, M, N, K):
     """rnamsm_gemm_bf16 (include/rnamsm.h): stated error of each operand mode vs fp64 -- bf16 (2^-9 operands),
-    bf16x3 (hi/lo bf16, ~2^-17), f16x3 (hi/lo fp16, ~2^-22: the same as the exact-fp32 kernel) -- with every epilogue."""
+    f16x3 (hi/lo fp16, ~2^-22: the same as the exact-fp32 kernel) -- with every epilogue."""
     from rnamsm import ops
     from rnamsm._lib import ACT_GELU_ERF
     a, w, b, r = _rand("h.a", (M, K)), _rand("h.w", (N, K), 0.05), _rand("h.b", (N,), 0.1), _rand("h.r", (M, N))
     base = a.double() @ w.double().t() + b.double()
     planes = {0: ops.split_bf16(w.to(dev), fmt=0), 1: ops.split_bf16(w.to(dev), fmt=1)}
-    for split, fmt, tol in ((1, 0, 6e-3), (3, 0, 3e-5), (3, 1, 3e-6)):
+    for split, fmt, tol in ((1, 0, 6e-3), (3, 1, 3e-6)):
         hi, lo = planes[fmt]
         y = ops.linear_bf16(a.to(dev), hi, lo if split == 3 else None, b.to(dev), split=split, fmt=fmt).cpu()
         assert rel_l2(y, base) < tol, (split, fmt)
@@ -788,7 +788,7 @@ def test_plane_input_gemm_kernels_agree(dev, M, N, K):
         for variant, group in ((0, 0), (1, 0), (2, 0), (3, 0), (3, 1), (3, 5), (4, 0)):
             _lib.check(lib.rnamsm_set_param(b"gemm16_dma", variant))
             _lib.check(lib.rnamsm_set_param(b"gemm_group", group))
-            for split, fmt, tol in ((1, 0, 2e-6), (3, 0, 4e-5), (3, 1, 3e-6)):
+            for split, fmt, tol in ((1, 0, 2e-6), (3, 1, 3e-6)):
                 ht = torch.float16 if fmt == 1 else torch.bfloat16
                 ap = ops.split_bf16(a.to(dev), want_lo=split == 3, fmt=fmt)
                 wp = ops.split_bf16(w.to(dev), want_lo=split == 3, fmt=fmt)
@@ -810,7 +810,7 @@ def test_plane_input_gemm_kernels_agree(dev, M, N, K):
         _lib.check(lib.rnamsm_set_param(b"gemm_group", 0))
 
 
-@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 0), (3, 1)])
+@pytest.mark.parametrize("split,fmt", [(1, 0), (3, 1)])
 def test_layernorm_folded_into_the_16bit_gemms(dev, split, fmt):
     """K1 folded in the 16-bit modes: a producer (out_proj shape: x += ctx W^T + b, new x also as planes + slab sums) feeding a
     consumer (QKV shape with q scaling; fc1 shape with GELU) that reads the RAW x planes and applies (mean, rstd) to its

@@ -256,6 +256,10 @@ def test_library_validates_arguments_without_a_gpu(lib):
     assert rc == -1 and b"N % 128" in lib.rnamsm_last_error()
     rc = lib.rnamsm_gemm_bias_act_res(16, 32, 16, None, None, 0, 16, 128, 4, 128, 32, 0, 1.0, 0, None, 1, None)
     assert rc == -2                                                  # RNAMSM_BF16 reserved
+    # the hi/lo-bf16 mode ("bf16x3", dtype 2 / split 3 with fmt 0) was removed in round 5: UNSUPPORTED, not a silent other mode
+    rc = lib.rnamsm_gemm_bf16(16, 64, 16, 16, None, None, 0, 16, 128, 4, 128, 64, 0, 1.0, 0, 3, 0, None, None, None, None, None)
+    assert rc == -2 and b"bf16x3" in lib.rnamsm_last_error()
+    assert "bf16x3" not in _lib.DTYPES
     rc = lib.rnamsm_col_attn_fused(16, 16, 16, 64, 16, 64, 4, 4, 1, 32, None, None, None, 0, 0, None)
     assert rc == -1 and b"head_dim" in lib.rnamsm_last_error()
     rc = lib.rnamsm_embed_ln(16, 16, 16, 16, 16, 16, 16, 1025, 4, 768, 12, 1026, 1, 1e-5, None, None)
