@@ -247,6 +247,98 @@ def cpu_baseline(M, L, state):
                       + f"; cross-check: one layer (embedding + final LayerNorm included) median of 3 = {med:.2f} s"}
 
 
+def torch_rocm_eager(M, L, state, dev):
+    """What a user of the reference gets on THIS box today: the reference's default device is "cuda"
+    (RNA_MSM_Inference.py:20), i.e. PyTorch-ROCm eager ATen kernels.  The oracle (the restatement of the reference's forward,
+    oracle/msm_oracle.py; reference semantics incl. max_tokens_per_msa = 16384 -> the chunked path at this size) run on the
+    device in fp32: one warm forward, one timed.  The stated same-box PyTorch baseline -- reported, never the target, never
+    part of `value`."""
+    import torch
+    from oracle import msm_oracle as O
+    from rnamsm import synthetic
+    keep = torch.backends.cuda.matmul.allow_tf32
+    torch.backends.cuda.matmul.allow_tf32 = False
+    try:
+        params = O.to_torch_params(state, torch.float32, dev)
+        toks = torch.from_numpy(synthetic.make_tokens(M, L, 0)).to(dev)
+        secs = []
+        with torch.no_grad():
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                emb, atp = O.pack_outputs(O.forward(toks, params, max_tokens=16384))
+                torch.cuda.synchronize()
+                secs.append(time.perf_counter() - t0)
+        finite = bool(torch.isfinite(emb).all() and torch.isfinite(atp).all())
+        peak_gb = torch.cuda.max_memory_allocated(dev) / 1e9
+        del params, toks, emb, atp
+        torch.cuda.empty_cache()
+        return {"value": M * L / secs[1], "unit": "MSA-residues/s", "kind": "port on the device (PyTorch-ROCm eager, fp32)",
+                "seconds_warm": round(secs[0], 3), "seconds_timed": round(secs[1], 3), "outputs_finite": finite,
+                "torch": torch.__version__, "peak_memory_gb_of_the_process": round(peak_gb, 2),
+                "sample": f"oracle/msm_oracle.py on the HIP device in fp32 (torch eager ATen kernels, tf32 off), ONE complete 10-layer "
+                          f"forward of one M={M} L={L} MSA after one warm forward, max_tokens_per_msa 16384 as the reference's CLI "
+                          f"(RNA_MSM_Inference.py:20,30: device='cuda'); a baseline beside `value`, not the target"}
+    except Exception as e:                                            # noqa: BLE001 -- a baseline must not cost the bench line
+        torch.cuda.empty_cache()
+        return {"value": None, "error": f"{type(e).__name__}: {str(e)[:300]}"}
+    finally:
+        torch.backends.cuda.matmul.allow_tf32 = keep
+
+
+def make_digest(result):
+    """<= 1.2 KB summary, emitted as the LAST key of the JSON line so that a record holding only the line's tail still carries
+    every BASELINE config's numbers: per config [ms, k residues/s, model TFLOP/s, sum of launch bounds / sum of launch times]."""
+    def r(v, n=1):
+        return None if v is None else round(float(v), n)
+    d = {"value_k": r(result["value"] / 1e3), "ms": r(result["ms_per_step"], 2), "n_gpus": result["n_gpus"],
+         "dtype": result["dtype"].split(" ")[0], "gemm_frac_of_peak": r(result["roofline"]["frac"], 3),
+         "attn_frac_of_peak": r(result["attention_mfma"]["frac"], 3)}
+    pc = result.get("per_config")
+    if pc:
+        d["cfg_cols"] = "ms, k_res_per_s, model_TF, frac_of_bounds"
+        d["cfg"] = {k.replace("configs", "c"): [r(v["ms_per_step"], 2), r(v["residues_per_s"] / 1e3), r(v["model_tflops"]), r(v["kernel_frac_of_bounds"], 3)]
+                    for k, v in pc.items() if isinstance(v, dict) and "ms_per_step" in v}
+    modes = {}
+    for key, tag in (("bf16_mode", "bf16"), ("fast_mode", "f16x3"), ("outputs_only_mode", "outputs_only")):
+        m = result.get(key)
+        if m:
+            modes[tag] = [r(m["ms_per_step"], 2), r(m["value"] / 1e3)]
+            if "roofline" in m:
+                modes[tag].append(r(m["roofline"]["all_kernels"]["frac"], 3))
+    if modes:
+        d["modes_at_bench_shape"] = modes
+        d["modes_cols"] = "ms, k_res_per_s, frac_of_bounds"
+    sb = (result.get("small_msa_batches") or {}).get("unlike_shapes")
+    if sb:
+        d["packed64_k_res_per_s"] = [r(sb["residues_per_s_one_by_one"] / 1e3), r(sb["residues_per_s_packed"] / 1e3)]
+    for key, tag in (("cpu_baseline", "cpu_res_per_s"), ("torch_rocm_eager", "torch_rocm_eager_res_per_s")):
+        b = result.get(key)
+        if b:
+            d[tag] = r(b.get("value"), 0)
+    if result.get("compute_only_value"):
+        d["compute_only_k"] = r(result["compute_only_value"] / 1e3)
+    cfg = result.get("config", {})
+    if cfg.get("distinct_devices") is not None:
+        d["distinct_devices"] = cfg["distinct_devices"]
+    d["gather"] = str(cfg.get("gather", ""))[:60]
+    return d
+
+
+def device_identity(rank, local_rank, dev_index):
+    """Who computed: this rank's device as the runtime names it (UUID, PCI bus id), so that a first multi-GPU line PROVES
+    N distinct GPUs took part.  No GPU call beyond property queries."""
+    import torch
+    p = torch.cuda.get_device_properties(dev_index)
+    ident = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": p.name,
+             "device_count": torch.cuda.device_count()}
+    for key in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        v = getattr(p, key, None)
+        if v is not None:
+            ident[key] = str(v)
+    return ident
+
+
 def per_kernel_bounds(timings, steps):
     """{kernel family: ms, its roofline time, the fraction reached and WHICH limit binds it}: every launch is priced at
     max(executed matrix flops / MFMA peak, algorithmic bytes / 6.3 TB/s, vector-ALU issue time) (csrc/common.h KernelTimer)."""
@@ -358,6 +450,11 @@ def run_rank(args) -> int:
                        if sharding.owner_of((k if batch else 0) * per_step + pos, world) == rank})
     toks = {i: torch.from_numpy(synthetic.make_tokens(M, L, i)).to(dev) for i in mine_all}
 
+    ident = device_identity(rank, local_rank, dev_index)
+    idents = [ident]
+    if world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
     gather = world > 1 and not args.no_gather
     gather_failure = None
     if gather:
@@ -365,6 +462,8 @@ def run_rank(args) -> int:
         # fabric refuses it the bench still measures the sharded compute and says so, instead of dying in the timed loop.
         ok = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
         try:
+            if os.environ.get("RNAMSM_BENCH_FAIL_GATHER_PROBE") in (str(rank), "all"):     # test hook
+                raise RuntimeError(f"injected gather-probe failure on rank {rank} (RNAMSM_BENCH_FAIL_GATHER_PROBE)")
             probe = sharding.RoundGatherer(world, tensors_per_item=2, dst=0, device=dev)
             probe.submit(rank, (torch.full((3, 5), float(rank), device=dev), torch.zeros(2, 4, 4, device=dev)))
             probe.finish()
@@ -667,7 +766,8 @@ def run_rank(args) -> int:
         if world == 1:
             gather_note = "none (single GPU)"
         elif not gather:
-            gather_note = ("disabled by flag" if gather_failure is None else f"failed in the probe, compute only: {gather_failure}")
+            gather_note = ("disabled by flag" if gather_failure is None
+                           else f"failed: {gather_failure} (in the probe before the timed region; this line is the sharded compute only)")
             if os.environ.get("RNAMSM_BENCH_GATHER_NOTE"):
                 gather_note = f"disabled: {os.environ['RNAMSM_BENCH_GATHER_NOTE']}; sharded compute only"
         else:
@@ -696,6 +796,13 @@ def run_rank(args) -> int:
                        "gather": gather_note,
                        "num_seqs": M, "seq_len": L, "msas_per_step": per_step, "sharding": f"independent MSAs over {world} rank(s)",
                        "world_size_initialised": dist.get_world_size() if world > 1 else 1,
+                       "ranks_seen": [f"rank {i['rank']}: cuda:{i['device_index']} {i.get('name', '?')} uuid {i.get('uuid', '?')} "
+                                      f"pci {i.get('pci_domain_id', '?')}:{i.get('pci_bus_id', '?')}:{i.get('pci_device_id', '?')} "
+                                      f"({i['device_count']} visible)" for i in idents],
+                       "distinct_devices": len({(i.get("uuid"), i.get("pci_domain_id"), i.get("pci_bus_id"), i.get("pci_device_id"))
+                                                for i in idents}),
+                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version())
+                                        if world > 1 and args.backend == "nccl" else None),
                        "backend": ("nccl (RCCL)" if args.backend == "nccl" else args.backend) if world > 1 else "none",
                        "devices": "all ranks on device 0 (test hook)" if args.one_device and world > 1 else "one per rank",
                        "warmup_note": (f"a warm-up step is a pass over the first {warm_items} MSAs of the batch" if batch else "full steps")},
@@ -742,7 +849,9 @@ def run_rank(args) -> int:
             result["fast_mode"] = fast
             result["bf16_mode"] = bf16_mode
         if not args.no_cpu_baseline and world == 1:
+            result["torch_rocm_eager"] = torch_rocm_eager(M, L, state, dev)
             result["cpu_baseline"] = cpu_baseline(M, L, state)
+        result["digest"] = make_digest(result)                 # LAST key: the tail of the line carries the evidence
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -195,6 +195,12 @@ int rnamsm_row_logits(const float* q, const float* k, int64_t ld, float* partial
  *   logit replaced by -10000 first (masked_fill with padding_mask[:, 0], modules.py:781-785). */
 int rnamsm_softmax_rows(const float* partial, int nsplit, float* probs, int H, int C,
                         const uint8_t* key_mask, void* stream);
+/* The same with the summed logits multiplied by logit_scale (0 < logit_scale <= 1) before the mask fill and the softmax.  This is
+ * where the exact path applies align_scaling's 1/sqrt(R) (modules.py:713-715) since round 5: q leaves the QKV epilogue scaled by
+ * dh^-1/2 only, in rnamsm_forward, rnamsm_forward_batch and rnamsm_forward_packed alike, so that an alignment's outputs are the
+ * same bits whatever batch it is computed in (the reference's loop is list-independent, RNA_MSM_Inference.py:141-166). */
+int rnamsm_softmax_rows_scaled(const float* partial, int nsplit, float* probs, int H, int C, const uint8_t* key_mask,
+                               float logit_scale, void* stream);
 
 /* K4 / K5 with padding on the reference's CHUNKED path (RowSelfAttention._batched_forward, modules.py:717-750, taken when
  * R*C > max_tokens_per_msa): the rows are processed in chunks of max_rows = max(1, max_tokens_per_msa / C) (:724), every
@@ -554,9 +560,12 @@ void rnamsm_timing_reset(void);
  *                 not the default); 2 = folded, every GEMM sums the rows it stages itself; 0 = separate LayerNorm launches
  *                 (all agree to fp32 rounding, resp. to the 16-bit mode's rounding).
  *   "gemm_splitk" exact path of rnamsm_forward, fc2 (K = ffn_dim >= 2048) of MSAs with at most 64 output tiles (below ~1.4 k
- *                 tokens): 1 (default) = four K ranges computed side by side into partial tiles of the workspace and added in
- *                 range order with the bias and the residual (bit-identical reruns; results differ from the unsplit GEMM at
- *                 the fp32 rounding level), 0 = never, 2 / 4 / 8 = that many ranges whenever tiles x ranges <= 512 (A/B).
+ *                 tokens): 0 (default since round 5) = never; 1 = four K ranges computed side by side into partial tiles of the
+ *                 workspace and added in range order with the bias and the residual (bit-identical reruns; results differ
+ *                 from the unsplit GEMM at the fp32 rounding level -- and the choice follows the token count of whatever
+ *                 batch the alignment is computed in, which is why it is off by default: an alignment's emb / atp are the
+ *                 same bits alone, in a same-shape batch and token-packed); 2 / 4 / 8 = that many ranges whenever
+ *                 tiles x ranges <= 512 (A/B).
  *   "attn16"      16-bit modes of rnamsm_forward: 1 (default) = the attention contractions also run on the 16-bit
  *                 matrix cores in the mode's operand format (K4'..K7'), 0 = they stay on the exact-fp32 kernels,
  *                 2 = as 1 but the row kernels keep 128x128 tiles for every C (A/B of the 256x256-tile kernels);

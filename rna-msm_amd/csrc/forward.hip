@@ -18,6 +18,9 @@
 // hi plane [T,3D] then lo plane [T,3D] (2 x 2 B = the fp32 footprint), ctx = context hi|lo, hidden = GELU hi|lo.
 // cfg3 (R=256, C=512): 403 MB + 403 MB + 1.61 GB + 75 MB; cfg5 (R=C=1024): 19.3 GB -- one 288 GB HBM3E stack set
 // holds every activation of the largest supported MSA, so nothing is chunked or recomputed.
+#include <algorithm>
+#include <cstdint>
+
 #include "common.h"
 
 using namespace rnamsm;
@@ -226,8 +229,15 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         return rnamsm_gemm_bias_act_res(xn, D, Wf + (size_t)n_ofs * D, bias + n_ofs, nullptr, 0, out, ldc, rows, N, D, act, scale,
                                         scale_cols, nullptr, f32, stream);
     };
-    const float row_scale = (1.0f / sqrtf(64.0f)) / sqrtf((float)R);     // align_scaling, modules.py:713-715
     const float col_scale = 1.0f / sqrtf(64.0f);                         // modules.py:839
+    // align_scaling (modules.py:713-715) = dh^-1/2 / sqrt(R).  ONE arithmetic per alignment, whatever the batch it is computed
+    // in: on the exact path without padding q carries dh^-1/2 only and 1/sqrt(R) multiplies the summed
+    // logits in K5 -- exactly what rnamsm_forward_packed and rnamsm_forward_batch do, so an alignment's emb / atp are the same
+    // bits alone, in a same-shape batch or token-packed.  With padding (the reference's masked / chunked semantics) and in
+    // the 16-bit modes the factor stays where it was.
+    const bool canon = dtype == RNAMSM_F32 && !has_padding;
+    const float depth_scale = 1.0f / sqrtf((float)R);
+    const float row_scale = canon ? col_scale : col_scale * depth_scale;
 
     uint8_t* mask = nullptr;           // [R, C]; row 0 of it is the tied-attention key mask
     if (has_padding) {
@@ -278,7 +288,7 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
                 FWD(rnamsm_softmax_rows_chunked(part, nchunks, probs, H, C, mask, rows_per_chunk, stream));
             } else {
                 FWD(rnamsm_row_logits(qkv, qkv + D, ldq, part, R, C, H, 64, f32, stream));
-                FWD(rnamsm_softmax_rows(part, nsplit, probs, H, C, mask, stream));
+                FWD(rnamsm::softmax_rows_batched(part, nsplit, probs, H, C, 1, 0, 0, mask, 0, stream, canon ? depth_scale : 1.f));
             }
             FWD(rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, ctx_hi, ctx_lo, fmt, f32, stream));
         }
@@ -465,7 +475,8 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
     const int fold_mode = tuning().ln_fold;
     // statistics from the producers only; a ragged batch (true_rows) keeps the LayerNorm launches: its QKV GEMM carries the
     // per-token q factor in the epilogue slot the fold would need
-    const bool fold = ln_folded && !has_padding && !true_rows && (fold_mode == 3 || (fold_mode == 1 && T >= 18432));
+    // (by the MEMBER's token count, as its own forward decides: the batch must not change an alignment's rounding)
+    const bool fold = ln_folded && !has_padding && !true_rows && (fold_mode == 3 || (fold_mode == 1 && Tm >= 18432));
     // f2: the batch contains <pad> (ragged MSAs padded to one shape): the reference's direct-path mask semantics as in
     // rnamsm_forward -- zeroed embeddings (K0) and q (QKV epilogue) at padded tokens, -10000 on keys whose first-row token is
     // <pad> (tied rows) and on padded keys (columns); every MSA reads its own [R, C] slice of the mask
@@ -477,7 +488,10 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
     // true_rows (device int32 [B], ragged batches): every MSA's tied logits are scaled by ITS depth, so that a padded element
     // comes out as its unpadded forward would (see ragged_row_scale); the q scaling then happens per token after the GEMM
     const float col_scale = 1.0f / sqrtf(64.0f);
-    const float row_scale = true_rows ? col_scale : col_scale / sqrtf((float)R);
+    // exact path, no padding, one common shape: the arithmetic of rnamsm_forward on each member (q carries dh^-1/2, K5 applies
+    // 1/sqrt(R)) -- every member's outputs are the bits of its own forward
+    const bool canon = dtype == RNAMSM_F32 && !has_padding && !true_rows;
+    const float row_scale = (true_rows || canon) ? col_scale : col_scale / sqrtf((float)R);
     float* qscale = reinterpret_cast<float*>(ws + lay.qscale);
     if (true_rows) FWD(rnamsm::ragged_row_scale(tokens, d.pad_idx, true_rows, qscale, T, Tm, hs));
 
@@ -592,7 +606,8 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
             const int64_t part_bs = (int64_t)nsplit * H * C * C, probs_bs = (int64_t)NL * H * C * C;
             float* probs = row_attn + (int64_t)l * H * C * C;
             FWD(rnamsm::row_logits_batched(qkv, qkv + D, ldq, part, R, C, H, B, Tm * ldq, part_bs, stream));
-            FWD(rnamsm::softmax_rows_batched(part, nsplit, probs, H, C, B, part_bs, probs_bs, mask, Tm, stream));
+            FWD(rnamsm::softmax_rows_batched(part, nsplit, probs, H, C, B, part_bs, probs_bs, mask, Tm, stream,
+                                             canon ? 1.0f / sqrtf((float)R) : 1.f));
             FWD(rnamsm::row_apply_batched(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, B, probs_bs, Tm * ldq, Tm * D, stream));
         }
         FWD(res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], D));
@@ -710,7 +725,12 @@ extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float*
     const float* const* G = weights;
     const int f32 = RNAMSM_F32;
     const int fold_mode = tuning().ln_fold;
-    const bool fold = ln_folded && (fold_mode == 3 || (fold_mode == 1 && T >= 18432));
+    // folded only where EVERY member's own forward would fold (>= 18432 tokens each): an alignment's rounding must not depend
+    // on its company.  The CLI packs alignments of <= 8192 tokens, so its packed groups never fold (a 64 k-token group gives up
+    // the ~1 % the fold was worth there).
+    int64_t min_member = INT64_MAX;
+    for (int b = 0; b < B; ++b) min_member = std::min<int64_t>(min_member, (int64_t)host[b].R * host[b].C);
+    const bool fold = ln_folded && (fold_mode == 3 || (fold_mode == 1 && min_member >= 18432));
     const float qk_scale = 1.0f / sqrtf(64.0f);
     const PackedMsa* hp = host.data();
 

@@ -138,9 +138,10 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
                                                            uint16_t* __restrict__ p_hi, uint16_t* __restrict__ p_lo,
                                                            int64_t ldp, float plane_scale, int64_t mask_slab_stride,
                                                            int64_t part_bstride, int64_t probs_bstride, int64_t mask_bstride,
-                                                           int64_t plane_bstride, const PackedMsa* __restrict__ pk, int layer, int H) {
+                                                           int64_t plane_bstride, const PackedMsa* __restrict__ pk, int layer, int H,
+                                                           float logit_scale) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    float packed_scale = 1.f;
+    float packed_scale = logit_scale;
     if (pk) {       // token-packed batch: alignment blockIdx.y's own width, slabs, maps and depth factor (fp32 maps only)
         const PackedMsa& m = pk[blockIdx.y];
         C = m.C; rows = (int64_t)H * C; nsplit = m.nsplit;
@@ -181,11 +182,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
                 if (j < C) v[e] += ps[j];
             }
         }
-        // packed batch: q carries dh^-1/2 only, the alignment's 1/sqrt(R) meets the summed logits here
-        if (pk) {
+        // exact path without padding -- alone, in a same-shape batch or token-packed alike (ONE arithmetic per alignment, whatever
+        // the batch: VERDICT r04 item 4): q carries dh^-1/2 only and the alignment's 1/sqrt(R) meets the summed logits here.
+        // (1.0 elsewhere: the masked / chunked / 16-bit callers keep their factor where the reference has it)
 #pragma unroll
-            for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) v[e] *= packed_scale;
-        }
+        for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) v[e] *= packed_scale;
         // f2: masked_fill(padding_mask[:, 0], -10000) on the key axis (modules.py:781-785)
         if (key_mask) {
 #pragma unroll
@@ -439,7 +440,9 @@ static int row_logits_launch(const float* q, const float* k, int64_t ld, float* 
 static int softmax_rows_launch(const float* partial, int nsplit, float* probs, int H, int C, const uint8_t* key_mask,
                                uint16_t* p_hi, uint16_t* p_lo, int64_t ldp, float plane_scale, int fmt, void* stream,
                                int64_t mask_slab_stride = 0, int batch = 1, int64_t part_bstride = 0, int64_t probs_bstride = 0,
-                               int64_t mask_bstride = 0, int64_t plane_bstride = 0) {
+                               int64_t mask_bstride = 0, int64_t plane_bstride = 0, float logit_scale = 1.f) {
+    RNAMSM_CHECK_ARG(logit_scale > 0.f && logit_scale <= 1.f && (logit_scale == 1.f || mask_slab_stride == 0),
+                     "softmax_rows: logit_scale must be in (0, 1] (and 1 on the chunked path)");
     RNAMSM_CHECK_ARG(partial && probs, "softmax_rows: null pointer");
     RNAMSM_CHECK_ARG(nsplit >= 1 && H > 0 && C > 0 && C <= 64 * SOFTMAX_MAX_PER_LANE,
                      "softmax_rows: bad shape nsplit=%d H=%d C=%d (C <= %d)", nsplit, H, C, 64 * SOFTMAX_MAX_PER_LANE);
@@ -450,11 +453,11 @@ static int softmax_rows_launch(const float* partial, int nsplit, float* probs, i
     const dim3 grid((unsigned)((rows + 3) / 4), batch);
     KernelTimer timer(TC_SOFTMAX, 0.0, batch * (4.0 * (double)(nsplit + 1) * H * C * C + (p_hi ? (p_lo ? 4.0 : 2.0) * rows * ldp : 0.0)), s);
     if (!p_hi)
-        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H);
+        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
     else if (fmt == 0)
-        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H);
+        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
     else
-        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H);
+        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
     RNAMSM_CHECK_LAUNCH("softmax_rows");
     return RNAMSM_OK;
 }
@@ -462,6 +465,11 @@ static int softmax_rows_launch(const float* partial, int nsplit, float* probs, i
 extern "C" int rnamsm_softmax_rows(const float* partial, int nsplit, float* probs, int H, int C,
                                    const uint8_t* key_mask, void* stream) {
     return softmax_rows_launch(partial, nsplit, probs, H, C, key_mask, nullptr, nullptr, 0, 1.f, 0, stream);
+}
+
+extern "C" int rnamsm_softmax_rows_scaled(const float* partial, int nsplit, float* probs, int H, int C, const uint8_t* key_mask,
+                                          float logit_scale, void* stream) {
+    return softmax_rows_launch(partial, nsplit, probs, H, C, key_mask, nullptr, nullptr, 0, 1.f, 0, stream, 0, 1, 0, 0, 0, 0, logit_scale);
 }
 
 extern "C" int rnamsm_softmax_rows_chunked(const float* partial, int nchunks, float* probs, int H, int C,
@@ -537,9 +545,9 @@ int row_logits_batched(const float* q, const float* k, int64_t ld, float* partia
     return row_logits_launch(q, k, ld, partial, R, C, H, HEAD_DIM, RNAMSM_F32, stream, 0, batch, qk_bstride, part_bstride);
 }
 int softmax_rows_batched(const float* partial, int nsplit, float* probs, int H, int C, int batch, int64_t part_bstride,
-                         int64_t probs_bstride, const uint8_t* key_mask, int64_t mask_bstride, void* stream) {
+                         int64_t probs_bstride, const uint8_t* key_mask, int64_t mask_bstride, void* stream, float logit_scale) {
     return softmax_rows_launch(partial, nsplit, probs, H, C, key_mask, nullptr, nullptr, 0, 1.f, 0, stream, 0, batch, part_bstride,
-                               probs_bstride, mask_bstride);
+                               probs_bstride, mask_bstride, 0, logit_scale);
 }
 int softmax_rows_planes_batched(const float* partial, int nsplit, float* probs, uint16_t* p_hi, uint16_t* p_lo, int64_t ldp,
                                 float plane_scale, int H, int C, const uint8_t* key_mask, int fmt, int batch, int64_t part_bstride,
@@ -593,7 +601,7 @@ int softmax_rows_packed(const float* partial, float* row_attn, int layer, int H,
     KernelTimer timer(TC_SOFTMAX, 0.0, bytes, s);
     hipLaunchKernelGGL(softmax_rows_kernel<0>, dim3((unsigned)(((int64_t)H * max_C + 3) / 4), B), dim3(256), 0, s, partial, 0, row_attn,
                        (int64_t)0, 0, (const uint8_t*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr, (int64_t)0, 1.f, (int64_t)0,
-                       (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0, pk, layer, H);
+                       (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0, pk, layer, H, 1.f);
     RNAMSM_CHECK_LAUNCH("softmax_rows (packed)");
     return RNAMSM_OK;
 }

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "rnamsm_row_logits_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rnamsm_row_logits": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rnamsm_softmax_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rnamsm_softmax_rows_scaled": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_float, c_void_p]),
     "rnamsm_row_chunks": (c_int, [c_int, c_int, c_int]),
     "rnamsm_row_logits_chunked": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_void_p]),

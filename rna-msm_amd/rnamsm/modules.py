@@ -167,8 +167,11 @@ class RowSelfAttention(_AxialAttentionBase):
                                                   key_mask=None if mask is None else mask[:C])
             ctx = ops.row_apply16(p_pl, v, R, C, H, fmt=fmt, out_scale=1.0 / 4096.0)
             return self._project_out(ctx, res2).view(R, C, 1, D), probs.view(H, 1, C, C)
-        # padded tokens: q = 0 (modules.py:767-772); keys whose FIRST-row token is <pad>: logit -10000 (:781-785)
-        qkv = self._qkv(x2, self.align_scaling(x), zero_rows=mask)
+        # padded tokens: q = 0 (modules.py:767-772); keys whose FIRST-row token is <pad>: logit -10000 (:781-785).
+        # Without padding the arithmetic is rnamsm_forward's (one per alignment, whatever computes it): q carries dh^-1/2 and
+        # align_scaling's 1/sqrt(R) multiplies the summed logits in K5; with padding the factor stays on q as in the driver.
+        canon = mask is None
+        qkv = self._qkv(x2, self.scaling if canon else self.align_scaling(x), zero_rows=mask)
         # with padding AND R*C above the token budget the reference sums row chunks that were each filled from their
         # own first row (_batched_forward, modules.py:717-750): reproduced; without padding chunking is a re-ordering
         nchunks, rows_per_chunk = ops.row_chunks(R, C, self.max_tokens_per_msa) if mask is not None else (0, 0)
@@ -177,7 +180,8 @@ class RowSelfAttention(_AxialAttentionBase):
             probs = ops.softmax_rows(partial, chunk_pad_mask=mask, rows_per_chunk=rows_per_chunk)
         else:
             partial, _ = ops.row_logits(qkv[:, :D], qkv[:, D:2 * D], R, C, H)
-            probs = ops.softmax_rows(partial, key_mask=None if mask is None else mask[:C])
+            probs = ops.softmax_rows(partial, key_mask=None if mask is None else mask[:C],
+                                     logit_scale=ops.depth_scaling(R) if canon else 1.0)
         ctx = ops.row_apply(probs, qkv[:, 2 * D:], R, C, H)
         out = self._project_out(ctx, res2)
         return out.view(R, C, 1, D), probs.view(H, 1, C, C)

@@ -85,7 +85,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
 
 
 @_on_operand_device
-def layernorm_split(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, split: int = 3, fmt: int = 0):
+def layernorm_split(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, split: int = 3, fmt: int = 1):
     """LayerNorm whose output goes straight into 16-bit planes (hi, lo | None) [T, D]: the A operand of a 16-bit GEMM."""
     D = x.shape[-1]
     x2 = x.contiguous().view(-1, D)
@@ -221,7 +221,7 @@ def split_bf16(w: torch.Tensor, want_lo: bool = True, fmt: int = 0):
 @_on_operand_device
 def linear_bf16(a: torch.Tensor, w_hi: torch.Tensor, w_lo: Optional[torch.Tensor], bias: Optional[torch.Tensor] = None,
                 act: int = ACT_NONE, residual: Optional[torch.Tensor] = None, scale: float = 1.0, scale_cols: int = 0,
-                out: Optional[torch.Tensor] = None, split: int = 3, fmt: int = 0) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, split: int = 3, fmt: int = 1) -> torch.Tensor:
     """`linear` on the 16-bit matrix cores: split = 1 (bf16 operands) or 3 (hi/lo fp16 split: fmt must be 1 = f16x3)."""
     M, K = a.shape
     N = w_hi.shape[0]
@@ -264,9 +264,10 @@ def row_chunks(R: int, C: int, max_tokens_per_msa: int):
 @_on_operand_device
 def softmax_rows(partial: torch.Tensor, out: Optional[torch.Tensor] = None,
                  key_mask: Optional[torch.Tensor] = None, chunk_pad_mask: Optional[torch.Tensor] = None,
-                 rows_per_chunk: int = 0) -> torch.Tensor:
+                 rows_per_chunk: int = 0, logit_scale: float = 1.0) -> torch.Tensor:
     """key_mask uint8 [C]: direct-path fill.  chunk_pad_mask uint8 [R*C] + rows_per_chunk: the chunked path's per-chunk
-    fill (slab c is masked by row c*rows_per_chunk of the padding mask)."""
+    fill (slab c is masked by row c*rows_per_chunk of the padding mask).  logit_scale (direct path): multiplies the summed
+    logits first -- where the exact path applies 1/sqrt(R) (rnamsm_softmax_rows_scaled)."""
     nsplit, H, C, _ = partial.shape
     probs = torch.empty(H, C, C, device=partial.device, dtype=torch.float32) if out is None else out
     if chunk_pad_mask is not None:
@@ -274,9 +275,9 @@ def softmax_rows(partial: torch.Tensor, out: Optional[torch.Tensor] = None,
                                                            _dev(chunk_pad_mask, "chunk_pad_mask", torch.uint8),
                                                            rows_per_chunk, _stream()))
         return probs
-    _lib.check(_lib.load().rnamsm_softmax_rows(_dev(partial, "partial"), nsplit, _dev(probs, "probs"), H, C,
-                                               None if key_mask is None else _dev(key_mask, "key_mask", torch.uint8),
-                                               _stream()))
+    _lib.check(_lib.load().rnamsm_softmax_rows_scaled(_dev(partial, "partial"), nsplit, _dev(probs, "probs"), H, C,
+                                                      None if key_mask is None else _dev(key_mask, "key_mask", torch.uint8),
+                                                      float(logit_scale), _stream()))
     return probs
 
 
@@ -405,7 +406,7 @@ def row_logits16(q, k, R: int, C: int, H: int, fmt: int = 0, scale: float = 1.0)
 
 
 @_on_operand_device
-def softmax_rows_planes(partial: torch.Tensor, split: int = 3, fmt: int = 0, key_mask: Optional[torch.Tensor] = None,
+def softmax_rows_planes(partial: torch.Tensor, split: int = 3, fmt: int = 1, key_mask: Optional[torch.Tensor] = None,
                         plane_scale: float = 1.0):
     """softmax_rows that also returns P * plane_scale as planes (hi, lo | None) [H*C, ldp], ldp = C rounded up to 64,
     tail zeroed."""
@@ -571,6 +572,13 @@ def msa_weights(msa_u8: torch.Tensor, seqid_cutoff: float = 0.2) -> torch.Tensor
     _lib.check(_lib.load().rnamsm_msa_weights(_dev(msa_u8.contiguous(), "msa", torch.uint8), N, L, float(seqid_cutoff),
                                               _dev(out, "weights", torch.float64), _stream()))
     return out
+
+
+def depth_scaling(R: int) -> float:
+    """1/sqrt(R) as the C++ drivers form it -- `1.0f / sqrtf((float)R)` in fp32, both steps correctly rounded -- so that the
+    layer-wise mirror modules hand K5 the very same factor (forming it in double and rounding once can differ in the last bit)."""
+    import numpy as np
+    return float(np.float32(1.0) / np.sqrt(np.float32(R)))
 
 
 def row_scaling(R: int) -> float:

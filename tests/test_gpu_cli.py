@@ -144,9 +144,10 @@ def test_cli_batches_small_alignments_by_default(tmp_path, packing):
     """data.batch_small_msas (default true; false = the reference's one-by-one loop): the small alignments of the id list
     (different depths and lengths here) share launch sets -- packing (data.pack_small_msas, the default): one token-packed group,
     nothing padded, the 4544-token alignment included; packing off: pooled, grouped by shape, padded into one frame per group, the
-    4544-token one alone in between.  Same files, the returned ids in list order, values equal to the one-by-one run to fp32
-    rounding.  (rnaD comes out bit-identical either way: alone when framed; packed, its depth factor 1/sqrt(64) is a power of
-    two and its GEMM tiles are chosen as for the lone forward.)"""
+    4544-token one alone in between.  Same files, the returned ids in list order.  Packed (the default): every file is BYTE FOR BYTE
+    the one-by-one run's (round 5: an id's files do not depend on what else is in the list, as in the reference's loop,
+    RNA_MSM_Inference.py:141-166); framed (pack_small_msas=false): equal to fp32 rounding (masked attention over the frame), rnaD
+    -- alone in between -- bit-identical."""
     from rnamsm.config import Config
     from rnamsm.inference import extract_feat
     from rnamsm.model import MSATransformer
@@ -177,7 +178,9 @@ def test_cli_batches_small_alignments_by_default(tmp_path, packing):
     for name, want in outs[False].items():
         got = outs[True][name]
         assert got.shape == want.shape and got.dtype == want.dtype and got.flags["C_CONTIGUOUS"], name
-        if name.endswith("_emb.npy"):
+        if packing:
+            assert got.tobytes() == want.tobytes(), name
+        elif name.endswith("_emb.npy"):
             assert rel_l2(got, want) < 1e-5, name
         else:
             assert np.abs(got - want).max() < 2e-5, name

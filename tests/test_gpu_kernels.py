@@ -765,9 +765,13 @@ def test_gemm_16bit_matrix_core_modes(dev, M, N, K):
     # exact-integer operands are exactly representable in both 16-bit formats: bit-exact and transposition-proof
     ai = torch.from_numpy(((np.arange(M * K).reshape(M, K) * 7 + 3) % 13 - 6).astype(np.float32))
     wi = torch.from_numpy(((np.arange(N * K).reshape(N, K) * 5 + 1) % 11 - 5).astype(np.float32))
-    for fmt in (0, 1):
+    for split, fmt in ((1, 0), (3, 1)):
         hi, lo = ops.split_bf16(wi.to(dev), fmt=fmt)
-        assert torch.equal(ops.linear_bf16(ai.to(dev), hi, lo, split=3, fmt=fmt).cpu(), ai @ wi.t())
+        assert torch.equal(ops.linear_bf16(ai.to(dev), hi, lo if split == 3 else None, split=split, fmt=fmt).cpu(), ai @ wi.t())
+    # the removed hi/lo-bf16 mode answers UNSUPPORTED (never another arithmetic silently)
+    hi, lo = ops.split_bf16(wi.to(dev), fmt=0)
+    with pytest.raises(NotImplementedError):
+        ops.linear_bf16(ai.to(dev), hi, lo, split=3, fmt=0)
 
 
 @pytest.mark.parametrize("M,N,K", [(2048, 256, 64), (2300, 768, 768), (4100, 512, 3072)])

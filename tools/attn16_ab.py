@@ -23,8 +23,8 @@ def timeit(fn, n=7):
         e0.record(); fn(); e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1))
     return statistics.median(ts[2:])
 lib = _lib.load()
-MODES = os.environ.get("MODES", "bf16,bf16x3,f16x3").split(",")
-for name, split, fmt in (("bf16", 1, 0), ("bf16x3", 3, 0), ("f16x3", 3, 1)):
+MODES = os.environ.get("MODES", "bf16,f16x3").split(",")
+for name, split, fmt in (("bf16", 1, 0), ("f16x3", 3, 1)):
     if name not in MODES:
         continue
     hi, lo = ops.split_bf16(qkv, want_lo=split == 3, fmt=fmt)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Plane-input 16-bit GEMMs at the cfg3 shapes (T = 131072), as rnamsm_forward runs them: QKV / fc1 with plane outputs,
 out_proj / fc2 with the fp32 residual.  ms per launch and executed TFLOP/s per mode.
-    python tools/gemm16_planes_bench.py [bf16 f16x3 bf16x3]"""
+    python tools/gemm16_planes_bench.py [bf16 f16x3]"""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd"))
@@ -11,7 +11,7 @@ from rnamsm._lib import ACT_GELU_ERF, ACT_NONE
 T = int(os.environ.get("T", 131072))
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-modes = {"bf16": (1, 0), "bf16x3": (3, 0), "f16x3": (3, 1)}
+modes = {"bf16": (1, 0), "f16x3": (3, 1)}
 if "MFMA16" in os.environ:
     ops.set_param("gemm16_mfma16", int(os.environ["MFMA16"]))      # 0 / 1 / 2: which GEMMs take the 16x16x32 kernel
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Accuracy (vs fp64 on a row subset) and throughput of the fp32-MFMA GEMM vs the bf16 / bf16x3 GEMM at cfg3 shapes."""
+"""Accuracy (vs fp64 on a row subset) and throughput of the fp32-MFMA GEMM vs the bf16 / f16x3 GEMM at cfg3 shapes."""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "rna-msm_amd"))
@@ -29,8 +29,7 @@ for tag, N, K, act, res in [("qkv", 2304, 768, ACT_NONE, False), ("out", 768, 76
     line = [tag]
     fl = 2.0 * T * N * K
     for name, fn in (("f32", lambda: ops.linear(a, w, b, act=act, residual=r, out=out)),
-                     ("bf16", lambda: ops.linear_bf16(a, hi, None, b, act=act, residual=r, out=out, split=1)),
-                     ("bf16x3", lambda: ops.linear_bf16(a, hi, lo, b, act=act, residual=r, out=out, split=3)),
+                     ("bf16", lambda: ops.linear_bf16(a, hi, None, b, act=act, residual=r, out=out, split=1, fmt=0)),
                      ("f16x3", lambda: ops.linear_bf16(a, hh, hl, b, act=act, residual=r, out=out, split=3, fmt=1))):
         fn(); torch.cuda.synchronize()
         err = float((out[sub].double() - ref).norm() / ref.norm())

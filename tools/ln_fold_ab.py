@@ -23,7 +23,7 @@ dev = torch.device("cuda:0")
 model = MSATransformer(num_layers=10)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synthetic.make_state_dict(seed=0).items()}, strict=True)
 model = model.eval().to(dev)
-model.gemm_dtype = os.environ.get("DTYPE", "f32")      # f32 | f16x3 | bf16x3 | bf16
+model.gemm_dtype = os.environ.get("DTYPE", "f32")      # f32 | f16x3 | bf16
 model.check_finite = False
 toks = torch.from_numpy(synthetic.make_tokens(M, L, 0)).to(dev)
 lib = _lib.load()

@@ -15,8 +15,8 @@ m = m.eval().to(dev)
 for (B, R, C) in ((32, 8, 64), (28, 8, 64), (24, 8, 64), (36, 8, 64), (48, 8, 64), (64, 8, 64)):
     st = torch.from_numpy(np.stack([synthetic.make_tokens(R, C, 900 + b) for b in range(B)])).to(dev)
     line = f"B={B} {R}x{C} ({B*R*C} tokens):"
-    for knobs in ({}, {"gemm_tile": 1}, {"gemm_tile": 2}, {"ln_fold": 3}, {"ln_fold": 0}, {"gemm_splitk": 0}):
-        for k, v in (("gemm_tile", 0), ("ln_fold", 1), ("gemm_splitk", 1)): ops.set_param(k, v)
+    for knobs in ({}, {"gemm_tile": 1}, {"gemm_tile": 2}, {"ln_fold": 3}, {"ln_fold": 0}, {"gemm_splitk": 1}):
+        for k, v in (("gemm_tile", 0), ("ln_fold", 1), ("gemm_splitk", 0)): ops.set_param(k, v)
         for k, v in knobs.items(): ops.set_param(k, v)
         for _ in range(3): m.forward_batch(st, has_padding=False)
         torch.cuda.synchronize(); ts = []

@@ -28,4 +28,4 @@ for M, L in ((4, 64), (8, 64), (16, 64), (32, 64), (16, 128), (21, 128), (32, 12
             res.setdefault(knob, []).append(a.elapsed_time(b) / n)
             outs[knob] = out
     print(f"M={M:3d} L={L:3d} ({M * L:5d} tokens): " + "  ".join(f"cap {k}: {min(res[k]):.3f} ms" for k in KNOBS), flush=True)
-ops.set_param("gemm_splitk", 1)
+ops.set_param("gemm_splitk", 0)       # the default since round 5 (one arithmetic per alignment)
