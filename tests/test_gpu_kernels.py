@@ -1030,7 +1030,7 @@ def test_integration_md_ctypes_stub_runs_and_matches_the_mirror_module(dev):
     from conftest import ROOT
     from rnamsm import modules
     src = open(os.path.join(ROOT, "INTEGRATION.md")).read()
-    code = re.search(r"```python\nimport ctypes, math, torch\n(.*?)```", src, re.S).group(0)[len("```python\n"):-3]
+    code = re.search(r"```python\nimport ctypes, numpy, torch\n(.*?)```", src, re.S).group(0)[len("```python\n"):-3]
     code = code.replace('ctypes.CDLL("rna-msm_amd/rnamsm/librnamsm_hip.so")',
                         f'ctypes.CDLL("{os.path.join(ROOT, "rna-msm_amd", "rnamsm", "librnamsm_hip.so")}")')
     ns = {}
