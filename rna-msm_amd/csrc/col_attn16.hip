@@ -41,8 +41,9 @@
 
 namespace rnamsm {
 
-// Throw-away what-if builds (wrong results, timing only; tools/whatif_col_attn16.sh): 1 no v_exp, 2 no row sums, 4 no LDS-DMA inside the
-// loop, 8 no P V MFMAs, 16 no S MFMAs.  0 in the shipped library.
+// Throw-away what-if builds (wrong results, timing only; tools/whatif_col_attn16.sh, profiles/r05_whatif_col_attn16.log): 1 no v_exp,
+// 2 no row sums, 4 no LDS-DMA inside the loop, 8 no P V MFMAs, 16 no S MFMAs, 32 never fall back, 64 one chunk per block.  0 in the
+// shipped library (every use folds away).
 #ifndef C16_WHATIF
 #define C16_WHATIF 0
 #endif
@@ -93,10 +94,6 @@ struct C16Cfg {
     static constexpr int EPI = 4 * 9216;                            // epilogue staging: 32 rows x 272 B (fp32) / 2 planes x 32 x 144 B per wave
     static constexpr int RING = C16_NST * BUF > EPI ? C16_NST * BUF : EPI;
     static constexpr int LDS = RING + 16;                           // + the four waves' overflow flags
-    // PERSIST: the context staging must not alias the ring (the next tile's first chunks are already landing in it while this
-    // tile's context leaves): 16-bit rows of 144 B, 32 per wave
-    static constexpr int STG_P = RING + 16;
-    static constexpr int LDS_P = STG_P + 4 * 4608;
     static constexpr int NDMA = (JC / 32) * NPL * 2;                // LDS-DMA requests per wave per chunk
 };
 
@@ -105,24 +102,14 @@ struct C16Cfg {
 // PRE (FAST only): q arrives PRESCALED by scale * log2(e) (the QKV GEMM's epilogue multiplies the q columns before it rounds them:
 // no second rounding) -- the scores are log2-domain already and p = v_exp_f32(s): not even the fma, no reference, no pre-pass.  A
 // row sum outside [2^-96, 2^96] (or not finite) sends the block to the TRACKED loop as before.
-// PERSIST (round 5; plain bf16, plane output, prescaled q, QB = 2, R % 64 == 0): gridDim.x blocks (two per CU) WALK the (column,
-// head, query block) tiles instead of one block per tile.  Why: what-if builds (tools/whatif_col_attn16.sh, profiles/
-// r05_whatif_col_attn16.log) put a block's cost OUTSIDE its key loop at 0.7 of the 3.55 ms of a 1024 x 1024 launch -- block start,
-// the first two chunks' flight time with nothing to compute, the Q loads, the drained ring and the stores at the end, 49152
-// times.  Walking: the K / V stream never drains (the last two iterations of a tile request the first two chunks of the NEXT
-// tile instead of redundant reloads), the next tile's Q fragments are requested right after the key loop and arrive while the
-// context is staged and stored, and the staging has its own LDS so that the ring keeps filling.  A tile whose row sums fail the
-// FAST loop's test is redone on the spot by the TRACKED loop (cold ring) -- same results as the one-block-per-tile form, bit
-// for bit (same tiles, same order of arithmetic per tile).
-template <int SPLIT, int FMT, int OUT, int QB, bool MASKED, bool FAST, bool PRE, bool PERSIST = false>
+template <int SPLIT, int FMT, int OUT, int QB, bool MASKED, bool FAST, bool PRE>
 __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kernel(
     const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
     const uint16_t* __restrict__ klo, const uint16_t* __restrict__ vhi, const uint16_t* __restrict__ vlo, int64_t ld,
     float* __restrict__ ctx, int64_t ldc, int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo,
     float scale, const uint8_t* __restrict__ pad_mask, int64_t qkv_bstride, int64_t ctx_bstride, int64_t mask_bstride,
-    int force_tracked, unsigned total_vids) {
+    int force_tracked) {
     static_assert(!FAST || (FMT == 0 && !MASKED), "the FAST loop needs bf16's exponent range and no -10000 scores");
-    static_assert(!PERSIST || (PRE && SPLIT == 1 && QB == 2 && OUT == 1), "the walking form is built for the forward's bf16 instance");
     static_assert(!PRE || FAST, "prescaled q is the FAST loop's input");
     using Cfg = C16Cfg<SPLIT, QB>;
     constexpr int NPL = Cfg::NPL, JC = Cfg::JC, TILE = Cfg::TILE, BUF = Cfg::BUF;
@@ -140,26 +127,15 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
 
     const unsigned iblocks = (R + Cfg::ROWS - 1) / Cfg::ROWS;
-    unsigned vid = blockIdx.x, prob, ib;
-    // the next virtual id >= v (stepping by the grid: this block's walk) that maps to a tile; total_vids when there is none
-    auto next_tile = [&](unsigned v, unsigned& p_, unsigned& ib_) -> unsigned {
-        for (; v < total_vids; v += gridDim.x)
-            if (xcd_panel_map(v, (unsigned)C * H, iblocks, p_, ib_)) return v;
-        return total_vids;
-    };
-    if (PERSIST) {
-        vid = next_tile(vid, prob, ib);
-        if (vid >= total_vids) return;
-    } else if (!xcd_panel_map(vid, (unsigned)C * H, iblocks, prob, ib)) {
-        return;
-    }
-    int c = prob / H, h = prob % H;                            // (constant per block unless PERSIST)
+    unsigned prob, ib;
+    if (!xcd_panel_map(blockIdx.x, (unsigned)C * H, iblocks, prob, ib)) return;
+    const int c = prob / H, h = prob % H;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    int irow0 = ib * Cfg::ROWS + wave * 32 * QB;               // this wave's queries: irow0 + 32 qb + li
-    bool active = irow0 < R;                                   // wave-uniform
-    int64_t col_off = (int64_t)c * ld + h * 64;                // + r*C*ld selects the alignment row
+    const int irow0 = ib * Cfg::ROWS + wave * 32 * QB;         // this wave's queries: irow0 + 32 qb + li
+    const bool active = irow0 < R;                             // wave-uniform
+    const int64_t col_off = (int64_t)c * ld + h * 64;          // + r*C*ld selects the alignment row
 
     const uint16_t* qpl[2] = {qhi, qlo};
     const uint16_t* kpl[2] = {khi, klo};
@@ -168,23 +144,15 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
     // Q fragments (B operand of S^T = K Q^T): lane (query i, half) holds q[i][16kk + 8*half + 0..7]; rows past R are clamped
     // (computed, never stored)
     V8 qf[QB][4][NPL];
-    auto load_q = [&](int irow0_, int64_t col_off_) __attribute__((always_inline)) {
-        // (PERSIST calls this once per tile: the lane geometry is re-derived from an opaque copy there, so that nothing computed
-        // for it at kernel entry has to be kept -- or spilled -- across the key loops)
-        int lane_q = lane;
-        if (PERSIST) asm volatile("" : "+v"(lane_q));
-        const int li_q = lane_q & 31, lh_q = lane_q >> 5;
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            const int qi = min(irow0_ + 32 * qb + li_q, R - 1);
-            const int64_t qo = (int64_t)qi * C * ld + col_off_ + 8 * lh_q;
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = min(irow0 + 32 * qb + li, R - 1);
+        const int64_t qo = (int64_t)qi * C * ld + col_off + 8 * lh;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int p = 0; p < NPL; ++p) qf[qb][kk][p] = *reinterpret_cast<const V8*>(qpl[p] + qo + 16 * kk);
-        }
-    };
-    load_q(irow0, col_off);
+            for (int p = 0; p < NPL; ++p) qf[qb][kk][p] = *reinterpret_cast<const V8*>(qpl[p] + qo + 16 * kk);
+    }
 
     // DMA map: a plane tile is JC / 8 groups of 8 key rows; wave w moves groups w and w+4.  Keys past R are clamped to the
     // last key: their scores are masked to -inf and their V values only meet P = 0.
@@ -194,35 +162,15 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
     // only the last chunk of a ragged column clamps its rows (a multiply per request, once per block)
     int64_t krow[JC / 32];
 #pragma unroll
-    for (int j = 0; j < JC / 32; ++j) krow[j] = (int64_t)(8 * (wave + 4 * j) + drow) * C * ld + (PERSIST ? 0 : col_off);
+    for (int j = 0; j < JC / 32; ++j) krow[j] = (int64_t)(8 * (wave + 4 * j) + drow) * C * ld + col_off;
     const int64_t chunk_stride = (int64_t)JC * C * ld;
-    // PERSIST: chunk `ch` (whole: R % JC == 0) of the tile whose column offset is coff -- this tile's or the next one's
-    // (the per-lane part is one v_mad_u64_u32 of the lane's row with the uniform row stride -- no 64-bit per-lane offsets are kept
-    // across the walk; C * ld < 2^32 is the launcher's condition)
-    const uint32_t row_stride32 = (uint32_t)C * (uint32_t)ld;
-    auto issue_at = [&](int ch, int buf, int64_t coff) __attribute__((always_inline)) {
-        char* base = smem_b + buf * BUF;
-        const uint64_t chunk_base = (uint64_t)(ch * chunk_stride + coff);           // uniform
-#pragma unroll
-        for (int j = 0; j < JC / 32; ++j) {
-            const int64_t ko = (int64_t)((uint64_t)(uint32_t)(8 * (wave + 4 * j) + drow) * (uint64_t)row_stride32 + chunk_base);
-            const int loff = (8 * (wave + 4 * j)) * T16_ROWB;
-            dma16(kpl[0] + ko + ck * 8, base + loff);
-            dma16(vpl[0] + ko + ct * 8, base + NPL * TILE + loff);
-        }
-    };
     auto issue = [&](int ch, int buf) __attribute__((always_inline)) {
-        if constexpr (PERSIST) {             // whole chunks only there: one addressing form for both loops (fewer live addresses)
-            issue_at(ch, buf, col_off);
-            return;
-        }
         char* base = smem_b + buf * BUF;
         const bool ragged = (ch + 1) * JC > R;                 // block-uniform
 #pragma unroll
         for (int j = 0; j < JC / 32; ++j) {
             const int row = 8 * (wave + 4 * j) + drow;
-            const int64_t ko = ragged ? (int64_t)min(ch * JC + row, R - 1) * C * ld + col_off
-                                      : krow[j] + ch * chunk_stride + (PERSIST ? col_off : 0);
+            const int64_t ko = ragged ? (int64_t)min(ch * JC + row, R - 1) * C * ld + col_off : krow[j] + ch * chunk_stride;
             const int loff = (8 * (wave + 4 * j)) * T16_ROWB;
 #pragma unroll
             for (int p = 0; p < NPL; ++p) {
@@ -282,7 +230,7 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
             for (int t = 0; t < 16; ++t) s[qb][t] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                if (C16_WHATIF & 16) { s[qb][kk] += (float)kf[kk][0][0] + (float)qf[qb][kk][0][0]; }
+                if (C16_WHATIF & 16) s[qb][kk] += (float)kf[kk][0][0] + (float)qf[qb][kk][0][0];
                 else s[qb] = mma16<SPLIT, FMT>(kf[kk], qf[qb][kk], s[qb]);
             }
         }
@@ -326,7 +274,7 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 if (!(C16_WHATIF & 1))
-                s[qb][t] = (PRE && !TRK) ? __builtin_amdgcn_exp2f(s[qb][t]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][t], c2, nm));
+                    s[qb][t] = (PRE && !TRK) ? __builtin_amdgcn_exp2f(s[qb][t]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][t], c2, nm));
                 if (SPLIT == 3) psum += s[qb][t];           // hi + lo carries P to 2^-17 / 2^-22: the fp32 values serve
             }
             if (SPLIT == 3) l_run[qb] += psum;
@@ -359,8 +307,8 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
                 if (C16_WHATIF & 8) {
                     asm volatile("" :: "v"(pf[qb][ks][0]), "v"(vf[0][ks][0]), "v"(vf[1][ks][0]));
                 } else {
-                o0[qb] = mma16<SPLIT, FMT>(vf[0][ks], pf[qb][ks], o0[qb]);
-                o1[qb] = mma16<SPLIT, FMT>(vf[1][ks], pf[qb][ks], o1[qb]);
+                    o0[qb] = mma16<SPLIT, FMT>(vf[0][ks], pf[qb][ks], o0[qb]);
+                    o1[qb] = mma16<SPLIT, FMT>(vf[1][ks], pf[qb][ks], o1[qb]);
                 }
             }
     };
@@ -402,7 +350,7 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
             m_run[qb] = -INFINITY;
             l_run[qb] = 0.f;
         }
-        const int nch = (C16_WHATIF & 64) ? 1 : (R + JC - 1) / JC, nfull = (C16_WHATIF & 64) ? 1 : R / JC;     // (64: one chunk only -- what a block costs outside its key loop)
+        const int nch = (C16_WHATIF & 64) ? 1 : (R + JC - 1) / JC, nfull = (C16_WHATIF & 64) ? 1 : R / JC;
         issue(0, 0);
         issue(min(1, nch - 1), 1);
         if (!TRK && !PRE) {
@@ -414,8 +362,8 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
         // lie past R therefore computes on clamped rows and stores nothing.)
         int slot = 0;                        // ring slot of chunk ch
         for (int ch = 0; ch < nfull; ++ch) {
-            if (C16_WHATIF & 4) wait_dma_then_barrier<0>(); else
-            wait_dma_then_barrier<Cfg::NDMA>();      // chunk ch has landed (every wave's share); everyone is done with chunk ch - 1
+            if (C16_WHATIF & 4) wait_dma_then_barrier<0>();
+            else wait_dma_then_barrier<Cfg::NDMA>();      // chunk ch has landed (every wave's share); everyone is done with chunk ch - 1
             if (!(C16_WHATIF & 4)) issue(min(ch + 2, nch - 1), slot == 0 ? 2 : slot - 1);
             const char* Kc = smem_b + slot * BUF;
             const char* Vc = Kc + NPL * TILE;
@@ -453,7 +401,7 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
         asm volatile("" : "+v"(lane_e));
         const int li_e = lane_e & 31, lh_e = lane_e >> 5;
         // wave-private staging: [32 queries][64 d] as 16-bit rows of 144 B (hi, then lo) or fp32 rows of 272 B
-        char* stg = PERSIST ? smem_b + Cfg::STG_P + wave * 4608 : smem_b + wave * 9216;
+        char* stg = smem_b + wave * 9216;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             const float inv = 1.f / row_sum(qb);
@@ -510,113 +458,28 @@ __global__ __launch_bounds__(C16_THREADS, QB == 1 ? 3 : 2) void col_attn16_kerne
         }
     };
 
-    // One tile the plain way: the FAST loop, the vote, the TRACKED loop where that fails (or where asked: "attn16" = 5), the store.
-    // known_bad: the FAST loop has already failed on this tile (PERSIST's hand-over).  Leaves the ring drained.
-    auto one_tile = [&](bool known_bad) __attribute__((always_inline)) {
-        // force_tracked: 0 = by shape, 1 = the TRACKED loop only ("attn16" = 5)
-        if (FAST && force_tracked != 1 && !known_bad) {
-            run(no_t());
-            // a row sum that reached 2^96 (or is not finite): some score lay > 96 log2 units above the query's first-tile scores.
-            // The block's waves share the ring, so they vote and redo the column together.
-            bool bad = false;
-            if (active) {
+    if (FAST && !force_tracked) {
+        run(no_t());
+        // a row sum that reached 2^96 (or is not finite): some score lay > 96 log2 units above the query's first-tile scores.
+        // The block's waves share the ring, so they vote and redo the column together.
+        bool bad = false;
+        if (active) {
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) bad = bad || !(row_sum(qb) < C16_OVERFLOW) || (PRE && !(row_sum(qb) > 1.f / C16_OVERFLOW));
-            }
-            int* flags = reinterpret_cast<int*>(smem_b + Cfg::RING);
-            const int wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
-            if (lane == 0) flags[wave] = wave_bad;
-            wait_dma_then_barrier<0>();
-            const int any_bad = (C16_WHATIF & 32) ? 0 : (flags[0] | flags[1] | flags[2] | flags[3]);       // block-uniform
-            if (!any_bad) {
-                store_context();
-                return;
-            }
-            wait_dma_then_barrier<0>();          // every wave has read the flags before the ring is refilled
+            for (int qb = 0; qb < QB; ++qb) bad = bad || !(row_sum(qb) < C16_OVERFLOW) || (PRE && !(row_sum(qb) > 1.f / C16_OVERFLOW));
         }
-        run(yes_t());
-        store_context();
-    };
-    if constexpr (PERSIST) {
-        const int nch = R / JC;                                  // >= 2 whole chunks (the launcher's condition)
-        bool warm = false;                                       // this tile's chunks 0, 1 are already in flight (requested by the previous tile)
-        int slot = 0;                                            // ring slot of the tile's chunk 0
-        for (;;) {                                               // (outer: resumes the streaming walk after a redone tile)
-        bool hand_over = force_tracked == 1;                     // leave the streaming walk (a tile failed the FAST test; or TRACKED was asked for)
-        while (!hand_over) {
-            unsigned nprob = 0, nib = 0;
-            const unsigned nvid = next_tile(vid + gridDim.x, nprob, nib);
-            const bool has_next = nvid < total_vids;
-            const int nc = has_next ? (int)(nprob / H) : c, nh = has_next ? (int)(nprob % H) : h;
-            const int64_t ncol_off = (int64_t)nc * ld + nh * 64;
-            const int nirow0 = has_next ? (int)nib * Cfg::ROWS + wave * 32 * QB : irow0;
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-#pragma unroll
-                for (int t = 0; t < 16; ++t) { o0[qb][t] = 0.f; o1[qb][t] = 0.f; }
-                m_run[qb] = -INFINITY;
-                l_run[qb] = 0.f;
-            }
-            if (!warm) {
-                issue_at(0, slot, col_off);
-                issue_at(1, slot == 2 ? 0 : slot + 1, col_off);
-            }
-            for (int ch = 0; ch < nch; ++ch) {
-                wait_dma_then_barrier<Cfg::NDMA>();      // chunk ch has landed; everyone is done with the chunk before it
-                const int pslot = slot == 0 ? 2 : slot - 1;
-                if (ch + 2 < nch) issue_at(ch + 2, pslot, col_off);
-                else if (has_next) issue_at(ch + 2 - nch, pslot, ncol_off);       // the stream goes on with the NEXT tile's first chunks
-                else issue_at(nch - 1, pslot, col_off);                           // the walk ends: a redundant reload keeps the counts uniform
-                const char* Kc = smem_b + slot * BUF;
-                const char* Vc = Kc + NPL * TILE;
-                tile(Kc, Vc, 0, ch * JC, no_t(), no_t());
-                __builtin_amdgcn_sched_barrier(0);
-                tile(Kc, Vc, 1, ch * JC + 32, no_t(), no_t());
-                slot = slot == 2 ? 0 : slot + 1;
-            }
-            warm = has_next;
-            bool bad = false;
-            if (active) {
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) bad = bad || !(row_sum(qb) < C16_OVERFLOW) || !(row_sum(qb) > 1.f / C16_OVERFLOW);
-            }
-            int* flags = reinterpret_cast<int*>(smem_b + Cfg::RING);
-            const int wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
-            if (lane == 0) flags[wave] = wave_bad;
-            // (no vmcnt wait while the walk goes on: the next tile's chunks stay in flight across this barrier)
-            if (has_next) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else wait_dma_then_barrier<0>();
-            if (flags[0] | flags[1] | flags[2] | flags[3]) {     // block-uniform; rare: this tile goes to the plain walk below
-                hand_over = true;
-                break;
-            }
-            // the next tile's Q fragments: requested now (this tile's are dead), they arrive while the context is staged and stored
-            if (has_next) load_q(nirow0, ncol_off);
+        int* flags = reinterpret_cast<int*>(smem_b + Cfg::RING);
+        const int wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+        if (lane == 0) flags[wave] = wave_bad;
+        wait_dma_then_barrier<0>();
+        const int any_bad = (C16_WHATIF & 32) ? 0 : (flags[0] | flags[1] | flags[2] | flags[3]);       // block-uniform
+        if (!any_bad) {
             store_context();
-            if (!has_next) return;
-            vid = nvid; c = nc; h = nh; irow0 = nirow0; active = irow0 < R; col_off = ncol_off;
+            return;
         }
-        // The tile at `vid` failed the FAST test (or the TRACKED loop was asked for): redo it with the online softmax on a cold
-        // ring -- exactly what the one-block-per-tile form does with it, so the results do not depend on who walks where -- and
-        // take up the streaming walk again behind it.
-        wait_dma_then_barrier<0>();                              // every wave has read the flags; whatever was in flight has landed
-        run(yes_t());
-        store_context();
-        {
-            unsigned nprob = 0, nib = 0;
-            vid = next_tile(vid + gridDim.x, nprob, nib);
-            if (vid >= total_vids) return;
-            c = nprob / H; h = nprob % H;
-            irow0 = (int)nib * Cfg::ROWS + wave * 32 * QB; active = irow0 < R; col_off = (int64_t)c * ld + h * 64;
-        }
-        wait_dma_then_barrier<0>();                              // the staging of the finished tile has been read by every wave
-        load_q(irow0, col_off);
-        warm = false;
-        slot = 0;
-        }
-    } else {
-        one_tile(false);
+        wait_dma_then_barrier<0>();          // every wave has read the flags before the ring is refilled
     }
+    run(yes_t());
+    store_context();
 }
 
 }  // namespace rnamsm
@@ -625,28 +488,21 @@ using namespace rnamsm;
 
 static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-template <int SP, int FMT, int OUT, int QB, bool MASK, bool FAST, bool PRE, bool PERSIST = false>
+template <int SP, int FMT, int OUT, int QB, bool MASK, bool FAST, bool PRE>
 static int col16_go(unsigned grid, int batch, hipStream_t s, const uint16_t* q_hi, const uint16_t* q_lo, const uint16_t* k_hi,
                     const uint16_t* k_lo, const uint16_t* v_hi, const uint16_t* v_lo, int64_t ld, float* ctx, int64_t ldc, int R, int C,
                     int H, uint16_t* ctx_hi, uint16_t* ctx_lo, float scale, const uint8_t* pad_mask, int64_t qkv_bstride,
                     int64_t ctx_bstride, int64_t mask_bstride, int force_tracked) {
     static DeviceOnce cfg;
-    auto kern = col_attn16_kernel<SP, FMT, OUT, QB, MASK, FAST, PRE, PERSIST>;
-    constexpr int lds = PERSIST ? C16Cfg<SP, QB>::LDS_P : C16Cfg<SP, QB>::LDS;
-    const unsigned total_vids = grid;
-    if (PERSIST) {                                   // two blocks per CU walk the tiles
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const unsigned walkers = 2u * (unsigned)(cus > 0 ? cus : 256);
-        if (grid > walkers) grid = walkers;
-    }
+    auto kern = col_attn16_kernel<SP, FMT, OUT, QB, MASK, FAST, PRE>;
+    constexpr int lds = C16Cfg<SP, QB>::LDS;
     if (cfg.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "col_attn16: hipFuncSetAttribute: %s", hipGetErrorString(e));
         cfg.mark();
     }
     hipLaunchKernelGGL(kern, dim3(grid, batch), dim3(C16_THREADS), lds, s, q_hi, q_lo, k_hi, k_lo, v_hi, v_lo, ld, ctx, ldc, R, C, H,
-                       ctx_hi, ctx_lo, scale, pad_mask, qkv_bstride, ctx_bstride, mask_bstride, force_tracked, total_vids);
+                       ctx_hi, ctx_lo, scale, pad_mask, qkv_bstride, ctx_bstride, mask_bstride, force_tracked);
     return RNAMSM_OK;
 }
 
@@ -682,7 +538,7 @@ static int col_attn16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const u
     // two query blocks per wave (256-query blocks) for plain bf16 without a mask when that adds no idle query rows; bf16
     // operands without a mask take the FAST loop ("attn16" = 4: one query block per wave, 5: TRACKED loop only; A/B and tests)
     const bool qb2 = !q_lo && !pad_mask && var != 4 && (R + 255) / 256 * 256 <= (R + 127) / 128 * 128;
-    const int force_tracked = var == 5 ? 1 : (var == 6 ? 2 : 0);
+    const int force_tracked = var == 5;
     const unsigned iblocks = qb2 ? (R + 255) / 256 : (R + 127) / 128;
     const unsigned grid = xcd_panel_grid((unsigned)C * H, iblocks);
     int rc;
@@ -695,12 +551,7 @@ static int col_attn16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const u
         else rc = prescaled ? col16_go<SP_, FMT_, OUT_, QB_, false, F_, F_>(CA_ARGS)                                  \
                             : col16_go<SP_, FMT_, OUT_, QB_, false, F_, false>(CA_ARGS);                              \
     } while (0)
-    // the walking (persistent) form: the forward's plain-bf16 instance on whole 64-key chunks ("attn16" = 6: one block per tile, A/B)
-    const bool walk = prescaled && !q_lo && ctx_hi && qb2 && R % 64 == 0 && R >= 128 && var != 6 && var != 5 &&
-                      (int64_t)C * ld < ((int64_t)1 << 32);
-    if (walk) {
-        rc = col16_go<1, 0, 1, 2, false, true, true, true>(CA_ARGS);
-    } else if (!q_lo) {
+    if (!q_lo) {
         if (qb2) { if (ctx_hi) CA_GO(1, 0, 1, 2); else CA_GO(1, 0, 0, 2); }
         else { if (ctx_hi) CA_GO(1, 0, 1, 1); else CA_GO(1, 0, 0, 1); }
     } else {
