@@ -460,7 +460,7 @@ int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* const* weig
                          int* err_flag, int has_padding, const int* true_rows, const float* const* ln_folded, int dtype,
                          const uint16_t* const* weight_planes, void* stream);
 
-/* B alignments of DIFFERENT shapes as one TOKEN-PACKED batch (round 4): no frame, no padding, exact fp32 path.  The reference
+/* B alignments of DIFFERENT shapes as one TOKEN-PACKED batch (round 4): no frame, no padding.  The reference
  * feeds short RNAs of unlike length and depth one by one (RNA_MSM_Inference.py:141-148, model.py:338-416 per MSA); a padded
  * frame of such alignments (rnamsm_forward_batch with true_rows) holds 1.4-1.5x their real tokens.  Here the alignments lie
  * back to back on the token axis and every output is the concatenation of what rnamsm_forward returns per alignment:
@@ -470,17 +470,21 @@ int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* const* weig
  * The per-token launches (LayerNorm, the six GEMMs of a layer) run once over the T real tokens; K0, K4-K7 and K10 take the
  * alignment from gridDim.y and its shape / offsets from a descriptor table the call writes into the workspace.  Every
  * alignment keeps the tied-logit slab split of its own forward; q carries dh^-1/2 and the alignment's 1/sqrt(R_b)
- * (align_scaling, modules.py:713-715) multiplies its summed logits -- one rounding apart from rnamsm_forward, which folds both
- * into q -- and fc2's split-K / the folded LayerNorm are decided by T: outputs equal rnamsm_forward's per alignment to fp32
- * rounding (tests: 2e-6), not bit for bit.  A packed batch builds no masks: <pad> inside it sets bit 3 (value 8) of *err_flag
- * and the caller reruns that batch framed.  dtype must be RNAMSM_F32 (RNAMSM_ERR_UNSUPPORTED otherwise: 16-bit batches go
- * through rnamsm_forward_batch); ln_folded as in rnamsm_forward or NULL.  rnamsm_forward_packed_workspace_bytes returns 0 for
- * a shape outside the limits. */
+ * (align_scaling, modules.py:713-715) multiplies its summed logits -- the arithmetic of rnamsm_forward itself since round 5 --
+ * fc2 is never split and LayerNorm is folded only where every member's own forward folds it (>= 18432 tokens each): with
+ * RNAMSM_F32 every alignment's outputs are rnamsm_forward's BIT FOR BIT (tests/test_gpu_forward.py).  A packed batch builds no
+ * masks: <pad> inside it sets bit 3 (value 8) of *err_flag and the caller reruns that batch framed.
+ * dtype RNAMSM_BF16 / RNAMSM_F16X3 (round 5; weight_planes as in rnamsm_forward, NULL for RNAMSM_F32): every Linear runs on the
+ * 16-bit matrix cores over the T packed tokens (LayerNorm and fc1 write operand planes); the attention contractions stay on
+ * the exact-fp32 descriptor kernels K4-K7 (a few per cent of a batch of small alignments).  An alignment then equals its own
+ * 16-bit forward to the mode's rounding.  ln_folded as in rnamsm_forward or NULL (fp32 only).
+ * rnamsm_forward_packed_workspace_bytes returns 0 for a shape outside the limits. */
 #define RNAMSM_ERR_PAD_IN_PACKED 8
 size_t rnamsm_forward_packed_workspace_bytes(const rnamsm_model_dims* dims, int B, const int* shapes);
 int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens, int B,
                           const int* shapes, void* workspace, size_t workspace_bytes, float* row_attn, float* repr, float* emb,
-                          float* atp, int* err_flag, const float* const* ln_folded, int dtype, void* stream);
+                          float* atp, int* err_flag, const float* const* ln_folded, int dtype,
+                          const uint16_t* const* weight_planes, void* stream);
 
 /* Per-kernel timing with HIP events recorded on the launch stream (measurement aid for bench.py's
  * roofline block; adds two event records per launch while enabled, nothing when disabled).

@@ -689,10 +689,12 @@ extern "C" size_t rnamsm_forward_packed_workspace_bytes(const rnamsm_model_dims*
 
 extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens, int B,
                                      const int* shapes, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
-                                     float* emb, float* atp, int* err_flag, const float* const* ln_folded, int dtype, void* stream) {
+                                     float* emb, float* atp, int* err_flag, const float* const* ln_folded, int dtype,
+                                     const uint16_t* const* weight_planes, void* stream) {
     RNAMSM_CHECK_ARG(dims && weights && tokens && shapes && workspace && row_attn && repr && emb && atp, "forward_packed: null pointer");
-    if (dtype != RNAMSM_F32)
-        return fail(RNAMSM_ERR_UNSUPPORTED, "forward_packed: the exact fp32 path only (16-bit batches: rnamsm_forward_batch)");
+    RNAMSM_CHECK_ARG(dtype >= RNAMSM_F32 && dtype <= RNAMSM_F16X3, "forward_packed: unknown dtype %d", dtype);
+    RNAMSM_NO_BF16X3(dtype == RNAMSM_BF16X3_REMOVED, "forward_packed");
+    RNAMSM_CHECK_ARG(dtype == RNAMSM_F32 || weight_planes, "forward_packed: the 16-bit modes need weight_planes");
     ForwardScope in_flight;
     const rnamsm_model_dims& d = *dims;
     const int D = d.embed_dim, H = d.num_heads, F = d.ffn_dim, NL = d.num_layers;
@@ -762,6 +764,60 @@ extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float*
     FWD(rnamsm::embed_ln_packed(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS], G[RNAMSM_W_LN_BEFORE_G],
                                 G[RNAMSM_W_LN_BEFORE_B], x, desc, B, T, D, d.vocab, d.num_positions, d.pad_idx, d.ln_eps, err_flag, hs,
                                 d.row_pos_dim));
+    if (dtype != RNAMSM_F32) {
+        // ---- 16-bit modes (round 5): every Linear -- 85-93 % of a packed batch -- on the 16-bit matrix cores over the T packed
+        // tokens, in the plane data flow of rnamsm_forward (LayerNorm and fc1 write planes, QKV / fc1 / fc2 stage plain copies);
+        // the attention contractions stay on the descriptor-driven fp32 kernels K4-K7 of the exact path: for the small alignments a
+        // packed batch is made of they are a few per cent of the time, they already take the member from gridDim.y, and their
+        // results are the exact path's (the 16-bit attention kernels would need descriptors in six kernel families for that
+        // few per cent).  q is scaled in the QKV epilogue (fp32 output), 1/sqrt(R_b) in K5, as on the exact path.
+        BigRowsScope big_rows_scope(dtype == RNAMSM_BF16);
+        const int split = dtype == RNAMSM_BF16 ? 1 : 3, fmt = dtype == RNAMSM_F16X3 ? 1 : 0;
+        uint16_t* xn_hi = reinterpret_cast<uint16_t*>(xn);
+        uint16_t* xn_lo = split == 3 ? xn_hi + T * D : nullptr;
+        uint16_t* hid_hi = reinterpret_cast<uint16_t*>(hidden);
+        uint16_t* hid_lo = split == 3 ? hid_hi + T * (int64_t)F : nullptr;
+        auto planes_of = [&](int layer, int slot) { return weight_planes + (size_t)layer * RNAMSM_PLANES_PER_LAYER + 2 * slot; };
+        // plane A -> fp32 out (QKV) / planes out (fc1) / fp32 residual (fc2)
+        auto lin_pl = [&](int layer, int slot, const uint16_t* ahi, const uint16_t* alo, int64_t lda, const float* bias, const float* res,
+                          float* out, uint16_t* ohi, uint16_t* olo, int64_t ldc, int N, int K, int act, float scale, int scale_cols) -> int {
+            const uint16_t* const* P = planes_of(layer, slot);
+            return rnamsm_gemm_bf16(nullptr, lda, P[0], P[1], bias, res, D, out, ldc, T, N, K, act, scale, scale_cols, split, fmt, ahi, alo,
+                                    ohi, olo, stream);
+        };
+        // fp32 A (the attention context), split while it is staged: x += ctx W^T + b
+        auto out_proj = [&](int layer, int slot, const float* bias) -> int {
+            const uint16_t* const* P = planes_of(layer, slot);
+            return rnamsm_gemm_bf16(ctx, D, P[0], P[1], bias, x, D, x, D, T, D, D, RNAMSM_ACT_NONE, 1.f, 0, split, fmt, nullptr, nullptr,
+                                    nullptr, nullptr, stream);
+        };
+        for (int l = 0; l < NL; ++l) {
+            const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
+            FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
+            FWD(lin_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, qkv, nullptr, nullptr, ldq, 3 * D, D, RNAMSM_ACT_NONE, qk_scale, D));
+            FWD(rnamsm::row_logits_packed(qkv, qkv + D, ldq, part, H, desc, hp, B, stream));
+            FWD(rnamsm::softmax_rows_packed(part, row_attn, l, H, desc, hp, B, stream));
+            FWD(rnamsm::row_apply_packed(row_attn, l, qkv + 2 * D, ldq, ctx, D, H, desc, hp, B, stream));
+            FWD(out_proj(l, 1, W[RNAMSM_WL_ROW_BO]));
+            FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
+            FWD(lin_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, qkv, nullptr, nullptr, ldq, 3 * D, D, RNAMSM_ACT_NONE,
+                       qk_scale * LOG2E, D));
+            FWD(rnamsm::col_attn_packed(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, H, desc, hp, B, stream, true));
+            FWD(out_proj(l, 3, W[RNAMSM_WL_COL_BO]));
+            FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
+            FWD(lin_pl(l, 4, xn_hi, xn_lo, D, W[RNAMSM_WL_FC1_B], nullptr, nullptr, hid_hi, hid_lo, F, F, D, RNAMSM_ACT_GELU_ERF, 1.f, 0));
+            FWD(lin_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE, 1.f, 0));
+        }
+        FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
+        int max_C16 = 0;
+        double out_floats16 = 0.0;
+        for (int b = 0; b < B; ++b) {
+            max_C16 = host[b].C > max_C16 ? host[b].C : max_C16;
+            out_floats16 += (double)(host[b].C - 1) * D + (double)NL * H * (host[b].C - 1) * (host[b].C - 1);
+        }
+        FWD(rnamsm::pack_outputs_packed(repr, row_attn, emb, atp, desc, B, max_C16, D, NL, H, out_floats16, err_flag, hs));
+        return RNAMSM_OK;
+    }
     if (fold) {
         FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
         FWD(rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream));

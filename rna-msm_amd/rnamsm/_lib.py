@@ -97,7 +97,8 @@ _SIGNATURES = {
                                      POINTER(c_void_p), c_void_p]),
     "rnamsm_forward_packed_workspace_bytes": (c_size_t, [POINTER(ModelDims), c_int, c_void_p]),
     "rnamsm_forward_packed": (c_int, [POINTER(ModelDims), POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p, c_size_t,
-                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_int, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_void_p), c_int, POINTER(c_void_p),
+                                      c_void_p]),
     "rnamsm_ln_fold_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                        c_void_p]),
     "rnamsm_row_partials": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),

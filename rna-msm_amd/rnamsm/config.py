@@ -25,22 +25,18 @@ class DataConfig:                       # RNA_MSM_Inference.py:20-32
     max_tokens: int = 16384
     max_seqs_per_msa: int = 512
     sample_method: str = "hhfilter"
-    # extra (not in the reference): small alignments (<= 3072 tokens each) of the id list are grouped by shape, padded into one
-    # frame per group and run as a ragged batch (MSATransformer.forward_ragged); outputs equal the one-by-one run to fp32 rounding (~1e-6;
-    # tests/test_gpu_forward.py::test_ragged_batch_equals_every_alignment_alone, tests/test_gpu_cli.py).  On by default since
-    # round 3: a lone forward of a few hundred tokens costs 5.5 ms on a mostly idle chip; data.batch_small_msas=false
-    # restores the strictly one-by-one loop of the reference (RNA_MSM_Inference.py:141-148)
+    # extra (not in the reference): the small alignments (<= 8192 tokens each) of the id list share launch sets
+    # (MSATransformer.forward_ragged).  On by default since round 3: a lone forward of a few hundred tokens costs 2.5 ms on a mostly
+    # idle chip; data.batch_small_msas=false restores the strictly one-by-one loop of the reference (RNA_MSM_Inference.py:141-148)
     batch_small_msas: bool = True
-    # ... and in the 16-bit arithmetic modes (model.gemm_dtype = bf16 | f16x3) only on request: there a ragged batch picks
-    # its GEMM kernels by the BATCH's token count, so an alignment's files would depend (at the mode's rounding level, ~1e-2
-    # in bf16) on what else is in the id list; one by one every alignment's output is a function of that alignment alone
+    # (round 3's framed ragged batches in a 16-bit mode, on request only; the default route below needs no opt-in)
     batch_small_msas_16bit: bool = False
-    # round 4: the groups of small alignments are TOKEN-PACKED -- back to back on the token axis, nothing padded
-    # (rnamsm_forward_packed, exact fp32 arithmetic) -- instead of padded into a frame; false = the framed ragged batch of round 3
-    # (A/B, tools/cli_throughput.py).  In a 16-bit mode (model.gemm_dtype != f32) the alignments of <= 1024 (bf16) / 2048 (hi/lo modes) tokens take this EXACT
-    # packed path as well: alone, such an alignment costs 2.6-3.4 ms of launches in any arithmetic, so the exact batch is faster and
-    # its files are the exact path's (every alignment's output then depends on the rest of the list at fp32 rounding only, ~1e-6);
-    # pack_small_msas=false or batch_small_msas=false keeps every alignment in the model's own arithmetic, one by one
+    # round 4: the groups are TOKEN-PACKED -- back to back on the token axis, nothing padded (rnamsm_forward_packed) -- instead of
+    # padded into a frame; false = the framed ragged batch of round 3 (A/B, tools/cli_throughput.py).  Round 5: in exact mode an
+    # alignment's files are BYTE FOR BYTE those of the one-by-one loop, whatever else is in the list (one arithmetic per alignment:
+    # tests/test_gpu_cli.py); in a 16-bit mode (model.gemm_dtype = bf16 | f16x3) the packed batch runs in that mode too (Linear
+    # layers on the 16-bit matrix cores, attention on the exact kernels), a lone small alignment as a packed batch of one, so an
+    # alignment's files depend on its company at fp32-accumulation rounding at most (which GEMM tile the batch's token count selects)
     pack_small_msas: bool = True
 
 

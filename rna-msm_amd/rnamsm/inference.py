@@ -225,11 +225,10 @@ def plan_groups(shapes: List[tuple]) -> List[List[int]]:
 # tokens / 256 members; and alignments of up to PACKED_SMALL_TOKENS wait for company (16-64 rows x 60-200 columns, ~5 k tokens
 # each: x1.4-1.5 packed against alone; framed they lost).
 PACKED_TOKENS, PACKED_MEMBERS, PACKED_SMALL_TOKENS = 65536, 256, 8192
-# ... and in a 16-bit arithmetic mode, where a lone forward of a mid-size alignment is cheaper than its share of an exact batch
-# (packed exact ~650 k residues/s; a lone forward costs 2.6 ms of launches in bf16, 3.4 ms in the hi/lo modes, up to a few thousand
-# tokens).  Measured (MODE=bf16 | f16x3 tools/cli_throughput.py, 64 alignments): bf16 tiny x2.1, small x1.0-1.2, mid x0.86-0.91 at a
-# limit of 2048-4096 -- hence 1024 there; f16x3 tiny x2.8, small x1.55, mid x1.00 at 2048.
-PACKED_SMALL_TOKENS_16BIT = {"bf16": 1024, "f16x3": 2048}
+# In a 16-bit arithmetic mode the packed batch runs in that mode too since round 5 (rnamsm_forward_packed: every Linear on the
+# 16-bit matrix cores, attention on the exact descriptor kernels), so the same limit applies.  (Round 4 had sent those small
+# alignments through the EXACT packed path, with limits of 1024 / 2048 tokens: there was no 16-bit packed batch.)
+PACKED_SMALL_TOKENS_16BIT = {"bf16": 8192, "f16x3": 8192}
 
 
 def joins_packed(group_shapes: List[tuple], shape: tuple) -> bool:
@@ -353,10 +352,8 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
             # an alignment's files would depend on its neighbours in the list at the mode's rounding level)
             exact = model.gemm_dtype == "f32"
             framed16 = bool(getattr(cfg.data, "batch_small_msas_16bit", False)) and ops.get_param("attn16") != 0
-            # groups are token-packed (no frame, no padding -- rnamsm_forward_packed, EXACT fp32 arithmetic), so any small alignments
-            # share one.  In a 16-bit mode the small alignments (<= PACKED_SMALL_TOKENS_16BIT[mode] tokens) take that exact path too: a lone
-            # 16-bit forward of so few tokens costs its 2.6-3.4 ms of launches whatever the arithmetic, the packed exact batch is
-            # faster AND closer to the reference -- unless 16-bit framed batches were asked for (data.batch_small_msas_16bit)
+            # groups are token-packed (no frame, no padding -- rnamsm_forward_packed, in the model's arithmetic mode), so any small
+            # alignments share one -- unless 16-bit framed batches were asked for (data.batch_small_msas_16bit)
             packing = (bool(getattr(cfg.data, "batch_small_msas", True)) and bool(getattr(cfg.data, "pack_small_msas", True))
                        and (exact or not framed16))
             batching = bool(getattr(cfg.data, "batch_small_msas", True)) and (exact or framed16 or packing)
@@ -372,9 +369,10 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                 pool.clear()
 
             def alone(i: int, t: torch.Tensor) -> dict:
-                """One member of a group by itself, in the arithmetic the GROUP runs in: the model's mode -- except that in a
-                16-bit mode the small alignments are the EXACT packed path's (a group of one must not come out in bf16 because it
-                had no company: ADVICE r04), so there a lone one is a packed batch of one."""
+                """One member of a group by itself, in the arithmetic the GROUP runs in (what a small alignment's
+                files hold must not depend on whether it had company).  Exact mode: its own forward IS the packed batch's
+                arithmetic, bit for bit.  16-bit modes: a packed batch's attention runs on the exact kernels, a lone forward's on
+                the 16-bit ones -- so there a lone small alignment is a packed batch of one."""
                 if packing and not exact:
                     try:
                         return model.forward_ragged([t], packed=True)[0]

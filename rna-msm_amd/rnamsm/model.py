@@ -385,22 +385,23 @@ class MSATransformer(nn.Module):
         return out
 
     def forward_packed(self, msas: List[torch.Tensor], fold_layernorm: Optional[bool] = None,
-                       need_repr: bool = False, _warn_16bit: bool = True) -> List[Dict[str, torch.Tensor]]:
+                       need_repr: bool = False, gemm_dtype: Optional[str] = None) -> List[Dict[str, torch.Tensor]]:
         """Alignments of DIFFERENT shapes ([R_b, C_b] int64 tokens, column 0 = <cls>, no <pad>) as ONE token-packed batch
-        (rnamsm_forward_packed, exact fp32 path): the alignments lie back to back on the token axis, nothing is padded.
+        (rnamsm_forward_packed): the alignments lie back to back on the token axis, nothing is padded.
         Returns per MSA what forward_one(need_repr=False) returns -- emb [C_b-1, D], atp [NL*H, C_b-1, C_b-1], row_attn
-        [NL, H, C_b, C_b] (views of the packed outputs; with need_repr also repr [R_b, C_b, D]) and the batch's "err" word --
-        equal to the MSA's own forward to fp32 rounding.  Never inspects "err" (bit 3 = ERR_PAD_IN_PACKED: a <pad> inside the
-        batch, whose masks this path does not build -- forward_ragged reruns such a batch framed)."""
+        [NL, H, C_b, C_b] (views of the packed outputs; with need_repr also repr [R_b, C_b, D]) and the batch's "err" word.
+        gemm_dtype: None = the model's mode; "f32" = the exact path whatever the model's mode.  Exact: every alignment's outputs
+        are its own forward's, BIT FOR BIT (round 5).  "bf16" / "f16x3" (must be the model's mode: the weight planes are per mode):
+        the Linear layers on the 16-bit matrix cores, attention on the exact descriptor kernels -- equal to the alignment's own
+        16-bit forward to the mode's rounding.  Never inspects "err" (bit 3 = ERR_PAD_IN_PACKED: a <pad> inside the batch, whose
+        masks this path does not build -- forward_ragged reruns such a batch framed)."""
         if self.training:
             raise NotImplementedError("inference only (model.eval())")
         if not msas or not all(t.is_cuda and t.ndim == 2 for t in msas):
             raise _lib.RnamsmError("forward_packed: a non-empty list of [R, C] token tensors on the HIP device")
-        if self.gemm_dtype != "f32" and _warn_16bit and not MSATransformer._warned_packed_exact:
-            import warnings
-            MSATransformer._warned_packed_exact = True
-            warnings.warn(f"forward_packed runs the exact fp32 path whatever gemm_dtype says (the model is in {self.gemm_dtype!r}); "
-                          "batches in a 16-bit mode go through forward_ragged(packed=False) / forward_batch")
+        mode = gemm_dtype or self.gemm_dtype
+        if mode != "f32" and mode != self.gemm_dtype:
+            raise ValueError("forward_packed: a 16-bit gemm_dtype must be the model's own (the weight planes are built per mode)")
         dev = msas[0].device
         fold = self.fold_layernorm if fold_layernorm is None else fold_layernorm
         with torch.cuda.device(dev):
@@ -428,10 +429,12 @@ class MSATransformer(nn.Module):
             emb = torch.empty(sum(n_emb), device=dev, dtype=torch.float32)
             atp = torch.empty(sum(n_atp), device=dev, dtype=torch.float32)
             err = torch.zeros(1, device=dev, dtype=torch.int32)
-            folded = self._folded_weights() if fold else None
+            dtype = _lib.DTYPES[mode]
+            folded = self._folded_weights() if (fold and dtype == _lib.F32) else None
+            planes = self._weight_planes() if dtype != _lib.F32 else None
             _lib.check(lib.rnamsm_forward_packed(ctypes.byref(dims), ptrs, toks.data_ptr(), B, shapes, ws.data_ptr(), ws.numel(),
                                                  row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(), err.data_ptr(),
-                                                 folded, _lib.F32, torch.cuda.current_stream().cuda_stream))
+                                                 folded, dtype, planes, torch.cuda.current_stream().cuda_stream))
         res, om, oe, oa, ot = [], 0, 0, 0, 0
         for b, t in enumerate(msas):
             r, c = int(t.shape[0]), cs[b]
@@ -444,28 +447,36 @@ class MSATransformer(nn.Module):
         return res
 
     ERR_PAD_IN_PACKED = 8
-    _warned_packed_exact = False
 
-    def forward_ragged(self, msas: List[torch.Tensor], packed: Optional[bool] = None) -> List[Dict[str, torch.Tensor]]:
-        """Alignments of DIFFERENT shapes ([R_b, C_b] int64 tokens, column 0 = <cls>) in one launch set.  packed (None = in
-        exact mode): the token-packed batch of forward_packed -- no padding, EXACT fp32 arithmetic whatever the model's mode; its
-        error word is read (one sync): index errors raise, a failed folded-LayerNorm precondition reruns without the fold, a
-        <pad> inside the batch reruns it framed.
-        Otherwise (16-bit modes by default, packed=False, <pad> present): padded into one [max R, max C] frame and run as a ragged batch
-        (rnamsm_forward_batch with true_rows; padding is computed too).  Returns per MSA what forward_one(need_repr=False)
-        returns -- emb [C_b-1, D], atp [NL*H, C_b-1, C_b-1], row_attn [NL, H, C_b, C_b] -- equal to the MSA's own forward to
-        fp32 rounding."""
+    def forward_ragged(self, msas: List[torch.Tensor], packed: Optional[bool] = None,
+                       gemm_dtype: Optional[str] = None) -> List[Dict[str, torch.Tensor]]:
+        """Alignments of DIFFERENT shapes ([R_b, C_b] int64 tokens, column 0 = <cls>) in one launch set.  packed (None = True):
+        the token-packed batch of forward_packed -- no padding -- in `gemm_dtype` (None = the model's mode; "f32" = exact whatever
+        the mode); its error word is read (one sync): index errors raise, a 16-bit batch with a non-finite output is redone on
+        the exact path (check_finite), a failed folded-LayerNorm precondition reruns without the fold, a <pad> inside the batch
+        reruns it framed.
+        Otherwise (packed=False, <pad> present): padded into one [max R, max C] frame and run as a ragged batch
+        (rnamsm_forward_batch with true_rows, in the model's mode; padding is computed too).  Returns per MSA what
+        forward_one(need_repr=False) returns -- emb [C_b-1, D], atp [NL*H, C_b-1, C_b-1], row_attn [NL, H, C_b, C_b]; packed
+        and exact: the MSA's own forward bit for bit; framed or 16-bit: equal to it to fp32 rounding / to the mode's rounding."""
         if packed is None:
-            packed = self.gemm_dtype == "f32"
-        if packed:          # (asked for explicitly in a 16-bit mode: the EXACT packed path -- what the CLI does with small alignments)
+            packed = True
+        if packed:
             import warnings
-            res = self.forward_packed(msas, _warn_16bit=False)
+            mode = gemm_dtype or self.gemm_dtype
+            res = self.forward_packed(msas, gemm_dtype=mode)
             err = int(res[0]["err"].item())
             if err & self.ERR_INDEX:
                 raise IndexError("batch: token or position index out of range")
+            if (err & self.ERR_NONFINITE) and mode != "f32" and self.check_finite and not (err & self.ERR_PAD_IN_PACKED):
+                warnings.warn(f"batch: gemm_dtype={mode!r} produced non-finite outputs (operand outside the 16-bit range); "
+                              "the batch is recomputed on the exact fp32 path")
+                mode = "f32"
+                res = self.forward_packed(msas, gemm_dtype=mode)
+                err = int(res[0]["err"].item())
             if (err & self.ERR_FOLD) and not (err & self.ERR_PAD_IN_PACKED):
                 warnings.warn("batch: a token row's mean exceeds 32x its spread; LayerNorm is applied in its own launches for this batch")
-                res = self.forward_packed(msas, fold_layernorm=False, _warn_16bit=False)
+                res = self.forward_packed(msas, fold_layernorm=False, gemm_dtype=mode)
                 err = int(res[0]["err"].item())
             if not (err & self.ERR_PAD_IN_PACKED):
                 return res

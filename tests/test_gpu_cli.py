@@ -187,11 +187,11 @@ def test_cli_batches_small_alignments_by_default(tmp_path, packing):
     assert np.array_equal(outs[True]["rnaD_emb.npy"], outs[False]["rnaD_emb.npy"])       # the large one ran alone: same bits
 
 
-def test_cli_in_a_16bit_mode_runs_its_small_alignments_on_the_exact_packed_path(tmp_path):
-    """model.gemm_dtype=bf16 through the CLI: alignments of <= 1024 tokens leave as ONE token-packed batch in EXACT fp32 arithmetic
-    (alone they would cost 2.6 ms of launches each in any arithmetic) -- their files equal the exact path's one-by-one files to
-    fp32 rounding, not bf16's; the larger ones run alone in bf16 (bit-identical to forward_one in that mode).
-    data.pack_small_msas=false keeps every alignment in the model's own arithmetic."""
+def test_cli_in_a_16bit_mode_packs_its_small_alignments_in_that_mode(tmp_path):
+    """model.gemm_dtype=bf16 through the CLI (round 5): the alignments of <= 8192 tokens leave as ONE token-packed batch IN bf16
+    (rnamsm_forward_packed with dtype bf16: Linear layers on the 16-bit matrix cores, attention on the exact kernels) -- their files
+    sit at bf16's distance from the exact path's, as the one-by-one bf16 files do, and close to those; the larger ones run alone in
+    bf16 (bit-identical to forward_one in that mode).  data.pack_small_msas=false keeps the one-by-one loop in the model's mode."""
     from rnamsm.config import Config
     from rnamsm.inference import extract_feat
     from rnamsm.model import MSATransformer
@@ -200,7 +200,7 @@ def test_cli_in_a_16bit_mode_runs_its_small_alignments_on_the_exact_packed_path(
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
     records = open(os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2")).read().splitlines()
     names, seqs = records[0::2], records[1::2]
-    shapes = {"rnaA": (3, 20), "rnaB": (9, 35), "rnaC": (40, 70), "rnaD": (5, 28), "rnaE": (12, 30)}     # rnaC: 2840 tokens > 1024
+    shapes = {"rnaA": (3, 20), "rnaB": (9, 35), "rnaC": (64, 140), "rnaD": (5, 28), "rnaE": (12, 30)}     # rnaC: 9024 tokens > 8192
     ids = sorted(shapes)
 
     def run(tag, dtype, **flags):
@@ -208,7 +208,7 @@ def test_cli_in_a_16bit_mode_runs_its_small_alignments_on_the_exact_packed_path(
         (root / "results").mkdir(parents=True)
         for i in ids:
             depth, length = shapes[i]
-            (root / "results" / f"{i}.a2m_msa2").write_text("".join(f"{names[r]}\n{(seqs[r] * 2)[:length]}\n" for r in range(depth)))
+            (root / "results" / f"{i}.a2m_msa2").write_text("".join(f"{names[r]}\n{(seqs[r] * 5)[:length]}\n" for r in range(depth)))
         (root / "rna_id.txt").write_text("\n".join(ids) + "\n")
         cfg = Config()
         cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = str(root), "results", "rna_id.txt"
@@ -230,15 +230,17 @@ def test_cli_in_a_16bit_mode_runs_its_small_alignments_on_the_exact_packed_path(
         if i == "rnaC":
             assert np.array_equal(default[e], bf16_alone[e])                       # above the limit: alone, in the model's mode
         else:
-            assert rel_l2(default[e], exact[e]) < 1e-5, i                          # the exact path's values ...
-            assert rel_l2(bf16_alone[e], exact[e]) > 1e-3, i                       # ... which bf16 alone is far from
+            d_pk, d_one = rel_l2(default[e], exact[e]), rel_l2(bf16_alone[e], exact[e])
+            assert 1e-4 < d_pk < 5e-2 and 1e-4 < d_one < 5e-2, (i, d_pk, d_one)    # both carry bf16's rounding, neither is the exact path
+            assert d_pk < 2.0 * d_one + 1e-3, (i, d_pk, d_one)                     # ... the packed batch no further from it than alone
         assert np.array_equal(own[e], bf16_alone[e]), i
 
 
-def test_cli_in_a_16bit_mode_a_lone_small_alignment_still_takes_the_exact_path(tmp_path):
-    """whether a small alignment's files carry fp32 or bf16 rounding must not depend on whether it had company.  A bf16
-    list with exactly ONE small alignment (and one large one, which runs alone in bf16): the small one's files must be the exact
-    path's (a packed batch of one), to fp32 rounding -- and identical to what it gets inside a group of small ones."""
+def test_cli_in_a_16bit_mode_a_lone_small_alignment_gets_the_arithmetic_of_a_group(tmp_path):
+    """what a small alignment's files hold must not depend on whether it had company.  A bf16 list with exactly ONE
+    small alignment (and one large one, which runs alone in bf16): the small one runs as a packed batch of one -- the arithmetic
+    of a group (16-bit Linear layers, exact attention) -- so its files equal what it gets inside a group of small ones (same
+    GEMM kernel at these sizes: the same bits), and carry bf16's distance from the exact path either way."""
     from rnamsm.config import Config
     from rnamsm.inference import extract_feat
     from rnamsm.model import MSATransformer
@@ -247,14 +249,14 @@ def test_cli_in_a_16bit_mode_a_lone_small_alignment_still_takes_the_exact_path(t
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
     records = open(os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2")).read().splitlines()
     names, seqs = records[0::2], records[1::2]
-    shapes = {"rnaA": (9, 35), "rnaB": (40, 70), "rnaC": (3, 20), "rnaD": (5, 28)}      # rnaB: 2840 tokens > 1024
+    shapes = {"rnaA": (9, 35), "rnaB": (64, 140), "rnaC": (3, 20), "rnaD": (5, 28)}      # rnaB: 9024 tokens > 8192
 
     def run(tag, dtype, ids, **flags):
         root = tmp_path / tag
         (root / "results").mkdir(parents=True)
         for i in ids:
             depth, length = shapes[i]
-            (root / "results" / f"{i}.a2m_msa2").write_text("".join(f"{names[r]}\n{(seqs[r] * 2)[:length]}\n" for r in range(depth)))
+            (root / "results" / f"{i}.a2m_msa2").write_text("".join(f"{names[r]}\n{(seqs[r] * 5)[:length]}\n" for r in range(depth)))
         (root / "rna_id.txt").write_text("\n".join(ids) + "\n")
         cfg = Config()
         cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = str(root), "results", "rna_id.txt"
@@ -271,6 +273,6 @@ def test_cli_in_a_16bit_mode_a_lone_small_alignment_still_takes_the_exact_path(t
     lone = run("bf16_lone_small", "bf16", ["rnaA", "rnaB"])
     grouped = run("bf16_group_of_small", "bf16", ["rnaA", "rnaB", "rnaC", "rnaD"])
     for name in ("rnaA_emb.npy", "rnaA_atp.npy"):
-        assert rel_l2(lone[name], exact[name]) < 1e-5, name                       # fp32 rounding, not bf16's ~1e-2
-        assert np.array_equal(lone[name], grouped[name]), name                    # ... and the same bits with or without company
+        assert np.array_equal(lone[name], grouped[name]), name                    # the same bits with or without company
+    assert 1e-4 < rel_l2(lone["rnaA_emb.npy"], exact["rnaA_emb.npy"]) < 5e-2      # bf16's rounding: the mode that was asked for
     assert np.array_equal(lone["rnaB_emb.npy"], grouped["rnaB_emb.npy"])          # the large one: alone in bf16 either way

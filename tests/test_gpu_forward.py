@@ -936,15 +936,42 @@ def test_batched_and_ragged_forward_in_the_16bit_modes(model, mode, emb_tol, atp
         # ragged batch: every alignment as alone
         shapes = [(8, 17), (3, 9), (12, 17), (1, 30), (7, 25), (12, 30)]
         msas = [torch.from_numpy(synthetic.make_tokens(r, c, 70 + i)).to("cuda:0") for i, (r, c) in enumerate(shapes)]
-        for t, got in zip(msas, m.forward_ragged(msas)):
-            emb, atp = O.pack_outputs(O.forward(t.cpu(), params))
-            assert got["emb"].shape == tuple(emb.shape) and got["atp"].shape == tuple(atp.shape)
-            assert rel_l2(got["emb"].cpu().numpy(), np.asarray(emb)) < emb_tol, (mode, tuple(t.shape))
-            assert np.abs(got["atp"].cpu().numpy() - np.asarray(atp)).max() < atp_tol, (mode, tuple(t.shape))
+        # (packed: round 5's rnamsm_forward_packed in the mode -- 16-bit Linear layers, exact attention; framed: round 3's padded frame)
+        for packed in (True, False):
+            for t, got in zip(msas, m.forward_ragged(msas, packed=packed)):
+                emb, atp = O.pack_outputs(O.forward(t.cpu(), params))
+                assert got["emb"].shape == tuple(emb.shape) and got["atp"].shape == tuple(atp.shape)
+                assert rel_l2(got["emb"].cpu().numpy(), np.asarray(emb)) < emb_tol, (mode, packed, tuple(t.shape))
+                assert np.abs(got["atp"].cpu().numpy() - np.asarray(atp)).max() < atp_tol, (mode, packed, tuple(t.shape))
+                if mode == "f16x3":
+                    one = m.checked_forward_one(t, need_repr=False)
+                    assert rel_l2(got["emb"].cpu().numpy(), one["emb"].cpu().numpy()) < 2e-5
+                    assert np.abs(got["atp"].cpu().numpy() - one["atp"].cpu().numpy()).max() < 5e-5
+        # a packed batch large enough for the 256x256-tile GEMM kernels (13.6 k tokens), unlike shapes, every kernel branch of the
+        # descriptor-driven attention (depth 1, R <= 16, ragged 32-key chunk, widths that are no multiple of 4): against each
+        # member's own forward in the mode -- f16x3 at fp32 grade, bf16 against the oracle at the mode's bar -- and rerun-identical
+        big_shapes = [(40, 150), (33, 64), (17, 33), (140, 35), (5, 133), (1, 21), (16, 40)]
+        big = [torch.from_numpy(synthetic.make_tokens(r, c, 520 + i)).to("cuda:0") for i, (r, c) in enumerate(big_shapes)]
+        outs, again = m.forward_packed(big, need_repr=True), m.forward_packed(big, need_repr=True)
+        assert int(outs[0]["err"].item()) == 0
+        for t, got, got2 in zip(big, outs, again):
+            assert torch.equal(got["emb"], got2["emb"]) and torch.equal(got["atp"], got2["atp"]) and torch.equal(got["repr"], got2["repr"])
+            one = m.checked_forward_one(t, need_repr=True)
             if mode == "f16x3":
-                one = m.checked_forward_one(t, need_repr=False)
-                assert rel_l2(got["emb"].cpu().numpy(), one["emb"].cpu().numpy()) < 2e-5
-                assert np.abs(got["atp"].cpu().numpy() - one["atp"].cpu().numpy()).max() < 5e-5
+                assert rel_l2(got["emb"].cpu().numpy(), one["emb"].cpu().numpy()) < 2e-5, tuple(t.shape)
+                assert rel_l2(got["repr"].cpu().numpy(), one["repr"].cpu().numpy()) < 2e-5, tuple(t.shape)
+                assert np.abs(got["atp"].cpu().numpy() - one["atp"].cpu().numpy()).max() < 1e-4, tuple(t.shape)
+            elif t.numel() <= 2500:
+                emb, atp = O.pack_outputs(O.forward(t.cpu(), params))
+                assert rel_l2(got["emb"].cpu().numpy(), np.asarray(emb)) < emb_tol, (mode, tuple(t.shape))
+                assert np.abs(got["atp"].cpu().numpy() - np.asarray(atp)).max() < atp_tol, (mode, tuple(t.shape))
+        with pytest.raises(ValueError):                         # a 16-bit mode other than the model's own: the weight planes are per mode
+            m.forward_packed(big[:2], gemm_dtype="bf16" if mode == "f16x3" else "f16x3")
+        exact = m.forward_packed(big[-2:], gemm_dtype="f32")    # ... the exact path is always available
+        m.gemm_dtype = "f32"
+        for t, got in zip(big[-2:], exact):
+            assert torch.equal(got["emb"], m.checked_forward_one(t, need_repr=False)["emb"])
+        m.gemm_dtype = mode
         if mode == "f16x3":          # the reference's padded batch (direct-path masks) through the batched 16-bit route
             g = golden("forward_padded_b2.npz")
             out = m.checked_forward_batch(torch.from_numpy(g["tokens"]).to("cuda:0"))
