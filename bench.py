@@ -325,17 +325,30 @@ def make_digest(result):
     return d
 
 
+def rccl_version():
+    """RCCL's version as torch reports it (backend "nccl" IS RCCL on ROCm); never raises: an evidence field must not cost the line."""
+    try:
+        import torch
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:                                            # noqa: BLE001
+        return f"unavailable ({type(e).__name__})"
+
+
 def device_identity(rank, local_rank, dev_index):
     """Who computed: this rank's device as the runtime names it (UUID, PCI bus id), so that a first multi-GPU line PROVES
     N distinct GPUs took part.  No GPU call beyond property queries."""
     import torch
-    p = torch.cuda.get_device_properties(dev_index)
-    ident = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "name": p.name,
-             "device_count": torch.cuda.device_count()}
-    for key in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
-        v = getattr(p, key, None)
-        if v is not None:
-            ident[key] = str(v)
+    ident = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device_count": torch.cuda.device_count()}
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        ident["name"] = p.name
+        for key in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+            v = getattr(p, key, None)
+            if v is not None:
+                ident[key] = str(v)
+    except Exception as e:                                            # noqa: BLE001 -- an evidence field must not cost the line
+        ident["name"] = f"properties unavailable ({type(e).__name__})"
     return ident
 
 
@@ -799,10 +812,11 @@ def run_rank(args) -> int:
                        "ranks_seen": [f"rank {i['rank']}: cuda:{i['device_index']} {i.get('name', '?')} uuid {i.get('uuid', '?')} "
                                       f"pci {i.get('pci_domain_id', '?')}:{i.get('pci_bus_id', '?')}:{i.get('pci_device_id', '?')} "
                                       f"({i['device_count']} visible)" for i in idents],
+                       # (by UUID / PCI address; where the runtime exposes neither, by the device index the rank was given)
                        "distinct_devices": len({(i.get("uuid"), i.get("pci_domain_id"), i.get("pci_bus_id"), i.get("pci_device_id"))
+                                                if (i.get("uuid") or i.get("pci_bus_id")) else ("index", i["device_index"])
                                                 for i in idents}),
-                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version())
-                                        if world > 1 and args.backend == "nccl" else None),
+                       "rccl_version": rccl_version() if world > 1 and args.backend == "nccl" else None,
                        "backend": ("nccl (RCCL)" if args.backend == "nccl" else args.backend) if world > 1 else "none",
                        "devices": "all ranks on device 0 (test hook)" if args.one_device and world > 1 else "one per rank",
                        "warmup_note": (f"a warm-up step is a pass over the first {warm_items} MSAs of the batch" if batch else "full steps")},

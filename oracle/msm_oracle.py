@@ -237,9 +237,11 @@ def pack_outputs(result: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, torch.T
 
 
 def multihead_self_attention(x: torch.Tensor, params, prefix: str, num_heads: int,
-                             key_padding_mask: Optional[torch.Tensor] = None, return_weights: bool = False):
-    """Self-attention path of msm/multihead_attention.py:154-397 (no attn_mask, no bias_kv, eval): q = q_proj(x)*dh^-0.5
-    (:256), bmm (:349), key_padding_mask [B, T] -> -inf on masked keys (:360-369), softmax (:371), bmm (:379), out_proj
+                             key_padding_mask: Optional[torch.Tensor] = None, return_weights: bool = False,
+                             attn_mask: Optional[torch.Tensor] = None):
+    """Self-attention path of msm/multihead_attention.py:154-397 (no bias_kv, eval): q = q_proj(x)*dh^-0.5
+    (:256), bmm (:349), attn_mask [T, T] ADDED to the scores of every batch element and head (:353-357), key_padding_mask
+    [B, T] -> -inf on masked keys (:360-369), softmax (:371), bmm (:379), out_proj
     (:387).  x [T, B, E] -> out [T, B, E]; with return_weights also the per-head probabilities [H, B, T, T] (:389-393;
     the reference's default returns their mean over heads, :394-397)."""
     T, B, E = x.shape
@@ -248,6 +250,8 @@ def multihead_self_attention(x: torch.Tensor, params, prefix: str, num_heads: in
     k = linear(x, _p(params, prefix, "k_proj.weight"), _p(params, prefix, "k_proj.bias")).view(T, B, num_heads, dh)
     v = linear(x, _p(params, prefix, "v_proj.weight"), _p(params, prefix, "v_proj.bias")).view(T, B, num_heads, dh)
     w = torch.einsum("ibhd,jbhd->bhij", q, k)
+    if attn_mask is not None:
+        w = w + attn_mask.to(w.dtype)[None, None]
     if key_padding_mask is not None:
         w = w.masked_fill(key_padding_mask.to(torch.bool)[:, None, None, :], float("-inf"))
     p = torch.softmax(w, -1)

@@ -345,8 +345,12 @@ class MultiheadAttention(_AxialAttentionBase):
         T; the probabilities never exist), weights = None;
       * key_padding_mask [B,T] (:360-369): masked keys get probability 0.  The reference fills -inf, the kernels -10000
         (exp underflows to 0 in fp32 either way); a batch element whose keys are ALL masked is NaN in the reference
-        (softmax over -inf only) -- outputs and weights of such an element are set to NaN here too (_reference_nan).
-    Raises for what is outside eval-mode self-attention: attn_mask, incremental state, static_kv, before_softmax,
+        (softmax over -inf only) -- outputs and weights of such an element are set to NaN here too (_reference_nan);
+      * attn_mask [T,T] float (round 5; :353-357): ADDED to the scaled scores of every batch element and head before the key
+        padding fill and the softmax (a causal mask is -inf above the diagonal).  Takes the weights route whatever
+        need_weights says (the fused kernel never sees the scores): the mask joins the fp32 logits of K4 by one rnamsm_add per
+        head; a query row left with no admissible key at all is NaN, as in the reference.
+    Raises for what is outside eval-mode self-attention: incremental state, static_kv, before_softmax,
     bias_kv / zero_attn, cross-attention, dropout in training."""
 
     def __init__(self, embed_dim, num_heads, kdim=None, vdim=None, dropout=0.0, bias=True, add_bias_kv=False,
@@ -360,15 +364,19 @@ class MultiheadAttention(_AxialAttentionBase):
         self.self_attention = True
 
     @staticmethod
-    def _reference_nan(out, weights, kpm, need_head_weights):
-        """msm/multihead_attention.py:360-371: masked_fill(-inf) then softmax -- a batch element with EVERY key masked comes out
-        NaN (attention output and weights).  The kernels give such an element uniform weights; one select per tensor restores
-        the reference's values (only when a mask was passed; no host sync)."""
-        dead = kpm.bool().all(dim=1)                                                # [B]
+    def _reference_nan(out, weights, kpm, need_head_weights, attn_mask=None):
+        """msm/multihead_attention.py:353-371: attn_mask added, masked_fill(-inf), then softmax -- a query left with NO admissible
+        key (every key padded, or padded / -inf in its attn_mask row) comes out NaN: attention output row and weights row.  The
+        kernels fill padded keys with -10000 and give such a query uniform weights over them; one select per tensor restores
+        the reference's values (only when a key mask was passed; no host sync).  out [T, B, E]."""
+        masked = kpm.bool()[:, None, :]                                             # [B, 1, T(keys)]
+        if attn_mask is not None:
+            masked = masked | torch.isneginf(attn_mask)[None]                       # [B, T(queries), T(keys)]
+        dead = masked.all(dim=2)                                                    # [B, T] or [B, 1]
         nan = torch.full((), float("nan"), device=out.device, dtype=out.dtype)
-        out = torch.where(dead[None, :, None], nan, out)
+        out = torch.where(dead.t()[:, :, None], nan, out)                           # [T | 1, B, 1] over [T, B, E]
         if weights is not None:
-            weights = torch.where(dead[None, :, None, None] if need_head_weights else dead[:, None, None], nan, weights)
+            weights = torch.where(dead[None, :, :, None] if need_head_weights else dead[:, :, None], nan, weights)
         return out, weights
 
     def forward(self, query, key=None, value=None, key_padding_mask=None, incremental_state=None, need_weights=True,
@@ -376,13 +384,14 @@ class MultiheadAttention(_AxialAttentionBase):
         out, weights = self._forward(query, key, value, key_padding_mask, incremental_state, need_weights, static_kv, attn_mask,
                                      before_softmax, need_head_weights)
         if key_padding_mask is not None:
-            out, weights = self._reference_nan(out, weights, key_padding_mask.to(out.device), need_head_weights and weights is not None)
+            out, weights = self._reference_nan(out, weights, key_padding_mask.to(out.device), need_head_weights and weights is not None,
+                                               None if attn_mask is None else attn_mask.to(out.device))
         return out, weights
 
     def _forward(self, query, key=None, value=None, key_padding_mask=None, incremental_state=None, need_weights=True,
                  static_kv=False, attn_mask=None, before_softmax=False, need_head_weights=False):
-        if attn_mask is not None or incremental_state is not None or static_kv:
-            raise NotImplementedError("attn_mask / incremental decoding are not implemented")
+        if incremental_state is not None or static_kv:
+            raise NotImplementedError("incremental decoding is not implemented")
         if before_softmax:
             raise NotImplementedError("before_softmax is not implemented")
         if (key is not None and key is not query) or (value is not None and value is not query):
@@ -399,10 +408,18 @@ class MultiheadAttention(_AxialAttentionBase):
             if tuple(key_padding_mask.shape) != (B, T):
                 raise ValueError(f"expected key_padding_mask of shape [{B}, {T}], got {tuple(key_padding_mask.shape)}")
             kpm = key_padding_mask.to(device=query.device, dtype=torch.uint8).contiguous()
+        am = None
+        want_weights = need_weights
+        if attn_mask is not None:
+            if tuple(attn_mask.shape) != (T, T) or not attn_mask.is_floating_point():
+                raise ValueError(f"expected a float attn_mask of shape [{T}, {T}], got {attn_mask.dtype} {tuple(attn_mask.shape)}")
+            am = attn_mask.to(device=query.device, dtype=torch.float32).contiguous()
+            need_weights = True                                         # the scores must exist for the mask to meet them
         x2 = query.contiguous().view(T * B, E)
         mode = _mode_of(self)
         if mode is not None:
-            return self._forward16(x2, T, B, E, kpm, need_weights, need_head_weights, *mode)
+            out, weights = self._forward16(x2, T, B, E, kpm, need_weights, need_head_weights, *mode, attn_mask=am)
+            return out, (weights if want_weights else None)
         qkv = self._qkv(x2, self.scaling)                               # [T*B, 3E], token (t, b) = row t*B + b
         if not need_weights:
             # fused: R := T, C := B; its pad mask is indexed like the tokens, [T, B]
@@ -417,15 +434,29 @@ class MultiheadAttention(_AxialAttentionBase):
         for b in range(B):                                              # one "alignment" of a single row per element
             qb = qkv3[:, b]                                             # [T, 3E] view, row stride B*3E
             partial, _ = ops.row_logits(qb[:, :E], qb[:, E:2 * E], 1, T, H)
+            self._add_attn_mask(partial, am)
             ops.softmax_rows(partial, out=probs[b], key_mask=None if kpm is None else kpm[b])
             ops.row_apply(probs[b], qb[:, 2 * E:], 1, T, H, out=ctx[:, b])
         out = self._project_out(ctx.view(T * B, E), None).view(T, B, E)
+        if not want_weights:
+            return out, None
         weights = probs.permute(1, 0, 2, 3)                             # [H, B, T, T]  (:389-393)
         if not need_head_weights:
             weights = ops.head_mean(weights)                            # [B, T, T]     (:394-397)
         return out, weights
 
-    def _forward16(self, x2, T, B, E, kpm, need_weights, need_head_weights, split, fmt):
+    @staticmethod
+    def _add_attn_mask(partial, am):
+        """attn_weights += attn_mask (msm/multihead_attention.py:353-357) on K4's fp32 logits [nsplit = 1, H, T, T] of one batch
+        element, head by head (rnamsm_add, in place)."""
+        if am is None:
+            return
+        if partial.shape[0] != 1:
+            raise NotImplementedError("attn_mask: the single-row logits are expected in one slab")
+        for h in range(partial.shape[1]):
+            ops.add(partial[0, h], am, out=partial[0, h])
+
+    def _forward16(self, x2, T, B, E, kpm, need_weights, need_head_weights, split, fmt, attn_mask=None):
         """The same two routes on the 16-bit kernels (operands as hi(/lo) planes, q unscaled, fp32 softmax)."""
         H = self.num_heads
         qkv = self._qkv_planes(x2, split, fmt)                          # planes [T*B, 3E]
@@ -442,6 +473,7 @@ class MultiheadAttention(_AxialAttentionBase):
         for b in range(B):
             qb = tuple(None if p is None else p[:, b] for p in qkv3)   # [T, 3E] plane views, row stride B*3E
             partial, _ = ops.row_logits16(_cols(qb, 0, E), _cols(qb, E, 2 * E), 1, T, H, fmt=fmt, scale=self.scaling)
+            self._add_attn_mask(partial, attn_mask)
             pb, p_pl = ops.softmax_rows_planes(partial, split=split, fmt=fmt, plane_scale=4096.0,
                                                key_mask=None if kpm is None else kpm[b])
             probs[b] = pb

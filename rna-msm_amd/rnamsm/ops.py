@@ -513,11 +513,15 @@ def pack_outputs(x_final: torch.Tensor, probs_all: torch.Tensor, C: int) -> Tupl
 
 
 @_on_operand_device
-def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a + b, fp32, same shape (the residual add of NormalizedResidualBlock around a foreign layer, modules.py:396)."""
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a + b, fp32, same shape (the residual add of NormalizedResidualBlock around a foreign layer, modules.py:396).  `out` (a
+    contiguous fp32 tensor of that shape) may be `a` or `b` itself: the kernel reads an element before it writes it."""
     assert a.shape == b.shape
-    a, b = a.contiguous(), b.contiguous()
-    out = torch.empty_like(a, dtype=torch.float32)
+    if out is None:
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a, dtype=torch.float32)
+    else:
+        assert out.shape == a.shape and out.is_contiguous() and a.is_contiguous() and b.is_contiguous()
     _lib.check(_lib.load().rnamsm_add(_dev(a, "a"), _dev(b, "b"), _dev(out, "out"), out.numel(), _stream()))
     return out
 

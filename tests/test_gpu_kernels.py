@@ -519,10 +519,45 @@ def test_generic_mha_matches_reference_fixture(dev, name):
     y7, w7 = mha(x, x, x, key_padding_mask=kpm, need_weights=False)
     assert w7 is None and rel_l2(y7.cpu(), gm["out_masked"]) < 2e-5
     mha.gemm_dtype = "f32"
-    with pytest.raises(NotImplementedError):
-        mha(x, x, x, attn_mask=torch.zeros(T, T, device=dev))
+    y8, w8 = mha(x, x, x, attn_mask=torch.zeros(T, T, device=dev))               # a zero attn_mask changes nothing (weights route)
+    assert rel_l2(y8.cpu(), g["out"]) < TOL_REL and np.abs(w8.cpu().numpy() - g["avg_weights"]).max() < TOL_PROB
+    with pytest.raises(ValueError):
+        mha(x, x, x, attn_mask=torch.zeros(T, T, dtype=torch.bool, device=dev))  # the reference ADDS the mask: float only
     with pytest.raises(ValueError):
         mha(x, x, x, key_padding_mask=torch.zeros(T, B, dtype=torch.bool, device=dev))
+
+
+def test_generic_mha_with_attn_mask_matches_reference_fixture(dev):
+    """msm/multihead_attention.py:353-357 (round 5): a float [T, T] attn_mask is added to the scores of every batch element and
+    head -- here a causal mask (-inf above the diagonal) plus finite biases -- alone and with a key_padding_mask; fixture from
+    the reference itself (tests/golden/make_golden_r5.py).  Queries left without any admissible key are NaN rows, as there."""
+    from rnamsm import modules as M
+    g = golden("mha_attn_mask.npz")
+    T, B, E, H = (int(v) for v in g["meta"])
+    state = synthetic.make_state_dict(seed=int(g["seed"]), embed_dim=E, num_layers=1, num_heads=H)
+    prefix = "layers.0.row_self_attention.layer"
+    mha = M.MultiheadAttention(E, H, self_attention=True)
+    mha.load_state_dict({k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in state.items() if k.startswith(prefix + ".")}, strict=True)
+    mha = mha.eval().to(dev)
+    x = torch.from_numpy(synthetic.normal("mha:attn_mask", 13, (T, B, E)).astype(np.float32)).to(dev)
+    am = torch.from_numpy(g["attn_mask"]).to(dev)
+    kpm = torch.from_numpy(g["key_padding_mask"]).to(dev)
+    for mode, tol, ptol in (("f32", TOL_REL, TOL_PROB), ("f16x3", 2e-5, 2e-5)):
+        mha.gemm_dtype = mode
+        y, w = mha(x, x, x, attn_mask=am)
+        assert rel_l2(y.cpu(), g["out"]) < tol and np.abs(w.cpu().numpy() - g["avg_weights"]).max() < ptol, mode
+        assert float(w[:, 0, 1:].abs().max()) == 0.0                           # query 0 attends to key 0 only
+        yh, wh = mha(x, x, x, attn_mask=am, need_head_weights=True)
+        assert torch.equal(yh, y) and np.abs(wh.cpu().numpy() - g["head_weights"]).max() < ptol, mode
+        yn, wn = mha(x, x, x, attn_mask=am, need_weights=False)                    # no weights returned; same route, same bits
+        assert wn is None and torch.equal(yn, y) and rel_l2(yn.cpu(), g["out_noweights"]) < max(tol, 1e-5), mode
+        yk, wk = mha(x, x, x, attn_mask=am, key_padding_mask=kpm)
+        want, want_w = g["out_kpm"], g["avg_weights_kpm"]
+        live = np.isfinite(want)
+        assert np.array_equal(np.isnan(yk.cpu().numpy()), ~live) and np.array_equal(np.isnan(wk.cpu().numpy()), np.isnan(want_w)), mode
+        assert rel_l2(np.where(live, yk.cpu().numpy(), 0.0), np.where(live, want, 0.0)) < tol, mode
+        assert np.nanmax(np.abs(wk.cpu().numpy() - want_w)) < ptol, mode
+    mha.gemm_dtype = "f32"
 
 
 def test_residual_block_around_a_foreign_layer_and_all_masked_mha_match_reference_fixtures(dev):

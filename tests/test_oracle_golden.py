@@ -213,6 +213,26 @@ def test_generic_mha_weights_and_key_padding_mask_match_reference(name):
     assert float(w[:, 0, :, T - 5:].max()) == 0.0 and float(w[:, B - 1, :, 3].max()) == 0.0
 
 
+def test_generic_mha_with_attn_mask_matches_reference():
+    """msm/multihead_attention.py:353-357: the float attn_mask is added to the scores before the key padding fill and the softmax
+    (fixture: a causal mask plus finite biases, alone and with a key_padding_mask; NaN rows where no key is admissible)."""
+    g = golden("mha_attn_mask.npz")
+    T, B, E, H = (int(v) for v in g["meta"])
+    st = O.to_torch_params(synthetic.make_state_dict(seed=int(g["seed"]), embed_dim=E, num_layers=1, num_heads=H))
+    x = torch.from_numpy(synthetic.normal("mha:attn_mask", 13, (T, B, E)).astype(np.float32))
+    pre = "layers.0.row_self_attention.layer"
+    am = torch.from_numpy(g["attn_mask"])
+    y, w = O.multihead_self_attention(x, st, pre, H, return_weights=True, attn_mask=am)
+    assert rel_l2(y, g["out"]) < 1e-5 and np.abs(w.numpy() - g["head_weights"]).max() < 2e-6
+    assert np.abs(w.mean(0).numpy() - g["avg_weights"]).max() < 2e-6
+    yk, wk = O.multihead_self_attention(x, st, pre, H, key_padding_mask=torch.from_numpy(g["key_padding_mask"]), return_weights=True,
+                                        attn_mask=am)
+    live = np.isfinite(g["out_kpm"])
+    assert np.array_equal(np.isnan(yk.numpy()), ~live)
+    assert rel_l2(np.where(live, yk.numpy(), 0.0), np.where(live, g["out_kpm"], 0.0)) < 1e-5
+    assert np.nanmax(np.abs(wk.mean(0).numpy() - g["avg_weights_kpm"])) < 2e-6
+
+
 def test_full_2drb1_alignment_tokens_and_default_subsampling_bit_exact(full_2drb1_a2m):
     """BASELINE configs[0] at full depth: the shipped 1176-row alignment (rebuilt from the reference reader's token matrix)
     through the reader, then `diversity-max` to the CLI default of 512 rows (utils/align.py:128-148) -- tokens bit-exact
