@@ -69,6 +69,62 @@ extern "C" size_t rnamsm_forward_workspace_bytes(const rnamsm_model_dims* dims, 
         if (rc_ != RNAMSM_OK) return rc_; \
     } while (0)
 
+namespace {
+// The token-parallel launches of the EXACT path -- LayerNorm (or its fold), the Linear that consumes it, the Linear that writes the
+// residual stream -- written once for the three drivers (rnamsm_forward, _forward_batch, _forward_packed; round 5: they had been
+// three copies of the same three lambdas).  T = tokens of the launch set and of the K-split decisions (the whole alignment's /
+// batch's count also where only the first `rows` tokens are computed: the outputs-only tail), so that a part of a Linear sums in
+// the order of the whole.
+struct ExactPath {
+    const rnamsm_model_dims& d;
+    float* x;                     // residual stream [T, D]
+    float* xn;                    // LayerNorm output [T, D] (unused when folded)
+    float* rowsum;                // slab sums of x, left by whoever wrote it (folded)
+    float* stats;                 // (mean, rstd) per token (folded)
+    float* splitk;                // split-K partial tiles
+    int64_t T;
+    bool fold;                    // LayerNorm applied inside the consuming GEMM
+    bool fold_sums;               // ... with the row statistics from the producers' epilogues (false: every GEMM sums its own rows, knob ln_fold = 2)
+    const float* const* ln_folded;
+    int* err_flag;
+    void* stream;
+
+    int norm(const float* g, const float* b, int64_t rows) const {
+        if (fold) return RNAMSM_OK;
+        return rnamsm_layernorm(x, g, b, xn, rows, d.embed_dim, d.ln_eps, stream);
+    }
+    // x[:rows] += A W^T + bias; folded: + the rows' slab sums, combined into (mean, rstd) right away
+    int res_linear(const float* A, int64_t lda, const float* Wf, const float* bias, int64_t rows, int K) const {
+        const int D = d.embed_dim;
+        if (fold_sums) {
+            FWD(rnamsm_gemm_residual_stats(A, lda, Wf, bias, x, D, x, D, rows, D, K, rowsum, T, RNAMSM_F32, stream));
+            return rnamsm_row_stats_from_partials(rowsum, T, rows, D, d.ln_eps, stats, err_flag, stream);
+        }
+        // > 1 only under the "gemm_splitk" knob (fc2 of small MSAs; off by default since round 5), decided by the WHOLE token count
+        const int ks = rnamsm::gemm_f32_splitk_factor(T, D, K);
+        if (ks > 1) return rnamsm::gemm_f32_splitk(A, lda, Wf, bias, x, D, x, D, rows, D, K, ks, splitk, static_cast<hipStream_t>(stream));
+        return rnamsm_gemm_bias_act_res(A, lda, Wf, bias, x, D, x, D, rows, D, K, RNAMSM_ACT_NONE, 1.f, 0, nullptr, RNAMSM_F32, stream);
+    }
+    // columns n_ofs .. n_ofs + N - 1 of the Linear in folded slot fslot (0 row QKV, 1 column QKV, 2 fc1) over `rows` tokens of LN(x)
+    int lin_normed(int layer, int fslot, const float* Wf, const float* bias, int n_ofs, float* out, int64_t ldc, int64_t rows, int N,
+                   int act, float scale, int scale_cols) const {
+        const int D = d.embed_dim;
+        if (fold) {
+            const float* const* Fp = ln_folded + (size_t)layer * RNAMSM_FOLDED_PER_LAYER + 3 * fslot;
+            return rnamsm_gemm_lnfold(x, D, Fp[0] + (size_t)n_ofs * D, Fp[1] + n_ofs, Fp[2] + n_ofs, d.ln_eps, fold_sums ? stats : nullptr,
+                                      err_flag, out, ldc, rows, N, D, act, scale, scale_cols, RNAMSM_F32, stream);
+        }
+        // (knob "gemm_splitk_short": the K = 768 GEMM of a lone small alignment split over idle CUs; by the FULL width of the Linear)
+        const int ks = rnamsm::gemm_f32_splitk_factor(T, fslot == 2 ? d.ffn_dim : 3 * D, D);
+        if (ks > 1 && N % 128 == 0)
+            return rnamsm::gemm_f32_splitk(xn, D, Wf + (size_t)n_ofs * D, bias + n_ofs, nullptr, 0, out, ldc, rows, N, D, ks, splitk,
+                                           static_cast<hipStream_t>(stream), act, scale, scale_cols);
+        return rnamsm_gemm_bias_act_res(xn, D, Wf + (size_t)n_ofs * D, bias + n_ofs, nullptr, 0, out, ldc, rows, N, D, act, scale,
+                                        scale_cols, nullptr, RNAMSM_F32, stream);
+    }
+};
+}  // namespace
+
 extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
                               int R, int C, void* workspace, size_t workspace_bytes, float* row_attn, float* repr,
                               float* emb, float* atp, int* err_flag, int has_padding, int max_tokens_per_msa, int outputs,
@@ -196,38 +252,15 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         FWD(rnamsm_gemm16_residual_stats(ahi, alo, lda, P[0], P[1], bias, x, D, T, D, K, split, fmt, xn_hi, xn_lo, D, rowsum, T, stream));
         return rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream);
     };
-    auto norm = [&](const float* g, const float* b, int64_t rows) -> int {
-        if (fold) return RNAMSM_OK;
-        return rnamsm_layernorm(x, g, b, xn, rows, D, d.ln_eps, stream);
-    };
-    // x[:rows] += A W^T + bias on the exact path; folded: + the rows' slab sums, combined into (mean, rstd) right away
+    // the exact path's token-parallel launches (ExactPath above): LayerNorm or its fold, the Linear it feeds, the residual Linear
+    const ExactPath ex{d, x, xn, rowsum, stats, splitk, T, fold, fold_sums, ln_folded, err_flag, stream};
+    auto norm = [&](const float* g, const float* b, int64_t rows) -> int { return ex.norm(g, b, rows); };
     auto res_linear = [&](const float* A, int64_t lda, const float* Wf, const float* bias, int64_t rows, int K) -> int {
-        if (fold_sums) {
-            FWD(rnamsm_gemm_residual_stats(A, lda, Wf, bias, x, D, x, D, rows, D, K, rowsum, T, f32, stream));
-            return rnamsm_row_stats_from_partials(rowsum, T, rows, D, d.ln_eps, stats, err_flag, stream);
-        }
-        // > 1 only for fc2 of small MSAs; decided by the WHOLE alignment's token count also where only the first `rows` are
-        // computed (outputs-only forward), so that those rows come out bit-identical to the full forward's
-        const int ks = rnamsm::gemm_f32_splitk_factor(T, D, K);
-        if (ks > 1) return rnamsm::gemm_f32_splitk(A, lda, Wf, bias, x, D, x, D, rows, D, K, ks, splitk, static_cast<hipStream_t>(stream));
-        return rnamsm_gemm_bias_act_res(A, lda, Wf, bias, x, D, x, D, rows, D, K, RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream);
+        return ex.res_linear(A, lda, Wf, bias, rows, K);
     };
-    // columns n_ofs .. n_ofs + N - 1 of the Linear in folded slot fslot (0 row QKV, 1 column QKV, 2 fc1) over `rows` tokens
     auto lin_normed = [&](int layer, int fslot, const float* Wf, const float* bias, int n_ofs, float* out, int64_t ldc,
                           int64_t rows, int N, int act, float scale, int scale_cols) -> int {
-        if (fold) {
-            const float* const* Fp = ln_folded + (size_t)layer * RNAMSM_FOLDED_PER_LAYER + 3 * fslot;
-            return rnamsm_gemm_lnfold(x, D, Fp[0] + (size_t)n_ofs * D, Fp[1] + n_ofs, Fp[2] + n_ofs, d.ln_eps, fold_sums ? stats : nullptr, err_flag, out, ldc, rows, N, D,
-                                      act, scale, scale_cols, f32, stream);
-        }
-        // a lone small alignment: the K = 768 GEMM split over idle CUs too (decided by the whole alignment's token count and the
-        // FULL width of the Linear, so that a part of it -- the outputs-only forward -- sums in the same order)
-        const int ks = rnamsm::gemm_f32_splitk_factor(T, fslot == 2 ? F : 3 * D, D);
-        if (ks > 1 && N % 128 == 0)
-            return rnamsm::gemm_f32_splitk(xn, D, Wf + (size_t)n_ofs * D, bias + n_ofs, nullptr, 0, out, ldc, rows, N, D, ks, splitk,
-                                           static_cast<hipStream_t>(stream), act, scale, scale_cols);
-        return rnamsm_gemm_bias_act_res(xn, D, Wf + (size_t)n_ofs * D, bias + n_ofs, nullptr, 0, out, ldc, rows, N, D, act, scale,
-                                        scale_cols, nullptr, f32, stream);
+        return ex.lin_normed(layer, fslot, Wf, bias, n_ofs, out, ldc, rows, N, act, scale, scale_cols);
     };
     const float col_scale = 1.0f / sqrtf(64.0f);                         // modules.py:839
     // align_scaling (modules.py:713-715) = dh^-1/2 / sqrt(R).  ONE arithmetic per alignment, whatever the batch it is computed
@@ -558,28 +591,14 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
         return RNAMSM_OK;
     }
 
-    auto norm = [&](const float* g, const float* b) -> int {
-        return fold ? RNAMSM_OK : rnamsm_layernorm(x, g, b, xn, T, D, d.ln_eps, stream);
-    };
+    const ExactPath ex{d, x, xn, rowsum, stats, splitk, T, fold, fold, ln_folded, err_flag, stream};
+    auto norm = [&](const float* g, const float* b) -> int { return ex.norm(g, b, T); };
     auto lin_normed = [&](int layer, int fslot, const float* Wf, const float* bias, float* out, int64_t ldc, int N, int act,
                           float scale, int scale_cols) -> int {
-        if (fold) {
-            const float* const* Fp = ln_folded + (size_t)layer * RNAMSM_FOLDED_PER_LAYER + 3 * fslot;
-            return rnamsm_gemm_lnfold(x, D, Fp[0], Fp[1], Fp[2], d.ln_eps, stats, err_flag, out, ldc, T, N, D, act, scale,
-                                      scale_cols, f32, stream);
-        }
-        const int ks = rnamsm::gemm_f32_splitk_factor(T, N, D);          // (few tokens: the K = 768 GEMM split over idle CUs)
-        if (ks > 1) return rnamsm::gemm_f32_splitk(xn, D, Wf, bias, nullptr, 0, out, ldc, T, N, D, ks, splitk, hs, act, scale, scale_cols);
-        return rnamsm_gemm_bias_act_res(xn, D, Wf, bias, nullptr, 0, out, ldc, T, N, D, act, scale, scale_cols, nullptr, f32, stream);
+        return ex.lin_normed(layer, fslot, Wf, bias, 0, out, ldc, T, N, act, scale, scale_cols);
     };
     auto res_linear = [&](const float* A, int64_t lda, const float* Wf, const float* bias, int K) -> int {
-        if (fold) {
-            FWD(rnamsm_gemm_residual_stats(A, lda, Wf, bias, x, D, x, D, T, D, K, rowsum, T, f32, stream));
-            return rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream);
-        }
-        const int ks = rnamsm::gemm_f32_splitk_factor(T, D, K);
-        if (ks > 1) return rnamsm::gemm_f32_splitk(A, lda, Wf, bias, x, D, x, D, T, D, K, ks, splitk, hs);
-        return rnamsm_gemm_bias_act_res(A, lda, Wf, bias, x, D, x, D, T, D, K, RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream);
+        return ex.res_linear(A, lda, Wf, bias, T, K);
     };
 
     // K0 of the whole batch in one launch (the row-position table restarts with every alignment: row index mod R)
@@ -725,7 +744,6 @@ extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float*
     float* ctx = wide + T * ldq;       // [T, D]
     float* hidden = wide;              // [T, F]
     const float* const* G = weights;
-    const int f32 = RNAMSM_F32;
     const int fold_mode = tuning().ln_fold;
     // folded only where EVERY member's own forward would fold (>= 18432 tokens each): an alignment's rounding must not depend
     // on its company.  The CLI packs alignments of <= 8192 tokens, so its packed groups never fold (a 64 k-token group gives up
@@ -736,28 +754,14 @@ extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float*
     const float qk_scale = 1.0f / sqrtf(64.0f);
     const PackedMsa* hp = host.data();
 
-    auto norm = [&](const float* g, const float* b) -> int {
-        return fold ? RNAMSM_OK : rnamsm_layernorm(x, g, b, xn, T, D, d.ln_eps, stream);
-    };
+    const ExactPath ex{d, x, xn, rowsum, stats, splitk, T, fold, fold, ln_folded, err_flag, stream};
+    auto norm = [&](const float* g, const float* b) -> int { return ex.norm(g, b, T); };
     auto lin_normed = [&](int layer, int fslot, const float* Wf, const float* bias, float* out, int64_t ldc, int N, int act,
                           float scale, int scale_cols) -> int {
-        if (fold) {
-            const float* const* Fp = ln_folded + (size_t)layer * RNAMSM_FOLDED_PER_LAYER + 3 * fslot;
-            return rnamsm_gemm_lnfold(x, D, Fp[0], Fp[1], Fp[2], d.ln_eps, stats, err_flag, out, ldc, T, N, D, act, scale,
-                                      scale_cols, f32, stream);
-        }
-        const int ks = rnamsm::gemm_f32_splitk_factor(T, N, D);          // (few tokens: the K = 768 GEMM split over idle CUs)
-        if (ks > 1) return rnamsm::gemm_f32_splitk(xn, D, Wf, bias, nullptr, 0, out, ldc, T, N, D, ks, splitk, hs, act, scale, scale_cols);
-        return rnamsm_gemm_bias_act_res(xn, D, Wf, bias, nullptr, 0, out, ldc, T, N, D, act, scale, scale_cols, nullptr, f32, stream);
+        return ex.lin_normed(layer, fslot, Wf, bias, 0, out, ldc, T, N, act, scale, scale_cols);
     };
     auto res_linear = [&](const float* A, int64_t lda, const float* Wf, const float* bias, int K) -> int {
-        if (fold) {
-            FWD(rnamsm_gemm_residual_stats(A, lda, Wf, bias, x, D, x, D, T, D, K, rowsum, T, f32, stream));
-            return rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream);
-        }
-        const int ks = rnamsm::gemm_f32_splitk_factor(T, D, K);
-        if (ks > 1) return rnamsm::gemm_f32_splitk(A, lda, Wf, bias, x, D, x, D, T, D, K, ks, splitk, hs);
-        return rnamsm_gemm_bias_act_res(A, lda, Wf, bias, x, D, x, D, T, D, K, RNAMSM_ACT_NONE, 1.f, 0, nullptr, f32, stream);
+        return ex.res_linear(A, lda, Wf, bias, T, K);
     };
 
     FWD(rnamsm::packed_descriptors_upload(hp, B, desc, hs));

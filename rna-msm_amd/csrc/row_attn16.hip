@@ -661,6 +661,11 @@ __global__ __launch_bounds__(512, 1) void row_logits16q_kernel(
 // matrix-pipe time in proportion to the bytes they pull into the CU, so the tile size is the lever.
 // 8 waves as 2 (M) x 4 (N): wave tile 128 x 64 = one alignment row; the loop is gemm16_swp_kernel's (two fragment sets,
 // one LDS read per MFMA, barrier in the middle of a tile), with the B fragments coming from "t" tiles by transposed read.
+// Throw-away what-if builds of row_apply16x_kernel (wrong results, timing only; tools/whatif_row_apply16.sh): 1 no MFMAs, 2 no LDS-DMA
+// inside the K loop, 4 one K tile per block, 8 no epilogue stores.  0 in the shipped library (every use folds away).
+#ifndef R16X_WHATIF
+#define R16X_WHATIF 0
+#endif
 constexpr int R16X_THREADS = 512;
 // KT = keys per K tile: 32 (64-B P rows; the hi/lo modes: four planes per stage) or 64 (128-B P rows = whole cache lines per
 // DMA row, half the barriers; plain bf16 only, knob "row16_bk64": two 64 KB stages)
@@ -781,6 +786,10 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
+                if (R16X_WHATIF & 1) {
+                    asm volatile("" :: "v"(f.a[0][mt][0]), "v"(b[0][nt][0]));
+                    continue;
+                }
                 if (SPLIT == 3) {
                     acc[mt][nt] = Half16<FMT>::mfma(f.a[NPL - 1][mt], b[0][nt], acc[mt][nt]);
                     acc[mt][nt] = Half16<FMT>::mfma(f.a[0][mt], b[NPL - 1][nt], acc[mt][nt]);
@@ -808,7 +817,7 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[mt][nt][t] = 0.f;
 
-    const int nk = (C + KT - 1) / KT;
+    const int nk = (R16X_WHATIF & 4) ? 1 : (C + KT - 1) / KT;
     issue(0, 0);
     wait_dma_then_barrier<0>();
     issue(nk > 1 ? 1 : 0, 1);
@@ -826,12 +835,12 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
         // every wave is done reading `cur` once its last fragments have arrived; tile kt+1 (issued one tile ago) must have landed
         wait_dma_then_barrier<0>();
         const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;              // clamped: the last reload is never read
-        if (!dephase || wm == 0) issue(k2, kt & 1);                // "gemm16_dephase": the upper wave group issues one step later
+        if ((!dephase || wm == 0) && !(R16X_WHATIF & 2)) issue(k2, kt & 1);                // "gemm16_dephase": the upper wave group issues one step later
         __builtin_amdgcn_sched_barrier(0);
         frag_load(nxt, 0, f[0]);
         frag_mma(f[(KS - 1) & 1], acc, next_set_t());
         interleave();
-        if (dephase && wm == 1) issue(k2, kt & 1);
+        if (dephase && wm == 1 && !(R16X_WHATIF & 2)) issue(k2, kt & 1);
         __builtin_amdgcn_sched_barrier(0);
     }
     {
@@ -859,6 +868,7 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
         const int ibase = i0 + wm * 128 + p * 64;
         auto rowoff = [&](int row) -> int64_t {
             const int i = ibase + row;
+            if ((R16X_WHATIF & 8) && i >= 0) return (int64_t)-1;
             return (r < R && i < C) ? ((int64_t)r * C + i) * ldc + h * 64 : (int64_t)-1;
         };
         slab_store_64x64<OUT>(a2, reinterpret_cast<float*>(smem_b) + wv * (64 * 68), li, lh, lane, rowoff, ctx, ctx_hi, ctx_lo);
