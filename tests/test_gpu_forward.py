@@ -1056,3 +1056,46 @@ def test_short_k_split_of_a_lone_small_alignment_agrees_to_rounding(model):
         assert not torch.equal(split["repr"], base["repr"])                      # the split form is what ran
         assert rel_l2(split["repr"].cpu().numpy(), base["repr"].cpu().numpy()) < 5e-6
         assert np.abs(split["atp"].cpu().numpy() - base["atp"].cpu().numpy()).max() < 2e-5
+
+
+def test_set_param_is_refused_while_a_forward_is_being_enqueued(model):
+    """the tuning knobs are process-global and read on the host while a driver enqueues its ~140 launches; a
+    write from another thread in that window would let one forward mix two settings.  The drivers count themselves in and
+    rnamsm_set_param refuses (RNAMSM_ERR_INVALID, nothing changed) until the count is zero again.  One thread enqueues forwards
+    back to back (ctypes releases the GIL inside the call), this one hammers a harmless knob: some writes must be refused with
+    the documented text, every refused write must have left the knob alone, and the writes succeed again afterwards."""
+    import threading
+    from rnamsm import _lib
+    m, _ = model
+    lib = _lib.load()
+    t = torch.from_numpy(synthetic.make_tokens(24, 60, 77)).to("cuda:0")
+    m.forward_one(t)
+    torch.cuda.synchronize()
+    stop = threading.Event()
+
+    def worker():
+        with torch.no_grad():
+            while not stop.is_set():
+                m.forward_one(t)
+        torch.cuda.synchronize()
+
+    th = threading.Thread(target=worker)
+    before = lib.rnamsm_get_param(b"gemm_group")
+    th.start()
+    refused = accepted = 0
+    try:
+        import time
+        t_end = time.time() + 1.0
+        while time.time() < t_end:
+            rc = lib.rnamsm_set_param(b"gemm_group", before)          # (the value it already has: harmless when accepted)
+            if rc == 0:
+                accepted += 1
+            else:
+                assert rc == -1 and b"forward driver is enqueuing" in lib.rnamsm_last_error()
+                refused += 1
+    finally:
+        stop.set()
+        th.join()
+    assert refused > 0, (refused, accepted)                            # the window was hit ...
+    assert lib.rnamsm_get_param(b"gemm_group") == before               # ... and nothing changed
+    assert lib.rnamsm_set_param(b"gemm_group", before) == 0            # idle again: writes go through
