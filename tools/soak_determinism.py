@@ -51,5 +51,21 @@ if os.environ.get("BIG", "1") != "0":
         mism += 0 if all(torch.equal(x["emb"], y["emb"]) and torch.equal(x["atp"], y["atp"]) for x, y in zip(out, ref)) else 1
     bad += mism
     print(f"packed batch of 40 unlike alignments: {ITER} reruns, {mism} mismatches", flush=True)
+    # round 5: every member of that batch against its OWN forward, bit for bit (one arithmetic per alignment), and the packed batch
+    # in the 16-bit modes (reruns)
+    mism = sum(0 if (torch.equal(r["emb"], (o := m.forward_one(t, need_repr=False))["emb"]) and torch.equal(r["atp"], o["atp"])) else 1
+               for t, r in zip(msas, ref))
+    bad += mism
+    print(f"packed members against their own forward: {len(msas)} alignments, {mism} not bit-identical", flush=True)
+    for mode in ("bf16", "f16x3"):
+        m.gemm_dtype = mode
+        ref16 = m.forward_packed(msas)
+        mism = 0
+        for _ in range(ITER):
+            out = m.forward_packed(msas)
+            mism += 0 if all(torch.equal(x["emb"], y["emb"]) and torch.equal(x["atp"], y["atp"]) for x, y in zip(out, ref16)) else 1
+        bad += mism
+        print(f"packed batch in {mode}: {ITER} reruns, {mism} mismatches", flush=True)
+    m.gemm_dtype = "f32"
 print("SOAK", "FAILED" if bad else "OK")
 sys.exit(1 if bad else 0)
