@@ -164,6 +164,15 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().row_vt = value != 0;
         return RNAMSM_OK;
     }
+    if (name && !strcmp(name, "row_narrow")) {
+        rnamsm::tuning().row_narrow = value != 0;
+        return RNAMSM_OK;
+    }
+    if (name && !strcmp(name, "row_narrow_rows")) {
+        if (value < 0 || value > 1024) return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: row_narrow_rows must be in [0, 1024]");
+        rnamsm::tuning().row_narrow_rows = value;
+        return RNAMSM_OK;
+    }
     if (name && !strcmp(name, "attn16")) {
         rnamsm::tuning().attn16 = value;
         return RNAMSM_OK;
@@ -264,6 +273,8 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "gemm_splitk")) return rnamsm::tuning().gemm_splitk;
     if (name && !strcmp(name, "gemm16_stagger")) return rnamsm::tuning().gemm16_stagger;
     if (name && !strcmp(name, "row_vt")) return rnamsm::tuning().row_vt;
+    if (name && !strcmp(name, "row_narrow")) return rnamsm::tuning().row_narrow;
+    if (name && !strcmp(name, "row_narrow_rows")) return rnamsm::tuning().row_narrow_rows;
     if (name && !strcmp(name, "gemm_tile")) return rnamsm::tuning().gemm_tile;
     if (name && !strcmp(name, "gemm_group")) return rnamsm::tuning().gemm_group;
     return -1;

@@ -20,6 +20,7 @@
 namespace rnamsm {
 
 constexpr int HEAD_DIM = 64;
+constexpr int ROW_NARROW_MAX_C = 64;     // alignments this narrow take the *_narrow kernels (K4, K6)
 constexpr int ROWLOGITS_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;
 constexpr int ROWAPPLY_LDS_BYTES = 2 * (TILE_KC + TILE_NC) * 4;
 constexpr int ROWAPPLY_VT_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;
@@ -35,13 +36,14 @@ constexpr int ROWAPPLY_VT_LDS_BYTES = 2 * (TILE_KC + TILE_KC) * 4;
 __global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
     const float* __restrict__ q, const float* __restrict__ k, int64_t ld, float* __restrict__ partial,
     int R, int C, int H, int nsplit, int rows_per_split, int chain_tiles, int64_t qk_bstride, int64_t part_bstride,
-    const PackedMsa* __restrict__ pk) {
+    const PackedMsa* __restrict__ pk, int skip_narrow) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Qs = smem;
     float* Ks = smem + 2 * TILE_KC;
     if (pk) {
         // token-packed batch (rnamsm_forward_packed): alignment blockIdx.y has its own shape, slabs and token offset
         const PackedMsa& m = pk[blockIdx.y];
+        if (skip_narrow && m.C <= ROW_NARROW_MAX_C) return;      // that alignment is row_logits_narrow_kernel's
         R = m.R; C = m.C; nsplit = m.nsplit; rows_per_split = m.rows_per_split;
         q += m.tok0 * ld;
         k += m.tok0 * ld;
@@ -125,13 +127,99 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_logits_kernel(
     }
 }
 
+// K4 for alignments of at most 64 columns (short RNAs: the shipped 2DRB_1 example is 36 wide).  The 128 x 128 tile spends
+// (C/128)^2 of its matrix-pipe time on real logits -- 8 % at C = 36, 118 us per layer at 512 x 36 -- so this kernel drops the
+// tile and the LDS altogether: block = (head, slab) as before, its four waves own the four 32 x 32 quadrants of the
+// [64, 64] logit block, and a lane loads ITS query / key token's 16-byte pieces straight into the MFMA operand registers
+// (lane (li, lh) -> token quadrant*32 + li, floats 8 kk + 4 lh ..+3: the operand layout of mma_core.h without the detour).
+// Two half-rows are in flight per wave: the d < 32 pieces of row r+1 are requested when row r's have been consumed.
+// Same slabs, same K order (row, kk, s), same chain folding as row_logits_kernel: the two kernels agree BIT FOR BIT, so an
+// alignment's maps do not depend on which one a batch routed it to.
+__global__ __launch_bounds__(256) void row_logits_narrow_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, int64_t ld, float* __restrict__ partial,
+    int R, int C, int H, int nsplit, int rows_per_split, int chain_rows, int64_t qk_bstride, int64_t part_bstride,
+    const PackedMsa* __restrict__ pk) {
+    if (pk) {
+        const PackedMsa& m = pk[blockIdx.y];
+        if (m.C > ROW_NARROW_MAX_C) return;                      // row_logits_kernel's
+        R = m.R; C = m.C; nsplit = m.nsplit; rows_per_split = m.rows_per_split;
+        q += m.tok0 * ld;
+        k += m.tok0 * ld;
+        partial += m.part_off;
+    } else {
+        q += blockIdx.y * qk_bstride;
+        k += blockIdx.y * qk_bstride;
+        partial += blockIdx.y * part_bstride;
+    }
+    if ((int)blockIdx.x >= H * nsplit) return;
+    const int h = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    const int i0 = (wave >> 1) * 32, j0 = (wave & 1) * 32;
+    if (i0 >= C || j0 >= C) return;                              // C <= 32: one quadrant holds it all (no barrier in this kernel)
+    const int r_begin = split * rows_per_split;
+    const int nrows = min(R, r_begin + rows_per_split) - r_begin;
+    // wave-uniform base (scalar registers) + one 32-bit lane offset per operand: the 16 loads of a row share two address registers
+    const float* qp = q + (int64_t)r_begin * C * ld + h * HEAD_DIM;
+    const float* kp = k + (int64_t)r_begin * C * ld + h * HEAD_DIM;
+    const unsigned qlane = (unsigned)(min(i0 + li, C - 1) * (int)ld + 4 * lh), klane = (unsigned)(min(j0 + li, C - 1) * (int)ld + 4 * lh);
+    const int64_t row_step = (int64_t)C * ld;
+
+    f32x16 acc, total;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = total[t] = 0.f;
+    f32x4 a0[4], b0[4], a1[4], b1[4];                            // d < 32 and d >= 32 of the row in flight
+    auto load_half = [&](f32x4 (&a)[4], f32x4 (&b)[4], int r, int half) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            a[kk] = *reinterpret_cast<const f32x4*>(qp + r * row_step + half * 32 + kk * 8 + qlane);
+            b[kk] = *reinterpret_cast<const f32x4*>(kp + r * row_step + half * 32 + kk * 8 + klane);
+        }
+    };
+    auto mma_half = [&](const f32x4 (&a)[4], const f32x4 (&b)[4]) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma32(a[kk][s], b[kk][s], acc);
+    };
+    load_half(a0, b0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);                           // same request order as in the loop: the wait counts at its head stay exact
+    load_half(a1, b1, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int r = 0; r < nrows; ++r) {
+        const int rn = r + 1 < nrows ? r + 1 : r;               // the last row's prefetch re-reads itself (no branch in the loop)
+        mma_half(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);                       // (hipcc otherwise sinks both requests to the end of the row:
+        load_half(a0, b0, rn, 0);                                //  no flight time left)
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_half(a1, b1, rn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if ((r + 1) % chain_rows == 0 || r + 1 == nrows) {       // <= 512-term accumulation chains, added in order (row_split.h)
+            total += acc;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+        }
+    }
+    float* out = partial + ((int64_t)split * H + h) * C * C;
+    const int j = j0 + li;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int i = i0 + (t & 3) + 8 * (t >> 2) + 4 * lh;
+        if (i < C && j < C) out[(int64_t)i * C + j] = total[t];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- K5
 // One wave per (h, i) row: sum the nsplit partial slabs in slab order, then softmax over j in fp32
 // (attn_weights.softmax(-1), modules.py:818/739).  C <= 1024 + 1 fits 17 values per lane.
 // PL: 0 = fp32 probabilities only; 1 / 2 = additionally bf16 / fp16 hi(+lo) planes [rows][ldp] (ldp = C rounded up
 // to 64, the tail zero-filled) holding P * plane_scale: the k-contiguous A operand of the 16-bit row_apply.
+// NE = values per lane (C <= 64 NE): 17 covers the maximum width; narrow alignments take the 1- or 4-value instance, whose slab
+// loop is 1 / 4 loads per slab instead of 17 predicated ones (23 -> 8 us per launch at 512 x 36, 40 slabs).  Same arithmetic: the
+// values a wider instance would carry beyond C are -inf / 0 and add nothing.
 constexpr int SOFTMAX_MAX_PER_LANE = 17;
-template <int PL>
+template <int PL, int NE = SOFTMAX_MAX_PER_LANE>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ partial, int nsplit,
                                                            float* __restrict__ probs, int64_t rows, int C,
                                                            const uint8_t* __restrict__ key_mask,
@@ -160,24 +248,25 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     if (key_mask) key_mask += blockIdx.y * mask_bstride;
     const int lane = threadIdx.x & 63;
     const int64_t slab = rows * C;
-    float v[SOFTMAX_MAX_PER_LANE];
+    float v[NE];
     float mx = -INFINITY;
     // slab-major: every slab iteration issues up to 17 independent loads per lane (the fp32 path sums 32+ slabs: one
     // dependent load per iteration left the kernel latency-bound at 3 TB/s); each element still adds its slabs in slab order
     const float* prow = partial + row * C;
     if (mask_slab_stride == 0) {
 #pragma unroll
-        for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const int j = lane + 64 * e;
             v[e] = j < C ? prow[j] : -INFINITY;
         }
         // (four slabs' loads in flight per lane: PMC showed the waves 94 % of their time in s_waitcnt, one HBM round
         // trip per slab; the adds stay in slab order)
-#pragma unroll 4
+        constexpr int SLAB_UNROLL = NE == 1 ? 8 : 4;
+#pragma unroll SLAB_UNROLL
         for (int sp = 1; sp < nsplit; ++sp) {
             const float* ps = prow + (int64_t)sp * slab;
 #pragma unroll
-            for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+            for (int e = 0; e < NE; ++e) {
                 const int j = lane + 64 * e;
                 if (j < C) v[e] += ps[j];
             }
@@ -186,11 +275,11 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
         // the batch: VERDICT r04 item 4): q carries dh^-1/2 only and the alignment's 1/sqrt(R) meets the summed logits here.
         // (1.0 elsewhere: the masked / chunked / 16-bit callers keep their factor where the reference has it)
 #pragma unroll
-        for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) v[e] *= packed_scale;
+        for (int e = 0; e < NE; ++e) v[e] *= packed_scale;
         // f2: masked_fill(padding_mask[:, 0], -10000) on the key axis (modules.py:781-785)
         if (key_mask) {
 #pragma unroll
-            for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+            for (int e = 0; e < NE; ++e) {
                 const int j = lane + 64 * e;
                 if (j < C && key_mask[j]) v[e] = -10000.f;
             }
@@ -200,7 +289,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
         // filled with -10000 where the chunk's OWN first row is padded (:727-737), then `attns += attn_weights`
         // in chunk order -- masks of slab sp start at key_mask + sp * mask_slab_stride
 #pragma unroll
-        for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const int j = lane + 64 * e;
             v[e] = j < C ? (key_mask[j] ? -10000.f : prow[j]) : -INFINITY;
         }
@@ -208,18 +297,18 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
             const float* ps = prow + (int64_t)sp * slab;
             const uint8_t* ms = key_mask + (int64_t)sp * mask_slab_stride;
 #pragma unroll
-            for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+            for (int e = 0; e < NE; ++e) {
                 const int j = lane + 64 * e;
                 if (j < C) v[e] += ms[j] ? -10000.f : ps[j];
             }
         }
     }
 #pragma unroll
-    for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) mx = fmaxf(mx, v[e]);
+    for (int e = 0; e < NE; ++e) mx = fmaxf(mx, v[e]);
     mx = wave_max(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int j = lane + 64 * e;
         v[e] = j < C ? expf(v[e] - mx) : 0.f;
         sum += v[e];
@@ -227,7 +316,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     sum = wave_sum(sum);
     const float inv = 1.f / sum;
 #pragma unroll
-    for (int e = 0; e < SOFTMAX_MAX_PER_LANE; ++e) {
+    for (int e = 0; e < NE; ++e) {
         const int j = lane + 64 * e;
         if (j < C) probs[row * C + j] = v[e] * inv;
         if (PL != 0 && j < ldp) {
@@ -256,11 +345,12 @@ template <bool ALIGNED, int OUT, bool VT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
     const float* __restrict__ probs, const float* __restrict__ v, int64_t ld, float* __restrict__ ctx, int64_t ldc,
     int R, int C, int H, uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, int64_t probs_bstride, int64_t v_bstride,
-    int64_t ctx_bstride, const PackedMsa* __restrict__ pk, int layer) {
+    int64_t ctx_bstride, const PackedMsa* __restrict__ pk, int layer, int skip_narrow) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ps = smem;                    // [2][BM][LDK]
     if (pk) {                            // token-packed batch (fp32 context only): alignment blockIdx.y's own shape and offsets
         const PackedMsa& m = pk[blockIdx.y];
+        if (skip_narrow && m.C <= ROW_NARROW_MAX_C) return;      // row_apply_narrow_kernel's
         R = m.R; C = m.C;
         probs += m.probs_off + (int64_t)layer * H * C * C;
         v += m.tok0 * ld;
@@ -363,6 +453,148 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void row_apply_kernel(
     slab_store_64x64<OUT>(acc, smem + wv * (64 * 68), w.li, w.lh, lane, rowoff, ctx, ctx_hi, ctx_lo);
 }
 
+// K6 for alignments of at most 64 columns.  The map P_h (<= 64 x 64) is the same for every alignment row, so a block keeps it:
+// staged once through LDS (zero-padded to [64][64]: keys >= C contribute exactly 0), each lane then holds ITS fragments of it
+// in registers for the whole block (<= 64 VGPRs) and the K loop has no LDS traffic at all.  A wave walks alignment rows
+// r = chunk start + wave, +4, ...; V of one row goes global -> registers in the MFMA B layout (lane (li, lh) reads
+// v[r, 8 kk + 4 lh + s, h, 32 nt + li]: two full 128-byte lines per instruction), the d >= 32 half requested while the
+// d < 32 half is being multiplied, and the context leaves from the accumulator registers the same way (128-byte runs).
+// Addressing: buffer loads / stores over the alignment's own V and context ranges -- ONE 32-bit lane offset for all 32 loads of
+// a half row (the key's row offset is wave-uniform and rides in the scalar offset), and the hardware range check instead of
+// branches: a key row past the alignment's last token reads 0, a context row >= C gets an out-of-range lane offset and is dropped.
+// K order (kk, s over the keys) as in row_apply_kernel, whose trailing all-zero key groups add +0: the results agree bit for bit.
+// NKK = key groups of 8 (C in (8 NKK - 8, 8 NKK]): compile-time, so the row loop is branch-free.
+template <int NKK>
+__device__ __forceinline__ void row_apply_narrow_rows(const float* Ps, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,
+                                                      int h, int r, int r_end, int li, int lh) {
+    constexpr int LDP = 68;
+    constexpr bool TWO = NKK > 4;                                // query rows 32..63 exist
+    constexpr int MT = TWO ? 2 : 1;
+    f32x4 pa[MT][NKK];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) pa[mt][kk] = *reinterpret_cast<const f32x4*>(&Ps[(mt * 32 + li) * LDP + kk * 8 + 4 * lh]);
+    // (R * C <= 65536 tokens here: the byte ranges fit the descriptor's 32 bits)
+    const unsigned OOB = 0xffffffffu;
+    const auto vsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(v + h * HEAD_DIM), 0, (int)((int64_t)R * C * ld * 4 - h * HEAD_DIM * 4), 0x00020000);
+    const auto cdst = __builtin_amdgcn_make_buffer_rsrc(ctx + h * HEAD_DIM, 0, (int)((int64_t)R * C * ldc * 4 - h * HEAD_DIM * 4), 0x00020000);
+    const unsigned vlane = (unsigned)(4 * lh * (int)ld + li) * 4u;        // bytes: key + 4 lh, head dim li
+    const unsigned clane = (unsigned)(4 * lh * (int)ldc + li) * 4u;       // bytes: query row + 4 lh
+    const unsigned clane_lo = lh ? OOB : clane;                           // a pair of rows (ib, ib + 4) of which only ib < C
+    const int ld4 = (int)ld * 4, ldc4 = (int)ldc * 4;
+    // the last key group: a lane whose key is >= C loads through an out-of-range offset, i.e. reads 0 (no select after the load,
+    // which would make the wave wait for its newest request first)
+    unsigned vlast[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vlast[s] = (NKK - 1) * 8 + 4 * lh + s >= C ? OOB : vlane;
+    f32x4 vb0[NKK], vb1[NKK];                                    // d < 32, d >= 32 of the row in flight: [kk][s]
+    auto load_half = [&](f32x4 (&vb)[NKK], int row, int nt) {
+        const int base = row * C * ld4 + nt * 128;               // wave-uniform byte offset of key 0
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                vb[kk][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vsrc, kk == NKK - 1 ? vlast[s] : vlane,
+                                                                                           base + (kk * 8 + s) * ld4, 0));
+    };
+    auto run_half = [&](const f32x4 (&vb)[NKK], int row, int nt) {
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[mt][t] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32(pa[mt][kk][s], vb[kk][s], acc[mt]);
+        const int base = row * C * ldc4 + nt * 128;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int ib = mt * 32 + (t & 3) + 8 * (t >> 2);  // rows ib (lh = 0) and ib + 4 (lh = 1) in one instruction
+                const float val = acc[mt][t];                     // (a bit_cast of the vector ELEMENT expression stores element 0: hipcc 7.2)
+                if (ib + 4 < 8 * (NKK - 1)) {                     // both below C whatever C is
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), cdst, clane, base + ib * ldc4, 0);
+                } else if (ib < 8 * NKK) {                        // the range check drops what lies at or past row C
+                    const unsigned off = ib + 4 < C ? clane : (ib < C ? clane_lo : OOB);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), cdst, off, base + ib * ldc4, 0);
+                }
+            }
+    };
+    load_half(vb0, r, 0);
+    __builtin_amdgcn_sched_barrier(0);                           // request order = the loop's: the wait counts at its head stay exact
+    load_half(vb1, r, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    for (; r < r_end; r += 4) {
+        const bool more = r + 4 < r_end;                         // wave-uniform
+        run_half(vb0, r, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_half(vb0, r + 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        run_half(vb1, r, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_half(vb1, r + 4, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(256) void row_apply_narrow_kernel(
+    const float* __restrict__ probs, const float* __restrict__ v, int64_t ld, float* __restrict__ ctx, int64_t ldc,
+    int R, int C, int H, int rows_per_block, int64_t probs_bstride, int64_t v_bstride, int64_t ctx_bstride,
+    const PackedMsa* __restrict__ pk, int layer) {
+    constexpr int LDP = 68;
+    __shared__ __attribute__((aligned(16))) float Ps[64 * LDP];
+    if (pk) {
+        const PackedMsa& m = pk[blockIdx.y];
+        if (m.C > ROW_NARROW_MAX_C) return;                      // row_apply_kernel's
+        R = m.R; C = m.C;
+        probs += m.probs_off + (int64_t)layer * H * C * C;
+        v += m.tok0 * ld;
+        ctx += m.tok0 * ldc;
+    } else {
+        probs += blockIdx.y * probs_bstride;
+        v += blockIdx.y * v_bstride;
+        ctx += blockIdx.y * ctx_bstride;
+    }
+    const int chunks = (R + rows_per_block - 1) / rows_per_block;
+    if ((int)blockIdx.x >= H * chunks) return;
+    const int h = blockIdx.x % H, chunk = blockIdx.x / H;        // the heads of one row chunk read the same token rows: neighbours
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+
+    const float* pbase = probs + (int64_t)h * C * C;
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        Ps[i * LDP + j] = (i < C && j < C) ? pbase[i * C + j] : 0.f;
+    }
+    __syncthreads();
+    const int r_end = min(R, (chunk + 1) * rows_per_block);
+    const int r = chunk * rows_per_block + wave;
+    if (r >= r_end) return;
+    switch ((C + 7) >> 3) {
+        case 1: row_apply_narrow_rows<1>(Ps, v, ld, ctx, ldc, R, C, h, r, r_end, li, lh); break;
+        case 2: row_apply_narrow_rows<2>(Ps, v, ld, ctx, ldc, R, C, h, r, r_end, li, lh); break;
+        case 3: row_apply_narrow_rows<3>(Ps, v, ld, ctx, ldc, R, C, h, r, r_end, li, lh); break;
+        case 4: row_apply_narrow_rows<4>(Ps, v, ld, ctx, ldc, R, C, h, r, r_end, li, lh); break;
+        case 5: row_apply_narrow_rows<5>(Ps, v, ld, ctx, ldc, R, C, h, r, r_end, li, lh); break;
+        case 6: row_apply_narrow_rows<6>(Ps, v, ld, ctx, ldc, R, C, h, r, r_end, li, lh); break;
+        case 7: row_apply_narrow_rows<7>(Ps, v, ld, ctx, ldc, R, C, h, r, r_end, li, lh); break;
+        default: row_apply_narrow_rows<8>(Ps, v, ld, ctx, ldc, R, C, h, r, r_end, li, lh); break;
+    }
+}
+
+// rows of one block of row_apply_narrow_kernel (a multiple of 4: one per wave and step): enough blocks for ~4 per CU, and
+// as many rows per block as that allows (the block's map staging is paid once).  Speed only: every row is computed alone.
+static inline int narrow_rows_per_block(int64_t rows_total, int H) {
+    if (tuning().row_narrow_rows > 0) return (tuning().row_narrow_rows + 3) & ~3;
+    int64_t rpb = (rows_total * H + 1023) / 1024;
+    rpb = (rpb + 3) & ~(int64_t)3;
+    return (int)(rpb < 4 ? 4 : rpb > 32 ? 32 : rpb);
+}
+
 template <typename K>
 static int set_lds(K kern, int bytes, const char* name) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -430,9 +662,14 @@ static int row_logits_launch(const float* q, const float* k, int64_t ld, float* 
     const unsigned grid = xcd_panel_grid((unsigned)(H * sp.nsplit), tiles_c * tiles_c);
     KernelTimer timer(TC_ROW_LOGITS, 2.0 * batch * H * C * C * R * HEAD_DIM,
                       4.0 * batch * (2.0 * R * C * H * HEAD_DIM + (double)sp.nsplit * H * C * C), static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(row_logits_kernel, dim3(grid, batch), dim3(GEMM_THREADS), ROWLOGITS_LDS_BYTES,
-                       static_cast<hipStream_t>(stream), q, k, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split,
-                       ROW_LOGITS_F32_CHAIN_ROWS * (HEAD_DIM / BK), qk_bstride, part_bstride, (const PackedMsa*)nullptr);
+    if (C <= ROW_NARROW_MAX_C && tuning().row_narrow)       // same slabs, same bits (see the kernel)
+        hipLaunchKernelGGL(row_logits_narrow_kernel, dim3((unsigned)(H * sp.nsplit), batch), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           q, k, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, ROW_LOGITS_F32_CHAIN_ROWS, qk_bstride, part_bstride,
+                           (const PackedMsa*)nullptr);
+    else
+        hipLaunchKernelGGL(row_logits_kernel, dim3(grid, batch), dim3(GEMM_THREADS), ROWLOGITS_LDS_BYTES,
+                           static_cast<hipStream_t>(stream), q, k, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split,
+                           ROW_LOGITS_F32_CHAIN_ROWS * (HEAD_DIM / BK), qk_bstride, part_bstride, (const PackedMsa*)nullptr, 0);
     RNAMSM_CHECK_LAUNCH("row_logits");
     return RNAMSM_OK;
 }
@@ -452,7 +689,11 @@ static int softmax_rows_launch(const float* partial, int nsplit, float* probs, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((rows + 3) / 4), batch);
     KernelTimer timer(TC_SOFTMAX, 0.0, batch * (4.0 * (double)(nsplit + 1) * H * C * C + (p_hi ? (p_lo ? 4.0 : 2.0) * rows * ldp : 0.0)), s);
-    if (!p_hi)
+    if (!p_hi && C <= 64)
+        hipLaunchKernelGGL((softmax_rows_kernel<0, 1>), grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
+    else if (!p_hi && C <= 256)
+        hipLaunchKernelGGL((softmax_rows_kernel<0, 4>), grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
+    else if (!p_hi)
         hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
     else if (fmt == 0)
         hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
@@ -505,6 +746,13 @@ static int row_apply_launch(const float* probs, const float* v, int64_t ld, floa
     const bool al = C % 4 == 0 && C >= 4 && aligned16(probs);
     const int out = ctx_hi ? 1 + plane_fmt : 0;
     KernelTimer timer(TC_ROW_APPLY, 2.0 * batch * H * C * C * R * HEAD_DIM, 4.0 * batch * (2.0 * R * C * H * HEAD_DIM + (double)H * C * C), s);
+    if (out == 0 && C <= ROW_NARROW_MAX_C && tuning().row_narrow) {
+        const int rpb = narrow_rows_per_block((int64_t)R * batch, H);
+        hipLaunchKernelGGL(row_apply_narrow_kernel, dim3((unsigned)(H * ((R + rpb - 1) / rpb)), batch), dim3(256), 0, s, probs, v, ld, ctx, ldc,
+                           R, C, H, rpb, probs_bstride, v_bstride, ctx_bstride, (const PackedMsa*)nullptr, 0);
+        RNAMSM_CHECK_LAUNCH("row_apply (narrow)");
+        return RNAMSM_OK;
+    }
 #define RA_GO2(AL_, OUT_, VT_)                                                                                    \
     do {                                                                                                          \
         static DeviceOnce cfg_;                                                                                 \
@@ -515,7 +763,7 @@ static int row_apply_launch(const float* probs, const float* v, int64_t ld, floa
             cfg_.mark();                                                                                          \
         }                                                                                                         \
         hipLaunchKernelGGL((row_apply_kernel<AL_, OUT_, VT_>), dim3(grid, batch), dim3(GEMM_THREADS), lds_, s, probs, \
-                           v, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, probs_bstride, v_bstride, ctx_bstride, (const PackedMsa*)nullptr, 0); \
+                           v, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, probs_bstride, v_bstride, ctx_bstride, (const PackedMsa*)nullptr, 0, 0); \
     } while (0)
 #define RA_GO(AL_, OUT_)                                                                                          \
     do {                                                                                                          \
@@ -572,19 +820,31 @@ int row_logits_packed(const float* q, const float* k, int64_t ld, float* partial
         if (rc) return rc;
         configured.mark();
     }
-    unsigned grid = 0;
+    // alignments of <= 64 columns go to the narrow kernel, the others to the tile kernel: two launches over the same descriptor
+    // table, each leaving the other's alignments alone (the kernels agree bit for bit, the split is speed only)
+    const bool narrow_on = tuning().row_narrow != 0;
+    unsigned grid = 0, grid_narrow = 0;
     double flops = 0.0, bytes = 0.0;
     for (int b = 0; b < B; ++b) {
         const PackedMsa& m = host[b];
-        const unsigned tiles_c = (m.C + BM - 1) / BM;
-        const unsigned g = xcd_panel_grid((unsigned)(H * m.nsplit), tiles_c * tiles_c);
-        grid = g > grid ? g : grid;
+        if (narrow_on && m.C <= ROW_NARROW_MAX_C) {
+            const unsigned g = (unsigned)(H * m.nsplit);
+            grid_narrow = g > grid_narrow ? g : grid_narrow;
+        } else {
+            const unsigned tiles_c = (m.C + BM - 1) / BM;
+            const unsigned g = xcd_panel_grid((unsigned)(H * m.nsplit), tiles_c * tiles_c);
+            grid = g > grid ? g : grid;
+        }
         flops += 2.0 * H * m.C * m.C * (double)m.R * HEAD_DIM;
         bytes += 4.0 * (2.0 * m.R * m.C * H * HEAD_DIM + (double)m.nsplit * H * m.C * m.C);
     }
     KernelTimer timer(TC_ROW_LOGITS, flops, bytes, static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(row_logits_kernel, dim3(grid, B), dim3(GEMM_THREADS), ROWLOGITS_LDS_BYTES, static_cast<hipStream_t>(stream), q, k,
-                       ld, partial, 0, 0, H, 0, 0, ROW_LOGITS_F32_CHAIN_ROWS * (HEAD_DIM / BK), (int64_t)0, (int64_t)0, pk);
+    if (grid_narrow)
+        hipLaunchKernelGGL(row_logits_narrow_kernel, dim3(grid_narrow, B), dim3(256), 0, static_cast<hipStream_t>(stream), q, k, ld, partial,
+                           0, 0, H, 0, 0, ROW_LOGITS_F32_CHAIN_ROWS, (int64_t)0, (int64_t)0, pk);
+    if (grid)
+        hipLaunchKernelGGL(row_logits_kernel, dim3(grid, B), dim3(GEMM_THREADS), ROWLOGITS_LDS_BYTES, static_cast<hipStream_t>(stream), q, k,
+                           ld, partial, 0, 0, H, 0, 0, ROW_LOGITS_F32_CHAIN_ROWS * (HEAD_DIM / BK), (int64_t)0, (int64_t)0, pk, narrow_on ? 1 : 0);
     RNAMSM_CHECK_LAUNCH("row_logits (packed)");
     return RNAMSM_OK;
 }
@@ -599,25 +859,44 @@ int softmax_rows_packed(const float* partial, float* row_attn, int layer, int H,
     RNAMSM_CHECK_ARG(max_C <= 64 * SOFTMAX_MAX_PER_LANE, "softmax_rows (packed): C <= %d", 64 * SOFTMAX_MAX_PER_LANE);
     hipStream_t s = static_cast<hipStream_t>(stream);
     KernelTimer timer(TC_SOFTMAX, 0.0, bytes, s);
-    hipLaunchKernelGGL(softmax_rows_kernel<0>, dim3((unsigned)(((int64_t)H * max_C + 3) / 4), B), dim3(256), 0, s, partial, 0, row_attn,
-                       (int64_t)0, 0, (const uint8_t*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr, (int64_t)0, 1.f, (int64_t)0,
-                       (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0, pk, layer, H, 1.f);
+#define SM_PK(NE_)                                                                                                                  \
+    hipLaunchKernelGGL((softmax_rows_kernel<0, NE_>), dim3((unsigned)(((int64_t)H * max_C + 3) / 4), B), dim3(256), 0, s, partial, 0, row_attn, \
+                       (int64_t)0, 0, (const uint8_t*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr, (int64_t)0, 1.f, (int64_t)0,    \
+                       (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0, pk, layer, H, 1.f)
+    if (max_C <= 64) SM_PK(1); else if (max_C <= 256) SM_PK(4); else SM_PK(SOFTMAX_MAX_PER_LANE);
+#undef SM_PK
     RNAMSM_CHECK_LAUNCH("softmax_rows (packed)");
     return RNAMSM_OK;
 }
 int row_apply_packed(const float* row_attn, int layer, const float* v, int64_t ld, float* ctx, int64_t ldc, int H, const PackedMsa* pk,
                      const PackedMsa* host, int B, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    unsigned grid = 0;
+    const bool narrow_on = tuning().row_narrow != 0;
+    unsigned grid = 0, grid_narrow = 0;
     double flops = 0.0, bytes = 0.0;
+    int64_t narrow_rows = 0;
+    int narrow_max_r = 0;
     for (int b = 0; b < B; ++b) {
         const PackedMsa& m = host[b];
-        const unsigned g = xcd_panel_grid((unsigned)H * ((m.R + 1) / 2), (m.C + BM - 1) / BM);
-        grid = g > grid ? g : grid;
+        if (narrow_on && m.C <= ROW_NARROW_MAX_C) {
+            narrow_rows += m.R;
+            narrow_max_r = m.R > narrow_max_r ? m.R : narrow_max_r;
+        } else {
+            const unsigned g = xcd_panel_grid((unsigned)H * ((m.R + 1) / 2), (m.C + BM - 1) / BM);
+            grid = g > grid ? g : grid;
+        }
         flops += 2.0 * H * m.C * m.C * (double)m.R * HEAD_DIM;
         bytes += 4.0 * (2.0 * m.R * m.C * H * HEAD_DIM + (double)H * m.C * m.C);
     }
     KernelTimer timer(TC_ROW_APPLY, flops, bytes, s);
+    if (narrow_rows) {
+        const int rpb = narrow_rows_per_block(narrow_rows, H);
+        grid_narrow = (unsigned)(H * ((narrow_max_r + rpb - 1) / rpb));
+        hipLaunchKernelGGL(row_apply_narrow_kernel, dim3(grid_narrow, B), dim3(256), 0, s, row_attn, v, ld, ctx, ldc, 0, 0, H, rpb,
+                           (int64_t)0, (int64_t)0, (int64_t)0, pk, layer);
+        RNAMSM_CHECK_LAUNCH("row_apply (packed, narrow)");
+    }
+    if (!grid) return RNAMSM_OK;
     // (maps of odd widths are not 16-byte aligned: the scalar-load instance for every alignment of the batch)
 #define RA_PK(VT_)                                                                                                \
     do {                                                                                                          \
@@ -629,7 +908,7 @@ int row_apply_packed(const float* row_attn, int layer, const float* v, int64_t l
             cfg_.mark();                                                                                          \
         }                                                                                                         \
         hipLaunchKernelGGL((row_apply_kernel<false, 0, VT_>), dim3(grid, B), dim3(GEMM_THREADS), lds_, s, row_attn, v, ld, ctx, ldc, 0, 0, \
-                           H, (uint16_t*)nullptr, (uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, pk, layer);  \
+                           H, (uint16_t*)nullptr, (uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, pk, layer, narrow_on ? 1 : 0);  \
     } while (0)
     if (tuning().row_vt) RA_PK(true); else RA_PK(false);
 #undef RA_PK

@@ -261,6 +261,51 @@ def test_row_attention_kernels(dev, R, C, H):
     assert rel_l2(ctx, want) < 5e-6
 
 
+@pytest.mark.parametrize("R,C,H", [(512, 36, 12), (7, 8, 3), (33, 32, 12), (40, 33, 4), (64, 64, 12), (13, 63, 5), (1, 40, 2), (300, 17, 12),
+                                   (9, 1, 2), (70, 57, 12)])
+def test_narrow_row_attention_kernels_equal_the_tile_kernels_bit_for_bit(dev, R, C, H):
+    """K4 / K6 at C <= 64 (row_logits_narrow_kernel, row_apply_narrow_kernel: no LDS tile, operands straight into the MFMA registers)
+    against the 128 x 128 tile kernels they replace there (knob "row_narrow" = 0): the same slabs and the same K order, so the
+    partial slabs and the context are the SAME BITS -- an alignment's maps must not depend on which kernel a batch routed it to --
+    and both against fp64.  Shapes: the shipped example's 512 x 36; one quadrant (C <= 32) and four; C = 64 exactly; key counts that
+    are no multiple of 8 (zero-padded last group) and of 4 (maps not 16-byte aligned); one row; more rows than one block's chunk;
+    also the reference's row-chunked slabs (rnamsm_row_logits_chunked)."""
+    from rnamsm import ops
+    qkv, D = _qkv(R, C, H, f"narrow{R}_{C}")
+    g = qkv.to(dev)
+    q = qkv[:, :D].double().view(R, C, H, 64)
+    k = qkv[:, D:2 * D].double().view(R, C, H, 64)
+    v = qkv[:, 2 * D:].double().view(R, C, H, 64)
+    outs = {}
+    try:
+        for narrow in (1, 0):
+            ops.set_param("row_narrow", narrow)
+            partial, nsplit = ops.row_logits(g[:, :D], g[:, D:2 * D], R, C, H)
+            probs = ops.softmax_rows(partial, logit_scale=ops.depth_scaling(R))
+            ctx = ops.row_apply(probs, g[:, 2 * D:], R, C, H)
+            chunked = ops.row_logits(g[:, :D], g[:, D:2 * D], R, C, H, rows_per_chunk=max(1, R // 3))[0] if R >= 3 else None
+            outs[narrow] = (partial.clone(), ctx.clone(), None if chunked is None else chunked.clone())
+    finally:
+        ops.set_param("row_narrow", 1)
+    assert torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1])
+    if outs[1][2] is not None:
+        assert torch.equal(outs[1][2], outs[0][2])
+    logits = torch.einsum("rihd,rjhd->hij", q, k)
+    assert rel_l2(outs[1][0].sum(0).cpu(), logits) < 5e-6
+    p = torch.softmax(outs[1][0].sum(0).double().cpu() * ops.depth_scaling(R), -1)
+    want = torch.einsum("hij,rjhd->rihd", p, v).reshape(R * C, D)
+    assert rel_l2(outs[1][1].cpu(), want) < 5e-6
+    # padding inside the fused activation's neighbourhood must not leak in: a non-finite key row right after the alignment's last token
+    # of a row (the zero-padded last key group reads it) leaves the context untouched
+    if C % 8 and R > 1:
+        g2 = g.clone()
+        probs = ops.softmax_rows(outs[1][0], logit_scale=ops.depth_scaling(R))
+        base = ops.row_apply(probs, g2[:, 2 * D:], R, C, H).clone()
+        g2[C:2 * C, 2 * D:] = float("inf")                                # row 1's V: row 0's padded key slots read into it
+        got = ops.row_apply(probs, g2[:, 2 * D:], R, C, H)
+        assert torch.equal(got[:C], base[:C])
+
+
 @pytest.mark.parametrize("R,C,H", ATT_SHAPES)
 def test_col_attention_kernel(dev, R, C, H):
     from rnamsm import ops
