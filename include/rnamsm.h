@@ -518,8 +518,14 @@ void rnamsm_timing_reset(void);
  *                 tile = block id; 1 = whole panels).  An XCD's panels beyond its full groups form one smaller group: no padding
  *                 groups (round 4).  Changes HBM-side traffic and speed, never results.
  *   "gemm_tile"   fp32 GEMM block tile: 0 (default) = 128x128, or 128x64 where that evens out the last round of blocks
- *                 on a small problem; 1 = always 128x128; 2 = always 128x64.  Results are bit-identical under either
- *                 tile: each output element sums its K products in the same order.
+ *                 on a small problem, or MIXED (round 5: whole rounds of 128x128 tiles, the tile positions of the last,
+ *                 partly empty round cut into their two 128x64 halves); 1 = always 128x128; 2 = always 128x64; 3 = mixed
+ *                 wherever a launch has both whole rounds and a tail; 4 = by shape among the two uniform tilings only (round
+ *                 4's rule, for A/B).  Results are bit-identical under every tiling: each
+ *                 output element sums its K products in the same order.
+ *   "row_narrow"  fp32 rnamsm_row_logits / rnamsm_row_apply at C <= 64: 1 (default) = the LDS-free narrow kernels, 0 = the
+ *                 128x128 tile kernels.  "row_narrow_rows": alignment rows per block of the narrow row_apply (0 = by shape).
+ *                 Speed only, results bit-identical.
  *   "row_vt"      fp32 rnamsm_row_apply: 1 (default) = the V tile is transposed while it is staged (ds_read_b128
  *                 fragments), 0 = staged as it lies in memory.  Speed only, results bit-identical.
  *   "gemm16_persist" / "gemm16_stagger"  256x256 16-bit GEMM: number of persistent blocks that walk the output tiles

@@ -156,7 +156,7 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         return RNAMSM_OK;
     }
     if (name && !strcmp(name, "gemm_tile")) {
-        if (value < 0 || value > 2) return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: gemm_tile must be 0, 1 or 2");
+        if (value < 0 || value > 4) return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: gemm_tile must be in [0, 4]");
         rnamsm::tuning().gemm_tile = value;
         return RNAMSM_OK;
     }

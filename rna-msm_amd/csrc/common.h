@@ -85,7 +85,7 @@ struct Tuning {
     int gemm16_big_rows = 0;       // rnamsm_gemm_bf16, plane operands: rows from which the 256x256-tile kernels are used (0 = 2048)
     int gemm16_big_rows_fwd = 0;   // ... inside rnamsm_forward / rnamsm_forward_batch: 0 = by mode (10752 plain bf16, 8960 hi/lo), > 0 = that many
     int gemm_group = 0;            // fp32 GEMM: row panels per XCD group of the block order (xcd_panel_map_grouped); 0 = by shape
-    int gemm_tile = 0;             // fp32 GEMM block tile: 0 = by shape, 1 = always 128x128, 2 = always 128x64
+    int gemm_tile = 0;             // fp32 GEMM block tile: 0 = by shape, 1 = always 128x128, 2 = always 128x64, 3 = mixed wherever a launch has whole rounds and a tail, 4 = by shape among the uniform tilings only (round 4's rule, A/B)
     int gemm_flat_tiles = 512;     // fp32 GEMM: at most this many tiles (the chip's block slots) -> dealt flat (tile = block id) instead of XCD-aware.  Larger values win the stand-alone GEMM A/B up to ~19 k tokens (tools/gemm_ab.py gemm_flat_tiles=512,2048,8192: T = 2064 QKV +28 %, 18944 fc2 +14 %) but LOSE 1-2 % inside the forward, where A was just written by the previous kernel and the XCD-aware order keeps each panel on one XCD (tools/lone_small_profile.py KNOBS=gemm_flat_tiles=4096)
     int gemm_splitk_short = 0;     // rnamsm_forward*, the K = 768 GEMMs of a lone small alignment (<= 192 tiles): K ranges (0 = off: the default -- measured no gain once the block order was fixed; 2, 4), gemm_f32_splitk_factor
     int gemm_splitk = 0;           // rnamsm_forward, fc2 below ~1.4 k tokens: 0 = never (default since round 5: a split chosen by the BATCH's token count made an alignment's bits depend on its company; costs a lone <= 1024-token alignment 0.4 of 2.5 ms, profiles/r05_splitk.log), 1 = four K ranges + an ordered reduction (gemm_f32_splitk_factor), 2 / 4 / 8 = forced (A/B)

@@ -52,35 +52,17 @@ __device__ __forceinline__ float sum8_dpp(float v) {
 // ZROWS: 0 = none; 1 = zero_rows is a uint8 mask, the scaled (q) columns of flagged rows are zeroed (f2: q *= 1 - padding_mask);
 // 2 = zero_rows is a float per-row factor multiplying the scaled columns after `scale` (ragged batches: 0 at <pad>,
 // 1/sqrt(true depth) elsewhere -- the general form of 1).
-template <int ACT, bool HAS_RES, int ZROWS, int NT, int FOLD = 0, bool STATS = false>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
-    const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
+// One output tile [m0, m0 + 128) x [n0, n0 + 64 NT): K loop over kc (W rows keep their stride K) and the epilogue.
+template <int ACT, bool HAS_RES, int ZROWS, int NT, int FOLD, bool STATS>
+__device__ __forceinline__ void gemm_f32_tile(
+    float* smem, const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc,
-    int M, int N, int K, float scale, int scale_cols, const void* __restrict__ zero_rows, int group,
-    const float* __restrict__ fold_c, float ln_eps, float* row_partials, int64_t pld, int* fold_flag) {
+    int M, int K, int kc, float scale, int scale_cols, const void* __restrict__ zero_rows,
+    const float* __restrict__ fold_c, float ln_eps, float* row_partials, int64_t pld, int* fold_flag, int m0, int n0) {
     using Cfg = GemmCfg<NT>;
-    constexpr int BN_ = Cfg::BN_, TILE_W = Cfg::TILE_W;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TILE_W = Cfg::TILE_W;
     float* As = smem;                    // [2][BM][LDK]
     float* Ws = smem + 2 * TILE_KC;      // [2][BN_][LDK]
-
-    const unsigned nb = N / BN_, mp = (M + BM - 1) / BM;
-    // split-K (group >> 16 = number of K ranges; launch_gemm_splitk): the grid holds that many copies of the tile grid, copy s
-    // accumulates K range s (W keeps its row stride K) and stores its tile into partial slab s of Cout ([ks][M][ldc])
-    const int ksplit = group >> 16;
-    unsigned bid = blockIdx.x;
-    int kc = K;
-    if (ksplit) {
-        const unsigned per = gridDim.x / ksplit, s_ = bid / per;
-        bid -= s_ * per;
-        kc = K / ksplit;
-        A += (int64_t)s_ * kc;
-        W += (int64_t)s_ * kc;
-        Cout += (int64_t)s_ * M * ldc;
-    }
-    unsigned mpanel, nblk;
-    if (!xcd_panel_map_ragged(bid, mp, nb, (unsigned)(group & 0xffff), mpanel, nblk)) return;
-    const int m0 = mpanel * BM, n0 = nblk * BN_;
 
     const WaveCoord w = wave_coord();
     const int c4 = threadIdx.x & 7, r0 = threadIdx.x >> 3;
@@ -258,6 +240,68 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
 }
 
 template <int ACT, bool HAS_RES, int ZROWS, int NT, int FOLD = 0, bool STATS = false>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
+    const float* residual, int64_t ldr, float* Cout, int64_t ldc,
+    int M, int N, int K, float scale, int scale_cols, const void* __restrict__ zero_rows, int group,
+    const float* __restrict__ fold_c, float ln_eps, float* row_partials, int64_t pld, int* fold_flag) {
+    constexpr int BN_ = GemmCfg<NT>::BN_;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned nb = N / BN_, mp = (M + BM - 1) / BM;
+    // split-K (group >> 16 = number of K ranges; launch_gemm_splitk): the grid holds that many copies of the tile grid, copy s
+    // accumulates K range s (W keeps its row stride K) and stores its tile into partial slab s of Cout ([ks][M][ldc])
+    const int ksplit = group >> 16;
+    unsigned bid = blockIdx.x;
+    int kc = K;
+    if (ksplit) {
+        const unsigned per = gridDim.x / ksplit, s_ = bid / per;
+        bid -= s_ * per;
+        kc = K / ksplit;
+        A += (int64_t)s_ * kc;
+        W += (int64_t)s_ * kc;
+        Cout += (int64_t)s_ * M * ldc;
+    }
+    unsigned mpanel, nblk;
+    if (!xcd_panel_map_ragged(bid, mp, nb, (unsigned)(group & 0xffff), mpanel, nblk)) return;
+    gemm_f32_tile<ACT, HAS_RES, ZROWS, NT, FOLD, STATS>(smem, A, lda, W, bias, residual, ldr, Cout, ldc, M, K, kc, scale, scale_cols, zero_rows,
+                                                        fold_c, ln_eps, row_partials, pld, fold_flag, (int)(mpanel * BM), (int)(nblk * BN_));
+}
+
+// MIXED tiles (round 5): a launch costs ceil(blocks / 512) rounds of co-resident pairs, and on a mid-size problem the last round is
+// mostly empty -- T = 18432, N = 2304: 2592 tiles = 5 full rounds + 32 tiles that cost a sixth (all-half-width tiles: 5184 = 10
+// rounds + 64, no better).  Here the first `full_blocks` block ids (whole rounds) are 128 x 128 tiles in the usual XCD order and
+// every tile position after them is cut into its two 128 x 64 halves, consecutive block ids: the last round then holds twice as
+// many blocks of half the length.  A tile's shape never touches an element's K order (one accumulator, k ascending): the result
+// is bit-identical to any other tiling -- unlike a split of K over the last round (stream-K), which would make an element's
+// rounding depend on how many rows the launch has, i.e. on the batch an alignment travels in.
+template <int ACT, bool HAS_RES, int ZROWS, int FOLD = 0, bool STATS = false>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_mixed_kernel(
+    const float* __restrict__ A, int64_t lda, const float* __restrict__ W, const float* __restrict__ bias,
+    const float* residual, int64_t ldr, float* Cout, int64_t ldc,
+    int M, int N, int K, float scale, int scale_cols, const void* __restrict__ zero_rows, int group, unsigned full_blocks,
+    const float* __restrict__ fold_c, float ln_eps, float* row_partials, int64_t pld, int* fold_flag) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned nb = N / BN, mp = (M + BM - 1) / BM;
+    unsigned mpanel, nblk;
+    if (blockIdx.x < full_blocks) {
+        if (!xcd_panel_map_ragged(blockIdx.x, mp, nb, (unsigned)group, mpanel, nblk)) return;
+        gemm_f32_tile<ACT, HAS_RES, ZROWS, 2, FOLD, STATS>(smem, A, lda, W, bias, residual, ldr, Cout, ldc, M, K, K, scale, scale_cols, zero_rows,
+                                                           fold_c, ln_eps, row_partials, pld, fold_flag, (int)(mpanel * BM), (int)(nblk * BN));
+    } else {
+        const unsigned u = blockIdx.x - full_blocks;
+        if (!xcd_panel_map_ragged(full_blocks + (u >> 1), mp, nb, (unsigned)group, mpanel, nblk)) return;
+        gemm_f32_tile<ACT, HAS_RES, ZROWS, 1, FOLD, STATS>(smem, A, lda, W, bias, residual, ldr, Cout, ldc, M, K, K, scale, scale_cols, zero_rows,
+                                                           fold_c, ln_eps, row_partials, pld, fold_flag, (int)(mpanel * BM),
+                                                           (int)(nblk * BN + (u & 1u) * 64u));
+    }
+}
+
+static inline int gemm_group_for(int mp, int nb, int NT, int ksplit) {
+    return tuning().gemm_group > 0 ? tuning().gemm_group
+                                   : ((int64_t)mp * nb * (ksplit > 1 ? ksplit : 1) <= tuning().gemm_flat_tiles ? 0 : (nb > 8 * (3 - NT) ? 8 : 1));
+}
+
+template <int ACT, bool HAS_RES, int ZROWS, int NT, int FOLD = 0, bool STATS = false>
 static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                           int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
                           const void* zero_rows, hipStream_t stream, const float* fold_c = nullptr,
@@ -281,8 +325,7 @@ static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const flo
     // than the chip has block slots ("gemm_flat_tiles", 512) is dealt FLAT (group 0: tile = block id), so that a lone small
     // alignment's 18-24 column tiles run on as many CUs of all XCDs instead of on one XCD's
     const int mp_ = (M + BM - 1) / BM;
-    const int group = tuning().gemm_group > 0 ? tuning().gemm_group
-                                              : ((int64_t)mp_ * nb * (ksplit > 1 ? ksplit : 1) <= tuning().gemm_flat_tiles ? 0 : (nb > 8 * (3 - NT) ? 8 : 1));
+    const int group = gemm_group_for(mp_, nb, NT, ksplit);
     const unsigned grid = xcd_panel_grid_ragged(mp_, nb, (unsigned)group) * (ksplit > 1 ? ksplit : 1);
     // algorithmic work: 2MNK flops; bytes = A + W + C once (+ residual read)
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
@@ -293,34 +336,81 @@ static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const flo
     return RNAMSM_OK;
 }
 
+template <int ACT, bool HAS_RES, int ZROWS, int FOLD = 0, bool STATS = false>
+static int launch_gemm_mixed(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
+                             int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
+                             const void* zero_rows, hipStream_t stream, unsigned full_blocks, const float* fold_c = nullptr,
+                             float ln_eps = 0.f, float* row_partials = nullptr, int64_t pld = 0, int* fold_flag = nullptr) {
+    using Cfg = GemmCfg<2>;
+    static DeviceOnce configured;
+    auto kern = gemm_f32_mixed_kernel<ACT, HAS_RES, ZROWS, FOLD, STATS>;
+    if (configured.pending()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FOLD ? Cfg::LDS_FOLD : Cfg::LDS_BYTES);
+        if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm (mixed tiles): hipFuncSetAttribute: %s", hipGetErrorString(e));
+        configured.mark();
+    }
+    const int nb = N / BN, mp_ = (M + BM - 1) / BM;
+    const int group = gemm_group_for(mp_, nb, 2, 1);
+    const unsigned all = xcd_panel_grid_ragged(mp_, nb, (unsigned)group);       // block ids of the all-full-tile order (incl. spare ids at its end)
+    const unsigned grid = full_blocks + 2u * (all - full_blocks);
+    KernelTimer timer(TC_GEMM, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N * (HAS_RES ? 2 : 1)), stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(GEMM_THREADS), FOLD ? Cfg::LDS_FOLD : Cfg::LDS_BYTES, stream, A, lda, W, bias,
+                       residual, ldr, Cout, ldc, M, N, K, scale, scale_cols, zero_rows, group, full_blocks, fold_c, ln_eps,
+                       row_partials, pld, fold_flag);
+    RNAMSM_CHECK_LAUNCH("gemm_f32 (mixed tiles)");
+    return RNAMSM_OK;
+}
+
 // Tile width from a per-CU time model calibrated on the box (tools/gemm_ab.py gemm_tile=1,2 at T = 8192 .. 131072):
 // blocks are dealt evenly, a CU holding b of them runs them two at a time; a co-resident pair costs 2 units of matrix
 // pipe time, a block running alone 1.1 (it nearly saturates the pipe by itself), a half-width block 0.5175 of a full
 // one (3.5 % per-flop penalty).  Half-width tiles are taken when the model gains more than 3 %: e.g. T = 8192, N = 768:
 // 384 full blocks -> 2 per busiest CU = 2.0 units, 768 half blocks -> 3 per CU = 1.6 units (measured 0.101 -> 0.082 ms);
 // cfg3 (exact multiples of 512 blocks) stays on full tiles.
-static inline bool half_width_tiles_win(int M, int N) {
+// Round 5: MIXED (see gemm_f32_mixed_kernel): whole rounds of full tiles, then the remaining tile positions as halves; taken
+// when the model gains another 2 % over the better uniform choice.  T = 18432: QKV 11.1 (full) / 10.9 (half) -> 10.6 units.
+struct TilePlan {
+    int kind;                 // 0 = 128 x 128 tiles, 1 = 128 x 64 tiles, 2 = mixed
+    unsigned full_blocks;     // mixed: block ids that are full tiles
+};
+static inline TilePlan tile_plan(int M, int N) {
     const int t = tuning().gemm_tile;
-    if (t == 1) return false;
-    if (t == 2) return true;
-    const long mp = (M + BM - 1) / BM;
+    const long mp = (M + BM - 1) / BM, nb = N / BN, tiles = mp * nb;
     auto cu_time = [](long blocks) {
         const long b = (blocks + 255) / 256;
         return 2.0 * (double)(b / 2) + 1.1 * (double)(b % 2);
     };
-    return 0.5175 * cu_time(mp * (N / 64)) < 0.97 * cu_time(mp * (N / 128));
+    // block ids below full_blocks must all be real tiles: whole rounds of 512 inside the panels every XCD owns
+    long full = tiles / 512 * 512;
+    const long common = 8 * (mp / 8) * nb;
+    while (full > common) full -= 512;
+    const bool can_mix = full > 0 && full < tiles && tiles > tuning().gemm_flat_tiles && tuning().gemm_group <= 0;
+    if (t == 1) return {0, 0};
+    if (t == 2) return {1, 0};
+    if (t == 3) return can_mix ? TilePlan{2, (unsigned)full} : TilePlan{0, 0};
+    const double c_full = cu_time(tiles), c_half = 0.5175 * cu_time(2 * tiles);
+    TilePlan best{0, 0};
+    double c_best = c_full;
+    if (c_half < 0.97 * c_full) {
+        best = {1, 0};
+        c_best = c_half;
+    }
+    if (t != 4 && can_mix && (double)(full / 256) + 0.5175 * cu_time(2 * (tiles - full)) < 0.98 * c_best) best = {2, (unsigned)full};
+    return best;
 }
 
 template <int ACT, bool HAS_RES, int ZROWS = 0>
 static int launch_gemm(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                        int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
                        const void* zero_rows, hipStream_t stream) {
-    if (ZROWS == 2 && half_width_tiles_win(M, N))       // ragged batches are small problems: keep the tile choice
-        return launch_gemm_nt<ACT, HAS_RES, 2, 1>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, scale, scale_cols,
-                                                  zero_rows, stream);
-    if (!ZROWS && half_width_tiles_win(M, N))
-        return launch_gemm_nt<ACT, HAS_RES, 0, 1>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, scale, scale_cols,
-                                                  zero_rows, stream);
+    const TilePlan plan = ZROWS == 1 ? TilePlan{0, 0} : tile_plan(M, N);      // (the uint8-mask form: padded single forwards, full tiles)
+    if (plan.kind == 2)
+        return launch_gemm_mixed<ACT, HAS_RES, ZROWS>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, scale, scale_cols, zero_rows,
+                                                      stream, plan.full_blocks);
+    if (plan.kind == 1)
+        return launch_gemm_nt<ACT, HAS_RES, ZROWS, 1>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, scale, scale_cols,
+                                                      zero_rows, stream);
     return launch_gemm_nt<ACT, HAS_RES, ZROWS, 2>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, scale, scale_cols,
                                                   zero_rows, stream);
 }
@@ -330,7 +420,11 @@ static int launch_gemm_fold(const float* X, int64_t ldx, const float* Wg, const 
                             float ln_eps, const float* row_partials, int64_t pld, int* fold_flag, float* Cout, int64_t ldc,
                             int M, int N, int K, float scale, int scale_cols, hipStream_t stream) {
     float* rp = const_cast<float*>(row_partials);                  // read-only in the FOLD kernels
-    if (half_width_tiles_win(M, N))
+    const TilePlan plan = tile_plan(M, N);
+    if (plan.kind == 2)
+        return launch_gemm_mixed<ACT, false, 0, FOLD>(X, ldx, Wg, dvec, nullptr, 0, Cout, ldc, M, N, K, scale, scale_cols, nullptr, stream,
+                                                      plan.full_blocks, cvec, ln_eps, rp, pld, fold_flag);
+    if (plan.kind == 1)
         return launch_gemm_nt<ACT, false, 0, 1, FOLD>(X, ldx, Wg, dvec, nullptr, 0, Cout, ldc, M, N, K, scale, scale_cols,
                                                           nullptr, stream, cvec, ln_eps, rp, pld, fold_flag);
     return launch_gemm_nt<ACT, false, 0, 2, FOLD>(X, ldx, Wg, dvec, nullptr, 0, Cout, ldc, M, N, K, scale, scale_cols,
@@ -341,7 +435,11 @@ static int launch_gemm_fold(const float* X, int64_t ldx, const float* Wg, const 
 static int launch_gemm_res_stats(const float* A, int64_t lda, const float* W, const float* bias, const float* residual,
                                  int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float* row_partials,
                                  int64_t pld, hipStream_t stream) {
-    if (half_width_tiles_win(M, N))
+    const TilePlan plan = tile_plan(M, N);
+    if (plan.kind == 2)
+        return launch_gemm_mixed<RNAMSM_ACT_NONE, true, 0, 0, true>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, 1.f, 0, nullptr, stream,
+                                                                    plan.full_blocks, nullptr, 0.f, row_partials, pld);
+    if (plan.kind == 1)
         return launch_gemm_nt<RNAMSM_ACT_NONE, true, 0, 1, 0, true>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, 1.f, 0,
                                                                         nullptr, stream, nullptr, 0.f, row_partials, pld);
     return launch_gemm_nt<RNAMSM_ACT_NONE, true, 0, 2, 0, true>(A, lda, W, bias, residual, ldr, Cout, ldc, M, N, K, 1.f, 0,

@@ -158,6 +158,47 @@ def test_folded_gemm_over_the_first_rows_of_a_longer_stream(dev):
     assert rel_l2(x2[:Mq].cpu(), (x[:Mq].double() + a.double() @ wo.double().t() + bo.double()).cpu()) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(12837, 768, 96), (7200, 2304, 64), (18432, 2304, 64), (8192, 768, 64), (66000, 128, 32)])
+def test_mixed_tile_gemm_is_bit_identical_to_the_uniform_tilings(dev, M, N, K):
+    """gemm_f32_mixed_kernel (round 5: whole rounds of 128 x 128 tiles, the tile positions of the last round as 128 x 64 halves;
+    knob "gemm_tile" = 3 forces it wherever a launch has both) against the all-128 x 128 launch, for every epilogue form the
+    forward uses: plain (+ GELU, + column scale), residual, residual + row sums, the folded LayerNorm (both stats forms), the
+    per-row factor of ragged batches.  Shapes: a ragged last row panel; a panel count that is no multiple of 8 (the whole rounds
+    must stay inside the panels every XCD owns); configs[0]'s QKV; one whole round exactly and no tail (falls back to full tiles);
+    one column block."""
+    from rnamsm import ops
+    from rnamsm._lib import ACT_GELU_ERF, ACT_NONE
+    a, w, b = _rand("mx.a", (M, K)).to(dev), _rand("mx.w", (N, K), 0.05).to(dev), _rand("mx.b", (N,), 0.1).to(dev)
+    gamma, beta = (_rand("mx.g", (K,), 0.2) + 1.0).to(dev), _rand("mx.be", (K,), 0.1).to(dev)
+    wg, c, d = ops.ln_fold_weights(w, b, gamma, beta)
+    res = None
+    if N == K:
+        res = _rand("mx.r", (M, N)).to(dev)
+    rowf = torch.rand(M, device=dev)
+    outs = {}
+    try:
+        for tile in (1, 3, 0):
+            ops.set_param("gemm_tile", tile)
+            o = [ops.linear(a, w, b), ops.linear(a, w, b, act=ACT_GELU_ERF, scale=0.125, scale_cols=min(N, 128)),
+                 ops.linear_row_scaled(a, w, b, rowf, scale=0.125, scale_cols=min(N, 128)),
+                 ops.linear_lnfold(a, wg, c, d, None, act=ACT_GELU_ERF), ops.linear_lnfold(a, wg, c, d, None, scale=0.125, scale_cols=min(N, 128))]
+            sq = _rand("mx.sq", (M, N)).to(dev)                              # residual forms: A = [M, N] @ W2 [N, N] needs N == K; use a square weight
+            w2 = _rand("mx.w2", (N, N), 0.03).to(dev)
+            if N <= 768:
+                x = sq.clone()
+                out, part = ops.linear_residual_stats(sq, w2, b, x, out=x)
+                st = ops.row_stats_from_partials(part, N)
+                o += [out.clone(), part.clone(), ops.linear(sq, w2, b, residual=sq), ops.linear_lnfold(sq, *ops.ln_fold_weights(w2, b, torch.ones(N, device=dev), torch.zeros(N, device=dev)), st)]
+            outs[tile] = o
+    finally:
+        ops.set_param("gemm_tile", 0)
+    for tile in (3, 0):
+        for i, (x, y) in enumerate(zip(outs[1], outs[tile])):
+            assert torch.equal(x, y), (tile, i, float((x - y).abs().max()))
+    want = a.double() @ w.double().t() + b.double()
+    assert rel_l2(outs[3][0].cpu(), want.cpu()) < 2e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(5, 128, 64), (300, 768, 768), (1025, 768, 3072), (200, 256, 96)])
 def test_residual_gemm_leaves_the_row_sums_of_what_it_stores(dev, M, N, K):
     """rnamsm_gemm_residual_stats (out_proj / fc2 + residual add): the output is bit-identical to the plain residual GEMM's
