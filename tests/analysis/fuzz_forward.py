@@ -40,7 +40,7 @@ EDGES = [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 1
 TOL = {"f32": (1e-4, 1e-4, 3.0), "f16x3": (1e-4, 1e-4, 4.0), "bf16x3": (2e-4, 3e-3, 5.0),
        "bf16": (2e-2, 2e-2, 2.0)}         # plain bf16: yardstick = the oracle run in bfloat16 (what the reference's .bfloat16() does)
 KNOB_DEFAULTS = {"ln_fold": 1, "gemm_tile": 0, "col_dma": -1, "row_vt": 1, "attn16": 1, "gemm_splitk": 0,
-                 "col_fast": 1, "gemm_flat_tiles": 512, "gemm_splitk_short": 0, "col_small": 1}     # (the last four: round 4)
+                 "col_fast": 1, "gemm_flat_tiles": 512, "gemm_splitk_short": 0, "col_small": 1, "row_narrow": 1}     # (col_fast .. col_small: round 4; row_narrow: round 5)
 
 
 def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mode=None, model=None, log=print):
@@ -65,11 +65,12 @@ def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mod
                 if R * C <= max_tokens:
                     break
             mode = str(rng.choice(["f32", "f32", "f16x3", "f16x3", "bf16"]))      # (same stream as before; the bf16x3 draws now run f16x3: the mode was removed in round 5)
-            knobs = {"ln_fold": int(rng.choice([0, 1, 2, 3])), "gemm_tile": int(rng.choice([0, 1, 2])),
+            knobs = {"ln_fold": int(rng.choice([0, 1, 2, 3])), "gemm_tile": int(rng.choice([0, 1, 2])),      # (3 = mixed tiles needs > 512 tiles: beyond this fuzz's sizes; tests/test_gpu_kernels.py holds it)
                      "col_dma": int(rng.choice([-1, 0, 1])), "row_vt": int(rng.choice([0, 1])), "attn16": int(rng.choice([0, 1, 1])),
                      "gemm_splitk": int(rng.choice([0, 1, 1, 2, 4, 8])), "col_fast": int(rng.choice([0, 1, 1])),
                      "gemm_flat_tiles": int(rng.choice([0, 512, 512, 100000])), "gemm_splitk_short": int(rng.choice([0, 0, 2, 4])),
                      "col_small": int(rng.choice([0, 1, 1]))}
+            knobs["row_narrow"] = int(rng.choice([0, 1, 1]))                 # (drawn last: the stream of the earlier knobs is unchanged)
             padded = rng.random() < 0.3 and R > 1 and C > 3
             if fixed:
                 (R, C), padded = fixed[case], False
