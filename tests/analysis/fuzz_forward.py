@@ -70,7 +70,7 @@ def run(cases=60, seed=0, max_tokens=6000, fixed=(), fixed_knobs=None, fixed_mod
                      "gemm_splitk": int(rng.choice([0, 1, 1, 2, 4, 8])), "col_fast": int(rng.choice([0, 1, 1])),
                      "gemm_flat_tiles": int(rng.choice([0, 512, 512, 100000])), "gemm_splitk_short": int(rng.choice([0, 0, 2, 4])),
                      "col_small": int(rng.choice([0, 1, 1]))}
-            knobs["row_narrow"] = int(rng.choice([0, 1, 1]))                 # (drawn last: the stream of the earlier knobs is unchanged)
+            knobs["row_narrow"] = int(rng.choice([0, 1, 1]))                 # (round 5; one more draw per case: the case stream differs from round 4's for the same seed)
             padded = rng.random() < 0.3 and R > 1 and C > 3
             if fixed:
                 (R, C), padded = fixed[case], False
