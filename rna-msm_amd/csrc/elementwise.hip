@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void ln_fold_weights_kernel(const float* __res
     }
 }
 
+constexpr int EMBED_RUN = 8;
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict__ tokens,
                                                        const float* __restrict__ embed_tokens,
                                                        const float* __restrict__ embed_positions,
@@ -173,7 +174,14 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
     const int nvec = D / 4;
     const int64_t T = pk ? packed_T : (int64_t)B * R * C;
     const int64_t stride = (int64_t)gridDim.x * 4;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += stride) {
+    // A wave takes RUNS of EMBED_RUN consecutive tokens: the position of a token is a prefix count over its alignment row, and
+    // inside a run it is the previous token's count + 1 bit -- one wave per token recounted its whole row prefix for every token
+    // (up to C / 64 dependent load + ballot steps each: 155 us where the output write takes 64, round 4's 0.39 of the HBM rate)
+    int count = 0;
+    for (int64_t run = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); run * EMBED_RUN < T; run += stride)
+    for (int t_ = 0; t_ < EMBED_RUN; ++t_) {
+        const int64_t row = run * EMBED_RUN + t_;
+        if (row >= T) break;
         int r, c;
         const int64_t* trow;
         if (pk) {
@@ -194,13 +202,17 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int64_t* __restrict
             trow = tokens + rg * C;
         }
         // pos = cumsum(tok != pad)[c] * (tok[c] != pad) + pad   (modules.py:288-290)
-        int count = 0;
-        for (int base = 0; base <= c; base += 64) {
-            const int cc = base + lane;
-            const bool nonpad = cc <= c && trow[cc] != pad_idx;
-            count += __popcll(__ballot(nonpad));
-        }
         int64_t tok = trow[c];
+        if (t_ == 0 || c == 0) {          // first token of the run or of an alignment row: count the prefix [0, c]
+            count = 0;
+            for (int base = 0; base <= c; base += 64) {
+                const int cc = base + lane;
+                const bool nonpad = cc <= c && trow[cc] != pad_idx;
+                count += __popcll(__ballot(nonpad));
+            }
+        } else {                          // same alignment row as the token before (c - 1): one more position
+            count += tok != pad_idx ? 1 : 0;
+        }
         int pos = (tok != pad_idx) ? count + pad_idx : pad_idx;
         if (tok < 0 || tok >= vocab || pos >= num_positions) {
             if (lane == 0 && err_flag) *err_flag = 1;
@@ -292,19 +304,35 @@ __global__ __launch_bounds__(256) void pack_outputs_kernel(const float* __restri
         atp += blockIdx.y * n_atp;
     }
     const int L = C - 1;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     bool bad = false;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_emb + n_atp; idx += stride) {
-        float v;
-        if (idx < n_emb) {
-            const int64_t cpos = idx / D, d = idx % D;                        // emb[c-1, d] = x_final[row 0, c, d]
-            emb[idx] = v = x_final[(cpos + 1) * D + d];
-        } else {
-            const int64_t a = idx - n_emb;
-            const int64_t j = a % L, i = (a / L) % L, ch = a / ((int64_t)L * L);
-            atp[a] = v = probs_all[(ch * C + (i + 1)) * C + (j + 1)];
+    // emb[c - 1, d] = x_final[row 0, c, d]: the run x_final[D, C * D) as it lies, float4 (D % 4 == 0; round 4's kernel paid two
+    // 64-bit divisions per 4-byte element: 0.43 of the HBM rate)
+    {
+        const int64_t n4 = n_emb / 4, stride = (int64_t)gridDim.x * blockDim.x;
+        const f32x4* src = reinterpret_cast<const f32x4*>(x_final + D);
+        f32x4* dst = reinterpret_cast<f32x4*>(emb);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const f32x4 v = src[i];
+            dst[i] = v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bad |= !(fabsf(v[e]) <= 3.4028234663852886e38f);     // inf or NaN
         }
-        bad |= !(fabsf(v) <= 3.4028234663852886e38f);                         // inf or NaN
+    }
+    // atp[ch, i, :] = probs_all[ch, i + 1, 1:]: one wave per map row, 32-bit indices inside the row
+    {
+        const int lane = threadIdx.x & 63;
+        const int64_t rows = (int64_t)(n_atp / ((int64_t)L > 0 ? L : 1)), wstride = (int64_t)gridDim.x * 4;
+        for (int64_t rw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); L > 0 && rw < rows; rw += wstride) {
+            const int64_t ch = rw / L;
+            const int i = (int)(rw - ch * L);
+            const float* src = probs_all + (ch * C + (i + 1)) * C + 1;
+            float* dst = atp + rw * L;
+            for (int j = lane; j < L; j += 64) {
+                const float v = src[j];
+                dst[j] = v;
+                bad |= !(fabsf(v) <= 3.4028234663852886e38f);
+            }
+        }
     }
     if (err_flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(err_flag, 4);
 }
@@ -407,7 +435,7 @@ int embed_ln_batched(const int64_t* tokens, const float* embed_tokens, const flo
     // algorithmic HBM bytes: the output rows and the token ids; the two embedding tables (3.2 MB) are L2-resident, their rows are
     // not HBM reads (counting them had given this launch a "fraction of roofline" above 1)
     KernelTimer timer(TC_EMBED, 0.0, 4.0 * T * D + 8.0 * T, stream);
-    hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid(T)), dim3(256), 0, stream, tokens, embed_tokens, embed_positions, row_pos,
+    hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid((T + EMBED_RUN - 1) / EMBED_RUN)), dim3(256), 0, stream, tokens, embed_tokens, embed_positions, row_pos,
                        gamma, beta, out, R, C, D, vocab, num_positions, pad_idx, eps, err_flag, B, row_pos_dim > 1 ? row_pos_dim : 0,
                        (const PackedMsa*)nullptr, (int64_t)0);
     RNAMSM_CHECK_LAUNCH("embed_ln");
@@ -417,7 +445,7 @@ int embed_ln_packed(const int64_t* tokens, const float* embed_tokens, const floa
                     const float* gamma, const float* beta, float* out, const PackedMsa* pk, int B, int64_t T, int D, int vocab,
                     int num_positions, int pad_idx, float eps, int* err_flag, hipStream_t stream, int row_pos_dim) {
     KernelTimer timer(TC_EMBED, 0.0, 4.0 * T * D + 8.0 * T, stream);
-    hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid(T)), dim3(256), 0, stream, tokens, embed_tokens, embed_positions, row_pos,
+    hipLaunchKernelGGL(embed_ln_kernel, dim3(rows_grid((T + EMBED_RUN - 1) / EMBED_RUN)), dim3(256), 0, stream, tokens, embed_tokens, embed_positions, row_pos,
                        gamma, beta, out, 0, 0, D, vocab, num_positions, pad_idx, eps, err_flag, B, row_pos_dim > 1 ? row_pos_dim : 0, pk, T);
     RNAMSM_CHECK_LAUNCH("embed_ln (packed)");
     return RNAMSM_OK;

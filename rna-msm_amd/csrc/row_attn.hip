@@ -588,6 +588,10 @@ __global__ __launch_bounds__(256) void row_apply_narrow_kernel(
 
 // rows of one block of row_apply_narrow_kernel (a multiple of 4: one per wave and step): enough blocks for ~4 per CU, and
 // as many rows per block as that allows (the block's map staging is paid once).  Speed only: every row is computed alone.
+static inline bool narrow_fits(int R, int C, int64_t ld, int64_t ldc) {
+    const int64_t lim = (int64_t)1 << 31;
+    return (int64_t)R * C * ld * 4 < lim && (int64_t)R * C * ldc * 4 < lim;
+}
 static inline int narrow_rows_per_block(int64_t rows_total, int H) {
     if (tuning().row_narrow_rows > 0) return (tuning().row_narrow_rows + 3) & ~3;
     int64_t rpb = (rows_total * H + 1023) / 1024;
@@ -746,7 +750,8 @@ static int row_apply_launch(const float* probs, const float* v, int64_t ld, floa
     const bool al = C % 4 == 0 && C >= 4 && aligned16(probs);
     const int out = ctx_hi ? 1 + plane_fmt : 0;
     KernelTimer timer(TC_ROW_APPLY, 2.0 * batch * H * C * C * R * HEAD_DIM, 4.0 * batch * (2.0 * R * C * H * HEAD_DIM + (double)H * C * C), s);
-    if (out == 0 && C <= ROW_NARROW_MAX_C && tuning().row_narrow) {
+    // (the narrow kernel addresses V and the context through 32-bit buffer offsets: the alignment's byte ranges must fit them)
+    if (out == 0 && C <= ROW_NARROW_MAX_C && tuning().row_narrow && narrow_fits(R, C, ld, ldc)) {
         const int rpb = narrow_rows_per_block((int64_t)R * batch, H);
         hipLaunchKernelGGL(row_apply_narrow_kernel, dim3((unsigned)(H * ((R + rpb - 1) / rpb)), batch), dim3(256), 0, s, probs, v, ld, ctx, ldc,
                            R, C, H, rpb, probs_bstride, v_bstride, ctx_bstride, (const PackedMsa*)nullptr, 0);
@@ -871,7 +876,9 @@ int softmax_rows_packed(const float* partial, float* row_attn, int layer, int H,
 int row_apply_packed(const float* row_attn, int layer, const float* v, int64_t ld, float* ctx, int64_t ldc, int H, const PackedMsa* pk,
                      const PackedMsa* host, int B, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool narrow_on = tuning().row_narrow != 0;
+    bool narrow_on = tuning().row_narrow != 0;
+    for (int b = 0; b < B && narrow_on; ++b)                     // (32-bit buffer offsets: never an issue at this model's row strides)
+        if (host[b].C <= ROW_NARROW_MAX_C && !narrow_fits(host[b].R, host[b].C, ld, ldc)) narrow_on = false;
     unsigned grid = 0, grid_narrow = 0;
     double flops = 0.0, bytes = 0.0;
     int64_t narrow_rows = 0;

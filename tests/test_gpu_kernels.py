@@ -482,7 +482,7 @@ def test_col_attention_online_softmax_rescale_is_exercised(dev):
         assert rel_l2(ctx, want) < 5e-6
 
 
-@pytest.mark.parametrize("R,C", [(3, 9), (16, 33), (5, 200)])
+@pytest.mark.parametrize("R,C", [(3, 9), (16, 33), (5, 200), (40, 130), (3, 600), (9, 8)])
 def test_embed_ln_matches_oracle_with_and_without_pad(dev, R, C):
     from rnamsm import ops
     state = synthetic.make_state_dict(seed=3, embed_dim=128, num_layers=1, num_heads=2)
@@ -497,14 +497,21 @@ def test_embed_ln_matches_oracle_with_and_without_pad(dev, R, C):
     toks[1, 2] = 1; toks[R - 1, C - 1] = 1; toks[2, 0] = 1
     x = ops.embed_ln(toks.to(dev), args[0], args[1], rowpos, lnw, lnb, pad_idx=1).cpu()
     assert rel_l2(x, O.embed(toks, params).reshape(R * C, -1)) < 2e-6
+    # (round 5: a wave walks runs of 8 consecutive tokens and carries the position count) pads scattered over run starts, run
+    # interiors and row starts
+    mask = torch.from_numpy(synthetic.normal(f"embpad{R}_{C}", 3, (R, C)) > 0.6)
+    toks2 = toks.clone(); toks2[mask] = 1
+    x = ops.embed_ln(toks2.to(dev), args[0], args[1], rowpos, lnw, lnb, pad_idx=1).cpu()
+    assert rel_l2(x, O.embed(toks2, params).reshape(R * C, -1)) < 2e-6
     bad = toks.clone(); bad[0, 1] = 12
     with pytest.raises(IndexError):
         ops.embed_ln(bad.to(dev), args[0], args[1], rowpos, lnw, lnb, pad_idx=1)
 
 
-def test_pack_outputs_is_a_pure_copy(dev):
+@pytest.mark.parametrize("C", [21, 150, 2, 66])
+def test_pack_outputs_is_a_pure_copy(dev, C):
     from rnamsm import ops
-    C, D, NL, H, R = 21, 128, 3, 2, 4
+    D, NL, H, R = 128, 3, 2, 4
     x = _rand("pk.x", (R * C, D)); p = _rand("pk.p", (NL, H, C, C))
     emb, atp = ops.pack_outputs(x.to(dev), p.to(dev), C)
     assert torch.equal(emb.cpu(), x.view(R, C, D)[0, 1:])
