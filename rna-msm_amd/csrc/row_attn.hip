@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void row_logits_narrow_kernel(
 // (attn_weights.softmax(-1), modules.py:818/739).  C <= 1024 + 1 fits 17 values per lane.
 // PL: 0 = fp32 probabilities only; 1 / 2 = additionally bf16 / fp16 hi(+lo) planes [rows][ldp] (ldp = C rounded up
 // to 64, the tail zero-filled) holding P * plane_scale: the k-contiguous A operand of the 16-bit row_apply.
-// NE = values per lane (C <= 64 NE): 17 covers the maximum width; narrow alignments take the 1- or 4-value instance, whose slab
+// NE = values per lane (C <= 64 NE): 17 covers the maximum width; narrower alignments take the 1-, 4- or 8-value instance, whose slab
 // loop is 1 / 4 loads per slab instead of 17 predicated ones (23 -> 8 us per launch at 512 x 36, 40 slabs).  Same arithmetic: the
 // values a wider instance would carry beyond C are -inf / 0 and add nothing.
 constexpr int SOFTMAX_MAX_PER_LANE = 17;
@@ -697,6 +697,8 @@ static int softmax_rows_launch(const float* partial, int nsplit, float* probs, i
         hipLaunchKernelGGL((softmax_rows_kernel<0, 1>), grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
     else if (!p_hi && C <= 256)
         hipLaunchKernelGGL((softmax_rows_kernel<0, 4>), grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
+    else if (!p_hi && C <= 512)
+        hipLaunchKernelGGL((softmax_rows_kernel<0, 8>), grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
     else if (!p_hi)
         hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
     else if (fmt == 0)
@@ -868,7 +870,7 @@ int softmax_rows_packed(const float* partial, float* row_attn, int layer, int H,
     hipLaunchKernelGGL((softmax_rows_kernel<0, NE_>), dim3((unsigned)(((int64_t)H * max_C + 3) / 4), B), dim3(256), 0, s, partial, 0, row_attn, \
                        (int64_t)0, 0, (const uint8_t*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr, (int64_t)0, 1.f, (int64_t)0,    \
                        (int64_t)0, (int64_t)0, (int64_t)0, (int64_t)0, pk, layer, H, 1.f)
-    if (max_C <= 64) SM_PK(1); else if (max_C <= 256) SM_PK(4); else SM_PK(SOFTMAX_MAX_PER_LANE);
+    if (max_C <= 64) SM_PK(1); else if (max_C <= 256) SM_PK(4); else if (max_C <= 512) SM_PK(8); else SM_PK(SOFTMAX_MAX_PER_LANE);
 #undef SM_PK
     RNAMSM_CHECK_LAUNCH("softmax_rows (packed)");
     return RNAMSM_OK;
