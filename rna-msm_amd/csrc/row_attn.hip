@@ -693,18 +693,18 @@ static int softmax_rows_launch(const float* partial, int nsplit, float* probs, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((rows + 3) / 4), batch);
     KernelTimer timer(TC_SOFTMAX, 0.0, batch * (4.0 * (double)(nsplit + 1) * H * C * C + (p_hi ? (p_lo ? 4.0 : 2.0) * rows * ldp : 0.0)), s);
-    if (!p_hi && C <= 64)
-        hipLaunchKernelGGL((softmax_rows_kernel<0, 1>), grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
-    else if (!p_hi && C <= 256)
-        hipLaunchKernelGGL((softmax_rows_kernel<0, 4>), grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
-    else if (!p_hi && C <= 512)
-        hipLaunchKernelGGL((softmax_rows_kernel<0, 8>), grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
-    else if (!p_hi)
-        hipLaunchKernelGGL(softmax_rows_kernel<0>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
-    else if (fmt == 0)
-        hipLaunchKernelGGL(softmax_rows_kernel<1>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
-    else
-        hipLaunchKernelGGL(softmax_rows_kernel<2>, grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, 0, H, logit_scale);
+#define SM_GO(PL_, NE_)                                                                                                            \
+    hipLaunchKernelGGL((softmax_rows_kernel<PL_, NE_>), grid, dim3(256), 0, s, partial, nsplit, probs, rows, C, key_mask, p_hi, p_lo, ldp, \
+                       plane_scale, mask_slab_stride, part_bstride, probs_bstride, mask_bstride, plane_bstride, (const PackedMsa*)nullptr, \
+                       0, H, logit_scale)
+#define SM_PICK(PL_)                                                                                                               \
+    do {                                                                                                                           \
+        if (C <= 64) SM_GO(PL_, 1); else if (C <= 256) SM_GO(PL_, 4); else if (C <= 512) SM_GO(PL_, 8);                            \
+        else SM_GO(PL_, SOFTMAX_MAX_PER_LANE);                                                                                     \
+    } while (0)
+    if (!p_hi) SM_PICK(0); else if (fmt == 0) SM_PICK(1); else SM_PICK(2);
+#undef SM_PICK
+#undef SM_GO
     RNAMSM_CHECK_LAUNCH("softmax_rows");
     return RNAMSM_OK;
 }
