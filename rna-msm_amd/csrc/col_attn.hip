@@ -301,6 +301,7 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
     const int li = lane & 31, lh = lane >> 5;
     const int irow0 = ib * CA_ROWS + wave * 32;
     const bool active = irow0 < q_rows;                      // wave-uniform
+    bool computing = active;                                 // (the fallback pass narrows it to the waves that asked for it)
     const int64_t col_off = (int64_t)c * ld + h * CA_HD;
 
     f32x4 qf[8];
@@ -466,17 +467,20 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
         for (int ch = 0; ch < nch; ch += 2) {                     // unrolled by two: the buffer index is a compile-time constant
             wait_dma_then_barrier<0>();      // chunk ch has landed (every wave's share) and the other buffer is free again
             if (ch + 1 < nch) issue(ch + 1, 1);
-            if (active) tile(std::integral_constant<int, 0>{}, ch * CD_JC, trk_tag);
+            if (computing) tile(std::integral_constant<int, 0>{}, ch * CD_JC, trk_tag);
             if (ch + 1 < nch) {
                 wait_dma_then_barrier<0>();
                 if (ch + 2 < nch) issue(ch + 2, 0);
-                if (active) tile(std::integral_constant<int, 1>{}, (ch + 1) * CD_JC, trk_tag);
+                if (computing) tile(std::integral_constant<int, 1>{}, (ch + 1) * CD_JC, trk_tag);
             }
         }
     };
     if (PRE && !pre_tracked_only) {
         run(std::integral_constant<bool, false>{});
-        // the block shares the ring: its waves vote and redo the column together
+        // the block shares the ring, so a second pass over the keys is the whole block's -- but only the WAVES that asked for it
+        // recompute (round 5; before, one bad row sent all 128 through the TRACKED loop): a row's arithmetic is a function of its
+        // own wave's 32 rows, whatever block they sit in.  (That made cutting the blocks of a mostly empty last round into 64-query
+        // halves a bit-identical change; measured 0.5-1 % SLOWER on deep, narrow alignments and removed: EXPERIMENTS R5.11.)
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         // lower bound 2^-64 (not 2^-100): v_exp_f32 flushes below 2^-126, so a row whose LARGEST weight is 2^-w silently drops keys
         // 2^-(126-w) below it; at 2^-64 (less log2 R <= 10 of spread) every dropped key is < 2^-52 of the sum, under fp32 rounding
@@ -488,9 +492,12 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
         const int any_bad = flags[0] | flags[1] | flags[2] | flags[3];       // block-uniform
         if (any_bad) {
             wait_dma_then_barrier<0>();      // every wave has read the flags and is done with the ring
+            computing = wave_bad != 0;
+            if (computing) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
-            m_run = -INFINITY; l_run = 0.f;
+                for (int t = 0; t < 16; ++t) { o0[t] = 0.f; o1[t] = 0.f; }
+                m_run = -INFINITY; l_run = 0.f;
+            }
             run(std::integral_constant<bool, true>{});
         }
     } else {

@@ -463,6 +463,39 @@ def test_col_attention_on_prescaled_q_without_a_running_maximum(dev, R, C, H):
         assert rel_l2(got.cpu(), truth(wild.cpu())) < 5e-6
 
 
+@pytest.mark.parametrize("R,C,H", [(512, 36, 12), (300, 100, 4), (129, 7, 2)])
+def test_col_attention_fallback_recomputes_only_the_waves_that_asked(dev, R, C, H):
+    """Round 5: when the FAST loop of the prescaled fp32 column kernel leaves exp2's range for some query, the block makes its second
+    (TRACKED) pass together -- it shares the key ring -- but only the WAVES that asked for it recompute; the other waves of the block
+    keep their FAST result.  So a query row's arithmetic depends on its own wave's 32 rows only: every row outside the wild
+    queries' waves comes out with the same bits as without the wild queries, and everything is finite and right against fp64."""
+    from rnamsm import ops
+    LOG2E = 1.4426950408889634
+    qkv, D = _qkv(R, C, H, f"cm{R}_{C}")
+    g = qkv.to(dev)
+    g[:, :D] *= 0.125 * LOG2E
+    wild = g.clone()
+    qv, kv = wild[:, :D].view(R, C, H, 64), wild[:, D:2 * D].view(R, C, H, 64)
+    qv[5, C // 2, H - 1] = 26.0 * kv[7, C // 2, H - 1] / kv[7, C // 2, H - 1].norm()          # overflow without a reference: wave 0 of block 0
+    qv[R - 3, 1, 0] = 26.0 * kv[2, 1, 0] / kv[2, 1, 0].norm()                                    # ... and a wave of the LAST block of another column
+    base = ops.col_attn(g[:, :D], g[:, D:2 * D], g[:, 2 * D:], R, C, H, prescaled=True).clone()
+    got = ops.col_attn(wild[:, :D], wild[:, D:2 * D], wild[:, 2 * D:], R, C, H, prescaled=True).clone()
+    assert bool(torch.isfinite(got).all())
+    same = base.view(R, C, H, 64) == got.view(R, C, H, 64)
+    same[0:32, C // 2, H - 1] = True
+    same[(R - 3) // 32 * 32:(R - 3) // 32 * 32 + 32, 1, 0] = True
+    assert bool(same.all())
+    cols = sorted({0, 1, C // 2, C - 1})
+
+    def truth(t):
+        q = t[:, :D].double().view(R, C, H, 64)[:, cols] / LOG2E
+        k = t[:, D:2 * D].double().view(R, C, H, 64)[:, cols]
+        v = t[:, 2 * D:].double().view(R, C, H, 64)[:, cols]
+        return torch.einsum("hcij,jchd->ichd", torch.softmax(torch.einsum("ichd,jchd->hcij", q, k), -1), v)
+    for t, o in ((g, base), (wild, got)):
+        assert rel_l2(o.view(R, C, H, 64)[:, cols].cpu(), truth(t).cpu()) < 5e-6
+
+
 def test_col_attention_online_softmax_rescale_is_exercised(dev):
     """Forces the running-max rescale branch: one late key dominates every query (spike placed in the last
     64-key chunk), and a second case puts the dominant key first so later tiles never rescale."""
