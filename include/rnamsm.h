@@ -251,8 +251,8 @@ int rnamsm_col_attn_fused_queries(const float* q, const float* k, const float* v
 /* K7 on PRESCALED q (round 4): q already carries dh^-1/2 * log2(e) (the scale / scale_cols of the QKV GEMM's epilogue), so the
  * scores are in log2 units and the kernel's first pass needs no running maximum -- p = exp2(s) on the raw score, no max chain, no
  * rescale of the accumulators (softmax does not depend on the reference point and fp32 keeps its relative precision at any
- * scale); a block whose row sums leave [2^-64, 2^100] (a score outside fp32's exponent range) redoes its column with the online
- * softmax in log2 units.  No mask, fp32 context; q_rows as in rnamsm_col_attn_fused_queries (q_rows == R: all rows).  Results
+ * scale); a wave (32 query rows) whose row sums leave [2^-64, 2^100] (a score outside fp32's exponent range) redoes its rows with
+ * the online softmax in log2 units (round 5: per wave, not per 128-query block -- a row's arithmetic does not depend on its block mates).  No mask, fp32 context; q_rows as in rnamsm_col_attn_fused_queries (q_rows == R: all rows).  Results
  * equal rnamsm_col_attn_fused on q / log2(e) to fp32 rounding.  What rnamsm_forward / _batch / _packed call on the exact path
  * when the MSA has no padding.  Knob "col_fast" = 0 keeps the online softmax only (A/B). */
 int rnamsm_col_attn_fused_prescaled(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc,
