@@ -842,7 +842,7 @@ def run_rank(args) -> int:
                                   "LayerNorms of every layer (applied to the accumulators of the QKV / fc1 GEMMs, row statistics "
                                   "left by the out_proj / fc2 epilogues: no LayerNorm launches) -- un-fused the same kernel "
                                   "measures 0.900 and the step is 1.25 % slower (DESIGN 3.4b)")
-                                 if (args.gemm_dtype == "f32" and M * L >= 18432) else None},
+                                 if (args.gemm_dtype == "f32" and M * L >= 4096) else None},
             "attention_mfma": {"kernels": "row_logits+row_apply+col_attn", "achieved": attn_fl / (attn_ms * 1e-3) / 1e12 if attn_ms else 0.0,
                                "peak": peak, "unit": flop_unit,
                                "frac": (attn_fl / (attn_ms * 1e-3) / 1e12 / peak) if attn_ms else 0.0},

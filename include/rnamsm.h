@@ -471,7 +471,8 @@ int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* const* weig
  * alignment from gridDim.y and its shape / offsets from a descriptor table the call writes into the workspace.  Every
  * alignment keeps the tied-logit slab split of its own forward; q carries dh^-1/2 and the alignment's 1/sqrt(R_b)
  * (align_scaling, modules.py:713-715) multiplies its summed logits -- the arithmetic of rnamsm_forward itself since round 5 --
- * fc2 is never split and LayerNorm is folded only where every member's own forward folds it (>= 18432 tokens each): with
+ * fc2 is never split and LayerNorm is folded only where every member's own forward folds it (>= 4096 tokens each; a list that mixes the two classes is
+ * best handed over as two batches, as the Python mirror does): with
  * RNAMSM_F32 every alignment's outputs are rnamsm_forward's BIT FOR BIT (tests/test_gpu_forward.py).  A packed batch builds no
  * masks: <pad> inside it sets bit 3 (value 8) of *err_flag and the caller reruns that batch framed.
  * dtype RNAMSM_BF16 / RNAMSM_F16X3 (round 5; weight_planes as in rnamsm_forward, NULL for RNAMSM_F32): every Linear runs on the
@@ -565,7 +566,7 @@ void rnamsm_timing_reset(void);
  *   "greedy_fused"  rnamsm_greedy_select: 1 (default) = one launch per step (one wave per row) for alignments of up to 3072
  *                 rows, three launches per step (one thread per row) above; 2 = always one; 0 = always three.  Same indices.
  *   "ln_fold"     rnamsm_forward with ln_folded given: 1 (default) = LayerNorm folded into the QKV / fc1 GEMMs, row sums
- *                 left by the out_proj / fc2 epilogues, for MSAs of R*C >= 18432 tokens (below that the separate launches
+ *                 left by the out_proj / fc2 epilogues, for MSAs of R*C >= 4096 tokens (rnamsm_get_param("ln_fold_min_tokens"); 18432 until round 5; below that the separate launches
  *                 are faster); 3 = for every shape, and in the 16-bit modes too (ln_folded16; measured neutral there, hence
  *                 not the default); 2 = folded, every GEMM sums the rows it stages itself; 0 = separate LayerNorm launches
  *                 (all agree to fp32 rounding, resp. to the 16-bit mode's rounding).

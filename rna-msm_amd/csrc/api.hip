@@ -273,6 +273,7 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "gemm_splitk")) return rnamsm::tuning().gemm_splitk;
     if (name && !strcmp(name, "gemm16_stagger")) return rnamsm::tuning().gemm16_stagger;
     if (name && !strcmp(name, "row_vt")) return rnamsm::tuning().row_vt;
+    if (name && !strcmp(name, "ln_fold_min_tokens")) return (int)rnamsm::LN_FOLD_MIN_TOKENS;      // read-only (common.h)
     if (name && !strcmp(name, "row_narrow")) return rnamsm::tuning().row_narrow;
     if (name && !strcmp(name, "row_narrow_rows")) return rnamsm::tuning().row_narrow_rows;
     if (name && !strcmp(name, "gemm_tile")) return rnamsm::tuning().gemm_tile;

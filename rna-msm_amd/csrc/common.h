@@ -72,6 +72,10 @@ struct KernelTimer {   // brackets one launch with two hipEventRecord calls when
 };
 
 // ---- tuning knobs (api.hip) -------------------------------------------------------------------------
+// The folded LayerNorm (forward.hip, knob "ln_fold" = 1) is taken by an alignment of at least this many tokens, in every exact
+// driver alike: the decision follows the MEMBER, never the batch.  Round 5: 18432 -> 4096 (tools/forward_knob_ab.py ln_fold=0,3 after
+// row_stats_from_partials lost its serial loads: +1.1 .. +1.6 % from 4096 tokens up, +0.4 % at 2048: profiles/r05_ln_fold_threshold_ab.log).
+constexpr int64_t LN_FOLD_MIN_TOKENS = 4096;
 struct Tuning {
     int gemm16_dma = 3;            // plane-input 16-bit GEMMs: 0 register staging, 1 / 2 LDS-DMA 128x128,
                                    // 3 = LDS-DMA 256x256 with software-pipelined fragments, BK = 64 for split 1 (default),
@@ -99,7 +103,7 @@ struct Tuning {
     int row16_q16 = 1;             // plain bf16 at C >= 384, C % 8 == 0: 1 = row_logits16q_kernel (16x16x32 MFMA, staged by operand), 0 = the 128x128 kernel
     int row16_max_rows = 32;       // hi/lo modes: cap on the rows of one row_logits16 slab (0 = none): accuracy, DESIGN 3.2
     int ln_fold = 1;               // rnamsm_forward with ln_folded: 1 = LayerNorm applied inside the consuming GEMM (row sums from the producers'
-                                   // epilogues) when R*C >= 18432, 3 = for every shape, 2 = every GEMM sums its rows itself (A/B), 0 = separate launches
+                                   // epilogues) when R*C >= LN_FOLD_MIN_TOKENS (4096), 3 = for every shape, 2 = every GEMM sums its rows itself (A/B), 0 = separate launches
     int greedy_fused = 1;          // rnamsm_greedy_select: 1 = one launch per step (fused distance / score / argmax) up to 3072 rows, 2 = always, 0 = three launches
     int attn16 = 1;                // 16-bit modes of rnamsm_forward: 1 = attention contractions on the 16-bit matrix cores too, 0 = fp32 attention
 };

@@ -222,12 +222,13 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
     // feed (gemm_f32.hip FOLD) -- norm() is then no launch at all, lin_normed() reads x itself and res_linear() (the GEMMs
     // that write x) leaves the row sums the next lin_normed() normalises with.
     // Measured (tools/ln_fold_ab.py, whole forward): -1.4 % at M = L = 1024, -1.25 % at M=256 L=512, -0.5 % at 128x256 and at
-    // 512x36 (18432 tokens); +3 % at 128x128, +1.8 % at 100x100 and 64x128 (launches there are a tile or two deep: the folded
-    // epilogues and the 30 small statistics launches sit on the critical path while the LayerNorm launches were nearly
-    // free) -- hence the token threshold of mode 1.
+    // 512x36 (18432 tokens).  Below that it used to LOSE (+3 % at 128x128, +1.8 % at 64x128: the 30 small statistics launches sat
+    // on the critical path at 10-15 us each) and mode 1 folded from 18432 tokens; since round 5 those launches take ~3 us
+    // (row_stats_from_partials keeps a row's slabs in flight) and the fold wins from 4096 tokens up: -1.1 .. -1.6 % at 64x64 .. 128x128
+    // and 256x36 .. 400x36, -0.4 % at 32x64 -- LN_FOLD_MIN_TOKENS (common.h).
     const int fold_mode = tuning().ln_fold;          // 0 off, 1 by shape, 2 GEMMs sum their own rows, 3 always
     const bool fold = ln_folded && dtype == RNAMSM_F32 && !has_padding &&
-                      (fold_mode >= 2 || (fold_mode == 1 && (int64_t)R * C >= 18432));
+                      (fold_mode >= 2 || (fold_mode == 1 && (int64_t)R * C >= LN_FOLD_MIN_TOKENS));
     const bool fold_sums = fold && fold_mode != 2;   // row sums travel from the residual epilogues to the consumers
     float* rowsum = reinterpret_cast<float*>(ws + lay.rowsum);
     float* stats = reinterpret_cast<float*>(ws + lay.stats);
@@ -509,7 +510,7 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
     // statistics from the producers only; a ragged batch (true_rows) keeps the LayerNorm launches: its QKV GEMM carries the
     // per-token q factor in the epilogue slot the fold would need
     // (by the MEMBER's token count, as its own forward decides: the batch must not change an alignment's rounding)
-    const bool fold = ln_folded && !has_padding && !true_rows && (fold_mode == 3 || (fold_mode == 1 && Tm >= 18432));
+    const bool fold = ln_folded && !has_padding && !true_rows && (fold_mode == 3 || (fold_mode == 1 && Tm >= LN_FOLD_MIN_TOKENS));
     // f2: the batch contains <pad> (ragged MSAs padded to one shape): the reference's direct-path mask semantics as in
     // rnamsm_forward -- zeroed embeddings (K0) and q (QKV epilogue) at padded tokens, -10000 on keys whose first-row token is
     // <pad> (tied rows) and on padded keys (columns); every MSA reads its own [R, C] slice of the mask
@@ -745,12 +746,12 @@ extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float*
     float* hidden = wide;              // [T, F]
     const float* const* G = weights;
     const int fold_mode = tuning().ln_fold;
-    // folded only where EVERY member's own forward would fold (>= 18432 tokens each): an alignment's rounding must not depend
-    // on its company.  The CLI packs alignments of <= 8192 tokens, so its packed groups never fold (a 64 k-token group gives up
-    // the ~1 % the fold was worth there).
+    // folded only where EVERY member's own forward would fold (>= LN_FOLD_MIN_TOKENS each): an alignment's rounding must not depend
+    // on its company.  A batch that mixes the two classes runs unfolded here -- the Python mirror (MSATransformer.forward_packed)
+    // therefore hands such a list over as two batches, one per class, and every member keeps the bits of its own forward.
     int64_t min_member = INT64_MAX;
     for (int b = 0; b < B; ++b) min_member = std::min<int64_t>(min_member, (int64_t)host[b].R * host[b].C);
-    const bool fold = ln_folded && (fold_mode == 3 || (fold_mode == 1 && min_member >= 18432));
+    const bool fold = ln_folded && (fold_mode == 3 || (fold_mode == 1 && min_member >= LN_FOLD_MIN_TOKENS));
     const float qk_scale = 1.0f / sqrtf(64.0f);
     const PackedMsa* hp = host.data();
 

@@ -231,6 +231,10 @@ PACKED_TOKENS, PACKED_MEMBERS, PACKED_SMALL_TOKENS = 65536, 256, 8192
 PACKED_SMALL_TOKENS_16BIT = {"bf16": 8192, "f16x3": 8192}
 
 
+def r_c_below(shape: tuple, limit: int) -> bool:
+    return shape[0] * shape[1] < limit
+
+
 def joins_packed(group_shapes: List[tuple], shape: tuple) -> bool:
     """Does a small alignment of `shape` join the waiting token-packed group?"""
     trial = list(group_shapes) + [shape]
@@ -238,12 +242,21 @@ def joins_packed(group_shapes: List[tuple], shape: tuple) -> bool:
             and sum(c * c for _, c in trial) <= FRAME_MAP_ELEMS)
 
 
-def plan_packed_groups(shapes: List[tuple]) -> List[List[int]]:
+def plan_packed_groups(shapes: List[tuple], fold_min_tokens: int = 0) -> List[List[int]]:
     """Partition pooled small alignments into token-packed groups, in list order, every position exactly once.  The number of
     groups is the least the three bounds allow; members are then dealt so that the groups hold about the same number of tokens
-    (64 + 6 alignments would otherwise run as one full group and one nearly empty launch set)."""
+    (64 + 6 alignments would otherwise run as one full group and one nearly empty launch set).
+    fold_min_tokens > 0 (exact mode): alignments of at least that many tokens take the folded LayerNorm, smaller ones do not, and a
+    launch set is one or the other -- the two classes are planned separately, so that no group has to be run as two batches
+    (MSATransformer.forward_packed would split a mixed one: correct, but two launch sets)."""
     if not shapes:
         return []
+    if fold_min_tokens > 0:
+        big = [j for j, (r, c) in enumerate(shapes) if r * c >= fold_min_tokens]
+        if 0 < len(big) < len(shapes):
+            small = [j for j in range(len(shapes)) if r_c_below(shapes[j], fold_min_tokens)]
+            return ([[big[j] for j in g] for g in plan_packed_groups([shapes[j] for j in big])]
+                    + [[small[j] for j in g] for g in plan_packed_groups([shapes[j] for j in small])])
     tok = [r * c for r, c in shapes]
     k = max(-(-len(shapes) // PACKED_MEMBERS), -(-sum(tok) // PACKED_TOKENS), -(-sum(c * c for _, c in shapes) // FRAME_MAP_ELEMS), 1)
     while True:
@@ -363,7 +376,9 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
             pool: List = []                                           # (idx, tokens on the host)
 
             def run_pool() -> None:
-                for members in (plan_packed_groups if packing else plan_groups)([tuple(t.shape) for _, t in pool]):
+                shapes_ = [tuple(t.shape) for _, t in pool]
+                fold_min = ops.get_param("ln_fold_min_tokens") if (exact and model.fold_layernorm and ops.get_param("ln_fold") == 1) else 0
+                for members in (plan_packed_groups(shapes_, fold_min) if packing else plan_groups(shapes_)):
                     group.extend((pool[j][0], torch.from_numpy(pool[j][1]).to(device)) for j in members)
                     flush()
                 pool.clear()

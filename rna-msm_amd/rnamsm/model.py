@@ -404,6 +404,23 @@ class MSATransformer(nn.Module):
             raise ValueError("forward_packed: a 16-bit gemm_dtype must be the model's own (the weight planes are built per mode)")
         dev = msas[0].device
         fold = self.fold_layernorm if fold_layernorm is None else fold_layernorm
+        if fold and mode == "f32":
+            # The folded LayerNorm is an alignment's own decision (>= ln_fold_min_tokens tokens; knob "ln_fold" = 1) and one launch
+            # set is folded or not as a whole: a list that mixes the two classes goes as two packed batches, one per class, so that
+            # every member still comes out as its own forward, bit for bit
+            lib = _lib.load()
+            thr = int(lib.rnamsm_get_param(b"ln_fold_min_tokens"))
+            big = [i for i, t in enumerate(msas) if int(t.shape[0]) * int(t.shape[1]) >= thr]
+            if 0 < len(big) < len(msas) and int(lib.rnamsm_get_param(b"ln_fold")) == 1:
+                small = [i for i in range(len(msas)) if i not in set(big)]
+                parts = [(idx, self.forward_packed([msas[i] for i in idx], fold_layernorm, need_repr, gemm_dtype)) for idx in (big, small)]
+                err = parts[0][1][0]["err"] | parts[1][1][0]["err"]
+                res = [None] * len(msas)
+                for idx, out in parts:
+                    for i, item in zip(idx, out):
+                        item["err"] = err
+                        res[i] = item
+                return res
         with torch.cuda.device(dev):
             lib = _lib.load()
             dims, ptrs, _ = self._packed_weights()

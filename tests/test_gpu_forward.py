@@ -466,7 +466,7 @@ def test_outputs_only_forward_is_bit_identical_and_skips_dead_rows(model, R, C):
 
 @pytest.mark.parametrize("R,C", [(8, 17), (64, 128), (33, 131), (1, 9), (130, 40)])
 def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model, R, C):
-    """K1 folded (the exact path's default on MSAs of >= 18432 tokens without padding; forced here with knob 3): the QKV /
+    """K1 folded (the exact path's default on MSAs of >= 4096 tokens without padding -- 18432 until round 5; forced here with knob 3): the QKV /
     fc1 GEMMs read the residual stream and apply (mean, rstd) to their accumulators.  Against the same forward with
     separate LayerNorm launches (the `ln_fold` knob and MSATransformer.fold_layernorm both switch it) the outputs agree to
     fp32 rounding, and against the oracle the folded forward is no further away than the unfolded one (x1.5)."""
@@ -475,7 +475,7 @@ def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model,
     tokens = synthetic.make_tokens(R, C, 5)
     toks = torch.from_numpy(tokens).to("cuda:0")
     try:
-        ops.set_param("ln_fold", 3)                                          # folded at every shape (default: >= 18432 tokens)
+        ops.set_param("ln_fold", 3)                                          # folded at every shape (default: >= 4096 tokens)
         fold = m.forward_one(toks, has_padding=False)
         ops.set_param("ln_fold", 0)
         plain = m.forward_one(toks, has_padding=False)
@@ -513,15 +513,17 @@ def test_folded_layernorm_forward_agrees_with_separate_layernorm_launches(model,
     finally:
         ops.set_param("ln_fold", 1)
     assert torch.equal(a["emb"], b["emb"]) and torch.equal(a["atp"], b["atp"])
-    # the default picks by size: below 18432 tokens the separate launches (they are faster there), from there on the fold
+    # the default picks by size: below ln_fold_min_tokens (4096) the separate launches, from there on the fold
     dflt = m.forward_one(toks, has_padding=False)
-    assert torch.equal(dflt["emb"], (fold if R * C >= 18432 else plain)["emb"])
+    assert ops.get_param("ln_fold_min_tokens") == 4096
+    assert torch.equal(dflt["emb"], (fold if R * C >= 4096 else plain)["emb"])
 
 
-def test_folded_layernorm_is_the_default_from_18432_tokens(model):
+@pytest.mark.parametrize("R,C", [(144, 128), (64, 64), (114, 36)])
+def test_folded_layernorm_is_the_default_from_4096_tokens(model, R, C):
     from rnamsm import ops
     m, _ = model
-    toks = torch.from_numpy(synthetic.make_tokens(144, 128, 2)).to("cuda:0")
+    toks = torch.from_numpy(synthetic.make_tokens(R, C, 2)).to("cuda:0")
     dflt = m.forward_one(toks, has_padding=False)
     try:
         ops.set_param("ln_fold", 3)
@@ -645,7 +647,7 @@ def test_batched_forward_of_same_shape_msas_equals_the_msas_one_by_one(model, B,
         emb, atp = O.pack_outputs(O.forward(toks[b].cpu(), params))
         assert rel_l2(batch["emb"][b].cpu().numpy(), np.asarray(emb)) < 1e-4
         assert np.abs(batch["atp"][b].cpu().numpy() - np.asarray(atp)).max() < 1e-4
-    try:                                                       # LayerNorm folded into the batch's GEMMs (default from 18432 tokens)
+    try:                                                       # LayerNorm folded into the batch's GEMMs (default from 4096 tokens per member)
         ops.set_param("ln_fold", 3)
         folded = m.checked_forward_batch(toks)
     finally:
@@ -800,10 +802,16 @@ def test_token_packed_batch_equals_every_alignment_alone(model):
             emb, atp = O.pack_outputs(O.forward(t.cpu(), params))
             assert rel_l2(got["emb"].cpu().numpy(), np.asarray(emb)) < 1e-4
             assert np.abs(got["atp"].cpu().numpy() - np.asarray(atp)).max() < 1e-4
-    # fold_layernorm=False changes nothing here: no member reaches the fold's threshold, so the default did not fold either
-    for t, got in zip(msas, m.forward_packed(msas, fold_layernorm=False)):
-        one = m.checked_forward_one(t, need_repr=False)
-        assert torch.equal(got["emb"], one["emb"]) and torch.equal(got["atp"], one["atp"])
+    # The list mixes members below and above the fold's threshold (4096 tokens since round 5: 40 x 150 and 140 x 35 are above):
+    # forward_packed handed it over as two batches, one per class -- the members above it carry the folded LayerNorm's rounding,
+    # those below it do not, each as its own forward decides (asserted bit for bit above).  With the fold off everywhere the same
+    # holds against the unfolded lone forward, and the small members' outputs do not move at all
+    nofold = m.forward_packed(msas, fold_layernorm=False)
+    for i, (t, got) in enumerate(zip(msas, nofold)):
+        one = m.forward_one(t, has_padding=False, need_repr=False, fold_layernorm=False)
+        assert torch.equal(got["emb"], one["emb"]) and torch.equal(got["atp"], one["atp"]), shapes[i]
+        big = shapes[i][0] * shapes[i][1] >= 4096
+        assert torch.equal(got["emb"], outs[i]["emb"]) != big, shapes[i]
     # more members than one descriptor launch carries (32 per launch: 32 + 32 + 6), every fourth checked against its lone forward
     many_shapes = [(1 + (i * 7) % 19, 5 + (i * 11) % 40) for i in range(70)]
     many = [torch.from_numpy(synthetic.make_tokens(r, c, 900 + i)).to("cuda:0") for i, (r, c) in enumerate(many_shapes)]

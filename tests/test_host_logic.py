@@ -461,3 +461,12 @@ def test_token_packed_groups_are_cut_in_list_order_and_balanced():
     assert plan_packed_groups([]) == [] and plan_packed_groups([(3, 20)]) == [[0]]
     assert plan_packed_groups([(40, 35), (2, 12), (2, 12), (2, 12), (40, 35)]) == [[0, 1, 2, 3, 4]]
     assert plan_packed_groups([(1, 1024)] * 3) == [[0], [1], [2]]                              # 1024^2 map elements each: alone
+    # exact mode (round 5): alignments on either side of the folded LayerNorm's threshold are planned separately -- every position
+    # once, no group mixes the classes
+    mixed = [(40, 150), (2, 12), (140, 35), (3, 9), (64, 64), (63, 64), (5, 133)]
+    groups = plan_packed_groups(mixed, 4096)
+    assert sorted(j for g in groups for j in g) == list(range(len(mixed)))
+    for g in groups:
+        assert len({mixed[j][0] * mixed[j][1] >= 4096 for j in g}) == 1
+    assert plan_packed_groups(mixed, 4096) == [[0, 2, 4], [1, 3, 5, 6]]
+    assert plan_packed_groups(mixed, 0) == plan_packed_groups(mixed) == [list(range(len(mixed)))]
