@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define RNAMSM_VERSION 400 /* major*10000 + minor*100 + patch; 4.0: rnamsm_model_dims.row_pos_dim, rnamsm_embed_ln_rows */
+#define RNAMSM_VERSION 500 /* major*10000 + minor*100 + patch; 5.0 (round 5): rnamsm_forward_packed takes dtype + weight_planes, dtype value 2
+                              * (bf16x3) answers UNSUPPORTED, + rnamsm_softmax_rows_scaled; 4.0: rnamsm_model_dims.row_pos_dim, rnamsm_embed_ln_rows */
 
 typedef enum {
     RNAMSM_OK = 0,
