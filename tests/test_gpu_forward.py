@@ -766,6 +766,32 @@ def test_ragged_batch_equals_every_alignment_alone(model, packed):
             assert rel_l2(got["emb"].cpu().numpy(), one["emb"].cpu().numpy()) < 1e-5
 
 
+def test_padded_alignment_above_max_tokens_follows_the_chunked_mask_semantics_at_full_size(model):
+    """A padded alignment of more than max_tokens_per_msa (16384) tokens takes the reference's row-CHUNKED path (modules.py:717-750):
+    129 rows per chunk at C = 127, every chunk's -10000 fill from the chunk's OWN first row -- here row 129 carries trailing pads and
+    row 0 a stray one, so the direct path's semantics give maps that differ by up to 1.0.  The committed fixtures force this path at
+    toy sizes (forward_m8_c17_chunk.npz, from the reference); this is the real threshold, against the oracle in fp64 WITH that
+    semantics, and against the direct-path truth to show the two differ (found by the round-5 fuzz, whose truth had used the latter)."""
+    import truth
+    m, _ = model
+    R, C = 140, 127
+    toks = synthetic.make_tokens(R, C, 1083).copy()
+    toks[129, 60:] = 1
+    toks[7, 100:] = 1
+    toks[0, 40] = 1
+    toks[R - 1, 1:] = 1
+    assert R * C > m.max_tokens_per_msa == 16384
+    t = torch.from_numpy(toks).to("cuda:0")
+    out = m.checked_forward_one(t, need_repr=False)
+    t_emb, t_atp = truth.oracle_outputs(toks, torch.float64, "cuda:0", max_tokens=m.max_tokens_per_msa)
+    e = truth.errors(out["emb"], out["atp"], t_emb, t_atp)
+    # (one map entry in 1.9 M sits at 1.2e-4: fp32 rounding at this size -- the fp32 oracle itself is ~1e-4 from its fp64 run here;
+    # the semantic difference asserted below is three orders of magnitude larger)
+    assert e["emb_rel_l2"] < 1e-4 and e["atp_max_abs"] < 3e-4 and e["atp_rel_l2"] < 1e-4, e
+    d_emb, d_atp = truth.oracle_outputs(toks, torch.float64, "cuda:0")
+    assert float((d_atp - t_atp).abs().max()) > 0.1
+
+
 def test_token_packed_batch_equals_every_alignment_alone(model):
     """rnamsm_forward_packed (round 4): alignments of unlike shapes back to back on the token axis, nothing padded.  Shapes
     chosen to reach every per-alignment branch of the packed kernels in ONE batch: depth 1; R <= 16 (the one-wave column kernel's
