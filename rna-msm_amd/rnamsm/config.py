@@ -25,7 +25,7 @@ class DataConfig:                       # RNA_MSM_Inference.py:20-32
     max_tokens: int = 16384
     max_seqs_per_msa: int = 512
     sample_method: str = "hhfilter"
-    # extra (not in the reference): the small alignments (<= 8192 tokens each) of the id list share launch sets
+    # extra (not in the reference): the small alignments (<= 16384 tokens each; 8192 in bf16) of the id list share launch sets
     # (MSATransformer.forward_ragged).  On by default since round 3: a lone forward of a few hundred tokens costs 2.5 ms on a mostly
     # idle chip; data.batch_small_msas=false restores the strictly one-by-one loop of the reference (RNA_MSM_Inference.py:141-148)
     batch_small_msas: bool = True

@@ -19,6 +19,8 @@ state = synthetic.make_state_dict(seed=0)
 model = MSATransformer(num_layers=10)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
 MODE = os.environ.get("MODE", "f32")                      # MODE=bf16 | f16x3: the CLI in a 16-bit arithmetic mode (model.gemm_dtype=...)
+if os.environ.get("PACKED_SMALL"):                       # A/B of the size up to which an alignment waits for company (exact mode)
+    inference.PACKED_SMALL_TOKENS = int(os.environ["PACKED_SMALL"])
 if os.environ.get("PACKED_SMALL_16"):
     inference.PACKED_SMALL_TOKENS_16BIT = {k: int(os.environ["PACKED_SMALL_16"]) for k in inference.PACKED_SMALL_TOKENS_16BIT}
 rng = np.random.RandomState(0)
