@@ -441,9 +441,9 @@ def test_token_packed_groups_are_cut_in_list_order_and_balanced():
     what it really holds -- tokens, members, map elements -- and shapes need not match; groups are consecutive runs of the list,
     as few as the bounds allow, holding about the same number of tokens."""
     from rnamsm.inference import FRAME_MAP_ELEMS, PACKED_MEMBERS, PACKED_TOKENS, joins_packed, plan_packed_groups
-    assert (PACKED_TOKENS, PACKED_MEMBERS) == (65536, 256)
+    assert (PACKED_TOKENS, PACKED_MEMBERS) == (131072, 256)
     assert joins_packed([], (3, 20)) and joins_packed([(2, 10), (2, 10)], (30, 50))         # unlike shapes share a group: nothing is padded
-    assert joins_packed([(30, 50)] * 42, (30, 50)) and not joins_packed([(30, 50)] * 43, (30, 50))      # 44 x 1500 > 65536 tokens
+    assert joins_packed([(30, 50)] * 86, (30, 50)) and not joins_packed([(30, 50)] * 87, (30, 50))      # 88 x 1500 > 131072 tokens
     assert joins_packed([(2, 8)] * 255, (2, 8)) and not joins_packed([(2, 8)] * 256, (2, 8))            # members
     assert joins_packed([(3, 256)] * 15, (3, 256)) and not joins_packed([(3, 256)] * 16, (3, 256))      # sum of C^2
     rng = np.random.RandomState(7)
