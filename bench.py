@@ -63,6 +63,9 @@ def parse_args(argv=None):
                     help="report an order-independent bit digest of every gathered output (N=1 and N=2 must agree)")
     ap.add_argument("--backend", default=os.environ.get("RNAMSM_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="test hook: gloo stages the gather through host memory (RCCL refuses two ranks on one device)")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="file for the COMPLETE result (per-kernel bounds, per-config block, 16-bit modes ...); stdout carries only the "
+                         "compact <= 4 KB line.  Empty string: no file")
     ap.add_argument("--one-device", action="store_true", default=os.environ.get("RNAMSM_BENCH_ONE_DEVICE") == "1",
                     help="test hook: every rank on device 0 (exercises the N > 1 flow on a one-GPU box)")
     args = ap.parse_args(argv)
@@ -323,6 +326,84 @@ def make_digest(result):
         d["distinct_devices"] = cfg["distinct_devices"]
     d["gather"] = str(cfg.get("gather", ""))[:60]
     return d
+
+
+COMPACT_LIMIT = 4096               # bytes of the LAST stdout line (the one the driver parses)
+
+
+def _short(v, n):
+    s = str(v)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_line(result):
+    """The line the driver parses: every key of the bench contract, `roofline` and `cpu_baseline` with their evidence fields, the
+    digest of all BASELINE configs -- and nothing else.  At most COMPACT_LIMIT bytes whatever the run measured (free-text fields are
+    clipped; should the line still be too long the optional blocks go first, the contract's keys never).  The complete result -- per-kernel
+    bounds, per-config block, 16-bit modes, thread sweep -- goes to the detail file (`--detail-out`), named in `detail`."""
+    def num(v, n=6):
+        return v if not isinstance(v, float) else float(f"{v:.{n}g}")
+
+    def pick(d, keys, clip=160):
+        out = {}
+        for k in keys:
+            if d is not None and k in d:
+                v = d[k]
+                out[k] = _short(v, clip) if isinstance(v, str) else num(v)
+        return out
+    cfg = result.get("config", {})
+    line = {k: num(result[k], 9) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                           "scaling", "vs_baseline", "dtype", "data") if k in result}
+    line["config"] = dict(pick(cfg, ("workload",), 260), **pick(cfg, ("gather",), 200),
+                          **pick(cfg, ("num_seqs", "seq_len", "msas_per_step", "world_size_initialised", "distinct_devices", "backend",
+                                       "rccl_version", "devices")))
+    roof = result.get("roofline") or {}
+    line["roofline"] = pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "flops_per_launch",
+                                   "traffic", "algorithmic_bytes_per_launch", "traffic_source", "traffic_replayed", "traffic_unit"), 120)
+    if result.get("attention_mfma"):
+        line["attention_mfma"] = pick(result["attention_mfma"], ("kernels", "achieved", "peak", "frac"), 60)
+    for k in ("compute_only_value", "compute_only_ms_per_step", "outputs_finite", "err_word", "model_tflops"):
+        if result.get(k) is not None:
+            line[k] = num(result[k])
+    if result.get("cpu_baseline"):
+        line["cpu_baseline"] = pick(result["cpu_baseline"], ("value", "unit", "cores", "kind", "cpu_model", "physical_cores",
+                                                             "full_forward_s", "sample"), 240)
+    if result.get("torch_rocm_eager"):
+        line["torch_rocm_eager"] = pick(result["torch_rocm_eager"], ("value", "unit", "seconds_timed", "error"), 120)
+    if result.get("output_digest"):
+        line["output_digest"] = pick(result["output_digest"], ("value", "items"))
+    gs = result.get("gather_stats")
+    if gs:
+        line["gather_stats"] = {k: ([num(x, 4) for x in v] if isinstance(v, list) else num(v, 4)) for k, v in gs.items()
+                                if k in ("per_rank_bytes_received", "per_rank_host_wait_s", "per_rank_stream_wait_ms", "bytes_received")}
+    if result.get("detail"):
+        line["detail"] = result["detail"]
+    line["digest"] = result.get("digest")
+    for drop in ("gather_stats", "attention_mfma", "torch_rocm_eager", "model_tflops", "detail"):      # never needed in practice
+        if len(json.dumps(line)) <= COMPACT_LIMIT:
+            break
+        line.pop(drop, None)
+    if len(json.dumps(line)) > COMPACT_LIMIT:
+        line["digest"] = {k: v for k, v in (line.get("digest") or {}).items() if k in ("value_k", "ms", "n_gpus", "dtype", "gemm_frac_of_peak")}
+        line["config"]["workload"] = _short(line["config"].get("workload", ""), 80)
+        line["config"]["gather"] = _short(line["config"].get("gather", ""), 60)
+    return line
+
+
+def emit(result, detail_out):
+    """Write the complete result to `detail_out` (one JSON document) and print the compact line as the ONLY stdout line."""
+    if detail_out:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_out)), exist_ok=True)
+            with open(detail_out, "w") as f:
+                json.dump(result, f)
+                f.write("\n")
+            result["detail"] = os.path.relpath(detail_out, ROOT) if os.path.abspath(detail_out).startswith(ROOT) else detail_out
+        except OSError as e:                                          # the detail file must not cost the line
+            result["detail"] = f"not written ({type(e).__name__})"
+    text = json.dumps(compact_line(result))
+    assert len(text) <= COMPACT_LIMIT, len(text)
+    print(text, flush=True)
 
 
 def rccl_version():
@@ -827,6 +908,7 @@ def run_rank(args) -> int:
             "model_tflops": flops_per_msa(M, L) * msas_timed / elapsed / 1e12,
             "roofline": (dict(mode_roofline(timings, args.gemm_dtype, mult, roof_local), traffic=traffic,
                               traffic_unit="bytes/launch of the GEMM kernels (HBM-side, PMC)", traffic_source=traffic_src,
+                              traffic_replayed=traffic is not None,
                               algorithmic_bytes_per_launch=g["bytes"] / max(1, g["launches"]))
                          if args.gemm_dtype != "f32" else None) or {"bound": "mfma", "kernel": gemm_kernel,
                          "achieved": gemm_tflops, "peak": peak, "unit": flop_unit,
@@ -835,6 +917,9 @@ def run_rank(args) -> int:
                          "flops_per_launch": g["flops"] / max(1, g["launches"]),
                          "traffic": traffic, "traffic_unit": "bytes/launch (HBM-side, PMC)",
                          "traffic_source": traffic_src,
+                         # counters cannot be collected inside a timed run: the figure is the committed PMC passes' (same workload,
+                         # same kernels, tools/prof_r06.sh), REPLAYED here -- not a measurement of this run
+                         "traffic_replayed": traffic is not None,
                          "algorithmic_bytes_per_launch": g["bytes"] / max(1, g["launches"]),
                          "measured_in": f"separate pass after the headline loop, HIP-event pairs on the launch stream, "
                                         f"{roof_local} MSA(s) on rank 0 in {roof_elapsed:.3f} s",
@@ -865,8 +950,8 @@ def run_rank(args) -> int:
         if not args.no_cpu_baseline and world == 1:
             result["torch_rocm_eager"] = torch_rocm_eager(M, L, state, dev)
             result["cpu_baseline"] = cpu_baseline(M, L, state)
-        result["digest"] = make_digest(result)                 # LAST key: the tail of the line carries the evidence
-        print(json.dumps(result), flush=True)
+        result["digest"] = make_digest(result)
+        emit(result, args.detail_out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

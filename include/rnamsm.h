@@ -324,7 +324,9 @@ int rnamsm_pad_mask(const int64_t* tokens, uint8_t* mask, int64_t n, int pad_idx
 /* K10 -- extract_feat's output section (RNA_MSM_Inference.py:151-166):
  *   emb[c-1, :]            = x_final[row 0, c, :]                c = 1..C-1      -> [C-1, D]
  *   atp[l*H+h, i-1, j-1]   = probs_all[l, h, i, j]               i,j = 1..C-1    -> [NL*H, C-1, C-1]
- * x_final [R*C, D] is the output of emb_layer_norm_after; probs_all [NL, H, C, C]. */
+ * x_final [R*C, D] is the output of emb_layer_norm_after; probs_all [NL, H, C, C].
+ * The embedding rows move as 16-byte vectors: D % 4 == 0, x_final and emb 16-byte aligned (refused with RNAMSM_ERR_INVALID
+ * otherwise); probs_all / atp have no alignment requirement. */
 int rnamsm_pack_outputs(const float* x_final, const float* probs_all, float* emb, float* atp,
                         int C, int D, int num_layers, int H, void* stream);
 

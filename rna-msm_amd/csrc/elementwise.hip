@@ -560,5 +560,8 @@ extern "C" int rnamsm_pack_outputs(const float* x_final, const float* probs_all,
                                    int num_layers, int H, void* stream) {
     RNAMSM_CHECK_ARG(x_final && probs_all && emb && atp, "pack_outputs: null pointer");
     RNAMSM_CHECK_ARG(C >= 2 && D > 0 && num_layers > 0 && H > 0, "pack_outputs: bad shape C=%d D=%d", C, D);
+    // the embedding rows are copied as 16-byte vectors (x_final + D is the first copied row): D % 4 and both pointers 16-byte aligned
+    RNAMSM_CHECK_ARG(D % 4 == 0, "pack_outputs: D=%d must be a multiple of 4", D);
+    RNAMSM_CHECK_ARG(aligned16(x_final) && aligned16(emb), "pack_outputs: x_final and emb must be 16-byte aligned");
     return pack_outputs_batched(x_final, probs_all, emb, atp, C, D, num_layers, H, 1, 0, 0, nullptr, static_cast<hipStream_t>(stream));
 }

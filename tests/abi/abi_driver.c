@@ -128,6 +128,9 @@ int main(void) {
     REFUSED(rnamsm_head_mean(NULL, buf, 12, 16, NULL));
     REFUSED(rnamsm_head_mean(buf, buf, 0, 16, NULL));
     REFUSED(rnamsm_pack_outputs(NULL, buf, buf, buf, 4, 768, 10, 12, NULL));
+    REFUSED(rnamsm_pack_outputs(buf, buf, buf, buf, 4, 6, 10, 12, NULL));                   /* D % 4 != 0: vector copy of the embedding rows */
+    REFUSED(rnamsm_pack_outputs(buf + 1, buf, buf, buf, 4, 768, 10, 12, NULL));             /* x_final not 16-byte aligned */
+    REFUSED(rnamsm_pack_outputs(buf, buf, buf + 1, buf, 4, 768, 10, 12, NULL));             /* emb not 16-byte aligned */
     REFUSED(rnamsm_contact_head(NULL, buf, buf, buf, buf, 1 << 16, 4, 120, NULL));
     REFUSED(rnamsm_contact_head(buf, buf, buf, buf, buf, 0, 400, 120, NULL));
     REFUSED(rnamsm_greedy_select(NULL, 8, 8, 4, 0, ints, buf, 1 << 16, NULL));

@@ -17,19 +17,59 @@ COMMON = ["--workload", "configs3", "--num-msas", "6", "--num-seqs", "16", "--se
           "--warmup", "1", "--digest", "--no-cpu-baseline", "--no-fast-mode"]
 
 
+COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "digest")
+
+
+def _parse(stdout, detail_path):
+    """bench.py's stdout is ONE JSON line, the last one, <= 4096 bytes, carrying the bench contract's keys (what the driver parses:
+    VERDICT r05 item 1); the complete result is the detail file.  Returns the detail with the compact line under "_compact"."""
+    out_lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    lines = [ln for ln in out_lines if ln.startswith("{")]
+    assert len(lines) == 1 and out_lines[-1] == lines[0], stdout          # ONE JSON line, from rank 0, and it is the LAST line
+    assert len(lines[0].encode()) <= 4096, len(lines[0])
+    compact = json.loads(lines[0])
+    assert all(k in compact for k in COMPACT_KEYS), sorted(compact)
+    assert all(k in compact["roofline"] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")), compact["roofline"]
+    assert all(k in compact["config"] for k in ("workload", "gather", "world_size_initialised", "distinct_devices"))
+    assert list(compact)[-1] == "digest"
+    detail = json.load(open(detail_path))
+    for k in ("metric", "n_gpus", "steps", "warmup", "scaling", "dtype"):
+        assert compact[k] == detail[k]
+    assert abs(compact["value"] - detail["value"]) <= 1e-6 * detail["value"]
+    detail["_compact"] = compact
+    return detail
+
+
 def _bench(extra, env=None, expect_rc=0):
+    import tempfile
     e = dict(os.environ)
     e.pop("WORLD_SIZE", None)
     e.pop("RANK", None)
     e.update(env or {})
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True,
-                       timeout=900, env=e, cwd=ROOT)
-    assert (p.returncode == 0) == (expect_rc == 0), (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
-    if expect_rc != 0:
-        return None
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout                     # ONE JSON line, from rank 0
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory(prefix="rnamsm_bench_test_") as tmp:
+        detail = os.path.join(tmp, "detail.json")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--detail-out", detail] + extra, capture_output=True,
+                           text=True, timeout=900, env=e, cwd=ROOT)
+        assert (p.returncode == 0) == (expect_rc == 0), (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+        if expect_rc != 0:
+            return None
+        return _parse(p.stdout, detail)
+
+
+def test_the_default_flow_with_both_baselines_prints_one_compact_last_line():
+    """The driver's command shape (`bench.py --gpus 1 --steps K --warmup W`, every optional block ON: per-config block, 16-bit modes,
+    cpu_baseline, torch_rocm_eager) at a small alignment shape: stdout's LAST line is the one compact JSON line (<= 4096 bytes,
+    _parse checks the keys) and it carries `roofline` and `cpu_baseline`; the detail file holds the blocks the line leaves out."""
+    res = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--num-seqs", "64", "--seq-len", "128"])
+    c = res["_compact"]
+    assert c["steps"] == 2 and c["warmup"] == 1 and c["n_gpus"] == 1 and c["dtype"] == "f32" and c["vs_baseline"] is None
+    assert c["roofline"]["bound"] == "mfma" and 0 < c["roofline"]["frac"] < 1 and c["roofline"]["launches"] > 0
+    assert c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] >= 1
+    assert c["torch_rocm_eager"]["value"] > 0 and c["digest"]["cpu_res_per_s"] > 0
+    assert abs(c["ms_per_step"] * c["steps"] * 1e-3 * c["value"] - 64 * 128 * 2) < 1e-3 * 64 * 128 * 2
+    for k in ("per_config", "per_kernel", "fast_mode", "bf16_mode", "kernel_ms_per_msa"):
+        assert k in res and k not in c, k
 
 
 def test_two_ranks_gather_the_same_outputs_as_one_rank():
@@ -67,7 +107,8 @@ def test_eight_ranks_on_one_device_gather_the_same_outputs_as_one_rank():
     assert len(eight["config"]["ranks_seen"]) == 8 and eight["config"]["distinct_devices"] == 1
     assert all(f"rank {r}:" in s for r, s in enumerate(eight["config"]["ranks_seen"]))
     assert one["config"]["distinct_devices"] == 1 and len(one["config"]["ranks_seen"]) == 1 and "uuid" in one["config"]["ranks_seen"][0]
-    assert list(eight)[-1] == "digest" and eight["digest"]["distinct_devices"] == 1 and len(json.dumps(eight["digest"])) <= 1200
+    assert eight["digest"]["distinct_devices"] == 1 and len(json.dumps(eight["digest"])) <= 1200
+    assert eight["_compact"]["config"]["distinct_devices"] == 1 and eight["_compact"]["output_digest"]["value"] == one["output_digest"]["value"]
     gs = eight["gather_stats"]
     assert len(gs["per_rank_bytes_received"]) == 8 and gs["per_rank_bytes_received"][0] > 0 and sum(gs["per_rank_bytes_received"][1:]) == 0
     assert eight["compute_only_value"] > 0
@@ -94,7 +135,7 @@ def test_a_dying_rank_fails_the_run_instead_of_hanging():
     _bench(["--gpus", "2", "--backend", "gloo", "--one-device"] + COMMON, env={"RNAMSM_BENCH_FAIL_RANK": "1"}, expect_rc=1)
 
 
-def test_the_drivers_torchrun_launch_takes_the_same_path():
+def test_the_drivers_torchrun_launch_takes_the_same_path(tmp_path):
     """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N ...`: bench.py then finds RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment
     and must NOT launch ranks of its own.  Same workload, same digest as the self-launched run; one JSON line from rank 0."""
@@ -106,12 +147,11 @@ def test_the_drivers_torchrun_launch_takes_the_same_path():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         e.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device"] + COMMON
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device",
+           "--detail-out", str(tmp_path / "detail.json")] + COMMON
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=e, cwd=ROOT)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout
-    two = json.loads(lines[0])
+    two = _parse(p.stdout, str(tmp_path / "detail.json"))
     one = _bench(["--gpus", "1"] + COMMON)
     assert two["n_gpus"] == 2 and two["config"]["world_size_initialised"] == 2
     assert two["output_digest"]["value"] == one["output_digest"]["value"]

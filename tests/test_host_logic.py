@@ -338,6 +338,50 @@ def test_bench_launcher_fails_loudly_without_a_gpu():
     assert "no CPU path" in p.stderr and not any(ln.startswith("{") for ln in p.stdout.splitlines())
 
 
+def test_bench_compact_line_fits_the_drivers_parser_whatever_the_run_measured():
+    """BENCH_r05.json came back `parsed: null` because bench.py's single line had grown to 20 KB.  The line
+    the driver parses is now bench.compact_line(result): <= 4096 bytes, a JSON round trip, every key of the bench contract plus
+    `roofline` / `cpu_baseline` with their evidence fields and the digest LAST.  Canned input: a complete round-5 result (20 KB,
+    tests/golden/bench_detail_canned.json) and a worst case built from it (8 ranks, long free-text fields, per-rank lists)."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    canned = json.loads(open(os.path.join(ROOT, "tests", "golden", "bench_detail_canned.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(canned)) > 15000                              # the input really is the oversized one
+    worst = json.loads(json.dumps(canned))
+    worst["n_gpus"] = 8
+    worst["config"]["gather"] = "failed: " + "RuntimeError: NCCL error in: some/very/long/path.cpp:1234, unhandled system error " * 20
+    worst["config"]["workload"] += " " + "x" * 2000
+    worst["config"]["ranks_seen"] = [f"rank {r}: cuda:{r} AMD Instinct MI355X uuid {'ab' * 16} pci 0:{r}:0 (8 visible)" for r in range(8)]
+    worst["config"]["distinct_devices"] = 8
+    worst["gather_stats"] = {"per_rank_bytes_received": [14.3e9] + [0] * 7, "per_rank_host_wait_s": [0.123456789] * 8,
+                             "per_rank_stream_wait_ms": [12.3456789] * 8, "free_text": "y" * 5000}
+    worst["compute_only_value"], worst["compute_only_ms_per_step"] = 5.1e6, 25.7
+    worst["output_digest"] = {"value": 2 ** 63 + 12345, "items": 512, "what": "z" * 500}
+    worst["cpu_baseline"]["sample"] = "s" * 3000
+    for res in (canned, worst):
+        line = bench.compact_line(res)
+        text = json.dumps(line)
+        assert len(text.encode()) <= bench.COMPACT_LIMIT == 4096, len(text)
+        back = json.loads(text)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline", "digest"):
+            assert k in back, k
+        assert list(back)[-1] == "digest" and back["digest"]["value_k"] == canned["digest"]["value_k"]
+        for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "flops_per_launch", "traffic",
+                  "algorithmic_bytes_per_launch", "traffic_source"):
+            assert k in back["roofline"], k
+        for k in ("value", "unit", "cores", "kind", "sample", "cpu_model", "full_forward_s"):
+            assert k in back["cpu_baseline"], k
+        for k in ("workload", "gather", "world_size_initialised", "distinct_devices"):
+            assert k in back["config"], k
+        assert back["torch_rocm_eager"]["value"] > 0
+        assert abs(back["value"] - res["value"]) <= 1e-8 * res["value"] and back["n_gpus"] == res["n_gpus"]
+        assert abs(back["roofline"]["frac"] - res["roofline"]["frac"]) < 1e-5
+    assert back["config"]["distinct_devices"] == 8 and len(back["gather_stats"]["per_rank_bytes_received"]) == 8
+    assert back["output_digest"]["value"] == 2 ** 63 + 12345 and back["compute_only_value"] == 5.1e6
+
+
 def test_reader_agrees_with_the_oracle_on_random_alignments():
     """Differential test of the product's reader/tokenizer (byte LUT, own FASTA parser) against the oracle's restatement
     (regex clean-up + digitize, the reference's method) on random a2m text: every character class (upper-case residues,
