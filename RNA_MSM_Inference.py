@@ -33,7 +33,9 @@ def main(argv=None):
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # default group gloo (rank / world bookkeeping, agreement); RCCL carries only the gathered output arrays, on a group of
+        # its own that extract_feat creates when RNAMSM_GATHER_TO_RANK0=1 -- with a host-staged gloo gather as the second transport
+        dist.init_process_group("gloo")
     try:
         extract_feat(cfg, gather_to_rank0=gather)
     finally:

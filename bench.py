@@ -5,7 +5,10 @@
 
 With N > 1 and no launcher environment this process (which makes no GPU call) starts the N ranks itself, one per
 GPU, and exits with their status; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`
-it runs as one rank.  Ranks talk over RCCL (backend "nccl"); rank 0 prints ONE JSON line.
+it runs as one rank.  The control plane (barriers, agreement, timing reductions) is a gloo group; RCCL (backend "nccl") carries
+the gathered output arrays only, with a host-staged gloo gather as the second transport if RCCL refuses
+(rnamsm.sharding.negotiate_gather_transport).  Rank 0 prints ONE compact JSON line (<= 4 KB: the bench contract's keys,
+`roofline`, `cpu_baseline`, the digest) and writes the complete result to --detail-out.
 
 Workloads (BASELINE.json `configs`):
   configs2 (default, the metric's config): one synthetic MSA of M=256 x L=512 per GPU per step -- weak scaling.
@@ -134,15 +137,26 @@ def launch_ranks(args) -> int:
         notes = os.path.join(tmp, "failures.txt")                       # ranks append what went wrong (exception texts)
         rc = _run_ranks(args, [], {"RNAMSM_BENCH_FAILURE_FILE": notes}, deadline)
         if rc != 0 and not args.no_gather and os.environ.get("RNAMSM_BENCH_FAIL_RANK") is None:
-            why = ""
-            try:
-                why = " | ".join(dict.fromkeys(l.strip() for l in open(notes) if l.strip()))[:600]
-            except OSError:
-                pass
-            print(f"bench.py: the {args.gpus}-rank run with the output gather ended with status {rc} ({why or 'no exception text'}); "
-                  f"measuring the sharded compute without the gather", file=sys.stderr, flush=True)
-            note = f"the run with the gather ended with status {rc}" + (f": {why}" if why else "")
-            rc = _run_ranks(args, ["--no-gather"], {"RNAMSM_BENCH_GATHER_NOTE": note, "RNAMSM_BENCH_FAILURE_FILE": notes}, deadline)
+            def why_text():
+                try:
+                    return " | ".join(dict.fromkeys(l.strip() for l in open(notes) if l.strip()))[:600]
+                except OSError:
+                    return ""
+            why = why_text()
+            # second transport first: fresh ranks on backend gloo -- the same sharded compute on the same GPUs,
+            # every output still gathered to rank 0, staged through host memory -- and only then the compute alone
+            if args.backend != "gloo":
+                print(f"bench.py: the {args.gpus}-rank run on backend {args.backend} ended with status {rc} ({why or 'no exception text'}); "
+                      f"running it again with the gather on gloo (host-staged)", file=sys.stderr, flush=True)
+                note = f"gloo fallback after: the run on backend {args.backend} ended with status {rc}" + (f": {why}" if why else "")
+                rc = _run_ranks(args, ["--backend", "gloo"], {"RNAMSM_BENCH_GATHER_NOTE": note, "RNAMSM_BENCH_FAILURE_FILE": notes}, deadline)
+            if rc != 0:
+                why = why_text()
+                print(f"bench.py: the {args.gpus}-rank run with the output gather ended with status {rc} ({why or 'no exception text'}); "
+                      f"measuring the sharded compute without the gather", file=sys.stderr, flush=True)
+                note = f"the run with the gather ended with status {rc}" + (f": {why}" if why else "")
+                rc = _run_ranks(args, ["--no-gather", "--backend", "gloo"],
+                                {"RNAMSM_BENCH_GATHER_NOTE": note, "RNAMSM_BENCH_FAILURE_FILE": notes}, deadline)
     return rc
 
 
@@ -496,10 +510,10 @@ def run_rank(args) -> int:
         # a collective that does not complete within this ends the rank (RCCL watchdog) instead of parking it until the
         # launcher's 25-minute deadline; the launcher then measures the compute-only curve
         pg_timeout = datetime.timedelta(seconds=float(os.environ.get("RNAMSM_BENCH_PG_TIMEOUT_S", "300")))
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=pg_timeout)
+        # the default group is ALWAYS gloo: control plane (barriers, agreement, timing reductions) and the gather's second transport;
+        # RCCL ("nccl") carries only the gathered output arrays, on a group of its own created in negotiate_gather_transport --
+        # so an RCCL that cannot come up costs the device-to-device gather, never the run
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
 
     def note_failure(text):
         path = os.environ.get("RNAMSM_BENCH_FAILURE_FILE")
@@ -551,25 +565,29 @@ def run_rank(args) -> int:
         dist.all_gather_object(idents, ident)
     gather = world > 1 and not args.no_gather
     gather_failure = None
+    gather_group = None                                              # None = the default group (RCCL point-to-point under "nccl")
+    gather_transport = args.backend
     if gather:
-        # Probe the gather once, outside the timed region (this also builds the point-to-point communicators): if the
-        # fabric refuses it the bench still measures the sharded compute and says so, instead of dying in the timed loop.
-        ok = torch.ones(1, device=dev if args.backend == "nccl" else "cpu")
-        try:
-            if os.environ.get("RNAMSM_BENCH_FAIL_GATHER_PROBE") in (str(rank), "all"):     # test hook
-                raise RuntimeError(f"injected gather-probe failure on rank {rank} (RNAMSM_BENCH_FAIL_GATHER_PROBE)")
-            probe = sharding.RoundGatherer(world, tensors_per_item=2, dst=0, device=dev)
-            probe.submit(rank, (torch.full((3, 5), float(rank), device=dev), torch.zeros(2, 4, 4, device=dev)))
-            probe.finish()
-            torch.cuda.synchronize()
-        except Exception as e:                                        # noqa: BLE001
-            ok.zero_()
-            gather_failure = f"{type(e).__name__}: {e}"
-            note_failure(f"rank {rank} gather probe: {gather_failure}")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if float(ok.item()) == 0.0:
+        # Probe the gather once, outside the timed region (this also builds the point-to-point communicators).  A fabric that refuses
+        # it does not cost the gathered outputs: the ranks agree over a gloo control group and move the gather onto that group
+        # (host-staged), in the same processes; only if that fails too the line is the sharded compute alone and says so.
+        inject = (f"injected gather-probe failure on rank {rank} (RNAMSM_BENCH_FAIL_GATHER_PROBE)"
+                  if os.environ.get("RNAMSM_BENCH_FAIL_GATHER_PROBE") in (str(rank), "all") else None)     # test hook
+        if os.environ.get("RNAMSM_BENCH_FAIL_GATHER_PROBE") == "both":                                   # ... and no fallback either
+            inject = f"injected gather-probe failure on rank {rank} (RNAMSM_BENCH_FAIL_GATHER_PROBE=both)"
+        group, label, mine = sharding.negotiate_gather_transport(dev, want_backend=args.backend, inject_failure=inject,
+                                                                 timeout=pg_timeout)
+        if mine:
+            note_failure(f"rank {rank} gather probe: {mine}")
+        if group is not False and label != "primary" and os.environ.get("RNAMSM_BENCH_FAIL_GATHER_PROBE") == "both":
+            group, label = False, "failed: " + label
+        if group is False:
             gather = False
-            gather_failure = gather_failure or "a peer failed in the probe"
+            gather_failure = label[len("failed: "):] if label.startswith("failed: ") else label
+        else:
+            gather_group = group
+            if label != "primary":
+                gather_transport, gather_failure = "gloo", label
     digest = torch.zeros((), dtype=torch.int64, device=dev)
     delivered = [0]
     last_gather = [None]
@@ -589,7 +607,7 @@ def run_rank(args) -> int:
         n_items = sum(len(it) for it in per)
         g = None
         if (gather and use_gather) or (args.digest and world == 1):
-            g = sharding.RoundGatherer(n_items, on_item=on_item, tensors_per_item=2, dst=0, device=dev)
+            g = sharding.RoundGatherer(n_items, on_item=on_item, tensors_per_item=2, dst=0, device=dev, group=gather_group)
         base = 0
         for items in per:
             for pos, msa in items:
@@ -613,9 +631,7 @@ def run_rank(args) -> int:
     def max_over_ranks(seconds):
         if world == 1:
             return seconds
-        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
-        if args.backend != "nccl":
-            t = t.cpu()
+        t = torch.tensor([seconds], dtype=torch.float64)                 # the control group is gloo
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -865,9 +881,12 @@ def run_rank(args) -> int:
             if os.environ.get("RNAMSM_BENCH_GATHER_NOTE"):
                 gather_note = f"disabled: {os.environ['RNAMSM_BENCH_GATHER_NOTE']}; sharded compute only"
         else:
-            gather_note = (f"rnamsm.sharding.RoundGatherer: emb+atp of every MSA to rank 0 over "
-                           f"{'RCCL point-to-point' if args.backend == 'nccl' else args.backend + ' (host-staged)'}, "
+            gather_note = ((f"{gather_failure} -- " if gather_failure else "")
+                           + f"rnamsm.sharding.RoundGatherer: emb+atp of every MSA to rank 0 over "
+                           f"{'RCCL point-to-point' if gather_transport == 'nccl' else gather_transport + ' (host-staged)'}, "
                            f"round k overlapping the forward of round k+1; {headline_delivered} MSAs delivered in the timed region")
+            if os.environ.get("RNAMSM_BENCH_GATHER_NOTE"):
+                gather_note = f"{os.environ['RNAMSM_BENCH_GATHER_NOTE']} -- " + gather_note
         base_cfg = "configs[3]" if batch else "configs[2]"
         if batch and (M, L) != (128, 256):
             base_cfg = "configs[3] at another MSA shape"
@@ -898,7 +917,7 @@ def run_rank(args) -> int:
                                                 if (i.get("uuid") or i.get("pci_bus_id")) else ("index", i["device_index"])
                                                 for i in idents}),
                        "rccl_version": rccl_version() if world > 1 and args.backend == "nccl" else None,
-                       "backend": ("nccl (RCCL)" if args.backend == "nccl" else args.backend) if world > 1 else "none",
+                       "backend": ("nccl (RCCL) for the gather, gloo control group" if args.backend == "nccl" else args.backend) if world > 1 else "none",
                        "devices": "all ranks on device 0 (test hook)" if args.one_device and world > 1 else "one per rank",
                        "warmup_note": (f"a warm-up step is a pass over the first {warm_items} MSAs of the batch" if batch else "full steps")},
             "compute_only_value": (residues / compute_only) if compute_only else None,

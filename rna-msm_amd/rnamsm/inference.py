@@ -349,8 +349,19 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
 
     # gather_to_rank0: outputs travel to rank 0 one ROUND (one MSA per rank) at a time, round k's RCCL transfers
     # overlapping round k+1's forward, and are handed to the writer as they arrive -- at most one round is resident
+    # Transport: RCCL point-to-point where it comes up; otherwise the ranks agree (over the default gloo group) to stage the same
+    # gather through host memory -- the outputs arrive on rank 0 either way (sharding.negotiate_gather_transport).  A default group
+    # that is not gloo (a caller's own nccl world) is used as it is, as before.
+    gather_group = None
+    if gathering and dist.get_backend() == "gloo":
+        gather_group, label, _ = sharding.negotiate_gather_transport(device, want_backend=os.environ.get("RNAMSM_GATHER_BACKEND", "nccl"))
+        if gather_group is False:
+            raise RuntimeError(f"gather_to_rank0: no transport to rank 0 ({label}); run without RNAMSM_GATHER_TO_RANK0 "
+                               f"(every rank then writes its own files)")
+        if label != "primary" and rank == 0:
+            print(f"gather to rank 0: {label}")
     gatherer = sharding.RoundGatherer(len(ids), on_item=lambda i, ts: emit(ids[i], ts[0], ts[1]), tensors_per_item=2,
-                                      dst=0, device=device) if gathering else None
+                                      dst=0, device=device, group=gather_group) if gathering else None
     try:
         with torch.no_grad():
             pending = reader.submit(read, mine[0]) if reader and len(mine) else None

@@ -46,6 +46,70 @@ def default_wire_device(group: Optional[dist.ProcessGroup] = None) -> torch.devi
     return torch.device("cpu")
 
 
+def negotiate_gather_transport(device: torch.device, want_backend: str = "nccl", inject_failure: Optional[str] = None,
+                               timeout=None):
+    """Decide ONCE, before any output travels, which transport the gather uses -- so that a fabric (or an RCCL build) that refuses
+    point-to-point traffic costs the overlap with compute, not the gathered outputs.  Collective: every
+    rank calls it.  The DEFAULT process group must be `gloo`: it is the control plane (agreement, barriers, timing reductions
+    never depend on the transport under test) and the second transport.
+
+    1. want_backend "nccl": an RCCL group is created in the same processes (`dist.new_group(backend="nccl")`, no restart, nothing
+       re-exec'ed) and the gather is probed on it (this also builds the point-to-point communicators); "gloo": the probe runs
+       on the default group;
+    2. the ranks agree on the outcome over the default gloo group;
+    3. if any rank failed, the probe is repeated on the default gloo group (payloads staged through host memory), agreed again.
+
+    Returns (group, label, failure): group = the RCCL group | None (the default gloo group) | False (no transport: compute only);
+    label = "primary" | "gloo fallback after: <first failure text>" | "failed: <text>"; failure = this rank's exception text or None.
+    `inject_failure` (test hook) makes the primary probe raise on this rank."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if dist.get_backend() != "gloo":
+        raise RuntimeError("negotiate_gather_transport: the default process group must be gloo (control plane + second transport)")
+
+    def attempt(step) -> Optional[str]:
+        try:
+            step()
+            return None
+        except Exception as e:                                        # noqa: BLE001 -- whatever the backend raises is the answer
+            return f"{type(e).__name__}: {e}"
+
+    def agree(mine: Optional[str]):
+        texts = [None] * world
+        dist.all_gather_object(texts, mine)
+        bad = [f"rank {r}: {str(t)[:300]}" for r, t in enumerate(texts) if t]
+        return bad[0] if bad else None
+
+    def gather_once(group):
+        g = RoundGatherer(world, tensors_per_item=2, dst=0, group=group, device=device)
+        g.submit(rank, (torch.full((3, 5), float(rank), device=device), torch.zeros(2, 4, 4, device=device)))
+        g.finish()
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+
+    # Two agreements per transport: (a) the group exists on every rank -- a rank that cannot even create it must say so BEFORE
+    # anybody blocks in a receive from it; (b) the point-to-point gather itself ran (a failure that shows only here is symmetric
+    # in practice; an asymmetric one costs the peers the group's timeout, then they land in the same fallback).
+    primary = [None]
+
+    def create():
+        if want_backend == "nccl":
+            primary[0] = dist.new_group(backend="nccl", timeout=timeout) if timeout is not None else dist.new_group(backend="nccl")
+        if inject_failure:
+            raise RuntimeError(inject_failure)
+
+    mine = attempt(create)
+    first = agree(mine)
+    if first is None:
+        mine = attempt(lambda: gather_once(primary[0]))
+        first = agree(mine)
+        if first is None:
+            return primary[0], "primary", None
+    second = agree(attempt(lambda: gather_once(None)))
+    if second is None:
+        return None, f"gloo fallback after: {first}", mine
+    return False, f"failed: {first}; gloo fallback: {second}", mine
+
+
 class RoundGatherer:
     """Streams per-item tensor tuples to `dst`, one round of `world` items at a time.
 

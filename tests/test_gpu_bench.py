@@ -120,11 +120,40 @@ def test_default_workload_runs_weak_scaling_through_the_same_gatherer():
     assert two["scaling"] == "weak" and two["config"]["msas_per_step"] == 2 and two["output_digest"]["items"] == 4
 
 
-def test_a_failing_gather_probe_leaves_a_compute_only_line_and_exit_code_zero():
-    """a fabric that refuses the point-to-point gather must not cost the scaling number.  The probe before the
-    timed region is made to fail on every rank (test hook; a refusal at communicator creation looks like this): the ranks agree to drop the gather, the run measures the sharded
-    compute, prints ONE line whose `config.gather` starts with "failed: <text>" and exits 0 -- without restarting any rank."""
+def test_a_failing_gather_probe_moves_the_gather_to_gloo_and_still_delivers_every_output():
+    """a fabric that refuses the point-to-point gather must cost neither the scaling number NOR the gathered
+    outputs.  The probe before the timed region is made to fail on every rank (test hook; a refusal at communicator creation looks
+    like this): the ranks agree over the gloo control group, move the gather onto it (host-staged) in the same processes, and the
+    ONE line is a GATHERED line -- `config.gather` starts with "gloo fallback after: <text>", every output delivered, bit-identical
+    to the N = 1 run's."""
+    one = _bench(["--gpus", "1"] + COMMON)
     two = _bench(["--gpus", "2", "--backend", "gloo", "--one-device"] + COMMON, env={"RNAMSM_BENCH_FAIL_GATHER_PROBE": "all"})
+    assert two["n_gpus"] == 2 and two["value"] > 0 and two["outputs_finite"]
+    assert two["config"]["gather"].startswith("gloo fallback after: ") and "injected gather-probe failure" in two["config"]["gather"]
+    assert "RoundGatherer" in two["config"]["gather"] and two["digest"]["gather"].startswith("gloo fallback after: ")
+    assert two["output_digest"]["items"] == one["output_digest"]["items"] == 6
+    assert two["output_digest"]["value"] == one["output_digest"]["value"]
+    assert two["gather_stats"]["per_rank_bytes_received"][0] > 0
+
+
+def test_one_failing_rank_is_enough_to_move_every_rank():
+    two = _bench(["--gpus", "2", "--backend", "gloo", "--one-device"] + COMMON, env={"RNAMSM_BENCH_FAIL_GATHER_PROBE": "1"})
+    assert two["config"]["gather"].startswith("gloo fallback after: rank 1: ") and two["output_digest"]["items"] == 6
+
+
+def test_rccl_refusing_two_ranks_on_one_device_is_a_real_refusal_the_fallback_survives():
+    """Not injected: backend nccl with both ranks on device 0.  RCCL refuses ("Duplicate GPU detected") -- or, should it accept,
+    the primary transport simply works; either way the line is gathered and the outputs are the N = 1 run's bits."""
+    one = _bench(["--gpus", "1"] + COMMON)
+    two = _bench(["--gpus", "2", "--backend", "nccl", "--one-device"] + COMMON, env={"RNAMSM_BENCH_PG_TIMEOUT_S": "120"})
+    assert two["n_gpus"] == 2 and "RoundGatherer" in two["config"]["gather"]
+    assert two["config"]["gather"].startswith(("gloo fallback after: ", "rnamsm.sharding.RoundGatherer"))
+    assert two["output_digest"]["items"] == 6 and two["output_digest"]["value"] == one["output_digest"]["value"]
+
+
+def test_when_no_transport_works_the_line_is_the_sharded_compute_alone_and_says_so():
+    """Both transports fail (test hook "both"): ONE line, exit code 0, `config.gather` = "failed: <texts>", nothing gathered."""
+    two = _bench(["--gpus", "2", "--backend", "gloo", "--one-device"] + COMMON, env={"RNAMSM_BENCH_FAIL_GATHER_PROBE": "both"})
     assert two["n_gpus"] == 2 and two["value"] > 0 and two["outputs_finite"]
     assert two["config"]["gather"].startswith("failed: ") and "injected gather-probe failure" in two["config"]["gather"]
     assert two["digest"]["gather"].startswith("failed: ")

@@ -80,6 +80,7 @@ def _gather_worker(rank, world, port, root):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ["LOCAL_RANK"] = "0"
+    os.environ["RNAMSM_GATHER_BACKEND"] = "gloo"      # two ranks on ONE device: RCCL refuses that (tests/test_gpu_bench.py covers the refusal)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from rnamsm.config import Config

@@ -145,3 +145,40 @@ def _strided_worker(rank, world, port, q):
 
 def test_gather_of_non_contiguous_payloads_and_stats():
     assert all(_run(_strided_worker, 2))
+
+
+def _negotiate_worker(rank, world, port, want, inject_on, q):
+    """negotiate_gather_transport as bench.py / the CLI call it: default group gloo; the primary transport is probed, the ranks
+    agree, a failure on ANY rank moves every rank to the gloo group -- and the gather then delivers on the group returned."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        inject = f"injected on rank {rank}" if inject_on in (rank, "all") else None
+        group, label, mine = sharding.negotiate_gather_transport(torch.device("cpu"), want_backend=want, inject_failure=inject)
+        n_items = 5
+        local = {i: _item(i) for i in sharding.shard_indices(n_items, rank, world)}
+        out = sharding.gather_arrays(local, n_items, dst=0, tensors_per_item=2, group=None if group is False else group)
+        ok = out is None if rank else (sorted(out) == list(range(n_items)) and all(
+            torch.equal(a, b) for i in range(n_items) for a, b in zip(out[i], _item(i))))
+        q.put((rank, bool(ok), group is None, label, mine))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("want,inject_on", [("gloo", None), ("gloo", 1), ("gloo", "all"), ("nccl", None)])
+def test_gather_transport_negotiation_falls_back_to_gloo_in_the_same_processes(want, inject_on):
+    """VERDICT r05 item 5.  ("nccl", None) on this GPU-less host is a REAL refusal, not an injected one: RCCL cannot come up, every
+    rank catches that, agrees over gloo, and the gather still delivers -- the first 8-GPU run cannot come back without outputs."""
+    if want == "nccl" and torch.cuda.is_available():
+        pytest.skip("on a GPU host the RCCL group may come up; the GPU suite covers that (tests/test_gpu_bench.py)")
+    res = sorted(_run(_negotiate_worker, 2, want, inject_on))
+    assert all(ok for _, ok, _, _, _ in res)
+    labels = {label for _, _, _, label, _ in res}
+    assert len(labels) == 1                                         # the ranks agree
+    label = labels.pop()
+    if want == "gloo" and inject_on is None:
+        assert label == "primary" and all(m is None for *_, m in res)
+    else:
+        assert label.startswith("gloo fallback after: rank ") and all(is_default for _, _, is_default, _, _ in res)
+        if inject_on == 1:
+            assert "injected on rank 1" in label and res[0][4] is None and "injected on rank 1" in res[1][4]
