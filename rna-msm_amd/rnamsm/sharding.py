@@ -93,6 +93,11 @@ def negotiate_gather_transport(device: torch.device, want_backend: str = "nccl",
 
     def create():
         if want_backend == "nccl":
+            # blocking wait (read when the group is constructed): a transfer that does not complete within the group's timeout
+            # RAISES in the waiting rank -- which lands in the fallback below -- instead of the watchdog tearing the process down;
+            # the gather's waits are host-side anyway (RoundGatherer._retire runs after the next forward has been enqueued)
+            import os
+            os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
             primary[0] = dist.new_group(backend="nccl", timeout=timeout) if timeout is not None else dist.new_group(backend="nccl")
         if inject_failure:
             raise RuntimeError(inject_failure)
