@@ -346,7 +346,7 @@ COMPACT_LIMIT = 4096               # bytes of the LAST stdout line (the one the 
 
 
 def _short(v, n):
-    s = str(v)
+    s = " ".join(str(v).split())                                       # one line: exception texts carry newlines
     return s if len(s) <= n else s[:n - 3] + "..."
 
 
@@ -402,6 +402,16 @@ def compact_line(result):
         line["config"]["workload"] = _short(line["config"].get("workload", ""), 80)
         line["config"]["gather"] = _short(line["config"].get("gather", ""), 60)
     return line
+
+
+def flush_c_stdio():
+    """Flush the C library's stdout / stderr buffers of this process (what native libraries printed so far)."""
+    try:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                                 # noqa: BLE001 -- never the reason a line is lost
+        pass
 
 
 def emit(result, detail_out):
@@ -970,10 +980,18 @@ def run_rank(args) -> int:
             result["torch_rocm_eager"] = torch_rocm_eager(M, L, state, dev)
             result["cpu_baseline"] = cpu_baseline(M, L, state)
         result["digest"] = make_digest(result)
+    # The JSON line must be the LAST line on stdout.  Native libraries write there through C stdio (RCCL's version banner: block-
+    # buffered on a pipe, flushed at process exit -- seen AFTER the line on the first real RCCL refusal, round 6): every rank flushes
+    # C stdio now, the ranks meet, rank 0 prints, and nothing is left in anybody's buffer to trail the line.
+    flush_c_stdio()
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
         emit(result, args.detail_out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+        flush_c_stdio()
     return 0
 
 

@@ -205,10 +205,6 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm16_stagger = value;
         return RNAMSM_OK;
     }
-    if (name && !strcmp(name, "prio16")) {
-        rnamsm::tuning().prio16 = value < 0 ? 0 : (value > 3 ? 3 : value);
-        return RNAMSM_OK;
-    }
     if (name && !strcmp(name, "gemm16_dephase")) {
         rnamsm::tuning().gemm16_dephase = value < 0 ? 0 : (value > 2 ? 2 : value);
         return RNAMSM_OK;
@@ -267,7 +263,6 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "gemm_flat_tiles")) return rnamsm::tuning().gemm_flat_tiles;
     if (name && !strcmp(name, "gemm_splitk_short")) return rnamsm::tuning().gemm_splitk_short;
     if (name && !strcmp(name, "gemm16_dephase")) return rnamsm::tuning().gemm16_dephase;
-    if (name && !strcmp(name, "prio16")) return rnamsm::tuning().prio16;
     if (name && !strcmp(name, "gemm16_big_rows")) return rnamsm::tuning().gemm16_big_rows;
     if (name && !strcmp(name, "gemm16_big_rows_fwd")) return rnamsm::tuning().gemm16_big_rows_fwd;
     if (name && !strcmp(name, "row16_q16")) return rnamsm::tuning().row16_q16;

@@ -83,7 +83,6 @@ struct Tuning {
     int gemm16_mfma16 = 1;         // plain-bf16 256x256 GEMM: 1 = v_mfma_f32_16x16x32_bf16 (gemm16_q16s_kernel) for wide N, 2 = always, 0 = 32x32x16
     int gemm16_persist = 256;      // 256x256 16-bit GEMM: > 0 = that many persistent blocks walk the tiles (256 = one per CU; +1-5%, tools/gemm16_persist_ab.py), 0 = one block per tile
     int gemm16_stagger = 0;        // ... and block b starts (b/8 % 4) x this many cycles late (spreads the store bursts)
-    int prio16 = 0;                // A/B of round 6 (guide T5) on the 8-wave 16-bit kernels: 0 none, 1 s_setprio pair per MFMA cluster, 2 static for waves 4-7
     int gemm16_dephase = 2;        // 256x256 16-bit GEMMs, who issues the LDS-DMA requests when: 0 = every wave right after the tile barrier;
                                    // 1 = the upper wave group one (micro-)step later; 2 = 1, and the 16x16x32 kernel stages by operand
                                    // (gemm16_q16s_kernel: W by the lower group, A by the upper one, half a tile apart)

@@ -552,7 +552,7 @@ struct HsCfg {
     static constexpr int KS = BK / 16;                      // MFMA k steps per tile
 };
 
-template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL, int BK, int PRIO = 0>
+template <int ACT, bool HAS_RES, int SPLIT, int FMT, bool O_PL, int BK>
 __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo, int64_t lda, const uint16_t* __restrict__ Whi,
     const uint16_t* __restrict__ Wlo, const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout,
@@ -579,7 +579,6 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
         const long long t0 = __builtin_amdgcn_s_memtime();
         while (__builtin_amdgcn_s_memtime() - t0 < (long long)stagger_cycles * ph) __builtin_amdgcn_s_sleep(8);
     }
-    if (PRIO == 2 && wv >= 4) __builtin_amdgcn_s_setprio(1);  // wave-uniform: a scalar branch around one s_setprio
     for (unsigned vid = blockIdx.x; vid < total_tiles; vid += gridDim.x) {
     unsigned mpanel, nblk;
     if (!xcd_panel_map_grouped(vid, mp, nb, (unsigned)group, mpanel, nblk)) continue;
@@ -646,7 +645,6 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
         }
         __builtin_amdgcn_sched_group_barrier(0x008, NMF - NDS, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     };
 
     f32x16 acc[4][2];
@@ -668,7 +666,6 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
         const char* nxt = smem_b + ((kt & 1) ^ 1) * Cfg::BUF;
 #pragma unroll
         for (int kk = 0; kk + 1 < KS; ++kk) {                 // step kk on f[kk&1], step kk+1's fragments arriving
-            if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
             frag_load(cur, kk + 1, f[(kk + 1) & 1]);
             hx_frag_mma<SPLIT, FMT>(f[kk & 1], acc);
             interleave();
@@ -685,7 +682,6 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
         if (!dephase || wm == 0) issue(k2, kt & 1);
         __builtin_amdgcn_sched_barrier(0);
         // last step of tile kt, step 0 of tile kt+1 arriving
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
         frag_load(nxt, 0, f[0]);
         hx_frag_mma<SPLIT, FMT>(f[(KS - 1) & 1], acc);
         interleave();
@@ -696,14 +692,11 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
         const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
 #pragma unroll
         for (int kk = 0; kk + 1 < KS; ++kk) {
-            if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
             frag_load(cur, kk + 1, f[(kk + 1) & 1]);
             hx_frag_mma<SPLIT, FMT>(f[kk & 1], acc);
             interleave();
         }
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
         hx_frag_mma<SPLIT, FMT>(f[(KS - 1) & 1], acc);
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
     }
     wait_dma_then_barrier<0>();                               // the clamped reload has landed: LDS is free for the epilogue
     // The epilogue's lane geometry is re-derived from an OPAQUE copy of the lane id inside the tile loop: values computed from
@@ -724,15 +717,13 @@ static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
                      float* Cout, int64_t ldc, int64_t lda, int M, int N, int K, float scale, int scale_cols,
                      const uint16_t* a_hi, const uint16_t* a_lo, uint16_t* o_hi, uint16_t* o_lo, hipStream_t stream,
                      const Fold16& fa = Fold16{}) {
-    static DeviceOnce configured[3];
-    const int prio = tuning().prio16 == 3 ? 1 : tuning().prio16;
-    auto kern = prio == 1 ? gemm16_swp_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL, BK, 1> : prio == 2 ? gemm16_swp_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL, BK, 2>
-                                                                                                   : gemm16_swp_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL, BK, 0>;
+    static DeviceOnce configured;
+    auto kern = gemm16_swp_kernel<ACT, HAS_RES, SPLIT, FMT, O_PL, BK>;
     constexpr int lds = HsCfg<SPLIT, BK>::LDS;
-    if (configured[prio].pending()) {
+    if (configured.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_swp: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured[prio].mark();
+        configured.mark();
     }
     // block order as in gemm_f32.hip: 32 blocks are resident per XCD; for the wide GEMMs (QKV 9, fc1 12 column blocks)
     // groups of 8 row panels keep a W slab shared by 8 panels instead of ~3: +5..6% (split 3), +7..10% (split 1),
@@ -842,9 +833,7 @@ __device__ __forceinline__ void hq_epilogue(f32x4a (&acc)[8][4], const HqEpiRegs
     }
 }
 
-// PRIO (guide T5, A/B of round 6): 0 = none; 1 = s_setprio 1 / 0 around every MFMA cluster with its interleaved fragment reads;
-// 2 = static s_setprio 1 for waves 4-7; 3 = s_setprio 1 / 0 around the bare MFMA cluster, the fragment reads issued before it
-template <int ACT, bool HAS_RES, bool O_PL, int PRIO = 0>
+template <int ACT, bool HAS_RES, bool O_PL>
 __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16s_kernel(
     const uint16_t* __restrict__ Ahi, int64_t lda, const uint16_t* __restrict__ Whi, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
@@ -911,7 +900,6 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16s_kernel(
     unsigned vid = blockIdx.x;
     int m0, n0;
     if (!find_tile(vid, m0, n0)) return;
-    if (PRIO == 2 && wv >= 4) __builtin_amdgcn_s_setprio(1);  // wv is wave-uniform (readfirstlane): a scalar branch around one s_setprio
     set_offsets(m0, n0);
     issue_mine(0, 0);
     bool stores_in_flight = false;                            // uniform
@@ -960,31 +948,22 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16s_kernel(
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                            \
     }                                                                                 \
     __builtin_amdgcn_sched_group_barrier(0x008, 16 - NDS_, 0);                        \
-    __builtin_amdgcn_sched_barrier(0);                                                \
-    if (PRIO == 1 || PRIO == 3) __builtin_amdgcn_s_setprio(0)
-#define HQ_HE() if (PRIO == 1) __builtin_amdgcn_s_setprio(1)      /* before the fragment reads: reads stay interleaved */
-#define HQ_HI() if (PRIO == 3) __builtin_amdgcn_s_setprio(1)      /* after them: reads first, then the bare MFMA cluster (the template's form) */
+    __builtin_amdgcn_sched_barrier(0)
     for (int kt = 0; kt + 1 < nk; ++kt) {
         const char* cur = smem_b + (kt & 1) * Cfg::BUF;
         const char* nxt = smem_b + ((kt & 1) ^ 1) * Cfg::BUF;
         const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;         // clamped: the last reload is never read (keeps the counts below fixed)
-        HQ_HE();
         load_a(cur, 1, 0, ah[1]);                             // u0 = (ks 0, h 0) computes; u1 = (ks 1, h 0) arriving: the last reads of W
         load_b(cur, 1, bq[1]);
-        HQ_HI();
         mma(0, ah[0], bq[0]);
         HQ_PIN(8);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave has read the W tile of `cur`
         if (wm == 0) issue_mine(k2, kt & 1);                  // W of tile kt+2 -> the W plane of `cur`
         __builtin_amdgcn_sched_barrier(0);
-        HQ_HE();
         load_a(cur, 0, 1, ah[0]);                             // u1 computes; u2 = (ks 0, h 1) arriving
-        HQ_HI();
         mma(0, ah[1], bq[1]);
         HQ_PIN(4);
-        HQ_HE();
         load_a(cur, 1, 1, ah[1]);                             // u2 computes; u3 = (ks 1, h 1) arriving: the last reads of A
-        HQ_HI();
         mma(1, ah[0], bq[0]);
         HQ_PIN(4);
         // every wave has read the A tile of `cur`, and tile kt+1 has landed: the A group waits for all of its requests, the W
@@ -993,39 +972,26 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16s_kernel(
         else wait_dma_then_barrier<0>();
         if (wm == 1) issue_mine(k2, kt & 1);                  // A of tile kt+2 -> the A plane of `cur`
         __builtin_amdgcn_sched_barrier(0);
-        HQ_HE();
         load_a(nxt, 0, 0, ah[0]);                             // u3 computes; the next tile's u0 operands arriving
         load_b(nxt, 0, bq[0]);
-        HQ_HI();
         mma(1, ah[1], bq[1]);
         HQ_PIN(8);
     }
     {
         const char* cur = smem_b + ((nk - 1) & 1) * Cfg::BUF;
-        HQ_HE();
         load_a(cur, 1, 0, ah[1]);
         load_b(cur, 1, bq[1]);
-        HQ_HI();
         mma(0, ah[0], bq[0]);
         HQ_PIN(8);
-        HQ_HE();
         load_a(cur, 0, 1, ah[0]);
-        HQ_HI();
         mma(0, ah[1], bq[1]);
         HQ_PIN(4);
-        HQ_HE();
         load_a(cur, 1, 1, ah[1]);
-        HQ_HI();
         mma(1, ah[0], bq[0]);
         HQ_PIN(4);
-        HQ_HE();
-        HQ_HI();
         mma(1, ah[1], bq[1]);
-        if (PRIO == 1 || PRIO == 3) __builtin_amdgcn_s_setprio(0);
     }
 #undef HQ_PIN
-#undef HQ_HI
-#undef HQ_HE
     wait_dma_then_barrier<0>();                               // every wave is done with LDS; the clamped reload has landed
     // what the epilogue reads (bias / fold vectors, row statistics) first, then the next tile's tile 0, then the stores
     HqEpiRegs er;
@@ -1069,15 +1035,13 @@ template <int ACT, bool HAS_RES, bool O_PL>
 static int launch_hq(const uint16_t* Whi, const float* bias, const float* residual, int64_t ldr, float* Cout, int64_t ldc,
                      int64_t lda, int M, int N, int K, float scale, int scale_cols, const uint16_t* a_hi, uint16_t* o_hi,
                      hipStream_t stream, const Fold16& fa = Fold16{}) {
-    static DeviceOnce configured[4];
-    const int prio = tuning().prio16;
-    auto kern = prio == 1 ? gemm16_q16s_kernel<ACT, HAS_RES, O_PL, 1> : prio == 2 ? gemm16_q16s_kernel<ACT, HAS_RES, O_PL, 2>
-              : prio == 3 ? gemm16_q16s_kernel<ACT, HAS_RES, O_PL, 3> : gemm16_q16s_kernel<ACT, HAS_RES, O_PL, 0>;
+    static DeviceOnce configured;
+    auto kern = gemm16_q16s_kernel<ACT, HAS_RES, O_PL>;        // staging split by operand between the wave groups
     constexpr int lds = HsCfg<1, 64>::LDS;
-    if (configured[prio].pending()) {
+    if (configured.pending()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return fail(RNAMSM_ERR_HIP, "gemm16_q16s: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        configured[prio].mark();
+        configured.mark();
     }
     const int group = tuning().gemm_group > 0 ? tuning().gemm_group
                                               : (N / HX_BN > 4 ? (int)xcd_group_for_persistent((M + HX_BM - 1) / HX_BM, 8) : 1);
