@@ -474,8 +474,9 @@ int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* const* weig
  * alignment from gridDim.y and its shape / offsets from a descriptor table the call writes into the workspace.  Every
  * alignment keeps the tied-logit slab split of its own forward; q carries dh^-1/2 and the alignment's 1/sqrt(R_b)
  * (align_scaling, modules.py:713-715) multiplies its summed logits -- the arithmetic of rnamsm_forward itself since round 5 --
- * fc2 is never split and LayerNorm is folded only where every member's own forward folds it (>= 4096 tokens each; a list that mixes the two classes is
- * best handed over as two batches, as the Python mirror does): with
+ * fc2 is never split and LayerNorm is folded only where every member's own forward folds it (>= 4096 tokens each; with ln_folded given
+ * and the by-shape rule in force a table that mixes the two classes is REFUSED with RNAMSM_ERR_INVALID: hand it over as two
+ * batches, one per class, as the Python mirror does): with
  * RNAMSM_F32 every alignment's outputs are rnamsm_forward's BIT FOR BIT (tests/test_gpu_forward.py).  A packed batch builds no
  * masks: <pad> inside it sets bit 3 (value 8) of *err_flag and the caller reruns that batch framed.
  * dtype RNAMSM_BF16 / RNAMSM_F16X3 (round 5; weight_planes as in rnamsm_forward, NULL for RNAMSM_F32): every Linear runs on the

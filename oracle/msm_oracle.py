@@ -44,9 +44,10 @@ def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor) -> torc
     return (x - mu) * torch.rsqrt(var + LN_EPS) * gamma + beta
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """nn.Linear: x @ w.T + b, w is [out, in]."""
-    return x @ w.t() + b
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """nn.Linear: x @ w.T + b, w is [out, in] (b may be None: bias=False)."""
+    y = x @ w.t()
+    return y if b is None else y + b
 
 
 def gelu_erf(x: torch.Tensor) -> torch.Tensor:
@@ -258,6 +259,77 @@ def multihead_self_attention(x: torch.Tensor, params, prefix: str, num_heads: in
     ctx = torch.einsum("bhij,jbhd->ibhd", p, v).reshape(T, B, E)
     out = linear(ctx, _p(params, prefix, "out_proj.weight"), _p(params, prefix, "out_proj.bias"))
     return (out, p.transpose(0, 1)) if return_weights else out
+
+
+def multihead_attention(query: torch.Tensor, key: Optional[torch.Tensor], value: Optional[torch.Tensor], w: Dict[str, torch.Tensor],
+                        num_heads: int, key_padding_mask: Optional[torch.Tensor] = None,
+                        attn_mask: Optional[torch.Tensor] = None, add_zero_attn: bool = False,
+                        saved: Optional[Dict[str, Optional[torch.Tensor]]] = None, static_kv: bool = False,
+                        before_softmax: bool = False):
+    """The GENERAL form of msm/multihead_attention.py:154-397 in eval mode -- everything the self-attention restatement above leaves
+    out: cross-attention (key / value of another length and width, :228-246), bias_k / bias_v (one learned key / value appended to
+    every batch element, :249-264), add_zero_attn (an all-zero key / value appended, :318-336), and incremental decoding through
+    a saved state (:273-311: prev_key / prev_value [B, H, S, dh] are prepended -- or, static_kv, replace the new ones -- and the
+    padding masks are joined by _append_prev_key_padding_mask, :399-434).
+    w: q_proj / k_proj / v_proj / out_proj .weight (+ .bias, optional), bias_k / bias_v [1, 1, E] (optional).
+    query [T, B, E]; key [S, B, kdim] / value [S, B, vdim] (None with static_kv once the state holds them).
+    Returns (out [T, B, E], per-head probabilities [H, B, T, S_total]); with `saved` given the dict is updated in place as the
+    reference updates its buffer.  before_softmax: (masked scores [B*H, T, S_total], v [B*H, S_total, dh]) as :371-372."""
+    T, B, E = query.shape
+    H, dh = num_heads, E // num_heads
+
+    def proj(x, name):
+        return linear(x, w[f"{name}.weight"], w.get(f"{name}.bias"))
+
+    q = proj(query, "q_proj") * dh ** -0.5                                                   # :247
+    k = None if key is None else proj(key, "k_proj")
+    v = None if value is None else proj(value, "v_proj")
+    am, kpm = attn_mask, key_padding_mask
+    if w.get("bias_k") is not None:                                                          # :249-264
+        k = torch.cat([k, w["bias_k"].expand(1, B, E)])
+        v = torch.cat([v, w["bias_v"].expand(1, B, E)])
+        if am is not None:
+            am = torch.cat([am, am.new_zeros(am.shape[0], 1)], dim=1)
+        if kpm is not None:
+            kpm = torch.cat([kpm, kpm.new_zeros(B, 1)], dim=1)
+    if saved is not None:                                                                    # :273-311
+        def from_state(t):                                                                   # [B, H, S, dh] -> [S, B, E]
+            return t.permute(2, 0, 1, 3).reshape(t.shape[2], B, E)
+        if saved.get("prev_key") is not None:
+            pk, pv = from_state(saved["prev_key"]), from_state(saved["prev_value"])
+            k = pk if static_kv else torch.cat([pk, k])
+            v = pv if static_kv else torch.cat([pv, v])
+        prev = saved.get("prev_key_padding_mask")
+        S = k.shape[0]
+        if prev is not None and static_kv:                                                   # :399-434
+            kpm = prev
+        elif prev is not None and kpm is not None:
+            kpm = torch.cat([prev.float(), kpm.float()], dim=1)
+        elif prev is not None:
+            kpm = torch.cat([prev.float(), torch.zeros(B, S - prev.shape[1])], dim=1)
+        elif kpm is not None:
+            kpm = torch.cat([torch.zeros(B, S - kpm.shape[1]), kpm.float()], dim=1)
+        saved["prev_key"] = k.view(S, B, H, dh).permute(1, 2, 0, 3).contiguous()
+        saved["prev_value"] = v.view(S, B, H, dh).permute(1, 2, 0, 3).contiguous()
+        saved["prev_key_padding_mask"] = kpm
+    if add_zero_attn:                                                                        # :318-336
+        k = torch.cat([k, k.new_zeros(1, B, E)])
+        v = torch.cat([v, v.new_zeros(1, B, E)])
+        if am is not None:
+            am = torch.cat([am, am.new_zeros(am.shape[0], 1)], dim=1)
+        if kpm is not None:
+            kpm = torch.cat([kpm, kpm.new_zeros(B, 1)], dim=1)
+    S = k.shape[0]
+    scores = torch.einsum("ibhd,jbhd->bhij", q.view(T, B, H, dh), k.view(S, B, H, dh))        # :338
+    if am is not None:
+        scores = scores + am.to(scores.dtype)[None, None]                                    # :343-347
+    if kpm is not None:
+        scores = scores.masked_fill(kpm.to(torch.bool)[:, None, None, :], float("-inf"))     # :349-356
+    if before_softmax:
+        return scores.reshape(B * H, T, S), v.view(S, B, H, dh).permute(1, 2, 0, 3).reshape(B * H, S, dh)
+    p = torch.softmax(scores, -1)
+    ctx = torch.einsum("bhij,jbhd->ibhd", p, v.view(S, B, H, dh)).reshape(T, B, E)
+    return linear(ctx, w["out_proj.weight"], w.get("out_proj.bias")), p.transpose(0, 1)
 
 
 def lm_head(features: torch.Tensor, params: Dict[str, torch.Tensor]) -> torch.Tensor:

@@ -133,9 +133,9 @@ Tuning& tuning() {
     static Tuning t;
     return t;
 }
-std::atomic<int>& forwards_enqueuing() {
-    static std::atomic<int> n{0};
-    return n;
+std::shared_mutex& tuning_lock() {
+    static std::shared_mutex m;
+    return m;
 }
 int& gemm16_big_rows_override() {
     static thread_local int v = 0;
@@ -143,7 +143,8 @@ int& gemm16_big_rows_override() {
 }
 }  // namespace rnamsm
 extern "C" int rnamsm_set_param(const char* name, int value) {
-    if (rnamsm::forwards_enqueuing().load(std::memory_order_acquire) != 0)
+    std::unique_lock<std::shared_mutex> exclusive(rnamsm::tuning_lock(), std::try_to_lock);
+    if (!exclusive.owns_lock())
         return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: a forward driver is enqueuing on another thread; knobs are process-global "
                                                 "and may only change between forwards");
     if (name && !strcmp(name, "gemm16_dma")) {

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <atomic>
+#include <shared_mutex>
 
 #include "../../include/rnamsm.h"
 
@@ -109,12 +110,14 @@ struct Tuning {
 };
 Tuning& tuning();
 // The knobs are process-global A/B instruments, read on the HOST while a driver enqueues its launches.  Writing one while another
-// thread is inside a forward driver would let that forward mix two settings (and, for the arithmetic knobs, two roundings): the
-// drivers count themselves in and rnamsm_set_param refuses (RNAMSM_ERR_INVALID) while the count is non-zero.
-std::atomic<int>& forwards_enqueuing();
+// thread is inside a forward driver would let that forward mix two settings (and, for the arithmetic knobs, two roundings).  One
+// reader-writer lock closes that (the earlier counter was check-then-act): a driver holds it SHARED for as long as it
+// enqueues, rnamsm_set_param takes it EXCLUSIVE with try_lock and refuses (RNAMSM_ERR_INVALID) when a driver holds it -- it never
+// blocks inside the library, and a driver that starts while a knob is being written waits the few nanoseconds the write takes.
+std::shared_mutex& tuning_lock();
 struct ForwardScope {
-    ForwardScope() { forwards_enqueuing().fetch_add(1, std::memory_order_acq_rel); }
-    ~ForwardScope() { forwards_enqueuing().fetch_sub(1, std::memory_order_acq_rel); }
+    ForwardScope() { tuning_lock().lock_shared(); }
+    ~ForwardScope() { tuning_lock().unlock_shared(); }
     ForwardScope(const ForwardScope&) = delete;
     ForwardScope& operator=(const ForwardScope&) = delete;
 };

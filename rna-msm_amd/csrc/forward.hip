@@ -510,7 +510,8 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
     // statistics from the producers only; a ragged batch (true_rows) keeps the LayerNorm launches: its QKV GEMM carries the
     // per-token q factor in the epilogue slot the fold would need
     // (by the MEMBER's token count, as its own forward decides: the batch must not change an alignment's rounding)
-    const bool fold = ln_folded && !has_padding && !true_rows && (fold_mode == 3 || (fold_mode == 1 && Tm >= LN_FOLD_MIN_TOKENS));
+    const bool fold = ln_folded && !has_padding && !true_rows && (fold_mode >= 2 || (fold_mode == 1 && Tm >= LN_FOLD_MIN_TOKENS));
+    const bool fold_sums = fold && fold_mode != 2;           // mode 2 (every GEMM sums its own rows): as in rnamsm_forward
     // f2: the batch contains <pad> (ragged MSAs padded to one shape): the reference's direct-path mask semantics as in
     // rnamsm_forward -- zeroed embeddings (K0) and q (QKV epilogue) at padded tokens, -10000 on keys whose first-row token is
     // <pad> (tied rows) and on padded keys (columns); every MSA reads its own [R, C] slice of the mask
@@ -592,7 +593,7 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
         return RNAMSM_OK;
     }
 
-    const ExactPath ex{d, x, xn, rowsum, stats, splitk, T, fold, fold, ln_folded, err_flag, stream};
+    const ExactPath ex{d, x, xn, rowsum, stats, splitk, T, fold, fold_sums, ln_folded, err_flag, stream};
     auto norm = [&](const float* g, const float* b) -> int { return ex.norm(g, b, T); };
     auto lin_normed = [&](int layer, int fslot, const float* Wf, const float* bias, float* out, int64_t ldc, int N, int act,
                           float scale, int scale_cols) -> int {
@@ -606,7 +607,7 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
     FWD(rnamsm::embed_ln_batched(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
                                  G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, B, R, C, D, d.vocab, d.num_positions, d.pad_idx,
                                  d.ln_eps, err_flag, hs, d.row_pos_dim));
-    if (fold) {
+    if (fold_sums) {
         FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
         FWD(rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream));
     }
@@ -746,16 +747,25 @@ extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float*
     float* hidden = wide;              // [T, F]
     const float* const* G = weights;
     const int fold_mode = tuning().ln_fold;
-    // folded only where EVERY member's own forward would fold (>= LN_FOLD_MIN_TOKENS each): an alignment's rounding must not depend
-    // on its company.  A batch that mixes the two classes runs unfolded here -- the Python mirror (MSATransformer.forward_packed)
-    // therefore hands such a list over as two batches, one per class, and every member keeps the bits of its own forward.
-    int64_t min_member = INT64_MAX;
-    for (int b = 0; b < B; ++b) min_member = std::min<int64_t>(min_member, (int64_t)host[b].R * host[b].C);
-    const bool fold = ln_folded && (fold_mode == 3 || (fold_mode == 1 && min_member >= LN_FOLD_MIN_TOKENS));
+    // folded where every member's own forward would fold (>= LN_FOLD_MIN_TOKENS each): an alignment's rounding must not depend on
+    // its company.  One launch set is one class: a table that MIXES the two classes under the by-shape rule (knob ln_fold = 1) is
+    // refused -- it could only run unfolded, and its large members would silently differ from rnamsm_forward by a rounding (ADVICE
+    // r05); the Python mirror (MSATransformer.forward_packed, plan_packed_groups) hands such a list over as two batches.
+    int64_t min_member = INT64_MAX, max_member = 0;
+    for (int b = 0; b < B; ++b) {
+        min_member = std::min<int64_t>(min_member, (int64_t)host[b].R * host[b].C);
+        max_member = std::max<int64_t>(max_member, (int64_t)host[b].R * host[b].C);
+    }
+    if (ln_folded && dtype == RNAMSM_F32 && fold_mode == 1 && min_member < LN_FOLD_MIN_TOKENS && max_member >= LN_FOLD_MIN_TOKENS)
+        return fail(RNAMSM_ERR_INVALID, "forward_packed: the batch mixes alignments below and from %lld tokens (LayerNorm folded from there): "
+                                        "pass the two classes as two batches, so that every alignment keeps the bits of its own forward",
+                    (long long)LN_FOLD_MIN_TOKENS);
+    const bool fold = ln_folded && (fold_mode >= 2 || (fold_mode == 1 && min_member >= LN_FOLD_MIN_TOKENS));
+    const bool fold_sums = fold && fold_mode != 2;
     const float qk_scale = 1.0f / sqrtf(64.0f);
     const PackedMsa* hp = host.data();
 
-    const ExactPath ex{d, x, xn, rowsum, stats, splitk, T, fold, fold, ln_folded, err_flag, stream};
+    const ExactPath ex{d, x, xn, rowsum, stats, splitk, T, fold, fold_sums, ln_folded, err_flag, stream};
     auto norm = [&](const float* g, const float* b) -> int { return ex.norm(g, b, T); };
     auto lin_normed = [&](int layer, int fslot, const float* Wf, const float* bias, float* out, int64_t ldc, int N, int act,
                           float scale, int scale_cols) -> int {
@@ -823,7 +833,7 @@ extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float*
         FWD(rnamsm::pack_outputs_packed(repr, row_attn, emb, atp, desc, B, max_C16, D, NL, H, out_floats16, err_flag, hs));
         return RNAMSM_OK;
     }
-    if (fold) {
+    if (fold_sums) {
         FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
         FWD(rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream));
     }

@@ -350,18 +350,69 @@ class MultiheadAttention(_AxialAttentionBase):
         padding fill and the softmax (a causal mask is -inf above the diagonal).  Takes the weights route whatever
         need_weights says (the fused kernel never sees the scores): the mask joins the fp32 logits of K4 by one rnamsm_add per
         head; a query row left with no admissible key at all is NaN, as in the reference.
-    Raises for what is outside eval-mode self-attention: incremental state, static_kv, before_softmax,
-    bias_kv / zero_attn, cross-attention, dropout in training."""
+    Round 6 -- the options of the reference's module outside plain self-attention (VERDICT r05 "missing" 3), on the GENERAL route
+    (_forward_general): cross-attention (key / value of another length; kdim / vdim), add_bias_kv, add_zero_attn, bias=False,
+    incremental_state (prev_key / prev_value / prev_key_padding_mask in the caller's dict under this module's own key, as
+    fairseq's FairseqIncrementalState keeps them, :24-58, 273-311, 399-434), static_kv, before_softmax (honoured where the
+    reference honours it: on its own route, i.e. with need_head_weights or an incremental state -- its torch.nn.functional route,
+    :170-199, ignores the flag).  That route always materialises the probabilities with the tied-row kernels on a square frame of
+    max(T, S) positions per batch element (K4 logits, the masks added as ONE fp32 [frame, frame] array with -inf at padded /
+    forbidden / out-of-range keys, K5, K6) and runs in exact fp32 whatever gemm_dtype says; T, S <= 1024.
+    Raises for dropout in training only."""
 
     def __init__(self, embed_dim, num_heads, kdim=None, vdim=None, dropout=0.0, bias=True, add_bias_kv=False,
                  add_zero_attn=False, self_attention=False, encoder_decoder_attention=False):
-        if not bias or add_bias_kv or add_zero_attn or encoder_decoder_attention:
-            raise NotImplementedError("only biased self-attention without bias_kv / zero_attn is implemented")
-        if (kdim not in (None, embed_dim)) or (vdim not in (None, embed_dim)):
-            raise NotImplementedError("kdim / vdim must equal embed_dim (self-attention)")
         super().__init__(embed_dim, num_heads, dropout=dropout)
         self.embed_dim = embed_dim
-        self.self_attention = True
+        self.kdim = embed_dim if kdim is None else kdim
+        self.vdim = embed_dim if vdim is None else vdim
+        self.qkv_same_dim = self.kdim == embed_dim and self.vdim == embed_dim
+        # (the flags select where k / v come from on the reference's own route, :228-246; round 5 and before forced self-attention)
+        self.self_attention = self_attention
+        self.encoder_decoder_attention = encoder_decoder_attention
+        if self_attention and not self.qkv_same_dim:
+            raise AssertionError("Self-attention requires query, key and value to be of the same size")      # :96-98
+        if self.kdim % 32 or self.vdim % 32:
+            raise ValueError("kdim / vdim must be multiples of 32 (the GEMM's K tile)")
+        if not (self.qkv_same_dim and bias):
+            self.k_proj = nn.Linear(self.kdim, embed_dim, bias=bias)
+            self.v_proj = nn.Linear(self.vdim, embed_dim, bias=bias)
+            self.q_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+            self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+        self._fusable = self.qkv_same_dim and bias                  # the packed [3E, E] QKV weight exists
+        if add_bias_kv:
+            self.bias_k = nn.Parameter(torch.zeros(1, 1, embed_dim))
+            self.bias_v = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        else:
+            self.bias_k = self.bias_v = None
+        self.add_zero_attn = add_zero_attn
+        import uuid
+        self._incremental_state_id = str(uuid.uuid4())              # :29-30
+
+    # ---- the caller's incremental_state dict, fairseq layout (:24-58, 447-463)
+    def _state_key(self) -> str:
+        return f"{self._incremental_state_id}.attn_state"
+
+    def _get_input_buffer(self, incremental_state):
+        if incremental_state is None or self._state_key() not in incremental_state:
+            return {}
+        return incremental_state[self._state_key()]
+
+    def _set_input_buffer(self, incremental_state, buffer):
+        if incremental_state is not None:
+            incremental_state[self._state_key()] = buffer
+        return incremental_state
+
+    def reorder_incremental_state(self, incremental_state, new_order):
+        """Beam reordering of the buffered keys / values (:436-452)."""
+        buf = self._get_input_buffer(incremental_state)
+        for name, val in list(buf.items()):
+            if val is None:
+                continue
+            if self.encoder_decoder_attention and val.size(0) == new_order.size(0):
+                break
+            buf[name] = val.index_select(0, new_order.to(val.device))
+        return self._set_input_buffer(incremental_state, buf)
 
     @staticmethod
     def _reference_nan(out, weights, kpm, need_head_weights, attn_mask=None):
@@ -381,11 +432,138 @@ class MultiheadAttention(_AxialAttentionBase):
 
     def forward(self, query, key=None, value=None, key_padding_mask=None, incremental_state=None, need_weights=True,
                 static_kv=False, attn_mask=None, before_softmax=False, need_head_weights=False):
-        out, weights = self._forward(query, key, value, key_padding_mask, incremental_state, need_weights, static_kv, attn_mask,
-                                     before_softmax, need_head_weights)
+        own_route = incremental_state is not None or static_kv or need_head_weights          # the reference's manual route (:201 ff.)
+        plain = (self._fusable and self.bias_k is None and not self.add_zero_attn and incremental_state is None and not static_kv
+                 and (key is None or key is query) and (value is None or value is query) and not (before_softmax and own_route))
+        if not plain:
+            return self._forward_general(query, key, value, key_padding_mask, incremental_state, need_weights, static_kv, attn_mask,
+                                         before_softmax and own_route, need_head_weights, own_route)
+        out, weights = self._forward(query, key, value, key_padding_mask, None, need_weights, False, attn_mask, False, need_head_weights)
         if key_padding_mask is not None:
             out, weights = self._reference_nan(out, weights, key_padding_mask.to(out.device), need_head_weights and weights is not None,
                                                None if attn_mask is None else attn_mask.to(out.device))
+        return out, weights
+
+    def _forward_general(self, query, key, value, key_padding_mask, incremental_state, need_weights, static_kv, attn_mask,
+                         before_softmax, need_head_weights, own_route):
+        """Every option of msm/multihead_attention.py:154-397 (class docstring, round 6).  Exact fp32."""
+        _check_inference(self, self.dropout)
+        if query.dim() != 3 or query.shape[2] != self.embed_dim:
+            raise ValueError(f"expected query of shape [T, B, {self.embed_dim}], got {tuple(query.shape)}")
+        if need_head_weights:
+            need_weights = True
+        T, B, E = query.shape
+        H, dev = self.num_heads, query.device
+        saved = None
+        if incremental_state is not None:
+            saved = self._get_input_buffer(incremental_state)
+            if "prev_key" in saved and static_kv:                    # :203-210: the buffered projections stand for key / value
+                assert self.encoder_decoder_attention and not self.self_attention
+                key = value = None
+        # where k / v come from: the flags on the reference's own route (:228-246), the arguments on its functional route (:170-199)
+        if own_route and self.self_attention:
+            ksrc = vsrc = query
+        elif own_route and self.encoder_decoder_attention:
+            ksrc = vsrc = key
+        else:
+            ksrc, vsrc = (query if key is None and not own_route else key), (query if value is None and not own_route else value)
+            if own_route and (ksrc is None) != (vsrc is None):
+                raise AssertionError("key and value must both be given")
+
+        def lin(x, layer, scale=1.0):
+            x2 = x.contiguous().view(-1, x.shape[-1]).float()
+            b = None if layer.bias is None else layer.bias.detach()
+            return ops.linear(x2, layer.weight.detach(), b, scale=scale, scale_cols=E if scale != 1.0 else 0).view(x.shape[0], B, E)
+
+        q = lin(query, self.q_proj, self.scaling)                    # (q_proj(query)) * dh^-1/2, :247
+        k = None if ksrc is None else lin(ksrc, self.k_proj)
+        v = None if vsrc is None else lin(vsrc, self.v_proj)
+        am = None if attn_mask is None else attn_mask.to(device=dev, dtype=torch.float32)
+        if am is not None and (am.dim() != 2 or am.shape[0] != T):
+            raise ValueError(f"expected a float attn_mask of shape [{T}, src_len], got {tuple(attn_mask.shape)}")
+        kpm = None if key_padding_mask is None else key_padding_mask.to(dev)
+
+        def grow(mask, rows):                                        # one more admissible key: a zero column (:255-264, 323-336)
+            return None if mask is None else torch.cat([mask, mask.new_zeros(rows, 1)], dim=1)
+
+        if self.bias_k is not None:                                  # :249-264
+            k = torch.cat([k, self.bias_k.detach().float().expand(1, B, E)])
+            v = torch.cat([v, self.bias_v.detach().float().expand(1, B, E)])
+            am, kpm = grow(am, T), grow(kpm, B)
+        if saved is not None:                                        # :273-311
+            def unpack(t):                                           # [B, H, S, dh] -> [S, B, E]
+                return t.to(dev).permute(2, 0, 1, 3).reshape(t.shape[2], B, E)
+            if saved.get("prev_key") is not None:
+                pk, pv = unpack(saved["prev_key"]), unpack(saved["prev_value"])
+                k = pk if static_kv else torch.cat([pk, k])
+                v = pv if static_kv else torch.cat([pv, v])
+            S = k.shape[0]
+            prev = saved.get("prev_key_padding_mask")
+            if prev is not None and static_kv:                       # _append_prev_key_padding_mask, :399-434
+                kpm = prev
+            elif prev is not None and kpm is not None:
+                kpm = torch.cat([prev.float(), kpm.float()], dim=1)
+            elif prev is not None:
+                kpm = torch.cat([prev.float(), torch.zeros(B, S - prev.shape[1], device=prev.device)], dim=1)
+            elif kpm is not None:
+                kpm = torch.cat([torch.zeros(B, S - kpm.shape[1], device=kpm.device), kpm.float()], dim=1)
+            saved["prev_key"] = k.view(S, B, H, self.head_dim).permute(1, 2, 0, 3).contiguous()
+            saved["prev_value"] = v.view(S, B, H, self.head_dim).permute(1, 2, 0, 3).contiguous()
+            saved["prev_key_padding_mask"] = kpm
+            self._set_input_buffer(incremental_state, saved)
+        if k is None:
+            raise AssertionError("no keys: key / value are None and the incremental state holds none")
+        if self.add_zero_attn:                                       # :318-336
+            k = torch.cat([k, k.new_zeros(1, B, E)])
+            v = torch.cat([v, v.new_zeros(1, B, E)])
+            am, kpm = grow(am, T), grow(kpm, B)
+        S = k.shape[0]
+        if am is not None and am.shape[1] != S:
+            raise ValueError(f"attn_mask has {am.shape[1]} key columns, the keys number {S}")
+        if kpm is not None and tuple(kpm.shape) != (B, S):
+            raise AssertionError(f"key_padding_mask must be [{B}, {S}], got {tuple(kpm.shape)}")
+        C = max(T, S)
+        if C > 1024:
+            raise NotImplementedError("the general route materialises [H, frame, frame] with kernels built for frames <= 1024")
+        kpm_b = None if kpm is None else kpm.to(device=dev).bool()
+        neg = float("-inf")
+        ctx = torch.empty(T, B, E, device=dev, dtype=torch.float32)
+        probs = torch.empty(B, H, T, S, device=dev, dtype=torch.float32)
+        scores = torch.empty(B, H, T, S, device=dev, dtype=torch.float32) if before_softmax else None
+        dead = torch.zeros(B, T, dtype=torch.bool, device=dev)       # queries without any admissible key: NaN rows in the reference
+        for b in range(B):
+            frame = torch.zeros(C, 3 * E, device=dev, dtype=torch.float32)      # q | k | v of this element on the square frame
+            frame[:T, :E], frame[:S, E:2 * E], frame[:S, 2 * E:] = q[:, b], k[:, b], v[:, b]
+            partial, _ = ops.row_logits(frame[:, :E], frame[:, E:2 * E], 1, C, H)
+            add = None
+            if am is not None or kpm_b is not None or S < C:
+                add = torch.zeros(C, C, device=dev, dtype=torch.float32)
+                if am is not None:
+                    add[:T, :S] = am
+                if kpm_b is not None:
+                    add[:, :S].masked_fill_(kpm_b[b][None, :], neg)
+                add[:, S:] = neg                                     # frame positions past the last key
+                dead[b] = torch.isneginf(add[:T, :S]).all(dim=1)
+                for h in range(H):
+                    ops.add(partial[0, h], add, out=partial[0, h])
+            if before_softmax:
+                scores[b] = partial[0, :, :T, :S]
+                continue
+            p = ops.softmax_rows(partial)                            # [H, C, C]
+            c_b = ops.row_apply(p, frame[:, 2 * E:], 1, C, H)        # [C, E]
+            ctx[:, b] = c_b[:T]
+            probs[b] = p[:, :T, :S]
+        if before_softmax:                                           # :358-359
+            return scores.view(B * H, T, S), v.view(S, B, H, self.head_dim).permute(1, 2, 0, 3).reshape(B * H, S, self.head_dim)
+        ob = None if self.out_proj.bias is None else self.out_proj.bias.detach()
+        out = ops.linear(ctx.view(T * B, E), self.out_proj.weight.detach(), ob).view(T, B, E)
+        nan = torch.full((), float("nan"), device=dev, dtype=torch.float32)
+        out = torch.where(dead.t()[:, :, None], nan, out)
+        if not need_weights:
+            return out, None
+        weights = torch.where(dead[:, None, :, None], nan, probs).permute(1, 0, 2, 3).contiguous()      # [H, B, T, S]  (:389-393)
+        if not need_head_weights:
+            weights = ops.head_mean(weights)                         # [B, T, S]     (:394-397)
         return out, weights
 
     def _forward(self, query, key=None, value=None, key_padding_mask=None, incremental_state=None, need_weights=True,
@@ -434,8 +612,8 @@ class MultiheadAttention(_AxialAttentionBase):
         for b in range(B):                                              # one "alignment" of a single row per element
             qb = qkv3[:, b]                                             # [T, 3E] view, row stride B*3E
             partial, _ = ops.row_logits(qb[:, :E], qb[:, E:2 * E], 1, T, H)
-            self._add_attn_mask(partial, am)
-            ops.softmax_rows(partial, out=probs[b], key_mask=None if kpm is None else kpm[b])
+            km = self._add_attn_mask(partial, am, None if kpm is None else kpm[b])
+            ops.softmax_rows(partial, out=probs[b], key_mask=km)
             ops.row_apply(probs[b], qb[:, 2 * E:], 1, T, H, out=ctx[:, b])
         out = self._project_out(ctx.view(T * B, E), None).view(T, B, E)
         if not want_weights:
@@ -446,15 +624,21 @@ class MultiheadAttention(_AxialAttentionBase):
         return out, weights
 
     @staticmethod
-    def _add_attn_mask(partial, am):
+    def _add_attn_mask(partial, am, key_mask=None):
         """attn_weights += attn_mask (msm/multihead_attention.py:353-357) on K4's fp32 logits [nsplit = 1, H, T, T] of one batch
-        element, head by head (rnamsm_add, in place)."""
+        element, head by head (rnamsm_add, in place).  Returns the key mask K5 still has to apply.
+        With BOTH masks the key padding joins the added mask as -inf (the reference's masked_fill value, :360-369) and K5 gets no
+        key mask: K5's own fill is -10000, which is only "minus infinity" next to scores of ordinary size -- under a finite
+        large-negative attn_mask (-1e9 block masks) a padded key would otherwise outweigh the admissible ones."""
         if am is None:
-            return
+            return key_mask
         if partial.shape[0] != 1:
             raise NotImplementedError("attn_mask: the single-row logits are expected in one slab")
+        if key_mask is not None:
+            am = am.masked_fill(key_mask.bool()[None, :], float("-inf"))
         for h in range(partial.shape[1]):
             ops.add(partial[0, h], am, out=partial[0, h])
+        return None
 
     def _forward16(self, x2, T, B, E, kpm, need_weights, need_head_weights, split, fmt, attn_mask=None):
         """The same two routes on the 16-bit kernels (operands as hi(/lo) planes, q unscaled, fp32 softmax)."""
@@ -473,9 +657,8 @@ class MultiheadAttention(_AxialAttentionBase):
         for b in range(B):
             qb = tuple(None if p is None else p[:, b] for p in qkv3)   # [T, 3E] plane views, row stride B*3E
             partial, _ = ops.row_logits16(_cols(qb, 0, E), _cols(qb, E, 2 * E), 1, T, H, fmt=fmt, scale=self.scaling)
-            self._add_attn_mask(partial, attn_mask)
-            pb, p_pl = ops.softmax_rows_planes(partial, split=split, fmt=fmt, plane_scale=4096.0,
-                                               key_mask=None if kpm is None else kpm[b])
+            km = self._add_attn_mask(partial, attn_mask, None if kpm is None else kpm[b])
+            pb, p_pl = ops.softmax_rows_planes(partial, split=split, fmt=fmt, plane_scale=4096.0, key_mask=km)
             probs[b] = pb
             ctx[:, b] = ops.row_apply16(p_pl, _cols(qb, 2 * E, 3 * E), 1, T, H, fmt=fmt, out_scale=1.0 / 4096.0)
         out = self._project_out(ctx.view(T * B, E), None).view(T, B, E)

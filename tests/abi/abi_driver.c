@@ -163,6 +163,18 @@ int main(void) {
     REFUSED(rnamsm_forward_batch(&dims, weights, toks, 2, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, 9, NULL, NULL));
     REFUSED(rnamsm_forward_batch(&dims, weights, toks, 2, 4, 4, buf, 1 << 16, buf, buf, buf, buf, ints, 0, NULL, NULL, 1, NULL, NULL));
     EXPECT(strstr(rnamsm_last_error(), "need weight_planes") != NULL);
+    {   /* the token-packed driver: refusals of the table itself, all before any launch */
+        const int two_classes[4] = {64, 128, 8, 40};          /* 8192 tokens (LayerNorm folded from 4096) next to 320 */
+        const int one_class[4] = {8, 40, 6, 33};
+        const int too_deep[2] = {1025, 8};
+        EXPECT(rnamsm_forward_packed_workspace_bytes(&dims, 2, two_classes) > 0 && rnamsm_forward_packed_workspace_bytes(&dims, 1, too_deep) == 0);
+        REFUSED(rnamsm_forward_packed(&dims, weights, toks, 1, too_deep, buf, (size_t)1 << 40, buf, buf, buf, buf, ints, NULL, 0, NULL, NULL));
+        REFUSED(rnamsm_forward_packed(&dims, weights, toks, 2, one_class, buf, 1 << 10, buf, buf, buf, buf, ints, NULL, 0, NULL, NULL));   /* workspace too small */
+        REFUSED(rnamsm_forward_packed(&dims, weights, toks, 2, one_class, buf, (size_t)1 << 40, buf, buf, buf, buf, ints, NULL, 1, NULL, NULL)); /* 16-bit mode without planes */
+        /* a table mixing the two LayerNorm-fold classes (by-shape rule, folded tables given) is refused, not run unfolded */
+        REFUSED(rnamsm_forward_packed(&dims, weights, toks, 2, two_classes, buf, (size_t)1 << 40, buf, buf, buf, buf, ints, weights, 0, NULL, NULL));
+        EXPECT(strstr(rnamsm_last_error(), "mixes alignments below and from 4096 tokens") != NULL);
+    }
     {
         rnamsm_model_dims bad = dims;
         bad.embed_dim = 700;

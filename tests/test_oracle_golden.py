@@ -329,3 +329,77 @@ def test_oracle_matches_the_msm_variant_of_the_model_shell(name):
         assert out["col_attentions"].shape == g["col_attentions"][b].shape == (L, H, C, R, R)
         assert np.abs(out["col_attentions"].numpy() - g["col_attentions"][b]).max() < 2e-5
         assert rel_l2(O.lm_head(out["representation"], params).numpy(), g["logits"][b]) < 1e-5
+
+
+def test_general_mha_restatement_matches_the_reference_on_every_option():
+    """oracle.multihead_attention (cross-attention, kdim / vdim, bias_kv, zero_attn, bias=False, incremental state, static_kv,
+    before_softmax, a finite large-negative attn_mask with key padding) against outputs of the reference itself
+    (tests/golden/mha_general.npz, tests/golden/make_golden_r6.py; msm/multihead_attention.py:154-434)."""
+    import mha_cases as MC
+    g = golden("mha_general.npz")
+    E, H = MC.E, MC.H
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    W = lambda tag, **kw: {k: tt(v) for k, v in MC.weights(tag, **kw).items()}
+
+    def close(a, b, tol=1e-5):
+        a, b = np.asarray(a), np.asarray(b)
+        assert a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b))
+        return rel_l2(np.nan_to_num(a), np.nan_to_num(b)) < tol
+
+    # finite large-negative mask + key padding
+    T, B = (int(v) for v in g["finite.meta"][:2])
+    x = tt(MC.rnd("finite.x", (T, B, E)))
+    y, w = O.multihead_attention(x, x, x, W("finite"), H, key_padding_mask=tt(g["finite.kpm"]), attn_mask=tt(g["finite.attn_mask"]))
+    assert close(y, g["finite.out"]) and np.abs(w.numpy() - g["finite.head_weights"]).max() < 2e-6
+    assert np.abs(w.mean(0).numpy() - g["finite.avg_weights"]).max() < 2e-6
+    # cross-attention
+    for tag, Tq, S in (("short_q", 9, 23), ("long_q", 27, 13)):
+        q, kv = tt(MC.rnd(f"cross.{tag}.q", (Tq, 3, E))), tt(MC.rnd(f"cross.{tag}.kv", (S, 3, E)))
+        y, w = O.multihead_attention(q, kv, kv, W("cross"), H)
+        assert close(y, g[f"cross.{tag}.out"]) and np.abs(w.mean(0).numpy() - g[f"cross.{tag}.avg_weights"]).max() < 2e-6
+        y, w = O.multihead_attention(q, kv, kv, W("cross"), H, key_padding_mask=tt(g[f"cross.{tag}.kpm"]))
+        assert close(y, g[f"cross.{tag}.out_kpm"]) and np.abs(w.numpy() - g[f"cross.{tag}.head_weights_kpm"]).max() < 2e-6
+    # kdim / vdim
+    q, k, v = tt(MC.rnd("kdim.q", (11, 2, E))), tt(MC.rnd("kdim.k", (17, 2, 96))), tt(MC.rnd("kdim.v", (17, 2, 160)))
+    y, w = O.multihead_attention(q, k, v, W("kdim", kdim=96, vdim=160), H)
+    assert close(y, g["kdim.out"]) and np.abs(w.numpy() - g["kdim.head_weights"]).max() < 2e-6
+    # bias_kv + zero_attn
+    x = tt(MC.rnd("biaskv.x", (14, 3, E)))
+    wb = W("biaskv", bias_kv=True)
+    y, w = O.multihead_attention(x, x, x, wb, H, add_zero_attn=True)
+    assert close(y, g["biaskv.out"]) and np.abs(w.mean(0).numpy() - g["biaskv.avg_weights"]).max() < 2e-6
+    y, w = O.multihead_attention(x, x, x, wb, H, add_zero_attn=True, key_padding_mask=tt(g["biaskv.kpm"]),
+                                 attn_mask=tt(MC.rnd("biaskv.am", (14, 14), 0.5)))
+    assert close(y, g["biaskv.out_masked"]) and np.abs(w.numpy() - g["biaskv.head_weights_masked"]).max() < 2e-6
+    # bias=False
+    x = tt(MC.rnd("nobias.x", (10, 2, E)))
+    y, w = O.multihead_attention(x, x, x, W("nobias", bias=False), H)
+    assert close(y, g["nobias.out"]) and np.abs(w.numpy() - g["nobias.head_weights"]).max() < 2e-6
+    # incremental self-attention
+    x = tt(MC.rnd("incr.x", (6, 2, E)))
+    wi, saved, ys = W("incr"), {}, []
+    for s in range(6):
+        y, w = O.multihead_attention(x[s:s + 1], x[s:s + 1], x[s:s + 1], wi, H, saved=saved)
+        ys.append(y)
+    assert close(torch.cat(ys), g["incr.out_steps"]) and np.abs(w.mean(0).numpy() - g["incr.last_weights"]).max() < 2e-6
+    assert close(saved["prev_key"], g["incr.final_prev_key"]) and close(saved["prev_value"], g["incr.final_prev_value"])
+    saved, ys = {}, []
+    for s in range(4):
+        kp = torch.tensor([[False], [True]]) if s == 2 else None
+        ys.append(O.multihead_attention(x[s:s + 1], x[s:s + 1], x[s:s + 1], wi, H, saved=saved, key_padding_mask=kp)[0])
+    assert close(torch.cat(ys), g["incr.out_steps_kpm"]) and np.array_equal(saved["prev_key_padding_mask"].numpy(), g["incr.final_kpm"])
+    # incremental encoder-decoder attention, static_kv
+    enc, q = tt(MC.rnd("incr_ed.enc", (12, 2, E))), tt(MC.rnd("incr_ed.q", (3, 2, E)))
+    we, saved, ekpm = W("incr_ed"), {}, tt(g["incr_ed.kpm"])
+    ys = [O.multihead_attention(q[0:1], enc, enc, we, H, key_padding_mask=ekpm, saved=saved, static_kv=True)[0]]
+    for s in (1, 2):
+        y, w = O.multihead_attention(q[s:s + 1], None, None, we, H, key_padding_mask=ekpm, saved=saved, static_kv=True)
+        ys.append(y)
+    assert close(torch.cat(ys), g["incr_ed.out_steps"]) and np.abs(w.mean(0).numpy() - g["incr_ed.last_weights"]).max() < 2e-6
+    # before_softmax
+    x = tt(MC.rnd("pre.x", (9, 2, E)))
+    sc, vv = O.multihead_attention(x, x, x, W("pre"), H, key_padding_mask=tt(g["pre.kpm"]), attn_mask=tt(MC.rnd("pre.am", (9, 9), 0.3)),
+                                   before_softmax=True)
+    fin = np.isfinite(g["pre.scores"])
+    assert np.array_equal(np.isneginf(sc.numpy()), ~fin) and np.abs(np.where(fin, sc.numpy() - g["pre.scores"], 0)).max() < 2e-5
+    assert close(vv, g["pre.values"])
