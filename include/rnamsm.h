@@ -511,66 +511,43 @@ int rnamsm_timing_get_bound(int category, double* bound_ms, double* mfma_ms, dou
 int rnamsm_timing_get_valu_bound(int category, double* valu_ms);
 void rnamsm_timing_reset(void);
 
-/* Knobs for in-process A/B measurements.  Known names:
+/* Knobs: process-global selectors between SHIPPED kernels / arithmetic rules, for in-process A/B measurements and for the tests that
+ * compare two kernels on the same input.  14 names since round 6 (round 5 had 24: the ten whose A/B was closed -- gemm16_persist,
+ * gemm16_stagger, gemm16_dephase, gemm16_big_rows, gemm16_big_rows_fwd, row16_q16, row16_bk64, row_narrow_rows, gemm_flat_tiles, row_vt --
+ * are constants now, the losing code paths are gone; rnamsm_set_param answers RNAMSM_ERR_INVALID for them).  rnamsm_set_param takes
+ * the knob table's lock exclusively and REFUSES (RNAMSM_ERR_INVALID) while a forward driver is enqueuing on another thread.
  *   "gemm16_dma"  staging of the plane-input 16-bit GEMMs: 0 register-staged, 1 (or 2) LDS-DMA 128x128 tile,
  *                 3 (default) = LDS-DMA 256x256 tile when the problem allows, software-pipelined fragment
  *                 reads and a mid-tile barrier (K tile 64 deep for plain bf16, 32 for the hi/lo modes), 4 = 3 with
- *                 32-deep K tiles for every mode.  Speed only.  (The plain 256x256 kernel that was value 2, the non-staged
- *                 16x16x32 kernel and the epilogue-hiding "gemm16_pp" kernel were removed from the library in round 4; their
- *                 measurements are in EXPERIMENTS.md, the last one's source under tools/probes/.)
+ *                 32-deep K tiles for every mode.  Speed only.
+ *   "gemm16_mfma16"  plain-bf16 256x256 GEMM: 1 (default) = the 16x16x32-MFMA kernel for N > 1024 or K >= 2048, 2 = for every shape,
+ *                 0 = the 32x32x16 kernel.  Results agree to fp32 rounding (the k order inside a step differs).
  *   "gemm_group"  GEMM block order (fp32 kernel and the 256x256 16-bit kernel): row panels per XCD group (0 = chosen
  *                 from the shape, default: 8 for N > 1024, else 1 -- and the fp32 kernel deals a GEMM of <= 512 tiles flat,
  *                 tile = block id; 1 = whole panels).  An XCD's panels beyond its full groups form one smaller group: no padding
- *                 groups (round 4).  Changes HBM-side traffic and speed, never results.
+ *                 groups.  Changes HBM-side traffic and speed, never results.
  *   "gemm_tile"   fp32 GEMM block tile: 0 (default) = 128x128, or 128x64 where that evens out the last round of blocks
- *                 on a small problem, or MIXED (round 5: whole rounds of 128x128 tiles, the tile positions of the last,
+ *                 on a small problem, or MIXED (whole rounds of 128x128 tiles, the tile positions of the last,
  *                 partly empty round cut into their two 128x64 halves); 1 = always 128x128; 2 = always 128x64; 3 = mixed
- *                 wherever a launch has both whole rounds and a tail; 4 = by shape among the two uniform tilings only (round
- *                 4's rule, for A/B).  Results are bit-identical under every tiling: each
- *                 output element sums its K products in the same order.
- *   "row_narrow"  fp32 rnamsm_row_logits / rnamsm_row_apply at C <= 64: 1 (default) = the LDS-free narrow kernels, 0 = the
- *                 128x128 tile kernels.  "row_narrow_rows": alignment rows per block of the narrow row_apply (0 = by shape).
- *                 Speed only, results bit-identical.
- *   "row_vt"      fp32 rnamsm_row_apply: 1 (default) = the V tile is transposed while it is staged (ds_read_b128
- *                 fragments), 0 = staged as it lies in memory.  Speed only, results bit-identical.
- *   "gemm16_persist" / "gemm16_stagger"  256x256 16-bit GEMM: number of persistent blocks that walk the output tiles
- *                 (default 256 = one per CU; 0 = one block per tile) and a per-block start offset in cycles (default 0;
- *                 measured: no effect).  Speed only, results bit-identical.
- *   "gemm16_mfma16"  plain-bf16 256x256 GEMM: 1 (default) = the 16x16x32-MFMA kernel for N > 1024 or K >= 2048, 2 = for every shape,
- *                 0 = the 32x32x16 kernel.  Results agree to fp32 rounding (the k order inside a step differs).
- *   "gemm16_dephase"  256x256 16-bit GEMMs on the 32x32x16 MFMA and the 256x256 row kernels: when the waves issue their LDS-DMA
- *                 requests (a wave is stuck ~100 cycles per request, and while both waves of a SIMD issue at once nobody feeds the
- *                 matrix pipe): 0 = all right after the tile barrier, 1 / 2 (default) = the upper wave group one (micro-)step
- *                 later.  (The 16x16x32 kernels always stage by operand: W by the lower group, A by the upper one, half a tile
- *                 apart: QKV +18 %, fc1 +14 %.)  Speed only, results bit-identical.
- *   "gemm16_big_rows" / "gemm16_big_rows_fwd"  plane-operand 16-bit GEMMs: rows from which the 256x256-tile kernels replace the
- *                 128x128 one -- in rnamsm_gemm_bf16 called directly (default 0 = 2048) and inside rnamsm_forward /
- *                 rnamsm_forward_batch (default 0 = 10752 for plain bf16, 8960 for the hi/lo modes: below ~9-10 k tokens the
- *                 256x256 kernels leave most CUs without a tile; 2048 tokens x1.33 / x1.59, 8192 x1.11 / x1.10).  The hi/lo modes'
- *                 kernels sum every element in the same order (bit-identical); plain bf16 changes MFMA shape (fp32 rounding).
- *   "gemm_flat_tiles"  fp32 GEMM: at most this many tiles (default 512 = the chip's block slots) are dealt flat, tile = block id, instead
- *                 of XCD-aware (A/B: larger values win a stand-alone GEMM and lose inside the forward).  Never changes results.
+ *                 wherever a launch has both whole rounds and a tail; 4 = by shape among the two uniform tilings only.
+ *                 Results are bit-identical under every tiling: each output element sums its K products in the same order.
  *   "gemm_splitk_short"  rnamsm_forward*, the K = 768 GEMMs of a lone small alignment (<= 192 tiles): 0 (default) = off, 2 / 4 = that
  *                 many K ranges with the epilogue applied by the reduction pass (A/B: no gain once the block order was fixed).
- *   "col_fast"    rnamsm_col_attn_fused_prescaled: 1 (default) = first pass without a running maximum, the online softmax as the
- *                 fallback of a block whose row sums leave [2^-64, 2^100]; 0 = the online softmax only (A/B; results agree to rounding).
- *   "row16_q16"   plain bf16 rnamsm_row_logits16 at C >= 384 with C % 8 == 0: 1 (default) = row_logits16q_kernel (256x256 tiles on the
- *                 16x16x32 MFMA, staged by operand, persistent blocks, register-direct epilogue), 0 = the 128x128 kernel.  Changes
- *                 the row split (rnamsm_row_logits16_nsplit) and agrees to fp32 rounding.
- *   "row16_bk64"  plain bf16, C >= 256: 1 (default) = rnamsm_row_apply16 stages 64 keys per tile (whole cache lines per P row, half
- *                 the barriers), 2 = rnamsm_row_logits16 too runs the 256x256-tile kernel with 64-deep tiles (measured equal to
- *                 its 128x128 kernel), 0 = neither.  Results agree to fp32 rounding.
+ *   "row_narrow"  fp32 rnamsm_row_logits / rnamsm_row_apply at C <= 64: 1 (default) = the LDS-free narrow kernels, 0 = the
+ *                 128x128 tile kernels.  Speed only, results bit-identical.
  *   "col_small"   fp32 rnamsm_col_attn_fused at R <= 16: 1 (default) = one wave per (column, head) on v_mfma_f32_16x16x4_f32,
  *                 no LDS; 0 = the 128-query-block kernels.  Results agree to fp32 rounding.
- *   "row16_max_rows"  hi/lo modes of rnamsm_row_logits16: cap on the rows of one partial slab (default 32, 0 = none).
- *                 Shorter fp32 accumulation chains; changes results at the rounding level (and the slab count).
+ *   "col_fast"    rnamsm_col_attn_fused_prescaled: 1 (default) = first pass without a running maximum, the online softmax as the
+ *                 fallback of a block whose row sums leave [2^-64, 2^100]; 0 = the online softmax only (results agree to rounding).
  *   "col_dma"     fp32 rnamsm_col_attn_fused: 1 = K/V chunks staged by LDS-DMA, 32-key chunks, three blocks per CU;
  *                 0 = register-staged 64-key chunks, two blocks per CU; -1 (default) = chosen from the shape.  Speed only
  *                 (the two kernels run the same arithmetic per 32-key tile; results agree to fp32 rounding).
+ *   "row16_max_rows"  hi/lo modes of rnamsm_row_logits16: cap on the rows of one partial slab (default 32, 0 = none).
+ *                 Shorter fp32 accumulation chains; changes results at the rounding level (and the slab count).
  *   "greedy_fused"  rnamsm_greedy_select: 1 (default) = one launch per step (one wave per row) for alignments of up to 3072
  *                 rows, three launches per step (one thread per row) above; 2 = always one; 0 = always three.  Same indices.
  *   "ln_fold"     rnamsm_forward with ln_folded given: 1 (default) = LayerNorm folded into the QKV / fc1 GEMMs, row sums
- *                 left by the out_proj / fc2 epilogues, for MSAs of R*C >= 4096 tokens (rnamsm_get_param("ln_fold_min_tokens"); 18432 until round 5; below that the separate launches
+ *                 left by the out_proj / fc2 epilogues, for MSAs of R*C >= 4096 tokens (rnamsm_get_param("ln_fold_min_tokens"); below that the separate launches
  *                 are faster); 3 = for every shape, and in the 16-bit modes too (ln_folded16; measured neutral there, hence
  *                 not the default); 2 = folded, every GEMM sums the rows it stages itself; 0 = separate LayerNorm launches
  *                 (all agree to fp32 rounding, resp. to the 16-bit mode's rounding).

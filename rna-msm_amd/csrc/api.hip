@@ -161,17 +161,8 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm_tile = value;
         return RNAMSM_OK;
     }
-    if (name && !strcmp(name, "row_vt")) {
-        rnamsm::tuning().row_vt = value != 0;
-        return RNAMSM_OK;
-    }
     if (name && !strcmp(name, "row_narrow")) {
         rnamsm::tuning().row_narrow = value != 0;
-        return RNAMSM_OK;
-    }
-    if (name && !strcmp(name, "row_narrow_rows")) {
-        if (value < 0 || value > 1024) return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: row_narrow_rows must be in [0, 1024]");
-        rnamsm::tuning().row_narrow_rows = value;
         return RNAMSM_OK;
     }
     if (name && !strcmp(name, "attn16")) {
@@ -196,36 +187,6 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().gemm16_mfma16 = value < 0 ? 0 : (value > 2 ? 2 : value);
         return RNAMSM_OK;
     }
-    if (name && !strcmp(name, "gemm16_persist")) {
-        if (value < 0 || value % 8 != 0) return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: gemm16_persist must be a non-negative multiple of 8");
-        rnamsm::tuning().gemm16_persist = value;
-        return RNAMSM_OK;
-    }
-    if (name && !strcmp(name, "gemm16_stagger")) {
-        if (value < 0 || value > 1000000) return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: gemm16_stagger must be in [0, 1e6] cycles");
-        rnamsm::tuning().gemm16_stagger = value;
-        return RNAMSM_OK;
-    }
-    if (name && !strcmp(name, "gemm16_dephase")) {
-        rnamsm::tuning().gemm16_dephase = value < 0 ? 0 : (value > 2 ? 2 : value);
-        return RNAMSM_OK;
-    }
-    if (name && !strcmp(name, "gemm16_big_rows")) {
-        rnamsm::tuning().gemm16_big_rows = value < 0 ? 0 : value;
-        return RNAMSM_OK;
-    }
-    if (name && !strcmp(name, "gemm16_big_rows_fwd")) {
-        rnamsm::tuning().gemm16_big_rows_fwd = value < 0 ? 0 : value;
-        return RNAMSM_OK;
-    }
-    if (name && !strcmp(name, "row16_q16")) {
-        rnamsm::tuning().row16_q16 = value != 0;
-        return RNAMSM_OK;
-    }
-    if (name && !strcmp(name, "row16_bk64")) {
-        rnamsm::tuning().row16_bk64 = value < 0 ? 0 : (value > 2 ? 2 : value);
-        return RNAMSM_OK;
-    }
     if (name && !strcmp(name, "row16_max_rows")) {
         if (value < 0 || value > 1024) return rnamsm::fail(RNAMSM_ERR_INVALID, "set_param: row16_max_rows must be in [0, 1024]");
         rnamsm::tuning().row16_max_rows = value;
@@ -243,10 +204,6 @@ extern "C" int rnamsm_set_param(const char* name, int value) {
         rnamsm::tuning().col_fast = value != 0;
         return RNAMSM_OK;
     }
-    if (name && !strcmp(name, "gemm_flat_tiles")) {
-        rnamsm::tuning().gemm_flat_tiles = value < 0 ? 0 : value;
-        return RNAMSM_OK;
-    }
     if (name && !strcmp(name, "gemm_splitk_short")) {
         rnamsm::tuning().gemm_splitk_short = value <= 0 ? 0 : (value >= 4 ? 4 : 2);
         return RNAMSM_OK;
@@ -261,22 +218,12 @@ extern "C" int rnamsm_get_param(const char* name) {
     if (name && !strcmp(name, "col_small")) return rnamsm::tuning().col_small;
     if (name && !strcmp(name, "col_dma")) return rnamsm::tuning().col_dma;
     if (name && !strcmp(name, "col_fast")) return rnamsm::tuning().col_fast;
-    if (name && !strcmp(name, "gemm_flat_tiles")) return rnamsm::tuning().gemm_flat_tiles;
     if (name && !strcmp(name, "gemm_splitk_short")) return rnamsm::tuning().gemm_splitk_short;
-    if (name && !strcmp(name, "gemm16_dephase")) return rnamsm::tuning().gemm16_dephase;
-    if (name && !strcmp(name, "gemm16_big_rows")) return rnamsm::tuning().gemm16_big_rows;
-    if (name && !strcmp(name, "gemm16_big_rows_fwd")) return rnamsm::tuning().gemm16_big_rows_fwd;
-    if (name && !strcmp(name, "row16_q16")) return rnamsm::tuning().row16_q16;
-    if (name && !strcmp(name, "row16_bk64")) return rnamsm::tuning().row16_bk64;
     if (name && !strcmp(name, "row16_max_rows")) return rnamsm::tuning().row16_max_rows;
-    if (name && !strcmp(name, "gemm16_persist")) return rnamsm::tuning().gemm16_persist;
     if (name && !strcmp(name, "gemm16_mfma16")) return rnamsm::tuning().gemm16_mfma16;
     if (name && !strcmp(name, "gemm_splitk")) return rnamsm::tuning().gemm_splitk;
-    if (name && !strcmp(name, "gemm16_stagger")) return rnamsm::tuning().gemm16_stagger;
-    if (name && !strcmp(name, "row_vt")) return rnamsm::tuning().row_vt;
     if (name && !strcmp(name, "ln_fold_min_tokens")) return (int)rnamsm::LN_FOLD_MIN_TOKENS;      // read-only (common.h)
     if (name && !strcmp(name, "row_narrow")) return rnamsm::tuning().row_narrow;
-    if (name && !strcmp(name, "row_narrow_rows")) return rnamsm::tuning().row_narrow_rows;
     if (name && !strcmp(name, "gemm_tile")) return rnamsm::tuning().gemm_tile;
     if (name && !strcmp(name, "gemm_group")) return rnamsm::tuning().gemm_group;
     return -1;

@@ -82,26 +82,14 @@ struct Tuning {
                                    // 3 = LDS-DMA 256x256 with software-pipelined fragments, BK = 64 for split 1 (default),
                                    // 4 = the same with BK = 32 for every split
     int gemm16_mfma16 = 1;         // plain-bf16 256x256 GEMM: 1 = v_mfma_f32_16x16x32_bf16 (gemm16_q16s_kernel) for wide N, 2 = always, 0 = 32x32x16
-    int gemm16_persist = 256;      // 256x256 16-bit GEMM: > 0 = that many persistent blocks walk the tiles (256 = one per CU; +1-5%, tools/gemm16_persist_ab.py), 0 = one block per tile
-    int gemm16_stagger = 0;        // ... and block b starts (b/8 % 4) x this many cycles late (spreads the store bursts)
-    int gemm16_dephase = 2;        // 256x256 16-bit GEMMs, who issues the LDS-DMA requests when: 0 = every wave right after the tile barrier;
-                                   // 1 = the upper wave group one (micro-)step later; 2 = 1, and the 16x16x32 kernel stages by operand
-                                   // (gemm16_q16s_kernel: W by the lower group, A by the upper one, half a tile apart)
-    int gemm16_big_rows = 0;       // rnamsm_gemm_bf16, plane operands: rows from which the 256x256-tile kernels are used (0 = 2048)
-    int gemm16_big_rows_fwd = 0;   // ... inside rnamsm_forward / rnamsm_forward_batch: 0 = by mode (10752 plain bf16, 8960 hi/lo), > 0 = that many
     int gemm_group = 0;            // fp32 GEMM: row panels per XCD group of the block order (xcd_panel_map_grouped); 0 = by shape
     int gemm_tile = 0;             // fp32 GEMM block tile: 0 = by shape, 1 = always 128x128, 2 = always 128x64, 3 = mixed wherever a launch has whole rounds and a tail, 4 = by shape among the uniform tilings only (round 4's rule, A/B)
-    int gemm_flat_tiles = 512;     // fp32 GEMM: at most this many tiles (the chip's block slots) -> dealt flat (tile = block id) instead of XCD-aware.  Larger values win the stand-alone GEMM A/B up to ~19 k tokens (tools/gemm_ab.py gemm_flat_tiles=512,2048,8192: T = 2064 QKV +28 %, 18944 fc2 +14 %) but LOSE 1-2 % inside the forward, where A was just written by the previous kernel and the XCD-aware order keeps each panel on one XCD (tools/lone_small_profile.py KNOBS=gemm_flat_tiles=4096)
     int gemm_splitk_short = 0;     // rnamsm_forward*, the K = 768 GEMMs of a lone small alignment (<= 192 tiles): K ranges (0 = off: the default -- measured no gain once the block order was fixed; 2, 4), gemm_f32_splitk_factor
     int gemm_splitk = 0;           // rnamsm_forward, fc2 below ~1.4 k tokens: 0 = never (default since round 5: a split chosen by the BATCH's token count made an alignment's bits depend on its company; costs a lone <= 1024-token alignment 0.4 of 2.5 ms, profiles/r05_splitk.log), 1 = four K ranges + an ordered reduction (gemm_f32_splitk_factor), 2 / 4 / 8 = forced (A/B)
-    int row_vt = 1;                // fp32 row_apply: 1 = V tile transposed while staged (b128 fragments), 0 = [k][n] tile
     int row_narrow = 1;            // fp32 K4 / K6 at C <= 64: 1 = the LDS-free narrow kernels (row_logits_narrow / row_apply_narrow; bit-identical), 0 = the 128 x 128 tile kernels (A/B)
-    int row_narrow_rows = 0;       // row_apply_narrow: alignment rows per block (0 = by shape; speed only)
     int col_small = 1;             // fp32 col_attn at R <= 16: 1 = one wave per (column, head), no LDS (col_attn_small_kernel), 0 = the 128-query blocks
     int col_fast = 1;              // fp32 col_attn on prescaled q (rnamsm_col_attn_fused_prescaled): 1 = FAST loop (no running maximum) with the TRACKED loop as fallback, 0 = TRACKED only (A/B)
     int col_dma = -1;              // fp32 col_attn: 1 = LDS-DMA staging, 32-key chunks, 3 blocks/CU; 0 = register-staged kernel; -1 = by shape
-    int row16_bk64 = 1;            // plain bf16 at C >= 256: 1 = row_apply16x on 64-key tiles, 2 = row_logits16 on the 256x256 kernel with 64-deep tiles too, 0 = neither
-    int row16_q16 = 1;             // plain bf16 at C >= 384, C % 8 == 0: 1 = row_logits16q_kernel (16x16x32 MFMA, staged by operand), 0 = the 128x128 kernel
     int row16_max_rows = 32;       // hi/lo modes: cap on the rows of one row_logits16 slab (0 = none): accuracy, DESIGN 3.2
     int ln_fold = 1;               // rnamsm_forward with ln_folded: 1 = LayerNorm applied inside the consuming GEMM (row sums from the producers'
                                    // epilogues) when R*C >= LN_FOLD_MIN_TOKENS (4096), 3 = for every shape, 2 = every GEMM sums its rows itself (A/B), 0 = separate launches
@@ -123,24 +111,22 @@ struct ForwardScope {
 };
 // rnamsm_forward's choice of the 16-bit GEMM tile by the MSA's token count: below ~9-10 k tokens the 256x256 kernels leave most
 // CUs without a tile (out_proj at 8192 tokens: 96 tiles for 256 CUs) and the 128x128 kernel is faster -- whole forward, one
-// process (tools/mid_size_tile_ab.py): 2048 tokens x1.33 (bf16) / x1.59 (f16x3), 4096 x1.14 / x1.32, 8192 x1.11 / x1.10, level at
+// process (round 3's mid-size tile A/B, in the history): 2048 tokens x1.33 (bf16) / x1.59 (f16x3), 4096 x1.14 / x1.32, 8192 x1.11 / x1.10, level at
 // 10 k (bf16) / 9 k (f16x3), 256x256 ahead from there (x0.92 at 12 k, x0.81-0.88 at 60 k).  The hi/lo modes' two kernels sum
 // every output element in the same order: bit-identical either way.
-// The choice is handed down as a THREAD-LOCAL override read by rnamsm_gemm_bf16 (gemm16_big_rows_now): the process-wide knob is
-// never written by a forward, so concurrent forwards from several threads / devices cannot leak their temporary threshold
+// The choice is handed down as a THREAD-LOCAL override read by rnamsm_gemm_bf16 (gemm16_big_rows_now): nothing process-wide is
+// written by a forward, so concurrent forwards from several threads / devices cannot leak their temporary threshold
 // into each other or into later direct rnamsm_gemm_bf16 calls.
 int& gemm16_big_rows_override();                 // api.hip: thread_local, 0 = none
 struct BigRowsScope {
     int saved;
     explicit BigRowsScope(bool plain_bf16) : saved(gemm16_big_rows_override()) {
-        const int fwd = tuning().gemm16_big_rows_fwd;
-        if (tuning().gemm16_big_rows == 0) gemm16_big_rows_override() = fwd > 0 ? fwd : (plain_bf16 ? 10752 : 8960);
+        gemm16_big_rows_override() = plain_bf16 ? 10752 : 8960;
     }
     ~BigRowsScope() { gemm16_big_rows_override() = saved; }
 };
-// rows from which rnamsm_gemm_bf16 uses the 256x256-tile kernels: the user's knob, else the calling forward's choice, else 2048
+// rows from which rnamsm_gemm_bf16 uses the 256x256-tile kernels: the calling forward's choice, else 2048
 inline int64_t gemm16_big_rows_now() {
-    if (tuning().gemm16_big_rows > 0) return tuning().gemm16_big_rows;
     const int o = gemm16_big_rows_override();
     return o > 0 ? o : 2048;
 }
@@ -336,7 +322,7 @@ static inline unsigned xcd_panel_grid_ragged(unsigned num_panels, unsigned inner
 }
 // Group size for PERSISTENT walks (block b takes virtual ids b, b + gridDim, ...): padding ids of a group that is not full
 // recur with the period of the walk, so whole blocks would own nothing but padding (16 row panels in groups of 8: a quarter of
-// the blocks did all the work -- 432 instead of 1136 TFLOP/s on a 4096^3 bf16 GEMM, tools/gemm16_square_knobs.py).  The
+// the blocks did all the work -- 432 instead of 1136 TFLOP/s on a 4096^3 bf16 GEMM, round 4's square-shape A/B).  The
 // largest G <= want that divides the panels per XCD leaves no padding inside the groups.
 static inline unsigned xcd_group_for_persistent(unsigned num_panels, unsigned want) {
     const unsigned local = (num_panels + 7u) / 8u;

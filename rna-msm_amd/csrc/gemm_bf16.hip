@@ -494,6 +494,7 @@ static int launch_hd(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
 // Rows are 64 B (32 halves): physical 16-B chunk = logical chunk ^ ((row >> 2) & 3), again 16 distinct slots per
 // ds_read_b128 lane group.
 constexpr int HX_BM = 256, HX_BN = 256, HX_BK = 32, HX_THREADS = 512;
+constexpr unsigned GEMM16_PERSISTENT_BLOCKS = 256;     // one per CU; a multiple of 8 keeps the XCD affinity of xcd_panel_map_grouped
 constexpr int HX_ROWB = HX_BK * 2;                     // 64 bytes per row
 constexpr int HX_PLANE = 256 * HX_ROWB;                // 16 KB
 template <int SPLIT>
@@ -557,8 +558,7 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     const uint16_t* __restrict__ Ahi, const uint16_t* __restrict__ Alo, int64_t lda, const uint16_t* __restrict__ Whi,
     const uint16_t* __restrict__ Wlo, const float* __restrict__ bias, const float* residual, int64_t ldr, float* Cout,
     int64_t ldc, int M, int N, int K, float scale, int scale_cols, uint16_t* __restrict__ Ohi, uint16_t* __restrict__ Olo,
-    int group, unsigned total_tiles, int stagger_cycles, int dephase_arg, Fold16 fa) {
-    const bool dephase = dephase_arg != 0;                    // uniform
+    int group, unsigned total_tiles, Fold16 fa) {
     using Cfg = HsCfg<SPLIT, BK>;
     constexpr int NPL = Cfg::NPL, ROWB = Cfg::ROWB, PLANE = Cfg::PLANE, KS = Cfg::KS;
     constexpr int NMF = 8 * (SPLIT == 3 ? 3 : 1);          // MFMAs per k step per wave
@@ -572,13 +572,8 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
     const int wm = wv >> 2, wn = wv & 3;
     // Persistent form: gridDim.x blocks (one per CU) walk the output tiles in launch order, block b taking virtual ids
     // b, b + gridDim.x, ... (gridDim.x % 8 == 0 keeps the XCD affinity of xcd_panel_map_grouped).  A tile's stores then
-    // drain while the block already accumulates its next tile, and a start offset per block (stagger_cycles x (b/8 % 4))
-    // spreads the CUs' store bursts over the tile period instead of letting all 256 CUs write at once.
-    if (stagger_cycles > 0) {
-        const unsigned ph = (blockIdx.x >> 3) & 3;
-        const long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (long long)stagger_cycles * ph) __builtin_amdgcn_s_sleep(8);
-    }
+    // drain while the block already accumulates its next tile.  (A start offset per block, to spread the CUs' store bursts over the
+    // tile period, was measured at 3 k .. 20 k cycles and changed nothing: EXPERIMENTS, round 2; removed in round 6.)
     for (unsigned vid = blockIdx.x; vid < total_tiles; vid += gridDim.x) {
     unsigned mpanel, nblk;
     if (!xcd_panel_map_grouped(vid, mp, nb, (unsigned)group, mpanel, nblk)) continue;
@@ -674,18 +669,18 @@ __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_swp_kernel(
         // have landed
         wait_dma_then_barrier<0>();
         const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;         // clamped: the last reload is never read
-        // "gemm16_dephase": a wave is stuck for ~100 cycles per LDS-DMA request it issues (8 per tile); when the two waves of a SIMD issue
+        // DEPHASED ISSUE: a wave is stuck for ~100 cycles per LDS-DMA request it issues (8 per tile); when the two waves of a SIMD issue
         // theirs at the same moment -- right after this barrier -- nobody feeds the matrix pipe meanwhile, so the upper wave group issues
         // one step later.  (Staging by operand as in gemm16_q16s_kernel -- row-half-major micro-steps,
         // W requested half a tile before A -- was built for this kernel too and measured no better than this delay: f16x3 six
         // GEMMs x1.026 against x1.035, plain bf16 QKV x1.01 and fc1 x0.93; EXPERIMENTS.md R3.3.)
-        if (!dephase || wm == 0) issue(k2, kt & 1);
+        if (wm == 0) issue(k2, kt & 1);
         __builtin_amdgcn_sched_barrier(0);
         // last step of tile kt, step 0 of tile kt+1 arriving
         frag_load(nxt, 0, f[0]);
         hx_frag_mma<SPLIT, FMT>(f[(KS - 1) & 1], acc);
         interleave();
-        if (dephase && wm == 1) issue(k2, kt & 1);
+        if (wm == 1) issue(k2, kt & 1);
         __builtin_amdgcn_sched_barrier(0);
     }
     {   // last tile
@@ -734,16 +729,14 @@ static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
                                               : (N / HX_BN > 4 ? (int)xcd_group_for_persistent((M + HX_BM - 1) / HX_BM, 8)
                                                                : (K <= 1024 ? (int)xcd_group_for_persistent((M + HX_BM - 1) / HX_BM, 4) : 1));
     const unsigned total = xcd_panel_grid_grouped((M + HX_BM - 1) / HX_BM, N / HX_BN, (unsigned)group);
-    // "gemm16_persist" = number of persistent blocks (0 = one block per tile, hardware dispatch); "gemm16_stagger" =
-    // start offset step in cycles
-    const unsigned pb = tuning().gemm16_persist > 0 ? (unsigned)tuning().gemm16_persist : 0u;
-    const unsigned grid = pb && pb < total ? pb : total;
+    // 256 persistent blocks (one per CU) walk the tiles: +1-5 % over one block per tile (round 2; the knob went in round 6)
+    const unsigned grid = GEMM16_PERSISTENT_BLOCKS < total ? GEMM16_PERSISTENT_BLOCKS : total;
     // (a folded-LayerNorm producer also writes the new residual stream as planes: the next consumer's A operand)
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K,
                       gemm16_bytes(M, N, K, HxCfg<SPLIT>::NPL, HAS_RES, O_PL) + (fa.xhi ? 2.0 * HxCfg<SPLIT>::NPL * (double)M * N : 0.0),
                       stream, PEAK_F16_MFMA_TFLOPS, SPLIT);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, a_lo, lda, Whi, Wlo, bias, residual, ldr, Cout,
-                       ldc, M, N, K, scale, scale_cols, o_hi, o_lo, group, total, pb ? tuning().gemm16_stagger : 0, tuning().gemm16_dephase, fa);
+                       ldc, M, N, K, scale, scale_cols, o_hi, o_lo, group, total, fa);
     RNAMSM_CHECK_LAUNCH("gemm16_swp");
     return RNAMSM_OK;
 }
@@ -837,8 +830,7 @@ template <int ACT, bool HAS_RES, bool O_PL>
 __global__ __launch_bounds__(HX_THREADS, 1) void gemm16_q16s_kernel(
     const uint16_t* __restrict__ Ahi, int64_t lda, const uint16_t* __restrict__ Whi, const float* __restrict__ bias,
     const float* residual, int64_t ldr, float* Cout, int64_t ldc, int M, int N, int K, float scale, int scale_cols,
-    uint16_t* __restrict__ Ohi, int group, unsigned total_tiles, int dephase_arg, Fold16 fa) {
-    (void)dephase_arg;
+    uint16_t* __restrict__ Ohi, int group, unsigned total_tiles, Fold16 fa) {
     using Cfg = HsCfg<1, 64>;
     constexpr int BK = 64, ROWB = Cfg::ROWB, PLANE = Cfg::PLANE;
     typedef typename Half16<0>::V8 V8;
@@ -1046,11 +1038,10 @@ static int launch_hq(const uint16_t* Whi, const float* bias, const float* residu
     const int group = tuning().gemm_group > 0 ? tuning().gemm_group
                                               : (N / HX_BN > 4 ? (int)xcd_group_for_persistent((M + HX_BM - 1) / HX_BM, 8) : 1);
     const unsigned total = xcd_panel_grid_grouped((M + HX_BM - 1) / HX_BM, N / HX_BN, (unsigned)group);
-    const unsigned pb = tuning().gemm16_persist > 0 ? (unsigned)tuning().gemm16_persist : 0u;
-    const unsigned grid = pb && pb < total ? pb : total;
+    const unsigned grid = GEMM16_PERSISTENT_BLOCKS < total ? GEMM16_PERSISTENT_BLOCKS : total;
     KernelTimer timer(TC_GEMM, 2.0 * M * N * K, gemm16_bytes(M, N, K, 1, HAS_RES, O_PL), stream, PEAK_F16_MFMA_TFLOPS, 1.0);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(HX_THREADS), lds, stream, a_hi, lda, Whi, bias, residual, ldr, Cout, ldc, M, N, K,
-                       scale, scale_cols, o_hi, group, total, tuning().gemm16_dephase, fa);
+                       scale, scale_cols, o_hi, group, total, fa);
     RNAMSM_CHECK_LAUNCH("gemm16_q16");
     return RNAMSM_OK;
 }
@@ -1193,7 +1184,7 @@ extern "C" int rnamsm_gemm_bf16(const float* A, int64_t lda, const uint16_t* W_h
          : launch_hs<ACT_, RES_, SP_, FMT_, OPL_, 32>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s))
 #define HQ_GO(ACT_, RES_, OPL_) \
     launch_hq<ACT_, RES_, OPL_>(W_hi, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, O_hi, s)
-    // rows from which the 256x256-tile kernels take over from the 128x128 one ("gemm16_big_rows"; rnamsm_forward raises it, see there)
+    // rows from which the 256x256-tile kernels take over from the 128x128 one (rnamsm_forward raises it, see there)
     const int64_t big_rows = gemm16_big_rows_now();
 #define HD_GO(ACT_, RES_, SP_, FMT_, OPL_) \
     launch_hd<ACT_, RES_, SP_, FMT_, OPL_>(W_hi, W_lo, bias, residual, ldr, Cout, ldc, lda, m, N, K, scale, scale_cols, A_hi, A_lo, O_hi, O_lo, s)

@@ -296,9 +296,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_f32_mixed_kernel(
     }
 }
 
+// A GEMM of at most this many tiles (the chip's block slots) is dealt flat (tile = block id) instead of XCD-aware.  Larger values win
+// the stand-alone GEMM A/B up to ~19 k tokens (T = 2064 QKV +28 %, 18944 fc2 +14 %) but LOSE 1-2 % inside the forward, where A was just
+// written by the previous kernel and the XCD-aware order keeps each panel on one XCD (a knob until round 6; EXPERIMENTS R4.8).
+constexpr int64_t GEMM_FLAT_TILES = 512;
 static inline int gemm_group_for(int mp, int nb, int NT, int ksplit) {
     return tuning().gemm_group > 0 ? tuning().gemm_group
-                                   : ((int64_t)mp * nb * (ksplit > 1 ? ksplit : 1) <= tuning().gemm_flat_tiles ? 0 : (nb > 8 * (3 - NT) ? 8 : 1));
+                                   : ((int64_t)mp * nb * (ksplit > 1 ? ksplit : 1) <= GEMM_FLAT_TILES ? 0 : (nb > 8 * (3 - NT) ? 8 : 1));
 }
 
 template <int ACT, bool HAS_RES, int ZROWS, int NT, int FOLD = 0, bool STATS = false>
@@ -322,7 +326,7 @@ static int launch_gemm_nt(const float* A, int64_t lda, const float* W, const flo
     // launch; same speed, the kernel is MFMA-bound).  N = 768 (6 column blocks) is already balanced and stays ungrouped.
     const int nb = N / Cfg::BN_;
     // (round 4) no padding groups: an XCD's last panels form a smaller group (xcd_panel_map_ragged); and a GEMM with no more tiles
-    // than the chip has block slots ("gemm_flat_tiles", 512) is dealt FLAT (group 0: tile = block id), so that a lone small
+    // than the chip has block slots (GEMM_FLAT_TILES, 512) is dealt FLAT (group 0: tile = block id), so that a lone small
     // alignment's 18-24 column tiles run on as many CUs of all XCDs instead of on one XCD's
     const int mp_ = (M + BM - 1) / BM;
     const int group = gemm_group_for(mp_, nb, NT, ksplit);
@@ -385,7 +389,7 @@ static inline TilePlan tile_plan(int M, int N) {
     long full = tiles / 512 * 512;
     const long common = 8 * (mp / 8) * nb;
     while (full > common) full -= 512;
-    const bool can_mix = full > 0 && full < tiles && tiles > tuning().gemm_flat_tiles && tuning().gemm_group <= 0;
+    const bool can_mix = full > 0 && full < tiles && tiles > GEMM_FLAT_TILES && tuning().gemm_group <= 0;
     if (t == 1) return {0, 0};
     if (t == 2) return {1, 0};
     if (t == 3) return can_mix ? TilePlan{2, (unsigned)full} : TilePlan{0, 0};

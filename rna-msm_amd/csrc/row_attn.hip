@@ -593,7 +593,6 @@ static inline bool narrow_fits(int R, int C, int64_t ld, int64_t ldc) {
     return (int64_t)R * C * ld * 4 < lim && (int64_t)R * C * ldc * 4 < lim;
 }
 static inline int narrow_rows_per_block(int64_t rows_total, int H) {
-    if (tuning().row_narrow_rows > 0) return (tuning().row_narrow_rows + 3) & ~3;
     int64_t rpb = (rows_total * H + 1023) / 1024;
     rpb = (rpb + 3) & ~(int64_t)3;
     return (int)(rpb < 4 ? 4 : rpb > 32 ? 32 : rpb);
@@ -774,7 +773,7 @@ static int row_apply_launch(const float* probs, const float* v, int64_t ld, floa
     } while (0)
 #define RA_GO(AL_, OUT_)                                                                                          \
     do {                                                                                                          \
-        if (tuning().row_vt) RA_GO2(AL_, OUT_, true); else RA_GO2(AL_, OUT_, false);                              \
+        RA_GO2(AL_, OUT_, true);       /* V tile transposed while staged (b128 fragments); the [k][n] tile went in round 6 */ \
     } while (0)
     if (al) {
         if (out == 0) RA_GO(true, 0); else if (out == 1) RA_GO(true, 1); else RA_GO(true, 2);
@@ -919,7 +918,7 @@ int row_apply_packed(const float* row_attn, int layer, const float* v, int64_t l
         hipLaunchKernelGGL((row_apply_kernel<false, 0, VT_>), dim3(grid, B), dim3(GEMM_THREADS), lds_, s, row_attn, v, ld, ctx, ldc, 0, 0, \
                            H, (uint16_t*)nullptr, (uint16_t*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, pk, layer, narrow_on ? 1 : 0);  \
     } while (0)
-    if (tuning().row_vt) RA_PK(true); else RA_PK(false);
+    RA_PK(true);
 #undef RA_PK
     RNAMSM_CHECK_LAUNCH("row_apply (packed)");
     return RNAMSM_OK;

@@ -304,8 +304,7 @@ template <int SPLIT, int FMT, int BK>
 __global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
     const uint16_t* __restrict__ qhi, const uint16_t* __restrict__ qlo, const uint16_t* __restrict__ khi,
     const uint16_t* __restrict__ klo, int64_t ld, float* __restrict__ partial, int R, int C, int H, int nsplit,
-    int rows_per_split, float scale, int64_t qk_bstride, int64_t part_bstride, const int* __restrict__ true_rows, int dephase_arg) {
-    const bool dephase = dephase_arg != 0;                   // uniform
+    int rows_per_split, float scale, int64_t qk_bstride, int64_t part_bstride, const int* __restrict__ true_rows) {
     // batched launch (rnamsm_forward_batch, 16-bit modes): MSA blockIdx.y; a ragged batch scales every MSA's logits by its own depth
     qhi += blockIdx.y * qk_bstride;
     khi += blockIdx.y * qk_bstride;
@@ -417,12 +416,12 @@ __global__ __launch_bounds__(512, 1) void row_logits16x_kernel(
         // every wave is done reading `cur` once its last fragments have arrived; tile kt+1 (issued one tile ago) must have landed
         wait_dma_then_barrier<0>();
         const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;        // clamped: the last reload is never read
-        if (!dephase || wm == 0) issue(k2, kt & 1);          // "gemm16_dephase": the upper wave group issues one step later (gemm_bf16.hip)
+        if (wm == 0) issue(k2, kt & 1);                      // dephased issue: the upper wave group issues one step later (gemm_bf16.hip)
         __builtin_amdgcn_sched_barrier(0);
         frag_load(nxt, 0, f[0]);
         frag_mma(f[(KS - 1) & 1], acc);
         interleave();
-        if (dephase && wm == 1) issue(k2, kt & 1);
+        if (wm == 1) issue(k2, kt & 1);
         __builtin_amdgcn_sched_barrier(0);
     }
     {
@@ -668,7 +667,7 @@ __global__ __launch_bounds__(512, 1) void row_logits16q_kernel(
 #endif
 constexpr int R16X_THREADS = 512;
 // KT = keys per K tile: 32 (64-B P rows; the hi/lo modes: four planes per stage) or 64 (128-B P rows = whole cache lines per
-// DMA row, half the barriers; plain bf16 only, knob "row16_bk64": two 64 KB stages)
+// DMA row, half the barriers; plain bf16 only: two 64 KB stages)
 template <int SPLIT, int KT>
 struct R16XCfg {
     static constexpr int NPL = SPLIT == 3 ? 2 : 1;
@@ -694,8 +693,7 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
     const uint16_t* __restrict__ phi, const uint16_t* __restrict__ plo, int64_t ldp, const uint16_t* __restrict__ vhi,
     const uint16_t* __restrict__ vlo, int64_t ld, float* __restrict__ ctx, int64_t ldc, int R, int C, int H,
     uint16_t* __restrict__ ctx_hi, uint16_t* __restrict__ ctx_lo, float out_scale, int64_t p_bstride, int64_t v_bstride,
-    int64_t ctx_bstride, int dephase_arg) {
-    const bool dephase = dephase_arg != 0;                   // uniform
+    int64_t ctx_bstride) {
     phi += blockIdx.y * p_bstride;                           // batched launch: MSA blockIdx.y
     vhi += blockIdx.y * v_bstride;
     if (plo) plo += blockIdx.y * p_bstride;
@@ -835,12 +833,12 @@ __global__ __launch_bounds__(R16X_THREADS, 1) void row_apply16x_kernel(
         // every wave is done reading `cur` once its last fragments have arrived; tile kt+1 (issued one tile ago) must have landed
         wait_dma_then_barrier<0>();
         const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;              // clamped: the last reload is never read
-        if ((!dephase || wm == 0) && !(R16X_WHATIF & 2)) issue(k2, kt & 1);                // "gemm16_dephase": the upper wave group issues one step later
+        if (wm == 0 && !(R16X_WHATIF & 2)) issue(k2, kt & 1);                              // dephased issue: the upper wave group issues one step later
         __builtin_amdgcn_sched_barrier(0);
         frag_load(nxt, 0, f[0]);
         frag_mma(f[(KS - 1) & 1], acc, next_set_t());
         interleave();
-        if (dephase && wm == 1 && !(R16X_WHATIF & 2)) issue(k2, kt & 1);
+        if (wm == 1 && !(R16X_WHATIF & 2)) issue(k2, kt & 1);
         __builtin_amdgcn_sched_barrier(0);
     }
     {
@@ -891,16 +889,16 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 // The 256x256 kernel (and the 256-slot row split that goes with it) is used for C >= 256 in the hi/lo modes: measured at
 // cfg3 in one process, split 3 0.40 -> 0.34 ms, but plain bf16 0.166 -> 0.185 ms (its 128x128 kernel already runs
 // 64-deep tiles of whole cache lines with two blocks per CU), so split 1 stays on 128x128.  "attn16" = 2 forces 128x128.
-// Round 3: the 256x256 kernel with 64-deep K tiles (whole cache lines per DMA row) for plain bf16, knob "row16_bk64" = 2:
+// Round 3: the 256x256 kernel with 64-deep K tiles (whole cache lines per DMA row) for plain bf16 (a knob until round 6):
 // 0.165-0.170 ms against 0.167-0.170 ms on the 128x128 kernel (cfg3, one process) -- no gain, stays off.  The same tile
-// depth in row_apply16x (64 keys per tile, "row16_bk64" >= 1) is the default: 0.215 -> 0.192 ms.
+// depth in row_apply16x (64 keys per tile) is what plain bf16 runs: 0.215 -> 0.192 ms.
 // Round 4: plain bf16 at C >= 384 (at C = 256 the 128x128 kernel's 2 blocks per CU win: 0.047 vs 0.054 ms at 128 x 256) with C % 8 == 0 takes row_logits16q_kernel (256x256 tiles on the 16x16x32 MFMA, staged by
-// operand; knob "row16_q16", default on): the same 256-slot row split as the other 256x256 kernel.
+// operand): the same 256-slot row split as the other 256x256 kernel.
 static inline bool row_logits16_q16(int C, bool split3) {
-    return !split3 && tuning().row16_q16 != 0 && C >= 384 && C % 8 == 0 && tuning().attn16 != 2;
+    return !split3 && C >= 384 && C % 8 == 0 && tuning().attn16 != 2;
 }
 static inline bool row_logits16_big(int C, bool split3) {
-    return ((split3 || tuning().row16_bk64 >= 2) && C >= 256 && tuning().attn16 != 2) || row_logits16_q16(C, split3);
+    return (split3 && C >= 256 && tuning().attn16 != 2) || row_logits16_q16(C, split3);
 }
 // row split of the 16-bit logits kernels; the hi/lo modes cap a slab's rows ("row16_max_rows", see row_split.h and DESIGN 3.2)
 static inline RowSplit row_split16(int R, int C, int H, bool big, bool split3) {
@@ -962,22 +960,22 @@ static int row_logits16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const
     KernelTimer timer(TC_ROW_LOGITS, 2.0 * batch * H * C * C * R * 64,
                       batch * ((q_lo ? 4.0 : 2.0) * 2.0 * R * C * H * 64 + 4.0 * (double)sp.nsplit * H * C * C), s, PEAK_F16_MFMA_TFLOPS,
                       q_lo ? 3.0 : 1.0);
+#define RL_BIG(SP_, FMT_)                                                                                           \
+    do {                                                                                                            \
+        constexpr int BKX_ = SP_ == 1 ? 64 : 32;                                                                    \
+        static DeviceOnce cfgx_;                                                                                    \
+        if (cfgx_.pending()) {                                                                                      \
+            int rc = set_lds16(row_logits16x_kernel<SP_, FMT_, BKX_>, R16LCfg<SP_, BKX_>::LDS, "row_logits16x");    \
+            if (rc) return rc;                                                                                      \
+            cfgx_.mark();                                                                                           \
+        }                                                                                                           \
+        hipLaunchKernelGGL((row_logits16x_kernel<SP_, FMT_, BKX_>), dim3(grid, batch), dim3(512), (R16LCfg<SP_, BKX_>::LDS), s, q_hi, q_lo,  \
+                           k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale, qk_bstride, part_bstride, true_rows); \
+    } while (0)
 #define RL_GO(SP_, FMT_)                                                                                            \
     do {                                                                                                            \
-        if (big) {                                                                                                  \
-            constexpr int BKX_ = SP_ == 1 ? 64 : 32;                                                                \
-            static DeviceOnce cfgx_;                                                                              \
-            if (cfgx_.pending()) {                                                                                           \
-                int rc = set_lds16(row_logits16x_kernel<SP_, FMT_, BKX_>, R16LCfg<SP_, BKX_>::LDS, "row_logits16x");  \
-                if (rc) return rc;                                                                                  \
-                cfgx_.mark();                                                                                       \
-            }                                                                                                       \
-            hipLaunchKernelGGL((row_logits16x_kernel<SP_, FMT_, BKX_>), dim3(grid, batch), dim3(512), (R16LCfg<SP_, BKX_>::LDS), s, q_hi, q_lo,  \
-                               k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale, qk_bstride, part_bstride, true_rows, tuning().gemm16_dephase); \
-            break;                                                                                                  \
-        }                                                                                                           \
-        static DeviceOnce cfg_;                                                                                   \
-        if (cfg_.pending()) {                                                                                                \
+        static DeviceOnce cfg_;                                                                                     \
+        if (cfg_.pending()) {                                                                                       \
             int rc = set_lds16(row_logits16_kernel<SP_, FMT_>, R16Cfg<SP_>::LDS, "row_logits16");                  \
             if (rc) return rc;                                                                                      \
             cfg_.mark();                                                                                            \
@@ -986,8 +984,11 @@ static int row_logits16_launch(const uint16_t* q_hi, const uint16_t* q_lo, const
                            q_lo, k_hi, k_lo, ld, partial, R, C, H, sp.nsplit, sp.rows_per_split, scale, qk_bstride, part_bstride, true_rows); \
     } while (0)
     RNAMSM_NO_BF16X3(q_lo && fmt == 0, "row_logits16");
+    // (plain bf16 on 256x256 tiles is row_logits16q_kernel, launched above; the 64-deep 32x32x16 variant measured level and went in round 6)
     if (!q_lo) RL_GO(1, 0);
+    else if (big) RL_BIG(3, 1);
     else RL_GO(3, 1);
+#undef RL_BIG
 #undef RL_GO
     RNAMSM_CHECK_LAUNCH("row_logits16");
     return RNAMSM_OK;
@@ -1021,7 +1022,7 @@ static int launch_apply16x(unsigned grid, int batch, hipStream_t s, const uint16
         cfg.mark();
     }
     hipLaunchKernelGGL(kern, dim3(grid, batch), dim3(R16X_THREADS), lds, s, p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H,
-                       ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride, tuning().gemm16_dephase);
+                       ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride);
     return RNAMSM_OK;
 }
 
@@ -1056,9 +1057,7 @@ static int row_apply16_launch(const uint16_t* p_hi, const uint16_t* p_lo, int64_
 #define RA_GO(SP_, FMT_, OUT_)                                                                                      \
     do {                                                                                                            \
         if (big) {                                                                                                  \
-            int rc = SP_ == 1 && tuning().row16_bk64                                                                \
-                         ? launch_apply16x<SP_, FMT_, OUT_, (SP_ == 1 ? 64 : 32)>(grid, batch, s, p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride) \
-                         : launch_apply16x<SP_, FMT_, OUT_, 32>(grid, batch, s, p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride); \
+            int rc = launch_apply16x<SP_, FMT_, OUT_, (SP_ == 1 ? 64 : 32)>(grid, batch, s, p_hi, p_lo, ldp, v_hi, v_lo, ld, ctx, ldc, R, C, H, ctx_hi, ctx_lo, out_scale, p_bstride, v_bstride, ctx_bstride); \
             if (rc) return rc;                                                                                      \
             break;                                                                                                  \
         }                                                                                                           \

@@ -125,20 +125,12 @@ def test_row_kernels_16bit_are_exact_on_integers(dev, split, fmt, R, C):
 
 @pytest.mark.parametrize("R,C,H", [(8, 300, 2), (5, 520, 1), (9, 257, 2), (4, 256, 1), (3, 300, 1), (64, 512, 12), (1, 256, 1)])
 def test_plain_bf16_row_kernels_with_64_deep_tiles(dev, R, C, H):
-    """Knob row16_bk64: plain bf16 at C >= 256 on the 256x256 row kernels with 64-deep K tiles (2: whole alignment rows per
-    logits tile; >= 1, the default: 64 keys per apply tile; 0: the 32-key apply tiles) -- same references and bounds for every
-    setting, plus the integer case."""
-    from rnamsm import _lib
-    lib = _lib.load()
-    try:
-        for knob in (2, 0):
-            _lib.check(lib.rnamsm_set_param(b"row16_bk64", knob))
-            assert lib.rnamsm_get_param(b"row16_bk64") == knob
-            test_row_attention_16bit(dev, R, C, H, 1, 0, 2e-6, 8e-3)
-            if H == 2:
-                test_row_kernels_16bit_are_exact_on_integers(dev, 1, 0, R, C)
-    finally:
-        _lib.check(lib.rnamsm_set_param(b"row16_bk64", 1))
+    """Plain bf16 at C >= 256: rnamsm_row_apply16 stages 64 keys per tile (whole cache lines per P row), the logits run on
+    row_logits16q_kernel from C >= 384 -- the shapes around those switches against the usual references and bounds, plus the integer
+    case.  (The 32-key apply tiles and the 64-deep 32x32x16 logits variant of the removed knob "row16_bk64" went in round 6.)"""
+    test_row_attention_16bit(dev, R, C, H, 1, 0, 2e-6, 8e-3)
+    if H == 2:
+        test_row_kernels_16bit_are_exact_on_integers(dev, 1, 0, R, C)
 
 
 def _col_ref(q, k, v):

@@ -19,6 +19,17 @@ def test_seeded_forward_fuzz_has_no_violation(seed):
     assert bad == 0, "\n".join(line for line in lines if line.startswith("BAD"))
 
 
+def test_forward_fuzz_with_mixed_tile_gemm_plans_and_tile_bit_identity():
+    """the mixed-tile fp32 GEMM (the default choice of every mid-size Linear, with the FOLD / STATS epilogues) was outside
+    the forward fuzz's knob and size space.  Every second case here is an 18 k .. 40 k-token alignment (whole rounds of 512 tiles plus
+    a tail), gemm_tile drawn from 0..4, and on those cases uniform 128x128 tiles and mixed plans must give the same bits."""
+    import fuzz_forward
+    lines = []
+    bad = fuzz_forward.run(cases=4, seed=61, max_tokens=2500, log=lines.append, big_every=2)
+    assert bad == 0, "\n".join(line for line in lines if line.startswith("BAD"))
+    assert sum(1 for line in lines if line.startswith("ok") and int(line.split("R=")[1].split()[0]) * int(line.split("C=")[1].split()[0]) >= 18000) == 2, lines
+
+
 def test_tall_narrow_alignments_where_the_reference_itself_is_noisy():
     """R >> C: tied logits are sums over R x 64 products; the reference's blocked CPU sgemm is up to 7e-3 off the truth on
     the maps there, the exact path (512-term chains) stays at 1e-4 .. 3e-4."""

@@ -1170,15 +1170,14 @@ def test_16x16x32_gemm_with_the_next_tile_requested_before_the_stores(dev, M, N,
 @pytest.mark.parametrize("split,fmt", [(1, 0), (3, 1)])
 @pytest.mark.parametrize("M,N,K,kind", [(16384, 2304, 768, "planes"), (9000, 3072, 768, "gelu"), (8200, 768, 3072, "residual"),
                                         (4100, 768, 768, "residual"), (2048, 1280, 128, "planes")])
-def test_dma_issue_schedules_of_the_256x256_gemms_are_bit_identical(dev, M, N, K, kind, split, fmt):
-    """Knob "gemm16_dephase": 0 = every wave issues its LDS-DMA requests right after the tile barrier, 1 = the upper wave group one
-    (micro-)step later, 2 (default) = 1, and the plain-bf16 16x16x32 kernel stages by operand behind two barriers per tile with a
-    counted vmcnt (gemm16_q16s_kernel; also taken by fc2, K >= 2048).  Pure scheduling: outputs must be bit-identical across the
-    three settings and across reruns (a wave that reads LDS ahead of a DMA shows as a rare mismatch: many tiles per block, ragged
-    last row panels, 2 .. 48 K tiles)."""
-    from rnamsm import ops, _lib
+def test_the_256x256_gemms_are_bit_identical_across_reruns(dev, M, N, K, kind, split, fmt):
+    """The 256x256 16-bit GEMMs overlap LDS-DMA writes with fragment reads behind counted waits (the upper wave group issues its
+    requests one micro-step after the lower one; the plain-bf16 16x16x32 kernel stages by operand behind two barriers per tile --
+    gemm16_q16s_kernel, also taken by fc2, K >= 2048).  A wave that reads LDS ahead of a DMA shows as a rare mismatch: many tiles
+    per block, ragged last row panels, 2 .. 48 K tiles, twelve reruns bit-identical; plain-bf16 fc2 also against float64.
+    (Until round 6 this test walked the issue schedules of the removed knob "gemm16_dephase": all bit-identical.)"""
+    from rnamsm import ops
     from rnamsm._lib import ACT_GELU_ERF
-    lib = _lib.load()
     lo = split == 3
     a = ops.split_bf16(_rand("dp.a", (M, K)).to(dev), want_lo=lo, fmt=fmt)
     w = ops.split_bf16(_rand("dp.w", (N, K), 0.05).to(dev), want_lo=lo, fmt=fmt)
@@ -1191,27 +1190,14 @@ def test_dma_issue_schedules_of_the_256x256_gemms_are_bit_identical(dev, M, N, K
         out = ops.linear_planes(a, w, b, act=ACT_GELU_ERF if kind == "gelu" else 0, out_planes=True, fmt=fmt)
         return [t for t in out if t is not None]
 
-    assert lib.rnamsm_get_param(b"gemm16_dephase") == 2
-    try:
-        want = None
-        for dp in (2, 0, 1, 2):
-            _lib.check(lib.rnamsm_set_param(b"gemm16_dephase", dp))
-            for _ in range(6):
-                got = [t.clone() for t in run()]
-                if want is None:
-                    want = got
-                # (plain bf16 at K >= 2048 switches MFMA shape with the knob: fc2 is compared per setting below)
-                same_kernel = not (split == 1 and K >= 2048 and N <= 1024)
-                if same_kernel:
-                    assert all(torch.equal(g, w_) for g, w_ in zip(got, want)), (dp, kind)
-            if split == 1 and K >= 2048 and N <= 1024:
-                again = [t.clone() for t in run()]
-                assert all(torch.equal(g, w_) for g, w_ in zip(again, got)), (dp, kind)          # reruns identical per setting
-                ht = torch.bfloat16
-                base = a[0].view(ht).double() @ w[0].view(ht).double().t() + b.double() + r.double()
-                assert rel_l2(got[0].double().cpu(), base.cpu()) < 2e-6
-    finally:
-        _lib.check(lib.rnamsm_set_param(b"gemm16_dephase", 2))
+    want = [t.clone() for t in run()]
+    for _ in range(12):
+        got = [t.clone() for t in run()]
+        assert all(torch.equal(g, w_) for g, w_ in zip(got, want)), kind
+    if split == 1 and K >= 2048 and N <= 1024:
+        ht = torch.bfloat16
+        base = a[0].view(ht).double() @ w[0].view(ht).double().t() + b.double() + r.double()
+        assert rel_l2(want[0].double().cpu(), base.cpu()) < 2e-6
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 2304, 96), (4100, 1280, 64), (1025, 768, 768), (129, 3072, 32), (9000, 2304, 64),

@@ -9,9 +9,6 @@ import torch
 from rnamsm import _lib, ops
 R, C, H = int(os.environ.get("R", 256)), int(os.environ.get("C", 512)), 12
 VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "1").split(",")]
-BK64 = [int(v) for v in os.environ.get("BK64", "1").split(",")]
-Q16 = [int(v) for v in os.environ.get("Q16", "1").split(",")]               # rnamsm_set_param("row16_q16", v) (plain bf16 logits)
-DEPHASE = [int(v) for v in os.environ.get("DEPHASE", "2").split(",")]       # rnamsm_set_param("gemm16_dephase", v)           # rnamsm_set_param("row16_bk64", v) (plain bf16 only)
 D = 64 * H
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -35,19 +32,13 @@ for name, split, fmt in (("bf16", 1, 0), ("f16x3", 3, 1)):
     line = [name]
     for rnd in range(int(os.environ.get("ROUNDS", 1))):
         for var in VARIANTS:
-            for bk in (BK64 if split == 1 else [0]):
-                for dp, q16 in [(d, q) for d in DEPHASE for q in (Q16 if split == 1 else [1])]:
-                    _lib.check(lib.rnamsm_set_param(b"row16_q16", q16))
+            for _ in (0,):
+                for _ in (0,):
                     _lib.check(lib.rnamsm_set_param(b"attn16", var))
-                    _lib.check(lib.rnamsm_set_param(b"row16_bk64", bk))
-                    _lib.check(lib.rnamsm_set_param(b"gemm16_dephase", dp))
                     t1 = timeit(lambda: ops.row_logits16(q, k, R, C, H, fmt=fmt, scale=ops.row_scaling(R)))
                     t2 = timeit(lambda: ops.row_apply16(pp, vv, R, C, H, fmt=fmt, out_scale=1 / 4096.0))
                     t3 = timeit(lambda: ops.col_attn16(q, k, vv, R, C, H, fmt=fmt, scale=0.125, out_planes=True))
                     t4 = timeit(lambda: ops.col_attn16(q, k, vv, R, C, H, fmt=0, out_planes=True, prescaled=True)) if fmt == 0 else float("nan")
-                    line.append(f"[v{var} bk64={bk} dephase={dp} q16={q16}] logits {t1:.3f} apply {t2:.3f} col {t3:.3f} col(prescaled q) {t4:.3f} ms")
+                    line.append(f"[v{var}] logits {t1:.3f} apply {t2:.3f} col {t3:.3f} col(prescaled q) {t4:.3f} ms")
     _lib.check(lib.rnamsm_set_param(b"attn16", 1))
-    _lib.check(lib.rnamsm_set_param(b"row16_q16", 1))
-    _lib.check(lib.rnamsm_set_param(b"row16_bk64", 1))
-    _lib.check(lib.rnamsm_set_param(b"gemm16_dephase", 2))
     print(" ".join(line), flush=True)

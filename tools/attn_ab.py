@@ -35,11 +35,3 @@ print(f"row_logits {t:.3f} ms  {2.0 * H * C * C * R * 64 / t / 1e9:.1f} TF (nspl
 probs = ops.softmax_rows(part)
 t = timeit(lambda: ops.row_apply(probs, v, R, C, H, out=ctx))
 print(f"row_apply  {t:.3f} ms  {2.0 * H * C * C * R * 64 / t / 1e9:.1f} TF")
-# row_apply: V tile transposed while staged (row_vt=1) vs the [k][n] tile (row_vt=0)
-lib = _lib.load()
-for rep in range(2):
-    for vt in (0, 1):
-        lib.rnamsm_set_param(b"row_vt", vt)
-        t = timeit(lambda: ops.row_apply(probs, v, R, C, H, out=ctx))
-        print(f"row_apply row_vt={vt} {t:.3f} ms  {2.0 * H * C * C * R * 64 / t / 1e9:.1f} TF")
-lib.rnamsm_set_param(b"row_vt", 1)

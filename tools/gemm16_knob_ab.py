@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Plain-bf16 plane GEMMs under knob settings, interleaved rounds in one process (the pool's devices differ and the chip
-is power-managed: only same-process numbers compare).  CONFIGS="base;gemm16_mfma16=2;gemm16_mfma16=0,gemm16_persist=0"
+is power-managed: only same-process numbers compare).  CONFIGS="base;gemm16_mfma16=2;gemm16_mfma16=0,gemm_group=1"
 (first = the reference for the diff and the ratio), T=..., ROUNDS=..., FORWARD=1 adds the whole bf16 forward at M=256 L=512."""
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -35,12 +35,9 @@ for shape in os.environ.get("SHAPES", "512x36,64x40,300x17,128x64,1024x60").spli
                 probs = ops.softmax_rows(partial, logit_scale=ops.depth_scaling(R))
                 res.setdefault(("logits", narrow), []).append(timed(lambda: ops.row_logits(g[:, :D], g[:, D:2 * D], R, C, H)))
                 res.setdefault(("softmax", narrow), []).append(timed(lambda: ops.softmax_rows(partial, logit_scale=ops.depth_scaling(R))))
-                for rpb in (RPB if narrow else [0]):
-                    ops.set_param("row_narrow_rows", rpb)
-                    res.setdefault(("apply", narrow, rpb), []).append(timed(lambda: ops.row_apply(probs, g[:, 2 * D:], R, C, H)))
-                ops.set_param("row_narrow_rows", 0)
+                res.setdefault(("apply", narrow, 0), []).append(timed(lambda: ops.row_apply(probs, g[:, 2 * D:], R, C, H)))
     finally:
-        ops.set_param("row_narrow", 1); ops.set_param("row_narrow_rows", 0)
+        ops.set_param("row_narrow", 1)
     hbm = 2.0 * R * C * H * 64 * 4 / 1e6
     print(f"{R} x {C} (nsplit {ns}; q+k or v+ctx = {hbm:.1f} MB = {hbm / 6.3:.1f} us at 6.3 TB/s): " +
           " | ".join(f"{k[0]}{'' if len(k) < 3 or not k[2] else '/rpb' + str(k[2])} {'narrow' if k[1] else 'tile'} {statistics.median(v):.1f} us"
