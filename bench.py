@@ -804,7 +804,7 @@ def run_rank(args) -> int:
         bf16_mode = measure_mode("bf16", 1.0)
         bf16_mode["accuracy"] = ("tests/test_gpu_fullsize.py holds this mode to 1.5x the drift of the reference's own "
                                  ".bfloat16() arithmetic against an fp64 truth at every BASELINE size "
-                                 "(profiles/r05_fullsize_parity.json)")
+                                 "(profiles/r06_fullsize_parity.json)")
 
     # ---- every BASELINE config on the driver-run line (N = 1): one MSA of each shape, 1 warm-up + 2 timed forwards with the
     # hooks off, then one instrumented forward for the per-launch roofline sums

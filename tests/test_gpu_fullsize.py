@@ -7,7 +7,7 @@ error the reference's OWN arithmetic makes against the same truth (the oracle in
     bf16 (configs[4])  :  drift(HIP bf16) <= 1.5 x drift(oracle .bfloat16())
 
 i.e. the kernels are held to the reference's own fp32 (bf16) noise at the size in question instead of to a free
-tolerance.  Every number is appended to gpurun_out/r05_fullsize_parity.json (copied to profiles/ when committed).
+tolerance.  Every number is appended to gpurun_out/r06_fullsize_parity.json (copied to profiles/ when committed).
 """
 import json
 import os
@@ -35,7 +35,7 @@ def model():
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     REPORT["_device"] = torch.cuda.get_device_name(0)
-    with open(os.path.join(out_dir, "r05_fullsize_parity.json"), "w") as f:
+    with open(os.path.join(out_dir, "r06_fullsize_parity.json"), "w") as f:
         json.dump(REPORT, f, indent=1)
 
 
