@@ -304,6 +304,12 @@ def col_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, R: int, C: int, 
                                                                _rowmajor(ctx, "ctx"), R, C, H, HEAD_DIM, R if q_rows is None else q_rows,
                                                                _stream()))
         return ctx
+    if q_rows is not None:      # only the first q_rows query rows are computed and stored (rnamsm_col_attn_fused_queries)
+        _lib.check(_lib.load().rnamsm_col_attn_fused_queries(_dev(q, "q"), _dev(k, "k"), _dev(v, "v"), ld, _dev(ctx, "ctx"),
+                                                             _rowmajor(ctx, "ctx"), R, C, H, HEAD_DIM, q_rows,
+                                                             None if pad_mask is None else _dev(pad_mask, "pad_mask", torch.uint8),
+                                                             F32, _stream()))
+        return ctx
     _lib.check(_lib.load().rnamsm_col_attn_fused(_dev(q, "q"), _dev(k, "k"), _dev(v, "v"), ld, _dev(ctx, "ctx"),
                                                  _rowmajor(ctx, "ctx"), R, C, H, HEAD_DIM,
                                                  None if pad_mask is None else _dev(pad_mask, "pad_mask", torch.uint8),

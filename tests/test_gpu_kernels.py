@@ -376,11 +376,14 @@ def test_col_attention_kernel(dev, R, C, H):
         assert np.abs(got.numpy() - p.numpy()).max() < 5e-6
 
 
-@pytest.mark.parametrize("R,C,H", [(1, 7, 3), (2, 64, 12), (8, 64, 12), (15, 33, 2), (16, 130, 4), (13, 5, 1)])
+@pytest.mark.parametrize("R,C,H", [(1, 7, 3), (2, 64, 12), (8, 64, 12), (15, 33, 2), (16, 130, 4), (13, 5, 1),
+                                   (17, 33, 2), (31, 40, 3), (32, 64, 12), (33, 17, 2), (48, 130, 4), (63, 5, 1), (64, 128, 12)])
 def test_col_attention_for_shallow_alignments_one_wave_per_problem(dev, R, C, H):
-    """col_attn_small_kernel (R <= 16: one wave per (column, head), v_mfma_f32_16x16x4_f32, no LDS) against fp64 and against the
-    128-query-block kernels it replaces (knob "col_small" = 0), without and with a padding mask (incl. a column whose keys are
-    all padded: uniform weights, as the -10000 fill gives), R = 1 (ctx = v)."""
+    """The one-wave-per-(column, head) kernels, no LDS -- col_attn_small_kernel (R <= 16, v_mfma_f32_16x16x4_f32) and, round 6,
+    col_attn_wave_kernel (R = 17..64: a 2 x 2 arrangement of 32 x 32 tiles of v_mfma_f32_32x32x2_f32, the second tile row / column
+    skipped at R <= 32) -- against fp64 and against the 128-query-block kernels they replace (knob "col_small" = 0), without and
+    with a padding mask (incl. a column whose keys are all padded: uniform weights, as the -10000 fill gives), R = 1 (ctx = v),
+    and restricted to the first query rows (bit-identical to the full launch)."""
     from rnamsm import ops
     qkv, D = _qkv(R, C, H, f"cs{R}_{C}")
     g = qkv.to(dev)
@@ -408,6 +411,11 @@ def test_col_attention_for_shallow_alignments_one_wave_per_problem(dev, R, C, H)
         assert rel_l2(small, want) < 5e-6, (R, C, H, mask is not None)
         assert np.abs(small.numpy() - want.numpy()).max() < 2e-5 * max(1.0, float(want.abs().max()))
         assert rel_l2(small, big) < 2e-6
+        if R > 2:
+            qr = max(1, R // 3)
+            part = torch.full((R * C, D), float("nan"), device=dev)
+            ops.col_attn(g[:, :D], g[:, D:2 * D], g[:, 2 * D:], R, C, H, pad_mask=gm, out=part, q_rows=qr)
+            assert torch.equal(part[:qr * C].cpu(), small[:qr * C]) and bool(torch.isnan(part[qr * C:]).all())
 
 
 @pytest.mark.parametrize("R,C,H", [(1, 7, 3), (8, 64, 12), (16, 130, 4), (17, 33, 2), (100, 30, 3), (129, 5, 1), (300, 4, 2)])
