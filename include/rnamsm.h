@@ -535,9 +535,8 @@ void rnamsm_timing_reset(void);
  *                 many K ranges with the epilogue applied by the reduction pass (A/B: no gain once the block order was fixed).
  *   "row_narrow"  fp32 rnamsm_row_logits / rnamsm_row_apply at C <= 64: 1 (default) = the LDS-free narrow kernels, 0 = the
  *                 128x128 tile kernels.  Speed only, results bit-identical.
- *   "col_small"   fp32 rnamsm_col_attn_fused at R <= 64: 1 (default) = one wave per (column, head), no LDS -- R <= 16 on
- *                 v_mfma_f32_16x16x4_f32, R = 17..64 (round 6) on a 2 x 2 arrangement of 32 x 32 tiles of v_mfma_f32_32x32x2_f32;
- *                 0 = the 128-query-block kernels.  Results agree to fp32 rounding.
+ *   "col_small"   fp32 rnamsm_col_attn_fused at R <= 16: 1 (default) = one wave per (column, head) on v_mfma_f32_16x16x4_f32,
+ *                 no LDS; 0 = the 128-query-block kernels.  Results agree to fp32 rounding.
  *   "col_fast"    rnamsm_col_attn_fused_prescaled: 1 (default) = first pass without a running maximum, the online softmax as the
  *                 fallback of a block whose row sums leave [2^-64, 2^100]; 0 = the online softmax only (results agree to rounding).
  *   "col_dma"     fp32 rnamsm_col_attn_fused: 1 = K/V chunks staged by LDS-DMA, 32-key chunks, three blocks per CU;

@@ -276,9 +276,9 @@ __global__ __launch_bounds__(CA_THREADS, MASKED ? 2 : 3) void col_attn_dma_kerne
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     if (pk) {
         // token-packed batch (rnamsm_forward_packed; unmasked, fp32 context): alignment blockIdx.y's own shape and token offset;
-        // the shallow ones (R <= pk_skip_shallow) belong to the one-wave-per-problem kernels' launches
+        // the shallow ones (R <= 16) belong to col_attn_small_kernel's launch when pk_skip_shallow is set
         const PackedMsa& m = pk[blockIdx.y];
-        if (m.R <= pk_skip_shallow) return;        // (0 = none; 64 with "col_small": the one-wave-per-problem kernels' launches)
+        if (pk_skip_shallow && m.R <= 16) return;
         R = m.R; C = m.C; q_rows = m.R;
         q += m.tok0 * ld;
         k += m.tok0 * ld;
@@ -669,169 +669,6 @@ __global__ __launch_bounds__(256) void col_attn_small_kernel(const float* __rest
             *reinterpret_cast<f32x4s*>(orow + 4 * t) = f32x4s{o[0][t], o[1][t], o[2][t], o[3][t]} * inv;
     }
 }
-
-// ---- K7 for alignments of 17..64 rows (round 6): ONE WAVE per (column, head) on the exact-fp32 v_mfma_f32_32x32x2_f32, no LDS, no
-// barrier.  The 128-query-block kernels give such a problem a block that is 13-50 % full, two key chunks of staging and four
-// barriers per chunk: at 64 x 128 that is 1536 half-empty blocks and 33 us per launch (2.6 % of BASELINE configs[1], more of the
-// shallow alignments the CLI meets).  Here the whole problem is a 2 x 2 arrangement of 32 x 32 tiles held by one wave
-// (lane = (li, lh), li = lane & 31 the tile row / column it feeds, lh = lane >> 5 its k-slot); the second tile row / column is
-// skipped by a wave-uniform branch when R <= 32.
-//   S^T = K Q^T   A = K (key 32 kt + li), B = Q^T (query 32 qt + li).  A lane fetches its row as eight float4 at d = 8 g + 4 lh and
-//                 step (g, e) pairs k-slot lh with d = 8 g + 4 lh + e in BOTH operands (any contraction order is valid as long as A
-//                 and B agree).  The accumulator register t of tile (kt, qt) is S^T[key 32 kt + 8 (t >> 2) + 4 lh + (t & 3)][query
-//                 32 qt + li]: the softmax over keys is 16 (or 32) registers and one lane exchange (xor 32).
-//   O^T = V^T P^T at step (kt, t) the k-slot lh stands for key 32 kt + 8 (t >> 2) + 4 lh + (t & 3), so the lane's OWN probability
-//                 register t is its B operand (no data movement, the trick of the other kernels).  A = V^T with the head dims dealt
-//                 over two tiles as d = 2 row + tile: lane (li, lh) fetches ONE float2 V[key][2 li, 2 li + 1] per step and feeds .x
-//                 to tile 0, .y to tile 1; registers t, t + 1, t + 2, t + 3 of the two tiles are then eight consecutive head dims
-//                 of query 32 qt + li: two float4 stores.
-// Same arithmetic as the other column kernels up to the summation order (softmax with the row maximum subtracted, as the
-// R <= 16 kernel); q_rows < R: only those query rows are stored.  ~200 registers: two waves per SIMD.
-template <bool MASKED>
-__global__ __launch_bounds__(256, 2) void col_attn_wave_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                            const float* __restrict__ v, int64_t ld, float* __restrict__ ctx,
-                                                            int64_t ldc, int R, int C, int H,
-                                                            const uint8_t* __restrict__ pad_mask, int q_rows,
-                                                            int64_t qkv_bstride, int64_t ctx_bstride,
-                                                            const PackedMsa* __restrict__ pk, int log2_domain) {
-    typedef float f32x4s __attribute__((ext_vector_type(4)));
-    typedef float f32x2s __attribute__((ext_vector_type(2)));
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int prob = blockIdx.x * 4 + wave;
-    if (pk) {                                                    // token-packed batch: the alignments of 17..64 rows only
-        const PackedMsa& m = pk[blockIdx.y];
-        if (m.R <= 16 || m.R > 64) return;
-        R = m.R; C = m.C; q_rows = m.R;
-        q += m.tok0 * ld;
-        k += m.tok0 * ld;
-        v += m.tok0 * ld;
-        ctx += m.tok0 * ldc;
-    } else {
-        q += blockIdx.y * qkv_bstride;
-        k += blockIdx.y * qkv_bstride;
-        v += blockIdx.y * qkv_bstride;
-        ctx += blockIdx.y * ctx_bstride;
-        if (MASKED) pad_mask += blockIdx.y * ((int64_t)R * C);
-    }
-    if (prob >= C * H) return;                                   // wave-uniform
-    const int c = prob / H, h = prob % H;
-    const int li = lane & 31, lh = lane >> 5;
-    const bool two = R > 32;                                     // wave-uniform: the second key / query tile exists
-    const int64_t col = (int64_t)c * ld + h * CA_HD;             // + row * C * ld
-    const int64_t rstride = (int64_t)C * ld;
-    // rows past R are clamped: masked as keys, not stored as queries
-    const int r0 = min(li, R - 1), r1 = min(32 + li, R - 1);
-    f32x4s kf[2][8], qf[2][8];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        kf[0][g] = *reinterpret_cast<const f32x4s*>(k + r0 * rstride + col + 8 * g + 4 * lh);
-        qf[0][g] = *reinterpret_cast<const f32x4s*>(q + r0 * rstride + col + 8 * g + 4 * lh);
-    }
-    if (two) {
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            kf[1][g] = *reinterpret_cast<const f32x4s*>(k + r1 * rstride + col + 8 * g + 4 * lh);
-            qf[1][g] = *reinterpret_cast<const f32x4s*>(q + r1 * rstride + col + 8 * g + 4 * lh);
-        }
-    }
-    f32x16 s[2][2];                                              // [key tile][query tile]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) s[a][b][t] = 0.f;
-#pragma unroll
-    for (int g = 0; g < 8; ++g)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            s[0][0] = mfma32(kf[0][g][e], qf[0][g][e], s[0][0]);
-            if (two) {
-                s[1][0] = mfma32(kf[1][g][e], qf[0][g][e], s[1][0]);
-                s[0][1] = mfma32(kf[0][g][e], qf[1][g][e], s[0][1]);
-                s[1][1] = mfma32(kf[1][g][e], qf[1][g][e], s[1][1]);
-            }
-        }
-    // the V operand of every step, requested before the softmax: one float2 per (key tile, t)
-    const float* vcol = v + (int64_t)c * ld + h * CA_HD + 2 * li;
-    f32x2s vv[2][16];
-#pragma unroll
-    for (int t = 0; t < 16; ++t) vv[0][t] = *reinterpret_cast<const f32x2s*>(vcol + min(8 * (t >> 2) + 4 * lh + (t & 3), R - 1) * rstride);
-    if (two) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-            vv[1][t] = *reinterpret_cast<const f32x2s*>(vcol + min(32 + 8 * (t >> 2) + 4 * lh + (t & 3), R - 1) * rstride);
-    }
-    // softmax over the keys of each query column (in-lane registers of both key tiles + the partner lane)
-    float inv[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        if (qt == 1 && !two) break;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            if (kt == 1 && !two) break;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int j = 32 * kt + 8 * (t >> 2) + 4 * lh + (t & 3);
-                float sc = s[kt][qt][t];
-                if (MASKED && j < R && pad_mask[(int64_t)j * C + c]) sc = -10000.f;       // modules.py:911-915
-                sc = j < R ? sc : -INFINITY;
-                s[kt][qt][t] = sc;
-                mx = fmaxf(mx, sc);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float l = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            if (kt == 1 && !two) break;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float p = log2_domain ? __builtin_amdgcn_exp2f(s[kt][qt][t] - mx) : __expf(s[kt][qt][t] - mx);   // keys past R: 0
-                s[kt][qt][t] = p;
-                l += p;
-            }
-        }
-        l += __shfl_xor(l, 32, 64);
-        inv[qt] = 1.f / l;
-    }
-    f32x16 o[2][2];                                              // [head-dim tile][query tile]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) o[a][b][t] = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        if (kt == 1 && !two) break;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            o[0][0] = mfma32(vv[kt][t][0], s[kt][0][t], o[0][0]);
-            o[1][0] = mfma32(vv[kt][t][1], s[kt][0][t], o[1][0]);
-            if (two) {
-                o[0][1] = mfma32(vv[kt][t][0], s[kt][1][t], o[0][1]);
-                o[1][1] = mfma32(vv[kt][t][1], s[kt][1][t], o[1][1]);
-            }
-        }
-    }
-    // register t of head-dim tile dt, query tile qt: head dim 2 (8 (t >> 2) + 4 lh + (t & 3)) + dt of query 32 qt + li
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        if (qt == 1 && !two) break;
-        const int j = 32 * qt + li;
-        if (j < q_rows) {
-            float* orow = ctx + ((int64_t)j * C + c) * ldc + h * CA_HD + 8 * lh;
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int t0 = 4 * gq;
-                *reinterpret_cast<f32x4s*>(orow + 16 * gq) = f32x4s{o[0][qt][t0], o[1][qt][t0], o[0][qt][t0 + 1], o[1][qt][t0 + 1]} * inv[qt];
-                *reinterpret_cast<f32x4s*>(orow + 16 * gq + 4) = f32x4s{o[0][qt][t0 + 2], o[1][qt][t0 + 2], o[0][qt][t0 + 3], o[1][qt][t0 + 3]} * inv[qt];
-            }
-        }
-    }
-}
 }  // namespace rnamsm
 
 static int col_attn_launch(const float* q, const float* k, const float* v, int64_t ld, float* ctx, int64_t ldc, int R, int C,
@@ -861,16 +698,6 @@ static int col_attn_launch(const float* q, const float* k, const float* v, int64
         else
             hipLaunchKernelGGL(col_attn_small_kernel<false>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, q_rows, qkv_bstride, ctx_bstride, (const PackedMsa*)nullptr, prescaled ? 1 : 0);
         RNAMSM_CHECK_LAUNCH("col_attn_small");
-        return RNAMSM_OK;
-    }
-    // alignments of 17..64 rows: one wave per (column, head) on 32x32 tiles, no LDS (the same knob: "col_small" = 0 keeps the blocks)
-    if (R <= 64 && !ctx_hi && tuning().col_small != 0) {
-        const dim3 sgrid(((unsigned)C * H + 3) / 4, batch);
-        if (pad_mask)
-            hipLaunchKernelGGL(col_attn_wave_kernel<true>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, q_rows, qkv_bstride, ctx_bstride, (const PackedMsa*)nullptr, prescaled ? 1 : 0);
-        else
-            hipLaunchKernelGGL(col_attn_wave_kernel<false>, sgrid, dim3(256), 0, s, q, k, v, ld, ctx, ldc, R, C, H, pad_mask, q_rows, qkv_bstride, ctx_bstride, (const PackedMsa*)nullptr, prescaled ? 1 : 0);
-        RNAMSM_CHECK_LAUNCH("col_attn_wave");
         return RNAMSM_OK;
     }
 #define CA_GO2(KERN_, LDS_, M_, OUT_)                                                                               \
@@ -934,14 +761,13 @@ int col_attn_packed(const float* q, const float* k, const float* v, int64_t ld, 
                     const PackedMsa* host, int B, void* stream, bool prescaled) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool split_shallow = tuning().col_small != 0;
-    unsigned grid = 0, sgrid = 0, wgrid = 0;     // tile kernel / R <= 16 / R = 17..64
+    unsigned grid = 0, sgrid = 0;
     double flops = 0.0, bytes = 0.0;
     for (int b = 0; b < B; ++b) {
         const PackedMsa& m = host[b];
-        if (split_shallow && m.R <= 64) {
+        if (split_shallow && m.R <= 16) {
             const unsigned g = ((unsigned)m.C * H + 3) / 4;
-            if (m.R <= 16) sgrid = g > sgrid ? g : sgrid;
-            else wgrid = g > wgrid ? g : wgrid;
+            sgrid = g > sgrid ? g : sgrid;
         } else {
             const unsigned g = xcd_panel_grid((unsigned)m.C * H, (m.R + CA_ROWS - 1) / CA_ROWS);
             grid = g > grid ? g : grid;
@@ -968,22 +794,17 @@ int col_attn_packed(const float* q, const float* k, const float* v, int64_t ld, 
             }
             hipLaunchKernelGGL((col_attn_dma_kernel<false, 0, true>), dim3(grid, B), dim3(CA_THREADS), CD_LDS_BYTES, s, q, k, v, ld, ctx, ldc, 0,
                                0, H, (const uint8_t*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr, 0, (int64_t)0, (int64_t)0, pk,
-                               split_shallow ? 64 : 0, tuning().col_fast ? 0 : 1);
+                               split_shallow ? 1 : 0, tuning().col_fast ? 0 : 1);
         } else
         hipLaunchKernelGGL((col_attn_dma_kernel<false, 0>), dim3(grid, B), dim3(CA_THREADS), CD_LDS_BYTES, s, q, k, v, ld, ctx, ldc, 0, 0, H,
                            (const uint8_t*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr, 0, (int64_t)0, (int64_t)0, pk,
-                           split_shallow ? 64 : 0, 0);
+                           split_shallow ? 1 : 0, 0);
         RNAMSM_CHECK_LAUNCH("col_attn (packed)");
     }
     if (sgrid) {
         hipLaunchKernelGGL(col_attn_small_kernel<false>, dim3(sgrid, B), dim3(256), 0, s, q, k, v, ld, ctx, ldc, 0, 0, H,
                            (const uint8_t*)nullptr, 0, (int64_t)0, (int64_t)0, pk, prescaled ? 1 : 0);
         RNAMSM_CHECK_LAUNCH("col_attn_small (packed)");
-    }
-    if (wgrid) {
-        hipLaunchKernelGGL(col_attn_wave_kernel<false>, dim3(wgrid, B), dim3(256), 0, s, q, k, v, ld, ctx, ldc, 0, 0, H,
-                           (const uint8_t*)nullptr, 0, (int64_t)0, (int64_t)0, pk, prescaled ? 1 : 0);
-        RNAMSM_CHECK_LAUNCH("col_attn_wave (packed)");
     }
     return RNAMSM_OK;
 }

@@ -376,14 +376,13 @@ def test_col_attention_kernel(dev, R, C, H):
         assert np.abs(got.numpy() - p.numpy()).max() < 5e-6
 
 
-@pytest.mark.parametrize("R,C,H", [(1, 7, 3), (2, 64, 12), (8, 64, 12), (15, 33, 2), (16, 130, 4), (13, 5, 1),
-                                   (17, 33, 2), (31, 40, 3), (32, 64, 12), (33, 17, 2), (48, 130, 4), (63, 5, 1), (64, 128, 12)])
+@pytest.mark.parametrize("R,C,H", [(1, 7, 3), (2, 64, 12), (8, 64, 12), (15, 33, 2), (16, 130, 4), (13, 5, 1), (17, 33, 2), (64, 128, 12)])
 def test_col_attention_for_shallow_alignments_one_wave_per_problem(dev, R, C, H):
-    """The one-wave-per-(column, head) kernels, no LDS -- col_attn_small_kernel (R <= 16, v_mfma_f32_16x16x4_f32) and, round 6,
-    col_attn_wave_kernel (R = 17..64: a 2 x 2 arrangement of 32 x 32 tiles of v_mfma_f32_32x32x2_f32, the second tile row / column
-    skipped at R <= 32) -- against fp64 and against the 128-query-block kernels they replace (knob "col_small" = 0), without and
-    with a padding mask (incl. a column whose keys are all padded: uniform weights, as the -10000 fill gives), R = 1 (ctx = v),
-    and restricted to the first query rows (bit-identical to the full launch)."""
+    """col_attn_small_kernel (R <= 16: one wave per (column, head), v_mfma_f32_16x16x4_f32, no LDS) against fp64 and against the
+    128-query-block kernels it replaces (knob "col_small" = 0), without and with a padding mask (incl. a column whose keys are
+    all padded: uniform weights, as the -10000 fill gives), R = 1 (ctx = v), and restricted to the first query rows
+    (rnamsm_col_attn_fused_queries: bit-identical to the full launch; the two shapes above 16 rows hold that for the block kernels).
+    (A one-wave-per-problem kernel for R = 17..64 on 32x32 tiles was built in round 6, correct, and not faster: EXPERIMENTS R6.6.)"""
     from rnamsm import ops
     qkv, D = _qkv(R, C, H, f"cs{R}_{C}")
     g = qkv.to(dev)
