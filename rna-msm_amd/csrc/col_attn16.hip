@@ -41,7 +41,7 @@
 
 namespace rnamsm {
 
-// Throw-away what-if builds (wrong results, timing only; tools/whatif_col_attn16.sh, profiles/r05_whatif_col_attn16.log): 1 no v_exp,
+// Throw-away what-if builds (wrong results, timing only; tools/whatif_col_attn16.sh, docs/history/profiles_r05/r05_whatif_col_attn16.log): 1 no v_exp,
 // 2 no row sums, 4 no LDS-DMA inside the loop, 8 no P V MFMAs, 16 no S MFMAs, 32 never fall back, 64 one chunk per block.  0 in the
 // shipped library (every use folds away).
 #ifndef C16_WHATIF

@@ -75,7 +75,7 @@ struct KernelTimer {   // brackets one launch with two hipEventRecord calls when
 // ---- tuning knobs (api.hip) -------------------------------------------------------------------------
 // The folded LayerNorm (forward.hip, knob "ln_fold" = 1) is taken by an alignment of at least this many tokens, in every exact
 // driver alike: the decision follows the MEMBER, never the batch.  Round 5: 18432 -> 4096 (tools/forward_knob_ab.py ln_fold=0,3 after
-// row_stats_from_partials lost its serial loads: +1.1 .. +1.6 % from 4096 tokens up, +0.4 % at 2048: profiles/r05_ln_fold_threshold_ab.log).
+// row_stats_from_partials lost its serial loads: +1.1 .. +1.6 % from 4096 tokens up, +0.4 % at 2048: docs/history/profiles_r05/r05_ln_fold_threshold_ab.log).
 constexpr int64_t LN_FOLD_MIN_TOKENS = 4096;
 struct Tuning {
     int gemm16_dma = 3;            // plane-input 16-bit GEMMs: 0 register staging, 1 / 2 LDS-DMA 128x128,
@@ -85,7 +85,7 @@ struct Tuning {
     int gemm_group = 0;            // fp32 GEMM: row panels per XCD group of the block order (xcd_panel_map_grouped); 0 = by shape
     int gemm_tile = 0;             // fp32 GEMM block tile: 0 = by shape, 1 = always 128x128, 2 = always 128x64, 3 = mixed wherever a launch has whole rounds and a tail, 4 = by shape among the uniform tilings only (round 4's rule, A/B)
     int gemm_splitk_short = 0;     // rnamsm_forward*, the K = 768 GEMMs of a lone small alignment (<= 192 tiles): K ranges (0 = off: the default -- measured no gain once the block order was fixed; 2, 4), gemm_f32_splitk_factor
-    int gemm_splitk = 0;           // rnamsm_forward, fc2 below ~1.4 k tokens: 0 = never (default since round 5: a split chosen by the BATCH's token count made an alignment's bits depend on its company; costs a lone <= 1024-token alignment 0.4 of 2.5 ms, profiles/r05_splitk.log), 1 = four K ranges + an ordered reduction (gemm_f32_splitk_factor), 2 / 4 / 8 = forced (A/B)
+    int gemm_splitk = 0;           // rnamsm_forward, fc2 below ~1.4 k tokens: 0 = never (default since round 5: a split chosen by the BATCH's token count made an alignment's bits depend on its company; costs a lone <= 1024-token alignment 0.4 of 2.5 ms, docs/history/profiles_r05/r05_splitk.log), 1 = four K ranges + an ordered reduction (gemm_f32_splitk_factor), 2 / 4 / 8 = forced (A/B)
     int row_narrow = 1;            // fp32 K4 / K6 at C <= 64: 1 = the LDS-free narrow kernels (row_logits_narrow / row_apply_narrow; bit-identical), 0 = the 128 x 128 tile kernels (A/B)
     int col_small = 1;             // fp32 col_attn at R <= 16: 1 = one wave per (column, head), no LDS (col_attn_small_kernel), 0 = the 128-query blocks
     int col_fast = 1;              // fp32 col_attn on prescaled q (rnamsm_col_attn_fused_prescaled): 1 = FAST loop (no running maximum) with the TRACKED loop as fallback, 0 = TRACKED only (A/B)

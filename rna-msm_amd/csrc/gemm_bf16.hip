@@ -724,7 +724,7 @@ static int launch_hs(const uint16_t* Whi, const uint16_t* Wlo, const float* bias
     // groups of 8 row panels keep a W slab shared by 8 panels instead of ~3: +5..6% (split 3), +7..10% (split 1),
     // measured in one process; of the 3-column-block GEMMs fc2 (K = 3072) is neutral to slightly worse and stays ungrouped, out_proj
     // (K = 768, HBM-bound by its fp32 residual traffic) takes groups of 4 panels since round 5: +2.3 % (bf16) / +2.5 % (f16x3) at
-    // T = 131072, +4.8 % / +1.0 % at T = 1048576, bit-identical (profiles/r05_gemm16_group_n768.log)
+    // T = 131072, +4.8 % / +1.0 % at T = 1048576, bit-identical (docs/history/profiles_r05/r05_gemm16_group_n768.log)
     const int group = tuning().gemm_group > 0 ? tuning().gemm_group
                                               : (N / HX_BN > 4 ? (int)xcd_group_for_persistent((M + HX_BM - 1) / HX_BM, 8)
                                                                : (K <= 1024 ? (int)xcd_group_for_persistent((M + HX_BM - 1) / HX_BM, 4) : 1));
