@@ -9,6 +9,8 @@ from rnamsm import synthetic, inference
 from rnamsm.config import Config
 from rnamsm.model import MSATransformer
 NS = int(os.environ.get("NSMALL", 64))
+DLO, DHI = (int(v) for v in os.environ.get("DEPTH", "2,12").split(","))       # rows per alignment (inclusive); "small" list of cli_throughput.py: DEPTH=4,24 LEN=40,120
+LLO, LHI = (int(v) for v in os.environ.get("LEN", "40,80").split(","))
 state = synthetic.make_state_dict(seed=0)
 model = MSATransformer(num_layers=10)
 model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
@@ -36,7 +38,7 @@ for rnd in range(3):
     os.makedirs(os.path.join(root, "results"))
     ids = [f"small{i:03d}" for i in range(NS)]
     for i in ids:
-        depth, length = int(rng.randint(2, 13)), int(rng.randint(40, 81))
+        depth, length = int(rng.randint(DLO, DHI + 1)), int(rng.randint(LLO, LHI + 1))
         rows = letters[rng.randint(0, 5, size=(depth, length))]
         with open(os.path.join(root, "results", f"{i}.a2m_msa2"), "w") as f:
             for r in range(depth):
