@@ -88,10 +88,15 @@ class _AsyncNpyWriter:
             except BaseException as e:                  # noqa: BLE001  (reported by close())
                 self._err = e
 
-    def submit(self, jobs, done) -> None:
-        """jobs: [(path, device tensor)], written in this order; done(): called by the worker after the last file."""
-        cur = torch.cuda.current_stream()
-        self._stream.wait_stream(cur)
+    def submit(self, jobs, done, after: Optional[torch.cuda.Event] = None) -> None:
+        """jobs: [(path, device tensor)], written in this order; done(): called by the worker after the last file.
+        after: an event recorded behind the kernels that produced the tensors -- the copies then wait for THAT point of the compute
+        stream only, not for what was enqueued since (the next packed group's forward: the CLI's pipelined pool); None = for
+        everything enqueued so far."""
+        if after is not None:
+            self._stream.wait_event(after)
+        else:
+            self._stream.wait_stream(torch.cuda.current_stream())
         staged = []
         with torch.cuda.stream(self._stream):
             for path, t in jobs:
@@ -228,6 +233,9 @@ def plan_groups(shapes: List[tuple]) -> List[List[int]]:
 # left at 8192; tools/cli_throughput.py with PACKED_SMALL / PACKED_SMALL_16)
 # (PACKED_TOKENS 65536 -> 131072: a 77 k-token list of small alignments as one group instead of two: 385 -> 408 MSA/s)
 PACKED_TOKENS, PACKED_MEMBERS, PACKED_SMALL_TOKENS = 131072, 256, 16384
+# The CLI's pooled path pipelines its token-packed groups (group g+1 enqueued before group g's error word is read); a pool that would be
+# one group of at least this many tokens is dealt into two so that there is something to overlap (RNAMSM_PIPELINE_SPLIT_TOKENS: A/B, 0 = never)
+PIPELINE_SPLIT_TOKENS = int(os.environ.get("RNAMSM_PIPELINE_SPLIT_TOKENS", "49152"))
 # In a 16-bit arithmetic mode the packed batch runs in that mode too since round 5 (rnamsm_forward_packed: every Linear on the
 # 16-bit matrix cores, attention on the exact descriptor kernels), so the same limit applies.  (Round 4 had sent those small
 # alignments through the EXACT packed path, with limits of 1024 / 2048 tokens: there was no 16-bit packed batch.)
@@ -245,23 +253,27 @@ def joins_packed(group_shapes: List[tuple], shape: tuple) -> bool:
             and sum(c * c for _, c in trial) <= FRAME_MAP_ELEMS)
 
 
-def plan_packed_groups(shapes: List[tuple], fold_min_tokens: int = 0) -> List[List[int]]:
+def plan_packed_groups(shapes: List[tuple], fold_min_tokens: int = 0, split_tokens: int = 0) -> List[List[int]]:
     """Partition pooled small alignments into token-packed groups, in list order, every position exactly once.  The number of
     groups is the least the three bounds allow; members are then dealt so that the groups hold about the same number of tokens
     (64 + 6 alignments would otherwise run as one full group and one nearly empty launch set).
     fold_min_tokens > 0 (exact mode): alignments of at least that many tokens take the folded LayerNorm, smaller ones do not, and a
     launch set is one or the other -- the two classes are planned separately, so that no group has to be run as two batches
-    (MSATransformer.forward_packed would split a mixed one: correct, but two launch sets)."""
+    (MSATransformer.forward_packed would split a mixed one: correct, but two launch sets).
+    split_tokens > 0: a class that would run as ONE group of at least that many tokens is dealt into two, so that the caller can
+    pipeline them (the second group's forward over the first one's deliveries)."""
     if not shapes:
         return []
     if fold_min_tokens > 0:
         big = [j for j, (r, c) in enumerate(shapes) if r * c >= fold_min_tokens]
         if 0 < len(big) < len(shapes):
             small = [j for j in range(len(shapes)) if r_c_below(shapes[j], fold_min_tokens)]
-            return ([[big[j] for j in g] for g in plan_packed_groups([shapes[j] for j in big])]
-                    + [[small[j] for j in g] for g in plan_packed_groups([shapes[j] for j in small])])
+            return ([[big[j] for j in g] for g in plan_packed_groups([shapes[j] for j in big], 0, split_tokens)]
+                    + [[small[j] for j in g] for g in plan_packed_groups([shapes[j] for j in small], 0, split_tokens)])
     tok = [r * c for r, c in shapes]
     k = max(-(-len(shapes) // PACKED_MEMBERS), -(-sum(tok) // PACKED_TOKENS), -(-sum(c * c for _, c in shapes) // FRAME_MAP_ELEMS), 1)
+    if k == 1 and split_tokens > 0 and sum(tok) >= split_tokens and len(shapes) >= 2:
+        k = 2
     while True:
         # next-fit with a soft budget of 1/k of the tokens: a group closes once it has reached the budget (the member that crosses
         # it still joins, bounds permitting), or earlier when the next member would break a hard bound
@@ -340,10 +352,10 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
     writer = _AsyncNpyWriter(device) if async_io and (not gathering or rank == 0) else None
     reader = ThreadPoolExecutor(1, thread_name_prefix="rnamsm-msa-reader") if async_io else None
 
-    def emit(rna_id: str, emb: torch.Tensor, atp: torch.Tensor) -> None:
+    def emit(rna_id: str, emb: torch.Tensor, atp: torch.Tensor, after: Optional[torch.cuda.Event] = None) -> None:
         if writer is not None:
             writer.submit([(save_dir / f"{rna_id}_atp.npy", atp), (save_dir / f"{rna_id}_emb.npy", emb)],
-                          lambda r=rna_id: written.append(r))
+                          lambda r=rna_id: written.append(r), after=after)
         else:
             write(rna_id, emb.cpu().numpy(), atp.cpu().numpy())
 
@@ -365,11 +377,11 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
     try:
         with torch.no_grad():
             pending = reader.submit(read, mine[0]) if reader and len(mine) else None
-            def deliver(idx: int, emb: torch.Tensor, atp: torch.Tensor) -> None:
+            def deliver(idx: int, emb: torch.Tensor, atp: torch.Tensor, after: Optional[torch.cuda.Event] = None) -> None:
                 if gatherer is not None:
                     gatherer.submit(idx, (emb, atp))
                 else:
-                    emit(ids[idx], emb, atp)
+                    emit(ids[idx], emb, atp, after)
 
             # data.batch_small_msas: small alignments go through ONE launch set per group (forward_ragged: padded into one
             # frame, every MSA scaled by its own depth); a lone forward of a few hundred tokens costs 5.5 ms on a mostly
@@ -392,9 +404,54 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
             def run_pool() -> None:
                 shapes_ = [tuple(t.shape) for _, t in pool]
                 fold_min = ops.get_param("ln_fold_min_tokens") if (exact and model.fold_layernorm and ops.get_param("ln_fold") == 1) else 0
-                for members in (plan_packed_groups(shapes_, fold_min) if packing else plan_groups(shapes_)):
-                    group.extend((pool[j][0], torch.from_numpy(pool[j][1]).to(device)) for j in members)
-                    flush()
+                if not packing:
+                    for members in plan_groups(shapes_):
+                        group.extend((pool[j][0], torch.from_numpy(pool[j][1]).to(device)) for j in members)
+                        flush()
+                    pool.clear()
+                    return
+                # Token-packed groups, PIPELINED (round 6): group g+1 is enqueued before group g's error word is read, so g's
+                # device-to-host copies and file writes run under g+1's forward instead of after it with the GPU idle (64 small
+                # alignments used to be one blocking 117 ms forward followed by 26 ms of deliveries).  A pool that would be ONE group
+                # of at least PIPELINE_SPLIT_TOKENS tokens is dealt into two for that.  Same launch sets per group as before: every
+                # member's files are byte for byte those of its own forward (exact mode).
+                # (one stream carries every forward: what belongs to group g -- its error word, its outputs -- is read behind an EVENT
+                # recorded right after g's launches, on side streams, or it would wait for g+1's forward as well)
+                waiting = None                                        # (members' (idx, tokens), begun forward, event) of the group in flight
+
+                def finish(entry) -> None:
+                    members_, (res, mode), ev = entry
+                    toks_ = [t for _, t in members_]
+                    try:
+                        outs = model.forward_ragged_finish(toks_, res, mode, after=ev)
+                        if outs is not res:
+                            ev = None                                 # a rerun: its outputs are behind everything enqueued so far
+                        if outs is None:                              # <pad> inside the batch: the framed rerun of forward_ragged
+                            outs = model.forward_ragged(toks_, packed=False)
+                    except IndexError:                                # name the offending alignment: one by one
+                        outs, ev = [alone(i, t) for i, t in members_], None
+                    if not all(o["emb"].is_contiguous() and o["atp"].is_contiguous() for o in outs):
+                        ev = None                                     # .contiguous() below would launch copies on the compute stream
+                    for (i, _), out in zip(members_, outs):
+                        deliver(i, out["emb"].contiguous(), out["atp"].contiguous(), ev)
+
+                for members in plan_packed_groups(shapes_, fold_min, split_tokens=PIPELINE_SPLIT_TOKENS):
+                    members_ = [(pool[j][0], torch.from_numpy(pool[j][1]).to(device)) for j in members]
+                    if len(members_) == 1:
+                        if waiting is not None:
+                            finish(waiting)
+                            waiting = None
+                        group.extend(members_)
+                        flush()
+                        continue
+                    begun = model.forward_ragged_begin([t for _, t in members_])
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
+                    if waiting is not None:
+                        finish(waiting)
+                    waiting = (members_, begun, ev)
+                if waiting is not None:
+                    finish(waiting)
                 pool.clear()
 
             def alone(i: int, t: torch.Tensor) -> dict:

@@ -465,6 +465,53 @@ class MSATransformer(nn.Module):
 
     ERR_PAD_IN_PACKED = 8
 
+    def forward_ragged_begin(self, msas: List[torch.Tensor], gemm_dtype: Optional[str] = None):
+        """First half of forward_ragged(packed=True): ENQUEUE the token-packed batch and return (res, mode) without reading its
+        error word -- no host sync, so the caller can enqueue the next group behind it and overlap this group's device-to-host
+        copies and file writes with that group's compute (the CLI's pooled path, round 6).  forward_ragged_finish completes it."""
+        mode = gemm_dtype or self.gemm_dtype
+        return self.forward_packed(msas, gemm_dtype=mode), mode
+
+    def _read_err_behind(self, err: torch.Tensor, after: Optional[torch.cuda.Event]) -> int:
+        """The error word of a launch set.  after = an event recorded right behind that launch set: the word is copied on a side
+        stream that waits for the EVENT, so the host is not held until what was enqueued afterwards has run too."""
+        if after is None:
+            return int(err.item())
+        dev = err.device
+        side = self._err_streams.get(dev) if hasattr(self, "_err_streams") else None
+        if side is None:
+            if not hasattr(self, "_err_streams"):
+                object.__setattr__(self, "_err_streams", {})
+            side = self._err_streams[dev] = torch.cuda.Stream(dev)
+        host = torch.empty((), dtype=err.dtype, pin_memory=True)
+        side.wait_event(after)
+        with torch.cuda.stream(side):
+            host.copy_(err, non_blocking=True)
+            err.record_stream(side)
+        side.synchronize()
+        return int(host)
+
+    def forward_ragged_finish(self, msas: List[torch.Tensor], res, mode: str, after: Optional[torch.cuda.Event] = None):
+        """Second half: read the batch's error word (ONE sync; behind `after`, an event recorded right after forward_ragged_begin, when
+        given) and act on it as forward_ragged documents -- index errors raise, a 16-bit batch with a non-finite output is redone on
+        the exact path, a failed folded-LayerNorm precondition reruns without the fold.  Returns the per-MSA results (`res` itself when
+        nothing had to be redone), or None when the batch holds <pad> (forward_ragged then reruns it framed)."""
+        import warnings
+        err = self._read_err_behind(res[0]["err"], after)
+        if err & self.ERR_INDEX:
+            raise IndexError("batch: token or position index out of range")
+        if (err & self.ERR_NONFINITE) and mode != "f32" and self.check_finite and not (err & self.ERR_PAD_IN_PACKED):
+            warnings.warn(f"batch: gemm_dtype={mode!r} produced non-finite outputs (operand outside the 16-bit range); "
+                          "the batch is recomputed on the exact fp32 path")
+            mode = "f32"
+            res = self.forward_packed(msas, gemm_dtype=mode)
+            err = int(res[0]["err"].item())
+        if (err & self.ERR_FOLD) and not (err & self.ERR_PAD_IN_PACKED):
+            warnings.warn("batch: a token row's mean exceeds 32x its spread; LayerNorm is applied in its own launches for this batch")
+            res = self.forward_packed(msas, fold_layernorm=False, gemm_dtype=mode)
+            err = int(res[0]["err"].item())
+        return None if (err & self.ERR_PAD_IN_PACKED) else res
+
     def forward_ragged(self, msas: List[torch.Tensor], packed: Optional[bool] = None,
                        gemm_dtype: Optional[str] = None) -> List[Dict[str, torch.Tensor]]:
         """Alignments of DIFFERENT shapes ([R_b, C_b] int64 tokens, column 0 = <cls>) in one launch set.  packed (None = True):
@@ -479,23 +526,8 @@ class MSATransformer(nn.Module):
         if packed is None:
             packed = True
         if packed:
-            import warnings
-            mode = gemm_dtype or self.gemm_dtype
-            res = self.forward_packed(msas, gemm_dtype=mode)
-            err = int(res[0]["err"].item())
-            if err & self.ERR_INDEX:
-                raise IndexError("batch: token or position index out of range")
-            if (err & self.ERR_NONFINITE) and mode != "f32" and self.check_finite and not (err & self.ERR_PAD_IN_PACKED):
-                warnings.warn(f"batch: gemm_dtype={mode!r} produced non-finite outputs (operand outside the 16-bit range); "
-                              "the batch is recomputed on the exact fp32 path")
-                mode = "f32"
-                res = self.forward_packed(msas, gemm_dtype=mode)
-                err = int(res[0]["err"].item())
-            if (err & self.ERR_FOLD) and not (err & self.ERR_PAD_IN_PACKED):
-                warnings.warn("batch: a token row's mean exceeds 32x its spread; LayerNorm is applied in its own launches for this batch")
-                res = self.forward_packed(msas, fold_layernorm=False, gemm_dtype=mode)
-                err = int(res[0]["err"].item())
-            if not (err & self.ERR_PAD_IN_PACKED):
+            res = self.forward_ragged_finish(msas, *self.forward_ragged_begin(msas, gemm_dtype))
+            if res is not None:
                 return res
         B = len(msas)
         R = max(int(t.shape[0]) for t in msas)

@@ -140,9 +140,12 @@ def test_cli_gather_to_rank0_streams_rounds_and_writes_the_same_files(tmp_path):
         assert a[name] == b[name], name
 
 
-@pytest.mark.parametrize("packing", [True, False])
-def test_cli_batches_small_alignments_by_default(tmp_path, packing):
-    """data.batch_small_msas (default true; false = the reference's one-by-one loop): the small alignments of the id list
+@pytest.mark.parametrize("packing", [True, "split", False])
+def test_cli_batches_small_alignments_by_default(tmp_path, packing, monkeypatch):
+    """(packing = "split", round 6: the pool's token-packed groups are PIPELINED -- group g+1 is enqueued before group g's error word
+    and outputs are read, on side streams behind an event -- and a pool that would be one large group is dealt into two; the split
+    threshold is lowered to 1 token here so that this small list takes that path: same bytes.)
+    data.batch_small_msas (default true; false = the reference's one-by-one loop): the small alignments of the id list
     (different depths and lengths here) share launch sets -- packing (data.pack_small_msas, the default): one token-packed group,
     nothing padded, the 4544-token alignment included; packing off: pooled, grouped by shape, padded into one frame per group, the
     4544-token one alone in between.  Same files, the returned ids in list order.  Packed (the default): every file is BYTE FOR BYTE
@@ -152,6 +155,10 @@ def test_cli_batches_small_alignments_by_default(tmp_path, packing):
     from rnamsm.config import Config
     from rnamsm.inference import extract_feat
     from rnamsm.model import MSATransformer
+    if packing == "split":
+        import rnamsm.inference as inf
+        monkeypatch.setattr(inf, "PIPELINE_SPLIT_TOKENS", 1)
+        packing = True
     state = synthetic.make_state_dict(seed=0)
     model = MSATransformer(num_layers=10)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)

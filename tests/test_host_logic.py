@@ -514,3 +514,9 @@ def test_token_packed_groups_are_cut_in_list_order_and_balanced():
         assert len({mixed[j][0] * mixed[j][1] >= 4096 for j in g}) == 1
     assert plan_packed_groups(mixed, 4096) == [[0, 2, 4], [1, 3, 5, 6]]
     assert plan_packed_groups(mixed, 0) == plan_packed_groups(mixed) == [list(range(len(mixed)))]
+    # round 6: a class that would be ONE group of at least split_tokens tokens is dealt into two (the CLI pipelines its groups)
+    many = [(8, 60)] * 40                                                               # 19200 tokens: one group ...
+    assert plan_packed_groups(many) == [list(range(40))] == plan_packed_groups(many, 0, split_tokens=20000)
+    two = plan_packed_groups(many, 0, split_tokens=19200)                               # ... two from the threshold on, evenly filled
+    assert [len(g) for g in two] == [20, 20] and sorted(i for g in two for i in g) == list(range(40))
+    assert plan_packed_groups([(8, 60)], 0, split_tokens=1) == [[0]]                    # a lone alignment is never split
