@@ -483,13 +483,13 @@ class MSATransformer(nn.Module):
             if not hasattr(self, "_err_streams"):
                 object.__setattr__(self, "_err_streams", {})
             side = self._err_streams[dev] = torch.cuda.Stream(dev)
-        host = torch.empty((), dtype=err.dtype, pin_memory=True)
+        host = torch.empty(err.shape, dtype=err.dtype, pin_memory=True)
         side.wait_event(after)
         with torch.cuda.stream(side):
             host.copy_(err, non_blocking=True)
             err.record_stream(side)
         side.synchronize()
-        return int(host)
+        return int(host.reshape(-1)[0])
 
     def forward_ragged_finish(self, msas: List[torch.Tensor], res, mode: str, after: Optional[torch.cuda.Event] = None):
         """Second half: read the batch's error word (ONE sync; behind `after`, an event recorded right after forward_ragged_begin, when
