@@ -400,6 +400,30 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
             small_limit = (PACKED_SMALL_TOKENS if exact else PACKED_SMALL_TOKENS_16BIT.get(model.gemm_dtype, 1024)) if packing else SMALL_MSA_TOKENS
             group: List = []                                          # (idx, tokens on the device)
             pool: List = []                                           # (idx, tokens on the host)
+            inflight: List = [None]                                   # the pipelined pool's group whose results are still on the device
+
+            def finish_packed(entry) -> None:
+                """Second half of a pipelined packed group: its error word and outputs, read behind the event recorded after its launches."""
+                members_, (res, mode), ev = entry
+                toks_ = [t for _, t in members_]
+                try:
+                    outs = model.forward_ragged_finish(toks_, res, mode, after=ev)
+                    if outs is not res:
+                        ev = None                                 # a rerun: its outputs are behind everything enqueued so far
+                    if outs is None:                              # <pad> inside the batch: the framed rerun of forward_ragged
+                        outs = model.forward_ragged(toks_, packed=False)
+                except IndexError:                                # name the offending alignment: one by one
+                    outs, ev = [alone(i, t) for i, t in members_], None
+                if not all(o["emb"].is_contiguous() and o["atp"].is_contiguous() for o in outs):
+                    ev = None                                     # .contiguous() below would launch copies on the compute stream
+                for (i, _), out in zip(members_, outs):
+                    deliver(i, out["emb"].contiguous(), out["atp"].contiguous(), ev)
+
+            def settle() -> None:
+                """Read back and deliver the packed group still in flight, if any."""
+                if inflight[0] is not None:
+                    entry, inflight[0] = inflight[0], None
+                    finish_packed(entry)
 
             def run_pool() -> None:
                 shapes_ = [tuple(t.shape) for _, t in pool]
@@ -417,41 +441,30 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                 # member's files are byte for byte those of its own forward (exact mode).
                 # (one stream carries every forward: what belongs to group g -- its error word, its outputs -- is read behind an EVENT
                 # recorded right after g's launches, on side streams, or it would wait for g+1's forward as well)
-                waiting = None                                        # (members' (idx, tokens), begun forward, event) of the group in flight
+                # The last group of a pool STAYS in flight when run_pool returns (inflight[0]): the reader goes on, the next pool's first group
+                # is enqueued behind it, and only then is it read back; settle() ends the pipeline (before a forward outside the pool, at the
+                # end of the list).
+                waiting = inflight[0]                                 # (members' (idx, tokens), begun forward, event) of the group in flight
+                inflight[0] = None
 
-                def finish(entry) -> None:
-                    members_, (res, mode), ev = entry
-                    toks_ = [t for _, t in members_]
-                    try:
-                        outs = model.forward_ragged_finish(toks_, res, mode, after=ev)
-                        if outs is not res:
-                            ev = None                                 # a rerun: its outputs are behind everything enqueued so far
-                        if outs is None:                              # <pad> inside the batch: the framed rerun of forward_ragged
-                            outs = model.forward_ragged(toks_, packed=False)
-                    except IndexError:                                # name the offending alignment: one by one
-                        outs, ev = [alone(i, t) for i, t in members_], None
-                    if not all(o["emb"].is_contiguous() and o["atp"].is_contiguous() for o in outs):
-                        ev = None                                     # .contiguous() below would launch copies on the compute stream
-                    for (i, _), out in zip(members_, outs):
-                        deliver(i, out["emb"].contiguous(), out["atp"].contiguous(), ev)
-
-                for members in plan_packed_groups(shapes_, fold_min, split_tokens=PIPELINE_SPLIT_TOKENS):
-                    members_ = [(pool[j][0], torch.from_numpy(pool[j][1]).to(device)) for j in members]
-                    if len(members_) == 1:
+                try:
+                    for members in plan_packed_groups(shapes_, fold_min, split_tokens=PIPELINE_SPLIT_TOKENS):
+                        members_ = [(pool[j][0], torch.from_numpy(pool[j][1]).to(device)) for j in members]
+                        if len(members_) == 1:
+                            if waiting is not None:
+                                finish_packed(waiting)
+                                waiting = None
+                            group.extend(members_)
+                            flush()
+                            continue
+                        begun = model.forward_ragged_begin([t for _, t in members_])
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream())
                         if waiting is not None:
-                            finish(waiting)
-                            waiting = None
-                        group.extend(members_)
-                        flush()
-                        continue
-                    begun = model.forward_ragged_begin([t for _, t in members_])
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream())
-                    if waiting is not None:
-                        finish(waiting)
-                    waiting = (members_, begun, ev)
-                if waiting is not None:
-                    finish(waiting)
+                            finish_packed(waiting)
+                        waiting = (members_, begun, ev)
+                finally:
+                    inflight[0] = waiting                             # also when a group raised: what is in flight is still delivered (salvage)
                 pool.clear()
 
             def alone(i: int, t: torch.Tensor) -> dict:
@@ -491,7 +504,9 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                             and not (tokens == alphabet.padding_idx).any()):
                         if pooled:
                             pool.append((idx, tokens))
-                            if len(pool) >= POOL_MSAS:
+                            # (packing: a full group's worth of tokens starts NOW -- the reader goes on under its forward -- instead of
+                            # waiting for POOL_MSAS alignments or the end of the list)
+                            if len(pool) >= POOL_MSAS or (packing and sum(t.size for _, t in pool) >= PACKED_TOKENS):
                                 run_pool()
                             continue
                         if not (joins_packed if packing else joins_group)([tuple(t.shape) for _, t in group], tuple(tokens.shape)):
@@ -499,6 +514,7 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                         group.append((idx, torch.from_numpy(tokens).to(device)))
                         continue
                     flush()
+                    settle()
                     out = model.checked_forward_one(torch.from_numpy(tokens).to(device), need_repr=False, what=rna_id)   # emb + atp are all that is written
                     deliver(idx, out["emb"], out["atp"])
 
@@ -514,12 +530,14 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                     try:
                         flush()
                         run_pool()
+                        settle()
                     except Exception as second:                       # noqa: BLE001
                         import warnings
                         warnings.warn(f"while writing the results computed before the error: {type(second).__name__}: {second}")
                 raise
             flush()
             run_pool()
+            settle()
             if gatherer is not None:
                 gatherer.finish()
     finally:
