@@ -253,27 +253,31 @@ def joins_packed(group_shapes: List[tuple], shape: tuple) -> bool:
             and sum(c * c for _, c in trial) <= FRAME_MAP_ELEMS)
 
 
-def plan_packed_groups(shapes: List[tuple], fold_min_tokens: int = 0, split_tokens: int = 0) -> List[List[int]]:
+def plan_packed_groups(shapes: List[tuple], fold_min_tokens: int = 0, split_tokens: int = 0, _min_groups: int = 1) -> List[List[int]]:
     """Partition pooled small alignments into token-packed groups, in list order, every position exactly once.  The number of
     groups is the least the three bounds allow; members are then dealt so that the groups hold about the same number of tokens
     (64 + 6 alignments would otherwise run as one full group and one nearly empty launch set).
     fold_min_tokens > 0 (exact mode): alignments of at least that many tokens take the folded LayerNorm, smaller ones do not, and a
     launch set is one or the other -- the two classes are planned separately, so that no group has to be run as two batches
     (MSATransformer.forward_packed would split a mixed one: correct, but two launch sets).
-    split_tokens > 0: a class that would run as ONE group of at least that many tokens is dealt into two, so that the caller can
-    pipeline them (the second group's forward over the first one's deliveries)."""
+    split_tokens > 0: a pool that would run as ONE group IN ALL, of at least that many tokens, is dealt into two, so that the caller
+    has something to pipeline (the second group's forward over the first one's deliveries: +7 % on 64 small alignments; a pool of
+    several groups pipelines already, and splitting its smaller class measured -2 %: profiles/r06_cli_pipeline_ab.log)."""
     if not shapes:
         return []
+    if split_tokens > 0:
+        plan = plan_packed_groups(shapes, fold_min_tokens)
+        if len(plan) == 1 and len(shapes) >= 2 and sum(r * c for r, c in shapes) >= split_tokens:
+            plan = plan_packed_groups(shapes, 0, 0, 2)
+        return plan
     if fold_min_tokens > 0:
         big = [j for j, (r, c) in enumerate(shapes) if r * c >= fold_min_tokens]
         if 0 < len(big) < len(shapes):
             small = [j for j in range(len(shapes)) if r_c_below(shapes[j], fold_min_tokens)]
-            return ([[big[j] for j in g] for g in plan_packed_groups([shapes[j] for j in big], 0, split_tokens)]
-                    + [[small[j] for j in g] for g in plan_packed_groups([shapes[j] for j in small], 0, split_tokens)])
+            return ([[big[j] for j in g] for g in plan_packed_groups([shapes[j] for j in big])]
+                    + [[small[j] for j in g] for g in plan_packed_groups([shapes[j] for j in small])])
     tok = [r * c for r, c in shapes]
-    k = max(-(-len(shapes) // PACKED_MEMBERS), -(-sum(tok) // PACKED_TOKENS), -(-sum(c * c for _, c in shapes) // FRAME_MAP_ELEMS), 1)
-    if k == 1 and split_tokens > 0 and sum(tok) >= split_tokens and len(shapes) >= 2:
-        k = 2
+    k = max(-(-len(shapes) // PACKED_MEMBERS), -(-sum(tok) // PACKED_TOKENS), -(-sum(c * c for _, c in shapes) // FRAME_MAP_ELEMS), _min_groups)
     while True:
         # next-fit with a soft budget of 1/k of the tokens: a group closes once it has reached the budget (the member that crosses
         # it still joins, bounds permitting), or earlier when the next member would break a hard bound

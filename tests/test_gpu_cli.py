@@ -155,16 +155,17 @@ def test_cli_batches_small_alignments_by_default(tmp_path, packing, monkeypatch)
     from rnamsm.config import Config
     from rnamsm.inference import extract_feat
     from rnamsm.model import MSATransformer
+    drop = ()
     if packing == "split":
         import rnamsm.inference as inf
         monkeypatch.setattr(inf, "PIPELINE_SPLIT_TOKENS", 1)
-        packing = True
+        packing, drop = True, ("rnaD",)     # seven small alignments of ONE fold class: one group in all -> dealt into two, pipelined
     state = synthetic.make_state_dict(seed=0)
     model = MSATransformer(num_layers=10)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
     records = open(os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2")).read().splitlines()
     names, seqs = records[0::2], records[1::2]
-    ids = [f"rna{c}" for c in "ABCDEFGH"]
+    ids = [f"rna{c}" for c in "ABCDEFGH" if f"rna{c}" not in drop]
     shapes = {"rnaA": (3, 20), "rnaB": (9, 35), "rnaC": (5, 28), "rnaD": (64, 70), "rnaE": (12, 30), "rnaF": (2, 12),
               "rnaG": (7, 33), "rnaH": (1, 35)}                      # rnaD = 4544 tokens: not small, runs alone in between
     outs = {}
@@ -192,7 +193,8 @@ def test_cli_batches_small_alignments_by_default(tmp_path, packing, monkeypatch)
             assert rel_l2(got, want) < 1e-5, name
         else:
             assert np.abs(got - want).max() < 2e-5, name
-    assert np.array_equal(outs[True]["rnaD_emb.npy"], outs[False]["rnaD_emb.npy"])       # the large one ran alone: same bits
+    if not drop:
+        assert np.array_equal(outs[True]["rnaD_emb.npy"], outs[False]["rnaD_emb.npy"])   # the large one ran alone: same bits
 
 
 def test_cli_in_a_16bit_mode_packs_its_small_alignments_in_that_mode(tmp_path):
