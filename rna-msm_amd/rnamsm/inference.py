@@ -235,7 +235,7 @@ def plan_groups(shapes: List[tuple]) -> List[List[int]]:
 PACKED_TOKENS, PACKED_MEMBERS, PACKED_SMALL_TOKENS = 131072, 256, 16384
 # The CLI's pooled path pipelines its token-packed groups (group g+1 enqueued before group g's error word is read); a pool that would be
 # one group of at least this many tokens is dealt into two so that there is something to overlap (RNAMSM_PIPELINE_SPLIT_TOKENS: A/B, 0 = never)
-PIPELINE_SPLIT_TOKENS = int(os.environ.get("RNAMSM_PIPELINE_SPLIT_TOKENS", "49152"))
+PIPELINE_SPLIT_TOKENS = int(os.environ.get("RNAMSM_PIPELINE_SPLIT_TOKENS", "24576"))
 # In a 16-bit arithmetic mode the packed batch runs in that mode too since round 5 (rnamsm_forward_packed: every Linear on the
 # 16-bit matrix cores, attention on the exact descriptor kernels), so the same limit applies.  (Round 4 had sent those small
 # alignments through the EXACT packed path, with limits of 1024 / 2048 tokens: there was no 16-bit packed batch.)
