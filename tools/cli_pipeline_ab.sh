@@ -1,24 +1,27 @@
-# Round 6: the CLI's pooled path pipelines its token-packed groups; A/B of the split threshold (RNAMSM_PIPELINE_SPLIT_TOKENS: 0 = a pool
-# that fits one group stays one group; 49152; 24576), ROUNDS rounds (default 5), separate processes on one box, interleaved.
+# Round 6: the CLI's pooled path pipelines its token-packed groups.  A/B over repeated separate processes on one box, interleaved:
+# CONFIGS (default below) = ";"-separated "ENV=val ENV=val" settings of RNAMSM_PIPELINE_SPLIT_TOKENS (a one-pool list of at least that many
+# tokens is dealt into two groups; 0 = never) and RNAMSM_FIRST_POOL_TOKENS (the first pool starts at that many tokens; 0 = off).
 O=gpurun_out
-: > $O/r06_cli_pipeline_ab.log
+LOG=$O/${LOGNAME_:-r06_cli_pipeline_ab.log}
+: > $LOG
+IFS=';' read -ra CFG <<< "${CONFIGS:-RNAMSM_PIPELINE_SPLIT_TOKENS=0 RNAMSM_FIRST_POOL_TOKENS=0;RNAMSM_PIPELINE_SPLIT_TOKENS=24576 RNAMSM_FIRST_POOL_TOKENS=0;RNAMSM_PIPELINE_SPLIT_TOKENS=24576 RNAMSM_FIRST_POOL_TOKENS=32768}"
 for rnd in $(seq 1 ${ROUNDS:-5}); do
-  for st in 0 49152 24576; do
-    echo "=== round $rnd RNAMSM_PIPELINE_SPLIT_TOKENS=$st" >> $O/r06_cli_pipeline_ab.log
-    RNAMSM_PIPELINE_SPLIT_TOKENS=$st N=1 M=8 L=40 python3 tools/cli_throughput.py 2>/dev/null | grep -E "alignments \(" >> $O/r06_cli_pipeline_ab.log
+  for c in "${CFG[@]}"; do
+    echo "=== round $rnd $c" >> $LOG
+    env $c N=1 M=8 L=40 python3 tools/cli_throughput.py 2>/dev/null | grep -E "alignments \(" >> $LOG
   done
 done
-python3 - <<'PY'
-import re, statistics, collections
+python3 - "$LOG" <<'PY'
+import re, statistics, collections, sys
 res = collections.defaultdict(lambda: collections.defaultdict(list))
 st = None
-for line in open("gpurun_out/r06_cli_pipeline_ab.log"):
-    m = re.match(r"=== round \d+ RNAMSM_PIPELINE_SPLIT_TOKENS=(\d+)", line)
+for line in open(sys.argv[1]):
+    m = re.match(r"=== round \d+ (.*)", line)
     if m:
-        st = int(m.group(1)); continue
+        st = m.group(1).replace("RNAMSM_", "").strip(); continue
     m = re.match(r"64 (\w+) alignments.*default \(token-packed groups\) [\d.]+ s = ([\d.]+) MSA/s", line)
     if m:
         res[m.group(1)][st].append(float(m.group(2)))
 for kind, d in res.items():
-    print(kind, " | ".join(f"split {s}: median {statistics.median(v):.1f} MSA/s (min {min(v):.1f}, max {max(v):.1f}, n={len(v)})" for s, v in sorted(d.items())))
+    print(kind, " | ".join(f"[{s}] median {statistics.median(v):.1f} MSA/s ({min(v):.1f}..{max(v):.1f}, n={len(v)})" for s, v in d.items()))
 PY
