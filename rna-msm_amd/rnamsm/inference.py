@@ -236,9 +236,6 @@ PACKED_TOKENS, PACKED_MEMBERS, PACKED_SMALL_TOKENS = 131072, 256, 16384
 # The CLI's pooled path pipelines its token-packed groups (group g+1 enqueued before group g's error word is read); a pool that would be
 # one group of at least this many tokens is dealt into two so that there is something to overlap (RNAMSM_PIPELINE_SPLIT_TOKENS: A/B, 0 = never)
 PIPELINE_SPLIT_TOKENS = int(os.environ.get("RNAMSM_PIPELINE_SPLIT_TOKENS", "24576"))
-# ... and the FIRST pool of a list starts as soon as it holds this many tokens (later ones at PACKED_TOKENS): the GPU works while the rest
-# of the list is still being read, and the last group -- whose deliveries nothing can hide -- is smaller (RNAMSM_FIRST_POOL_TOKENS: A/B, 0 = off)
-FIRST_POOL_TOKENS = int(os.environ.get("RNAMSM_FIRST_POOL_TOKENS", "32768"))
 # In a 16-bit arithmetic mode the packed batch runs in that mode too since round 5 (rnamsm_forward_packed: every Linear on the
 # 16-bit matrix cores, attention on the exact descriptor kernels), so the same limit applies.  (Round 4 had sent those small
 # alignments through the EXACT packed path, with limits of 1024 / 2048 tokens: there was no 16-bit packed batch.)
@@ -408,8 +405,6 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
             group: List = []                                          # (idx, tokens on the device)
             pool: List = []                                           # (idx, tokens on the host)
             inflight: List = [None]                                   # the pipelined pool's group whose results are still on the device
-            pools_run = [0]
-            end_of_list = [False]
 
             def finish_packed(entry) -> None:
                 """Second half of a pipelined packed group: its error word and outputs, read behind the event recorded after its launches."""
@@ -456,11 +451,8 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                 waiting = inflight[0]                                 # (members' (idx, tokens), begun forward, event) of the group in flight
                 inflight[0] = None
 
-                # (a pool that starts early or follows another one pipelines with its neighbours: only a list that is ONE pool is split)
-                split = PIPELINE_SPLIT_TOKENS if (pools_run[0] == 0 and waiting is None and end_of_list[0]) else 0
-                pools_run[0] += 1
                 try:
-                    for members in plan_packed_groups(shapes_, fold_min, split_tokens=split):
+                    for members in plan_packed_groups(shapes_, fold_min, split_tokens=PIPELINE_SPLIT_TOKENS):
                         members_ = [(pool[j][0], torch.from_numpy(pool[j][1]).to(device)) for j in members]
                         if len(members_) == 1:
                             if waiting is not None:
@@ -518,8 +510,7 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                             pool.append((idx, tokens))
                             # (packing: a full group's worth of tokens starts NOW -- the reader goes on under its forward -- instead of
                             # waiting for POOL_MSAS alignments or the end of the list)
-                            if len(pool) >= POOL_MSAS or (packing and sum(t.size for _, t in pool) >= (
-                                    FIRST_POOL_TOKENS if (pools_run[0] == 0 and FIRST_POOL_TOKENS > 0) else PACKED_TOKENS)):
+                            if len(pool) >= POOL_MSAS or (packing and sum(t.size for _, t in pool) >= PACKED_TOKENS):
                                 run_pool()
                             continue
                         if not (joins_packed if packing else joins_group)([tuple(t.shape) for _, t in group], tuple(tokens.shape)):
@@ -542,7 +533,6 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                 if gatherer is None:
                     try:
                         flush()
-                        end_of_list[0] = True
                         run_pool()
                         settle()
                     except Exception as second:                       # noqa: BLE001
@@ -550,7 +540,6 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                         warnings.warn(f"while writing the results computed before the error: {type(second).__name__}: {second}")
                 raise
             flush()
-            end_of_list[0] = True
             run_pool()
             settle()
             if gatherer is not None:

@@ -1,10 +1,11 @@
 # Round 6: the CLI's pooled path pipelines its token-packed groups.  A/B over repeated separate processes on one box, interleaved:
 # CONFIGS (default below) = ";"-separated "ENV=val ENV=val" settings of RNAMSM_PIPELINE_SPLIT_TOKENS (a one-pool list of at least that many
-# tokens is dealt into two groups; 0 = never) and RNAMSM_FIRST_POOL_TOKENS (the first pool starts at that many tokens; 0 = off).
+# tokens is dealt into two groups; 0 = never).  (RNAMSM_FIRST_POOL_TOKENS -- the first pool of a list starting early -- existed for one A/B in
+# round 6, commit d34cda6: small +2.7 % within noise, mid -1.8 %, removed; profiles/r06_cli_first_pool_ab.log.)
 O=gpurun_out
 LOG=$O/${LOGNAME_:-r06_cli_pipeline_ab.log}
 : > $LOG
-IFS=';' read -ra CFG <<< "${CONFIGS:-RNAMSM_PIPELINE_SPLIT_TOKENS=0 RNAMSM_FIRST_POOL_TOKENS=0;RNAMSM_PIPELINE_SPLIT_TOKENS=24576 RNAMSM_FIRST_POOL_TOKENS=0;RNAMSM_PIPELINE_SPLIT_TOKENS=24576 RNAMSM_FIRST_POOL_TOKENS=32768}"
+IFS=';' read -ra CFG <<< "${CONFIGS:-RNAMSM_PIPELINE_SPLIT_TOKENS=0;RNAMSM_PIPELINE_SPLIT_TOKENS=49152;RNAMSM_PIPELINE_SPLIT_TOKENS=24576}"
 for rnd in $(seq 1 ${ROUNDS:-5}); do
   for c in "${CFG[@]}"; do
     echo "=== round $rnd $c" >> $LOG
