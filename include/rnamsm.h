@@ -29,8 +29,10 @@
 extern "C" {
 #endif
 
-#define RNAMSM_VERSION 500 /* major*10000 + minor*100 + patch; 5.0 (round 5): rnamsm_forward_packed takes dtype + weight_planes, dtype value 2
-                              * (bf16x3) answers UNSUPPORTED, + rnamsm_softmax_rows_scaled; 4.0: rnamsm_model_dims.row_pos_dim, rnamsm_embed_ln_rows */
+#define RNAMSM_VERSION 600 /* major*10000 + minor*100 + patch; 6.0 (round 6): same 63 entry points and signatures; ten knob names of
+                              * rnamsm_set_param are gone (INVALID), rnamsm_forward_packed refuses a table mixing the two LayerNorm-fold classes,
+                              * rnamsm_pack_outputs requires D % 4 == 0 and 16-byte-aligned x_final / emb.  5.0: rnamsm_forward_packed takes dtype +
+                              * weight_planes, dtype value 2 (bf16x3) answers UNSUPPORTED, + rnamsm_softmax_rows_scaled; 4.0: row_pos_dim, rnamsm_embed_ln_rows */
 
 typedef enum {
     RNAMSM_OK = 0,

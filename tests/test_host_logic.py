@@ -183,7 +183,7 @@ def test_library_exports_every_symbol_declared_in_the_header(lib):
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.rnamsm_version() == 500         # ABI 5.0 (round 5): rnamsm_forward_packed(dtype, weight_planes), bf16x3 removed, + rnamsm_softmax_rows_scaled
+    assert lib.rnamsm_version() == 600         # ABI 6.0 (round 6): same entry points; ten knob names removed, two refusals added (include/rnamsm.h)
 
 
 def test_no_kernel_of_the_shipped_library_spills(lib):
