@@ -187,6 +187,24 @@ def pmc_traffic_per_launch(kernel_prefix="rnamsm::gemm_f32_kernel", tag=""):
     return (tot / n if n else None), os.path.basename(files[-1])
 
 
+def pmc_traffic_by_kernel(kernel_prefix="rnamsm::gemm", tag=""):
+    """The same committed PMC passes, per GEMM kernel instance (detail file only): HBM-side read / write bytes per
+    launch, launches, matrix-pipe busy fraction -- next to `algorithmic_bytes_per_launch` of the family."""
+    import glob
+    import re
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json"))
+                   if re.fullmatch(rf"r\d+_{tag}pmc_summary\.json", os.path.basename(f)))
+    if not files:
+        return None
+    out = {}
+    for name, v in json.load(open(files[-1])).items():
+        if name.startswith(kernel_prefix) and "hbm_read_bytes_corrected" in v:
+            out[name.replace("rnamsm::", "")] = {"hbm_read_bytes": round(v["hbm_read_bytes_corrected"]), "hbm_write_bytes": round(v.get("hbm_write_bytes", 0.0)),
+                                                "launches_in_the_pass": v.get("dispatches_FETCH_SIZE"),
+                                                "mfma_pipe_busy_frac": v.get("mfma_pipe_busy_frac")}
+    return {"source": os.path.basename(files[-1]), "replayed": True, "per_launch": out}
+
+
 def host_cpu_info():
     """(model name, physical cores, logical CPUs) from /proc/cpuinfo."""
     model, cores = "unknown", set()
@@ -964,6 +982,10 @@ def run_rank(args) -> int:
             "per_kernel": per_kernel_bounds(timings, roof_local),
             "kernel_time_share_of_roofline_pass": kern_ms / (1e3 * roof_elapsed),
         }
+        tag = {"f32": "", "bf16": "bf16_", "f16x3": "f16x3_"}[args.gemm_dtype] if (M, L) == (256, 512) else (
+            "cfg4_bf16_" if (M, L) == (1024, 1024) and args.gemm_dtype == "bf16" else None)
+        if tag is not None:
+            result["gemm_traffic_by_kernel"] = pmc_traffic_by_kernel("rnamsm::gemm", tag)
         if args.digest:
             result["output_digest"] = {"value": headline_digest, "items": headline_delivered,
                                        "what": "sum over gathered outputs of (global item index + 1) * sum(int32 bit patterns), mod 2^64"}
