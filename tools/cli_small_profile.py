@@ -46,7 +46,7 @@ for rnd in range(3):
     open(os.path.join(root, "rna_id.txt"), "w").write("\n".join(ids) + "\n")
     cfg = Config()
     cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = root, "results", "rna_id.txt"
-    cfg.data.sample_method, cfg.data.max_seqs_per_msa = "first", 64
+    cfg.data.sample_method, cfg.data.max_seqs_per_msa = "first", int(os.environ.get("MAXSEQS", 64))
     acc.clear()
     prof = cProfile.Profile() if rnd == 2 else None
     torch.cuda.synchronize(); t0 = time.perf_counter()
