@@ -423,11 +423,20 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                 for (i, _), out in zip(members_, outs):
                     deliver(i, out["emb"].contiguous(), out["atp"].contiguous(), ev)
 
+            def finish_one(entry) -> None:
+                """Second half of a pipelined lone forward (the one-by-one loop of alignments too large to wait for company)."""
+                _, idx_, t_dev, has_pad, out, ev = entry
+                done = model.finish_forward_one(t_dev, out, has_pad, need_repr=False, what=ids[idx_], after=ev)
+                deliver(idx_, done["emb"], done["atp"], ev if done is out else None)
+
+            def finish_any(entry) -> None:
+                (finish_one if entry[0] == "one" else finish_packed)(entry)
+
             def settle() -> None:
-                """Read back and deliver the packed group still in flight, if any."""
+                """Read back and deliver what is still in flight, if anything: a packed group or a lone forward."""
                 if inflight[0] is not None:
                     entry, inflight[0] = inflight[0], None
-                    finish_packed(entry)
+                    finish_any(entry)
 
             def run_pool() -> None:
                 shapes_ = [tuple(t.shape) for _, t in pool]
@@ -456,7 +465,7 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                         members_ = [(pool[j][0], torch.from_numpy(pool[j][1]).to(device)) for j in members]
                         if len(members_) == 1:
                             if waiting is not None:
-                                finish_packed(waiting)
+                                finish_any(waiting)
                                 waiting = None
                             group.extend(members_)
                             flush()
@@ -465,7 +474,7 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                         ev = torch.cuda.Event()
                         ev.record(torch.cuda.current_stream())
                         if waiting is not None:
-                            finish_packed(waiting)
+                            finish_any(waiting)
                         waiting = (members_, begun, ev)
                 finally:
                     inflight[0] = waiting                             # also when a group raised: what is in flight is still delivered (salvage)
@@ -518,9 +527,20 @@ def extract_feat(cfg: Config, model: Optional[MSATransformer] = None, gather_to_
                         group.append((idx, torch.from_numpy(tokens).to(device)))
                         continue
                     flush()
+                    has_pad = bool((tokens == alphabet.padding_idx).any())          # on the host: no device round trip before the launches
+                    t_dev = torch.from_numpy(tokens).to(device)
+                    if gatherer is not None:       # (the gather orders its transfers behind the compute stream: one by one there, as before)
+                        settle()
+                        out = model.checked_forward_one(t_dev, has_pad, need_repr=False, what=rna_id)   # emb + atp are all that is written
+                        deliver(idx, out["emb"], out["atp"])
+                        continue
+                    # PIPELINED (round 6): this forward is enqueued BEFORE the previous one's error word and outputs are read -- the ~3 ms
+                    # of host work per alignment (weight-table check, ~140 launches, delivery) no longer idle the GPU between forwards
+                    out = model.forward_one(t_dev, has_pad, need_repr=False)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream())
                     settle()
-                    out = model.checked_forward_one(torch.from_numpy(tokens).to(device), need_repr=False, what=rna_id)   # emb + atp are all that is written
-                    deliver(idx, out["emb"], out["atp"])
+                    inflight[0] = ("one", idx, t_dev, has_pad, out, ev)
 
             try:
                 read_and_run()

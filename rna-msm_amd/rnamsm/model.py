@@ -194,9 +194,10 @@ class MSATransformer(nn.Module):
         self._pack_key = key
         return self._pack
 
-    def _weight_planes(self):
-        """bf16 hi/lo planes of the six GEMM weights per layer (rnamsm_split_bf16), built once per weight version."""
-        dims, ptrs, keep = self._packed_weights()
+    def _weight_planes(self, checked: bool = False):
+        """bf16 hi/lo planes of the six GEMM weights per layer (rnamsm_split_bf16), built once per weight version.
+        checked: the caller has just called _packed_weights() (its walk over 275 parameters costs 0.7 ms of host time per call)."""
+        dims, ptrs, keep = self._pack if checked else self._packed_weights()
         fmt = 1 if self.gemm_dtype == "f16x3" else 0
         if self._planes is not None and self._planes[0] is self._pack_key and self._planes[3] == fmt:
             return self._planes[1]
@@ -212,10 +213,10 @@ class MSATransformer(nn.Module):
         self._planes = (self._pack_key, arr, tensors, fmt)
         return arr
 
-    def _folded_weights(self):
+    def _folded_weights(self, checked: bool = False):
         """LayerNorm folded into the Linear it feeds (rnamsm_ln_fold_weights): per layer {Wg, c, d} for the row QKV, the
-        column QKV and fc1, built once per weight version.  rnamsm_forward's `ln_folded` table."""
-        dims, ptrs, keep = self._packed_weights()
+        column QKV and fc1, built once per weight version.  rnamsm_forward's `ln_folded` table.  checked: see _weight_planes."""
+        dims, ptrs, keep = self._pack if checked else self._packed_weights()
         if self._folded is not None and self._folded[0] is self._pack_key:
             return self._folded[1]
         ng, nl = len(_lib.W_GLOBAL), len(_lib.W_LAYER)
@@ -233,11 +234,11 @@ class MSATransformer(nn.Module):
         self._folded = (self._pack_key, arr, tensors)
         return arr
 
-    def _folded_planes(self):
+    def _folded_planes(self, checked: bool = False):
         """The folded LayerNorm weights of the 16-bit modes: per layer {Wg_hi, Wg_lo, c, d} for the row QKV, the column QKV and
         fc1 -- Wg = W * gamma split into the mode's planes, c = the row sums of what the planes hold (the GEMM multiplies
-        those, so they are what has to cancel), d = bias + W beta.  rnamsm_forward's `ln_folded16` table."""
-        dims, ptrs, keep = self._packed_weights()
+        those, so they are what has to cancel), d = bias + W beta.  rnamsm_forward's `ln_folded16` table.  checked: see _weight_planes."""
+        dims, ptrs, keep = self._pack if checked else self._packed_weights()
         fmt = 1 if self.gemm_dtype == "f16x3" else 0
         want_lo = self.gemm_dtype != "bf16"
         if self._folded16 is not None and self._folded16[0] is self._pack_key and self._folded16[3] == (fmt, want_lo):
@@ -354,8 +355,8 @@ class MSATransformer(nn.Module):
             dtype = _lib.DTYPES[mode]
             if dtype != _lib.F32 and mode != self.gemm_dtype:
                 raise ValueError("forward_batch: a 16-bit gemm_dtype must be the model's own (the weight planes are built per mode)")
-            planes = self._weight_planes() if dtype != _lib.F32 else None
-            folded = self._folded_weights() if (fold and not has_padding and dtype == _lib.F32) else None
+            planes = self._weight_planes(checked=True) if dtype != _lib.F32 else None
+            folded = self._folded_weights(checked=True) if (fold and not has_padding and dtype == _lib.F32) else None
             _lib.check(lib.rnamsm_forward_batch(ctypes.byref(dims), ptrs, toks.data_ptr(), B, R, C, ws.data_ptr(), ws.numel(),
                                                 row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
                                                 err.data_ptr(), int(has_padding),
@@ -447,8 +448,8 @@ class MSATransformer(nn.Module):
             atp = torch.empty(sum(n_atp), device=dev, dtype=torch.float32)
             err = torch.zeros(1, device=dev, dtype=torch.int32)
             dtype = _lib.DTYPES[mode]
-            folded = self._folded_weights() if (fold and dtype == _lib.F32) else None
-            planes = self._weight_planes() if dtype != _lib.F32 else None
+            folded = self._folded_weights(checked=True) if (fold and dtype == _lib.F32) else None
+            planes = self._weight_planes(checked=True) if dtype != _lib.F32 else None
             _lib.check(lib.rnamsm_forward_packed(ctypes.byref(dims), ptrs, toks.data_ptr(), B, shapes, ws.data_ptr(), ws.numel(),
                                                  row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(), err.data_ptr(),
                                                  folded, dtype, planes, torch.cuda.current_stream().cuda_stream))
@@ -559,8 +560,16 @@ class MSATransformer(nn.Module):
         like the reference's embedding lookup would; an MSA whose 16-bit-mode outputs are not finite is recomputed on the exact
         path; one that trips the folded LayerNorm's precondition (rnamsm.h, K1 folded) is computed again with separate
         LayerNorm launches -- the caller never sees the difference."""
-        out = self.forward_one(tokens2d, has_padding, need_repr)
-        err = int(out["err"].item())
+        return self.finish_forward_one(tokens2d, self.forward_one(tokens2d, has_padding, need_repr), has_padding, need_repr, what)
+
+    def finish_forward_one(self, tokens2d: torch.Tensor, out: Dict[str, torch.Tensor], has_padding: Optional[bool] = None,
+                           need_repr: bool = True, what: str = "MSA",
+                           after: Optional[torch.cuda.Event] = None) -> Dict[str, torch.Tensor]:
+        """Second half of checked_forward_one, for callers that pipeline (the CLI's one-by-one loop, round 6): `out` = what
+        forward_one(tokens2d, ...) returned (launches enqueued, nothing read back), `after` = an event recorded right behind those
+        launches -- the error word is then read on a side stream behind THAT event, so the forward enqueued since is not waited
+        for.  Returns `out` itself when nothing had to be redone."""
+        err = self._read_err_behind(out["err"], after)
         if err & self.ERR_INDEX:
             raise IndexError(f"{what}: token or position index out of range")
         import warnings
@@ -612,10 +621,10 @@ class MSATransformer(nn.Module):
             MSATransformer._warned_chunked16 = True
             warnings.warn(f"gemm_dtype={gemm_dtype!r}: a padded MSA above max_tokens_per_msa ({R} x {C} > {max_tokens}) follows the "
                           "reference's chunked mask semantics, which exist in the exact-fp32 kernels only -- it runs in fp32")
-        planes = self._weight_planes() if dtype != _lib.F32 else None
-        folded = self._folded_weights() if (dtype == _lib.F32 and not has_padding and fold) else None
+        planes = self._weight_planes(checked=True) if dtype != _lib.F32 else None
+        folded = self._folded_weights(checked=True) if (dtype == _lib.F32 and not has_padding and fold) else None
         # the 16-bit modes fold only on request (knob ln_fold = 3: measured neutral there): no tables otherwise
-        folded16 = self._folded_planes() if (dtype != _lib.F32 and not has_padding and fold
+        folded16 = self._folded_planes(checked=True) if (dtype != _lib.F32 and not has_padding and fold
                                              and ops.get_param("ln_fold") == 3) else None
         _lib.check(lib.rnamsm_forward(ctypes.byref(dims), ptrs, toks.data_ptr(), R, C, ws.data_ptr(), ws.numel(),
                                       row_attn.data_ptr(), rep.data_ptr(), emb.data_ptr(), atp.data_ptr(),
