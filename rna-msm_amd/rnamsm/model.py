@@ -23,6 +23,19 @@ from .alphabet import RNAAlphabet
 from .modules import AxialTransformerLayer
 
 
+
+# A process-wide counter of parameter registrations (torch's global hook: fires on every Module.register_parameter / attribute
+# assignment of an nn.Parameter).  MSATransformer._packed_weights keeps its list of Parameter objects for as long as the counter stands.
+_PARAM_GENERATION = [0]
+
+
+def _count_parameter_registration(module, name, param):          # noqa: ARG001
+    _PARAM_GENERATION[0] += 1
+    return None
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_count_parameter_registration)
+
 class _LMHeadParams(nn.Module):
     """Parameters of the reference's RobertaLMHead (modules.py:303-319); run by MSATransformer.lm_logits."""
 
@@ -91,6 +104,7 @@ class MSATransformer(nn.Module):
         self.requires_grad_(False)
         self._pack_key = None
         self._pack = None
+        self._plist, self._plist_gen = None, -1          # cached list(self.parameters()) and the generation it was built in
         self._workspace = None
         self._lm_pad = None
         self.compute_logits = True        # model.py:402; forward(need_logits=False) skips the LM head
@@ -140,6 +154,12 @@ class MSATransformer(nn.Module):
             self._pack_key = None
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .float() / .cuda(): parameters may be REPLACED without a registration (torch writes module._parameters directly when
+        # it cannot swap .data in place): the cached parameter list of _packed_weights starts over
+        object.__setattr__(self, "_plist", None)
+        return super()._apply(fn, *args, **kwargs)
+
     def max_tokens_per_msa_(self, value: int) -> None:
         """model.py:418-428.  The reference uses it to bound memory by chunking; the HIP kernels tile internally, so
         without padding results are identical for every value.  With padding the reference's chunked row attention fills
@@ -157,7 +177,14 @@ class MSATransformer(nn.Module):
 
     # ------------------------------------------------------------------ weight packing for rnamsm_forward
     def _packed_weights(self):
-        params = list(self.parameters())
+        # Is the packed table still the model's weights?  (data_ptr, version) of every parameter -- over a CACHED list of the Parameter
+        # objects: walking the module tree for them (self.parameters()) cost 0.6 ms of host time per forward, a fifth of a lone small
+        # alignment's forward.  The list is rebuilt whenever ANY module anywhere registered a parameter since (a global counter bumped
+        # by torch's parameter-registration hook), which is the only way a Parameter OBJECT of this model can have been replaced.
+        if self._plist is None or self._plist_gen != _PARAM_GENERATION[0]:
+            object.__setattr__(self, "_plist", list(self.parameters()))
+            object.__setattr__(self, "_plist_gen", _PARAM_GENERATION[0])
+        params = self._plist
         key = tuple((p.data_ptr(), p._version) for p in params)
         if key == self._pack_key:
             return self._pack
