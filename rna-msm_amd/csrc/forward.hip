@@ -20,6 +20,7 @@
 // holds every activation of the largest supported MSA, so nothing is chunked or recomputed.
 #include <algorithm>
 #include <cstdint>
+#include <functional>
 
 #include "common.h"
 
@@ -123,6 +124,44 @@ struct ExactPath {
                                         scale_cols, nullptr, RNAMSM_F32, stream);
     }
 };
+}  // namespace
+
+namespace {
+// ONE layer skeleton for every driver and arithmetic mode (round 6): AxialTransformerLayer.forward
+// (modules.py:242-267) with its three NormalizedResidualBlocks (modules.py:385-401) unrolled -- row block, column block, feed-forward
+// block, each "LayerNorm (or its fold) + the Linear it feeds", "the block's middle", "the Linear that adds into the residual stream".
+// A driver describes HOW each step runs on its layout (one alignment / a same-shape batch / a token-packed batch; exact fp32 / 16-bit
+// planes) by filling the steps below; WHAT runs in which order is written here once.  `last_layer_tail` (optional) may finish the
+// forward after the last layer's row block (rnamsm_forward's outputs-only tail): it sets `finished`.
+struct LayerSteps {
+    typedef std::function<int(int layer, const float* const* W)> Step;
+    Step row_qkv;            // K1 (or fold) + K2/K3: q | k | v of the tied row attention
+    Step row_attention;      // K4 logits, K5 softmax (writes the layer's maps), K6 apply
+    Step row_out;            // K2 + K8: x += ctx Wo^T + bo
+    std::function<int(int layer, const float* const* W, bool& finished)> last_layer_tail;
+    Step col_qkv;            // K1 (or fold) + K2/K3
+    Step col_attention;      // K7
+    Step col_out;            // K2 + K8
+    Step ffn;                // K1 (or fold) + fc1 + erf-GELU, fc2 + residual
+};
+int run_layers(const LayerSteps& s, const float* const* weights, int num_layers, bool& finished) {
+    finished = false;
+    for (int l = 0; l < num_layers; ++l) {
+        const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
+        FWD(s.row_qkv(l, W));
+        FWD(s.row_attention(l, W));
+        FWD(s.row_out(l, W));
+        if (l == num_layers - 1 && s.last_layer_tail) {
+            FWD(s.last_layer_tail(l, W, finished));
+            if (finished) return RNAMSM_OK;
+        }
+        FWD(s.col_qkv(l, W));
+        FWD(s.col_attention(l, W));
+        FWD(s.col_out(l, W));
+        FWD(s.ffn(l, W));
+    }
+    return RNAMSM_OK;
+}
 }  // namespace
 
 extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const* weights, const int64_t* tokens,
@@ -290,10 +329,9 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
         FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
         FWD(rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream));
     }
-    for (int l = 0; l < NL; ++l) {
-        const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
-        float* probs = row_attn + (int64_t)l * H * C * C;
-        // ---- tied row attention block
+    LayerSteps st;
+    // ---- tied row attention block
+    st.row_qkv = [&](int l, const float* const* W) -> int {
         if (!fold && !fold16) FWD(ln_for_gemm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
         if (attn16) {
             // q stays unscaled in the planes; the scaling multiplies the fp32 logits (see include/rnamsm.h)
@@ -303,37 +341,43 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
                 FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
                               RNAMSM_ACT_NONE, 1.f, 0));
             if (mask) FWD(rnamsm_zero_plane_rows(qkv_hi, qkv_lo, mask, T, D, ldq, stream));      // q *= 1 - padding_mask
+            return RNAMSM_OK;
+        }
+        if (planes)
+            return linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
+                             RNAMSM_ACT_NONE, row_scale, D);
+        if (fold) return lin_normed(l, 0, nullptr, nullptr, 0, qkv, ldq, T, 3 * D, RNAMSM_ACT_NONE, row_scale, D);
+        return linear(l, 0, xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, 3 * D, D, RNAMSM_ACT_NONE, row_scale, D,
+                      mask);
+    };
+    st.row_attention = [&](int l, const float* const*) -> int {
+        float* probs = row_attn + (int64_t)l * H * C * C;
+        if (attn16) {
             FWD(rnamsm_row_logits16(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), ldq, part, R, C, H, 64, row_scale, fmt, stream));
             FWD(rnamsm_softmax_rows_planes(part, rnamsm_row_logits16_nsplit(R, C, H, split), probs, p_hi, p_lo, ldp, 4096.f, H, C,
                                            mask, fmt, stream));
-            FWD(rnamsm_row_apply16(p_hi, p_lo, ldp, qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C, H, 64, 1.f / 4096.f,
-                                   ctx_hi, ctx_lo, fmt, stream));
-        } else {
-            if (planes)
-                FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
-                              RNAMSM_ACT_NONE, row_scale, D));
-            else if (fold)
-                FWD(lin_normed(l, 0, nullptr, nullptr, 0, qkv, ldq, T, 3 * D, RNAMSM_ACT_NONE, row_scale, D));
-            else
-                FWD(linear(l, 0, xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
-                           RNAMSM_ACT_NONE, row_scale, D, mask));
-            if (nchunks) {
-                FWD(rnamsm_row_logits_chunked(qkv, qkv + D, ldq, part, R, C, H, 64, rows_per_chunk, f32, stream));
-                FWD(rnamsm_softmax_rows_chunked(part, nchunks, probs, H, C, mask, rows_per_chunk, stream));
-            } else {
-                FWD(rnamsm_row_logits(qkv, qkv + D, ldq, part, R, C, H, 64, f32, stream));
-                FWD(rnamsm::softmax_rows_batched(part, nsplit, probs, H, C, 1, 0, 0, mask, 0, stream, canon ? depth_scale : 1.f));
-            }
-            FWD(rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, ctx_hi, ctx_lo, fmt, f32, stream));
+            return rnamsm_row_apply16(p_hi, p_lo, ldp, qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C, H, 64, 1.f / 4096.f,
+                                      ctx_hi, ctx_lo, fmt, stream);
         }
-        if (fold16)
-            FWD(res16_fold(l, 1, ctx_hi, ctx_lo, D, W[RNAMSM_WL_ROW_BO], D));
-        else if (planes)
-            FWD(linear_pl(l, 1, ctx_hi, ctx_lo, D, W[RNAMSM_WL_ROW_BO], x, D, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE, 1.f, 0));
-        else
-            FWD(dtype == RNAMSM_F32 ? res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], T, D)
-                                    : linear(l, 1, ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
-        if (l == NL - 1 && !(outputs & RNAMSM_OUT_REPR) && dtype == RNAMSM_F32 && !has_padding && R > 1) {
+        if (nchunks) {
+            FWD(rnamsm_row_logits_chunked(qkv, qkv + D, ldq, part, R, C, H, 64, rows_per_chunk, f32, stream));
+            FWD(rnamsm_softmax_rows_chunked(part, nchunks, probs, H, C, mask, rows_per_chunk, stream));
+        } else {
+            FWD(rnamsm_row_logits(qkv, qkv + D, ldq, part, R, C, H, 64, f32, stream));
+            FWD(rnamsm::softmax_rows_batched(part, nsplit, probs, H, C, 1, 0, 0, mask, 0, stream, canon ? depth_scale : 1.f));
+        }
+        return rnamsm_row_apply(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, ctx_hi, ctx_lo, fmt, f32, stream);
+    };
+    // a block's last Linear, adding into the residual stream: slot 1 (row out_proj) / 3 (column out_proj)
+    auto out_linear = [&](int l, int slot, const float* Wf, const float* bias) -> int {
+        if (fold16) return res16_fold(l, slot, ctx_hi, ctx_lo, D, bias, D);
+        if (planes) return linear_pl(l, slot, ctx_hi, ctx_lo, D, bias, x, D, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE, 1.f, 0);
+        return dtype == RNAMSM_F32 ? res_linear(ctx, D, Wf, bias, T, D)
+                                   : linear(l, slot, ctx, D, Wf, bias, x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr);
+    };
+    st.row_out = [&](int l, const float* const* W) -> int { return out_linear(l, 1, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO]); };
+    if (!(outputs & RNAMSM_OUT_REPR) && dtype == RNAMSM_F32 && !has_padding && R > 1)
+        st.last_layer_tail = [&](int l, const float* const* W, bool& finished) -> int {
             // Only emb (alignment row 0 of the final representation) and the maps are wanted, and the maps are complete:
             // from here on every row but row 0 is dead.  The last column attention still needs K and V of all rows
             // (LayerNorm + the k|v two thirds of the QKV GEMM over all T tokens), but its queries, its out_proj, the FFN
@@ -350,75 +394,66 @@ extern "C" int rnamsm_forward(const rnamsm_model_dims* dims, const float* const*
             FWD(res_linear(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], Tq, F));
             FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, Tq, D, d.ln_eps, stream));
             FWD(rnamsm::pack_outputs_batched(repr, row_attn, emb, atp, C, D, NL, H, 1, 0, 0, err_flag, static_cast<hipStream_t>(stream)));
+            finished = true;
             return RNAMSM_OK;
-        }
-        // ---- column attention block
+        };
+    // ---- column attention block
+    // 16-bit, bf16 operand formats, no padding: q leaves the QKV epilogue PRESCALED by dh^-0.5 log2(e) (multiplied in before the
+    // rounding to 16 bits) and the column kernel exponentiates the scores as they come (rnamsm_col_attn16_prescaled)
+    const bool pre16 = fmt == 0 && !mask && !fold16;
+    // exact path without padding: q leaves the QKV epilogue in log2 units (dh^-1/2 * log2(e)) and the column kernel's first
+    // pass runs without a running maximum (rnamsm_col_attn_fused_prescaled)
+    const bool pre32 = dtype == RNAMSM_F32 && !mask;
+    st.col_qkv = [&](int l, const float* const* W) -> int {
         if (!fold && !fold16) FWD(ln_for_gemm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
         if (attn16) {
-            // bf16 operand formats, no padding: q leaves the QKV epilogue PRESCALED by dh^-0.5 log2(e) (multiplied in before the
-            // rounding to 16 bits) and the column kernel exponentiates the scores as they come (rnamsm_col_attn16_prescaled)
-            const bool pre = fmt == 0 && !mask && !fold16;
-            if (fold16)
-                FWD(lin16_fold(l, 1, qkv_hi, qkv_lo, ldq, 3 * D, RNAMSM_ACT_NONE));
-            else
-                FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
-                              RNAMSM_ACT_NONE, pre ? col_scale * 1.4426950408889634f : 1.f, pre ? D : 0));
-            if (pre)
-                FWD(rnamsm_col_attn16_prescaled(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C,
-                                                H, 64, ctx_hi, ctx_lo, stream));
-            else
-                FWD(rnamsm_col_attn16(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C,
-                                      H, 64, col_scale, mask, ctx_hi, ctx_lo, fmt, stream));
-        } else {
-            // exact path without padding: q leaves the QKV epilogue in log2 units (dh^-1/2 * log2(e)) and the column kernel's first
-            // pass runs without a running maximum (rnamsm_col_attn_fused_prescaled)
-            const bool pre32 = dtype == RNAMSM_F32 && !mask;
-            const float cs = pre32 ? col_scale * LOG2E : col_scale;
-            if (planes)
-                FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
-                              RNAMSM_ACT_NONE, col_scale, D));
-            else if (fold)
-                FWD(lin_normed(l, 1, nullptr, nullptr, 0, qkv, ldq, T, 3 * D, RNAMSM_ACT_NONE, cs, D));
-            else
-                FWD(linear(l, 2, xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, 3 * D, D,
-                           RNAMSM_ACT_NONE, cs, D, nullptr));
-            if (pre32)
-                FWD(rnamsm_col_attn_fused_prescaled(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, R, stream));
-            else
-                FWD(rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, mask, ctx_hi, ctx_lo, fmt, f32, stream));
+            if (fold16) return lin16_fold(l, 1, qkv_hi, qkv_lo, ldq, 3 * D, RNAMSM_ACT_NONE);
+            return linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D,
+                             RNAMSM_ACT_NONE, pre16 ? col_scale * 1.4426950408889634f : 1.f, pre16 ? D : 0);
         }
-        if (fold16)
-            FWD(res16_fold(l, 3, ctx_hi, ctx_lo, D, W[RNAMSM_WL_COL_BO], D));
-        else if (planes)
-            FWD(linear_pl(l, 3, ctx_hi, ctx_lo, D, W[RNAMSM_WL_COL_BO], x, D, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE, 1.f, 0));
-        else
-            FWD(dtype == RNAMSM_F32 ? res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], T, D)
-                                    : linear(l, 3, ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], x, D, x, D, D, D, RNAMSM_ACT_NONE, 1.f, 0, nullptr));
-        // ---- feed-forward block
+        const float cs = pre32 ? col_scale * LOG2E : col_scale;
+        if (planes)
+            return linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, nullptr, nullptr, ldq, 3 * D, D,
+                             RNAMSM_ACT_NONE, col_scale, D);
+        if (fold) return lin_normed(l, 1, nullptr, nullptr, 0, qkv, ldq, T, 3 * D, RNAMSM_ACT_NONE, cs, D);
+        return linear(l, 2, xn, D, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], nullptr, 0, qkv, ldq, 3 * D, D, RNAMSM_ACT_NONE, cs, D, nullptr);
+    };
+    st.col_attention = [&](int, const float* const*) -> int {
+        if (attn16) {
+            if (pre16)
+                return rnamsm_col_attn16_prescaled(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C,
+                                                   H, 64, ctx_hi, ctx_lo, stream);
+            return rnamsm_col_attn16(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, nullptr, D, R, C,
+                                     H, 64, col_scale, mask, ctx_hi, ctx_lo, fmt, stream);
+        }
+        if (pre32) return rnamsm_col_attn_fused_prescaled(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, R, stream);
+        return rnamsm_col_attn_fused(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, 64, mask, ctx_hi, ctx_lo, fmt, f32, stream);
+    };
+    st.col_out = [&](int l, const float* const* W) -> int { return out_linear(l, 3, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO]); };
+    // ---- feed-forward block
+    st.ffn = [&](int l, const float* const* W) -> int {
         if (!fold && !fold16) FWD(ln_for_gemm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
         if (fold16) {
             FWD(lin16_fold(l, 2, hid_hi, hid_lo, F, F, RNAMSM_ACT_GELU_ERF));
-            if (l + 1 < NL)
-                FWD(res16_fold(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], F));
-            else      // the last fc2 feeds the final LayerNorm kernel, which reads the fp32 stream
-                FWD(linear_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, D, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE,
-                              1.f, 0));
-        } else if (planes) {
+            if (l + 1 < NL) return res16_fold(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], F);
+            // the last fc2 feeds the final LayerNorm kernel, which reads the fp32 stream
+            return linear_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, D, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE, 1.f, 0);
+        }
+        if (planes) {
             FWD(linear_pl(l, 4, xn_hi, xn_lo, D, W[RNAMSM_WL_FC1_B], nullptr, 0, nullptr, hid_hi, hid_lo, F, F, D,
                           RNAMSM_ACT_GELU_ERF, 1.f, 0));
-            FWD(linear_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, D, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE,
-                          1.f, 0));
-        } else {
-            if (fold)
-                FWD(lin_normed(l, 2, nullptr, nullptr, 0, hidden, F, T, F, RNAMSM_ACT_GELU_ERF, 1.f, 0));
-            else
-                FWD(linear(l, 4, xn, D, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], nullptr, 0, hidden, F, F, D,
-                           RNAMSM_ACT_GELU_ERF, 1.f, 0, nullptr));
-            FWD(dtype == RNAMSM_F32 ? res_linear(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], T, F)
-                                    : linear(l, 5, hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], x, D, x, D, D, F, RNAMSM_ACT_NONE, 1.f, 0,
-                                             nullptr));
+            return linear_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, D, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE, 1.f, 0);
         }
-    }
+        if (fold)
+            FWD(lin_normed(l, 2, nullptr, nullptr, 0, hidden, F, T, F, RNAMSM_ACT_GELU_ERF, 1.f, 0));
+        else
+            FWD(linear(l, 4, xn, D, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], nullptr, 0, hidden, F, F, D, RNAMSM_ACT_GELU_ERF, 1.f, 0, nullptr));
+        return dtype == RNAMSM_F32 ? res_linear(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], T, F)
+                                   : linear(l, 5, hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], x, D, x, D, D, F, RNAMSM_ACT_NONE, 1.f, 0, nullptr);
+    };
+    bool finished = false;
+    FWD(run_layers(st, weights, NL, finished));
+    if (finished) return RNAMSM_OK;
     FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
     FWD(rnamsm::pack_outputs_batched(repr, row_attn, emb, atp, C, D, NL, H, 1, 0, 0, err_flag, static_cast<hipStream_t>(stream)));
     return RNAMSM_OK;
@@ -562,32 +597,45 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
         FWD(rnamsm::embed_ln_batched(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS],
                                      G[RNAMSM_W_LN_BEFORE_G], G[RNAMSM_W_LN_BEFORE_B], x, B, R, C, D, d.vocab, d.num_positions, d.pad_idx,
                                      d.ln_eps, err_flag, hs, d.row_pos_dim));
-        for (int l = 0; l < NL; ++l) {
-            const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
-            float* probs = row_attn + (int64_t)l * H * C * C;
-            // ---- tied row attention
-            FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
+        auto ln16 = [&](const float* g, const float* b_) -> int { return rnamsm_layernorm_split(x, g, b_, xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream); };
+        LayerSteps st;
+        st.row_qkv = [&](int l, const float* const* W) -> int {
+            FWD(ln16(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
             FWD(linear_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D, RNAMSM_ACT_NONE));
             if (mask) FWD(rnamsm_zero_plane_rows(qkv_hi, qkv_lo, mask, T, D, ldq, stream));             // q *= 1 - padding_mask
+            return RNAMSM_OK;
+        };
+        st.row_attention = [&](int l, const float* const*) -> int {
+            float* probs = row_attn + (int64_t)l * H * C * C;
             FWD(rnamsm::row_logits16_batched(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), ldq, part, R, C, H, row_scale, fmt, B, Tm * ldq, part_bs,
                                              true_rows, stream));
             FWD(rnamsm::softmax_rows_planes_batched(part, nsplit16, probs, p_hi, p_lo, ldp, 4096.f, H, C, mask, fmt, B, part_bs, probs_bs, Tm,
                                                     plane_bs, stream));
-            FWD(rnamsm::row_apply16_batched(p_hi, p_lo, ldp, qkv_hi + 2 * D, lo_at(2 * D), ldq, D, R, C, H, 1.f / 4096.f, ctx_hi, ctx_lo, fmt, B,
-                                            plane_bs, Tm * ldq, Tm * D, stream));
-            FWD(linear_pl(l, 1, ctx_hi, ctx_lo, D, W[RNAMSM_WL_ROW_BO], x, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE));
-            // ---- column attention
-            FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
-            FWD(linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D, RNAMSM_ACT_NONE,
-                          pre ? col_scale * 1.4426950408889634f : 1.f, pre ? D : 0));
-            FWD(rnamsm::col_attn16_batched(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, D, R, C, H, col_scale,
-                                           R > 1 ? mask : nullptr, ctx_hi, ctx_lo, fmt, B, Tm * ldq, Tm * D, Tm, stream, pre));
-            FWD(linear_pl(l, 3, ctx_hi, ctx_lo, D, W[RNAMSM_WL_COL_BO], x, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE));
-            // ---- feed-forward
-            FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
+            return rnamsm::row_apply16_batched(p_hi, p_lo, ldp, qkv_hi + 2 * D, lo_at(2 * D), ldq, D, R, C, H, 1.f / 4096.f, ctx_hi, ctx_lo, fmt, B,
+                                               plane_bs, Tm * ldq, Tm * D, stream);
+        };
+        st.row_out = [&](int l, const float* const* W) -> int {
+            return linear_pl(l, 1, ctx_hi, ctx_lo, D, W[RNAMSM_WL_ROW_BO], x, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE);
+        };
+        st.col_qkv = [&](int l, const float* const* W) -> int {
+            FWD(ln16(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
+            return linear_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, nullptr, qkv_hi, qkv_lo, ldq, 3 * D, D, RNAMSM_ACT_NONE,
+                             pre ? col_scale * 1.4426950408889634f : 1.f, pre ? D : 0);
+        };
+        st.col_attention = [&](int, const float* const*) -> int {
+            return rnamsm::col_attn16_batched(qkv_hi, qkv_lo, qkv_hi + D, lo_at(D), qkv_hi + 2 * D, lo_at(2 * D), ldq, D, R, C, H, col_scale,
+                                              R > 1 ? mask : nullptr, ctx_hi, ctx_lo, fmt, B, Tm * ldq, Tm * D, Tm, stream, pre);
+        };
+        st.col_out = [&](int l, const float* const* W) -> int {
+            return linear_pl(l, 3, ctx_hi, ctx_lo, D, W[RNAMSM_WL_COL_BO], x, x, nullptr, nullptr, D, D, D, RNAMSM_ACT_NONE);
+        };
+        st.ffn = [&](int l, const float* const* W) -> int {
+            FWD(ln16(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
             FWD(linear_pl(l, 4, xn_hi, xn_lo, D, W[RNAMSM_WL_FC1_B], nullptr, nullptr, hid_hi, hid_lo, F, F, D, RNAMSM_ACT_GELU_ERF));
-            FWD(linear_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE));
-        }
+            return linear_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE);
+        };
+        bool finished = false;
+        FWD(run_layers(st, weights, NL, finished));
         FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
         FWD(rnamsm::pack_outputs_batched(repr, row_attn, emb, atp, C, D, NL, H, B, Tm * D, (int64_t)NL * H * C * C, err_flag, hs));
         return RNAMSM_OK;
@@ -611,37 +659,45 @@ extern "C" int rnamsm_forward_batch(const rnamsm_model_dims* dims, const float* 
         FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
         FWD(rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream));
     }
-    for (int l = 0; l < NL; ++l) {
-        const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
-        // ---- tied row attention: projections over the batch, K4-K6 per MSA
+    LayerSteps st;
+    // ---- tied row attention: projections over the batch, K4-K6 per MSA
+    st.row_qkv = [&](int l, const float* const* W) -> int {
         FWD(norm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
         if (true_rows)         // q = ((x Wq^T + bq) dh^-1/2) * (0 at <pad>, 1/sqrt(true depth) elsewhere), per token, in the epilogue
-            FWD(rnamsm_gemm_row_scaled(xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, T, 3 * D, D, row_scale, D, qscale,
-                                       f32, stream));
-        else if (mask)     // q *= 1 - padding_mask (modules.py:767-772) in the epilogue
-            FWD(rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, T, 3 * D, D,
-                                         RNAMSM_ACT_NONE, row_scale, D, mask, f32, stream));
-        else
-            FWD(lin_normed(l, 0, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, row_scale, D));
-        {   // K4-K6 of all B MSAs in one launch each (gridDim.y = B); the maps land in row_attn [B, NL, H, C, C]
-            const int64_t part_bs = (int64_t)nsplit * H * C * C, probs_bs = (int64_t)NL * H * C * C;
-            float* probs = row_attn + (int64_t)l * H * C * C;
-            FWD(rnamsm::row_logits_batched(qkv, qkv + D, ldq, part, R, C, H, B, Tm * ldq, part_bs, stream));
-            FWD(rnamsm::softmax_rows_batched(part, nsplit, probs, H, C, B, part_bs, probs_bs, mask, Tm, stream,
-                                             canon ? 1.0f / sqrtf((float)R) : 1.f));
-            FWD(rnamsm::row_apply_batched(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, B, probs_bs, Tm * ldq, Tm * D, stream));
-        }
-        FWD(res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], D));
-        // ---- column attention
+            return rnamsm_gemm_row_scaled(xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, T, 3 * D, D, row_scale, D, qscale,
+                                          f32, stream);
+        if (mask)              // q *= 1 - padding_mask (modules.py:767-772) in the epilogue
+            return rnamsm_gemm_bias_act_res(xn, D, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], nullptr, 0, qkv, ldq, T, 3 * D, D,
+                                            RNAMSM_ACT_NONE, row_scale, D, mask, f32, stream);
+        return lin_normed(l, 0, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, row_scale, D);
+    };
+    st.row_attention = [&](int l, const float* const*) -> int {
+        // K4-K6 of all B MSAs in one launch each (gridDim.y = B); the maps land in row_attn [B, NL, H, C, C]
+        const int64_t part_bs = (int64_t)nsplit * H * C * C, probs_bs = (int64_t)NL * H * C * C;
+        float* probs = row_attn + (int64_t)l * H * C * C;
+        FWD(rnamsm::row_logits_batched(qkv, qkv + D, ldq, part, R, C, H, B, Tm * ldq, part_bs, stream));
+        FWD(rnamsm::softmax_rows_batched(part, nsplit, probs, H, C, B, part_bs, probs_bs, mask, Tm, stream,
+                                         canon ? 1.0f / sqrtf((float)R) : 1.f));
+        return rnamsm::row_apply_batched(probs, qkv + 2 * D, ldq, ctx, D, R, C, H, B, probs_bs, Tm * ldq, Tm * D, stream);
+    };
+    st.row_out = [&](int, const float* const* W) -> int { return res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], D); };
+    // ---- column attention
+    st.col_qkv = [&](int l, const float* const* W) -> int {
         FWD(norm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
-        FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, mask ? col_scale : col_scale * LOG2E, D));
-        FWD(rnamsm::col_attn_batched(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, B, Tm * ldq, Tm * D, mask, stream, !mask));
-        FWD(res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], D));
-        // ---- feed-forward
+        return lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, mask ? col_scale : col_scale * LOG2E, D);
+    };
+    st.col_attention = [&](int, const float* const*) -> int {
+        return rnamsm::col_attn_batched(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, R, C, H, B, Tm * ldq, Tm * D, mask, stream, !mask);
+    };
+    st.col_out = [&](int, const float* const* W) -> int { return res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], D); };
+    // ---- feed-forward
+    st.ffn = [&](int l, const float* const* W) -> int {
         FWD(norm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
         FWD(lin_normed(l, 2, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], hidden, F, F, RNAMSM_ACT_GELU_ERF, 1.f, 0));
-        FWD(res_linear(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], F));
-    }
+        return res_linear(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], F);
+    };
+    bool finished = false;
+    FWD(run_layers(st, weights, NL, finished));
     FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
     // K10 of the whole batch in one launch (gridDim.y = alignment)
     FWD(rnamsm::pack_outputs_batched(repr, row_attn, emb, atp, C, D, NL, H, B, Tm * D, (int64_t)NL * H * C * C, err_flag, hs));
@@ -775,6 +831,16 @@ extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float*
         return ex.res_linear(A, lda, Wf, bias, T, K);
     };
 
+    // the attention steps of BOTH arithmetic modes of this driver: the exact descriptor kernels K4-K6 / K7 (member from gridDim.y)
+    auto row_attention_packed = [&](int l, const float* const*) -> int {
+        FWD(rnamsm::row_logits_packed(qkv, qkv + D, ldq, part, H, desc, hp, B, stream));
+        FWD(rnamsm::softmax_rows_packed(part, row_attn, l, H, desc, hp, B, stream));
+        return rnamsm::row_apply_packed(row_attn, l, qkv + 2 * D, ldq, ctx, D, H, desc, hp, B, stream);
+    };
+    auto col_attention_packed = [&](int, const float* const*) -> int {
+        return rnamsm::col_attn_packed(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, H, desc, hp, B, stream, true);
+    };
+
     FWD(rnamsm::packed_descriptors_upload(hp, B, desc, hs));
     FWD(rnamsm::embed_ln_packed(tokens, G[RNAMSM_W_EMBED_TOKENS], G[RNAMSM_W_EMBED_POSITIONS], G[RNAMSM_W_ROW_POS], G[RNAMSM_W_LN_BEFORE_G],
                                 G[RNAMSM_W_LN_BEFORE_B], x, desc, B, T, D, d.vocab, d.num_positions, d.pad_idx, d.ln_eps, err_flag, hs,
@@ -806,23 +872,28 @@ extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float*
             return rnamsm_gemm_bf16(ctx, D, P[0], P[1], bias, x, D, x, D, T, D, D, RNAMSM_ACT_NONE, 1.f, 0, split, fmt, nullptr, nullptr,
                                     nullptr, nullptr, stream);
         };
-        for (int l = 0; l < NL; ++l) {
-            const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
-            FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
-            FWD(lin_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, qkv, nullptr, nullptr, ldq, 3 * D, D, RNAMSM_ACT_NONE, qk_scale, D));
-            FWD(rnamsm::row_logits_packed(qkv, qkv + D, ldq, part, H, desc, hp, B, stream));
-            FWD(rnamsm::softmax_rows_packed(part, row_attn, l, H, desc, hp, B, stream));
-            FWD(rnamsm::row_apply_packed(row_attn, l, qkv + 2 * D, ldq, ctx, D, H, desc, hp, B, stream));
-            FWD(out_proj(l, 1, W[RNAMSM_WL_ROW_BO]));
-            FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
-            FWD(lin_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, qkv, nullptr, nullptr, ldq, 3 * D, D, RNAMSM_ACT_NONE,
-                       qk_scale * LOG2E, D));
-            FWD(rnamsm::col_attn_packed(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, H, desc, hp, B, stream, true));
-            FWD(out_proj(l, 3, W[RNAMSM_WL_COL_BO]));
-            FWD(rnamsm_layernorm_split(x, W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B], xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream));
+        auto ln16 = [&](const float* g, const float* b_) -> int { return rnamsm_layernorm_split(x, g, b_, xn_hi, xn_lo, T, D, d.ln_eps, fmt, stream); };
+        LayerSteps st;
+        st.row_qkv = [&](int l, const float* const* W) -> int {
+            FWD(ln16(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
+            return lin_pl(l, 0, xn_hi, xn_lo, D, W[RNAMSM_WL_ROW_BQKV], nullptr, qkv, nullptr, nullptr, ldq, 3 * D, D, RNAMSM_ACT_NONE, qk_scale, D);
+        };
+        st.row_attention = row_attention_packed;
+        st.row_out = [&](int l, const float* const* W) -> int { return out_proj(l, 1, W[RNAMSM_WL_ROW_BO]); };
+        st.col_qkv = [&](int l, const float* const* W) -> int {
+            FWD(ln16(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
+            return lin_pl(l, 2, xn_hi, xn_lo, D, W[RNAMSM_WL_COL_BQKV], nullptr, qkv, nullptr, nullptr, ldq, 3 * D, D, RNAMSM_ACT_NONE,
+                          qk_scale * LOG2E, D);
+        };
+        st.col_attention = col_attention_packed;
+        st.col_out = [&](int l, const float* const* W) -> int { return out_proj(l, 3, W[RNAMSM_WL_COL_BO]); };
+        st.ffn = [&](int l, const float* const* W) -> int {
+            FWD(ln16(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
             FWD(lin_pl(l, 4, xn_hi, xn_lo, D, W[RNAMSM_WL_FC1_B], nullptr, nullptr, hid_hi, hid_lo, F, F, D, RNAMSM_ACT_GELU_ERF, 1.f, 0));
-            FWD(lin_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE, 1.f, 0));
-        }
+            return lin_pl(l, 5, hid_hi, hid_lo, F, W[RNAMSM_WL_FC2_B], x, x, nullptr, nullptr, D, D, F, RNAMSM_ACT_NONE, 1.f, 0);
+        };
+        bool finished = false;
+        FWD(run_layers(st, weights, NL, finished));
         FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
         int max_C16 = 0;
         double out_floats16 = 0.0;
@@ -837,25 +908,29 @@ extern "C" int rnamsm_forward_packed(const rnamsm_model_dims* dims, const float*
         FWD(rnamsm_row_partials(x, rowsum, T, D, stream));
         FWD(rnamsm_row_stats_from_partials(rowsum, T, T, D, d.ln_eps, stats, err_flag, stream));
     }
-    for (int l = 0; l < NL; ++l) {
-        const float* const* W = weights + RNAMSM_W_GLOBAL_COUNT + (size_t)l * RNAMSM_W_LAYER_COUNT;
-        // ---- tied row attention (q carries dh^-1/2; each alignment's 1/sqrt(R) is applied to its summed logits in K5)
+    LayerSteps st;
+    // ---- tied row attention (q carries dh^-1/2; each alignment's 1/sqrt(R) is applied to its summed logits in K5)
+    st.row_qkv = [&](int l, const float* const* W) -> int {
         FWD(norm(W[RNAMSM_WL_ROW_LN_G], W[RNAMSM_WL_ROW_LN_B]));
-        FWD(lin_normed(l, 0, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, qk_scale, D));
-        FWD(rnamsm::row_logits_packed(qkv, qkv + D, ldq, part, H, desc, hp, B, stream));
-        FWD(rnamsm::softmax_rows_packed(part, row_attn, l, H, desc, hp, B, stream));
-        FWD(rnamsm::row_apply_packed(row_attn, l, qkv + 2 * D, ldq, ctx, D, H, desc, hp, B, stream));
-        FWD(res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], D));
-        // ---- column attention
+        return lin_normed(l, 0, W[RNAMSM_WL_ROW_WQKV], W[RNAMSM_WL_ROW_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, qk_scale, D);
+    };
+    st.row_attention = row_attention_packed;
+    st.row_out = [&](int, const float* const* W) -> int { return res_linear(ctx, D, W[RNAMSM_WL_ROW_WO], W[RNAMSM_WL_ROW_BO], D); };
+    // ---- column attention
+    st.col_qkv = [&](int l, const float* const* W) -> int {
         FWD(norm(W[RNAMSM_WL_COL_LN_G], W[RNAMSM_WL_COL_LN_B]));
-        FWD(lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, qk_scale * LOG2E, D));
-        FWD(rnamsm::col_attn_packed(qkv, qkv + D, qkv + 2 * D, ldq, ctx, D, H, desc, hp, B, stream, true));
-        FWD(res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], D));
-        // ---- feed-forward
+        return lin_normed(l, 1, W[RNAMSM_WL_COL_WQKV], W[RNAMSM_WL_COL_BQKV], qkv, ldq, 3 * D, RNAMSM_ACT_NONE, qk_scale * LOG2E, D);
+    };
+    st.col_attention = col_attention_packed;
+    st.col_out = [&](int, const float* const* W) -> int { return res_linear(ctx, D, W[RNAMSM_WL_COL_WO], W[RNAMSM_WL_COL_BO], D); };
+    // ---- feed-forward
+    st.ffn = [&](int l, const float* const* W) -> int {
         FWD(norm(W[RNAMSM_WL_FFN_LN_G], W[RNAMSM_WL_FFN_LN_B]));
         FWD(lin_normed(l, 2, W[RNAMSM_WL_FC1_W], W[RNAMSM_WL_FC1_B], hidden, F, F, RNAMSM_ACT_GELU_ERF, 1.f, 0));
-        FWD(res_linear(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], F));
-    }
+        return res_linear(hidden, F, W[RNAMSM_WL_FC2_W], W[RNAMSM_WL_FC2_B], F);
+    };
+    bool finished = false;
+    FWD(run_layers(st, weights, NL, finished));
     FWD(rnamsm_layernorm(x, G[RNAMSM_W_LN_AFTER_G], G[RNAMSM_W_LN_AFTER_B], repr, T, D, d.ln_eps, stream));
     int max_C = 0;
     double out_floats = 0.0;
