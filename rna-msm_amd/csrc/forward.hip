@@ -1,7 +1,8 @@
 // Whole-forward driver: one C call enqueues K0..K10 for one MSA on the caller's stream
 // (MSATransformer.forward, model.py:338-416, with AxialTransformerLayer.forward, modules.py:242-267, and
 // NormalizedResidualBlock.forward, modules.py:385-401, unrolled into 13 launches per layer, 10 with
-// LayerNorm folded into the GEMMs).
+// LayerNorm folded into the GEMMs).  The order of a layer's steps is written once (LayerSteps / run_layers below); the three
+// drivers -- one alignment, a same-shape batch, a token-packed batch -- fill the steps for their layout and arithmetic.
 //
 // HBM layout of the workspace (T = R*C tokens, D = embed dim, F = 4D):
 //   x      [T, D]    residual stream, updated in place by the out_proj / fc2 epilogues (K8)
