@@ -286,3 +286,45 @@ def test_cli_in_a_16bit_mode_a_lone_small_alignment_gets_the_arithmetic_of_a_gro
         assert np.array_equal(lone[name], grouped[name]), name                    # the same bits with or without company
     assert 1e-4 < rel_l2(lone["rnaA_emb.npy"], exact["rnaA_emb.npy"]) < 5e-2      # bf16's rounding: the mode that was asked for
     assert np.array_equal(lone["rnaB_emb.npy"], grouped["rnaB_emb.npy"])          # the large one: alone in bf16 either way
+
+
+@pytest.mark.parametrize("batching", [True, False])
+def test_a_bad_alignment_late_in_the_list_does_not_cost_the_results_before_it(tmp_path, batching):
+    """The CLI loop is pipelined (round 6): a forward is enqueued before the previous one's results are read back, small alignments
+    wait in a pool.  An alignment that cannot be read (an invalid character: the reference raises ValueError("Invalid tokens in
+    input"), utils/tokenization.py:107-129) must still surface as that error -- and everything computed or read BEFORE it must be on
+    disk, byte for byte what a clean run over those ids writes (the one-by-one loop of the reference would have written them before
+    reaching the bad file).  batching = the pooled / packed default and the strictly one-by-one loop."""
+    from rnamsm.config import Config
+    from rnamsm.inference import extract_feat
+    from rnamsm.model import MSATransformer
+    state = synthetic.make_state_dict(seed=0)
+    model = MSATransformer(num_layers=10)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    records = open(os.path.join(GOLDEN, "2DRB_1_first64.a2m_msa2")).read().splitlines()
+    names, seqs = records[0::2], records[1::2]
+    shapes = {"rnaA": (5, 30), "rnaB": (9, 35), "rnaC": (3, 22), "rnaD": (4, 25), "rnaE": (6, 28)}
+    outs = {}
+    for kind, ids in (("clean", ["rnaA", "rnaB", "rnaC"]), ("broken", ["rnaA", "rnaB", "rnaC", "rnaD", "rnaE"])):
+        root = tmp_path / kind
+        (root / "results").mkdir(parents=True)
+        for i in ids:
+            depth, length = shapes[i]
+            text = "".join(f"{names[r]}\\n{(seqs[r] * 2)[:length]}\\n" for r in range(depth))
+            if i == "rnaD":
+                text = text.replace("A", "!", 1)                    # not a residue, not an insertion marker
+            (root / "results" / f"{i}.a2m_msa2").write_text(text)
+        (root / "rna_id.txt").write_text("\\n".join(ids) + "\\n")
+        cfg = Config()
+        cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = str(root), "results", "rna_id.txt"
+        cfg.data.sample_method, cfg.data.max_seqs_per_msa, cfg.data.batch_small_msas = "first", 64, batching
+        if kind == "clean":
+            assert extract_feat(cfg, model=model) == ids
+        else:
+            with pytest.raises(ValueError, match="Invalid tokens"):
+                extract_feat(cfg, model=model)
+        outs[kind] = {f.name: f.read_bytes() for f in sorted((root / "results").glob("*.npy"))}
+    assert len(outs["clean"]) == 6
+    for name, want in outs["clean"].items():
+        assert outs["broken"].get(name) == want, name                # everything before the bad file: written, same bytes
+    assert not any(n.startswith(("rnaD", "rnaE")) for n in outs["broken"])
