@@ -310,11 +310,11 @@ def test_a_bad_alignment_late_in_the_list_does_not_cost_the_results_before_it(tm
         (root / "results").mkdir(parents=True)
         for i in ids:
             depth, length = shapes[i]
-            text = "".join(f"{names[r]}\\n{(seqs[r] * 2)[:length]}\\n" for r in range(depth))
+            text = "".join(f"{names[r]}\n{(seqs[r] * 2)[:length]}\n" for r in range(depth))
             if i == "rnaD":
                 text = text.replace("A", "!", 1)                    # not a residue, not an insertion marker
             (root / "results" / f"{i}.a2m_msa2").write_text(text)
-        (root / "rna_id.txt").write_text("\\n".join(ids) + "\\n")
+        (root / "rna_id.txt").write_text("\n".join(ids) + "\n")
         cfg = Config()
         cfg.data.root_path, cfg.data.MSA_path, cfg.data.MSA_list = str(root), "results", "rna_id.txt"
         cfg.data.sample_method, cfg.data.max_seqs_per_msa, cfg.data.batch_small_msas = "first", 64, batching
